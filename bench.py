@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the VectorX prover hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W            (N>1: launched by torch.distributed.run)
+
+A "step" is one pass of the hot path over one synthetic header_range_512-shaped witness
+(BASELINE.json configs[2]: n = 2^21 rows x 135 wire columns, blow-up 8, cap height 4) that is already
+resident in HBM when the timed region starts.  With N GPUs every rank proves its own witness
+(proof-level sharding — the reference's MapReduce fan-out, /root/reference/circuits/builder/
+subchain_verification.rs:72-78 — no data-path collective), so scaling is "weak" and `value` is the
+whole-job rate.  One JSON line is printed by rank 0; it carries `roofline` (HIP-event-timed dominant
+HBM-bound kernel family, the coset-LDE NTT) and `cpu_baseline` (the oracle = CPU restatement of
+plonky2 v0.2.0, timed on this box's host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+
+HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--log-n", type=int, default=21, help="log2 trace rows (21 = header_range_512 stand-in)")
+    ap.add_argument("--ncols", type=int, default=135)
+    ap.add_argument("--workload", default="auto", choices=["auto", "commit", "prove"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-log-n", type=int, default=17)
+    return ap.parse_args()
+
+
+def synth_witness_matrix(seed, ncols, n):
+    """uniform field elements from a fixed-seed PRNG; column-major [ncols][n]"""
+    rng = np.random.default_rng(seed)
+    return rng.integers(0, 0xFFFFFFFF00000001, size=(ncols, n), dtype=np.uint64)
+
+
+def cpu_baseline_commit(args):
+    """oracle (kind = "port"): PolynomialBatch::from_values on a bounded sample, all host cores."""
+    import oracle_lib
+    oracle = oracle_lib.load()
+    cores = oracle.L.vxo_num_threads()
+    s_log = min(args.cpu_sample_log_n, args.log_n)
+    vals = synth_witness_matrix(1234, args.ncols, 1 << s_log)
+    t0 = time.perf_counter()
+    oracle.commit(vals, 3, 4, want_leaves=False)
+    dt = time.perf_counter() - t0
+    scale = float(1 << (args.log_n - s_log))  # rows scale linearly (the log factor favours the CPU slightly)
+    return {
+        "value": 1.0 / (dt * scale),
+        "unit": "trace commits/sec",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"oracle PolynomialBatch::from_values on [{args.ncols}][2^{s_log}] took {dt:.2f} s with {cores} "
+                  f"OpenMP threads; scaled x{int(scale)} to 2^{args.log_n} rows",
+    }
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    import vectorx_amd as vx
+
+    ctx = vx.Context(local_rank)  # no CPU fallback: raises if the HIP library / GPU is missing
+    n = 1 << args.log_n
+    workload = args.workload
+    if workload == "auto":
+        workload = "prove" if hasattr(vx, "Circuit") else "commit"
+
+    def barrier():
+        ctx.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        ctx.sync()
+
+    if workload == "commit":
+        host = synth_witness_matrix(0x5EED0000 + rank, args.ncols, n)
+        d_in = ctx.alloc(host.nbytes)
+        ctx.upload(d_in, host)
+        del host
+
+        def step():
+            b = vx.PolynomialBatch.from_values_dev(ctx, d_in, args.log_n, args.ncols, 3, 4)
+            cap = b.cap()
+            b.free()
+            return cap
+        metric = "header_range_512 trace commits/sec (PolynomialBatch::from_values of the 135-column wire trace; stage 1 of prove())"
+        unit = "trace commits/sec"
+        wl_name = f"header_range_512 stand-in: wires commit, n=2^{args.log_n} rows x {args.ncols} cols, blowup 8, cap_height 4"
+    else:
+        import bench_prove
+        step, metric, unit, wl_name = bench_prove.make_step(ctx, args, rank)
+
+    for _ in range(args.warmup):
+        step()
+    ctx.prof_enable(True)
+    ctx.prof_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = ctx.prof()
+    ctx.prof_enable(False)
+
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        lde = prof.get("lde", {"ms": 0.0, "calls": 0, "alg_bytes": 0.0})
+        roof = None
+        if lde["calls"]:
+            per_launch_ms = lde["ms"] / lde["calls"]
+            per_launch_bytes = lde["alg_bytes"] / lde["calls"]
+            achieved = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9
+            roof = {
+                "kernel": "ntt_pass_kernel (coset-LDE family: 8 coset NTTs per column, 2 passes each)",
+                "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                "alg_bytes_per_launch": per_launch_bytes, "ms_per_launch": round(per_launch_ms, 4),
+                "launches": lde["calls"],
+            }
+        out = {
+            "metric": metric, "value": world * args.steps / dt, "unit": unit,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u64 (Goldilocks field, integer modular arithmetic)", "data": "synthetic",
+            "config": {"workload": wl_name, "parallelism": f"proof-level x{world} (one witness per GPU, no collective)"},
+            "roofline": roof,
+            "stage_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in prof.items()},
+            "stage_alg_GBps": {k: round(v["alg_bytes"] / (v["ms"] * 1e-3) / 1e9, 1) for k, v in prof.items()
+                               if v["alg_bytes"] and v["ms"]},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline_commit(args) if workload == "commit" else bench_prove.cpu_baseline(args)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,118 @@
+/* vxprover.h — C ABI of libvxprover.so, the MI355X (gfx950) prover backend for VectorX's plonky2x
+ * circuits (header_range_256 / header_range_512 / rotate).
+ *
+ * This is the drop-in boundary of SURVEY.md §8(b).  The reference reaches the hot path through
+ *   /root/reference/circuits/header_range.rs:167-170   circuit.prove(&input) / circuit.verify(..)
+ *   /root/reference/circuits/rotate.rs:193             (same, rotate)
+ *   /root/reference/bin/header_range_512.rs:16         HeaderRangeCircuit::<..>::entrypoint()
+ * which land in the un-vendored plonky2 v0.2.0 crate (/root/reference/Cargo.lock:4848-4905):
+ *   plonky2::fri::oracle::PolynomialBatch::{from_values, from_coeffs}      -> vx_batch_commit
+ *   plonky2::hash::merkle_tree::MerkleTree::{new, prove}                   -> vx_merkle_*, vx_batch_open_row
+ *   plonky2_field::fft::{fft, ifft}, polynomial::{coset_fft, coset_ifft}   -> vx_ntt_batch
+ *   plonky2::hash::poseidon::Poseidon::poseidon                            -> vx_poseidon_permute
+ *   plonky2::plonk::prover::prove_with_partition_witness                   -> vx_prove
+ *   plonky2::plonk::circuit_data::CircuitData::verify                      -> (host side)
+ * INTEGRATION.md shows the Rust `extern "C"` block a maintainer adds on the reference side.
+ *
+ * Conventions (all entry points):
+ *   - field element  = little-endian uint64_t; inputs may be non-canonical (< 2^64), outputs are
+ *     canonical (< p = 2^64 - 2^32 + 1);  F_p^2 element = two consecutive u64 [c0, c1].
+ *   - matrices are COLUMN-MAJOR [ncols][n]  (plonky2 `wire_values[wire][row]`).
+ *   - a hash / Merkle digest = 4 u64.
+ *   - return 0 on success, negative VX_E_* on failure; vx_last_error() gives a thread-local message.
+ *     Nothing unwinds or aborts across this boundary.  There is NO CPU fallback: every compute entry
+ *     point fails with VX_E_NO_DEVICE when no gfx950 device is usable.
+ *   - the caller owns every host buffer; the library owns the opaque handles (freed by vx_*_free /
+ *     vx_ctx_destroy).  A vx_ctx is bound to one device and one HIP stream; use one ctx per host
+ *     thread.  Contexts are independent, so 8 threads can drive 8 GPUs.
+ */
+#ifndef VXPROVER_H
+#define VXPROVER_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VX_OK 0
+#define VX_E_INVALID (-1)    /* bad argument */
+#define VX_E_NO_DEVICE (-2)  /* no usable HIP device (the library never falls back to the CPU) */
+#define VX_E_HIP (-3)        /* a HIP runtime call failed */
+#define VX_E_NOMEM (-4)
+#define VX_E_PROOF (-5)      /* prover-level failure (e.g. zeta in the subgroup, unsatisfied witness check) */
+
+typedef struct vx_ctx vx_ctx;
+typedef struct vx_batch vx_batch;     /* device-resident PolynomialBatch: coeffs + LDE + Merkle tree */
+typedef struct vx_circuit vx_circuit; /* device-resident prover key: CommonCircuitData + ProverOnlyCircuitData */
+
+/* ---- library / context ------------------------------------------------------------------- */
+const char* vx_last_error(void);
+const char* vx_version(void);
+int vx_device_count(void);
+int vx_ctx_create(int device, vx_ctx** out);
+void vx_ctx_destroy(vx_ctx* ctx);
+int vx_ctx_sync(vx_ctx* ctx);
+/* Opaque hipStream_t of the context (so a harness can record its own events on the right stream). */
+void* vx_ctx_stream(vx_ctx* ctx);
+
+/* Per-kernel-family HIP-event timing.  enable=1 brackets every launch family with events on the
+ * context's stream; vx_prof_get returns accumulated milliseconds and launch counts since the last
+ * vx_prof_reset.  names/ms/calls may be NULL to query the entry count. */
+int vx_prof_enable(vx_ctx* ctx, int enable);
+int vx_prof_reset(vx_ctx* ctx);
+int vx_prof_count(vx_ctx* ctx);
+int vx_prof_get(vx_ctx* ctx, int index, char* name_out, size_t name_cap, double* ms_out, uint64_t* calls_out,
+                double* alg_bytes_out);
+
+/* ---- raw device buffers (keep inputs resident in HBM between calls) ----------------------- */
+int vx_dev_alloc(vx_ctx* ctx, size_t bytes, void** dptr);
+int vx_dev_free(vx_ctx* ctx, void* dptr);
+int vx_dev_upload(vx_ctx* ctx, void* dptr, const void* host, size_t bytes);
+int vx_dev_download(vx_ctx* ctx, void* host, const void* dptr, size_t bytes);
+
+/* ---- L1 primitives on host buffers --------------------------------------------------------- */
+/* plonky2_field::fft conventions, natural order in and out, in place, column-major [ncols][2^log_n].
+ * kind: 0 fft, 1 ifft, 2 coset_fft(shift), 3 coset_ifft(shift). */
+#define VX_NTT_FFT 0
+#define VX_NTT_IFFT 1
+#define VX_NTT_COSET_FFT 2
+#define VX_NTT_COSET_IFFT 3
+int vx_ntt_batch(vx_ctx* ctx, uint64_t* data, int log_n, size_t ncols, int kind, uint64_t shift);
+/* Same transform on a DEVICE buffer, results left in the library's native bit-reversed order
+ * (no permutation pass); this is the form the benchmark times. dst may equal src. */
+int vx_ntt_batch_dev(vx_ctx* ctx, const uint64_t* src, uint64_t* dst, int log_n, size_t ncols, int kind,
+                     uint64_t shift);
+/* Poseidon permutation on `count` independent 12-element states (Poseidon::poseidon). */
+int vx_poseidon_permute(vx_ctx* ctx, uint64_t* states, size_t count);
+/* MerkleTree::new over ROW-MAJOR leaves [n_leaves][width] with hash_or_noop leaves and two_to_one
+ * nodes.  digests_out (optional) [n_leaves][4]; cap_out [2^cap_height][4]. */
+int vx_merkle_cap(vx_ctx* ctx, const uint64_t* leaves, size_t n_leaves, size_t width, int cap_height,
+                  uint64_t* digests_out, uint64_t* cap_out);
+
+/* ---- L2: PolynomialBatch handles ------------------------------------------------------------ */
+/* PolynomialBatch::from_values (is_coeffs = 0: values on H, natural order) or from_coeffs
+ * (is_coeffs = 1: coefficients, natural order).  cols: column-major [ncols][2^log_n]; src_on_device
+ * selects whether `cols` is a host pointer or a device pointer obtained from vx_dev_alloc.
+ * Afterwards the batch owns device copies of the coefficients, the 2^rate_bits blow-up LDE on the
+ * coset 7*H' in bit-reversed row order, all leaf digests and the Merkle tree down to the cap. */
+int vx_batch_commit(vx_ctx* ctx, const uint64_t* cols, int src_on_device, int log_n, size_t ncols, int rate_bits,
+                    int cap_height, int is_coeffs, vx_batch** out);
+void vx_batch_free(vx_batch* b);
+int vx_batch_cap(vx_batch* b, uint64_t* cap_out /* [2^cap_height][4] */);
+/* coefficients of column `col`, natural order, n values */
+int vx_batch_coeffs(vx_batch* b, size_t col, uint64_t* out);
+/* LDE leaf `row` (bit-reversed row order, i.e. MerkleTree leaf index): ncols values + the Merkle
+ * path (log2(8n) - cap_height digests, bottom-up) — MerkleTree::prove + tree.get. */
+int vx_batch_open_row(vx_batch* b, size_t row, uint64_t* values_out, uint64_t* path_out);
+/* all leaf digests [8n][4] (testing aid) */
+int vx_batch_digests(vx_batch* b, uint64_t* out);
+/* Download rows [row0, row0+nrows) of the LDE, row-major [nrows][ncols] (testing aid). */
+int vx_batch_lde_rows(vx_batch* b, size_t row0, size_t nrows, uint64_t* out);
+/* PolynomialCoeffs::to_extension().eval(zeta) for every column: out [ncols][2]. */
+int vx_batch_eval_ext(vx_batch* b, const uint64_t zeta[2], uint64_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VXPROVER_H */

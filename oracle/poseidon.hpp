@@ -1,0 +1,166 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see field.hpp header for the full notice and parity status).
+// Restates  plonky2/src/hash/poseidon.rs, poseidon_goldilocks.rs, hashing.rs, hash_types.rs,
+//           merkle_tree.rs, merkle_proofs.rs  of plonky2 v0.2.0          
+// PINNED by the three permutation known-answer vectors of SURVEY.md Appendix B.2
+// (tests/golden/poseidon_kat.json) and the round-constant checksum of B.1.
+#pragma once
+#include "field.hpp"
+#include "poseidon_constants.h"
+#include <array>
+#include <cstring>
+
+namespace vxo {
+
+static const int SPONGE_WIDTH = 12, SPONGE_RATE = 8, HALF_N_FULL_ROUNDS = 4, N_PARTIAL_ROUNDS = 22;
+static const int N_ROUNDS = 2 * HALF_N_FULL_ROUNDS + N_PARTIAL_ROUNDS;
+static const u64 ROUND_CONSTANTS[VX_POSEIDON_N_ROUND_CONSTANTS] = VX_POSEIDON_ROUND_CONSTANTS_INIT;
+static const u64 MDS_CIRC[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+static const u64 MDS_DIAG[12] = {8, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+typedef std::array<u64, 12> State;
+
+static inline u64 sbox(u64 x) {
+  u64 x2 = sqr(x), x4 = sqr(x2), x3 = mul(x, x2);
+  return mul(x3, x4);
+}
+// poseidon.rs::mds_layer (naive form)
+static inline void mds_layer(State& s) {
+  State o;
+  for (int r = 0; r < 12; ++r) {
+    u128 acc = 0;  // 12 terms < 2^6 * 2^64 each: fits
+    for (int i = 0; i < 12; ++i) acc += (u128)MDS_CIRC[i] * s[(i + r) % 12];
+    acc += (u128)MDS_DIAG[r] * s[r];
+    o[r] = reduce128(acc);
+  }
+  s = o;
+}
+// poseidon.rs::poseidon — naive partial rounds (equivalent to upstream's FAST_PARTIAL_* form).
+static inline void permute(State& s) {
+  int rc = 0;
+  for (int r = 0; r < N_ROUNDS; ++r) {
+    for (int i = 0; i < 12; ++i) s[i] = add(s[i], ROUND_CONSTANTS[rc++]);
+    bool full = r < HALF_N_FULL_ROUNDS || r >= HALF_N_FULL_ROUNDS + N_PARTIAL_ROUNDS;
+    if (full)
+      for (int i = 0; i < 12; ++i) s[i] = sbox(s[i]);
+    else
+      s[0] = sbox(s[0]);
+    mds_layer(s);
+  }
+}
+
+struct Hash {
+  u64 e[4];
+  bool operator==(const Hash& o) const { return !memcmp(e, o.e, sizeof e); }
+};
+
+// hashing.rs::hash_n_to_m_no_pad with m = 4 (overwrite-mode sponge)
+static inline Hash hash_no_pad(const u64* in, size_t n) {
+  State s{};
+  for (size_t off = 0; off < n; off += SPONGE_RATE) {
+    size_t len = n - off < (size_t)SPONGE_RATE ? n - off : SPONGE_RATE;
+    for (size_t i = 0; i < len; ++i) s[i] = in[off + i];
+    permute(s);
+  }
+  if (n == 0) {
+    // upstream: empty input performs zero permutations and squeezes the zero state
+  }
+  Hash h;
+  for (int i = 0; i < 4; ++i) h.e[i] = s[i];
+  return h;
+}
+// hashing.rs::hash_n_to_m_no_pad general squeeze
+static inline std::vector<u64> hash_n_to_m_no_pad(const u64* in, size_t n, size_t m) {
+  State s{};
+  for (size_t off = 0; off < n; off += SPONGE_RATE) {
+    size_t len = n - off < (size_t)SPONGE_RATE ? n - off : SPONGE_RATE;
+    for (size_t i = 0; i < len; ++i) s[i] = in[off + i];
+    permute(s);
+  }
+  std::vector<u64> out;
+  for (;;) {
+    for (int i = 0; i < SPONGE_RATE; ++i) {
+      out.push_back(s[i]);
+      if (out.size() == m) return out;
+    }
+    permute(s);
+  }
+}
+// hash_types / Hasher::hash_or_noop
+static inline Hash hash_or_noop(const u64* in, size_t n) {
+  if (n <= 4) {
+    Hash h{{0, 0, 0, 0}};
+    for (size_t i = 0; i < n; ++i) h.e[i] = in[i];
+    return h;
+  }
+  return hash_no_pad(in, n);
+}
+// PoseidonHash::two_to_one
+static inline Hash two_to_one(const Hash& l, const Hash& r) {
+  State s{};
+  for (int i = 0; i < 4; ++i) s[i] = l.e[i], s[4 + i] = r.e[i];
+  permute(s);
+  Hash h;
+  for (int i = 0; i < 4; ++i) h.e[i] = s[i];
+  return h;
+}
+
+// ---------------------------------------------------------------------------------------------
+// merkle_tree.rs::MerkleTree (outputs only: cap + proofs; upstream's interleaved digest buffer is
+// an internal layout that does not affect either).  Leaves are row-major: leaf i = leaves[i*width..].
+// ---------------------------------------------------------------------------------------------
+struct MerkleTree {
+  size_t n_leaves = 0, width = 0;
+  int cap_height = 0;
+  std::vector<u64> leaves;                 // n_leaves * width
+  std::vector<std::vector<Hash>> layers;   // layers[0] = leaf digests, last = cap
+  const std::vector<Hash>& cap() const { return layers.back(); }
+  const u64* leaf(size_t i) const { return &leaves[i * width]; }
+
+  void build(std::vector<u64>&& lv, size_t w, int cap_h) {
+    leaves = std::move(lv);
+    width = w;
+    n_leaves = leaves.size() / w;
+    int lg = log2_strict(n_leaves);
+    assert(cap_h <= lg);
+    cap_height = cap_h;
+    layers.clear();
+    layers.emplace_back(n_leaves);
+    {
+      std::vector<Hash>& d = layers[0];
+      long long nl = (long long)n_leaves;
+#pragma omp parallel for schedule(static)
+      for (long long i = 0; i < nl; ++i) d[i] = hash_or_noop(&leaves[(size_t)i * w], w);
+    }
+    for (int lvl = lg; lvl > cap_h; --lvl) {
+      const std::vector<Hash>& prev = layers.back();
+      std::vector<Hash> next(prev.size() / 2);
+      long long nn = (long long)next.size();
+#pragma omp parallel for schedule(static)
+      for (long long i = 0; i < nn; ++i) next[i] = two_to_one(prev[2 * i], prev[2 * i + 1]);
+      layers.push_back(std::move(next));
+    }
+  }
+  // MerkleTree::prove — siblings bottom-up, length log2(n) - cap_height
+  std::vector<Hash> prove(size_t idx) const {
+    std::vector<Hash> sib;
+    for (size_t l = 0; l + 1 < layers.size(); ++l) {
+      sib.push_back(layers[l][idx ^ 1]);
+      idx >>= 1;
+    }
+    return sib;
+  }
+};
+
+// merkle_proofs.rs::verify_merkle_proof_to_cap
+static inline bool verify_merkle_proof_to_cap(const u64* leaf, size_t width, size_t idx,
+                                              const std::vector<Hash>& cap,
+                                              const std::vector<Hash>& siblings) {
+  Hash cur = hash_or_noop(leaf, width);
+  for (const Hash& s : siblings) {
+    cur = (idx & 1) ? two_to_one(s, cur) : two_to_one(cur, s);
+    idx >>= 1;
+  }
+  return idx < cap.size() && cur == cap[idx];
+}
+
+}  // namespace vxo

@@ -1,0 +1,149 @@
+"""ctypes loader for oracle/liboracle.so — TEST INFRASTRUCTURE ONLY (the CPU restatement of plonky2
+v0.2.0's prover arithmetic; see oracle/field.hpp for the notice and parity status)."""
+import ctypes
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+P = 0xFFFFFFFF00000001
+_vp, _sz, _i, _u64 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_uint64
+
+
+def build():
+    so = ROOT / "oracle" / "liboracle.so"
+    r = subprocess.run(["make", "-C", str(ROOT / "oracle")], capture_output=True, text=True)
+    if r.returncode and not so.exists():
+        raise RuntimeError("oracle build failed:\n" + r.stdout + r.stderr)
+    return so
+
+
+class Oracle:
+    def __init__(self, L):
+        self.L = L
+        L.vxo_mul.restype = L.vxo_add.restype = L.vxo_sub.restype = L.vxo_inv.restype = L.vxo_pow.restype = _u64
+        L.vxo_root_of_unity.restype = _u64
+        for f in (L.vxo_mul, L.vxo_add, L.vxo_sub, L.vxo_pow):
+            f.argtypes = [_u64, _u64]
+        L.vxo_inv.argtypes = [_u64]
+        L.vxo_root_of_unity.argtypes = [_i]
+        L.vxo_ext_mul.argtypes = [_vp, _vp, _vp]
+        L.vxo_ext_inv.argtypes = [_vp, _vp]
+        L.vxo_poseidon_permute.argtypes = [_vp, _sz]
+        L.vxo_hash_no_pad.argtypes = [_vp, _sz, _vp]
+        L.vxo_hash_or_noop.argtypes = [_vp, _sz, _vp]
+        L.vxo_two_to_one.argtypes = [_vp, _vp, _vp]
+        L.vxo_ntt_batch.argtypes = [_vp, _i, _sz, _i, _u64]
+        L.vxo_merkle.argtypes = [_vp, _sz, _sz, _i, _vp, _vp]
+        L.vxo_commit.argtypes = [_vp, _i, _sz, _i, _i, _i, _vp, _vp, _vp, _vp]
+        L.vxo_set_num_threads.argtypes = [_i]
+        L.vxo_num_threads.restype = _i
+
+    # field
+    def mul(self, a, b): return self.L.vxo_mul(a, b)
+    def add(self, a, b): return self.L.vxo_add(a, b)
+    def sub(self, a, b): return self.L.vxo_sub(a, b)
+    def inv(self, a): return self.L.vxo_inv(a)
+    def pow(self, a, e): return self.L.vxo_pow(a, e)
+    def root_of_unity(self, k): return self.L.vxo_root_of_unity(k)
+
+    def ext_mul(self, x, y):
+        x, y = np.asarray(x, np.uint64), np.asarray(y, np.uint64)
+        o = np.empty(2, np.uint64)
+        self.L.vxo_ext_mul(x.ctypes.data, y.ctypes.data, o.ctypes.data)
+        return o
+
+    def ext_inv(self, x):
+        x = np.asarray(x, np.uint64)
+        o = np.empty(2, np.uint64)
+        self.L.vxo_ext_inv(x.ctypes.data, o.ctypes.data)
+        return o
+
+    def ext_pow(self, x, e):
+        r = np.array([1, 0], np.uint64)
+        b = np.asarray(x, np.uint64)
+        while e:
+            if e & 1:
+                r = self.ext_mul(r, b)
+            b = self.ext_mul(b, b)
+            e >>= 1
+        return r
+
+    # hashing
+    def poseidon_permute(self, states):
+        a = np.ascontiguousarray(states, np.uint64).reshape(-1, 12).copy()
+        self.L.vxo_poseidon_permute(a.ctypes.data, a.shape[0])
+        return a
+
+    def hash_no_pad(self, v):
+        v = np.ascontiguousarray(v, np.uint64)
+        o = np.empty(4, np.uint64)
+        self.L.vxo_hash_no_pad(v.ctypes.data, v.size, o.ctypes.data)
+        return o
+
+    def hash_or_noop(self, v):
+        v = np.ascontiguousarray(v, np.uint64)
+        o = np.empty(4, np.uint64)
+        self.L.vxo_hash_or_noop(v.ctypes.data, v.size, o.ctypes.data)
+        return o
+
+    def two_to_one(self, l, r):
+        l, r = np.ascontiguousarray(l, np.uint64), np.ascontiguousarray(r, np.uint64)
+        o = np.empty(4, np.uint64)
+        self.L.vxo_two_to_one(l.ctypes.data, r.ctypes.data, o.ctypes.data)
+        return o
+
+    def ntt_batch(self, cols, kind, shift=7):
+        a = np.ascontiguousarray(cols, np.uint64).copy()
+        if a.ndim == 1:
+            a = a[None, :]
+        ncols, n = a.shape
+        self.L.vxo_ntt_batch(a.ctypes.data, int(n).bit_length() - 1, ncols, kind, shift)
+        return a
+
+    def merkle(self, leaves, cap_height):
+        a = np.ascontiguousarray(leaves, np.uint64)
+        n, w = a.shape
+        dig = np.empty((n, 4), np.uint64)
+        cap = np.empty((1 << cap_height, 4), np.uint64)
+        self.L.vxo_merkle(a.ctypes.data, n, w, cap_height, dig.ctypes.data, cap.ctypes.data)
+        return dig, cap
+
+    def commit(self, cols, rate_bits=3, cap_height=4, is_coeffs=False, want_leaves=True):
+        a = np.ascontiguousarray(cols, np.uint64)
+        ncols, n = a.shape
+        log_n = int(n).bit_length() - 1
+        N = n << rate_bits
+        coeffs = np.empty((ncols, n), np.uint64)
+        leaves = np.empty((N, ncols), np.uint64) if want_leaves else None
+        dig = np.empty((N, 4), np.uint64)
+        cap = np.empty((1 << cap_height, 4), np.uint64)
+        self.L.vxo_commit(a.ctypes.data, log_n, ncols, rate_bits, cap_height, int(is_coeffs), coeffs.ctypes.data,
+                          leaves.ctypes.data if want_leaves else None, dig.ctypes.data, cap.ctypes.data)
+        return {"coeffs": coeffs, "leaves": leaves, "digests": dig, "cap": cap}
+
+
+_cached = None
+
+
+def load() -> Oracle:
+    global _cached
+    if _cached is None:
+        so = build()
+        _cached = Oracle(ctypes.CDLL(str(so)))
+    return _cached
+
+
+def rand_field(rng, shape):
+    """uniform canonical field elements"""
+    return rng.integers(0, P, size=shape, dtype=np.uint64)
+
+
+def np_add(a, b):
+    """vectorised field addition of canonical uint64 arrays"""
+    a = np.asarray(a, np.uint64)
+    b = np.asarray(b, np.uint64)
+    s = a + b
+    s = s + (s < a).astype(np.uint64) * np.uint64(0xFFFFFFFF)
+    return np.where(s >= np.uint64(P), s - np.uint64(P), s)

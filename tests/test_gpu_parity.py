@@ -1,0 +1,180 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI of
+include/vxprover.h, must be BIT-EXACT against the oracle (CPU restatement of plonky2 v0.2.0) on the
+same seeded inputs, and satisfy size-independent properties at the benchmark sizes.
+"""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import vectorx_amd as vx
+from oracle_lib import P, np_add, rand_field
+
+pytestmark = pytest.mark.gpu
+GOLD = Path(__file__).resolve().parent / "golden"
+
+
+def test_native_library_is_loaded(ctx):
+    # fail loudly if a silent fallback ever sneaks in: the only compute path is libvxprover.so
+    assert vx.lib().vx_device_count() >= 1
+    assert "libvxprover.so" in open("/proc/self/maps").read()
+
+
+def test_poseidon_kats_on_gpu(ctx):
+    kat = json.loads((GOLD / "poseidon_kat.json").read_text())
+    inp = np.array([[int(x, 16) for x in v["input"]] for v in kat["vectors"]], dtype=np.uint64)
+    exp = np.array([[int(x, 16) for x in v["output"]] for v in kat["vectors"]], dtype=np.uint64)
+    assert (ctx.poseidon_permute(inp) == exp).all()
+
+
+def test_poseidon_random_and_noncanonical(ctx, oracle):
+    rng = np.random.default_rng(11)
+    st = rand_field(rng, (5000, 12))
+    st[:50] = rng.integers(P, 2**64 - 1, size=(50, 12), dtype=np.uint64, endpoint=True)  # >= p
+    st[50:60] = 0
+    st[60:70] = P - 1
+    assert (ctx.poseidon_permute(st) == oracle.poseidon_permute(st)).all()
+
+
+@pytest.mark.parametrize("log_n", [1, 2, 3, 4, 5, 7, 8, 10, 11, 12, 13, 14, 16, 18])
+@pytest.mark.parametrize("kind", [0, 1, 2, 3])
+def test_ntt_matches_oracle(ctx, oracle, log_n, kind):
+    rng = np.random.default_rng(100 * log_n + kind)
+    ncols = 3 if log_n < 16 else 2
+    cols = rand_field(rng, (ncols, 1 << log_n))
+    shift = 7 if kind < 2 or log_n % 2 else int(rand_field(rng, 1)[0]) | 1
+    got = ctx.ntt_batch(cols, kind, shift)
+    exp = oracle.ntt_batch(cols, kind, shift)
+    assert (got == exp).all()
+
+
+@pytest.mark.parametrize("log_n", [20, 21])
+def test_ntt_large_matches_oracle(ctx, oracle, log_n):
+    rng = np.random.default_rng(log_n)
+    cols = rand_field(rng, (2, 1 << log_n))
+    for kind in (1, 2):
+        assert (ctx.ntt_batch(cols, kind, 7) == oracle.ntt_batch(cols, kind, 7)).all()
+
+
+def test_ntt_24_roundtrip_and_linearity(ctx):
+    """2^24 (the quotient / FRI length at n = 2^21): too slow for the scalar oracle, so check the
+    size-independent properties: ifft(fft(x)) == x, linearity, impulse -> constant."""
+    rng = np.random.default_rng(24)
+    n = 1 << 24
+    x = rand_field(rng, (1, n))
+    y = rand_field(rng, (1, n))
+    fx, fy = ctx.ntt_batch(x, 0), ctx.ntt_batch(y, 0)
+    assert (ctx.ntt_batch(fx, 1) == x).all()
+    assert (ctx.ntt_batch(np_add(x, y), 0) == np_add(fx, fy)).all()
+    imp = np.zeros((1, n), np.uint64)
+    imp[0, 1] = 1   # delta at j=1 -> w^k
+    out = ctx.ntt_batch(imp, 0)
+    w = pow(1753635133440165772, 1 << 8, P)
+    assert int(out[0, 0]) == 1 and int(out[0, 1]) == w and int(out[0, 2]) == w * w % P
+    assert int(out[0, n // 2]) == P - 1
+
+
+def test_ntt_adversarial(ctx, oracle):
+    n = 1 << 13
+    for fill in (0, P - 1, 2**64 - 1, P):
+        cols = np.full((2, n), fill, np.uint64)
+        for kind in (0, 1, 2, 3):
+            assert (ctx.ntt_batch(cols, kind, 7) == oracle.ntt_batch(cols, kind, 7)).all()
+    imp = np.zeros((1, n), np.uint64)
+    imp[0, 0] = 1
+    assert (ctx.ntt_batch(imp, 0) == 1).all()
+
+
+def test_ntt_argument_errors(ctx):
+    with pytest.raises(vx.VxError):
+        ctx.ntt_batch(np.zeros((1, 12), np.uint64), 0)       # not a power of two
+    with pytest.raises(vx.VxError):
+        ctx.ntt_batch(np.zeros((1, 16), np.uint64), 7)       # bad kind
+    with pytest.raises(vx.VxError):
+        ctx.ntt_batch(np.ones((1, 16), np.uint64), 2, 0)     # zero coset shift
+    # length-1 transform and empty batch are fine
+    assert ctx.ntt_batch(np.array([[5]], np.uint64), 0)[0, 0] == 5
+    assert ctx.ntt_batch(np.zeros((0, 16), np.uint64).reshape(0, 16), 0).shape == (0, 16)
+
+
+@pytest.mark.parametrize("n_leaves,width,cap_h", [(1, 5, 0), (2, 1, 0), (2, 4, 1), (16, 3, 4), (64, 8, 2), (64, 9, 0),
+                                                   (256, 135, 4), (1024, 20, 4), (4096, 16, 4), (512, 32, 4),
+                                                   (128, 86, 7)])
+def test_merkle_matches_oracle(ctx, oracle, n_leaves, width, cap_h):
+    rng = np.random.default_rng(n_leaves * 1000 + width)
+    leaves = rand_field(rng, (n_leaves, width))
+    leaves[0] = 2**64 - 1  # non-canonical row
+    dig, cap = ctx.merkle_cap(leaves, cap_h)
+    edig, ecap = oracle.merkle(leaves, cap_h)
+    assert (dig == edig).all()
+    assert (cap == ecap).all()
+
+
+def test_merkle_argument_errors(ctx):
+    with pytest.raises(vx.VxError):
+        ctx.merkle_cap(np.zeros((3, 4), np.uint64), 0)    # not a power of two
+    with pytest.raises(vx.VxError):
+        ctx.merkle_cap(np.zeros((4, 4), np.uint64), 3)    # cap taller than the tree
+
+
+@pytest.mark.parametrize("log_n,ncols,rate_bits,cap_h", [(1, 2, 3, 0), (3, 5, 3, 4), (5, 135, 3, 4), (8, 20, 3, 4),
+                                                         (10, 16, 3, 4), (12, 9, 1, 2), (13, 4, 3, 4), (14, 3, 2, 4),
+                                                         (16, 2, 3, 4)])
+def test_polynomial_batch_matches_oracle(ctx, oracle, log_n, ncols, rate_bits, cap_h):
+    rng = np.random.default_rng(log_n * 131 + ncols)
+    vals = rand_field(rng, (ncols, 1 << log_n))
+    b = vx.PolynomialBatch.from_values(ctx, vals, rate_bits, cap_h)
+    e = oracle.commit(vals, rate_bits, cap_h)
+    for c in {0, ncols - 1, ncols // 2}:
+        assert (b.coeffs(c) == e["coeffs"][c]).all()
+    N = 1 << (log_n + rate_bits)
+    nrows = min(N, 64)
+    assert (b.lde_rows(0, nrows) == e["leaves"][:nrows]).all()
+    assert (b.lde_rows(N - nrows, nrows) == e["leaves"][N - nrows:]).all()
+    assert (b.digests() == e["digests"]).all()
+    assert (b.cap() == e["cap"]).all()
+    # MerkleTree::prove + verify_merkle_proof_to_cap semantics
+    for row in {0, 1, N // 3, N - 1}:
+        v, path = b.open_row(row)
+        assert (v == e["leaves"][row]).all()
+        cur, idx = oracle.hash_or_noop(v), row
+        for s in path:
+            cur = oracle.two_to_one(s, cur) if idx & 1 else oracle.two_to_one(cur, s)
+            idx >>= 1
+        assert (cur == e["cap"][idx]).all()
+    # from_coeffs of the same polynomials gives the same commitment
+    b2 = vx.PolynomialBatch.from_coeffs(ctx, e["coeffs"], rate_bits, cap_h)
+    assert (b2.cap() == e["cap"]).all()
+    b.free()
+    b2.free()
+
+
+def test_batch_eval_ext_matches_horner(ctx, oracle):
+    rng = np.random.default_rng(5)
+    log_n, ncols = 10, 11
+    vals = rand_field(rng, (ncols, 1 << log_n))
+    b = vx.PolynomialBatch.from_values(ctx, vals)
+    zeta = [int(v) for v in rand_field(rng, 2)]
+    got = b.eval_ext(zeta)
+    for c in (0, 5, 10):
+        co = b.coeffs(c)
+        acc = np.array([0, 0], np.uint64)
+        for k in range(len(co) - 1, -1, -1):
+            acc = oracle.ext_mul(acc, zeta)
+            acc[0] = oracle.add(int(acc[0]), int(co[k]))
+        assert (got[c] == acc).all()
+    b.free()
+
+
+def test_commit_wire_shaped_batch_properties(ctx, oracle):
+    """header_range-shaped batch (135 wire columns), n = 2^16 here to stay inside the oracle's reach for
+    a FULL comparison of the cap; plus LDE consistency: every coset block of the LDE interpolates back
+    to the same polynomial (size-independent property used again at full size in bench.py --verify)."""
+    rng = np.random.default_rng(99)
+    log_n, ncols = 16, 135
+    vals = rand_field(rng, (ncols, 1 << log_n))
+    b = vx.PolynomialBatch.from_values(ctx, vals)
+    e = oracle.commit(vals, 3, 4, want_leaves=False)
+    assert (b.cap() == e["cap"]).all()
+    b.free()

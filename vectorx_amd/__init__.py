@@ -1,0 +1,292 @@
+"""vectorx_amd — MI355X (gfx950) prover backend for VectorX's plonky2x circuits.
+
+The product is ``libvxprover.so`` (hand-written HIP kernels behind the C ABI of ``include/vxprover.h``).
+This package is the thin Python host-side mirror of the plonky2 surface that the reference reaches
+through ``circuit.prove(&input)`` (/root/reference/circuits/header_range.rs:167) — same names and
+argument meaning as plonky2 v0.2.0's ``PolynomialBatch::from_values``, ``MerkleTree::new``,
+``fft`` / ``ifft`` / ``coset_fft`` — and it is what the parity tests and ``bench.py`` drive.
+
+There is NO CPU fallback: importing works anywhere (so the symbol-export test can run on a CPU box),
+but every compute call raises :class:`VxError` unless the HIP library is built and a gfx950 device is
+present.  Nothing here imports ``oracle/``.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+_PKG = Path(__file__).resolve().parent
+_LIB_PATH = _PKG / "libvxprover.so"
+P = 0xFFFFFFFF00000001
+
+VX_OK, VX_E_INVALID, VX_E_NO_DEVICE, VX_E_HIP, VX_E_NOMEM, VX_E_PROOF = 0, -1, -2, -3, -4, -5
+NTT_FFT, NTT_IFFT, NTT_COSET_FFT, NTT_COSET_IFFT = 0, 1, 2, 3
+
+
+class VxError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"vxprover error {code}: {msg}")
+        self.code = code
+
+
+def build(verbose: bool = False) -> Path:
+    """Compile libvxprover.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    r = subprocess.run(["make", "-C", str(_PKG / "csrc")], capture_output=True, text=True)
+    if verbose or r.returncode:
+        print(r.stdout[-4000:], r.stderr[-4000:])
+    if r.returncode:
+        raise RuntimeError("building libvxprover.so failed")
+    return _LIB_PATH
+
+
+_lib = None
+
+_u64p = ctypes.POINTER(ctypes.c_uint64)
+_vp = ctypes.c_void_p
+_sz = ctypes.c_size_t
+_i = ctypes.c_int
+_u64 = ctypes.c_uint64
+
+# name -> (restype, argtypes).  Mirrors include/vxprover.h one-to-one (tests/test_abi.py checks that).
+_SIGNATURES = {
+    "vx_last_error": (ctypes.c_char_p, []),
+    "vx_version": (ctypes.c_char_p, []),
+    "vx_device_count": (_i, []),
+    "vx_ctx_create": (_i, [_i, ctypes.POINTER(_vp)]),
+    "vx_ctx_destroy": (None, [_vp]),
+    "vx_ctx_sync": (_i, [_vp]),
+    "vx_ctx_stream": (_vp, [_vp]),
+    "vx_prof_enable": (_i, [_vp, _i]),
+    "vx_prof_reset": (_i, [_vp]),
+    "vx_prof_count": (_i, [_vp]),
+    "vx_prof_get": (_i, [_vp, _i, ctypes.c_char_p, _sz, ctypes.POINTER(ctypes.c_double), _u64p,
+                         ctypes.POINTER(ctypes.c_double)]),
+    "vx_dev_alloc": (_i, [_vp, _sz, ctypes.POINTER(_vp)]),
+    "vx_dev_free": (_i, [_vp, _vp]),
+    "vx_dev_upload": (_i, [_vp, _vp, _vp, _sz]),
+    "vx_dev_download": (_i, [_vp, _vp, _vp, _sz]),
+    "vx_ntt_batch": (_i, [_vp, _vp, _i, _sz, _i, _u64]),
+    "vx_ntt_batch_dev": (_i, [_vp, _vp, _vp, _i, _sz, _i, _u64]),
+    "vx_poseidon_permute": (_i, [_vp, _vp, _sz]),
+    "vx_merkle_cap": (_i, [_vp, _vp, _sz, _sz, _i, _vp, _vp]),
+    "vx_batch_commit": (_i, [_vp, _vp, _i, _i, _sz, _i, _i, _i, ctypes.POINTER(_vp)]),
+    "vx_batch_free": (None, [_vp]),
+    "vx_batch_cap": (_i, [_vp, _vp]),
+    "vx_batch_coeffs": (_i, [_vp, _sz, _vp]),
+    "vx_batch_open_row": (_i, [_vp, _sz, _vp, _vp]),
+    "vx_batch_digests": (_i, [_vp, _vp]),
+    "vx_batch_lde_rows": (_i, [_vp, _sz, _sz, _vp]),
+    "vx_batch_eval_ext": (_i, [_vp, _vp, _vp]),
+}
+
+
+def lib() -> ctypes.CDLL:
+    """Load libvxprover.so.  Fails loudly (no fallback) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not _LIB_PATH.exists():
+            raise VxError(VX_E_NO_DEVICE, f"{_LIB_PATH} is missing — run `python -c 'import __graft_entry__ as g; "
+                          "g.build()'` (hipcc, gfx950).  There is no CPU fallback.")
+        L = ctypes.CDLL(str(_LIB_PATH))
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _chk(rc: int):
+    if rc != 0:
+        raise VxError(rc, lib().vx_last_error().decode(errors="replace"))
+
+
+def _as_u64(a, shape=None) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+class Context:
+    """One (device, HIP stream) pair — `vx_ctx`."""
+
+    def __init__(self, device: int = 0):
+        self._h = _vp()
+        _chk(lib().vx_ctx_create(device, ctypes.byref(self._h)))
+        self.device = device
+
+    def close(self):
+        if self._h:
+            lib().vx_ctx_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        _chk(lib().vx_ctx_sync(self._h))
+
+    @property
+    def stream(self) -> int:
+        return lib().vx_ctx_stream(self._h)
+
+    # ---- profiling ----
+    def prof_enable(self, on: bool = True):
+        _chk(lib().vx_prof_enable(self._h, int(on)))
+
+    def prof_reset(self):
+        _chk(lib().vx_prof_reset(self._h))
+
+    def prof(self) -> dict:
+        n = lib().vx_prof_count(self._h)
+        out = {}
+        for k in range(n):
+            name = ctypes.create_string_buffer(64)
+            ms, by, calls = ctypes.c_double(), ctypes.c_double(), _u64()
+            _chk(lib().vx_prof_get(self._h, k, name, 64, ctypes.byref(ms), ctypes.byref(calls), ctypes.byref(by)))
+            out[name.value.decode()] = {"ms": ms.value, "calls": calls.value, "alg_bytes": by.value}
+        return out
+
+    # ---- device buffers ----
+    def alloc(self, nbytes: int) -> int:
+        p = _vp()
+        _chk(lib().vx_dev_alloc(self._h, nbytes, ctypes.byref(p)))
+        return p.value
+
+    def free(self, dptr: int):
+        _chk(lib().vx_dev_free(self._h, dptr))
+
+    def upload(self, dptr: int, host: np.ndarray):
+        host = np.ascontiguousarray(host)
+        _chk(lib().vx_dev_upload(self._h, dptr, host.ctypes.data, host.nbytes))
+
+    def download(self, dptr: int, nbytes: int) -> np.ndarray:
+        out = np.empty(nbytes // 8, dtype=np.uint64)
+        _chk(lib().vx_dev_download(self._h, out.ctypes.data, dptr, nbytes))
+        return out
+
+    # ---- L1 (plonky2_field::fft / hash::poseidon / hash::merkle_tree) ----
+    def ntt_batch(self, cols: np.ndarray, kind: int, shift: int = 7) -> np.ndarray:
+        """cols: [ncols][n] column-major; returns the transformed copy, natural order (fft.rs)."""
+        a = _as_u64(cols).copy()
+        if a.ndim == 1:
+            a = a[None, :]
+        ncols, n = a.shape
+        log_n = int(n).bit_length() - 1
+        if n == 0 or (1 << log_n) != n:
+            raise VxError(VX_E_INVALID, f"length {n} is not a power of two")
+        _chk(lib().vx_ntt_batch(self._h, a.ctypes.data, log_n, ncols, kind, shift))
+        return a
+
+    def ntt_batch_dev(self, src: int, dst: int, log_n: int, ncols: int, kind: int, shift: int = 7):
+        _chk(lib().vx_ntt_batch_dev(self._h, src, dst, log_n, ncols, kind, shift))
+
+    def poseidon_permute(self, states: np.ndarray) -> np.ndarray:
+        a = _as_u64(states).reshape(-1, 12).copy()
+        _chk(lib().vx_poseidon_permute(self._h, a.ctypes.data, a.shape[0]))
+        return a
+
+    def merkle_cap(self, leaves: np.ndarray, cap_height: int):
+        """MerkleTree::new(leaves, cap_height) -> (digests [n][4], cap [2^cap_height][4])."""
+        a = _as_u64(leaves)
+        n, w = a.shape
+        dig = np.empty((n, 4), dtype=np.uint64)
+        cap = np.empty((1 << cap_height, 4), dtype=np.uint64)
+        _chk(lib().vx_merkle_cap(self._h, a.ctypes.data, n, w, cap_height, dig.ctypes.data, cap.ctypes.data))
+        return dig, cap
+
+
+class PolynomialBatch:
+    """Device-resident plonky2 `PolynomialBatch` (fri/oracle.rs) — `vx_batch`."""
+
+    def __init__(self, ctx: Context, handle, log_n, ncols, rate_bits, cap_height):
+        self.ctx, self._h = ctx, handle
+        self.log_n, self.ncols, self.rate_bits, self.cap_height = log_n, ncols, rate_bits, cap_height
+
+    @classmethod
+    def _commit(cls, ctx, cols, rate_bits, cap_height, is_coeffs, dev_ptr=None, log_n=None, ncols=None):
+        h = _vp()
+        if dev_ptr is None:
+            a = _as_u64(cols)
+            ncols, n = a.shape
+            log_n = int(n).bit_length() - 1
+            if n == 0 or (1 << log_n) != n:
+                raise VxError(VX_E_INVALID, f"length {n} is not a power of two")
+            _chk(lib().vx_batch_commit(ctx._h, a.ctypes.data, 0, log_n, ncols, rate_bits, cap_height, is_coeffs,
+                                       ctypes.byref(h)))
+        else:
+            _chk(lib().vx_batch_commit(ctx._h, dev_ptr, 1, log_n, ncols, rate_bits, cap_height, is_coeffs,
+                                       ctypes.byref(h)))
+        return cls(ctx, h, log_n, ncols, rate_bits, cap_height)
+
+    @classmethod
+    def from_values(cls, ctx, values, rate_bits=3, cap_height=4):
+        return cls._commit(ctx, values, rate_bits, cap_height, 0)
+
+    @classmethod
+    def from_coeffs(cls, ctx, coeffs, rate_bits=3, cap_height=4):
+        return cls._commit(ctx, coeffs, rate_bits, cap_height, 1)
+
+    @classmethod
+    def from_values_dev(cls, ctx, dev_ptr, log_n, ncols, rate_bits=3, cap_height=4):
+        return cls._commit(ctx, None, rate_bits, cap_height, 0, dev_ptr=dev_ptr, log_n=log_n, ncols=ncols)
+
+    def free(self):
+        if self._h:
+            lib().vx_batch_free(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    @property
+    def n(self):
+        return 1 << self.log_n
+
+    @property
+    def lde_size(self):
+        return 1 << (self.log_n + self.rate_bits)
+
+    def cap(self) -> np.ndarray:
+        out = np.empty((1 << self.cap_height, 4), dtype=np.uint64)
+        _chk(lib().vx_batch_cap(self._h, out.ctypes.data))
+        return out
+
+    def coeffs(self, col: int) -> np.ndarray:
+        out = np.empty(self.n, dtype=np.uint64)
+        _chk(lib().vx_batch_coeffs(self._h, col, out.ctypes.data))
+        return out
+
+    def digests(self) -> np.ndarray:
+        out = np.empty((self.lde_size, 4), dtype=np.uint64)
+        _chk(lib().vx_batch_digests(self._h, out.ctypes.data))
+        return out
+
+    def lde_rows(self, row0: int, nrows: int) -> np.ndarray:
+        out = np.empty((nrows, self.ncols), dtype=np.uint64)
+        _chk(lib().vx_batch_lde_rows(self._h, row0, nrows, out.ctypes.data))
+        return out
+
+    def open_row(self, row: int):
+        """(leaf values, Merkle path) — `MerkleTree::prove(row)` + `tree.get(row)`."""
+        vals = np.empty(self.ncols, dtype=np.uint64)
+        path = np.empty((self.log_n + self.rate_bits - self.cap_height, 4), dtype=np.uint64)
+        _chk(lib().vx_batch_open_row(self._h, row, vals.ctypes.data, path.ctypes.data))
+        return vals, path
+
+    def eval_ext(self, zeta) -> np.ndarray:
+        z = _as_u64(zeta, (2,))
+        out = np.empty((self.ncols, 2), dtype=np.uint64)
+        _chk(lib().vx_batch_eval_ext(self._h, z.ctypes.data, out.ctypes.data))
+        return out

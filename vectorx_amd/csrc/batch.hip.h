@@ -1,0 +1,242 @@
+// Device-resident PolynomialBatch (plonky2::fri::oracle::PolynomialBatch, plonky2 v0.2.0
+// plonky2/src/fri/oracle.rs — un-vendored, /root/reference/Cargo.lock:4848-4905).
+//
+// HBM layout of one batch (n = 2^log_n rows, N = n * 2^rate_bits LDE rows, m columns):
+//   coeffs [m][n]  u64, column-major, BIT-REVERSED coefficient order (position rev(j) holds c_j)
+//   lde    [m][N]  u64, column-major, row index = MerkleTree leaf index = rev_N(LDE point index);
+//                  coset r (points 7*w_N^(r + 2^rate_bits * k)) is the contiguous row block
+//                  [rev(r)*n, (rev(r)+1)*n)
+//   tree   level 0 = N leaf digests (4 u64 each), then N/2, ... down to the 2^cap_height cap.
+#pragma once
+#include "vx_runtime.hip.h"
+
+struct vx_batch {
+  vx_ctx* ctx = nullptr;
+  int log_n = 0, rate_bits = 0, cap_height = 0;
+  size_t ncols = 0;
+  u64* coeffs = nullptr;
+  u64* lde = nullptr;
+  u64* tree = nullptr;
+  size_t cap_off = 0;  // digest index of the cap level inside `tree`
+};
+
+__global__ void canon_kernel(u64* __restrict__ x, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] = gl_canon(x[i]);
+}
+
+static int get_scale_tables(vx_ctx* c, int log_n, int bits, const std::vector<u64>& shifts, u64 pre_mul, u64** out) {
+  std::string key = std::to_string(log_n) + ":" + std::to_string(bits) + ":" + std::to_string(pre_mul);
+  for (u64 s : shifts) key += ":" + std::to_string(s);
+  auto it = c->scale_cache.find(key);
+  if (it != c->scale_cache.end()) {
+    *out = it->second;
+    return VX_OK;
+  }
+  u64* d = nullptr;
+  VXCHK(build_scale_tables(c, log_n, bits, shifts, pre_mul, &d));
+  c->scale_cache[key] = d;
+  *out = d;
+  return VX_OK;
+}
+
+// fft / ifft / coset_fft / coset_ifft on natural-order input; result in bit-reversed order.
+static int ntt_natural_to_bitrev(vx_ctx* c, const u64* src, u64* dst, int log_n, size_t ncols, int kind, u64 shift) {
+  using namespace vxh;
+  if (log_n < 1 || log_n > ROOT_TABLE_LOG) return vx_fail(VX_E_INVALID, "ntt: log_n=%d out of range [1,24]", log_n);
+  size_t n = (size_t)1 << log_n;
+  double bytes = 16.0 * (double)n * (double)ncols;
+  u64 ninv = inv((u64)n % P);
+  shift = canon(shift);
+  switch (kind) {
+    case VX_NTT_FFT:
+      return run_ntt(c, src, dst, n, n, 0, 0, log_n, ncols, 1, false, false, nullptr, 0, 1, "ntt_fwd", bytes);
+    case VX_NTT_IFFT:
+      return run_ntt(c, src, dst, n, n, 0, 0, log_n, ncols, 1, true, false, nullptr, 0, ninv, "ntt_inv", bytes);
+    case VX_NTT_COSET_FFT: {
+      if (shift == 0) return vx_fail(VX_E_INVALID, "coset_fft: shift must be non-zero");
+      int bits = log_n / 2;
+      u64* tab = nullptr;
+      VXCHK(get_scale_tables(c, log_n, bits, {shift}, 1, &tab));
+      return run_ntt(c, src, dst, n, n, 0, 0, log_n, ncols, 1, false, false, tab, bits, 1, "ntt_coset_fwd", bytes);
+    }
+    default: {
+      if (shift == 0) return vx_fail(VX_E_INVALID, "coset_ifft: shift must be non-zero");
+      int bits = log_n / 2;
+      u64* tab = nullptr;
+      VXCHK(get_scale_tables(c, log_n, bits, {inv(shift)}, ninv, &tab));
+      VXCHK(run_ntt(c, src, dst, n, n, 0, 0, log_n, ncols, 1, true, false, nullptr, 0, 1, "ntt_coset_inv", bytes));
+      hipLaunchKernelGGL(scale_bitrev_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)ncols), dim3(256), 0,
+                         c->stream, dst, n, log_n, tab, bits);
+      HIPCHK(hipGetLastError());
+      return VX_OK;
+    }
+  }
+}
+
+static int batch_alloc(vx_ctx* c, int log_n, size_t ncols, int rate_bits, int cap_height, vx_batch** out) {
+  vx_batch* b = new vx_batch();
+  b->ctx = c;
+  b->log_n = log_n;
+  b->rate_bits = rate_bits;
+  b->cap_height = cap_height;
+  b->ncols = ncols;
+  size_t n = (size_t)1 << log_n, N = n << rate_bits;
+  size_t nd = merkle_tree_digest_count(N, cap_height);
+  if (hipMalloc(&b->coeffs, n * ncols * 8) != hipSuccess || hipMalloc(&b->lde, N * ncols * 8) != hipSuccess ||
+      hipMalloc(&b->tree, nd * 32) != hipSuccess) {
+    hipFree(b->coeffs);
+    hipFree(b->lde);
+    hipFree(b->tree);
+    delete b;
+    return vx_fail(VX_E_NOMEM, "batch_alloc: out of device memory (n=2^%d, %zu cols, blow-up 2^%d)", log_n, ncols, rate_bits);
+  }
+  *out = b;
+  return VX_OK;
+}
+
+// coefficients (bit-reversed, device) -> LDE -> leaf digests -> Merkle levels
+static int batch_lde_and_tree(vx_ctx* c, vx_batch* b) {
+  using namespace vxh;
+  const int log_n = b->log_n, rb = b->rate_bits;
+  const size_t n = (size_t)1 << log_n, N = n << rb, m = b->ncols;
+  const int nz = 1 << rb;
+  // block z of the bit-reversed LDE holds coset r = rev_rb(z): shift 7 * w_N^r
+  std::vector<u64> shifts(nz);
+  u64 wN = root_of_unity(log_n + rb);
+  for (int z = 0; z < nz; ++z) shifts[z] = mul(7, pow(wN, reverse_bits((size_t)z, rb)));
+  int bits = log_n / 2;
+  u64* tab = nullptr;
+  VXCHK(get_scale_tables(c, log_n, bits, shifts, 1, &tab));
+  VXCHK(run_ntt(c, b->coeffs, b->lde, n, N, 0, n, log_n, m, nz, false, true, tab, bits, 1, "lde",
+                (double)m * 8.0 * ((double)n + (double)N)));
+  {
+    ProfScope ps(c, "hash_leaves", (double)m * 8.0 * (double)N);
+    hipLaunchKernelGGL(hash_leaves_colmajor_kernel, dim3((unsigned)((N + HASH_THREADS - 1) / HASH_THREADS)),
+                       dim3(HASH_THREADS), 0, c->stream, b->lde, N, N, (int)m, b->tree);
+    HIPCHK(hipGetLastError());
+  }
+  VXCHK(build_merkle_levels(c, b->tree, N, b->cap_height, &b->cap_off));
+  return VX_OK;
+}
+
+static int batch_commit_device(vx_ctx* c, vx_batch* b, const u64* src, size_t n, bool is_coeffs) {
+  using namespace vxh;
+  const size_t m = b->ncols;
+  if (is_coeffs) {
+    ProfScope ps(c, "bitrev_permute", 16.0 * (double)n * (double)m);
+    hipLaunchKernelGGL(bitrev_permute_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)m), dim3(256), 0, c->stream, src,
+                       b->coeffs, b->log_n, n, n);
+    HIPCHK(hipGetLastError());
+  } else {
+    u64 ninv = inv((u64)n % P);
+    VXCHK(run_ntt(c, src, b->coeffs, n, n, 0, 0, b->log_n, m, 1, true, false, nullptr, 0, ninv, "intt",
+                  16.0 * (double)n * (double)m));
+  }
+  return batch_lde_and_tree(c, b);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Evaluation of every column at an extension point (plonk/proof.rs OpeningSet::new ->
+// PolynomialCoeffs::to_extension().eval(zeta)).  Coefficients are in bit-reversed order, so the
+// kernel pairs position pos with zeta^rev(pos) from a table built once per zeta.
+// ------------------------------------------------------------------------------------------------
+__global__ void zeta_table_kernel(const u64* __restrict__ pows /* [log_n][2]: zeta^(2^b) */, int log_n, u64* __restrict__ ztab) {
+  size_t pos = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pos >> log_n) return;
+  u32 j = bitrev32((u32)pos, log_n);
+  ext2 acc = ext_make(1, 0);
+  for (int b = 0; b < log_n; ++b)
+    if ((j >> b) & 1) acc = ext_mul(acc, ext_make(pows[2 * b], pows[2 * b + 1]));
+  ztab[2 * pos] = acc.a;
+  ztab[2 * pos + 1] = acc.b;
+}
+
+static int build_zeta_table(vx_ctx* c, vxh::Ext zeta, int log_n, u64* ztab) {
+  std::vector<u64> pows(2 * (log_n > 0 ? log_n : 1));
+  vxh::Ext p = zeta;
+  for (int b = 0; b < log_n; ++b) {
+    pows[2 * b] = p.a;
+    pows[2 * b + 1] = p.b;
+    p = vxh::emul(p, p);
+  }
+  u64* d = nullptr;
+  HIPCHK(hipMalloc(&d, pows.size() * 8));
+  HIPCHK(hipMemcpyAsync(d, pows.data(), pows.size() * 8, hipMemcpyHostToDevice, c->stream));
+  size_t n = (size_t)1 << log_n;
+  {
+    ProfScope ps(c, "zeta_table");
+    hipLaunchKernelGGL(zeta_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, d, log_n, ztab);
+  }
+  HIPCHK(hipStreamSynchronize(c->stream));
+  hipFree(d);
+  return VX_OK;
+}
+
+#define EVAL_BLOCKS 128
+#define EVAL_COLS 8
+__global__ __launch_bounds__(256) void eval_ext_kernel(const u64* __restrict__ coeffs, size_t n, size_t ncols,
+                                                       const u64* __restrict__ ztab, u64* __restrict__ partial) {
+  const size_t c0 = (size_t)blockIdx.y * EVAL_COLS;
+  u64 aa[EVAL_COLS], ab[EVAL_COLS];
+#pragma unroll
+  for (int g = 0; g < EVAL_COLS; ++g) aa[g] = ab[g] = 0;
+  for (size_t pos = (size_t)blockIdx.x * 256 + threadIdx.x; pos < n; pos += (size_t)EVAL_BLOCKS * 256) {
+    const ulonglong2 z = reinterpret_cast<const ulonglong2*>(ztab)[pos];
+#pragma unroll
+    for (int g = 0; g < EVAL_COLS; ++g) {
+      if (c0 + g < ncols) {
+        u64 v = coeffs[(c0 + g) * n + pos];
+        aa[g] = gl_mad(v, z.x, aa[g]);
+        ab[g] = gl_mad(v, z.y, ab[g]);
+      }
+    }
+  }
+  __shared__ u64 red[4][EVAL_COLS][2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int g = 0; g < EVAL_COLS; ++g) {
+    u64 a = aa[g], b = ab[g];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      a = gl_add(a, __shfl_down(a, off, 64));
+      b = gl_add(b, __shfl_down(b, off, 64));
+    }
+    if (lane == 0) {
+      red[wave][g][0] = a;
+      red[wave][g][1] = b;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < EVAL_COLS * 2) {
+    int g = threadIdx.x >> 1, k = threadIdx.x & 1;
+    u64 s = gl_add(gl_add(red[0][g][k], red[1][g][k]), gl_add(red[2][g][k], red[3][g][k]));
+    if (c0 + g < ncols) partial[((c0 + g) * EVAL_BLOCKS + blockIdx.x) * 2 + k] = s;
+  }
+}
+
+static int batch_eval_ext(vx_ctx* c, const u64* coeffs, size_t n, int log_n, size_t ncols, const u64* ztab, uint64_t* out_host) {
+  (void)log_n;
+  u64* partial = nullptr;
+  HIPCHK(hipMalloc(&partial, ncols * EVAL_BLOCKS * 16));
+  {
+    ProfScope ps(c, "eval_ext", 8.0 * (double)n * (double)ncols);
+    hipLaunchKernelGGL(eval_ext_kernel, dim3(EVAL_BLOCKS, (unsigned)((ncols + EVAL_COLS - 1) / EVAL_COLS)), dim3(256), 0,
+                       c->stream, coeffs, n, ncols, ztab, partial);
+  }
+  std::vector<u64> h(ncols * EVAL_BLOCKS * 2);
+  hipError_t e = hipMemcpyAsync(h.data(), partial, h.size() * 8, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  hipFree(partial);
+  if (e != hipSuccess) return vx_fail(VX_E_HIP, "batch_eval_ext: %s", hipGetErrorString(e));
+  for (size_t col = 0; col < ncols; ++col) {
+    u64 a = 0, b = 0;
+    for (int k = 0; k < EVAL_BLOCKS; ++k) {
+      a = vxh::add(a, h[(col * EVAL_BLOCKS + k) * 2]);
+      b = vxh::add(b, h[(col * EVAL_BLOCKS + k) * 2 + 1]);
+    }
+    out_host[2 * col] = a;
+    out_host[2 * col + 1] = b;
+  }
+  return VX_OK;
+}

@@ -1,0 +1,107 @@
+// Host-side Goldilocks / Poseidon used by the PRODUCT library for the tiny sequential pieces that stay
+// on the CPU: twiddle/shift table construction and the Fiat-Shamir challenger (plonky2::iop::challenger,
+// SURVEY.md A.6).  This is deliberately independent of oracle/ (which is test infrastructure).
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+#include "poseidon_constants.h"
+
+namespace vxh {
+typedef uint64_t u64;
+typedef unsigned __int128 u128;
+static const u64 P = 0xFFFFFFFF00000001ULL;
+static const u64 EPS = 0xFFFFFFFFULL;
+
+static inline u64 canon(u64 x) { return x >= P ? x - P : x; }
+static inline u64 add(u64 a, u64 b) {
+  u64 s = a + b;
+  if (s < a) s += EPS;
+  return canon(s);
+}
+static inline u64 sub(u64 a, u64 b) { return a >= b ? a - b : a + (P - b); }
+static inline u64 neg(u64 a) { return a ? P - a : 0; }
+static inline u64 reduce128(u128 x) {
+  u64 lo = (u64)x, hi = (u64)(x >> 64);
+  u64 hh = hi >> 32, hl = hi & EPS;
+  u64 t = lo - hh;
+  if (lo < hh) t -= EPS;
+  u64 m = hl * EPS;
+  u64 r = t + m;
+  if (r < m) r += EPS;
+  return canon(r);
+}
+static inline u64 mul(u64 a, u64 b) { return reduce128((u128)a * b); }
+static inline u64 pow(u64 b, u64 e) {
+  u64 r = 1;
+  while (e) {
+    if (e & 1) r = mul(r, b);
+    b = mul(b, b);
+    e >>= 1;
+  }
+  return r;
+}
+static inline u64 inv(u64 a) { return pow(a, P - 2); }
+static const u64 POWER_OF_TWO_GENERATOR = 1753635133440165772ULL;
+static inline u64 root_of_unity(int log_n) {
+  u64 g = POWER_OF_TWO_GENERATOR;
+  for (int i = log_n; i < 32; ++i) g = mul(g, g);
+  return g;
+}
+static inline size_t reverse_bits(size_t x, int bits) {
+  size_t r = 0;
+  for (int i = 0; i < bits; ++i) {
+    r = (r << 1) | (x & 1);
+    x >>= 1;
+  }
+  return r;
+}
+
+struct Ext {
+  u64 a, b;
+};
+static inline Ext emul(Ext x, Ext y) {
+  return Ext{add(mul(x.a, y.a), mul(7, mul(x.b, y.b))), add(mul(x.a, y.b), mul(x.b, y.a))};
+}
+static inline Ext eadd(Ext x, Ext y) { return Ext{add(x.a, y.a), add(x.b, y.b)}; }
+static inline Ext esub(Ext x, Ext y) { return Ext{sub(x.a, y.a), sub(x.b, y.b)}; }
+static inline Ext einv(Ext x) {
+  u64 d = sub(mul(x.a, x.a), mul(7, mul(x.b, x.b)));
+  u64 di = inv(d);
+  return Ext{mul(x.a, di), mul(neg(x.b), di)};
+}
+static inline Ext epow(Ext b, u64 e) {
+  Ext r{1, 0};
+  while (e) {
+    if (e & 1) r = emul(r, b);
+    b = emul(b, b);
+    e >>= 1;
+  }
+  return r;
+}
+
+// Poseidon permutation (host copy, used only by the challenger and public-input hash).
+static const u64 RC[VX_POSEIDON_N_ROUND_CONSTANTS] = VX_POSEIDON_ROUND_CONSTANTS_INIT;
+static inline u64 sbox(u64 x) {
+  u64 x2 = mul(x, x), x4 = mul(x2, x2), x3 = mul(x, x2);
+  return mul(x3, x4);
+}
+static inline void poseidon(u64* s) {
+  static const u64 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+  int rc = 0;
+  for (int r = 0; r < 30; ++r) {
+    for (int i = 0; i < 12; ++i) s[i] = add(s[i], RC[rc++]);
+    if (r < 4 || r >= 26)
+      for (int i = 0; i < 12; ++i) s[i] = sbox(s[i]);
+    else
+      s[0] = sbox(s[0]);
+    u64 o[12];
+    for (int k = 0; k < 12; ++k) {
+      u128 acc = 0;
+      for (int i = 0; i < 12; ++i) acc += (u128)C[i] * s[(i + k) % 12];
+      if (k == 0) acc += (u128)8 * s[0];
+      o[k] = reduce128(acc);
+    }
+    for (int i = 0; i < 12; ++i) s[i] = o[i];
+  }
+}
+}  // namespace vxh

@@ -1,0 +1,97 @@
+// Poseidon Merkle-tree kernels for gfx950.
+// Replaces plonky2::hash::merkle_tree::MerkleTree::new (leaf hash_or_noop + two_to_one levels, cap at
+// depth cap_height) and hashing::hash_n_to_m_no_pad — plonky2 v0.2.0 plonky2/src/hash/{merkle_tree,
+// hashing}.rs, un-vendored (/root/reference/Cargo.lock:4848-4905); semantics per SURVEY.md A.2/A.4.
+//
+// Leaf hashing reads the LDE in its native COLUMN-MAJOR layout: one thread per LDE row, so the 64
+// lanes of a wavefront read 64 consecutive rows of one column (512 B coalesced) — the transpose that
+// plonky2 materialises on the CPU (fri/oracle.rs: transpose + reverse_index_bits_in_place) never exists.
+#pragma once
+#include "poseidon.hip.h"
+
+#define HASH_THREADS 256
+
+// digests[row] = hash_or_noop(row of `ncols` values), column-major source.
+__global__ __launch_bounds__(HASH_THREADS) void hash_leaves_colmajor_kernel(
+    const u64* __restrict__ cols, size_t col_stride, size_t nrows, int ncols, u64* __restrict__ digests) {
+  size_t row = (size_t)blockIdx.x * HASH_THREADS + threadIdx.x;
+  if (row >= nrows) return;
+  u64 s[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) s[i] = 0;
+  if (ncols <= 4) {
+    for (int c = 0; c < ncols; ++c) s[c] = gl_canon(cols[(size_t)c * col_stride + row]);
+  } else {
+    int c = 0;
+    for (; c + 8 <= ncols; c += 8) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s[i] = gl_canon(cols[(size_t)(c + i) * col_stride + row]);
+      poseidon_permute(s);
+    }
+    if (c < ncols) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (c + i < ncols) s[i] = gl_canon(cols[(size_t)(c + i) * col_stride + row]);
+      poseidon_permute(s);
+    }
+  }
+  u64* d = digests + row * 4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) d[i] = s[i];
+}
+
+// Row-major leaves [nrows][width] (C-ABI vx_merkle_cap and the FRI commit-phase trees, whose leaves
+// are 16 consecutive F_p^2 values = 32 contiguous u64).
+__global__ __launch_bounds__(HASH_THREADS) void hash_leaves_rowmajor_kernel(
+    const u64* __restrict__ leaves, size_t nrows, int width, u64* __restrict__ digests) {
+  size_t row = (size_t)blockIdx.x * HASH_THREADS + threadIdx.x;
+  if (row >= nrows) return;
+  const u64* src = leaves + row * (size_t)width;
+  u64 s[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) s[i] = 0;
+  if (width <= 4) {
+    for (int c = 0; c < width; ++c) s[c] = gl_canon(src[c]);
+  } else {
+    int c = 0;
+    for (; c + 8 <= width; c += 8) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s[i] = gl_canon(src[c + i]);
+      poseidon_permute(s);
+    }
+    if (c < width) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (c + i < width) s[i] = gl_canon(src[c + i]);
+      poseidon_permute(s);
+    }
+  }
+  u64* d = digests + row * 4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) d[i] = s[i];
+}
+
+// parents[i] = two_to_one(children[2i], children[2i+1])
+__global__ __launch_bounds__(HASH_THREADS) void merkle_level_kernel(const u64* __restrict__ children,
+                                                                    u64* __restrict__ parents, size_t n_parents) {
+  size_t i = (size_t)blockIdx.x * HASH_THREADS + threadIdx.x;
+  if (i >= n_parents) return;
+  const ulonglong2* c = reinterpret_cast<const ulonglong2*>(children + i * 8);
+  ulonglong2 v0 = c[0], v1 = c[1], v2 = c[2], v3 = c[3];
+  u64 s[12] = {v0.x, v0.y, v1.x, v1.y, v2.x, v2.y, v3.x, v3.y, 0, 0, 0, 0};
+  poseidon_permute(s);
+  ulonglong2* o = reinterpret_cast<ulonglong2*>(parents + i * 4);
+  o[0] = make_ulonglong2(s[0], s[1]);
+  o[1] = make_ulonglong2(s[2], s[3]);
+}
+
+__global__ void poseidon_permute_kernel(u64* __restrict__ states, size_t count) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  u64 s[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) s[k] = gl_canon(states[i * 12 + k]);
+  poseidon_permute(s);
+#pragma unroll
+  for (int k = 0; k < 12; ++k) states[i * 12 + k] = s[k];
+}

@@ -1,0 +1,279 @@
+// Runtime plumbing of libvxprover.so: error reporting, context (device + stream + root tables),
+// HIP-event profiler, NTT planner/launcher, Merkle builder.  Host code around hand-written kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <map>
+#include <string>
+#include <vector>
+#include "../../include/vxprover.h"
+#include "host_field.h"
+#include "merkle.hip.h"
+#include "ntt.hip.h"
+
+static thread_local char g_err[512] = "";
+static int vx_fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  return code;
+}
+#define HIPCHK(expr)                                                                              \
+  do {                                                                                            \
+    hipError_t _e = (expr);                                                                       \
+    if (_e != hipSuccess)                                                                         \
+      return vx_fail(_e == hipErrorOutOfMemory ? VX_E_NOMEM : VX_E_HIP, "%s failed: %s (%s:%d)",  \
+                     #expr, hipGetErrorString(_e), __FILE__, __LINE__);                           \
+  } while (0)
+#define VXCHK(expr)        \
+  do {                     \
+    int _r = (expr);       \
+    if (_r != VX_OK) return _r; \
+  } while (0)
+
+struct ProfEntry {
+  double ms = 0, alg_bytes = 0;
+  uint64_t calls = 0;
+};
+struct ProfPending {
+  std::string name;
+  hipEvent_t a, b;
+  double alg_bytes;
+};
+
+struct vx_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  u64* root_lo = nullptr;  // w_{2^24}^k
+  u64* root_hi = nullptr;  // w_{2^24}^(4096k)
+  bool prof_on = false;
+  std::vector<ProfPending> pending;
+  std::vector<hipEvent_t> event_pool;
+  std::map<std::string, ProfEntry> prof;
+  std::vector<std::string> prof_order;
+  std::map<std::string, u64*> scale_cache;  // device scale tables keyed by (log_n, bits, shifts)
+  hipDeviceProp_t props;
+
+  hipEvent_t get_event() {
+    if (!event_pool.empty()) {
+      hipEvent_t e = event_pool.back();
+      event_pool.pop_back();
+      return e;
+    }
+    hipEvent_t e;
+    hipEventCreate(&e);
+    return e;
+  }
+  void fold() {
+    for (auto& p : pending) {
+      hipEventSynchronize(p.b);
+      float ms = 0;
+      hipEventElapsedTime(&ms, p.a, p.b);
+      if (!prof.count(p.name)) prof_order.push_back(p.name);
+      ProfEntry& e = prof[p.name];
+      e.ms += ms;
+      e.calls += 1;
+      e.alg_bytes += p.alg_bytes;
+      event_pool.push_back(p.a);
+      event_pool.push_back(p.b);
+    }
+    pending.clear();
+  }
+};
+
+// RAII bracket: events on the context's own stream around one kernel family.
+struct ProfScope {
+  vx_ctx* c;
+  hipEvent_t a{}, b{};
+  const char* name;
+  double bytes;
+  ProfScope(vx_ctx* ctx, const char* n, double alg_bytes = 0) : c(ctx), name(n), bytes(alg_bytes) {
+    if (c->prof_on) {
+      a = c->get_event();
+      b = c->get_event();
+      hipEventRecord(a, c->stream);
+    }
+  }
+  ~ProfScope() {
+    if (c->prof_on) {
+      hipEventRecord(b, c->stream);
+      c->pending.push_back({name, a, b, bytes});
+    }
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// NTT planning / launching
+// ------------------------------------------------------------------------------------------------
+struct NttPass {
+  int r_log, t_log, b_lo;
+};
+static std::vector<NttPass> plan_ntt(int log_n) {
+  std::vector<NttPass> v;
+  if (log_n <= 12) {
+    v.push_back({log_n, 0, 0});
+    return v;
+  }
+  const int r_final = 11;
+  int rem = log_n - r_final;
+  int k = (rem + 9) / 10;  // strided passes of <= 10 stages
+  int b = log_n;
+  for (int i = 0; i < k; ++i) {
+    int r = (rem + (k - i) - 1) / (k - i);
+    rem -= r;
+    b -= r;
+    int t = NTT_MAX_TILE_LOG - r;
+    if (t > 4) t = 4;
+    v.push_back({r, t, b});
+  }
+  int t = NTT_MAX_TILE_LOG - r_final;
+  if (t > log_n - r_final) t = log_n - r_final;
+  v.push_back({r_final, t, 0});
+  return v;
+}
+
+template <int R>
+static hipError_t launch_ntt_pass_r(const NttPassParams& p, dim3 grid, size_t lds, hipStream_t s) {
+  static bool attr_set[16] = {};
+  int dev = 0;
+  hipGetDevice(&dev);
+  if (!attr_set[dev & 15]) {
+    hipError_t e = hipFuncSetAttribute((const void*)ntt_pass_kernel<R>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       100 * 1024);
+    if (e != hipSuccess) return e;
+    attr_set[dev & 15] = true;
+  }
+  hipLaunchKernelGGL(ntt_pass_kernel<R>, grid, dim3(NTT_THREADS), lds, s, p);
+  return hipGetLastError();
+}
+static hipError_t launch_ntt_pass(int r_log, const NttPassParams& p, dim3 grid, size_t lds, hipStream_t s) {
+  switch (r_log) {
+    case 1: return launch_ntt_pass_r<1>(p, grid, lds, s);
+    case 2: return launch_ntt_pass_r<2>(p, grid, lds, s);
+    case 3: return launch_ntt_pass_r<3>(p, grid, lds, s);
+    case 4: return launch_ntt_pass_r<4>(p, grid, lds, s);
+    case 5: return launch_ntt_pass_r<5>(p, grid, lds, s);
+    case 6: return launch_ntt_pass_r<6>(p, grid, lds, s);
+    case 7: return launch_ntt_pass_r<7>(p, grid, lds, s);
+    case 8: return launch_ntt_pass_r<8>(p, grid, lds, s);
+    case 9: return launch_ntt_pass_r<9>(p, grid, lds, s);
+    case 10: return launch_ntt_pass_r<10>(p, grid, lds, s);
+    case 11: return launch_ntt_pass_r<11>(p, grid, lds, s);
+    case 12: return launch_ntt_pass_r<12>(p, grid, lds, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+// Scale tables for x[j] *= base_mul * shift^j, split as hi[j >> bits] * lo[j & mask]; `nz` slices with
+// per-slice shift.  Layout per slice: [2^(log_n-bits) hi entries][2^bits lo entries]; hi carries `pre_mul`.
+static int build_scale_tables(vx_ctx* c, int log_n, int bits, const std::vector<u64>& shifts, u64 pre_mul,
+                              u64** dptr_out) {
+  using namespace vxh;
+  size_t nh = (size_t)1 << (log_n - bits), nl = (size_t)1 << bits;
+  std::vector<u64> host(shifts.size() * (nh + nl));
+  for (size_t z = 0; z < shifts.size(); ++z) {
+    u64* hi = &host[z * (nh + nl)];
+    u64* lo = hi + nh;
+    u64 s = shifts[z];
+    u64 acc = 1;
+    for (size_t i = 0; i < nl; ++i) {
+      lo[i] = acc;
+      acc = mul(acc, s);
+    }
+    u64 step = acc;  // s^(2^bits)
+    acc = pre_mul;
+    for (size_t i = 0; i < nh; ++i) {
+      hi[i] = acc;
+      acc = mul(acc, step);
+    }
+  }
+  u64* d = nullptr;
+  HIPCHK(hipMalloc(&d, host.size() * 8));
+  HIPCHK(hipMemcpyAsync(d, host.data(), host.size() * 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));  // host vector goes out of scope
+  *dptr_out = d;
+  return VX_OK;
+}
+
+// Post-scale kernel for coset_ifft: element at bit-reversed position pos holds c_j, j = rev(pos);
+// multiply by hi[j >> bits] * lo[j & mask].
+__global__ void scale_bitrev_kernel(u64* __restrict__ data, size_t col_stride, int log_n, const u64* __restrict__ tab,
+                                    int bits) {
+  size_t pos = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pos >> log_n) return;
+  u32 j = bitrev32((u32)pos, log_n);
+  u64* col = data + (size_t)blockIdx.y * col_stride;
+  u64 s = gl_mul(tab[j >> bits], tab[((size_t)1 << (log_n - bits)) + (j & ((1u << bits) - 1))]);
+  col[pos] = gl_mul(col[pos], s);
+}
+
+// Run a full batched transform of length 2^log_n on `ncols` columns x `nz` slices.
+//   in_bitrev : input stored in bit-reversed order (true for device-resident coefficients)
+//   pre       : optional prescale tables (device), one slice per z
+// Output is in bit-reversed order at `out` (in place after the first pass).
+static int run_ntt(vx_ctx* c, const u64* in, u64* out, size_t in_col_stride, size_t out_col_stride, size_t in_z_stride,
+                   size_t out_z_stride, int log_n, size_t ncols, int nz, bool inverse, bool in_bitrev, const u64* pre,
+                   int pre_bits, u64 post_scale, const char* label, double alg_bytes) {
+  if (log_n < 1 || log_n > ROOT_TABLE_LOG) return vx_fail(VX_E_INVALID, "run_ntt: log_n=%d out of range [1,24]", log_n);
+  if (ncols == 0) return VX_OK;
+  std::vector<NttPass> plan = plan_ntt(log_n);
+  ProfScope ps(c, label, alg_bytes);
+  for (size_t i = 0; i < plan.size(); ++i) {
+    const NttPass& ps_ = plan[i];
+    NttPassParams p;
+    bool first = i == 0, last = i + 1 == plan.size();
+    p.in = first ? in : out;
+    p.out = out;
+    p.in_col_stride = first ? in_col_stride : out_col_stride;
+    p.out_col_stride = out_col_stride;
+    p.in_z_stride = first ? in_z_stride : out_z_stride;
+    p.out_z_stride = out_z_stride;
+    p.log_n = log_n;
+    p.b_lo = ps_.b_lo;
+    p.t_log = ps_.t_log;
+    p.in_bitrev = first && in_bitrev;
+    p.inverse = inverse;
+    p.root_lo = c->root_lo;
+    p.root_hi = c->root_hi;
+    p.pre = first ? pre : nullptr;
+    p.pre_bits = pre_bits;
+    p.post_scale = last ? post_scale : 1;
+    size_t tile = (size_t)1 << (ps_.r_log + ps_.t_log);
+    size_t lds = (tile + (tile >> 5) + 1 + ((size_t)1 << (ps_.r_log - 1 > 0 ? ps_.r_log - 1 : 0))) * 8 + 16;
+    dim3 grid((unsigned)((size_t)1 << (log_n - ps_.r_log - ps_.t_log)), (unsigned)ncols, (unsigned)nz);
+    // gridDim.y is limited to 65535; column counts here are < 1000.
+    hipError_t e = launch_ntt_pass(ps_.r_log, p, grid, lds, c->stream);
+    if (e != hipSuccess) return vx_fail(VX_E_HIP, "ntt pass launch failed: %s", hipGetErrorString(e));
+  }
+  return VX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Merkle tree over precomputed leaf digests: `tree` holds level 0 (n_leaves digests) followed by each
+// parent level down to the cap (2^cap_height digests).  Returns the digest offset of the cap level.
+// ------------------------------------------------------------------------------------------------
+static size_t merkle_tree_digest_count(size_t n_leaves, int cap_height) {
+  size_t total = 0;
+  for (size_t n = n_leaves; n >= ((size_t)1 << cap_height); n >>= 1) {
+    total += n;
+    if (n == 1) break;
+  }
+  return total;
+}
+static int build_merkle_levels(vx_ctx* c, u64* tree, size_t n_leaves, int cap_height, size_t* cap_offset_digests) {
+  ProfScope ps(c, "merkle_levels");
+  size_t off = 0, n = n_leaves;
+  while (n > ((size_t)1 << cap_height)) {
+    size_t np = n >> 1;
+    hipLaunchKernelGGL(merkle_level_kernel, dim3((unsigned)((np + HASH_THREADS - 1) / HASH_THREADS)),
+                       dim3(HASH_THREADS), 0, c->stream, tree + off * 4, tree + (off + n) * 4, np);
+    off += n;
+    n = np;
+  }
+  HIPCHK(hipGetLastError());
+  *cap_offset_digests = off;
+  return VX_OK;
+}

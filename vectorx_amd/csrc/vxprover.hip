@@ -1,0 +1,350 @@
+// libvxprover.so — C ABI (include/vxprover.h) over the hand-written gfx950 kernels.
+// There is NO CPU fallback anywhere in this file: without a usable HIP device every compute entry
+// point returns VX_E_NO_DEVICE.
+#include "vx_runtime.hip.h"
+#include "batch.hip.h"
+
+extern "C" {
+
+const char* vx_last_error(void) { return g_err; }
+const char* vx_version(void) { return "vxprover 0.1 (gfx950)"; }
+
+int vx_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int vx_ctx_create(int device, vx_ctx** out) {
+  if (!out) return vx_fail(VX_E_INVALID, "vx_ctx_create: out is NULL");
+  *out = nullptr;
+  int n = vx_device_count();
+  if (n <= 0) return vx_fail(VX_E_NO_DEVICE, "no HIP device visible (libvxprover has no CPU fallback)");
+  if (device < 0 || device >= n) return vx_fail(VX_E_INVALID, "device %d out of range (have %d)", device, n);
+  HIPCHK(hipSetDevice(device));
+  vx_ctx* c = new vx_ctx();
+  c->device = device;
+  HIPCHK(hipGetDeviceProperties(&c->props, device));
+  HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  // root tables for w = primitive 2^24-th root of unity
+  {
+    using namespace vxh;
+    std::vector<u64> lo(4096), hi(4096);
+    u64 w = root_of_unity(ROOT_TABLE_LOG);
+    u64 acc = 1;
+    for (int i = 0; i < 4096; ++i) {
+      lo[i] = acc;
+      acc = mul(acc, w);
+    }
+    u64 w12 = acc;  // w^4096
+    acc = 1;
+    for (int i = 0; i < 4096; ++i) {
+      hi[i] = acc;
+      acc = mul(acc, w12);
+    }
+    HIPCHK(hipMalloc(&c->root_lo, 4096 * 8));
+    HIPCHK(hipMalloc(&c->root_hi, 4096 * 8));
+    HIPCHK(hipMemcpy(c->root_lo, lo.data(), 4096 * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->root_hi, hi.data(), 4096 * 8, hipMemcpyHostToDevice));
+  }
+  *out = c;
+  return VX_OK;
+}
+
+void vx_ctx_destroy(vx_ctx* c) {
+  if (!c) return;
+  hipSetDevice(c->device);
+  hipStreamSynchronize(c->stream);
+  c->fold();
+  for (auto e : c->event_pool) hipEventDestroy(e);
+  for (auto& kv : c->scale_cache) hipFree(kv.second);
+  hipFree(c->root_lo);
+  hipFree(c->root_hi);
+  hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int vx_ctx_sync(vx_ctx* c) {
+  if (!c) return vx_fail(VX_E_INVALID, "ctx is NULL");
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return VX_OK;
+}
+void* vx_ctx_stream(vx_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int vx_prof_enable(vx_ctx* c, int enable) {
+  if (!c) return vx_fail(VX_E_INVALID, "ctx is NULL");
+  c->prof_on = enable != 0;
+  return VX_OK;
+}
+int vx_prof_reset(vx_ctx* c) {
+  if (!c) return vx_fail(VX_E_INVALID, "ctx is NULL");
+  HIPCHK(hipStreamSynchronize(c->stream));
+  c->fold();
+  c->prof.clear();
+  c->prof_order.clear();
+  return VX_OK;
+}
+int vx_prof_count(vx_ctx* c) {
+  if (!c) return vx_fail(VX_E_INVALID, "ctx is NULL");
+  if (hipStreamSynchronize(c->stream) != hipSuccess) return vx_fail(VX_E_HIP, "stream sync failed");
+  c->fold();
+  return (int)c->prof_order.size();
+}
+int vx_prof_get(vx_ctx* c, int index, char* name_out, size_t name_cap, double* ms_out, uint64_t* calls_out,
+                double* alg_bytes_out) {
+  if (!c) return vx_fail(VX_E_INVALID, "ctx is NULL");
+  if (index < 0 || index >= (int)c->prof_order.size()) return vx_fail(VX_E_INVALID, "prof index out of range");
+  const std::string& nm = c->prof_order[index];
+  const ProfEntry& e = c->prof[nm];
+  if (name_out && name_cap) {
+    strncpy(name_out, nm.c_str(), name_cap - 1);
+    name_out[name_cap - 1] = 0;
+  }
+  if (ms_out) *ms_out = e.ms;
+  if (calls_out) *calls_out = e.calls;
+  if (alg_bytes_out) *alg_bytes_out = e.alg_bytes;
+  return VX_OK;
+}
+
+int vx_dev_alloc(vx_ctx* c, size_t bytes, void** dptr) {
+  if (!c || !dptr) return vx_fail(VX_E_INVALID, "vx_dev_alloc: NULL argument");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipMalloc(dptr, bytes ? bytes : 8));
+  return VX_OK;
+}
+int vx_dev_free(vx_ctx* c, void* dptr) {
+  if (!c) return vx_fail(VX_E_INVALID, "ctx is NULL");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipFree(dptr));
+  return VX_OK;
+}
+int vx_dev_upload(vx_ctx* c, void* dptr, const void* host, size_t bytes) {
+  if (!c || !dptr || !host) return vx_fail(VX_E_INVALID, "vx_dev_upload: NULL argument");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipMemcpyAsync(dptr, host, bytes, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return VX_OK;
+}
+int vx_dev_download(vx_ctx* c, void* host, const void* dptr, size_t bytes) {
+  if (!c || !dptr || !host) return vx_fail(VX_E_INVALID, "vx_dev_download: NULL argument");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipMemcpyAsync(host, dptr, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return VX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// L1
+// ---------------------------------------------------------------------------------------------
+int vx_ntt_batch_dev(vx_ctx* c, const uint64_t* src, uint64_t* dst, int log_n, size_t ncols, int kind, uint64_t shift) {
+  if (!c || !src || !dst) return vx_fail(VX_E_INVALID, "vx_ntt_batch_dev: NULL argument");
+  if (kind < 0 || kind > 3) return vx_fail(VX_E_INVALID, "vx_ntt_batch_dev: kind %d", kind);
+  HIPCHK(hipSetDevice(c->device));
+  return ntt_natural_to_bitrev(c, src, dst, log_n, ncols, kind, shift);
+}
+
+int vx_ntt_batch(vx_ctx* c, uint64_t* data, int log_n, size_t ncols, int kind, uint64_t shift) {
+  if (!c) return vx_fail(VX_E_INVALID, "vx_ntt_batch: ctx is NULL");
+  if (kind < 0 || kind > 3) return vx_fail(VX_E_INVALID, "vx_ntt_batch: kind %d", kind);
+  if (log_n < 0 || log_n > ROOT_TABLE_LOG) return vx_fail(VX_E_INVALID, "vx_ntt_batch: log_n %d", log_n);
+  if (ncols == 0) return VX_OK;
+  if (!data) return vx_fail(VX_E_INVALID, "vx_ntt_batch: data is NULL");
+  if ((kind == VX_NTT_COSET_FFT || kind == VX_NTT_COSET_IFFT) && vxh::canon(shift) == 0)
+    return vx_fail(VX_E_INVALID, "vx_ntt_batch: coset shift must be non-zero");
+  HIPCHK(hipSetDevice(c->device));
+  size_t n = (size_t)1 << log_n, bytes = n * ncols * 8;
+  u64 *a = nullptr, *b = nullptr;
+  HIPCHK(hipMalloc(&a, bytes));
+  HIPCHK(hipMalloc(&b, bytes));
+  int rc = VX_OK;
+  do {
+    if (hipMemcpyAsync(a, data, bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) { rc = vx_fail(VX_E_HIP, "upload failed"); break; }
+    if (log_n == 0) {
+      // length-1 transform is the identity up to canonicalisation
+      hipLaunchKernelGGL(canon_kernel, dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, c->stream, a, ncols);
+      if (hipMemcpyAsync(data, a, bytes, hipMemcpyDeviceToHost, c->stream) != hipSuccess) { rc = vx_fail(VX_E_HIP, "download failed"); break; }
+      break;
+    }
+    rc = ntt_natural_to_bitrev(c, a, a, log_n, ncols, kind, shift);
+    if (rc) break;
+    hipLaunchKernelGGL(bitrev_permute_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)ncols), dim3(256), 0, c->stream,
+                       a, b, log_n, n, n);
+    if (hipMemcpyAsync(data, b, bytes, hipMemcpyDeviceToHost, c->stream) != hipSuccess) { rc = vx_fail(VX_E_HIP, "download failed"); break; }
+  } while (0);
+  hipError_t e = hipStreamSynchronize(c->stream);
+  hipFree(a);
+  hipFree(b);
+  if (rc == VX_OK && e != hipSuccess) rc = vx_fail(VX_E_HIP, "vx_ntt_batch: %s", hipGetErrorString(e));
+  return rc;
+}
+
+int vx_poseidon_permute(vx_ctx* c, uint64_t* states, size_t count) {
+  if (!c || !states) return vx_fail(VX_E_INVALID, "vx_poseidon_permute: NULL argument");
+  if (!count) return VX_OK;
+  HIPCHK(hipSetDevice(c->device));
+  u64* d = nullptr;
+  HIPCHK(hipMalloc(&d, count * 96));
+  hipError_t e = hipMemcpyAsync(d, states, count * 96, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) {
+    ProfScope ps(c, "poseidon_permute");
+    hipLaunchKernelGGL(poseidon_permute_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, c->stream, d, count);
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(states, d, count * 96, hipMemcpyDeviceToHost, c->stream);
+  hipError_t e2 = hipStreamSynchronize(c->stream);
+  hipFree(d);
+  if (e != hipSuccess || e2 != hipSuccess)
+    return vx_fail(VX_E_HIP, "vx_poseidon_permute: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+  return VX_OK;
+}
+
+int vx_merkle_cap(vx_ctx* c, const uint64_t* leaves, size_t n_leaves, size_t width, int cap_height,
+                  uint64_t* digests_out, uint64_t* cap_out) {
+  if (!c || !leaves || !cap_out) return vx_fail(VX_E_INVALID, "vx_merkle_cap: NULL argument");
+  if (n_leaves == 0 || (n_leaves & (n_leaves - 1))) return vx_fail(VX_E_INVALID, "vx_merkle_cap: n_leaves must be a power of two");
+  if (cap_height < 0 || ((size_t)1 << cap_height) > n_leaves) return vx_fail(VX_E_INVALID, "vx_merkle_cap: cap_height %d too large", cap_height);
+  if (width == 0) return vx_fail(VX_E_INVALID, "vx_merkle_cap: width 0");
+  HIPCHK(hipSetDevice(c->device));
+  u64 *dl = nullptr, *tree = nullptr;
+  size_t nd = merkle_tree_digest_count(n_leaves, cap_height);
+  HIPCHK(hipMalloc(&dl, n_leaves * width * 8));
+  if (hipMalloc(&tree, nd * 32) != hipSuccess) { hipFree(dl); return vx_fail(VX_E_NOMEM, "vx_merkle_cap: out of device memory"); }
+  int rc = VX_OK;
+  size_t cap_off = 0;
+  do {
+    if (hipMemcpyAsync(dl, leaves, n_leaves * width * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess) { rc = vx_fail(VX_E_HIP, "upload failed"); break; }
+    {
+      ProfScope ps(c, "hash_leaves_rowmajor");
+      hipLaunchKernelGGL(hash_leaves_rowmajor_kernel, dim3((unsigned)((n_leaves + HASH_THREADS - 1) / HASH_THREADS)),
+                         dim3(HASH_THREADS), 0, c->stream, dl, n_leaves, (int)width, tree);
+    }
+    rc = build_merkle_levels(c, tree, n_leaves, cap_height, &cap_off);
+    if (rc) break;
+    if (digests_out && hipMemcpyAsync(digests_out, tree, n_leaves * 32, hipMemcpyDeviceToHost, c->stream) != hipSuccess) { rc = vx_fail(VX_E_HIP, "download failed"); break; }
+    if (hipMemcpyAsync(cap_out, tree + cap_off * 4, ((size_t)32) << cap_height, hipMemcpyDeviceToHost, c->stream) != hipSuccess) { rc = vx_fail(VX_E_HIP, "download failed"); break; }
+  } while (0);
+  hipError_t e = hipStreamSynchronize(c->stream);
+  hipFree(dl);
+  hipFree(tree);
+  if (rc == VX_OK && e != hipSuccess) rc = vx_fail(VX_E_HIP, "vx_merkle_cap: %s", hipGetErrorString(e));
+  return rc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// L2
+// ---------------------------------------------------------------------------------------------
+int vx_batch_commit(vx_ctx* c, const uint64_t* cols, int src_on_device, int log_n, size_t ncols, int rate_bits,
+                    int cap_height, int is_coeffs, vx_batch** out) {
+  if (!c || !cols || !out) return vx_fail(VX_E_INVALID, "vx_batch_commit: NULL argument");
+  *out = nullptr;
+  if (log_n < 1 || log_n + rate_bits > ROOT_TABLE_LOG) return vx_fail(VX_E_INVALID, "vx_batch_commit: log_n=%d rate_bits=%d unsupported (need 1 <= log_n, log_n+rate_bits <= 24)", log_n, rate_bits);
+  if (rate_bits < 0 || rate_bits > 4) return vx_fail(VX_E_INVALID, "vx_batch_commit: rate_bits %d", rate_bits);
+  if (ncols == 0 || ncols > 4096) return vx_fail(VX_E_INVALID, "vx_batch_commit: ncols %zu", ncols);
+  if (cap_height < 0 || cap_height > log_n + rate_bits) return vx_fail(VX_E_INVALID, "vx_batch_commit: cap_height %d", cap_height);
+  HIPCHK(hipSetDevice(c->device));
+  vx_batch* b = nullptr;
+  int rc = batch_alloc(c, log_n, ncols, rate_bits, cap_height, &b);
+  if (rc) return rc;
+  size_t n = (size_t)1 << log_n;
+  const u64* src = cols;
+  u64* staging = nullptr;
+  if (!src_on_device) {
+    // stage the host matrix in the LDE buffer's tail?  Keep it simple: separate staging buffer.
+    if (hipMalloc(&staging, n * ncols * 8) != hipSuccess) { vx_batch_free(b); return vx_fail(VX_E_NOMEM, "vx_batch_commit: staging alloc failed"); }
+    if (hipMemcpyAsync(staging, cols, n * ncols * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess) { hipFree(staging); vx_batch_free(b); return vx_fail(VX_E_HIP, "vx_batch_commit: upload failed"); }
+    src = staging;
+  }
+  rc = batch_commit_device(c, b, src, n, is_coeffs != 0);
+  hipError_t e = hipStreamSynchronize(c->stream);
+  if (staging) hipFree(staging);
+  if (rc == VX_OK && e != hipSuccess) rc = vx_fail(VX_E_HIP, "vx_batch_commit: %s", hipGetErrorString(e));
+  if (rc) { vx_batch_free(b); return rc; }
+  *out = b;
+  return VX_OK;
+}
+
+void vx_batch_free(vx_batch* b) {
+  if (!b) return;
+  hipSetDevice(b->ctx->device);
+  hipStreamSynchronize(b->ctx->stream);
+  hipFree(b->coeffs);
+  hipFree(b->lde);
+  hipFree(b->tree);
+  delete b;
+}
+
+int vx_batch_cap(vx_batch* b, uint64_t* cap_out) {
+  if (!b || !cap_out) return vx_fail(VX_E_INVALID, "vx_batch_cap: NULL argument");
+  return vx_dev_download(b->ctx, cap_out, b->tree + b->cap_off * 4, ((size_t)32) << b->cap_height);
+}
+
+int vx_batch_coeffs(vx_batch* b, size_t col, uint64_t* out) {
+  if (!b || !out) return vx_fail(VX_E_INVALID, "vx_batch_coeffs: NULL argument");
+  if (col >= b->ncols) return vx_fail(VX_E_INVALID, "vx_batch_coeffs: column %zu out of range", col);
+  vx_ctx* c = b->ctx;
+  HIPCHK(hipSetDevice(c->device));
+  size_t n = (size_t)1 << b->log_n;
+  u64* tmp = nullptr;
+  HIPCHK(hipMalloc(&tmp, n * 8));
+  hipLaunchKernelGGL(bitrev_permute_kernel, dim3((unsigned)((n + 255) / 256), 1), dim3(256), 0, c->stream,
+                     b->coeffs + col * n, tmp, b->log_n, n, n);
+  int rc = vx_dev_download(c, out, tmp, n * 8);
+  hipFree(tmp);
+  return rc;
+}
+
+int vx_batch_open_row(vx_batch* b, size_t row, uint64_t* values_out, uint64_t* path_out) {
+  if (!b || !values_out || !path_out) return vx_fail(VX_E_INVALID, "vx_batch_open_row: NULL argument");
+  size_t N = (size_t)1 << (b->log_n + b->rate_bits);
+  if (row >= N) return vx_fail(VX_E_INVALID, "vx_batch_open_row: row %zu out of range", row);
+  vx_ctx* c = b->ctx;
+  HIPCHK(hipSetDevice(c->device));
+  // strided gather of one row: a 2D copy (pitch = column stride)
+  HIPCHK(hipMemcpy2DAsync(values_out, 8, b->lde + row, N * 8, 8, b->ncols, hipMemcpyDeviceToHost, c->stream));
+  size_t off = 0, n = N, idx = row;
+  int k = 0;
+  while (n > ((size_t)1 << b->cap_height)) {
+    HIPCHK(hipMemcpyAsync(path_out + 4 * k, b->tree + (off + (idx ^ 1)) * 4, 32, hipMemcpyDeviceToHost, c->stream));
+    off += n;
+    n >>= 1;
+    idx >>= 1;
+    ++k;
+  }
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return VX_OK;
+}
+
+int vx_batch_digests(vx_batch* b, uint64_t* out) {
+  if (!b || !out) return vx_fail(VX_E_INVALID, "vx_batch_digests: NULL argument");
+  size_t N = (size_t)1 << (b->log_n + b->rate_bits);
+  return vx_dev_download(b->ctx, out, b->tree, N * 32);
+}
+
+int vx_batch_lde_rows(vx_batch* b, size_t row0, size_t nrows, uint64_t* out) {
+  if (!b || !out) return vx_fail(VX_E_INVALID, "vx_batch_lde_rows: NULL argument");
+  size_t N = (size_t)1 << (b->log_n + b->rate_bits);
+  if (row0 + nrows > N) return vx_fail(VX_E_INVALID, "vx_batch_lde_rows: range out of bounds");
+  vx_ctx* c = b->ctx;
+  HIPCHK(hipSetDevice(c->device));
+  // out[r*ncols + col] = lde[col*N + row0 + r]: one 2D copy per column (dst pitch = ncols*8)
+  for (size_t col = 0; col < b->ncols; ++col)
+    HIPCHK(hipMemcpy2DAsync(out + col, b->ncols * 8, b->lde + col * N + row0, 8, 8, nrows, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return VX_OK;
+}
+
+int vx_batch_eval_ext(vx_batch* b, const uint64_t zeta[2], uint64_t* out) {
+  if (!b || !zeta || !out) return vx_fail(VX_E_INVALID, "vx_batch_eval_ext: NULL argument");
+  vx_ctx* c = b->ctx;
+  HIPCHK(hipSetDevice(c->device));
+  u64* ztab = nullptr;
+  size_t n = (size_t)1 << b->log_n;
+  HIPCHK(hipMalloc(&ztab, n * 16));
+  int rc = build_zeta_table(c, vxh::Ext{vxh::canon(zeta[0]), vxh::canon(zeta[1])}, b->log_n, ztab);
+  if (rc == VX_OK) rc = batch_eval_ext(c, b->coeffs, n, b->log_n, b->ncols, ztab, out);
+  hipStreamSynchronize(c->stream);
+  hipFree(ztab);
+  return rc;
+}
+
+}  // extern "C"
