@@ -112,6 +112,60 @@ int vx_batch_lde_rows(vx_batch* b, size_t row0, size_t nrows, uint64_t* out);
 /* PolynomialCoeffs::to_extension().eval(zeta) for every column: out [ncols][2]. */
 int vx_batch_eval_ext(vx_batch* b, const uint64_t zeta[2], uint64_t* out);
 
+/* ---- L3: circuits and whole proofs ------------------------------------------------------------
+ * vx_circuit_desc carries what plonky2's CommonCircuitData + ProverOnlyCircuitData hold for the hot
+ * path (plonk/circuit_data.rs): the configuration, the gate list with its selector grouping
+ * (gates/selectors.rs SelectorsInfo), the coset shifts k_is, the public-input targets, and the VALUES
+ * of the preprocessed polynomials [selectors.., constants.., sigmas..] on H (column-major, natural
+ * row order) from which constants_sigmas_commitment and circuit_digest are derived at load time.
+ * Gate set of this round: NoopGate, ConstantGate, PublicInputGate, ArithmeticGate (base), PoseidonGate
+ * (SURVEY.md §8 f-4 lists the remaining recursion gates as "next"). */
+#define VX_GATE_NOOP 0
+#define VX_GATE_CONSTANT 1
+#define VX_GATE_PUBLIC_INPUT 2
+#define VX_GATE_ARITHMETIC 3
+#define VX_GATE_POSEIDON 4
+
+typedef struct vx_circuit_desc {
+  int32_t degree_bits;
+  int32_t num_wires, num_routed_wires, num_challenges;  /* 135, 80, 2 */
+  int32_t rate_bits, cap_height, pow_bits, num_query_rounds; /* 3, 4, 16, 28 */
+  int32_t quotient_degree_factor;                       /* 8 */
+  int32_t num_gates;
+  const int32_t* gate_types;       /* [num_gates], sorted by (degree, id) as CircuitBuilder::build does */
+  const int32_t* gate_params;      /* ArithmeticGate: num_ops; ConstantGate: num_consts; else 0 */
+  const int32_t* selector_indices; /* selector polynomial of each gate */
+  const int32_t* group_starts;     /* SelectorsInfo.groups[selector_indices[g]] = [start, end) */
+  const int32_t* group_ends;
+  int32_t num_selectors;
+  int32_t num_constants;           /* selectors + gate constants (CommonCircuitData::num_constants) */
+  const uint64_t* constants_sigmas; /* [num_constants + num_routed_wires][2^degree_bits] values on H */
+  const uint64_t* k_is;            /* [num_routed_wires] */
+  int32_t num_public_inputs;
+  const uint32_t* pi_rows;         /* public input target = wire (pi_rows[i], pi_cols[i]) */
+  const uint32_t* pi_cols;
+} vx_circuit_desc;
+
+/* CircuitBuilder::build's prover-side tail: commit the preprocessed polynomials (kept resident in HBM
+ * for every later proof of this circuit) and derive circuit_digest. */
+int vx_circuit_create(vx_ctx* ctx, const vx_circuit_desc* desc, vx_circuit** out);
+void vx_circuit_free(vx_circuit* c);
+int vx_circuit_digest(vx_circuit* c, uint64_t digest_out[4]);
+int vx_circuit_constants_sigmas_cap(vx_circuit* c, uint64_t* cap_out /* [2^cap_height][4] */);
+
+/* plonky2::plonk::prover::prove_with_partition_witness.  `wires` is the finished witness matrix,
+ * column-major [num_wires][2^degree_bits] (Witness.wire_values), host pointer or (wires_on_device)
+ * a device pointer from vx_dev_alloc.  pow_witness_hint (optional): use this FRI proof-of-work witness
+ * instead of grinding — upstream picks it with a parallel find_any, so it is not reproducible run to
+ * run; without a hint the SMALLEST valid witness is chosen (deterministic).  The proof is written in
+ * plonky2's `ProofWithPublicInputs::to_bytes` layout (util/serialization) into
+ * out_buf; *out_len is capacity on entry and the byte length on return (VX_E_INVALID + required size
+ * in *out_len if too small). */
+int vx_prove(vx_ctx* ctx, vx_circuit* circuit, const uint64_t* wires, int wires_on_device,
+             const uint64_t* pow_witness_hint, uint8_t* out_buf, size_t* out_len);
+/* Upper bound of the proof size in bytes for this circuit. */
+size_t vx_proof_size_bound(vx_circuit* circuit);
+
 #ifdef __cplusplus
 }
 #endif

@@ -112,3 +112,114 @@ void vxo_commit(const u64* cols, int log_n, size_t ncols, int rate_bits, int cap
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// Whole-proof surface: circuit load, prove, verify (plonk.hpp)
+// ---------------------------------------------------------------------------------------------
+#include "plonk.hpp"
+
+extern "C" {
+
+// Same layout as vx_circuit_desc in include/vxprover.h (declared again here: the oracle shares no
+// code with the product).
+struct vxo_circuit_desc {
+  int32_t degree_bits, num_wires, num_routed_wires, num_challenges, rate_bits, cap_height, pow_bits, num_query_rounds,
+      quotient_degree_factor, num_gates;
+  const int32_t *gate_types, *gate_params, *selector_indices, *group_starts, *group_ends;
+  int32_t num_selectors, num_constants;
+  const uint64_t* constants_sigmas;
+  const uint64_t* k_is;
+  int32_t num_public_inputs;
+  const uint32_t *pi_rows, *pi_cols;
+};
+
+void* vxo_circuit_create(const vxo_circuit_desc* d) {
+  Circuit* c = new Circuit();
+  c->degree_bits = d->degree_bits;
+  c->num_wires = d->num_wires;
+  c->num_routed_wires = d->num_routed_wires;
+  c->num_challenges = d->num_challenges;
+  c->rate_bits = d->rate_bits;
+  c->cap_height = d->cap_height;
+  c->pow_bits = d->pow_bits;
+  c->num_query_rounds = d->num_query_rounds;
+  c->quotient_degree_factor = d->quotient_degree_factor;
+  for (int i = 0; i < d->num_gates; ++i) {
+    Gate g;
+    g.type = d->gate_types[i];
+    g.param = d->gate_params[i];
+    g.selector_index = d->selector_indices[i];
+    g.group_start = d->group_starts[i];
+    g.group_end = d->group_ends[i];
+    c->gates.push_back(g);
+  }
+  c->num_selectors = d->num_selectors;
+  c->num_constants = d->num_constants;
+  c->k_is.assign(d->k_is, d->k_is + d->num_routed_wires);
+  for (int i = 0; i < d->num_public_inputs; ++i) c->public_inputs.push_back({d->pi_rows[i], d->pi_cols[i]});
+  size_t n = (size_t)1 << d->degree_bits, m = (size_t)d->num_constants + d->num_routed_wires;
+  std::vector<std::vector<u64>> cols(m);
+  for (size_t k = 0; k < m; ++k) {
+    cols[k].assign(d->constants_sigmas + k * n, d->constants_sigmas + (k + 1) * n);
+    for (auto& x : cols[k]) x = canon(x);
+  }
+  c->finalize(std::move(cols));
+  return c;
+}
+void vxo_circuit_free(void* c) { delete (Circuit*)c; }
+void vxo_circuit_digest(void* c, u64* out4) { memcpy(out4, ((Circuit*)c)->circuit_digest.e, 32); }
+void vxo_circuit_cap(void* c, u64* out) {
+  const auto& cap = ((Circuit*)c)->constants_sigmas.tree.cap();
+  memcpy(out, cap.data(), cap.size() * 32);
+}
+
+// Returns proof byte length (> 0), or -1 with the message in err.  timings_out (optional, 8 doubles):
+// wires_commit, zs_pp, zs_pp_commit, quotient_eval, quotient_commit, openings, fri, total  (seconds).
+long long vxo_prove(void* cv, const u64* wires, const u64* pow_hint, uint8_t* out, size_t cap, double* timings_out,
+                    char* err, size_t err_cap) {
+  Circuit* c = (Circuit*)cv;
+  try {
+    size_t n = c->n();
+    std::vector<std::vector<u64>> w(c->num_wires);
+    for (int k = 0; k < c->num_wires; ++k) {
+      w[k].assign(wires + (size_t)k * n, wires + (size_t)(k + 1) * n);
+      for (auto& x : w[k]) x = canon(x);
+    }
+    ProveOptions opt;
+    if (pow_hint) opt.has_pow_hint = true, opt.pow_hint = *pow_hint;
+    ProverTimings tm;
+    Proof p = prove(*c, w, opt, &tm);
+    std::vector<uint8_t> bytes = serialize_proof(p);
+    if (timings_out) {
+      double t[8] = {tm.wires_commit, tm.zs_pp, tm.zs_pp_commit, tm.quotient_eval, tm.quotient_commit, tm.openings, tm.fri, tm.total};
+      memcpy(timings_out, t, sizeof t);
+    }
+    if (bytes.size() > cap) {
+      snprintf(err, err_cap, "output buffer too small: need %zu bytes", bytes.size());
+      return -1;
+    }
+    memcpy(out, bytes.data(), bytes.size());
+    return (long long)bytes.size();
+  } catch (const std::exception& e) {
+    snprintf(err, err_cap, "%s", e.what());
+    return -1;
+  }
+}
+
+// 0 = proof accepted; -1 = rejected / malformed with the reason in err.
+int vxo_verify(void* cv, const uint8_t* proof, size_t len, char* err, size_t err_cap) {
+  Circuit* c = (Circuit*)cv;
+  Proof p;
+  if (!deserialize_proof(*c, proof, len, p)) {
+    snprintf(err, err_cap, "malformed proof bytes");
+    return -1;
+  }
+  std::string r = verify(*c, p);
+  if (!r.empty()) {
+    snprintf(err, err_cap, "%s", r.c_str());
+    return -1;
+  }
+  return 0;
+}
+
+}  // extern "C"

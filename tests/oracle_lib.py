@@ -124,6 +124,70 @@ class Oracle:
         return {"coeffs": coeffs, "leaves": leaves, "digests": dig, "cap": cap}
 
 
+class OracleCircuit:
+    """Circuit loaded into the oracle: prove (CPU restatement) and verify (restated plonky2 verifier)."""
+
+    def __init__(self, oracle: "Oracle", desc_ptr):
+        L = oracle.L
+        L.vxo_circuit_create.restype = _vp
+        L.vxo_circuit_create.argtypes = [_vp]
+        L.vxo_circuit_free.argtypes = [_vp]
+        L.vxo_circuit_digest.argtypes = [_vp, _vp]
+        L.vxo_circuit_cap.argtypes = [_vp, _vp]
+        L.vxo_prove.restype = ctypes.c_longlong
+        L.vxo_prove.argtypes = [_vp, _vp, _vp, _vp, _sz, _vp, ctypes.c_char_p, _sz]
+        L.vxo_verify.restype = _i
+        L.vxo_verify.argtypes = [_vp, _vp, _sz, ctypes.c_char_p, _sz]
+        self.L = L
+        self.desc = ctypes.cast(desc_ptr, ctypes.POINTER(ctypes.c_int32))
+        self.cap_height = int(self.desc[5])
+        self._h = L.vxo_circuit_create(ctypes.cast(desc_ptr, _vp))
+
+    def free(self):
+        if self._h:
+            self.L.vxo_circuit_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    def digest(self):
+        o = np.empty(4, np.uint64)
+        self.L.vxo_circuit_digest(self._h, o.ctypes.data)
+        return o
+
+    def cap(self):
+        o = np.empty((1 << self.cap_height, 4), np.uint64)
+        self.L.vxo_circuit_cap(self._h, o.ctypes.data)
+        return o
+
+    def prove(self, wires, pow_hint=None, want_timings=False):
+        w = np.ascontiguousarray(wires, np.uint64)
+        buf = np.empty(1 << 22, np.uint8)
+        err = ctypes.create_string_buffer(512)
+        hint = np.array([pow_hint], np.uint64) if pow_hint is not None else None
+        tm = np.zeros(8, np.float64)
+        r = self.L.vxo_prove(self._h, w.ctypes.data, hint.ctypes.data if hint is not None else None, buf.ctypes.data,
+                             buf.size, tm.ctypes.data, err, 512)
+        if r < 0:
+            raise RuntimeError("oracle prove failed: " + err.value.decode())
+        proof = bytes(buf[:r])
+        if want_timings:
+            names = ["wires_commit", "zs_pp", "zs_pp_commit", "quotient_eval", "quotient_commit", "openings", "fri", "total"]
+            return proof, dict(zip(names, tm.tolist()))
+        return proof
+
+    def verify(self, proof: bytes):
+        """returns '' when the proof is accepted, else the rejection reason"""
+        b = np.frombuffer(proof, np.uint8)
+        err = ctypes.create_string_buffer(512)
+        r = self.L.vxo_verify(self._h, b.ctypes.data, b.size, err, 512)
+        return "" if r == 0 else err.value.decode()
+
+
 _cached = None
 
 

@@ -83,11 +83,12 @@ static int batch_alloc(vx_ctx* c, int log_n, size_t ncols, int rate_bits, int ca
   b->ncols = ncols;
   size_t n = (size_t)1 << log_n, N = n << rate_bits;
   size_t nd = merkle_tree_digest_count(N, cap_height);
-  if (hipMalloc(&b->coeffs, n * ncols * 8) != hipSuccess || hipMalloc(&b->lde, N * ncols * 8) != hipSuccess ||
-      hipMalloc(&b->tree, nd * 32) != hipSuccess) {
-    hipFree(b->coeffs);
-    hipFree(b->lde);
-    hipFree(b->tree);
+  if (c->pool_alloc((void**)&b->coeffs, n * ncols * 8) != hipSuccess ||
+      c->pool_alloc((void**)&b->lde, N * ncols * 8) != hipSuccess ||
+      c->pool_alloc((void**)&b->tree, nd * 32) != hipSuccess) {
+    c->pool_free(b->coeffs);
+    c->pool_free(b->lde);
+    c->pool_free(b->tree);
     delete b;
     return vx_fail(VX_E_NOMEM, "batch_alloc: out of device memory (n=2^%d, %zu cols, blow-up 2^%d)", log_n, ncols, rate_bits);
   }

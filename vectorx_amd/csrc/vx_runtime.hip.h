@@ -56,6 +56,49 @@ struct vx_ctx {
   std::vector<std::string> prof_order;
   std::map<std::string, u64*> scale_cache;  // device scale tables keyed by (log_n, bits, shifts)
   hipDeviceProp_t props;
+  // Size-bucketed caching allocator: a prover re-uses the same multi-GB shapes proof after proof, and
+  // hipMalloc/hipFree of 20 GB costs hundreds of ms.  Blocks are recycled by exact size; everything
+  // runs on the context's single stream, so reuse is stream-ordered and safe without extra syncs.
+  std::multimap<size_t, void*> free_blocks;
+  std::map<void*, size_t> live_blocks;
+  size_t pooled_bytes = 0;
+  hipError_t pool_alloc(void** out, size_t bytes) {
+    if (bytes == 0) bytes = 8;
+    bytes = (bytes + 255) & ~(size_t)255;
+    auto it = free_blocks.find(bytes);
+    if (it != free_blocks.end()) {
+      *out = it->second;
+      free_blocks.erase(it);
+      pooled_bytes -= bytes;
+      live_blocks[*out] = bytes;
+      return hipSuccess;
+    }
+    hipError_t e = hipMalloc(out, bytes);
+    if (e != hipSuccess && !free_blocks.empty()) {
+      (void)hipGetLastError();
+      pool_trim();
+      e = hipMalloc(out, bytes);
+    }
+    if (e == hipSuccess) live_blocks[*out] = bytes;
+    return e;
+  }
+  void pool_free(void* p) {
+    if (!p) return;
+    auto it = live_blocks.find(p);
+    if (it == live_blocks.end()) {
+      hipFree(p);
+      return;
+    }
+    free_blocks.insert({it->second, p});
+    pooled_bytes += it->second;
+    live_blocks.erase(it);
+  }
+  void pool_trim() {
+    hipStreamSynchronize(stream);
+    for (auto& kv : free_blocks) hipFree(kv.second);
+    free_blocks.clear();
+    pooled_bytes = 0;
+  }
 
   hipEvent_t get_event() {
     if (!event_pool.empty()) {

@@ -58,6 +58,8 @@ void vx_ctx_destroy(vx_ctx* c) {
   c->fold();
   for (auto e : c->event_pool) hipEventDestroy(e);
   for (auto& kv : c->scale_cache) hipFree(kv.second);
+  c->pool_trim();
+  for (auto& kv : c->live_blocks) hipFree(kv.first);
   hipFree(c->root_lo);
   hipFree(c->root_hi);
   hipStreamDestroy(c->stream);
@@ -266,10 +268,9 @@ int vx_batch_commit(vx_ctx* c, const uint64_t* cols, int src_on_device, int log_
 void vx_batch_free(vx_batch* b) {
   if (!b) return;
   hipSetDevice(b->ctx->device);
-  hipStreamSynchronize(b->ctx->stream);
-  hipFree(b->coeffs);
-  hipFree(b->lde);
-  hipFree(b->tree);
+  b->ctx->pool_free(b->coeffs);
+  b->ctx->pool_free(b->lde);
+  b->ctx->pool_free(b->tree);
   delete b;
 }
 

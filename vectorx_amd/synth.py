@@ -1,0 +1,104 @@
+"""Loader for libvxsynth.so — the synthetic circuit + witness generator (caller-side stand-in for
+plonky2x's CircuitBuilder::build and witness generation; see synth/synth_circuit.cpp for the declared
+gate mix).  Plain host code, no GPU, no oracle."""
+from __future__ import annotations
+
+import ctypes
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+_PKG = Path(__file__).resolve().parent
+_SO = _PKG / "libvxsynth.so"
+
+
+class CircuitDesc(ctypes.Structure):
+    """ctypes mirror of `vx_circuit_desc` (include/vxprover.h)."""
+    _fields_ = [
+        ("degree_bits", ctypes.c_int32), ("num_wires", ctypes.c_int32), ("num_routed_wires", ctypes.c_int32),
+        ("num_challenges", ctypes.c_int32), ("rate_bits", ctypes.c_int32), ("cap_height", ctypes.c_int32),
+        ("pow_bits", ctypes.c_int32), ("num_query_rounds", ctypes.c_int32),
+        ("quotient_degree_factor", ctypes.c_int32), ("num_gates", ctypes.c_int32),
+        ("gate_types", ctypes.c_void_p), ("gate_params", ctypes.c_void_p), ("selector_indices", ctypes.c_void_p),
+        ("group_starts", ctypes.c_void_p), ("group_ends", ctypes.c_void_p),
+        ("num_selectors", ctypes.c_int32), ("num_constants", ctypes.c_int32),
+        ("constants_sigmas", ctypes.c_void_p), ("k_is", ctypes.c_void_p),
+        ("num_public_inputs", ctypes.c_int32), ("pi_rows", ctypes.c_void_p), ("pi_cols", ctypes.c_void_p),
+    ]
+
+
+def build() -> Path:
+    r = subprocess.run(["make", "-C", str(_PKG / "synth")], capture_output=True, text=True)
+    if r.returncode and not _SO.exists():
+        raise RuntimeError("building libvxsynth.so failed:\n" + r.stdout + r.stderr)
+    return _SO
+
+
+_lib = None
+
+
+def _load():
+    global _lib
+    if _lib is None:
+        if not _SO.exists():
+            build()
+        L = ctypes.CDLL(str(_SO))
+        L.vxs_build.restype = ctypes.c_void_p
+        L.vxs_build.argtypes = [ctypes.c_int, ctypes.c_uint64, ctypes.c_int]
+        L.vxs_free.argtypes = [ctypes.c_void_p]
+        L.vxs_desc.restype = ctypes.POINTER(CircuitDesc)
+        L.vxs_desc.argtypes = [ctypes.c_void_p]
+        L.vxs_witness.restype = ctypes.c_void_p
+        L.vxs_witness.argtypes = [ctypes.c_void_p]
+        L.vxs_public_inputs.restype = ctypes.c_void_p
+        L.vxs_public_inputs.argtypes = [ctypes.c_void_p]
+        L.vxs_row_counts.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        L.vxs_release_host_buffers.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+        _lib = L
+    return _lib
+
+
+class SynthCircuit:
+    """A synthetic standard_recursion_config circuit with a satisfying witness."""
+
+    def __init__(self, degree_bits: int, seed: int = 0, poseidon_percent: int = 50):
+        L = _load()
+        self._h = L.vxs_build(degree_bits, seed, poseidon_percent)
+        if not self._h:
+            raise ValueError("vxs_build rejected the parameters")
+        self.degree_bits = degree_bits
+        self.n = 1 << degree_bits
+        self.desc_ptr = L.vxs_desc(self._h)
+        self.desc = self.desc_ptr.contents
+        self.num_wires = self.desc.num_wires
+        self.seed, self.poseidon_percent = seed, poseidon_percent
+
+    def witness(self) -> np.ndarray:
+        """[num_wires][n] column-major view of the generator's buffer (copy before freeing)."""
+        p = _load().vxs_witness(self._h)
+        buf = (ctypes.c_uint64 * (self.num_wires * self.n)).from_address(p)
+        return np.frombuffer(buf, dtype=np.uint64).reshape(self.num_wires, self.n)
+
+    def public_inputs(self) -> np.ndarray:
+        p = _load().vxs_public_inputs(self._h)
+        return np.frombuffer((ctypes.c_uint64 * 4).from_address(p), dtype=np.uint64).copy()
+
+    def row_counts(self) -> dict:
+        out = np.zeros(3, np.uint64)
+        _load().vxs_row_counts(self._h, out.ctypes.data)
+        return {"poseidon": int(out[0]), "arithmetic": int(out[1]), "noop": int(out[2]), "other": 2}
+
+    def release_host_buffers(self, witness=True, preprocessed=True):
+        _load().vxs_release_host_buffers(self._h, int(witness), int(preprocessed))
+
+    def free(self):
+        if self._h:
+            _load().vxs_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
