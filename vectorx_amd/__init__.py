@@ -81,6 +81,12 @@ _SIGNATURES = {
     "vx_batch_digests": (_i, [_vp, _vp]),
     "vx_batch_lde_rows": (_i, [_vp, _sz, _sz, _vp]),
     "vx_batch_eval_ext": (_i, [_vp, _vp, _vp]),
+    "vx_circuit_create": (_i, [_vp, _vp, ctypes.POINTER(_vp)]),
+    "vx_circuit_free": (None, [_vp]),
+    "vx_circuit_digest": (_i, [_vp, _vp]),
+    "vx_circuit_constants_sigmas_cap": (_i, [_vp, _vp]),
+    "vx_prove": (_i, [_vp, _vp, _vp, _i, _vp, _vp, ctypes.POINTER(_sz)]),
+    "vx_proof_size_bound": (_sz, [_vp]),
 }
 
 
@@ -290,3 +296,57 @@ class PolynomialBatch:
         out = np.empty((self.ncols, 2), dtype=np.uint64)
         _chk(lib().vx_batch_eval_ext(self._h, z.ctypes.data, out.ctypes.data))
         return out
+
+
+class Circuit:
+    """Device-resident prover key — `vx_circuit` (plonky2 `CircuitData`: common + prover-only parts).
+
+    `desc_ptr` is a pointer to a `vx_circuit_desc` (e.g. `vectorx_amd.synth.SynthCircuit.desc_ptr`).
+    `prove` mirrors `circuit.prove(&input)` of the reference (/root/reference/circuits/header_range.rs:167)
+    at the level of plonky2's `prove_with_partition_witness`: finished witness in, proof bytes out.
+    """
+
+    def __init__(self, ctx: Context, desc_ptr):
+        self.ctx = ctx
+        self._h = _vp()
+        _chk(lib().vx_circuit_create(ctx._h, ctypes.cast(desc_ptr, _vp), ctypes.byref(self._h)))
+        d = ctypes.cast(desc_ptr, ctypes.POINTER(ctypes.c_int32))
+        self.degree_bits, self.num_wires, self.cap_height = int(d[0]), int(d[1]), int(d[5])
+
+    def free(self):
+        if self._h:
+            lib().vx_circuit_free(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    def digest(self) -> np.ndarray:
+        out = np.empty(4, dtype=np.uint64)
+        _chk(lib().vx_circuit_digest(self._h, out.ctypes.data))
+        return out
+
+    def constants_sigmas_cap(self) -> np.ndarray:
+        out = np.empty((1 << self.cap_height, 4), dtype=np.uint64)
+        _chk(lib().vx_circuit_constants_sigmas_cap(self._h, out.ctypes.data))
+        return out
+
+    def prove(self, wires=None, pow_witness=None, dev_ptr=None) -> bytes:
+        """wires: [num_wires][n] column-major host matrix, or dev_ptr: device pointer to the same."""
+        cap = lib().vx_proof_size_bound(self._h)
+        buf = np.empty(cap, dtype=np.uint8)
+        ln = _sz(cap)
+        hint = np.array([pow_witness], dtype=np.uint64) if pow_witness is not None else None
+        if dev_ptr is None:
+            w = _as_u64(wires)
+            if w.shape != (self.num_wires, 1 << self.degree_bits):
+                raise VxError(VX_E_INVALID, f"witness matrix has shape {w.shape}")
+            src, on_dev = w.ctypes.data, 0
+        else:
+            src, on_dev = dev_ptr, 1
+        _chk(lib().vx_prove(self.ctx._h, self._h, src, on_dev, hint.ctypes.data if hint is not None else None,
+                            buf.ctypes.data, ctypes.byref(ln)))
+        return bytes(buf[:ln.value])

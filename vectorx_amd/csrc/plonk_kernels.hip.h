@@ -1,0 +1,507 @@
+// PLONK-side kernels of the gfx950 prover: permutation argument (Z + partial products), quotient
+// (vanishing-polynomial) evaluation over the LDE, quotient chunking, batch reduction for the opening
+// proof, FRI folding, proof-of-work grinding, query gathers.
+// Replaces, from plonky2 v0.2.0 (un-vendored, /root/reference/Cargo.lock:4848-4905):
+//   plonk/prover.rs   wires_permutation_partial_products_round, compute_quotient_polys
+//   plonk/vanishing_poly.rs eval_vanishing_poly_base_batch, evaluate_gate_constraints_base_batch
+//   gates/{noop,constant,public_input,arithmetic_base,poseidon}.rs eval_unfiltered_base_batch
+//   fri/oracle.rs     prove_openings (reduce_polys_base, divide_by_linear)
+//   fri/prover.rs     fri_committed_trees, fri_proof_of_work, fri_prover_query_rounds
+// Every kernel is one-thread-per-row over COLUMN-MAJOR data, so the 64 lanes of a wavefront read 64
+// consecutive rows of one column (512 B coalesced) for every column they touch.
+#pragma once
+#include "ntt.hip.h"
+#include "poseidon.hip.h"
+
+#define VX_MAX_GATES 8
+#define VX_MAX_CHALLENGES 2
+#define VX_MAX_RATE 16
+
+struct GateDev {
+  int type, param, selector_index, group_start, group_end;
+};
+
+// ------------------------------------------------------------------------------------------------
+// Permutation argument, step 1: per-row chunk quotients  prod(num)/prod(den) over chunks of `deg` wires.
+// cp[(ch*nchunks + k)*n + i].  (prover.rs: quotient_chunk_products)
+// ------------------------------------------------------------------------------------------------
+struct PermParams {
+  const u64* wires;   // [>=nr][n] natural row order
+  const u64* sigmas;  // [nr][n] sigma values on H
+  const u64* k_is;    // [nr]
+  const u64 *root_lo, *root_hi;
+  size_t n;
+  int log_n, nr, deg, nchunks, nch;
+  u64 betas[VX_MAX_CHALLENGES], gammas[VX_MAX_CHALLENGES];
+  u64* cp;
+};
+
+#define PERM_MAX_CHUNKS 16
+__global__ __launch_bounds__(256) void perm_chunk_products_kernel(PermParams p) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= p.n) return;
+  const int ch = blockIdx.y;
+  const u64 beta = p.betas[ch], gamma = p.gammas[ch];
+  const u64 x = root_pow24(p.root_lo, p.root_hi, (u32)(i << (ROOT_TABLE_LOG - p.log_n)));
+  const u64 bx = gl_mul(beta, x);
+  u64 np[PERM_MAX_CHUNKS], dp[PERM_MAX_CHUNKS];
+  for (int k = 0; k < p.nchunks; ++k) {
+    u64 a = 1, b = 1;
+    int j1 = min(p.nr, (k + 1) * p.deg);
+    for (int j = k * p.deg; j < j1; ++j) {
+      u64 w = gl_canon(p.wires[(size_t)j * p.n + i]);
+      u64 wg = gl_add(w, gamma);
+      u64 num = gl_mad(p.k_is[j], bx, wg);
+      u64 den = gl_mad(beta, p.sigmas[(size_t)j * p.n + i], wg);
+      a = gl_mul(a, num);
+      b = gl_mul(b, den);
+    }
+    np[k] = a;
+    dp[k] = b;
+  }
+  // Montgomery batch inversion of dp[0..nchunks)
+  u64 pre[PERM_MAX_CHUNKS];
+  u64 acc = 1;
+  for (int k = 0; k < p.nchunks; ++k) {
+    pre[k] = acc;
+    acc = gl_mul(acc, dp[k]);
+  }
+  u64 ia = gl_inv(acc);
+  for (int k = p.nchunks - 1; k >= 0; --k) {
+    u64 inv_k = gl_mul(ia, pre[k]);
+    ia = gl_mul(ia, dp[k]);
+    p.cp[((size_t)ch * p.nchunks + k) * p.n + i] = gl_mul(np[k], inv_k);
+  }
+}
+
+// step 2: product of each 256-row block  (the prefix product over rows is the one serial loop of the
+// CPU prover; here it is a 3-phase multiplicative scan)
+__device__ __forceinline__ u64 block_prod_256(u64 v, u64* sh) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = gl_mul(v, __shfl_down(v, off, 64));
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) sh[wave] = v;
+  __syncthreads();
+  return gl_mul(gl_mul(sh[0], sh[1]), gl_mul(sh[2], sh[3]));
+}
+__global__ __launch_bounds__(256) void perm_block_products_kernel(const u64* __restrict__ cp, size_t n, int nchunks,
+                                                                  u64* __restrict__ block_prod) {
+  __shared__ u64 sh[4];
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int ch = blockIdx.y;
+  u64 v = 1;
+  if (i < n)
+    for (int k = 0; k < nchunks; ++k) v = gl_mul(v, cp[((size_t)ch * nchunks + k) * n + i]);
+  u64 t = block_prod_256(v, sh);
+  if (threadIdx.x == 0) block_prod[(size_t)ch * gridDim.x + blockIdx.x] = t;
+}
+// step 3: exclusive scan of the block products (one wavefront per challenge; sequential over chunks of 64)
+__global__ void perm_scan_blocks_kernel(u64* __restrict__ block_prod, size_t nblocks) {
+  const int ch = blockIdx.x;
+  u64* bp = block_prod + (size_t)ch * nblocks;
+  const int lane = threadIdx.x;  // 64 threads
+  u64 carry = 1;
+  for (size_t base = 0; base < nblocks; base += 64) {
+    u64 v = base + lane < nblocks ? bp[base + lane] : 1;
+    u64 incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      u64 o = __shfl_up(incl, off, 64);
+      if (lane >= off) incl = gl_mul(incl, o);
+    }
+    u64 excl = __shfl_up(incl, 1, 64);
+    if (lane == 0) excl = 1;
+    if (base + lane < nblocks) bp[base + lane] = gl_mul(carry, excl);
+    carry = gl_mul(carry, __shfl(incl, 63, 64));
+  }
+}
+// step 4: Z and the partial products.  out columns: [Z_0.., Z_{nch-1}, pp_{0,0..npp-1}, pp_{1,..}]
+__global__ __launch_bounds__(256) void perm_write_kernel(const u64* __restrict__ cp, size_t n, int nchunks, int nch,
+                                                         const u64* __restrict__ block_carry, u64* __restrict__ out) {
+  __shared__ u64 sc[256];
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int ch = blockIdx.y;
+  const int npp = nchunks - 1;
+  u64 v = 1;
+  if (i < n)
+    for (int k = 0; k < nchunks; ++k) v = gl_mul(v, cp[((size_t)ch * nchunks + k) * n + i]);
+  // inclusive scan of v over the block (Hillis-Steele in LDS)
+  sc[threadIdx.x] = v;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {
+    u64 t = threadIdx.x >= off ? sc[threadIdx.x - off] : 1;
+    __syncthreads();
+    sc[threadIdx.x] = gl_mul(sc[threadIdx.x], t);
+    __syncthreads();
+  }
+  u64 excl = threadIdx.x ? sc[threadIdx.x - 1] : 1;
+  if (i >= n) return;
+  u64 z = gl_mul(block_carry[(size_t)ch * gridDim.x + blockIdx.x], excl);
+  out[(size_t)ch * n + i] = z;
+  u64 acc = z;
+  for (int k = 0; k < npp; ++k) {
+    acc = gl_mul(acc, cp[((size_t)ch * nchunks + k) * n + i]);
+    out[((size_t)nch + (size_t)ch * npp + k) * n + i] = acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Quotient evaluation: one thread per LDE row (bit-reversed row order, like every LDE buffer).
+// ------------------------------------------------------------------------------------------------
+struct QuotientParams {
+  const u64 *cs, *wires, *zs;  // LDE buffers, column stride N
+  const u64* k_is;
+  const u64 *root_lo, *root_hi;
+  size_t N;
+  int log_n, rate_bits;
+  int num_selectors, num_constants, nr, num_wires, nch, npp, deg;
+  int num_gates;
+  GateDev gates[VX_MAX_GATES];
+  u64 betas[VX_MAX_CHALLENGES], gammas[VX_MAX_CHALLENGES], alphas[VX_MAX_CHALLENGES];
+  u64 pih[4];
+  u64 zh[VX_MAX_RATE], zh_inv[VX_MAX_RATE];  // ZeroPolyOnCoset evals / inverses, indexed by coset r
+  u64 n_field;                               // n mod p
+  u64* out;                                  // [nch][N]
+};
+
+struct AlphaAcc {
+  u64 acc[VX_MAX_CHALLENGES], pw[VX_MAX_CHALLENGES];
+};
+GLD void acc_push(AlphaAcc& a, const QuotientParams& p, u64 term) {
+#pragma unroll
+  for (int c = 0; c < VX_MAX_CHALLENGES; ++c) {
+    a.acc[c] = gl_mad(term, a.pw[c], a.acc[c]);
+    a.pw[c] = gl_mul(a.pw[c], p.alphas[c]);
+  }
+}
+
+#define UNUSED_SELECTOR_U64 0xFFFFFFFFULL
+
+__global__ __launch_bounds__(256) void quotient_kernel(QuotientParams p) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= p.N) return;
+  const size_t N = p.N;
+  const int log_n = p.log_n, rb = p.rate_bits;
+  const u32 nmask = (1u << log_n) - 1;
+  const u32 z = (u32)(i >> log_n);
+  const u32 r = bitrev32(z, rb);
+  const u32 k = bitrev32((u32)i & nmask, log_n);
+  const u32 j = (k << rb) | r;  // natural LDE index
+  const size_t i_next = ((size_t)z << log_n) | bitrev32((k + 1) & nmask, log_n);
+  const u64 x = gl_mul7(root_pow24(p.root_lo, p.root_hi, j << (ROOT_TABLE_LOG - log_n - rb)));
+#define CS(c) (p.cs[(size_t)(c) * N + i])
+#define WIRE(c) (p.wires[(size_t)(c) * N + i])
+#define ZS(c) (p.zs[(size_t)(c) * N + i])
+
+  AlphaAcc A;
+#pragma unroll
+  for (int c = 0; c < VX_MAX_CHALLENGES; ++c) A.acc[c] = 0, A.pw[c] = 1;
+
+  // (1) L_0(x) (Z(x) - 1) per challenge;  eval_l_0 = Z_H(x) / (n (x - 1))
+  const u64 l0 = gl_mul(p.zh[r], gl_inv(gl_mul(p.n_field, gl_sub(x, 1))));
+  for (int ch = 0; ch < p.nch; ++ch) acc_push(A, p, gl_mul(l0, gl_sub(ZS(ch), 1)));
+  // (2) partial-product checks per challenge
+  for (int ch = 0; ch < p.nch; ++ch) {
+    const u64 beta = p.betas[ch], gamma = p.gammas[ch];
+    const u64 bx = gl_mul(beta, x);
+    u64 prev = ZS(ch);
+    const int nchunks = p.npp + 1;
+    for (int kk = 0; kk < nchunks; ++kk) {
+      u64 np = 1, dp = 1;
+      const int j1 = min(p.nr, (kk + 1) * p.deg);
+      for (int jj = kk * p.deg; jj < j1; ++jj) {
+        u64 wg = gl_add(WIRE(jj), gamma);
+        np = gl_mul(np, gl_mad(p.k_is[jj], bx, wg));
+        dp = gl_mul(dp, gl_mad(beta, CS(p.num_constants + jj), wg));
+      }
+      u64 next = kk < p.npp ? ZS(p.nch + ch * p.npp + kk) : p.zs[(size_t)ch * N + i_next];
+      acc_push(A, p, gl_sub(gl_mul(prev, np), gl_mul(next, dp)));
+      prev = next;
+    }
+  }
+  // (3) gate constraints: sum_g filter_g * sum_i c_{g,i} alpha^(i + offset)
+  const u64 base_pw[VX_MAX_CHALLENGES] = {A.pw[0], A.pw[1]};
+  for (int g = 0; g < p.num_gates; ++g) {
+    const GateDev gd = p.gates[g];
+    if (gd.type == 0) continue;  // NoopGate: no constraints
+    const u64 s = CS(gd.selector_index);
+    u64 filter = 1;
+    for (int q = gd.group_start; q < gd.group_end; ++q)
+      if (q != g) filter = gl_mul(filter, gl_sub((u64)q, s));
+    if (p.num_selectors > 1) filter = gl_mul(filter, gl_sub(UNUSED_SELECTOR_U64, s));
+    AlphaAcc G;
+#pragma unroll
+    for (int c = 0; c < VX_MAX_CHALLENGES; ++c) G.acc[c] = 0, G.pw[c] = base_pw[c];
+    const int c0 = p.num_selectors;  // gate constants start after the selectors
+    if (gd.type == 1) {              // ConstantGate
+      for (int q = 0; q < gd.param; ++q) acc_push(G, p, gl_sub(CS(c0 + q), WIRE(q)));
+    } else if (gd.type == 2) {  // PublicInputGate
+      for (int q = 0; q < 4; ++q) acc_push(G, p, gl_sub(WIRE(q), p.pih[q]));
+    } else if (gd.type == 3) {  // ArithmeticGate
+      const u64 k0 = CS(c0), k1 = CS(c0 + 1);
+      for (int q = 0; q < gd.param; ++q) {
+        u64 m0 = WIRE(4 * q), m1 = WIRE(4 * q + 1), ad = WIRE(4 * q + 2), o = WIRE(4 * q + 3);
+        u64 rhs = gl_mad(gl_mul(m0, m1), k0, gl_mul(ad, k1));
+        acc_push(G, p, gl_sub(o, rhs));
+      }
+    } else if (gd.type == 4) {  // PoseidonGate (gates/poseidon.rs wire layout)
+      const u64 swap = WIRE(24);
+      acc_push(G, p, gl_mul(swap, gl_sub(swap, 1)));
+      u64 st[12];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        u64 lhs = WIRE(q), rhs = WIRE(q + 4), d = WIRE(25 + q);
+        acc_push(G, p, gl_sub(gl_mul(swap, gl_sub(rhs, lhs)), d));
+        st[q] = gl_add(lhs, d);
+        st[q + 4] = gl_sub(rhs, d);
+      }
+#pragma unroll
+      for (int q = 8; q < 12; ++q) st[q] = WIRE(q);
+      int round = 0;
+#pragma unroll 1
+      for (int rr = 0; rr < 4; ++rr) {
+#pragma unroll
+        for (int q = 0; q < 12; ++q) st[q] = gl_add(st[q], POSEIDON_RC[12 * round + q]);
+        if (rr != 0) {
+#pragma unroll
+          for (int q = 0; q < 12; ++q) {
+            u64 in = WIRE(29 + 12 * (rr - 1) + q);
+            acc_push(G, p, gl_sub(st[q], in));
+            st[q] = in;
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 12; ++q) st[q] = poseidon_sbox(st[q]);
+        poseidon_mds(st);
+        ++round;
+      }
+#pragma unroll 1
+      for (int rr = 0; rr < 22; ++rr) {
+#pragma unroll
+        for (int q = 0; q < 12; ++q) st[q] = gl_add(st[q], POSEIDON_RC[12 * round + q]);
+        u64 in = WIRE(65 + rr);
+        acc_push(G, p, gl_sub(st[0], in));
+        st[0] = poseidon_sbox(in);
+        poseidon_mds(st);
+        ++round;
+      }
+#pragma unroll 1
+      for (int rr = 0; rr < 4; ++rr) {
+#pragma unroll
+        for (int q = 0; q < 12; ++q) st[q] = gl_add(st[q], POSEIDON_RC[12 * round + q]);
+#pragma unroll
+        for (int q = 0; q < 12; ++q) {
+          u64 in = WIRE(87 + 12 * rr + q);
+          acc_push(G, p, gl_sub(st[q], in));
+          st[q] = in;
+        }
+#pragma unroll
+        for (int q = 0; q < 12; ++q) st[q] = poseidon_sbox(st[q]);
+        poseidon_mds(st);
+        ++round;
+      }
+#pragma unroll
+      for (int q = 0; q < 12; ++q) acc_push(G, p, gl_sub(st[q], WIRE(12 + q)));
+    }
+#pragma unroll
+    for (int c = 0; c < VX_MAX_CHALLENGES; ++c) A.acc[c] = gl_mad(filter, G.acc[c], A.acc[c]);
+  }
+  const u64 zi = p.zh_inv[r];
+  for (int ch = 0; ch < p.nch; ++ch) p.out[(size_t)ch * N + i] = gl_mul(A.acc[ch], zi);
+#undef CS
+#undef WIRE
+#undef ZS
+}
+
+// ------------------------------------------------------------------------------------------------
+// Quotient chunking.  After a per-coset inverse NTT (scaled by 1/n), u[z][pos] holds, for coset
+// r = rev(z) and coefficient j = rev_n(pos), U_r[j] * s_r^j with s_r = 7 w_N^r.  The chunk polynomials
+// t_c (t(X) = sum_c X^(cn) t_c(X)) follow from a size-2^rb inverse DFT across cosets:
+//   t_c[j] = 7^(-nc) / 2^rb * sum_r w_rate^(-rc) * s_r^(-j) * u_r[j]
+// in : u   [nch][2^rb][n]   (block z of challenge ch at (ch*2^rb + z)*n)
+// out: t   [nch*2^rb][n]    bit-reversed coefficient order (chunk c of challenge ch = column ch*2^rb+c)
+// ------------------------------------------------------------------------------------------------
+struct ChunkParams {
+  const u64* u;
+  u64* t;
+  const u64* inv_tab;  // [2^rb slices z][hi(2^(log_n-bits)) + lo(2^bits)] tables of s_{rev(z)}^(-j)
+  int log_n, rb, bits;
+  u64 w_rate_inv_pows[VX_MAX_RATE];  // w_rate^(-k)
+  u64 chunk_scale[VX_MAX_RATE];      // 7^(-nc) / 2^rb
+};
+__global__ __launch_bounds__(256) void quotient_chunks_kernel(ChunkParams p) {
+  const size_t n = (size_t)1 << p.log_n;
+  const size_t pos = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (pos >= n) return;
+  const int ch = blockIdx.y, rate = 1 << p.rb;
+  const u32 j = bitrev32((u32)pos, p.log_n);
+  const size_t slice = ((size_t)1 << (p.log_n - p.bits)) + ((size_t)1 << p.bits);
+  u64 U[VX_MAX_RATE];
+  for (int z = 0; z < rate; ++z) {
+    const u64* tab = p.inv_tab + (size_t)z * slice;
+    u64 sc = gl_mul(tab[j >> p.bits], tab[((size_t)1 << (p.log_n - p.bits)) + (j & ((1u << p.bits) - 1))]);
+    int r = (int)bitrev32((u32)z, p.rb);
+    U[r] = gl_mul(p.u[((size_t)ch * rate + z) * n + pos], sc);
+  }
+  for (int c = 0; c < rate; ++c) {
+    u64 acc = 0;
+    for (int r = 0; r < rate; ++r) acc = gl_mad(U[r], p.w_rate_inv_pows[(r * c) & (rate - 1)], acc);
+    p.t[((size_t)ch * rate + c) * n + pos] = gl_mul(acc, p.chunk_scale[c]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Opening proof: F[pos] = sum_j alpha^j f_j[pos] over a list of column groups (reduce_polys_base).
+// out: 2 columns (a then b), each n.  Column groups are (ptr, ncols) with column stride n.
+// ------------------------------------------------------------------------------------------------
+#define REDUCE_MAX_GROUPS 4
+struct ReduceParams {
+  const u64* cols[REDUCE_MAX_GROUPS];
+  int ncols[REDUCE_MAX_GROUPS];
+  int ngroups;
+  const u64* alpha_pows;  // [total][2]
+  size_t n;
+  u64* out;  // [2][n]
+};
+__global__ __launch_bounds__(256) void reduce_polys_kernel(ReduceParams p) {
+  size_t pos = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (pos >= p.n) return;
+  u64 a = 0, b = 0;
+  int jj = 0;
+  for (int g = 0; g < p.ngroups; ++g) {
+    const u64* base = p.cols[g];
+    for (int c = 0; c < p.ncols[g]; ++c, ++jj) {
+      u64 v = base[(size_t)c * p.n + pos];
+      a = gl_mad(v, p.alpha_pows[2 * jj], a);
+      b = gl_mad(v, p.alpha_pows[2 * jj + 1], b);
+    }
+  }
+  p.out[pos] = a;
+  p.out[p.n + pos] = b;
+}
+
+// final[i] = shift0 * (F0(x_i) - y0)/(x_i - z0) + (F1(x_i) - y1)/(x_i - z1)   in F_p^2, x_i on the LDE coset.
+// fl: [4][N] LDE of (F0.a, F0.b, F1.a, F1.b); out interleaved ext [N][2] (bit-reversed row order).
+struct CombineParams {
+  const u64* fl;
+  const u64 *root_lo, *root_hi;
+  size_t N;
+  int log_N;
+  u64 y0[2], y1[2], z0[2], z1[2], shift0[2];
+  u64* out;
+};
+__global__ __launch_bounds__(256) void fri_combine_kernel(CombineParams p) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= p.N) return;
+  u32 j = bitrev32((u32)i, p.log_N);
+  u64 x = gl_mul7(root_pow24(p.root_lo, p.root_hi, j << (ROOT_TABLE_LOG - p.log_N)));
+  ext2 d0 = ext_make(gl_sub(x, p.z0[0]), gl_neg(p.z0[1]));
+  ext2 d1 = ext_make(gl_sub(x, p.z1[0]), gl_neg(p.z1[1]));
+  ext2 inv01 = ext_inv(ext_mul(d0, d1));
+  ext2 i0 = ext_mul(inv01, d1), i1 = ext_mul(inv01, d0);
+  ext2 n0 = ext_make(gl_sub(p.fl[i], p.y0[0]), gl_sub(p.fl[p.N + i], p.y0[1]));
+  ext2 n1 = ext_make(gl_sub(p.fl[2 * p.N + i], p.y1[0]), gl_sub(p.fl[3 * p.N + i], p.y1[1]));
+  ext2 q0 = ext_mul(n0, i0), q1 = ext_mul(n1, i1);
+  ext2 res = ext_add(ext_mul(q0, ext_make(p.shift0[0], p.shift0[1])), q1);
+  reinterpret_cast<ulonglong2*>(p.out)[i] = make_ulonglong2(res.a, res.b);
+}
+
+// ------------------------------------------------------------------------------------------------
+// FRI folding in the VALUE domain (bit-identical to fri_committed_trees' coefficient fold + coset_fft):
+// leaf k holds v[16k + t] = f(y0 * w_16^rev4(t)),  y0 = shift * w_M^rev(k).  Writing
+// f(X) = sum_t X^t f_t(X^16):  d_t = y0^t f_t(y0^16) = (1/16) sum_s w_16^(-st) e_s  and the folded value is
+// sum_t beta^t f_t(y0^16) = sum_t d_t (beta / y0)^t.
+// ------------------------------------------------------------------------------------------------
+struct FoldParams {
+  const u64* in;  // [M][2]
+  u64* out;       // [M >> arity_bits][2]
+  const u64 *root_lo, *root_hi;
+  size_t M;
+  int log_M, arity_bits;
+  u64 beta[2];
+  u64 shift_inv;        // (7^(16^round))^-1
+  u64 w_inv_pows[16];   // w_arity^(-k)
+  u64 arity_inv;        // 1/arity
+};
+__global__ __launch_bounds__(256) void fri_fold_kernel(FoldParams p) {
+  const size_t Mo = p.M >> p.arity_bits;
+  size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= Mo) return;
+  const int ar = 1 << p.arity_bits;
+  const int log_Mo = p.log_M - p.arity_bits;
+  ext2 e[16];
+  const ulonglong2* src = reinterpret_cast<const ulonglong2*>(p.in) + k * ar;
+  for (int t = 0; t < ar; ++t) {
+    ulonglong2 v = src[t];
+    e[bitrev32((u32)t, p.arity_bits)] = ext_make(v.x, v.y);
+  }
+  // y0^-1 = shift^-1 * w_M^(-rev(k))
+  u32 kr = bitrev32((u32)k, log_Mo);
+  u32 ex = kr << (ROOT_TABLE_LOG - p.log_M);
+  ex = ((1u << ROOT_TABLE_LOG) - ex) & ((1u << ROOT_TABLE_LOG) - 1);
+  u64 y0inv = gl_mul(p.shift_inv, root_pow24(p.root_lo, p.root_hi, ex));
+  ext2 bq = ext_scale(ext_make(p.beta[0], p.beta[1]), y0inv);  // beta / y0
+  // Horner over t from the top: acc = acc * bq + d_t
+  ext2 acc = ext_make(0, 0);
+  for (int t = ar - 1; t >= 0; --t) {
+    u64 da = 0, db = 0;
+    for (int s = 0; s < ar; ++s) {
+      u64 w = p.w_inv_pows[(s * t) & (ar - 1)];
+      da = gl_mad(e[s].a, w, da);
+      db = gl_mad(e[s].b, w, db);
+    }
+    acc = ext_add(ext_mul(acc, bq), ext_make(da, db));
+  }
+  acc = ext_scale(acc, p.arity_inv);
+  reinterpret_cast<ulonglong2*>(p.out)[k] = make_ulonglong2(acc.a, acc.b);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Proof of work (fri/prover.rs::fri_proof_of_work): candidate c goes into sponge slot `pos` of the
+// pre-loaded duplex state; accept when the LAST squeezed element (state[7]) has >= pow_bits leading
+// zero bits.  atomicMin keeps the SMALLEST valid witness of the batch, so the result is deterministic
+// (upstream's rayon find_any is not).
+// ------------------------------------------------------------------------------------------------
+struct PowParams {
+  u64 state[12];
+  int pos, pow_bits;
+  u64 base;
+  unsigned long long* result;  // initialised to ~0
+};
+__global__ __launch_bounds__(256) void pow_grind_kernel(PowParams p) {
+  u64 cand = p.base + (u64)blockIdx.x * 256 + threadIdx.x;
+  if (cand >= GL_P) return;
+  u64 s[12];
+#pragma unroll
+  for (int q = 0; q < 12; ++q) s[q] = p.state[q];
+#pragma unroll
+  for (int q = 0; q < 8; ++q)
+    if (q == p.pos) s[q] = cand;
+  poseidon_permute(s);
+  if ((s[7] >> (64 - p.pow_bits)) == 0) atomicMin(p.result, (unsigned long long)cand);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Query gathers (fri_prover_query_rounds: tree.get(i) + tree.prove(i)).
+// One block per query; out row = [width leaf values][depth x 4 sibling digests].
+// colmajor: leaf value c = data[c*stride + idx];  else data[idx*width + c].
+// ------------------------------------------------------------------------------------------------
+__global__ void gather_open_kernel(const u64* __restrict__ data, size_t stride, int width, int colmajor,
+                                   const u64* __restrict__ tree, size_t n_leaves, int depth,
+                                   const u64* __restrict__ indices, u64* __restrict__ out) {
+  const size_t idx = (size_t)indices[blockIdx.x];
+  u64* o = out + (size_t)blockIdx.x * ((size_t)width + 4 * (size_t)depth);
+  for (int c = threadIdx.x; c < width; c += blockDim.x)
+    o[c] = gl_canon(colmajor ? data[(size_t)c * stride + idx] : data[idx * (size_t)width + c]);
+  for (int t = threadIdx.x; t < 4 * depth; t += blockDim.x) {
+    int lvl = t >> 2, e = t & 3;
+    // level offset = sum_{l<lvl} n_leaves >> l
+    size_t off = 0, nl = n_leaves;
+    for (int l = 0; l < lvl; ++l) {
+      off += nl;
+      nl >>= 1;
+    }
+    size_t node = (idx >> lvl) ^ 1;
+    o[width + t] = tree[(off + node) * 4 + e];
+  }
+}

@@ -1,0 +1,657 @@
+// Host orchestration of a whole proof on one MI355X: the MI355X-native counterpart of
+// plonky2::plonk::prover::prove_with_partition_witness + fri::oracle::PolynomialBatch::prove_openings +
+// fri::prover::fri_proof (plonky2 v0.2.0, un-vendored: /root/reference/Cargo.lock:4848-4905; reached from
+// /root/reference/circuits/header_range.rs:167 `circuit.prove(&input)`; transcript order per SURVEY.md A.6-A.8).
+// Everything heavy is a kernel launch on the context's stream; the host keeps only the Fiat-Shamir
+// transcript (a few hundred field elements per proof) and the proof assembly.
+#pragma once
+#include "batch.hip.h"
+#include "challenger.h"
+#include "plonk_kernels.hip.h"
+
+struct vx_circuit {
+  vx_ctx* ctx = nullptr;
+  int degree_bits = 0, num_wires = 0, nr = 0, nch = 0, rate_bits = 0, cap_height = 0, pow_bits = 0, num_queries = 0, qdf = 0;
+  int num_selectors = 0, num_constants = 0;
+  std::vector<GateDev> gates;
+  std::vector<u64> k_is_host;
+  std::vector<uint32_t> pi_rows, pi_cols;
+  std::vector<int> arity_bits;
+  vx_batch* cs = nullptr;  // constants_sigmas commitment (resident across proofs)
+  u64* sigmas = nullptr;   // [nr][n] sigma VALUES on H (natural order) for the permutation argument
+  u64* k_is = nullptr;     // device copy
+  vxh::Hash4 digest;
+  int npp() const { return (nr + qdf - 1) / qdf - 1; }
+  size_t n() const { return (size_t)1 << degree_bits; }
+};
+
+static int circuit_create(vx_ctx* c, const vx_circuit_desc* d, vx_circuit** out) {
+  if (d->degree_bits < 1 || d->degree_bits + d->rate_bits > ROOT_TABLE_LOG) return vx_fail(VX_E_INVALID, "circuit: degree_bits=%d rate_bits=%d unsupported", d->degree_bits, d->rate_bits);
+  if (d->num_challenges < 1 || d->num_challenges > VX_MAX_CHALLENGES) return vx_fail(VX_E_INVALID, "circuit: num_challenges %d unsupported", d->num_challenges);
+  if (d->num_gates < 1 || d->num_gates > VX_MAX_GATES) return vx_fail(VX_E_INVALID, "circuit: num_gates %d unsupported", d->num_gates);
+  if (d->rate_bits < 1 || (1 << d->rate_bits) > VX_MAX_RATE) return vx_fail(VX_E_INVALID, "circuit: rate_bits %d unsupported", d->rate_bits);
+  if (d->quotient_degree_factor != (1 << d->rate_bits)) return vx_fail(VX_E_INVALID, "circuit: quotient_degree_factor must equal the blow-up (standard_recursion_config: 8)");
+  if (d->num_routed_wires > d->num_wires || d->num_routed_wires < 1) return vx_fail(VX_E_INVALID, "circuit: bad wire counts");
+  if ((d->num_routed_wires + d->quotient_degree_factor - 1) / d->quotient_degree_factor > PERM_MAX_CHUNKS) return vx_fail(VX_E_INVALID, "circuit: too many partial-product chunks");
+  if (d->pow_bits < 0 || d->pow_bits > 40) return vx_fail(VX_E_INVALID, "circuit: pow_bits %d unsupported", d->pow_bits);
+  if (!d->constants_sigmas || !d->k_is) return vx_fail(VX_E_INVALID, "circuit: NULL preprocessed data");
+  for (int g = 0; g < d->num_gates; ++g) {
+    int t = d->gate_types[g];
+    if (t < VX_GATE_NOOP || t > VX_GATE_POSEIDON) return vx_fail(VX_E_INVALID, "circuit: gate type %d is not in the supported set", t);
+    if (t == VX_GATE_POSEIDON && d->num_wires < 135) return vx_fail(VX_E_INVALID, "circuit: PoseidonGate needs 135 wires");
+    if (t == VX_GATE_ARITHMETIC && 4 * d->gate_params[g] > d->num_wires) return vx_fail(VX_E_INVALID, "circuit: ArithmeticGate ops exceed the wires");
+    if (d->selector_indices[g] < 0 || d->selector_indices[g] >= d->num_selectors) return vx_fail(VX_E_INVALID, "circuit: bad selector index");
+  }
+  vx_circuit* k = new vx_circuit();
+  k->ctx = c;
+  k->degree_bits = d->degree_bits;
+  k->num_wires = d->num_wires;
+  k->nr = d->num_routed_wires;
+  k->nch = d->num_challenges;
+  k->rate_bits = d->rate_bits;
+  k->cap_height = d->cap_height;
+  k->pow_bits = d->pow_bits;
+  k->num_queries = d->num_query_rounds;
+  k->qdf = d->quotient_degree_factor;
+  k->num_selectors = d->num_selectors;
+  k->num_constants = d->num_constants;
+  for (int g = 0; g < d->num_gates; ++g)
+    k->gates.push_back(GateDev{d->gate_types[g], d->gate_params[g], d->selector_indices[g], d->group_starts[g], d->group_ends[g]});
+  k->k_is_host.assign(d->k_is, d->k_is + d->num_routed_wires);
+  for (auto& v : k->k_is_host) v = vxh::canon(v);
+  k->pi_rows.assign(d->pi_rows, d->pi_rows + d->num_public_inputs);
+  k->pi_cols.assign(d->pi_cols, d->pi_cols + d->num_public_inputs);
+  for (int i = 0; i < d->num_public_inputs; ++i)
+    if (k->pi_rows[i] >= k->n() || (int)k->pi_cols[i] >= k->num_wires) {
+      delete k;
+      return vx_fail(VX_E_INVALID, "circuit: public input target out of range");
+    }
+  // fri/reduction_strategies.rs ConstantArityBits(4, 5)
+  {
+    int db = k->degree_bits;
+    while (db > 5 && db + k->rate_bits - 4 >= k->cap_height) {
+      k->arity_bits.push_back(4);
+      db -= 4;
+    }
+  }
+  const size_t n = k->n();
+  const size_t m = (size_t)k->num_constants + k->nr;
+  int rc = batch_alloc(c, k->degree_bits, m, k->rate_bits, k->cap_height, &k->cs);
+  if (rc) { delete k; return rc; }
+  u64* staging = nullptr;
+  if (hipMalloc(&staging, m * n * 8) != hipSuccess || hipMalloc(&k->sigmas, (size_t)k->nr * n * 8) != hipSuccess ||
+      hipMalloc(&k->k_is, k->nr * 8) != hipSuccess) {
+    hipFree(staging);
+    return vx_fail(VX_E_NOMEM, "circuit: out of device memory");
+  }
+  HIPCHK(hipMemcpyAsync(staging, d->constants_sigmas, m * n * 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(k->k_is, k->k_is_host.data(), k->nr * 8, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(canon_kernel, dim3((unsigned)((m * n + 255) / 256)), dim3(256), 0, c->stream, staging, m * n);
+  HIPCHK(hipMemcpyAsync(k->sigmas, staging + (size_t)k->num_constants * n, (size_t)k->nr * n * 8, hipMemcpyDeviceToDevice, c->stream));
+  rc = batch_commit_device(c, k->cs, staging, n, false);
+  hipError_t e = hipStreamSynchronize(c->stream);
+  hipFree(staging);
+  if (rc == VX_OK && e != hipSuccess) rc = vx_fail(VX_E_HIP, "circuit: %s", hipGetErrorString(e));
+  if (rc) return rc;
+  // circuit_digest = hash_no_pad(cap || [degree_bits])   (empty domain separator)
+  std::vector<u64> pre(((size_t)4 << k->cap_height) + 1);
+  HIPCHK(hipMemcpy(pre.data(), k->cs->tree + k->cs->cap_off * 4, (size_t)32 << k->cap_height, hipMemcpyDeviceToHost));
+  pre.back() = (u64)k->degree_bits;
+  k->digest = vxh::hash_no_pad(pre.data(), pre.size());
+  *out = k;
+  return VX_OK;
+}
+
+static void circuit_free(vx_circuit* k) {
+  if (!k) return;
+  hipSetDevice(k->ctx->device);
+  hipStreamSynchronize(k->ctx->stream);
+  if (k->cs) {
+    k->ctx->pool_free(k->cs->coeffs);
+    k->ctx->pool_free(k->cs->lde);
+    k->ctx->pool_free(k->cs->tree);
+    delete k->cs;
+  }
+  hipFree(k->sigmas);
+  hipFree(k->k_is);
+  delete k;
+}
+
+static void batch_release(vx_ctx* c, vx_batch* b) {
+  if (!b) return;
+  c->pool_free(b->coeffs);
+  c->pool_free(b->lde);
+  c->pool_free(b->tree);
+  delete b;
+}
+
+struct ByteSink {
+  std::vector<uint8_t> b;
+  void f(u64 v) {
+    for (int i = 0; i < 8; ++i) b.push_back((uint8_t)(v >> (8 * i)));
+  }
+  void words(const u64* p, size_t n) {
+    for (size_t i = 0; i < n; ++i) f(p[i]);
+  }
+  void u8(uint8_t v) { b.push_back(v); }
+};
+
+static size_t proof_size_bound(const vx_circuit* k) {
+  size_t cap = (size_t)32 << k->cap_height;
+  size_t depth0 = k->degree_bits + k->rate_bits - k->cap_height;
+  size_t widths = (size_t)k->num_constants + k->nr + k->num_wires + (size_t)k->nch * (1 + k->npp()) + (size_t)k->nch * k->qdf;
+  size_t open = 16 * (widths + k->nch);
+  size_t per_query = 8 * widths + 4 * (1 + 32 * depth0) + k->arity_bits.size() * (16 * 16 + 1 + 32 * depth0);
+  return (3 + k->arity_bits.size()) * cap + open + k->num_queries * per_query + 16 * 256 + 8 + 8 * k->pi_rows.size() + 4096;
+}
+
+// One device scratch allocation that is returned to the pool when the proof ends.
+struct Scratch {
+  vx_ctx* c;
+  std::vector<void*> ptrs;
+  explicit Scratch(vx_ctx* ctx) : c(ctx) {}
+  ~Scratch() {
+    for (void* p : ptrs) c->pool_free(p);
+  }
+  u64* get(size_t words) {
+    void* p = nullptr;
+    if (c->pool_alloc(&p, words * 8) != hipSuccess) return nullptr;
+    ptrs.push_back(p);
+    return (u64*)p;
+  }
+};
+
+static int prove_impl(vx_ctx* c, vx_circuit* k, const u64* wires_in, bool wires_on_device, const u64* pow_hint,
+                      std::vector<uint8_t>& proof_out) {
+  using namespace vxh;
+  const size_t n = k->n();
+  const int lg = k->degree_bits, rb = k->rate_bits, LG = lg + rb;
+  const size_t N = (size_t)1 << LG;
+  const int nch = k->nch, npp = k->npp(), nchunks = npp + 1, qdf = k->qdf, rate = 1 << rb;
+  const size_t cap_words = (size_t)4 << k->cap_height;
+  Scratch S(c);
+  vx_batch *wires_b = nullptr, *zs_b = nullptr, *quot_b = nullptr;
+  struct Cleanup {
+    vx_ctx* c;
+    vx_batch **a, **b, **d;
+    ~Cleanup() {
+      batch_release(c, *a);
+      batch_release(c, *b);
+      batch_release(c, *d);
+    }
+  } cleanup{c, &wires_b, &zs_b, &quot_b};
+
+  // ---- witness on device ----
+  const u64* d_wires = wires_in;
+  if (!wires_on_device) {
+    ProfScope ps(c, "h2d_witness");
+    u64* w = S.get((size_t)k->num_wires * n);
+    if (!w) return vx_fail(VX_E_NOMEM, "prove: out of device memory (witness)");
+    HIPCHK(hipMemcpyAsync(w, wires_in, (size_t)k->num_wires * n * 8, hipMemcpyHostToDevice, c->stream));
+    d_wires = w;
+  }
+  // public inputs = witness.get_targets(public_inputs); public_inputs_hash = hash_no_pad(..)
+  std::vector<u64> public_inputs(k->pi_rows.size());
+  for (size_t i = 0; i < public_inputs.size(); ++i) {
+    const u64* src = d_wires + (size_t)k->pi_cols[i] * n + k->pi_rows[i];
+    HIPCHK(hipMemcpyAsync(&public_inputs[i], src, 8, hipMemcpyDeviceToHost, c->stream));
+  }
+  HIPCHK(hipStreamSynchronize(c->stream));
+  for (auto& v : public_inputs) v = canon(v);
+  Hash4 pih = hash_no_pad(public_inputs.data(), public_inputs.size());
+
+  // ---- wires commitment ----
+  VXCHK(batch_alloc(c, lg, k->num_wires, rb, k->cap_height, &wires_b));
+  VXCHK(batch_commit_device(c, wires_b, d_wires, n, false));
+  std::vector<u64> wires_cap(cap_words), zs_cap(cap_words), quot_cap(cap_words);
+  HIPCHK(hipMemcpyAsync(wires_cap.data(), wires_b->tree + wires_b->cap_off * 4, cap_words * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+
+  Challenger ch;
+  ch.observe_elements(k->digest.e, 4);
+  ch.observe_elements(pih.e, 4);
+  ch.observe_elements(wires_cap.data(), cap_words);
+  u64 betas[VX_MAX_CHALLENGES] = {0}, gammas[VX_MAX_CHALLENGES] = {0}, alphas[VX_MAX_CHALLENGES] = {0};
+  for (int i = 0; i < nch; ++i) betas[i] = ch.get_challenge();
+  for (int i = 0; i < nch; ++i) gammas[i] = ch.get_challenge();
+
+  // ---- Z and partial products ----
+  {
+    const size_t nblocks = (n + 255) / 256;
+    u64* cp = S.get((size_t)nch * nchunks * n);
+    u64* bp = S.get((size_t)nch * nblocks);
+    u64* zs_vals = S.get((size_t)nch * (1 + npp) * n);
+    if (!cp || !bp || !zs_vals) return vx_fail(VX_E_NOMEM, "prove: out of device memory (permutation argument)");
+    {
+      ProfScope ps(c, "perm_z_partial_products", (double)nch * 8.0 * n * (2.0 * k->nr + 1 + npp));
+      PermParams pp;
+      pp.wires = d_wires;
+      pp.sigmas = k->sigmas;
+      pp.k_is = k->k_is;
+      pp.root_lo = c->root_lo;
+      pp.root_hi = c->root_hi;
+      pp.n = n;
+      pp.log_n = lg;
+      pp.nr = k->nr;
+      pp.deg = qdf;
+      pp.nchunks = nchunks;
+      pp.nch = nch;
+      for (int i = 0; i < VX_MAX_CHALLENGES; ++i) pp.betas[i] = betas[i], pp.gammas[i] = gammas[i];
+      pp.cp = cp;
+      hipLaunchKernelGGL(perm_chunk_products_kernel, dim3((unsigned)nblocks, nch), dim3(256), 0, c->stream, pp);
+      hipLaunchKernelGGL(perm_block_products_kernel, dim3((unsigned)nblocks, nch), dim3(256), 0, c->stream, cp, n, nchunks, bp);
+      hipLaunchKernelGGL(perm_scan_blocks_kernel, dim3(nch), dim3(64), 0, c->stream, bp, nblocks);
+      hipLaunchKernelGGL(perm_write_kernel, dim3((unsigned)nblocks, nch), dim3(256), 0, c->stream, cp, n, nchunks, nch, bp, zs_vals);
+      HIPCHK(hipGetLastError());
+    }
+    VXCHK(batch_alloc(c, lg, (size_t)nch * (1 + npp), rb, k->cap_height, &zs_b));
+    VXCHK(batch_commit_device(c, zs_b, zs_vals, n, false));
+  }
+  HIPCHK(hipMemcpyAsync(zs_cap.data(), zs_b->tree + zs_b->cap_off * 4, cap_words * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  ch.observe_elements(zs_cap.data(), cap_words);
+  for (int i = 0; i < nch; ++i) alphas[i] = ch.get_challenge();
+
+  // ---- quotient polynomials ----
+  {
+    u64* qv = S.get((size_t)nch * N);
+    u64* qu = S.get((size_t)nch * N);
+    if (!qv || !qu) return vx_fail(VX_E_NOMEM, "prove: out of device memory (quotient)");
+    {
+      QuotientParams qp;
+      memset(&qp, 0, sizeof qp);
+      qp.cs = k->cs->lde;
+      qp.wires = wires_b->lde;
+      qp.zs = zs_b->lde;
+      qp.k_is = k->k_is;
+      qp.root_lo = c->root_lo;
+      qp.root_hi = c->root_hi;
+      qp.N = N;
+      qp.log_n = lg;
+      qp.rate_bits = rb;
+      qp.num_selectors = k->num_selectors;
+      qp.num_constants = k->num_constants;
+      qp.nr = k->nr;
+      qp.num_wires = k->num_wires;
+      qp.nch = nch;
+      qp.npp = npp;
+      qp.deg = qdf;
+      qp.num_gates = (int)k->gates.size();
+      for (size_t g = 0; g < k->gates.size(); ++g) qp.gates[g] = k->gates[g];
+      for (int i = 0; i < VX_MAX_CHALLENGES; ++i) qp.betas[i] = betas[i], qp.gammas[i] = gammas[i], qp.alphas[i] = alphas[i];
+      for (int i = 0; i < 4; ++i) qp.pih[i] = pih.e[i];
+      // ZeroPolyOnCoset: Z_H(x) on coset r = 7^n * w_rate^r - 1
+      u64 shift_n = pow(7, n), g_rate = root_of_unity(rb), pw = 1;
+      for (int r = 0; r < rate; ++r) {
+        qp.zh[r] = sub(mul(shift_n, pw), 1);
+        qp.zh_inv[r] = inv(qp.zh[r]);
+        pw = mul(pw, g_rate);
+      }
+      qp.n_field = (u64)n % P;
+      qp.out = qv;
+      size_t bytes_read = 8ull * N * ((size_t)k->num_constants + k->nr + k->num_wires + (size_t)nch * (2 + npp));
+      ProfScope ps(c, "quotient_eval", (double)bytes_read);
+      hipLaunchKernelGGL(quotient_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, qp);
+      HIPCHK(hipGetLastError());
+    }
+    // per-coset inverse NTT (input rows of each block are in bit-reversed order), then the cross-coset
+    // inverse DFT that separates the degree-n chunks
+    u64 ninv = inv((u64)n % P);
+    VXCHK(run_ntt(c, qv, qu, N, N, n, n, lg, nch, rate, true, true, nullptr, 0, ninv, "quotient_intt", 16.0 * N * nch));
+    VXCHK(batch_alloc(c, lg, (size_t)nch * qdf, rb, k->cap_height, &quot_b));
+    {
+      std::vector<u64> inv_shifts(rate);
+      u64 wN = root_of_unity(LG);
+      for (int z = 0; z < rate; ++z) inv_shifts[z] = inv(mul(7, pow(wN, reverse_bits((size_t)z, rb))));
+      int bits = lg / 2;
+      u64* tab = nullptr;
+      VXCHK(get_scale_tables(c, lg, bits, inv_shifts, 1, &tab));
+      ChunkParams cp;
+      memset(&cp, 0, sizeof cp);
+      cp.u = qu;
+      cp.t = quot_b->coeffs;
+      cp.inv_tab = tab;
+      cp.log_n = lg;
+      cp.rb = rb;
+      cp.bits = bits;
+      u64 wr_inv = inv(root_of_unity(rb)), pw = 1;
+      for (int i = 0; i < rate; ++i) {
+        cp.w_rate_inv_pows[i] = pw;
+        pw = mul(pw, wr_inv);
+      }
+      u64 s_inv = inv(pow(7, n)), rate_inv = inv((u64)rate);
+      pw = rate_inv;
+      for (int q = 0; q < rate; ++q) {
+        cp.chunk_scale[q] = pw;
+        pw = mul(pw, s_inv);
+      }
+      ProfScope ps(c, "quotient_chunks", 16.0 * N * nch);
+      hipLaunchKernelGGL(quotient_chunks_kernel, dim3((unsigned)((n + 255) / 256), nch), dim3(256), 0, c->stream, cp);
+      HIPCHK(hipGetLastError());
+    }
+    VXCHK(batch_lde_and_tree(c, quot_b));
+  }
+  HIPCHK(hipMemcpyAsync(quot_cap.data(), quot_b->tree + quot_b->cap_off * 4, cap_words * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  ch.observe_elements(quot_cap.data(), cap_words);
+  Ext zeta = ch.get_extension_challenge();
+  {
+    Ext zp = zeta;
+    for (int i = 0; i < lg; ++i) zp = emul(zp, zp);
+    if (zp.a == 1 && zp.b == 0) return vx_fail(VX_E_PROOF, "Opening point is in the subgroup.");
+  }
+  const u64 g = root_of_unity(lg);
+  Ext gzeta{mul(zeta.a, g), mul(zeta.b, g)};
+
+  // ---- openings ----
+  vx_batch* oracles[4] = {k->cs, wires_b, zs_b, quot_b};
+  std::vector<u64> ev[4], zs_next(2 * (size_t)nch);
+  {
+    u64* ztab = S.get(2 * n);
+    if (!ztab) return vx_fail(VX_E_NOMEM, "prove: out of device memory (openings)");
+    VXCHK(build_zeta_table(c, zeta, lg, ztab));
+    for (int o = 0; o < 4; ++o) {
+      ev[o].resize(2 * oracles[o]->ncols);
+      VXCHK(batch_eval_ext(c, oracles[o]->coeffs, n, lg, oracles[o]->ncols, ztab, ev[o].data()));
+    }
+    VXCHK(build_zeta_table(c, gzeta, lg, ztab));
+    VXCHK(batch_eval_ext(c, zs_b->coeffs, n, lg, nch, ztab, zs_next.data()));
+  }
+  // to_fri_openings: batch 0 = [constants, sigmas, wires, zs, partial products, quotient], batch 1 = [zs_next]
+  std::vector<Ext> batch0, batch1;
+  for (int o = 0; o < 4; ++o)
+    for (size_t i = 0; i < oracles[o]->ncols; ++i) batch0.push_back(Ext{ev[o][2 * i], ev[o][2 * i + 1]});
+  for (int i = 0; i < nch; ++i) batch1.push_back(Ext{zs_next[2 * i], zs_next[2 * i + 1]});
+  for (Ext e : batch0) ch.observe_ext(e);
+  for (Ext e : batch1) ch.observe_ext(e);
+
+  // ---- prove_openings ----
+  Ext alpha = ch.get_extension_challenge();
+  const size_t nb0 = batch0.size(), nb1 = batch1.size();
+  std::vector<u64> apows(2 * nb0);
+  {
+    Ext a{1, 0};
+    for (size_t j = 0; j < nb0; ++j) {
+      apows[2 * j] = a.a;
+      apows[2 * j + 1] = a.b;
+      a = emul(a, alpha);
+    }
+  }
+  // F_b(z_b) = sum_j alpha^j opening_j   (= the verifier's PrecomputedReducedOpenings)
+  Ext y0{0, 0}, y1{0, 0};
+  for (size_t j = nb0; j-- > 0;) y0 = eadd(emul(y0, alpha), batch0[j]);
+  for (size_t j = nb1; j-- > 0;) y1 = eadd(emul(y1, alpha), batch1[j]);
+  u64* fcoef = S.get(4 * n);
+  u64* flde = S.get(4 * N);
+  u64* d_apows = S.get(2 * nb0);
+  if (!fcoef || !flde || !d_apows) return vx_fail(VX_E_NOMEM, "prove: out of device memory (opening proof)");
+  HIPCHK(hipMemcpyAsync(d_apows, apows.data(), apows.size() * 8, hipMemcpyHostToDevice, c->stream));
+  {
+    ReduceParams rp;
+    memset(&rp, 0, sizeof rp);
+    rp.ngroups = 4;
+    size_t total = 0;
+    for (int o = 0; o < 4; ++o) {
+      rp.cols[o] = oracles[o]->coeffs;
+      rp.ncols[o] = (int)oracles[o]->ncols;
+      total += oracles[o]->ncols;
+    }
+    rp.alpha_pows = d_apows;
+    rp.n = n;
+    rp.out = fcoef;
+    ProfScope ps(c, "reduce_polys", 8.0 * n * total);
+    hipLaunchKernelGGL(reduce_polys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, rp);
+    rp.ngroups = 1;
+    rp.cols[0] = zs_b->coeffs;
+    rp.ncols[0] = nch;
+    rp.out = fcoef + 2 * n;
+    hipLaunchKernelGGL(reduce_polys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, rp);
+    HIPCHK(hipGetLastError());
+  }
+  // LDE of (F0.a, F0.b, F1.a, F1.b): an F_p^2 NTT with base-field roots is two F_p NTTs
+  {
+    std::vector<u64> shifts(rate);
+    u64 wN = root_of_unity(LG);
+    for (int z = 0; z < rate; ++z) shifts[z] = mul(7, pow(wN, reverse_bits((size_t)z, rb)));
+    int bits = lg / 2;
+    u64* tab = nullptr;
+    VXCHK(get_scale_tables(c, lg, bits, shifts, 1, &tab));
+    VXCHK(run_ntt(c, fcoef, flde, n, N, 0, n, lg, 4, rate, false, true, tab, bits, 1, "fri_lde", 4.0 * 8.0 * ((double)n + N)));
+  }
+  // FRI value arrays per round (interleaved ext, bit-reversed order) and their trees
+  const size_t R = k->arity_bits.size();
+  std::vector<u64*> fvals(R + 1, nullptr), ftrees(R, nullptr);
+  std::vector<size_t> flen(R + 1), fcapoff(R, 0);
+  flen[0] = N;
+  for (size_t r = 0; r < R; ++r) flen[r + 1] = flen[r] >> k->arity_bits[r];
+  for (size_t r = 0; r <= R; ++r) {
+    fvals[r] = S.get(2 * flen[r]);
+    if (!fvals[r]) return vx_fail(VX_E_NOMEM, "prove: out of device memory (FRI)");
+  }
+  {
+    CombineParams cp;
+    memset(&cp, 0, sizeof cp);
+    cp.fl = flde;
+    cp.root_lo = c->root_lo;
+    cp.root_hi = c->root_hi;
+    cp.N = N;
+    cp.log_N = LG;
+    cp.y0[0] = y0.a, cp.y0[1] = y0.b, cp.y1[0] = y1.a, cp.y1[1] = y1.b;
+    cp.z0[0] = zeta.a, cp.z0[1] = zeta.b, cp.z1[0] = gzeta.a, cp.z1[1] = gzeta.b;
+    Ext sh = epow(alpha, nb1);  // alpha.shift_poly: *= alpha^|batch 1|
+    cp.shift0[0] = sh.a, cp.shift0[1] = sh.b;
+    cp.out = fvals[0];
+    ProfScope ps(c, "fri_combine", 48.0 * N);
+    hipLaunchKernelGGL(fri_combine_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, cp);
+    HIPCHK(hipGetLastError());
+  }
+  // ---- FRI commit phase ----
+  std::vector<std::vector<u64>> commit_caps;
+  {
+    u64 shift = 7;
+    for (size_t r = 0; r < R; ++r) {
+      const int ab = k->arity_bits[r];
+      const size_t M = flen[r], leaves = M >> ab;
+      const int width = 2 << ab;
+      size_t nd = merkle_tree_digest_count(leaves, k->cap_height);
+      ftrees[r] = S.get(nd * 4);
+      if (!ftrees[r]) return vx_fail(VX_E_NOMEM, "prove: out of device memory (FRI trees)");
+      {
+        ProfScope ps(c, "fri_hash_leaves", 16.0 * M);
+        hipLaunchKernelGGL(hash_leaves_rowmajor_kernel, dim3((unsigned)((leaves + HASH_THREADS - 1) / HASH_THREADS)),
+                           dim3(HASH_THREADS), 0, c->stream, fvals[r], leaves, width, ftrees[r]);
+        HIPCHK(hipGetLastError());
+      }
+      VXCHK(build_merkle_levels(c, ftrees[r], leaves, k->cap_height, &fcapoff[r]));
+      std::vector<u64> cap(cap_words);
+      HIPCHK(hipMemcpyAsync(cap.data(), ftrees[r] + fcapoff[r] * 4, cap_words * 8, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(hipStreamSynchronize(c->stream));
+      ch.observe_elements(cap.data(), cap_words);
+      commit_caps.push_back(cap);
+      Ext beta = ch.get_extension_challenge();
+      FoldParams fp;
+      memset(&fp, 0, sizeof fp);
+      fp.in = fvals[r];
+      fp.out = fvals[r + 1];
+      fp.root_lo = c->root_lo;
+      fp.root_hi = c->root_hi;
+      fp.M = M;
+      fp.log_M = LG;
+      for (size_t q = 0; q < r; ++q) fp.log_M -= k->arity_bits[q];
+      fp.arity_bits = ab;
+      fp.beta[0] = beta.a, fp.beta[1] = beta.b;
+      fp.shift_inv = inv(shift);
+      u64 wa_inv = inv(root_of_unity(ab)), pw = 1;
+      for (int q = 0; q < (1 << ab); ++q) {
+        fp.w_inv_pows[q] = pw;
+        pw = mul(pw, wa_inv);
+      }
+      fp.arity_inv = inv((u64)1 << ab);
+      {
+        ProfScope ps(c, "fri_fold", 16.0 * M);
+        hipLaunchKernelGGL(fri_fold_kernel, dim3((unsigned)((leaves + 255) / 256)), dim3(256), 0, c->stream, fp);
+        HIPCHK(hipGetLastError());
+      }
+      shift = pow(shift, (u64)1 << ab);
+    }
+    // final polynomial: the last value array (bit-reversed, on the coset shift*H) -> coefficients, on the host
+    const size_t Mf = flen[R];
+    const int lMf = [&] { int l = 0; while (((size_t)1 << l) < Mf) ++l; return l; }();
+    std::vector<u64> hv(2 * Mf);
+    HIPCHK(hipMemcpyAsync(hv.data(), fvals[R], hv.size() * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    std::vector<Ext> coeffs(Mf);
+    {
+      // coefficient j = shift^-j / Mf * sum_k v_k w^(-jk), v_k at natural index k = rev(position)
+      u64 w_inv = inv(root_of_unity(lMf)), s_inv = inv(shift), m_inv = inv((u64)Mf % P);
+      std::vector<u64> wp(Mf);
+      wp[0] = 1;
+      for (size_t i = 1; i < Mf; ++i) wp[i] = mul(wp[i - 1], w_inv);
+      u64 sj = m_inv;
+      for (size_t j = 0; j < Mf; ++j) {
+        u64 a = 0, b = 0;
+        for (size_t pos = 0; pos < Mf; ++pos) {
+          size_t kk = reverse_bits(pos, lMf);
+          u64 w = wp[(j * kk) & (Mf - 1)];
+          a = add(a, mul(hv[2 * pos], w));
+          b = add(b, mul(hv[2 * pos + 1], w));
+        }
+        coeffs[j] = Ext{mul(a, sj), mul(b, sj)};
+        sj = mul(sj, s_inv);
+      }
+    }
+    const size_t keep = Mf >> rb;
+    for (size_t j = keep; j < Mf; ++j)
+      if (coeffs[j].a || coeffs[j].b) return vx_fail(VX_E_PROOF, "FRI final polynomial has non-zero high coefficients (witness does not satisfy the circuit?)");
+    coeffs.resize(keep);
+    for (Ext e : coeffs) ch.observe_ext(e);
+    // ---- proof of work ----
+    u64 pow_witness = 0;
+    {
+      auto check = [&](u64 cand) {
+        Challenger c2 = ch;
+        c2.observe_element(cand);
+        return (c2.get_challenge() >> (64 - k->pow_bits)) == 0;
+      };
+      if (pow_hint) {
+        pow_witness = canon(*pow_hint);
+        if (k->pow_bits > 0 && !check(pow_witness)) return vx_fail(VX_E_INVALID, "pow_witness hint does not satisfy the proof-of-work condition");
+      } else if (k->pow_bits > 0) {
+        PowParams pp;
+        memset(&pp, 0, sizeof pp);
+        for (int q = 0; q < 12; ++q) pp.state[q] = ch.sponge[q];
+        for (size_t q = 0; q < ch.input.size(); ++q) pp.state[q] = ch.input[q];
+        pp.pos = (int)ch.input.size();
+        pp.pow_bits = k->pow_bits;
+        unsigned long long* d_res = (unsigned long long*)S.get(1);
+        if (!d_res) return vx_fail(VX_E_NOMEM, "prove: out of device memory (pow)");
+        pp.result = d_res;
+        const u64 batch = (u64)1 << 22;
+        unsigned long long res = ~0ull;
+        ProfScope ps(c, "pow_grind");
+        for (u64 base = 0; res == ~0ull; base += batch) {
+          HIPCHK(hipMemsetAsync(d_res, 0xFF, 8, c->stream));
+          pp.base = base;
+          hipLaunchKernelGGL(pow_grind_kernel, dim3((unsigned)(batch / 256)), dim3(256), 0, c->stream, pp);
+          HIPCHK(hipMemcpyAsync(&res, d_res, 8, hipMemcpyDeviceToHost, c->stream));
+          HIPCHK(hipStreamSynchronize(c->stream));
+          if (base > ((u64)1 << 44)) return vx_fail(VX_E_PROOF, "Proof of work failed. This is highly unlikely!");
+        }
+        pow_witness = res;
+        if (!check(pow_witness)) return vx_fail(VX_E_PROOF, "internal error: GPU proof-of-work witness rejected by the host transcript");
+      }
+      ch.observe_element(pow_witness);
+      (void)ch.get_challenge();  // pow_response
+    }
+    // ---- query rounds ----
+    const int nq = k->num_queries;
+    std::vector<u64> x_indices(nq);
+    for (int q = 0; q < nq; ++q) x_indices[q] = ch.get_challenge() % (u64)N;
+    const int depth0 = LG - k->cap_height;
+    std::vector<std::vector<u64>> init_out(4);
+    std::vector<std::vector<u64>> step_out(R);
+    {
+      ProfScope ps(c, "query_gather");
+      u64* d_idx = S.get((size_t)nq * (R + 1));
+      if (!d_idx) return vx_fail(VX_E_NOMEM, "prove: out of device memory (queries)");
+      std::vector<u64> idx_host((size_t)nq * (R + 1));
+      for (int q = 0; q < nq; ++q) {
+        u64 xi = x_indices[q];
+        idx_host[q] = xi;
+        for (size_t r = 0; r < R; ++r) {
+          xi >>= k->arity_bits[r];
+          idx_host[(r + 1) * nq + q] = xi;
+        }
+      }
+      HIPCHK(hipMemcpyAsync(d_idx, idx_host.data(), idx_host.size() * 8, hipMemcpyHostToDevice, c->stream));
+      for (int o = 0; o < 4; ++o) {
+        size_t rowlen = oracles[o]->ncols + 4 * (size_t)depth0;
+        u64* d_out = S.get(rowlen * nq);
+        if (!d_out) return vx_fail(VX_E_NOMEM, "prove: out of device memory (queries)");
+        hipLaunchKernelGGL(gather_open_kernel, dim3(nq), dim3(128), 0, c->stream, oracles[o]->lde, N, (int)oracles[o]->ncols, 1,
+                           oracles[o]->tree, N, depth0, d_idx, d_out);
+        init_out[o].resize(rowlen * nq);
+        HIPCHK(hipMemcpyAsync(init_out[o].data(), d_out, rowlen * nq * 8, hipMemcpyDeviceToHost, c->stream));
+      }
+      for (size_t r = 0; r < R; ++r) {
+        const int ab = k->arity_bits[r];
+        const size_t leaves = flen[r] >> ab;
+        int depth = 0;
+        while (((size_t)1 << (depth + k->cap_height)) < leaves) ++depth;
+        const int width = 2 << ab;
+        size_t rowlen = width + 4 * (size_t)depth;
+        u64* d_out = S.get(rowlen * nq);
+        if (!d_out) return vx_fail(VX_E_NOMEM, "prove: out of device memory (queries)");
+        hipLaunchKernelGGL(gather_open_kernel, dim3(nq), dim3(128), 0, c->stream, fvals[r], 0, width, 0, ftrees[r], leaves, depth,
+                           d_idx + (r + 1) * nq, d_out);
+        step_out[r].resize(rowlen * nq);
+        HIPCHK(hipMemcpyAsync(step_out[r].data(), d_out, rowlen * nq * 8, hipMemcpyDeviceToHost, c->stream));
+      }
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    // ---- serialise (util/serialization::write_proof_with_public_inputs) ----
+    ByteSink w;
+    w.b.reserve(proof_size_bound(k));
+    w.words(wires_cap.data(), cap_words);
+    w.words(zs_cap.data(), cap_words);
+    w.words(quot_cap.data(), cap_words);
+    // OpeningSet: constants, plonk_sigmas, wires, plonk_zs, plonk_zs_next, partial_products, quotient_polys
+    w.words(ev[0].data(), 2 * (size_t)k->num_constants);
+    w.words(ev[0].data() + 2 * (size_t)k->num_constants, 2 * (size_t)k->nr);
+    w.words(ev[1].data(), ev[1].size());
+    w.words(ev[2].data(), 2 * (size_t)nch);
+    w.words(zs_next.data(), 2 * (size_t)nch);
+    w.words(ev[2].data() + 2 * (size_t)nch, ev[2].size() - 2 * (size_t)nch);
+    w.words(ev[3].data(), ev[3].size());
+    for (auto& cp : commit_caps) w.words(cp.data(), cap_words);
+    for (int q = 0; q < nq; ++q) {
+      for (int o = 0; o < 4; ++o) {
+        size_t width = oracles[o]->ncols, rowlen = width + 4 * (size_t)depth0;
+        const u64* row = &init_out[o][rowlen * q];
+        w.words(row, width);
+        w.u8((uint8_t)depth0);
+        w.words(row + width, 4 * (size_t)depth0);
+      }
+      for (size_t r = 0; r < R; ++r) {
+        const int ab = k->arity_bits[r];
+        const size_t leaves = flen[r] >> ab;
+        int depth = 0;
+        while (((size_t)1 << (depth + k->cap_height)) < leaves) ++depth;
+        size_t width = (size_t)2 << ab, rowlen = width + 4 * (size_t)depth;
+        const u64* row = &step_out[r][rowlen * q];
+        w.words(row, width);
+        w.u8((uint8_t)depth);
+        w.words(row + width, 4 * (size_t)depth);
+      }
+    }
+    for (Ext e : coeffs) {
+      w.f(e.a);
+      w.f(e.b);
+    }
+    w.f(pow_witness);
+    w.words(public_inputs.data(), public_inputs.size());
+    proof_out.swap(w.b);
+  }
+  return VX_OK;
+}

@@ -3,6 +3,7 @@
 // point returns VX_E_NO_DEVICE.
 #include "vx_runtime.hip.h"
 #include "batch.hip.h"
+#include "prover.hip.h"
 
 extern "C" {
 
@@ -346,6 +347,47 @@ int vx_batch_eval_ext(vx_batch* b, const uint64_t zeta[2], uint64_t* out) {
   hipStreamSynchronize(c->stream);
   hipFree(ztab);
   return rc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// L3
+// ---------------------------------------------------------------------------------------------
+int vx_circuit_create(vx_ctx* c, const vx_circuit_desc* desc, vx_circuit** out) {
+  if (!c || !desc || !out) return vx_fail(VX_E_INVALID, "vx_circuit_create: NULL argument");
+  *out = nullptr;
+  HIPCHK(hipSetDevice(c->device));
+  return circuit_create(c, desc, out);
+}
+void vx_circuit_free(vx_circuit* k) { circuit_free(k); }
+int vx_circuit_digest(vx_circuit* k, uint64_t digest_out[4]) {
+  if (!k || !digest_out) return vx_fail(VX_E_INVALID, "vx_circuit_digest: NULL argument");
+  memcpy(digest_out, k->digest.e, 32);
+  return VX_OK;
+}
+int vx_circuit_constants_sigmas_cap(vx_circuit* k, uint64_t* cap_out) {
+  if (!k || !cap_out) return vx_fail(VX_E_INVALID, "vx_circuit_constants_sigmas_cap: NULL argument");
+  return vx_batch_cap(k->cs, cap_out);
+}
+size_t vx_proof_size_bound(vx_circuit* k) { return k ? proof_size_bound(k) : 0; }
+
+int vx_prove(vx_ctx* c, vx_circuit* k, const uint64_t* wires, int wires_on_device, const uint64_t* pow_witness_hint,
+             uint8_t* out_buf, size_t* out_len) {
+  if (!c || !k || !wires || !out_buf || !out_len) return vx_fail(VX_E_INVALID, "vx_prove: NULL argument");
+  if (k->ctx != c) return vx_fail(VX_E_INVALID, "vx_prove: circuit belongs to a different context");
+  HIPCHK(hipSetDevice(c->device));
+  std::vector<uint8_t> proof;
+  int rc = prove_impl(c, k, wires, wires_on_device != 0, pow_witness_hint, proof);
+  if (rc != VX_OK) {
+    hipStreamSynchronize(c->stream);
+    return rc;
+  }
+  if (proof.size() > *out_len) {
+    *out_len = proof.size();
+    return vx_fail(VX_E_INVALID, "vx_prove: output buffer too small, need %zu bytes", proof.size());
+  }
+  memcpy(out_buf, proof.data(), proof.size());
+  *out_len = proof.size();
+  return VX_OK;
 }
 
 }  // extern "C"
