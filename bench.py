@@ -37,7 +37,9 @@ def parse():
     ap.add_argument("--ncols", type=int, default=135)
     ap.add_argument("--workload", default="auto", choices=["auto", "commit", "prove"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-log-n", type=int, default=17)
+    ap.add_argument("--cpu-sample-log-n", type=int, default=None,
+                    help="rows (log2) of the bounded CPU-baseline sample (default 14 for prove, 17 for commit)")
+    ap.add_argument("--poseidon-percent", type=int, default=50, help="share of PoseidonGate rows in the synthetic circuit")
     return ap.parse_args()
 
 
@@ -86,6 +88,8 @@ def main():
     workload = args.workload
     if workload == "auto":
         workload = "prove" if hasattr(vx, "Circuit") else "commit"
+    if args.cpu_sample_log_n is None:
+        args.cpu_sample_log_n = 14 if workload == "prove" else 17
 
     def barrier():
         ctx.sync()

@@ -1,0 +1,56 @@
+"""Whole-proof workload for bench.py: one step = one vx_prove of a header_range_512-shaped synthetic circuit
+(BASELINE.json configs[2]: 2^21 rows, 135 wires, blow-up 8, full FRI) with the witness already in HBM."""
+import time
+
+import numpy as np
+
+
+def make_step(ctx, args, rank):
+    import vectorx_amd as vx
+    from vectorx_amd.synth import SynthCircuit
+
+    sc = SynthCircuit(args.log_n, seed=0x5EED0000 + rank, poseidon_percent=args.poseidon_percent)
+    counts = sc.row_counts()
+    circuit = vx.Circuit(ctx, sc.desc_ptr)   # constants_sigmas commitment stays resident (per-circuit, not per-proof)
+    w = sc.witness()
+    d_w = ctx.alloc(w.nbytes)
+    ctx.upload(d_w, w)
+    del w
+    sc.release_host_buffers(witness=True, preprocessed=True)
+    state = {"proof": None}
+
+    def step():
+        state["proof"] = circuit.prove(dev_ptr=d_w)
+        return state["proof"]
+
+    metric = "header_range_512 proofs/sec"
+    unit = "proofs/sec"
+    wl = (f"header_range_512 stand-in: one plonky2 proof of a synthetic standard_recursion_config circuit, n=2^{args.log_n} rows x 135 wires "
+          f"(80 routed), blowup 8, cap_height 4, FRI arity 16 / 28 queries / 16 PoW bits; gate rows: {counts['poseidon']} PoseidonGate, "
+          f"{counts['arithmetic']} ArithmeticGate(20 ops), {counts['noop']} NoopGate, 1 PublicInputGate, 1 ConstantGate "
+          f"(the real 64 map + 63 reduce + 1 outer proof DAG and its gate mix need the Rust circuit builder: SURVEY.md §0.7)")
+    make_step.keepalive = (sc, circuit, d_w, state)
+    return step, metric, unit, wl
+
+
+def cpu_baseline(args):
+    """oracle (kind "port": CPU restatement of plonky2 v0.2.0, OpenMP over all host cores) proving a bounded
+    sample — the same circuit family at 2^cpu_sample_log_n rows — scaled linearly in rows to the bench size."""
+    import oracle_lib
+    from vectorx_amd.synth import SynthCircuit
+
+    oracle = oracle_lib.load()
+    cores = oracle.L.vxo_num_threads()
+    s_log = min(args.cpu_sample_log_n, args.log_n)
+    sc = SynthCircuit(s_log, seed=0x5EED0000, poseidon_percent=args.poseidon_percent)
+    oc = oracle_lib.OracleCircuit(oracle, sc.desc_ptr)
+    t0 = time.perf_counter()
+    proof, tm = oc.prove(sc.witness(), want_timings=True)
+    dt = time.perf_counter() - t0
+    assert oc.verify(proof) == ""
+    scale = float(1 << (args.log_n - s_log))
+    return {
+        "value": 1.0 / (dt * scale), "unit": "proofs/sec", "cores": cores, "kind": "port",
+        "sample": (f"oracle prove() of the same synthetic circuit family at 2^{s_log} rows took {dt:.2f} s on {cores} OpenMP threads "
+                   f"(stages s: {', '.join(f'{k}={v:.2f}' for k, v in tm.items())}); scaled x{int(scale)} (linear in rows) to 2^{args.log_n}"),
+    }

@@ -658,11 +658,17 @@ static Proof prove(const Circuit& c, const std::vector<std::vector<u64>>& wire_v
   }
   // ---- proof of work (fri/prover.rs::fri_proof_of_work; smallest witness => deterministic) ----
   {
+    // upstream's shortcut: pre-load the pending inputs into a copy of the sponge, put the candidate in the
+    // next slot, permute, and look at the LAST squeezed element (what get_challenge() would pop).
+    State base = ch.sponge;
+    for (size_t i = 0; i < ch.input.size(); ++i) base[i] = ch.input[i];
+    const size_t pos = ch.input.size();
     auto ok = [&](u64 cand) {
-      Challenger c2 = ch;
-      c2.observe_element(cand);
-      u64 resp = c2.get_challenge();
-      return __builtin_clzll(resp | 1) >= c.pow_bits && (resp >> (64 - c.pow_bits)) == 0;
+      State s = base;
+      s[pos] = cand;
+      permute(s);
+      u64 resp = s[SPONGE_RATE - 1];
+      return c.pow_bits == 0 || (resp >> (64 - c.pow_bits)) == 0;
     };
     u64 wts = 0;
     if (opt.has_pow_hint) {

@@ -25,12 +25,24 @@ static inline u64 sbox(u64 x) {
 }
 // poseidon.rs::mds_layer (naive form)
 static inline void mds_layer(State& s) {
+  // All MDS entries are < 2^6: accumulate the low and high 32-bit halves of the state separately in
+  // 64-bit lanes (sums < 2^42, auto-vectorisable) and fold once — same value as the u128 form upstream
+  // uses (poseidon.rs::mds_row_shf), without 128-bit multiplies.
+  uint64_t lo[24], hi[24];
+  for (int i = 0; i < 12; ++i) {
+    lo[i] = lo[i + 12] = s[i] & 0xFFFFFFFFULL;
+    hi[i] = hi[i + 12] = s[i] >> 32;
+  }
   State o;
   for (int r = 0; r < 12; ++r) {
-    u128 acc = 0;  // 12 terms < 2^6 * 2^64 each: fits
-    for (int i = 0; i < 12; ++i) acc += (u128)MDS_CIRC[i] * s[(i + r) % 12];
-    acc += (u128)MDS_DIAG[r] * s[r];
-    o[r] = reduce128(acc);
+    u64 al = 0, ah = 0;
+    for (int i = 0; i < 12; ++i) {
+      al += MDS_CIRC[i] * lo[i + r];
+      ah += MDS_CIRC[i] * hi[i + r];
+    }
+    al += MDS_DIAG[r] * lo[r];
+    ah += MDS_DIAG[r] * hi[r];
+    o[r] = reduce128((u128)al + ((u128)ah << 32));
   }
   s = o;
 }

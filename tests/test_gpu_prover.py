@@ -1,0 +1,120 @@
+"""GPU parity tests of the whole-proof path (run with -m gpu on an MI355X).
+
+vx_prove (HIP, through the C ABI) must produce BYTE-IDENTICAL proofs to the oracle (CPU restatement of
+plonky2 v0.2.0's prove_with_partition_witness) on the same circuit and witness — every Merkle cap, every
+opening, every FRI commitment, the same (smallest) proof-of-work witness, the same query openings — at
+sizes the oracle finishes in seconds; at the benchmark sizes (2^20 / 2^21 rows, BASELINE.json configs[1]
+and configs[2]) the oracle's restated VERIFIER must accept the GPU proof (the size-independent property
+the reference's own tests use: prove -> verify, /root/reference/circuits/header_range.rs:167-170).
+"""
+import numpy as np
+import pytest
+
+import oracle_lib
+import vectorx_amd as vx
+from vectorx_amd.synth import SynthCircuit
+
+pytestmark = pytest.mark.gpu
+P = oracle_lib.P
+
+
+@pytest.mark.parametrize("degree_bits,pct", [(3, 50), (4, 100), (5, 0), (6, 50), (7, 70), (9, 50), (10, 20), (12, 50), (13, 50)])
+def test_proof_bytes_identical_to_oracle(ctx, oracle, degree_bits, pct):
+    sc = SynthCircuit(degree_bits, seed=1000 + degree_bits, poseidon_percent=pct)
+    oc = oracle_lib.OracleCircuit(oracle, sc.desc_ptr)
+    gc = vx.Circuit(ctx, sc.desc_ptr)
+    assert (gc.digest() == oc.digest()).all()                      # circuit_digest
+    assert (gc.constants_sigmas_cap() == oc.cap()).all()           # constants_sigmas_commitment
+    gp = gc.prove(sc.witness())
+    op = oc.prove(sc.witness())
+    assert len(gp) == len(op)
+    assert gp == op
+    assert oc.verify(gp) == ""
+    gc.free()
+
+
+def test_pow_hint_and_device_resident_witness(ctx, oracle):
+    sc = SynthCircuit(8, seed=5, poseidon_percent=50)
+    oc = oracle_lib.OracleCircuit(oracle, sc.desc_ptr)
+    gc = vx.Circuit(ctx, sc.desc_ptr)
+    w = sc.witness()
+    ref = gc.prove(w)
+    pw = int(np.frombuffer(ref[-40:-32], dtype="<u8")[0])
+    # the grinder returns the SMALLEST valid witness: no smaller candidate is accepted as a hint
+    for cand in range(max(0, pw - 3), pw):
+        with pytest.raises(vx.VxError):
+            gc.prove(w, pow_witness=cand)
+    assert gc.prove(w, pow_witness=pw) == ref
+    # a different valid witness (as upstream's nondeterministic find_any may pick) gives a proof that
+    # differs only after the PoW field and still verifies; the oracle reproduces it given the same hint
+    cand = pw + 1
+    other = None
+    while other is None:
+        try:
+            other = gc.prove(w, pow_witness=cand)
+        except vx.VxError:
+            cand += 1
+    assert other != ref and oc.verify(other) == ""
+    assert oc.prove(w, pow_hint=cand) == other
+    # witness already resident in HBM
+    d = ctx.alloc(w.nbytes)
+    ctx.upload(d, w)
+    assert gc.prove(dev_ptr=d) == ref
+    ctx.free(d)
+    gc.free()
+
+
+def test_noncanonical_witness_encoding_gives_the_same_proof(ctx):
+    sc = SynthCircuit(6, seed=9, poseidon_percent=50)
+    gc = vx.Circuit(ctx, sc.desc_ptr)
+    w = sc.witness().copy()
+    ref = gc.prove(w)
+    small = w < np.uint64(2**32 - 1)      # x + p still fits in u64
+    w[small] = w[small] + np.uint64(P)
+    assert small.any() and gc.prove(w) == ref
+    gc.free()
+
+
+def test_unsatisfied_witness_is_not_silently_proved(ctx, oracle):
+    sc = SynthCircuit(6, seed=11, poseidon_percent=50)
+    oc = oracle_lib.OracleCircuit(oracle, sc.desc_ptr)
+    gc = vx.Circuit(ctx, sc.desc_ptr)
+    w = sc.witness().copy()
+    w[3, 9] = (int(w[3, 9]) + 1) % P
+    try:
+        bad = gc.prove(w)
+    except vx.VxError as e:          # quotient not a polynomial => non-zero high FRI coefficients
+        assert e.code == vx.VX_E_PROOF
+    else:
+        assert oc.verify(bad) != ""
+    gc.free()
+
+
+def test_prove_argument_errors(ctx):
+    sc = SynthCircuit(4, seed=1, poseidon_percent=50)
+    gc = vx.Circuit(ctx, sc.desc_ptr)
+    with pytest.raises(vx.VxError):
+        gc.prove(np.zeros((135, 8), np.uint64))       # wrong number of rows
+    d = sc.desc
+    old = d.quotient_degree_factor
+    d.quotient_degree_factor = 4
+    with pytest.raises(vx.VxError):
+        vx.Circuit(ctx, sc.desc_ptr)                  # unsupported configuration is refused, not mis-proved
+    d.quotient_degree_factor = old
+    gc.free()
+
+
+@pytest.mark.parametrize("degree_bits", [16, 20])
+def test_large_proof_is_accepted_by_the_restated_verifier(ctx, oracle, degree_bits):
+    """header_range_256 stand-in (2^20 rows) and a mid size: the oracle cannot PROVE these in seconds, but its
+    verifier checks a GPU proof in well under a second."""
+    sc = SynthCircuit(degree_bits, seed=degree_bits, poseidon_percent=50)
+    oc = oracle_lib.OracleCircuit(oracle, sc.desc_ptr)   # the verifier side only uses its cap + digest
+    gc = vx.Circuit(ctx, sc.desc_ptr)
+    gp = gc.prove(sc.witness())
+    assert (gc.digest() == oc.digest()).all()
+    assert oc.verify(gp) == ""
+    bad = bytearray(gp)
+    bad[len(gp) // 2] ^= 1
+    assert oc.verify(bytes(bad)) != ""
+    gc.free()

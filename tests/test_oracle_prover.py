@@ -1,0 +1,106 @@
+"""CPU tests of the oracle's whole-proof path, following the reference's own test pattern
+(/root/reference/circuits/header_range.rs:167-170, circuits/builder/decoder.rs:263-264:
+`circuit.prove(&input)` then `circuit.verify(&proof, ..)`): the restated prover's proofs must be accepted
+by the restated verifier, and any tampering must be rejected.  Also pins the synthetic circuit
+generator (the caller-side stand-in) and the serialisation layout.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+
+import oracle_lib
+from vectorx_amd.synth import SynthCircuit
+
+P = oracle_lib.P
+
+
+@pytest.fixture(scope="module")
+def small(oracle):
+    sc = SynthCircuit(5, seed=7, poseidon_percent=50)
+    oc = oracle_lib.OracleCircuit(oracle, sc.desc_ptr)
+    proof = oc.prove(sc.witness())
+    return sc, oc, proof
+
+
+def test_synthetic_circuit_shape():
+    sc = SynthCircuit(6, seed=1, poseidon_percent=50)
+    d = sc.desc
+    assert (d.num_wires, d.num_routed_wires, d.num_challenges) == (135, 80, 2)        # standard_recursion_config
+    assert (d.rate_bits, d.cap_height, d.pow_bits, d.num_query_rounds) == (3, 4, 16, 28)
+    assert d.quotient_degree_factor == 8 and d.num_selectors == 2 and d.num_constants == 4
+    rc = sc.row_counts()
+    assert rc["poseidon"] + rc["arithmetic"] + rc["noop"] + rc["other"] == 64
+    k = np.frombuffer((ctypes.c_uint64 * 80).from_address(d.k_is), dtype=np.uint64)
+    assert int(k[0]) == 1 and int(k[1]) == 7 and int(k[5]) == 7 ** 5                 # k_is = 7^j
+    w = sc.witness()
+    assert w.shape == (135, 64) and int(w.max()) < P
+    # deterministic in (degree_bits, seed, poseidon_percent)
+    assert (SynthCircuit(6, seed=1, poseidon_percent=50).witness() == w).all()
+    assert not (SynthCircuit(6, seed=2, poseidon_percent=50).witness() == w).all()
+
+
+def test_witness_poseidon_rows_match_the_permutation(oracle):
+    sc = SynthCircuit(5, seed=3, poseidon_percent=100)
+    w = sc.witness()
+    sel1 = np.frombuffer((ctypes.c_uint64 * (84 * 32)).from_address(sc.desc.constants_sigmas), dtype=np.uint64).reshape(84, 32)[1]
+    rows = [i for i in range(32) if int(sel1[i]) == 4]
+    assert len(rows) >= 20
+    for r in rows[:6]:
+        assert (oracle.poseidon_permute(w[0:12, r])[0] == w[12:24, r]).all()
+    # row 2 hashes the public inputs; row 0 (PublicInputGate) carries the hash
+    pi = sc.public_inputs()
+    assert (w[0:4, 2] == pi).all()
+    assert (w[0:4, 0] == oracle.hash_no_pad(pi)).all()
+
+
+def test_prove_verify_round_trip(small):
+    sc, oc, proof = small
+    assert oc.verify(proof) == ""
+    # public inputs are the tail of the serialised proof (write_proof_with_public_inputs)
+    assert np.frombuffer(proof[-32:], dtype="<u8").tolist() == sc.public_inputs().tolist()
+
+
+def test_proof_is_deterministic_and_accepts_a_pow_hint(small):
+    sc, oc, proof = small
+    assert oc.prove(sc.witness()) == proof
+    # pow_witness sits just before the 4 public inputs; re-proving with it as a hint reproduces the proof
+    pw = int(np.frombuffer(proof[-40:-32], dtype="<u8")[0])
+    assert oc.prove(sc.witness(), pow_hint=pw) == proof
+    with pytest.raises(RuntimeError):
+        oc.prove(sc.witness(), pow_hint=pw + 1 if (pw + 1) % 65536 else pw + 2)  # almost surely invalid
+
+
+@pytest.mark.parametrize("offset", [0, 100, 3 * 512 + 8, 3 * 512 + 16 * 200, 20000, 60000, -48, -8])
+def test_tampered_proofs_are_rejected(small, offset):
+    sc, oc, proof = small
+    bad = bytearray(proof)
+    bad[offset] ^= 1
+    assert oc.verify(bytes(bad)) != ""
+
+
+def test_truncated_or_padded_proofs_are_rejected(small):
+    sc, oc, proof = small
+    assert oc.verify(proof[:-1]) != ""
+    assert oc.verify(proof + b"\0") != ""
+    assert oc.verify(b"") != ""
+
+
+def test_unsatisfied_witness_is_rejected(small, oracle):
+    sc, oc, _ = small
+    w = sc.witness().copy()
+    w[3, 9] = (int(w[3, 9]) + 1) % P
+    bad = oc.prove(w)
+    assert oc.verify(bad) != ""
+
+
+@pytest.mark.parametrize("degree_bits,pct", [(3, 50), (4, 0), (6, 100), (7, 30)])
+def test_round_trip_other_shapes(oracle, degree_bits, pct):
+    sc = SynthCircuit(degree_bits, seed=degree_bits * 10 + pct, poseidon_percent=pct)
+    oc = oracle_lib.OracleCircuit(oracle, sc.desc_ptr)
+    proof = oc.prove(sc.witness())
+    assert oc.verify(proof) == ""
+    # a proof for one circuit does not verify against another circuit
+    sc2 = SynthCircuit(degree_bits, seed=999, poseidon_percent=(pct + 37) % 100)  # different gate layout
+    oc2 = oracle_lib.OracleCircuit(oracle, sc2.desc_ptr)
+    assert oc2.verify(proof) != ""
