@@ -3,18 +3,17 @@
 
     python bench.py --gpus N --steps K --warmup W            (N>1: launched by torch.distributed.run)
 
-A "step" is one pass of the hot path over one synthetic header_range_512-shaped witness
-(BASELINE.json configs[2]: n = 2^21 rows x 135 wire columns, blow-up 8, cap height 4) that is already
-resident in HBM when the timed region starts.  With N GPUs every rank proves its own witness
-(proof-level sharding — the reference's MapReduce fan-out, /root/reference/circuits/builder/
-subchain_verification.rs:72-78 — no data-path collective), so scaling is "weak" and `value` is the
-whole-job rate.  One JSON line is printed by rank 0; it carries `roofline` (HIP-event-timed dominant
-HBM-bound kernel family, the coset-LDE NTT) and `cpu_baseline` (the oracle = CPU restatement of
-plonky2 v0.2.0, timed on this box's host cores on a bounded sample).
+A "step" is one pass of the hot path — one whole plonky2 proof (`vx_prove`) — over one synthetic
+header_range_512-shaped witness (BASELINE.json configs[2]: n = 2^21 rows x 135 wire columns, blow-up 8,
+cap height 4, full FRI) that is already resident in HBM when the timed region starts.  With N GPUs every
+rank proves its own witness (proof-level sharding — the reference's MapReduce fan-out,
+/root/reference/circuits/builder/subchain_verification.rs:72-78 — no data-path collective), so scaling is
+"weak" and `value` is the whole-job rate.  One JSON line is printed by rank 0; it carries `roofline`
+(HIP-event-timed coset-LDE NTT kernel family on the library's own stream) and `cpu_baseline` (the oracle =
+CPU restatement of plonky2 v0.2.0, timed on this box's host cores on a bounded sample).
 """
 import argparse
 import json
-import os
 import sys
 import time
 from pathlib import Path
@@ -35,7 +34,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log-n", type=int, default=21, help="log2 trace rows (21 = header_range_512 stand-in)")
     ap.add_argument("--ncols", type=int, default=135)
-    ap.add_argument("--workload", default="auto", choices=["auto", "commit", "prove"])
+    ap.add_argument("--workload", default="prove", choices=["commit", "prove"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-log-n", type=int, default=None,
                     help="rows (log2) of the bounded CPU-baseline sample (default 14 for prove, 17 for commit)")
@@ -61,10 +60,7 @@ def cpu_baseline_commit(args):
     dt = time.perf_counter() - t0
     scale = float(1 << (args.log_n - s_log))  # rows scale linearly (the log factor favours the CPU slightly)
     return {
-        "value": 1.0 / (dt * scale),
-        "unit": "trace commits/sec",
-        "cores": cores,
-        "kind": "port",
+        "value": 1.0 / (dt * scale), "unit": "trace commits/sec", "cores": cores, "kind": "port",
         "sample": f"oracle PolynomialBatch::from_values on [{args.ncols}][2^{s_log}] took {dt:.2f} s with {cores} "
                   f"OpenMP threads; scaled x{int(scale)} to 2^{args.log_n} rows",
     }
@@ -72,33 +68,19 @@ def cpu_baseline_commit(args):
 
 def main():
     args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     import vectorx_amd as vx
+    from vectorx_amd import dist_harness as H
 
+    rank, world, local_rank = H.env_rank()
+    dist = H.init("nccl", local_rank)
     ctx = vx.Context(local_rank)  # no CPU fallback: raises if the HIP library / GPU is missing
     n = 1 << args.log_n
-    workload = args.workload
-    if workload == "auto":
-        workload = "prove" if hasattr(vx, "Circuit") else "commit"
     if args.cpu_sample_log_n is None:
-        args.cpu_sample_log_n = 14 if workload == "prove" else 17
+        args.cpu_sample_log_n = 14 if args.workload == "prove" else 17
+    keep = []
 
-    def barrier():
-        ctx.sync()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        ctx.sync()
-
-    if workload == "commit":
+    if args.workload == "commit":
         host = synth_witness_matrix(0x5EED0000 + rank, args.ncols, n)
         d_in = ctx.alloc(host.nbytes)
         ctx.upload(d_in, host)
@@ -112,27 +94,22 @@ def main():
         metric = "header_range_512 trace commits/sec (PolynomialBatch::from_values of the 135-column wire trace; stage 1 of prove())"
         unit = "trace commits/sec"
         wl_name = f"header_range_512 stand-in: wires commit, n=2^{args.log_n} rows x {args.ncols} cols, blowup 8, cap_height 4"
+        cleanup = lambda: ctx.free(d_in)
     else:
         import bench_prove
-        step, metric, unit, wl_name = bench_prove.make_step(ctx, args, rank)
+        step, metric, unit, wl_name, cleanup = bench_prove.make_step(ctx, args, rank)
 
-    for _ in range(args.warmup):
-        step()
-    ctx.prof_enable(True)
-    ctx.prof_reset()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
+    def sync():
+        ctx.sync()
+        torch.cuda.synchronize()
+
+    def before_timed():
+        ctx.prof_enable(True)
+        ctx.prof_reset()
+
+    dt = H.run_timed(step, args.steps, args.warmup, sync, dist, device=f"cuda:{local_rank}", before_timed=before_timed)
     prof = ctx.prof()
     ctx.prof_enable(False)
-
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
 
     if rank == 0:
         lde = prof.get("lde", {"ms": 0.0, "calls": 0, "alg_bytes": 0.0})
@@ -142,16 +119,17 @@ def main():
             per_launch_bytes = lde["alg_bytes"] / lde["calls"]
             achieved = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9
             roof = {
-                "kernel": "ntt_pass_kernel (coset-LDE family: 8 coset NTTs per column, 2 passes each)",
+                "kernel": "ntt_pass_kernel, coset-LDE launches (each = 8 coset NTTs per column, 2 passes; wires 135 / Z+pp 20 / quotient 16 columns)",
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
                 "alg_bytes_per_launch": per_launch_bytes, "ms_per_launch": round(per_launch_ms, 4),
                 "launches": lde["calls"],
             }
+        agg = H.aggregate(world, args.steps, dt)
         out = {
-            "metric": metric, "value": world * args.steps / dt, "unit": unit,
+            "metric": metric, "value": agg["value"], "unit": unit,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": agg["ms_per_step"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u64 (Goldilocks field, integer modular arithmetic)", "data": "synthetic",
             "config": {"workload": wl_name, "parallelism": f"proof-level x{world} (one witness per GPU, no collective)"},
             "roofline": roof,
@@ -160,11 +138,12 @@ def main():
                                if v["alg_bytes"] and v["ms"]},
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline_commit(args) if workload == "commit" else bench_prove.cpu_baseline(args)
-        print(json.dumps(out))
+            out["cpu_baseline"] = cpu_baseline_commit(args) if args.workload == "commit" else bench_prove.cpu_baseline(args)
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    cleanup()      # free device objects BEFORE the context goes away
     ctx.close()
 
 

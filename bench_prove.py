@@ -29,8 +29,12 @@ def make_step(ctx, args, rank):
           f"(80 routed), blowup 8, cap_height 4, FRI arity 16 / 28 queries / 16 PoW bits; gate rows: {counts['poseidon']} PoseidonGate, "
           f"{counts['arithmetic']} ArithmeticGate(20 ops), {counts['noop']} NoopGate, 1 PublicInputGate, 1 ConstantGate "
           f"(the real 64 map + 63 reduce + 1 outer proof DAG and its gate mix need the Rust circuit builder: SURVEY.md §0.7)")
-    make_step.keepalive = (sc, circuit, d_w, state)
-    return step, metric, unit, wl
+    def cleanup():
+        circuit.free()
+        ctx.free(d_w)
+        sc.free()
+
+    return step, metric, unit, wl, cleanup
 
 
 def cpu_baseline(args):

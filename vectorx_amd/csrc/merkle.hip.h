@@ -26,18 +26,18 @@ __global__ __launch_bounds__(HASH_THREADS) void hash_leaves_colmajor_kernel(
     for (; c + 8 <= ncols; c += 8) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) s[i] = gl_canon(cols[(size_t)(c + i) * col_stride + row]);
-      poseidon_permute(s);
+      poseidon_permute_nc(s);
     }
     if (c < ncols) {
 #pragma unroll
       for (int i = 0; i < 8; ++i)
         if (c + i < ncols) s[i] = gl_canon(cols[(size_t)(c + i) * col_stride + row]);
-      poseidon_permute(s);
+      poseidon_permute_nc(s);
     }
   }
   u64* d = digests + row * 4;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) d[i] = s[i];
+  for (int i = 0; i < 4; ++i) d[i] = gl_canon(s[i]);
 }
 
 // Row-major leaves [nrows][width] (C-ABI vx_merkle_cap and the FRI commit-phase trees, whose leaves
@@ -57,18 +57,18 @@ __global__ __launch_bounds__(HASH_THREADS) void hash_leaves_rowmajor_kernel(
     for (; c + 8 <= width; c += 8) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) s[i] = gl_canon(src[c + i]);
-      poseidon_permute(s);
+      poseidon_permute_nc(s);
     }
     if (c < width) {
 #pragma unroll
       for (int i = 0; i < 8; ++i)
         if (c + i < width) s[i] = gl_canon(src[c + i]);
-      poseidon_permute(s);
+      poseidon_permute_nc(s);
     }
   }
   u64* d = digests + row * 4;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) d[i] = s[i];
+  for (int i = 0; i < 4; ++i) d[i] = gl_canon(s[i]);
 }
 
 // parents[i] = two_to_one(children[2i], children[2i+1])
