@@ -90,6 +90,11 @@ int vx_poseidon_permute(vx_ctx* ctx, uint64_t* states, size_t count);
 int vx_merkle_cap(vx_ctx* ctx, const uint64_t* leaves, size_t n_leaves, size_t width, int cap_height,
                   uint64_t* digests_out, uint64_t* cap_out);
 
+/* Element-wise field arithmetic on the device (testing aid for the hand-written Goldilocks primitives):
+ * op 0: a*b, 1: a+b, 2: a-b, 3: a*b+c (c = a), 4: a^-1 (b ignored), 5: a*b via the non-canonical path then
+ * canonicalised.  Inputs may be non-canonical; outputs canonical. */
+int vx_field_op(vx_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
+
 /* ---- L2: PolynomialBatch handles ------------------------------------------------------------ */
 /* PolynomialBatch::from_values (is_coeffs = 0: values on H, natural order) or from_coeffs
  * (is_coeffs = 1: coefficients, natural order).  cols: column-major [ncols][2^log_n]; src_on_device

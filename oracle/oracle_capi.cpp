@@ -166,6 +166,50 @@ void* vxo_circuit_create(const vxo_circuit_desc* d) {
   c->finalize(std::move(cols));
   return c;
 }
+// VerifierOnlyCircuitData: the verifier needs the circuit parameters, the gate list, k_is and the
+// constants_sigmas CAP (+ the digest derived from it) — not the preprocessed polynomials.  Used by the tests
+// to check GPU proofs at sizes where committing 84 columns x 2^24 rows on the CPU would take minutes.
+void* vxo_circuit_create_verifier(const vxo_circuit_desc* d, const u64* cap) {
+  Circuit* c = new Circuit();
+  c->degree_bits = d->degree_bits;
+  c->num_wires = d->num_wires;
+  c->num_routed_wires = d->num_routed_wires;
+  c->num_challenges = d->num_challenges;
+  c->rate_bits = d->rate_bits;
+  c->cap_height = d->cap_height;
+  c->pow_bits = d->pow_bits;
+  c->num_query_rounds = d->num_query_rounds;
+  c->quotient_degree_factor = d->quotient_degree_factor;
+  for (int i = 0; i < d->num_gates; ++i) {
+    Gate g;
+    g.type = d->gate_types[i];
+    g.param = d->gate_params[i];
+    g.selector_index = d->selector_indices[i];
+    g.group_start = d->group_starts[i];
+    g.group_end = d->group_ends[i];
+    c->gates.push_back(g);
+  }
+  c->num_selectors = d->num_selectors;
+  c->num_constants = d->num_constants;
+  c->k_is.assign(d->k_is, d->k_is + d->num_routed_wires);
+  for (int i = 0; i < d->num_public_inputs; ++i) c->public_inputs.push_back({d->pi_rows[i], d->pi_cols[i]});
+  c->num_gate_constraints = 0;
+  for (const Gate& g : c->gates) c->num_gate_constraints = std::max(c->num_gate_constraints, g.num_constraints());
+  c->compute_fri_params();
+  std::vector<Hash> capv((size_t)1 << d->cap_height);
+  std::vector<u64> pre;
+  for (size_t i = 0; i < capv.size(); ++i)
+    for (int k = 0; k < 4; ++k) {
+      capv[i].e[k] = canon(cap[4 * i + k]);
+      pre.push_back(capv[i].e[k]);
+    }
+  pre.push_back((u64)d->degree_bits);
+  c->constants_sigmas.tree.layers.clear();
+  c->constants_sigmas.tree.layers.push_back(capv);
+  c->constants_sigmas.tree.cap_height = d->cap_height;
+  c->circuit_digest = hash_no_pad(pre.data(), pre.size());
+  return c;
+}
 void vxo_circuit_free(void* c) { delete (Circuit*)c; }
 void vxo_circuit_digest(void* c, u64* out4) { memcpy(out4, ((Circuit*)c)->circuit_digest.e, 32); }
 void vxo_circuit_cap(void* c, u64* out) {

@@ -127,10 +127,13 @@ class Oracle:
 class OracleCircuit:
     """Circuit loaded into the oracle: prove (CPU restatement) and verify (restated plonky2 verifier)."""
 
-    def __init__(self, oracle: "Oracle", desc_ptr):
+    def __init__(self, oracle: "Oracle", desc_ptr, verifier_cap=None):
+        """verifier_cap: build a VERIFIER-ONLY circuit from a constants_sigmas cap (no CPU commitment)."""
         L = oracle.L
         L.vxo_circuit_create.restype = _vp
         L.vxo_circuit_create.argtypes = [_vp]
+        L.vxo_circuit_create_verifier.restype = _vp
+        L.vxo_circuit_create_verifier.argtypes = [_vp, _vp]
         L.vxo_circuit_free.argtypes = [_vp]
         L.vxo_circuit_digest.argtypes = [_vp, _vp]
         L.vxo_circuit_cap.argtypes = [_vp, _vp]
@@ -141,7 +144,11 @@ class OracleCircuit:
         self.L = L
         self.desc = ctypes.cast(desc_ptr, ctypes.POINTER(ctypes.c_int32))
         self.cap_height = int(self.desc[5])
-        self._h = L.vxo_circuit_create(ctypes.cast(desc_ptr, _vp))
+        if verifier_cap is None:
+            self._h = L.vxo_circuit_create(ctypes.cast(desc_ptr, _vp))
+        else:
+            cap = np.ascontiguousarray(verifier_cap, np.uint64)
+            self._h = L.vxo_circuit_create_verifier(ctypes.cast(desc_ptr, _vp), cap.ctypes.data)
 
     def free(self):
         if self._h:

@@ -104,17 +104,31 @@ def test_prove_argument_errors(ctx):
     gc.free()
 
 
-@pytest.mark.parametrize("degree_bits", [16, 20])
+@pytest.mark.parametrize("degree_bits", [16, 20, 21])
 def test_large_proof_is_accepted_by_the_restated_verifier(ctx, oracle, degree_bits):
-    """header_range_256 stand-in (2^20 rows) and a mid size: the oracle cannot PROVE these in seconds, but its
-    verifier checks a GPU proof in well under a second."""
+    """2^16 (full oracle cross-check of the preprocessed commitment), header_range_256 stand-in (2^20 rows,
+    BASELINE.json configs[1]) and header_range_512 stand-in (2^21 rows, configs[2]): the oracle cannot PROVE
+    these in seconds, but its restated verifier checks a GPU proof in well under a second.  At 2^20 / 2^21 the
+    verifier-side circuit is built from the constants_sigmas cap (VerifierOnlyCircuitData) — committing 84
+    columns x 2^24 rows on the CPU would take minutes; the cap itself is pinned against the oracle at <= 2^16."""
     sc = SynthCircuit(degree_bits, seed=degree_bits, poseidon_percent=50)
-    oc = oracle_lib.OracleCircuit(oracle, sc.desc_ptr)   # the verifier side only uses its cap + digest
     gc = vx.Circuit(ctx, sc.desc_ptr)
-    gp = gc.prove(sc.witness())
+    if degree_bits <= 16:
+        oc = oracle_lib.OracleCircuit(oracle, sc.desc_ptr)
+        assert (gc.constants_sigmas_cap() == oc.cap()).all()
+    else:
+        oc = oracle_lib.OracleCircuit(oracle, sc.desc_ptr, verifier_cap=gc.constants_sigmas_cap())
     assert (gc.digest() == oc.digest()).all()
+    w = sc.witness()
+    d = ctx.alloc(w.nbytes)
+    ctx.upload(d, w)
+    sc.release_host_buffers(witness=True, preprocessed=True)
+    gp = gc.prove(dev_ptr=d)
     assert oc.verify(gp) == ""
-    bad = bytearray(gp)
-    bad[len(gp) // 2] ^= 1
-    assert oc.verify(bytes(bad)) != ""
+    for off in (len(gp) // 2, 100, len(gp) - 50):
+        bad = bytearray(gp)
+        bad[off] ^= 1
+        assert oc.verify(bytes(bad)) != ""
+    assert gc.prove(dev_ptr=d) == gp          # deterministic at full size too
+    ctx.free(d)
     gc.free()

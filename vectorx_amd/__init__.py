@@ -20,7 +20,7 @@ from pathlib import Path
 import numpy as np
 
 _PKG = Path(__file__).resolve().parent
-_LIB_PATH = _PKG / "libvxprover.so"
+_LIB_PATH = Path(os.environ.get("VXPROVER_LIB", _PKG / "libvxprover.so"))  # override = kernel A/B experiments only
 P = 0xFFFFFFFF00000001
 
 VX_OK, VX_E_INVALID, VX_E_NO_DEVICE, VX_E_HIP, VX_E_NOMEM, VX_E_PROOF = 0, -1, -2, -3, -4, -5
@@ -73,6 +73,7 @@ _SIGNATURES = {
     "vx_ntt_batch_dev": (_i, [_vp, _vp, _vp, _i, _sz, _i, _u64]),
     "vx_poseidon_permute": (_i, [_vp, _vp, _sz]),
     "vx_merkle_cap": (_i, [_vp, _vp, _sz, _sz, _i, _vp, _vp]),
+    "vx_field_op": (_i, [_vp, _i, _vp, _vp, _vp, _sz]),
     "vx_batch_commit": (_i, [_vp, _vp, _i, _i, _sz, _i, _i, _i, ctypes.POINTER(_vp)]),
     "vx_batch_free": (None, [_vp]),
     "vx_batch_cap": (_i, [_vp, _vp]),
@@ -194,6 +195,12 @@ class Context:
 
     def ntt_batch_dev(self, src: int, dst: int, log_n: int, ncols: int, kind: int, shift: int = 7):
         _chk(lib().vx_ntt_batch_dev(self._h, src, dst, log_n, ncols, kind, shift))
+
+    def field_op(self, op: int, a, b) -> np.ndarray:
+        a, b = _as_u64(a), _as_u64(b)
+        out = np.empty_like(a)
+        _chk(lib().vx_field_op(self._h, op, a.ctypes.data, b.ctypes.data, out.ctypes.data, a.size))
+        return out
 
     def poseidon_permute(self, states: np.ndarray) -> np.ndarray:
         a = _as_u64(states).reshape(-1, 12).copy()

@@ -16,10 +16,27 @@ typedef uint32_t u32;
 #define GLD __device__ __forceinline__
 
 GLD u64 gl_canon(u64 x) { return x >= GL_P ? x - GL_P : x; }
+
+// ---- instruction-count-minimal building blocks (gfx950: every VOP3 / multiply-class instruction costs
+// about the same issue time, so fewer instructions is the only lever; see tools/ubench_int.hip).
+// Carries travel in SGPR pairs (lane masks) produced / consumed by the *_co instructions, which hipcc does
+// not use on its own for 64-bit compare-and-fix sequences.
+GLD u64 gl_pack(u32 lo, u32 hi) { return ((u64)hi << 32) | lo; }
+
+// a, b canonical  ->  (a + b) mod p, canonical.   S = a+b in [0, 2p-2];  S >= p  <=>  a carry out of
+// (a+b) or of (a+b)+EPS;  in that case the answer is (S + EPS) mod 2^64.
 GLD u64 gl_add(u64 a, u64 b) {
-  u64 s = a + b;
-  if (s < a) s += GL_EPS;
-  return gl_canon(s);
+  u32 s0, s1, t0, t1;
+  u64 c0, c1, c2, c3;
+  asm("v_add_co_u32_e64 %0, %1, %2, %3" : "=v"(s0), "=s"(c0) : "v"((u32)a), "v"((u32)b));
+  asm("v_addc_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(s1), "=s"(c1) : "v"((u32)(a >> 32)), "v"((u32)(b >> 32)), "s"(c0));
+  asm("v_add_co_u32_e64 %0, %1, %2, -1" : "=v"(t0), "=s"(c2) : "v"(s0));
+  asm("v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(t1), "=s"(c3) : "v"(s1), "s"(c2));
+  const u64 sel = c1 | c3;
+  u32 r0, r1;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r0) : "v"(s0), "v"(t0), "s"(sel));
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r1) : "v"(s1), "v"(t1), "s"(sel));
+  return gl_pack(r0, r1);
 }
 GLD u64 gl_sub(u64 a, u64 b) {
   u64 d = a - b;
@@ -27,25 +44,86 @@ GLD u64 gl_sub(u64 a, u64 b) {
 }
 GLD u64 gl_neg(u64 a) { return a ? GL_P - a : 0; }
 GLD u64 gl_dbl(u64 a) { return gl_add(a, a); }
+
+// 64 x 64 -> 128 with four v_mad_u64_u32; the 32-bit addends are small enough that no step can carry.
+GLD void gl_mul128(u64 a, u64 b, u64& lo, u64& hi) {
+  const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+  const u64 p00 = (u64)a0 * b0;
+  const u64 p01 = (u64)a0 * b1 + (p00 >> 32);
+  const u64 p10 = (u64)a1 * b0 + (u32)p01;
+  hi = (u64)a1 * b1 + (p01 >> 32) + (p10 >> 32);
+  lo = (p10 << 32) | (u32)p00;
+}
+// hi*2^64 + lo  ->  SOME u64 congruent to it mod p (not necessarily canonical).
+//   x = lo + hl*EPS - hh   (hi = hh*2^32 + hl, 2^64 = EPS, 2^96 = -1)
+//   (T, cT) = hl*EPS + lo  in one v_mad_u64_u32 with carry-out;  u = T - hh with borrow bw;
+//   result = u + (cT - bw)*EPS  (mod 2^64): the four (cT, bw) cases are exact — when both are set the wrapped
+//   u already equals T + 2^64 - hh, a valid representative because 2^64 = EPS (mod p).
+GLD u64 gl_reduce128_nc(u64 lo, u64 hi) {
+  const u32 hh = (u32)(hi >> 32), hl = (u32)hi;
+  u64 T, cT, b0, bw;
+  const u32 eps = 0xFFFFFFFFu;
+  asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(T), "=s"(cT) : "v"(hl), "v"(eps), "v"(lo));
+  u32 u0, u1;
+  asm("v_sub_co_u32_e64 %0, %1, %2, %3" : "=v"(u0), "=s"(b0) : "v"((u32)T), "v"(hh));
+  asm("v_subbrev_co_u32_e64 %0, %1, 0, %2, %3" : "=v"(u1), "=s"(bw) : "v"((u32)(T >> 32)), "s"(b0));
+  const u64 m1 = cT & ~bw, m2 = bw & ~cT;  // +EPS  /  -EPS (= + 0xFFFFFFFF00000001)
+  u32 d0, d1;
+  asm("v_cndmask_b32_e64 %0, 0, -1, %1" : "=v"(d0) : "s"(m1));
+  asm("v_cndmask_b32_e64 %0, %1, 1, %2" : "=v"(d0) : "v"(d0), "s"(m2));
+  asm("v_cndmask_b32_e64 %0, 0, -1, %1" : "=v"(d1) : "s"(m2));
+  return gl_pack(u0, u1) + gl_pack(d0, d1);
+}
 // x = hi*2^64 + lo  ->  x mod p (canonical)
-GLD u64 gl_reduce128(u64 lo, u64 hi) {
-  u64 hh = hi >> 32, hl = hi & GL_EPS;
-  u64 t = lo - hh;
-  if (lo < hh) t -= GL_EPS;
-  u64 m = (hl << 32) - hl;  // hl * (2^32-1)
-  u64 r = t + m;
-  if (r < m) r += GL_EPS;
-  return gl_canon(r);
+GLD u64 gl_reduce128(u64 lo, u64 hi) { return gl_canon(gl_reduce128_nc(lo, hi)); }
+// Fused multiply(-add)-reduce, 16 (18) VALU instructions, no register-pair shuffling:
+//   a*b (+c) = p00 + (p10 + cM*2^64)*2^32 + p11*2^64   with p10 = a1*b0 + a0*b1 (carry-out cM),
+//   lo64 = p00 + (p10 mod 2^32)*2^32,  hi64 = p11 + (p10 >> 32) + carries = hh*2^32 + hl,
+//   result = lo64 + hl*EPS - (hh + cM)       (2^64 = EPS, 2^96 = -1 mod p; cM rides in as the borrow-in
+//   of the final subtraction), fixed up exactly as in gl_reduce128_nc.
+template <bool WITH_ADDEND>
+GLD u64 gl_mulmad_nc(u64 a, u64 b, u64 c) {
+  const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+  u64 p00, c0 = 0;
+  if (WITH_ADDEND)
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(p00), "=s"(c0) : "v"(a0), "v"(b0), "v"(c));
+  else
+    p00 = (u64)a0 * b0;
+  const u64 p01 = (u64)a0 * b1;
+  const u64 p11 = (u64)a1 * b1;
+  u64 p10, cM;
+  asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(p10), "=s"(cM) : "v"(a1), "v"(b0), "v"(p01));
+  u32 lo1, hl, hh;
+  u64 cL, cH, cX;
+  asm("v_add_co_u32_e64 %0, %1, %2, %3" : "=v"(lo1), "=s"(cL) : "v"((u32)(p00 >> 32)), "v"((u32)p10));
+  asm("v_addc_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(hl), "=s"(cH) : "v"((u32)p11), "v"((u32)(p10 >> 32)), "s"(cL));
+  asm("v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(hh), "=s"(cX) : "v"((u32)(p11 >> 32)), "s"(cH));
+  if (WITH_ADDEND) {  // the addend's carry out of p00 is worth 2^64: one more unit of hi64
+    u64 cH2, cX2;
+    asm("v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(hl), "=s"(cH2) : "v"(hl), "s"(c0));
+    asm("v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(hh), "=s"(cX2) : "v"(hh), "s"(cH2));
+  }
+  const u64 lo = gl_pack((u32)p00, lo1);
+  u64 T, cT, bb, bw;
+  const u32 eps = 0xFFFFFFFFu;
+  asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(T), "=s"(cT) : "v"(hl), "v"(eps), "v"(lo));
+  u32 u0, u1;
+  asm("v_subb_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(u0), "=s"(bb) : "v"((u32)T), "v"(hh), "s"(cM));
+  asm("v_subbrev_co_u32_e64 %0, %1, 0, %2, %3" : "=v"(u1), "=s"(bw) : "v"((u32)(T >> 32)), "s"(bb));
+  const u64 m1 = cT & ~bw, m2 = bw & ~cT;
+  u32 d0, d1;
+  asm("v_cndmask_b32_e64 %0, 0, -1, %1" : "=v"(d0) : "s"(m1));
+  asm("v_cndmask_b32_e64 %0, %1, 1, %2" : "=v"(d0) : "v"(d0), "s"(m2));
+  asm("v_cndmask_b32_e64 %0, 0, -1, %1" : "=v"(d1) : "s"(m2));
+  return gl_pack(u0, u1) + gl_pack(d0, d1);
 }
-GLD u64 gl_mul(u64 a, u64 b) { return gl_reduce128(a * b, __umul64hi(a, b)); }
+GLD u64 gl_mul_nc(u64 a, u64 b) { return gl_mulmad_nc<false>(a, b, 0); }
+GLD u64 gl_mul(u64 a, u64 b) { return gl_canon(gl_mul_nc(a, b)); }
 GLD u64 gl_sqr(u64 a) { return gl_mul(a, a); }
-// a*b + c, c canonical
-GLD u64 gl_mad(u64 a, u64 b, u64 c) {
-  u64 lo = a * b, hi = __umul64hi(a, b);
-  u64 l2 = lo + c;
-  hi += (l2 < lo);
-  return gl_reduce128(l2, hi);
-}
+// a*b + c (any u64 representatives) -> some representative
+GLD u64 gl_mad_nc(u64 a, u64 b, u64 c) { return gl_mulmad_nc<true>(a, b, c); }
+// a*b + c, canonical result
+GLD u64 gl_mad(u64 a, u64 b, u64 c) { return gl_canon(gl_mad_nc(a, b, c)); }
 GLD u64 gl_pow(u64 b, u64 e) {
   u64 r = 1;
   while (e) {

@@ -23,7 +23,7 @@
 #pragma once
 #include "goldilocks.hip.h"
 
-#define NTT_THREADS 256
+#define NTT_THREADS 512
 #define NTT_MAX_TILE_LOG 13  // 8192 elements = 64 KiB of LDS
 #define ROOT_TABLE_LOG 24    // root tables cover sizes up to 2^24
 #define ROOT_SPLIT 12

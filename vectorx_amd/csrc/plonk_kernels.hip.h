@@ -177,7 +177,7 @@ GLD void acc_push(AlphaAcc& a, const QuotientParams& p, u64 term) {
 
 #define UNUSED_SELECTOR_U64 0xFFFFFFFFULL
 
-__global__ __launch_bounds__(256) void quotient_kernel(QuotientParams p) {
+__global__ __launch_bounds__(256, 4) void quotient_kernel(QuotientParams p) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= p.N) return;
   const size_t N = p.N;

@@ -30,44 +30,12 @@ __constant__ u64 POSEIDON_FAST_VS[22][11] = VX_FAST_PARTIAL_VS_INIT;
 #define POSEIDON_RATE 8
 
 // ---- non-canonical ("nc") arithmetic: values are any u64 congruent to the field element ----------
-GLD void gl_mul128(u64 a, u64 b, u64& lo, u64& hi) {
-  const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
-  const u64 p00 = (u64)a0 * b0;
-  const u64 p01 = (u64)a0 * b1 + (p00 >> 32);
-  const u64 p10 = (u64)a1 * b0 + (u32)p01;
-  hi = (u64)a1 * b1 + (p01 >> 32) + (p10 >> 32);
-  lo = (p10 << 32) | (u32)p00;
-}
-// hi*2^64 + lo  ->  some u64 congruent mod p
-GLD u64 gl_reduce128_nc(u64 lo, u64 hi) {
-  const u64 hh = hi >> 32, hl = hi & GL_EPS;
-  u64 t = lo - hh;
-  if (lo < hh) t -= GL_EPS;
-  const u64 m = (hl << 32) - hl;
-  u64 r = t + m;
-  if (r < m) r += GL_EPS;
-  return r;
-}
-GLD u64 gl_mul_nc(u64 a, u64 b) {
-  u64 lo, hi;
-  gl_mul128(a, b, lo, hi);
-  return gl_reduce128_nc(lo, hi);
-}
 // a: any u64, b: CANONICAL (< p)  ->  a + b (nc).  One carry fix suffices because b <= 2^64 - 2^32.
 GLD u64 gl_add_nc_c(u64 a, u64 b) {
   u64 s = a + b;
   if (s < a) s += GL_EPS;
   return s;
 }
-// a*b + c (all nc)
-GLD u64 gl_mad_nc(u64 a, u64 b, u64 c) {
-  u64 lo, hi;
-  gl_mul128(a, b, lo, hi);
-  const u64 l2 = lo + c;
-  hi += (l2 < lo);  // hi <= 2^64 - 2: no overflow
-  return gl_reduce128_nc(l2, hi);
-}
-
 GLD u64 poseidon_sbox_nc(u64 x) {
   const u64 x2 = gl_mul_nc(x, x), x4 = gl_mul_nc(x2, x2), x3 = gl_mul_nc(x, x2);
   return gl_mul_nc(x3, x4);
@@ -117,15 +85,17 @@ struct acc192 {
 GLD void acc_mul_add(acc192& A, u64 a, u64 b) {
   u64 lo, hi;
   gl_mul128(a, b, lo, hi);
-  const u64 l2 = A.lo + lo;
-  const u64 carry = l2 < lo;
-  const u64 h1 = A.hi + hi;
-  const u32 c1 = h1 < hi;
-  const u64 h2 = h1 + carry;
-  const u32 c2 = h2 < carry;
-  A.lo = l2;
-  A.hi = h2;
-  A.c += c1 + c2;
+  // 160-bit add with one carry chain through SGPR lane masks (5 instructions)
+  u32 l0, l1, h0, h1, cc;
+  u64 c0, c1, c2, c3, c4;
+  asm("v_add_co_u32_e64 %0, %1, %2, %3" : "=v"(l0), "=s"(c0) : "v"((u32)A.lo), "v"((u32)lo));
+  asm("v_addc_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(l1), "=s"(c1) : "v"((u32)(A.lo >> 32)), "v"((u32)(lo >> 32)), "s"(c0));
+  asm("v_addc_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(h0), "=s"(c2) : "v"((u32)A.hi), "v"((u32)hi), "s"(c1));
+  asm("v_addc_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(h1), "=s"(c3) : "v"((u32)(A.hi >> 32)), "v"((u32)(hi >> 32)), "s"(c2));
+  asm("v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(cc), "=s"(c4) : "v"(A.c), "s"(c3));
+  A.lo = gl_pack(l0, l1);
+  A.hi = gl_pack(h0, h1);
+  A.c = cc;
 }
 // lo + hi*2^64 + c*2^128,  2^128 = -2^32 (mod p)
 GLD u64 acc_reduce_nc(const acc192& A) {

@@ -233,6 +233,46 @@ int vx_merkle_cap(vx_ctx* c, const uint64_t* leaves, size_t n_leaves, size_t wid
   return rc;
 }
 
+__global__ void field_op_kernel(int op, const u64* __restrict__ a, const u64* __restrict__ b, u64* __restrict__ out, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const u64 xr = a[i], yr = b[i];
+  const u64 x = gl_canon(xr), y = gl_canon(yr);
+  u64 r = 0;
+  switch (op) {
+    case 0: r = gl_mul(xr, yr); break;          // multiply accepts any representatives
+    case 1: r = gl_add(x, y); break;            // add / sub are defined on canonical inputs
+    case 2: r = gl_sub(x, y); break;
+    case 3: r = gl_mad(xr, yr, xr); break;
+    case 4: r = x ? gl_inv(x) : 0; break;
+    default: r = gl_canon(gl_mul_nc(xr, yr)); break;
+  }
+  out[i] = r;
+}
+
+int vx_field_op(vx_ctx* c, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
+  if (!c || !a || !b || !out) return vx_fail(VX_E_INVALID, "vx_field_op: NULL argument");
+  if (op < 0 || op > 5) return vx_fail(VX_E_INVALID, "vx_field_op: op %d", op);
+  if (!n) return VX_OK;
+  HIPCHK(hipSetDevice(c->device));
+  u64 *da = nullptr, *db = nullptr, *dout = nullptr;
+  HIPCHK(hipMalloc(&da, n * 8));
+  HIPCHK(hipMalloc(&db, n * 8));
+  HIPCHK(hipMalloc(&dout, n * 8));
+  hipError_t e = hipMemcpyAsync(da, a, n * 8, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(db, b, n * 8, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(field_op_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, op, da, db, dout, n);
+    e = hipMemcpyAsync(out, dout, n * 8, hipMemcpyDeviceToHost, c->stream);
+  }
+  hipError_t e2 = hipStreamSynchronize(c->stream);
+  hipFree(da);
+  hipFree(db);
+  hipFree(dout);
+  if (e != hipSuccess || e2 != hipSuccess) return vx_fail(VX_E_HIP, "vx_field_op: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+  return VX_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // L2
 // ---------------------------------------------------------------------------------------------
