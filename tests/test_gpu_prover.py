@@ -35,11 +35,13 @@ def test_proof_bytes_identical_to_oracle(ctx, oracle, degree_bits, pct):
 
 def test_pow_hint_and_device_resident_witness(ctx, oracle):
     sc = SynthCircuit(8, seed=5, poseidon_percent=50)
+    sc.desc.pow_bits = 6       # 1 in 64 candidates is valid: the "next valid witness" search below stays short
     oc = oracle_lib.OracleCircuit(oracle, sc.desc_ptr)
     gc = vx.Circuit(ctx, sc.desc_ptr)
     w = sc.witness()
     ref = gc.prove(w)
     pw = int(np.frombuffer(ref[-40:-32], dtype="<u8")[0])
+    assert oc.prove(w) == ref
     # the grinder returns the SMALLEST valid witness: no smaller candidate is accepted as a hint
     for cand in range(max(0, pw - 3), pw):
         with pytest.raises(vx.VxError):
