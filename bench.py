@@ -118,10 +118,20 @@ def main():
             per_launch_ms = lde["ms"] / lde["calls"]
             per_launch_bytes = lde["alg_bytes"] / lde["calls"]
             achieved = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9
+            # HBM bytes per launch: PMC counters cannot be read from inside this process, so the measured
+            # traffic-per-algorithmic-byte ratio of this kernel (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
+            # passes, gfx950 correction applied — profiles/r01_pmc_traffic.md) scales the launch's algorithmic bytes.
+            traffic = None
+            try:
+                pmc = json.loads((ROOT / "profiles" / "pmc_traffic_lde.json").read_text())
+                traffic = per_launch_bytes * float(pmc["traffic_bytes_per_alg_byte"])
+            except Exception:
+                pass
             roof = {
                 "kernel": "ntt_pass_kernel, coset-LDE launches (each = 8 coset NTTs per column, 2 passes; wires 135 / Z+pp 20 / quotient 16 columns)",
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                "traffic_source": "profiles/r01_pmc_traffic.md (PMC FETCH_SIZE+WRITE_SIZE ratio x algorithmic bytes)",
                 "alg_bytes_per_launch": per_launch_bytes, "ms_per_launch": round(per_launch_ms, 4),
                 "launches": lde["calls"],
             }
