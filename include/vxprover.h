@@ -117,6 +117,20 @@ int vx_batch_lde_rows(vx_batch* b, size_t row0, size_t nrows, uint64_t* out);
 /* PolynomialCoeffs::to_extension().eval(zeta) for every column: out [ncols][2]. */
 int vx_batch_eval_ext(vx_batch* b, const uint64_t zeta[2], uint64_t* out);
 
+/* ---- L2 pieces on caller-owned DEVICE buffers (building blocks of the multi-GPU sharded commitment,
+ * vectorx_amd/sharded.py: column-shard iNTT+LDE -> one all-to-all -> row-shard leaf hashing + subtrees).
+ * vx_lde_columns_dev: values on H (natural order, column-major [ncols][2^log_n]) -> coset LDE
+ *   [ncols][2^(log_n+rate_bits)] in bit-reversed row order (the layout of vx_batch); coeffs_out (optional,
+ *   [ncols][2^log_n], bit-reversed coefficient order) receives the interpolated coefficients.
+ * vx_hash_rows_dev: MerkleTree::new over `nrows` leaves whose values are column-major with column stride
+ *   `col_stride` (u64 elements); writes the 2^cap_height cap digests to cap_out (HOST) and, if tree_out (device,
+ *   merkle digest count x 4 u64, see vx_merkle_digest_count) is non-NULL, every level. */
+int vx_lde_columns_dev(vx_ctx* ctx, const uint64_t* values, int log_n, size_t ncols, int rate_bits, uint64_t* lde_out,
+                       uint64_t* coeffs_out);
+int vx_hash_rows_dev(vx_ctx* ctx, const uint64_t* cols, size_t col_stride, size_t nrows, size_t ncols, int cap_height,
+                     uint64_t* tree_out, uint64_t* cap_out);
+size_t vx_merkle_digest_count(size_t n_leaves, int cap_height);
+
 /* ---- L3: circuits and whole proofs ------------------------------------------------------------
  * vx_circuit_desc carries what plonky2's CommonCircuitData + ProverOnlyCircuitData hold for the hot
  * path (plonk/circuit_data.rs): the configuration, the gate list with its selector grouping

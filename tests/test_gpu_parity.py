@@ -178,3 +178,20 @@ def test_commit_wire_shaped_batch_properties(ctx, oracle):
     e = oracle.commit(vals, 3, 4, want_leaves=False)
     assert (b.cap() == e["cap"]).all()
     b.free()
+
+
+def test_sharded_commit_single_rank_matches_batch(ctx, oracle):
+    """vectorx_amd.sharded on one GPU (world 1: the collective steps are no-ops) — exercises the device-buffer
+    entry points vx_lde_columns_dev / vx_hash_rows_dev that the multi-GPU path is built from; the N>1 index logic
+    is covered on CPU by tests/test_multiproc.py (gloo)."""
+    import torch
+    from vectorx_amd import sharded
+    rng = np.random.default_rng(77)
+    log_n, ncols = 12, 21
+    vals = rand_field(rng, (ncols, 1 << log_n))
+    be = sharded.GpuBackend(ctx, torch.device("cuda", 0))
+    cap, rows = sharded.commit_sharded(be, None, be.from_host(vals), ncols, log_n, 3, 4)
+    e = oracle.commit(vals, 3, 4)
+    assert (cap == e["cap"]).all()
+    got = rows.cpu().numpy().view(np.uint64)
+    assert (got.T[:64] == e["leaves"][:64]).all() and (got.T[-64:] == e["leaves"][-64:]).all()

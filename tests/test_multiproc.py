@@ -37,3 +37,31 @@ def test_single_process_harness():
     dt = H.run_timed(lambda: calls.append(1), steps=3, warmup=2, sync=lambda: None, dist=None)
     assert len(calls) == 5 and dt > 0
     assert abs(H.aggregate(4, 3, 0.5)["value"] - 24.0) < 1e-12
+
+
+def _run_workers(script, nproc):
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), str(ROOT / "tests" / script)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=str(ROOT))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def test_sharded_commit_gloo_world2():
+    """column-shard LDE -> all-to-all -> row-shard hashing -> cap all-gather == the unsharded commitment"""
+    out = _run_workers("_mp_sharded_worker.py", 2)
+    assert out["world"] == 2 and all(ok_cap and ok_rows for _, ok_cap, ok_rows in out["results"])
+
+
+def test_sharded_commit_gloo_world4():
+    out = _run_workers("_mp_sharded_worker.py", 4)
+    assert out["world"] == 4 and all(ok_cap and ok_rows for _, ok_cap, ok_rows in out["results"])
+
+
+def test_sharded_column_blocks():
+    from vectorx_amd import sharded
+    per, blocks = sharded.column_blocks(135, 4)
+    assert per == 34 and blocks == [(0, 34), (34, 68), (68, 102), (102, 135)]
+    per, blocks = sharded.column_blocks(20, 8)
+    assert per == 3 and blocks[6] == (18, 20) and blocks[7] == (20, 20)     # trailing ranks own only padding

@@ -82,6 +82,9 @@ _SIGNATURES = {
     "vx_batch_digests": (_i, [_vp, _vp]),
     "vx_batch_lde_rows": (_i, [_vp, _sz, _sz, _vp]),
     "vx_batch_eval_ext": (_i, [_vp, _vp, _vp]),
+    "vx_lde_columns_dev": (_i, [_vp, _vp, _i, _sz, _i, _vp, _vp]),
+    "vx_hash_rows_dev": (_i, [_vp, _vp, _sz, _sz, _sz, _i, _vp, _vp]),
+    "vx_merkle_digest_count": (_sz, [_sz, _i]),
     "vx_circuit_create": (_i, [_vp, _vp, ctypes.POINTER(_vp)]),
     "vx_circuit_free": (None, [_vp]),
     "vx_circuit_digest": (_i, [_vp, _vp]),
@@ -195,6 +198,14 @@ class Context:
 
     def ntt_batch_dev(self, src: int, dst: int, log_n: int, ncols: int, kind: int, shift: int = 7):
         _chk(lib().vx_ntt_batch_dev(self._h, src, dst, log_n, ncols, kind, shift))
+
+    def lde_columns_dev(self, values_ptr: int, log_n: int, ncols: int, rate_bits: int, lde_ptr: int, coeffs_ptr: int = 0):
+        _chk(lib().vx_lde_columns_dev(self._h, values_ptr, log_n, ncols, rate_bits, lde_ptr, coeffs_ptr or None))
+
+    def hash_rows_dev(self, cols_ptr: int, col_stride: int, nrows: int, ncols: int, cap_height: int, tree_ptr: int = 0):
+        cap = np.empty((1 << cap_height, 4), dtype=np.uint64)
+        _chk(lib().vx_hash_rows_dev(self._h, cols_ptr, col_stride, nrows, ncols, cap_height, tree_ptr or None, cap.ctypes.data))
+        return cap
 
     def field_op(self, op: int, a, b) -> np.ndarray:
         a, b = _as_u64(a), _as_u64(b)

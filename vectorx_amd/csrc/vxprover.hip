@@ -389,6 +389,61 @@ int vx_batch_eval_ext(vx_batch* b, const uint64_t zeta[2], uint64_t* out) {
   return rc;
 }
 
+int vx_lde_columns_dev(vx_ctx* c, const uint64_t* values, int log_n, size_t ncols, int rate_bits, uint64_t* lde_out,
+                       uint64_t* coeffs_out) {
+  if (!c || !values || !lde_out) return vx_fail(VX_E_INVALID, "vx_lde_columns_dev: NULL argument");
+  if (log_n < 1 || rate_bits < 0 || rate_bits > 4 || log_n + rate_bits > ROOT_TABLE_LOG)
+    return vx_fail(VX_E_INVALID, "vx_lde_columns_dev: log_n=%d rate_bits=%d unsupported", log_n, rate_bits);
+  if (ncols == 0) return VX_OK;
+  HIPCHK(hipSetDevice(c->device));
+  using namespace vxh;
+  const size_t n = (size_t)1 << log_n, N = n << rate_bits;
+  u64* coeffs = coeffs_out;
+  if (!coeffs && c->pool_alloc((void**)&coeffs, n * ncols * 8) != hipSuccess) return vx_fail(VX_E_NOMEM, "vx_lde_columns_dev: out of device memory");
+  int rc = run_ntt(c, values, coeffs, n, n, 0, 0, log_n, ncols, 1, true, false, nullptr, 0, inv((u64)n % P), "intt", 16.0 * n * ncols);
+  if (rc == VX_OK) {
+    const int nz = 1 << rate_bits;
+    std::vector<u64> shifts(nz);
+    u64 wN = root_of_unity(log_n + rate_bits);
+    for (int z = 0; z < nz; ++z) shifts[z] = mul(7, pow(wN, reverse_bits((size_t)z, rate_bits)));
+    u64* tab = nullptr;
+    rc = get_scale_tables(c, log_n, log_n / 2, shifts, 1, &tab);
+    if (rc == VX_OK)
+      rc = run_ntt(c, coeffs, lde_out, n, N, 0, n, log_n, ncols, nz, false, true, tab, log_n / 2, 1, "lde", (double)ncols * 8.0 * ((double)n + N));
+  }
+  hipError_t e = hipStreamSynchronize(c->stream);
+  if (!coeffs_out) c->pool_free(coeffs);
+  if (rc == VX_OK && e != hipSuccess) rc = vx_fail(VX_E_HIP, "vx_lde_columns_dev: %s", hipGetErrorString(e));
+  return rc;
+}
+
+size_t vx_merkle_digest_count(size_t n_leaves, int cap_height) { return merkle_tree_digest_count(n_leaves, cap_height); }
+
+int vx_hash_rows_dev(vx_ctx* c, const uint64_t* cols, size_t col_stride, size_t nrows, size_t ncols, int cap_height,
+                     uint64_t* tree_out, uint64_t* cap_out) {
+  if (!c || !cols || !cap_out) return vx_fail(VX_E_INVALID, "vx_hash_rows_dev: NULL argument");
+  if (nrows == 0 || (nrows & (nrows - 1)) || ((size_t)1 << cap_height) > nrows || cap_height < 0)
+    return vx_fail(VX_E_INVALID, "vx_hash_rows_dev: nrows must be a power of two >= 2^cap_height");
+  if (ncols == 0 || ncols > 4096) return vx_fail(VX_E_INVALID, "vx_hash_rows_dev: ncols %zu", ncols);
+  HIPCHK(hipSetDevice(c->device));
+  u64* tree = tree_out;
+  const size_t nd = merkle_tree_digest_count(nrows, cap_height);
+  if (!tree && c->pool_alloc((void**)&tree, nd * 32) != hipSuccess) return vx_fail(VX_E_NOMEM, "vx_hash_rows_dev: out of device memory");
+  {
+    ProfScope ps(c, "hash_leaves", (double)ncols * 8.0 * (double)nrows);
+    hipLaunchKernelGGL(hash_leaves_colmajor_kernel, dim3((unsigned)((nrows + HASH_THREADS - 1) / HASH_THREADS)), dim3(HASH_THREADS), 0,
+                       c->stream, cols, col_stride, nrows, (int)ncols, tree);
+  }
+  size_t cap_off = 0;
+  int rc = build_merkle_levels(c, tree, nrows, cap_height, &cap_off);
+  hipError_t e = hipSuccess;
+  if (rc == VX_OK) e = hipMemcpyAsync(cap_out, tree + cap_off * 4, (size_t)32 << cap_height, hipMemcpyDeviceToHost, c->stream);
+  hipError_t e2 = hipStreamSynchronize(c->stream);
+  if (!tree_out) c->pool_free(tree);
+  if (rc == VX_OK && (e != hipSuccess || e2 != hipSuccess)) rc = vx_fail(VX_E_HIP, "vx_hash_rows_dev: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+  return rc;
+}
+
 // ---------------------------------------------------------------------------------------------
 // L3
 // ---------------------------------------------------------------------------------------------
