@@ -101,6 +101,14 @@ def lib() -> ctypes.CDLL:
         if not _LIB_PATH.exists():
             raise VxError(VX_E_NO_DEVICE, f"{_LIB_PATH} is missing — run `python -c 'import __graft_entry__ as g; "
                           "g.build()'` (hipcc, gfx950).  There is no CPU fallback.")
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64; if it is loaded AFTER the
+        # system one that libvxprover.so would pull in, torch.cuda later reports "No HIP GPUs are available".
+        # Importing torch first makes both resolve to the same runtime (torch is only plumbing here: device
+        # buffers for the multi-GPU path, torch.distributed).  Without torch the system ROCm runtime is used.
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
         L = ctypes.CDLL(str(_LIB_PATH))
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(L, name)
