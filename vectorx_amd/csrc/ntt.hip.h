@@ -53,7 +53,7 @@ GLD u64 root_pow24(const u64* __restrict__ lo, const u64* __restrict__ hi, u32 e
 }
 
 // LDS padding: one extra 8-byte word every 32 words keeps power-of-two strides conflict-free.
-GLD u32 lds_pad(u32 i) { return i + (i >> 5); }
+GLD u32 lds_pad(u32 i) { return i + (i >> 5) + (i >> 9); }  // second level spreads the bit-reversed first-pass load (stride 2^9+)
 
 template <int E>
 GLD void reg_butterflies(u64 (&x)[1 << E], const u64* __restrict__ tw, u32 base_low, int lo_bits,

@@ -285,7 +285,7 @@ static int run_ntt(vx_ctx* c, const u64* in, u64* out, size_t in_col_stride, siz
     p.pre_bits = pre_bits;
     p.post_scale = last ? post_scale : 1;
     size_t tile = (size_t)1 << (ps_.r_log + ps_.t_log);
-    size_t lds = (tile + (tile >> 5) + 1 + ((size_t)1 << (ps_.r_log - 1 > 0 ? ps_.r_log - 1 : 0))) * 8 + 16;
+    size_t lds = (tile + (tile >> 5) + (tile >> 9) + 1 + ((size_t)1 << (ps_.r_log - 1 > 0 ? ps_.r_log - 1 : 0))) * 8 + 16;
     dim3 grid((unsigned)((size_t)1 << (log_n - ps_.r_log - ps_.t_log)), (unsigned)ncols, (unsigned)nz);
     // gridDim.y is limited to 65535; column counts here are < 1000.
     hipError_t e = launch_ntt_pass(ps_.r_log, p, grid, lds, c->stream);
