@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--workload", default="prove", choices=["commit", "prove"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-log-n", type=int, default=None,
-                    help="rows (log2) of the bounded CPU-baseline sample (default 14 for prove, 17 for commit)")
+                    help="rows (log2) of the bounded CPU-baseline sample (default 16 for prove, 17 for commit)")
     ap.add_argument("--poseidon-percent", type=int, default=50, help="share of PoseidonGate rows in the synthetic circuit")
     return ap.parse_args()
 
@@ -77,7 +77,7 @@ def main():
     ctx = vx.Context(local_rank)  # no CPU fallback: raises if the HIP library / GPU is missing
     n = 1 << args.log_n
     if args.cpu_sample_log_n is None:
-        args.cpu_sample_log_n = 14 if args.workload == "prove" else 17
+        args.cpu_sample_log_n = 16 if args.workload == "prove" else 17
     keep = []
 
     if args.workload == "commit":

@@ -37,6 +37,14 @@ void vxo_poseidon_permute(u64* state, size_t count) {
     for (int k = 0; k < 12; ++k) state[i * 12 + k] = s[k];
   }
 }
+void vxo_poseidon_permute_naive(u64* state, size_t count) {
+  for (size_t i = 0; i < count; ++i) {
+    State s;
+    for (int k = 0; k < 12; ++k) s[k] = canon(state[i * 12 + k]);
+    permute_naive(s);
+    for (int k = 0; k < 12; ++k) state[i * 12 + k] = s[k];
+  }
+}
 void vxo_hash_no_pad(const u64* in, size_t n, u64* out4) {
   std::vector<u64> t(in, in + n);
   for (auto& x : t) x = canon(x);

@@ -675,7 +675,20 @@ static Proof prove(const Circuit& c, const std::vector<std::vector<u64>>& wire_v
       wts = opt.pow_hint;
       if (!ok(wts)) throw std::runtime_error("pow_witness hint does not satisfy the proof-of-work condition");
     } else {
-      while (!ok(wts)) ++wts;
+      // smallest valid witness, searched in parallel blocks (upstream: rayon find_any => any valid witness)
+      const u64 block = (u64)1 << 14;
+      for (u64 base = 0;; base += block) {
+        u64 best = ~(u64)0;
+#pragma omp parallel for schedule(static) reduction(min : best)
+        for (long long k = 0; k < (long long)block; ++k) {
+          u64 cand = base + (u64)k;
+          if (cand < best && ok(cand)) best = cand;
+        }
+        if (best != ~(u64)0) {
+          wts = best;
+          break;
+        }
+      }
     }
     proof.fri.pow_witness = wts;
     ch.observe_element(wts);

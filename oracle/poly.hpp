@@ -101,15 +101,48 @@ struct PolynomialBatch {
     rate_bits = rate_bits_;
     int lg = degree_log + rate_bits;
     size_t N = (size_t)1 << lg, nn = n();
+    // Same values as  leaves[reverse_bits(j)][c] = coset_fft_7(lde(coeffs[c]))[j]  (checked against direct
+    // evaluation in tests/test_oracle_golden.py), computed the cache-friendly way so the oracle is a fair CPU
+    // baseline: a decimation-in-frequency pass leaves X[rev(i)] at position i, i.e. already in leaf order, and
+    // the column-major result is transposed into row-major leaves in blocks.
     std::vector<u64> leaves(N * ncols);
+    std::vector<u64> colmajor(N * ncols);
+    // shared tables: shift^i for i < n, and w_N^k for k < N/2
+    std::vector<u64> shift_pows(nn), roots(N / 2 ? N / 2 : 1);
+    {
+      u64 p = 1;
+      for (size_t i = 0; i < nn; ++i) shift_pows[i] = p, p = mul(p, MULTIPLICATIVE_GENERATOR);
+      u64 w = root_of_unity(lg);
+      p = 1;
+      for (size_t k = 0; k < N / 2; ++k) roots[k] = p, p = mul(p, w);
+    }
     long long nc = (long long)ncols;
 #pragma omp parallel for schedule(dynamic)
     for (long long c = 0; c < nc; ++c) {
-      std::vector<u64> v(N, 0);
-      for (size_t i = 0; i < nn; ++i) v[i] = coeffs[c][i];
-      coset_fft_inplace(v.data(), lg, MULTIPLICATIVE_GENERATOR);
-      for (size_t j = 0; j < N; ++j) leaves[reverse_bits(j, lg) * ncols + c] = v[j];
+      u64* v = &colmajor[(size_t)c * N];
+      for (size_t i = 0; i < nn; ++i) v[i] = mul(coeffs[c][i], shift_pows[i]);
+      for (size_t i = nn; i < N; ++i) v[i] = 0;
+      for (size_t half = N / 2, step = 1; half >= 1; half >>= 1, step <<= 1)  // Gentleman-Sande, no permutation
+        for (size_t k = 0; k < N; k += 2 * half)
+          for (size_t j = 0; j < half; ++j) {
+            u64 a = v[k + j], b = v[k + j + half];
+            v[k + j] = add(a, b);
+            v[k + j + half] = mul(sub(a, b), roots[j * step]);
+          }
     }
+    {
+      const size_t RB = 64;
+      long long nblk = (long long)((N + RB - 1) / RB);
+#pragma omp parallel for schedule(static)
+      for (long long blk = 0; blk < nblk; ++blk) {
+        size_t r0 = (size_t)blk * RB, r1 = std::min(N, r0 + RB);
+        for (size_t c = 0; c < ncols; ++c) {
+          const u64* src = &colmajor[c * N];
+          for (size_t r = r0; r < r1; ++r) leaves[r * ncols + c] = src[r];
+        }
+      }
+    }
+    std::vector<u64>().swap(colmajor);
     tree.build(std::move(leaves), ncols, cap_height);
   }
   // from_values: ifft per column, then from_coeffs

@@ -46,8 +46,8 @@ static inline void mds_layer(State& s) {
   }
   s = o;
 }
-// poseidon.rs::poseidon — naive partial rounds (equivalent to upstream's FAST_PARTIAL_* form).
-static inline void permute(State& s) {
+// poseidon.rs::poseidon_naive — the reference form, pinned by the known-answer vectors.
+static inline void permute_naive(State& s) {
   int rc = 0;
   for (int r = 0; r < N_ROUNDS; ++r) {
     for (int i = 0; i < 12; ++i) s[i] = add(s[i], ROUND_CONSTANTS[rc++]);
@@ -56,6 +56,53 @@ static inline void permute(State& s) {
       for (int i = 0; i < 12; ++i) s[i] = sbox(s[i]);
     else
       s[0] = sbox(s[0]);
+    mds_layer(s);
+  }
+}
+
+// poseidon.rs::poseidon — partial rounds in the sparse "fast" form upstream uses (its FAST_PARTIAL_* tables are
+// unavailable; the equivalent constants are re-derived and proven equal to the naive form on the KATs and random
+// states by tools/gen_poseidon_fast_constants.py, and tests/test_oracle_golden.py re-checks permute == permute_naive).
+// Used for all hashing so that the oracle is a fair CPU baseline; gate constraints keep the naive formulas.
+#include "poseidon_fast_constants.h"
+static const u64 FAST_FIRST[12] = VX_FAST_PARTIAL_FIRST_ROUND_CONSTANT_INIT;
+static const u64 FAST_K[22] = VX_FAST_PARTIAL_ROUND_CONSTANTS_INIT;
+static const u64 FAST_INIT[11][11] = VX_FAST_PARTIAL_INITIAL_MATRIX_INIT;
+static const u64 FAST_W_HATS[22][11] = VX_FAST_PARTIAL_W_HATS_INIT;
+static const u64 FAST_VS[22][11] = VX_FAST_PARTIAL_VS_INIT;
+// sum of up to 12 products < 12 * 2^128: accumulate in (u128 low, small high) and fold 2^128 = -2^32 (mod p)
+static inline u64 dot_reduce(const u64* a, const u64* b, int n, u64 extra_a = 0, u64 extra_b = 0) {
+  u128 acc = (u128)extra_a * extra_b;
+  u64 over = 0;
+  for (int i = 0; i < n; ++i) {
+    u128 t = (u128)a[i] * b[i];
+    acc += t;
+    over += acc < t;
+  }
+  u64 r = reduce128(acc);
+  return sub(r, mul(over, (u64)1 << 32));
+}
+static inline void permute(State& s) {
+  int rc = 0;
+  for (int r = 0; r < HALF_N_FULL_ROUNDS; ++r) {
+    for (int i = 0; i < 12; ++i) s[i] = sbox(add(s[i], ROUND_CONSTANTS[rc++]));
+    mds_layer(s);
+  }
+  for (int i = 0; i < 12; ++i) s[i] = add(s[i], FAST_FIRST[i]);
+  {
+    u64 t[11];
+    for (int r = 0; r < 11; ++r) t[r] = dot_reduce(&s[1], FAST_INIT[r], 11);
+    for (int r = 0; r < 11; ++r) s[1 + r] = t[r];
+  }
+  for (int r = 0; r < N_PARTIAL_ROUNDS; ++r) {
+    u64 s0 = add(sbox(s[0]), FAST_K[r]);
+    u64 d = dot_reduce(&s[1], FAST_W_HATS[r], 11, s0, MDS_CIRC[0] + MDS_DIAG[0]);
+    for (int i = 0; i < 11; ++i) s[1 + i] = reduce128((u128)s0 * FAST_VS[r][i] + s[1 + i]);
+    s[0] = d;
+  }
+  rc = 12 * (HALF_N_FULL_ROUNDS + N_PARTIAL_ROUNDS);
+  for (int r = 0; r < HALF_N_FULL_ROUNDS; ++r) {
+    for (int i = 0; i < 12; ++i) s[i] = sbox(add(s[i], ROUND_CONSTANTS[rc++]));
     mds_layer(s);
   }
 }

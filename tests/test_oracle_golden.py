@@ -31,6 +31,28 @@ def test_poseidon_known_answer_vectors(oracle):
         assert (got == exp).all()
 
 
+def test_fast_partial_round_form_equals_the_naive_permutation(oracle):
+    """The oracle hashes with the sparse partial-round form (as upstream does); it must equal the naive
+    reference form — which is the one the KATs pin — on the KAT inputs, edge states and random states."""
+    import ctypes
+    kat = json.loads((GOLD / "poseidon_kat.json").read_text())
+    rng = np.random.default_rng(5)
+    st = np.concatenate([
+        np.array([[int(x, 16) for x in v["input"]] for v in kat["vectors"]], dtype=np.uint64),
+        np.full((1, 12), 1, np.uint64), np.full((1, 12), P - 2, np.uint64),
+        rand_field(rng, (500, 12))])
+    fast = oracle.poseidon_permute(st)
+    naive = st.copy()
+    oracle.L.vxo_poseidon_permute_naive.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+    oracle.L.vxo_poseidon_permute_naive(naive.ctypes.data, naive.shape[0])
+    assert (fast == naive).all()
+    exp = np.array([[int(x, 16) for x in v["output"]] for v in kat["vectors"]], dtype=np.uint64)
+    assert (naive[:3] == exp).all()
+    r = subprocess.run([sys.executable, str(ROOT / "tools" / "gen_poseidon_fast_constants.py"), "--check"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
 def test_round_constants_regenerate_and_match_committed_headers():
     r = subprocess.run([sys.executable, str(ROOT / "tools" / "gen_poseidon_constants.py"), "--check"],
                        capture_output=True, text=True)

@@ -172,14 +172,17 @@ def main():
         assert a == b, f"fast form differs from naive on test {t}"
         if t < 3:
             assert a[0] == kat_out0[t]
-    path = Path(__file__).resolve().parent.parent / "vectorx_amd" / "csrc" / "poseidon_fast_constants.h"
+    root = Path(__file__).resolve().parent.parent
+    # the product and the oracle share no code: each gets its own generated copy
+    paths = [root / "vectorx_amd" / "csrc" / "poseidon_fast_constants.h", root / "oracle" / "poseidon_fast_constants.h"]
     text = header_text(first, k, init, w_hats, vs)
     if "--check" in sys.argv:
-        ok = path.exists() and path.read_text() == text
+        ok = all(p.exists() and p.read_text() == text for p in paths)
         print("ok" if ok else "MISMATCH")
         sys.exit(0 if ok else 1)
-    path.write_text(text)
-    print("fast partial-round constants verified on", len(tests), "states; wrote", path)
+    for p in paths:
+        p.write_text(text)
+    print("fast partial-round constants verified on", len(tests), "states; wrote", *paths)
 
 
 if __name__ == "__main__":
