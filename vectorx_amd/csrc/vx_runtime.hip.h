@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <map>
 #include <string>
@@ -12,6 +13,7 @@
 #include "host_field.h"
 #include "merkle.hip.h"
 #include "ntt.hip.h"
+#include "ntt2.hip.h"
 
 static thread_local char g_err[512] = "";
 static int vx_fail(int code, const char* fmt, ...) {
@@ -169,7 +171,7 @@ static std::vector<NttPass> plan_ntt(int log_n) {
     rem -= r;
     b -= r;
     int t = NTT_MAX_TILE_LOG - r;
-    if (t > 4) t = 4;
+    if (t > 4 && !(k == 1 && r >= 8)) t = 4;  // single strided pass of 8..10 stages: full 8192-element tile (ntt2 kernel)
     v.push_back({r, t, b});
   }
   int t = NTT_MAX_TILE_LOG - r_final;
@@ -208,6 +210,68 @@ static hipError_t launch_ntt_pass(int r_log, const NttPassParams& p, dim3 grid, 
     case 12: return launch_ntt_pass_r<12>(p, grid, lds, s);
     default: return hipErrorInvalidValue;
   }
+}
+
+// ---- second-generation pass (ntt2.hip.h) for full 8192-element tiles --------------------------------------
+static bool ntt2_eligible(const NttPass& ps, bool strided) {
+  static const bool disabled = getenv("VX_NTT_V1") != nullptr;  // A/B switch: force the generic kernel
+  if (disabled || ps.r_log + ps.t_log != NTT2_TILE_LOG) return false;
+  return strided ? (ps.r_log >= 8 && ps.r_log <= 10 && ps.b_lo >= ps.t_log) : (ps.r_log == 11);
+}
+template <int R, int E2, int E3, bool STRIDED, bool IN_BITREV, bool PRE, bool INV>
+static hipError_t launch_ntt2_k(const Ntt2Params& q, dim3 grid, hipStream_t s) {
+  auto kern = ntt2_pass_kernel<R, 4, E2, E3, STRIDED, IN_BITREV, PRE, INV>;
+  static bool attr_set[16] = {};
+  int dev = 0;
+  hipGetDevice(&dev);
+  const size_t tile = (size_t)1 << NTT2_TILE_LOG;
+  const size_t lds = (tile + (tile >> 5) + (tile >> 9) + 1 + (R > 10 ? ((size_t)1 << (R - 1)) : ((size_t)1 << R))) * 8 + 16;
+  if (!attr_set[dev & 15]) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    if (e != hipSuccess) return e;
+    attr_set[dev & 15] = true;
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(NTT2_THREADS), lds, s, q);
+  return hipGetLastError();
+}
+template <int R, int E2, int E3, bool STRIDED>
+static hipError_t launch_ntt2_r(const NttPassParams& p, const Ntt2Params& q, dim3 grid, hipStream_t s) {
+  const bool inv = p.inverse != 0, br = p.in_bitrev != 0, pre = p.pre != nullptr;
+  if (!STRIDED) {  // final contiguous pass: never first, never prescaled
+    return inv ? launch_ntt2_k<R, E2, E3, STRIDED, false, false, true>(q, grid, s)
+               : launch_ntt2_k<R, E2, E3, STRIDED, false, false, false>(q, grid, s);
+  }
+  if (!br && !pre) return inv ? launch_ntt2_k<R, E2, E3, STRIDED, false, false, true>(q, grid, s)
+                              : launch_ntt2_k<R, E2, E3, STRIDED, false, false, false>(q, grid, s);
+  if (!br && pre && !inv) return launch_ntt2_k<R, E2, E3, STRIDED, false, true, false>(q, grid, s);
+  if (br && pre && !inv) return launch_ntt2_k<R, E2, E3, STRIDED, true, true, false>(q, grid, s);
+  if (br && !pre && inv) return launch_ntt2_k<R, E2, E3, STRIDED, true, false, true>(q, grid, s);
+  return hipErrorInvalidValue;  // combination not instantiated: caller falls back
+}
+static hipError_t launch_ntt2_pass(const NttPass& ps, const NttPassParams& p, dim3 grid, hipStream_t s) {
+  Ntt2Params q;
+  q.in = p.in;
+  q.out = p.out;
+  q.in_col_stride = p.in_col_stride;
+  q.out_col_stride = p.out_col_stride;
+  q.in_z_stride = p.in_z_stride;
+  q.out_z_stride = p.out_z_stride;
+  q.log_n = p.log_n;
+  q.b_lo = p.b_lo;
+  q.root_lo = p.root_lo;
+  q.root_hi = p.root_hi;
+  q.pre = p.pre;
+  q.pre_bits = p.pre_bits;
+  q.post_scale = p.post_scale;
+  if (ps.b_lo > 0) {
+    switch (ps.r_log) {
+      case 8: return launch_ntt2_r<8, 4, 0, true>(p, q, grid, s);
+      case 9: return launch_ntt2_r<9, 3, 2, true>(p, q, grid, s);
+      case 10: return launch_ntt2_r<10, 4, 2, true>(p, q, grid, s);
+      default: return hipErrorInvalidValue;
+    }
+  }
+  return launch_ntt2_r<11, 4, 3, false>(p, q, grid, s);
 }
 
 // Scale tables for x[j] *= base_mul * shift^j, split as hi[j >> bits] * lo[j & mask]; `nz` slices with
@@ -288,7 +352,12 @@ static int run_ntt(vx_ctx* c, const u64* in, u64* out, size_t in_col_stride, siz
     size_t lds = (tile + (tile >> 5) + (tile >> 9) + 1 + ((size_t)1 << (ps_.r_log - 1 > 0 ? ps_.r_log - 1 : 0))) * 8 + 16;
     dim3 grid((unsigned)((size_t)1 << (log_n - ps_.r_log - ps_.t_log)), (unsigned)ncols, (unsigned)nz);
     // gridDim.y is limited to 65535; column counts here are < 1000.
-    hipError_t e = launch_ntt_pass(ps_.r_log, p, grid, lds, c->stream);
+    hipError_t e = hipErrorInvalidValue;
+    if (ntt2_eligible(ps_, ps_.b_lo > 0)) e = launch_ntt2_pass(ps_, p, grid, c->stream);
+    if (e == hipErrorInvalidValue) {  // not a hot shape (or a variant that is not instantiated): generic kernel
+      (void)hipGetLastError();
+      e = launch_ntt_pass(ps_.r_log, p, grid, lds, c->stream);
+    }
     if (e != hipSuccess) return vx_fail(VX_E_HIP, "ntt pass launch failed: %s", hipGetErrorString(e));
   }
   return VX_OK;
