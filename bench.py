@@ -51,8 +51,10 @@ def synth_witness_matrix(seed, ncols, n):
 def cpu_baseline_commit(args):
     """oracle (kind = "port"): PolynomialBatch::from_values on a bounded sample, all host cores."""
     import oracle_lib
+    import bench_prove
     oracle = oracle_lib.load()
-    cores = oracle.L.vxo_num_threads()
+    cores = bench_prove.usable_cores()   # affinity capped by the cgroup CPU quota
+    oracle.L.vxo_set_num_threads(cores)
     s_log = min(args.cpu_sample_log_n, args.log_n)
     vals = synth_witness_matrix(1234, args.ncols, 1 << s_log)
     t0 = time.perf_counter()

@@ -37,6 +37,21 @@ def make_step(ctx, args, rank):
     return step, metric, unit, wl, cleanup
 
 
+def usable_cores():
+    """host cores this process may actually use: the scheduler affinity, capped by the cgroup CPU quota
+    (the GPU box reports 256 logical CPUs but the container is limited by cpu.max)."""
+    import math
+    import os
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, math.ceil(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(args):
     """oracle (kind "port": CPU restatement of plonky2 v0.2.0, OpenMP over all host cores) proving a bounded
     sample — the same circuit family at 2^cpu_sample_log_n rows — scaled linearly in rows to the bench size."""
@@ -44,7 +59,8 @@ def cpu_baseline(args):
     from vectorx_amd.synth import SynthCircuit
 
     oracle = oracle_lib.load()
-    cores = oracle.L.vxo_num_threads()
+    cores = usable_cores()
+    oracle.L.vxo_set_num_threads(cores)
     s_log = min(args.cpu_sample_log_n, args.log_n)
     sc = SynthCircuit(s_log, seed=0x5EED0000, poseidon_percent=args.poseidon_percent)
     oc = oracle_lib.OracleCircuit(oracle, sc.desc_ptr)
