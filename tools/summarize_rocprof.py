@@ -33,7 +33,7 @@ def main():
     tr = list(csv.DictReader(open(trace)))
     lde = defaultdict(list)
     for r in tr:
-        if "ntt_pass_kernel" in r["Kernel_Name"] and int(r["Grid_Size_Z"]) == 8:
+        if "pass_kernel" in r["Kernel_Name"] and "ntt" in r["Kernel_Name"] and int(r["Grid_Size_Z"]) == 8:
             cols = int(r["Grid_Size_Y"])
             lde[(r["Kernel_Name"].split("(")[0].replace("void ", ""), cols)].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     L += ["", "## Coset-LDE dispatches (grid.z = 8 cosets), by kernel instantiation and column count", "",
