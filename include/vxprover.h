@@ -71,6 +71,11 @@ int vx_dev_free(vx_ctx* ctx, void* dptr);
 int vx_dev_upload(vx_ctx* ctx, void* dptr, const void* host, size_t bytes);
 int vx_dev_download(vx_ctx* ctx, void* host, const void* dptr, size_t bytes);
 
+/* Page-locked host buffers: a witness generated into one is uploaded by vx_prove at full PCIe Gen5 rate
+ * (pageable memory goes through a staging copy at a fraction of it). */
+int vx_host_alloc(vx_ctx* ctx, size_t bytes, void** hptr);
+int vx_host_free(vx_ctx* ctx, void* hptr);
+
 /* ---- L1 primitives on host buffers --------------------------------------------------------- */
 /* plonky2_field::fft conventions, natural order in and out, in place, column-major [ncols][2^log_n].
  * kind: 0 fft, 1 ifft, 2 coset_fft(shift), 3 coset_ifft(shift). */

@@ -67,6 +67,8 @@ _SIGNATURES = {
                          ctypes.POINTER(ctypes.c_double)]),
     "vx_dev_alloc": (_i, [_vp, _sz, ctypes.POINTER(_vp)]),
     "vx_dev_free": (_i, [_vp, _vp]),
+    "vx_host_alloc": (_i, [_vp, _sz, ctypes.POINTER(_vp)]),
+    "vx_host_free": (_i, [_vp, _vp]),
     "vx_dev_upload": (_i, [_vp, _vp, _vp, _sz]),
     "vx_dev_download": (_i, [_vp, _vp, _vp, _sz]),
     "vx_ntt_batch": (_i, [_vp, _vp, _i, _sz, _i, _u64]),
@@ -181,6 +183,18 @@ class Context:
 
     def free(self, dptr: int):
         _chk(lib().vx_dev_free(self._h, dptr))
+
+    def host_alloc(self, shape) -> np.ndarray:
+        """page-locked uint64 host array (freed with host_free(arr))"""
+        n = int(np.prod(shape))
+        p = _vp()
+        _chk(lib().vx_host_alloc(self._h, n * 8, ctypes.byref(p)))
+        buf = (ctypes.c_uint64 * n).from_address(p.value)
+        arr = np.frombuffer(buf, dtype=np.uint64).reshape(shape)
+        return arr
+
+    def host_free(self, arr: np.ndarray):
+        _chk(lib().vx_host_free(self._h, arr.ctypes.data))
 
     def upload(self, dptr: int, host: np.ndarray):
         host = np.ascontiguousarray(host)

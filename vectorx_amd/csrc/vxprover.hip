@@ -122,6 +122,19 @@ int vx_dev_free(vx_ctx* c, void* dptr) {
   HIPCHK(hipFree(dptr));
   return VX_OK;
 }
+int vx_host_alloc(vx_ctx* c, size_t bytes, void** hptr) {
+  if (!c || !hptr) return vx_fail(VX_E_INVALID, "vx_host_alloc: NULL argument");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipHostMalloc(hptr, bytes ? bytes : 8, hipHostMallocDefault));
+  return VX_OK;
+}
+int vx_host_free(vx_ctx* c, void* hptr) {
+  if (!c) return vx_fail(VX_E_INVALID, "ctx is NULL");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipHostFree(hptr));
+  return VX_OK;
+}
 int vx_dev_upload(vx_ctx* c, void* dptr, const void* host, size_t bytes) {
   if (!c || !dptr || !host) return vx_fail(VX_E_INVALID, "vx_dev_upload: NULL argument");
   HIPCHK(hipSetDevice(c->device));
