@@ -137,6 +137,17 @@ def main():
                 "alg_bytes_per_launch": per_launch_bytes, "ms_per_launch": round(per_launch_ms, 4),
                 "launches": lde["calls"],
             }
+        # The dominant kernel by TIME is the Poseidon leaf hashing, which is integer-ALU bound (no HBM/MFMA roofline
+        # applies): report its rate next to the instruction count measured with rocprofv3 --pmc SQ_INSTS_VALU.
+        alu = None
+        hl = prof.get("hash_leaves")
+        if hl and hl["calls"] and args.workload == "prove":
+            N = n << 3
+            perms = N * (17 + 3 + 2)   # ceil(135/8) + ceil(20/8) + ceil(16/8) sponge permutations per LDE row
+            ms = hl["ms"] / args.steps
+            alu = {"kernel": "hash_leaves_colmajor_kernel", "bound": "integer ALU (VALU issue)", "perms_per_proof": perms,
+                   "ms_per_proof": round(ms, 2), "gperms_per_s": round(perms / (ms * 1e-3) / 1e9, 3),
+                   "valu_insts_per_perm": 22060, "source": "profiles/r01_history + DESIGN.md §3 (SQ_INSTS_VALU / permutations)"}
         agg = H.aggregate(world, args.steps, dt)
         out = {
             "metric": metric, "value": agg["value"], "unit": unit,
@@ -145,6 +156,7 @@ def main():
             "vs_baseline": None, "dtype": "u64 (Goldilocks field, integer modular arithmetic)", "data": "synthetic",
             "config": {"workload": wl_name, "parallelism": f"proof-level x{world} (one witness per GPU, no collective)"},
             "roofline": roof,
+            "alu_bound_dominant_kernel": alu,
             "stage_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in prof.items()},
             "stage_alg_GBps": {k: round(v["alg_bytes"] / (v["ms"] * 1e-3) / 1e9, 1) for k, v in prof.items()
                                if v["alg_bytes"] and v["ms"]},
