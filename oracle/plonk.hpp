@@ -797,7 +797,7 @@ static std::string verify(const Circuit& c, const Proof& p) {
     }
   }
   // ---- FRI ----
-  if ((pow_response >> (64 - c.pow_bits)) != 0) return "proof of work check failed";
+  if (c.pow_bits > 0 && (pow_response >> (64 - c.pow_bits)) != 0) return "proof of work check failed";
   if ((int)p.fri.query_rounds.size() != c.num_query_rounds) return "wrong number of FRI query rounds";
   size_t final_len = n;
   for (int ab : c.reduction_arity_bits) final_len >>= ab;

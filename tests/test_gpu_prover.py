@@ -134,3 +134,18 @@ def test_large_proof_is_accepted_by_the_restated_verifier(ctx, oracle, degree_bi
     assert gc.prove(dev_ptr=d) == gp          # deterministic at full size too
     ctx.free(d)
     gc.free()
+
+
+@pytest.mark.parametrize("field,value", [("num_challenges", 1), ("cap_height", 0), ("cap_height", 2), ("pow_bits", 0),
+                                         ("pow_bits", 20), ("num_query_rounds", 5), ("num_query_rounds", 40)])
+def test_config_variants_stay_byte_identical(ctx, oracle, field, value):
+    """FriConfig / CircuitConfig knobs other than standard_recursion_config's values (plonk/circuit_data.rs):
+    the same descriptor drives the oracle and the GPU prover, and the proofs must still agree byte for byte."""
+    sc = SynthCircuit(7, seed=77, poseidon_percent=50)
+    setattr(sc.desc, field, value)
+    oc = oracle_lib.OracleCircuit(oracle, sc.desc_ptr)
+    gc = vx.Circuit(ctx, sc.desc_ptr)
+    gp = gc.prove(sc.witness())
+    assert gp == oc.prove(sc.witness())
+    assert oc.verify(gp) == ""
+    gc.free()
