@@ -70,6 +70,9 @@ int vx_dev_alloc(vx_ctx* ctx, size_t bytes, void** dptr);
 int vx_dev_free(vx_ctx* ctx, void* dptr);
 int vx_dev_upload(vx_ctx* ctx, void* dptr, const void* host, size_t bytes);
 int vx_dev_download(vx_ctx* ctx, void* host, const void* dptr, size_t bytes);
+/* Scatter `count` 8-byte values from a contiguous host array into device memory at dptr + i*dst_stride_bytes
+ * (e.g. one ROW of a column-major witness matrix: stride = 8 * 2^degree_bits). */
+int vx_dev_upload_strided(vx_ctx* ctx, void* dptr, size_t dst_stride_bytes, const uint64_t* host, size_t count);
 
 /* Page-locked host buffers: a witness generated into one is uploaded by vx_prove at full PCIe Gen5 rate
  * (pageable memory goes through a staging copy at a fraction of it). */

@@ -65,3 +65,20 @@ def test_sharded_column_blocks():
     assert per == 34 and blocks == [(0, 34), (34, 68), (68, 102), (102, 135)]
     per, blocks = sharded.column_blocks(20, 8)
     assert per == 3 and blocks[6] == (18, 20) and blocks[7] == (20, 20)     # trailing ranks own only padding
+
+
+def test_mapreduce_dag_is_partition_independent():
+    """4 map + 3 reduce + 1 outer proofs: the root digest must not depend on how the jobs are spread over ranks
+    (world 1 vs world 2), every proof must verify, and the per-layer barriers must see every job exactly once."""
+    one = _run_workers("_mp_dag_worker.py", 1)
+    two = _run_workers("_mp_dag_worker.py", 2)
+    assert one["proofs"] == two["proofs"] == 8
+    assert one["layers"] == [["map", 4], ["reduce", 2], ["reduce", 1], ["outer", 1]]
+    assert one["root"] == two["root"]
+    assert one["per_rank"] == [8] and sorted(two["per_rank"]) == [2, 6] or sum(two["per_rank"]) == 8
+
+
+def test_dag_spec_header_range_512():
+    from vectorx_amd.mapreduce import DagSpec
+    s = DagSpec()
+    assert s.num_proofs() == 128 and [len(j) for _, j in s.layers()] == [64, 32, 16, 8, 4, 2, 1, 1]

@@ -71,6 +71,7 @@ _SIGNATURES = {
     "vx_host_free": (_i, [_vp, _vp]),
     "vx_dev_upload": (_i, [_vp, _vp, _vp, _sz]),
     "vx_dev_download": (_i, [_vp, _vp, _vp, _sz]),
+    "vx_dev_upload_strided": (_i, [_vp, _vp, _sz, _vp, _sz]),
     "vx_ntt_batch": (_i, [_vp, _vp, _i, _sz, _i, _u64]),
     "vx_ntt_batch_dev": (_i, [_vp, _vp, _vp, _i, _sz, _i, _u64]),
     "vx_poseidon_permute": (_i, [_vp, _vp, _sz]),
@@ -199,6 +200,11 @@ class Context:
     def upload(self, dptr: int, host: np.ndarray):
         host = np.ascontiguousarray(host)
         _chk(lib().vx_dev_upload(self._h, dptr, host.ctypes.data, host.nbytes))
+
+    def upload_row(self, dptr: int, n_rows: int, row: int, values: np.ndarray):
+        """write one row of a column-major [len(values)][n_rows] u64 matrix that lives at dptr"""
+        v = np.ascontiguousarray(values, dtype=np.uint64)
+        _chk(lib().vx_dev_upload_strided(self._h, dptr + 8 * row, 8 * n_rows, v.ctypes.data, v.size))
 
     def download(self, dptr: int, nbytes: int) -> np.ndarray:
         out = np.empty(nbytes // 8, dtype=np.uint64)

@@ -142,6 +142,14 @@ int vx_dev_upload(vx_ctx* c, void* dptr, const void* host, size_t bytes) {
   HIPCHK(hipStreamSynchronize(c->stream));
   return VX_OK;
 }
+int vx_dev_upload_strided(vx_ctx* c, void* dptr, size_t dst_stride_bytes, const uint64_t* host, size_t count) {
+  if (!c || !dptr || !host) return vx_fail(VX_E_INVALID, "vx_dev_upload_strided: NULL argument");
+  if (dst_stride_bytes < 8) return vx_fail(VX_E_INVALID, "vx_dev_upload_strided: stride must be >= 8");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipMemcpy2DAsync(dptr, dst_stride_bytes, host, 8, 8, count, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return VX_OK;
+}
 int vx_dev_download(vx_ctx* c, void* host, const void* dptr, size_t bytes) {
   if (!c || !dptr || !host) return vx_fail(VX_E_INVALID, "vx_dev_download: NULL argument");
   HIPCHK(hipSetDevice(c->device));

@@ -1,0 +1,148 @@
+"""Proof-level MapReduce scheduler: the shape of a REAL header_range_N proof.
+
+`verify_subchain` (/root/reference/circuits/builder/subchain_verification.rs:72-78, 233-289) is a plonky2x MapReduce:
+N/8 map proofs (8 headers each), a binary tree of reduce proofs that each verify their two children, and one outer
+proof on top (/root/reference/circuits/header_range.rs:31-58) — 64 + 63 + 1 = 128 plonky2 proofs for header_range_512.
+Proofs inside a layer are independent; a layer can only start when the layer below is done (its proofs are the
+witness of the next one).  This module schedules that DAG over the G GPUs of a node, one process per GPU:
+
+  * layer jobs are dealt round-robin to ranks; every rank proves its jobs on its own GPU;
+  * the only exchange is an all-gather of the (tiny) proof digests at each layer barrier — proof-level data
+    parallelism, no data-path collective; a parent job's public inputs are derived from its children's digests, so
+    the dependency is real: no parent can be proven before its children.
+
+The three circuits (map / reduce / outer) are synthetic stand-ins of configurable size (the real circuits need the
+Rust builder and the recursion gate set); what is real is the DAG, the barriers and the prover.
+The prover behind `make_prover` is pluggable: the GPU library in production, the oracle in the CPU/gloo tests.
+"""
+from __future__ import annotations
+
+import hashlib
+import time
+from dataclasses import dataclass
+
+import numpy as np
+
+P = 0xFFFFFFFF00000001
+
+
+@dataclass
+class DagSpec:
+    num_map: int = 64              # header_range_512: 512 / HEADERS_PER_MAP(8)  (circuits/consts.rs:6)
+    map_log_n: int = 18
+    reduce_log_n: int = 16
+    outer_log_n: int = 19
+    poseidon_percent: int = 50
+
+    def layers(self):
+        """[(kind, [job ids])...]: map layer, reduce layers (binary tree), outer."""
+        assert self.num_map >= 2 and self.num_map & (self.num_map - 1) == 0
+        out = [("map", list(range(self.num_map)))]
+        width = self.num_map // 2
+        while width >= 1:
+            out.append(("reduce", list(range(width))))
+            width //= 2
+        out.append(("outer", [0]))
+        return out
+
+    def num_proofs(self):
+        return sum(len(j) for _, j in self.layers())
+
+    def log_n(self, kind):
+        return {"map": self.map_log_n, "reduce": self.reduce_log_n, "outer": self.outer_log_n}[kind]
+
+
+def digest_to_field(d: bytes) -> np.ndarray:
+    """32-byte digest -> 4 field elements (public inputs of the parent job)"""
+    return np.array([int.from_bytes(d[8 * i:8 * i + 8], "little") % P for i in range(4)], dtype=np.uint64)
+
+
+def child_inputs(layer_idx: int, job: int, prev_digests: dict) -> np.ndarray:
+    """Public inputs of a job: H(layer, job) for map jobs, H(left child digest || right child digest) above."""
+    if layer_idx == 0:
+        return digest_to_field(hashlib.sha256(b"map" + job.to_bytes(4, "little")).digest())
+    if len(prev_digests) == 1:      # outer proof: single child (the root reduce proof)
+        return digest_to_field(hashlib.sha256(b"outer" + prev_digests[0]).digest())
+    return digest_to_field(hashlib.sha256(prev_digests[2 * job] + prev_digests[2 * job + 1]).digest())
+
+
+def run_dag(spec: DagSpec, make_prover, dist=None, sync=lambda: None):
+    """make_prover(kind, log_n, job_ids) -> object with .prove(job, public_inputs) -> proof bytes, prepared (circuit
+    loaded, per-job witnesses resident) BEFORE the timed region; witness generation is outside the hot path (U9).
+    Returns dict(root=<digest of the outer proof>, seconds=<timed DAG wall time>, proofs=<count>, per_layer=[...])."""
+    world = dist.get_world_size() if dist is not None else 1
+    rank = dist.get_rank() if dist is not None else 0
+    layers = spec.layers()
+    # ---- setup (untimed): one prover per circuit kind, holding this rank's jobs of every layer of that kind ----
+    my_jobs = []
+    for li, (kind, jobs) in enumerate(layers):
+        my_jobs.append([j for j in jobs if j % world == rank])
+    provers = {}
+    for kind in ("map", "reduce", "outer"):
+        wanted = [(li, j) for li, (k, _) in enumerate(layers) if k == kind for j in my_jobs[li]]
+        if wanted:
+            provers[kind] = make_prover(kind, spec.log_n(kind), wanted)
+    sync()
+    if dist is not None:
+        dist.barrier()
+    # ---- timed: layer by layer ----
+    t0 = time.perf_counter()
+    prev = {}
+    per_layer = []
+    all_proofs = {}
+    for li, (kind, jobs) in enumerate(layers):
+        tl = time.perf_counter()
+        mine = {}
+        for j in my_jobs[li]:
+            pi = child_inputs(li, j, prev)
+            proof = provers[kind].prove((li, j), pi)
+            mine[j] = hashlib.sha256(proof).digest()
+            all_proofs[(li, j)] = proof
+        sync()
+        if dist is not None:          # layer barrier: all-gather of the digests (32 B per proof)
+            gathered = [None] * world
+            dist.all_gather_object(gathered, mine)
+            prev = {}
+            for g in gathered:
+                prev.update(g)
+        else:
+            prev = mine
+        assert sorted(prev) == jobs, "a layer's jobs were not all proven"
+        per_layer.append({"kind": kind, "jobs": len(jobs), "ms": (time.perf_counter() - tl) * 1e3})
+    seconds = time.perf_counter() - t0
+    return {"root": prev[0], "seconds": seconds, "proofs": spec.num_proofs(), "per_layer": per_layer, "my_proofs": all_proofs}
+
+
+class GpuProver:
+    """One circuit kind on one GPU: circuit loaded once (constants_sigmas resident), one device-resident witness per
+    job; `prove` patches the two witness rows that depend on the public inputs and calls vx_prove."""
+
+    def __init__(self, ctx, kind, log_n, jobs, poseidon_percent=50):
+        import vectorx_amd as vx
+        from vectorx_amd.synth import SynthCircuit
+        self.ctx, self.n = ctx, 1 << log_n
+        circuit_seed = {"map": 101, "reduce": 202, "outer": 303}[kind]
+        self.sc = SynthCircuit(log_n, seed=circuit_seed, poseidon_percent=poseidon_percent, witness_seed=0)
+        self.circuit = vx.Circuit(ctx, self.sc.desc_ptr)
+        self.wit = {}
+        for (li, j) in jobs:
+            sj = SynthCircuit(log_n, seed=circuit_seed, poseidon_percent=poseidon_percent, witness_seed=1000 * li + j + 1)
+            w = sj.witness()
+            d = ctx.alloc(w.nbytes)
+            ctx.upload(d, w)
+            self.wit[(li, j)] = d
+            sj.free()
+        self.sc.release_host_buffers(witness=True, preprocessed=True)
+
+    def prove(self, key, public_inputs):
+        d = self.wit[key]
+        r0, r2 = self.sc.patch_public_inputs(public_inputs)
+        self.ctx.upload_row(d, self.n, 0, r0)
+        self.ctx.upload_row(d, self.n, 2, r2)
+        return self.circuit.prove(dev_ptr=d)
+
+    def free(self):
+        for d in self.wit.values():
+            self.ctx.free(d)
+        self.circuit.free()
+        self.sc.free()

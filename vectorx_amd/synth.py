@@ -46,6 +46,9 @@ def _load():
         L = ctypes.CDLL(str(_SO))
         L.vxs_build.restype = ctypes.c_void_p
         L.vxs_build.argtypes = [ctypes.c_int, ctypes.c_uint64, ctypes.c_int]
+        L.vxs_build2.restype = ctypes.c_void_p
+        L.vxs_build2.argtypes = [ctypes.c_int, ctypes.c_uint64, ctypes.c_int, ctypes.c_uint64]
+        L.vxs_patch_public_inputs.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         L.vxs_free.argtypes = [ctypes.c_void_p]
         L.vxs_desc.restype = ctypes.POINTER(CircuitDesc)
         L.vxs_desc.argtypes = [ctypes.c_void_p]
@@ -62,9 +65,10 @@ def _load():
 class SynthCircuit:
     """A synthetic standard_recursion_config circuit with a satisfying witness."""
 
-    def __init__(self, degree_bits: int, seed: int = 0, poseidon_percent: int = 50):
+    def __init__(self, degree_bits: int, seed: int = 0, poseidon_percent: int = 50, witness_seed: int | None = None):
+        """`seed` fixes the circuit; `witness_seed` (default = seed) only the witness values."""
         L = _load()
-        self._h = L.vxs_build(degree_bits, seed, poseidon_percent)
+        self._h = L.vxs_build2(degree_bits, seed, poseidon_percent, seed if witness_seed is None else witness_seed)
         if not self._h:
             raise ValueError("vxs_build rejected the parameters")
         self.degree_bits = degree_bits
@@ -83,6 +87,14 @@ class SynthCircuit:
     def public_inputs(self) -> np.ndarray:
         p = _load().vxs_public_inputs(self._h)
         return np.frombuffer((ctypes.c_uint64 * 4).from_address(p), dtype=np.uint64).copy()
+
+    def patch_public_inputs(self, pi) -> tuple:
+        """New public inputs on the same circuit: returns (row0, row2), the only two witness rows that change."""
+        pi = np.ascontiguousarray(pi, dtype=np.uint64)
+        r0 = np.empty(self.num_wires, np.uint64)
+        r2 = np.empty(self.num_wires, np.uint64)
+        _load().vxs_patch_public_inputs(self._h, pi.ctypes.data, r0.ctypes.data, r2.ctypes.data)
+        return r0, r2
 
     def row_counts(self) -> dict:
         out = np.zeros(3, np.uint64)

@@ -122,13 +122,20 @@ extern "C" {
 
 typedef struct vxs_circuit vxs_circuit;
 
+vxs_circuit* vxs_build2(int degree_bits, uint64_t seed, int poseidon_percent, uint64_t witness_seed);
 vxs_circuit* vxs_build(int degree_bits, uint64_t seed, int poseidon_percent) {
+  return vxs_build2(degree_bits, seed, poseidon_percent, seed);
+}
+// `seed` fixes the CIRCUIT (gate layout, arithmetic constants, copy constraints); `witness_seed` only the witness
+// values (public inputs, free wires) — many witnesses of one circuit, as the MapReduce jobs of one map/reduce circuit.
+vxs_circuit* vxs_build2(int degree_bits, uint64_t seed, int poseidon_percent, uint64_t witness_seed) {
   if (degree_bits < 3 || degree_bits > 24 || poseidon_percent < 0 || poseidon_percent > 100) return nullptr;
   Synth* S = new Synth();
   S->degree_bits = degree_bits;
   const size_t n = S->n = (size_t)1 << degree_bits;
   const int NW = 135, NR = 80, NSEL = 2, NCONST = 4;
   SplitMix rng{seed};
+  SplitMix wrng{witness_seed ^ 0xA5A5A5A55A5A5A5AULL};
 
   // gates sorted by (degree, id): Noop(0) < Constant(1) < PublicInput(1) < Arithmetic(3) < Poseidon(7);
   // selector_polynomials(max_degree = 9): 7 + 5 - 1 > 9 so two greedy groups [0,4) and [4,5).
@@ -166,7 +173,7 @@ vxs_circuit* vxs_build(int degree_bits, uint64_t seed, int poseidon_percent) {
 
   // public inputs
   S->public_inputs.resize(4);
-  for (auto& v : S->public_inputs) v = rng.field();
+  for (auto& v : S->public_inputs) v = wrng.field();
   // row 1: constants 0, 1
   set_gate(1, 1);
   c0[1] = 0;
@@ -192,7 +199,8 @@ vxs_circuit* vxs_build(int degree_bits, uint64_t seed, int poseidon_percent) {
   }
   // body: interleave Poseidon and arithmetic rows so both gate kinds are spread over the trace
   size_t row = 3, pos_left = n_pos, ar_left = n_arith;
-  size_t prev_pos_row = 2;
+  size_t prev_pos_row = 0;
+  bool have_prev_pos = false;  // the hash chain starts from free inputs, so only rows 0 and 2 depend on the public inputs
   bool have_prev_arith = false;
   size_t prev_arith_row = 0;
   u64 prev_arith_out = 0;
@@ -201,9 +209,11 @@ vxs_circuit* vxs_build(int degree_bits, uint64_t seed, int poseidon_percent) {
     if (!do_pos && ar_left == 0) do_pos = true;
     if (do_pos) {
       set_gate(row, 4);
-      memcpy(in, out, sizeof in);
+      if (have_prev_pos) memcpy(in, out, sizeof in);
+      else for (int i = 0; i < 12; ++i) in[i] = wrng.field();
       fill_poseidon_row(w, n, row, in, out);
-      for (int i = 0; i < 12; ++i) dsu.unite(cell(i, row), cell(12 + i, prev_pos_row));
+      if (have_prev_pos) for (int i = 0; i < 12; ++i) dsu.unite(cell(i, row), cell(12 + i, prev_pos_row));
+      have_prev_pos = true;
       prev_pos_row = row;
       --pos_left;
     } else {
@@ -212,8 +222,8 @@ vxs_circuit* vxs_build(int degree_bits, uint64_t seed, int poseidon_percent) {
       c0[row] = k0;
       c1[row] = k1;
       for (int op = 0; op < 20; ++op) {
-        u64 m0 = (op == 0 && !have_prev_arith) ? rng.field() : prev_arith_out;
-        u64 m1 = rng.field(), ad = rng.field();
+        u64 m0 = (op == 0 && !have_prev_arith) ? wrng.field() : prev_arith_out;
+        u64 m1 = wrng.field(), ad = wrng.field();
         u64 o = add(mul(mul(m0, m1), k0), mul(ad, k1));
         w[(size_t)(4 * op) * n + row] = m0;
         w[(size_t)(4 * op + 1) * n + row] = m1;
@@ -293,6 +303,28 @@ vxs_circuit* vxs_build(int degree_bits, uint64_t seed, int poseidon_percent) {
 }
 
 void vxs_free(vxs_circuit* c) { delete reinterpret_cast<Synth*>(c); }
+/* New public inputs for the same circuit: only witness rows 0 (PublicInputGate) and 2 (in-circuit hash of the
+ * public inputs) change.  Writes the two rows (num_wires values each) for the caller to patch into its copy of the
+ * witness matrix, and updates the generator's own copy if it is still held. */
+void vxs_patch_public_inputs(vxs_circuit* c, const uint64_t pi[4], uint64_t* row0_out, uint64_t* row2_out) {
+  Synth* S = reinterpret_cast<Synth*>(c);
+  const int NW = 135;
+  std::vector<u64> tmp((size_t)NW * 4, 0);  // a 4-row scratch witness, rows 0 and 2 used
+  u64 in[12] = {0}, out[12];
+  for (int i = 0; i < 4; ++i) in[i] = canon(pi[i]);
+  fill_poseidon_row(tmp.data(), 4, 2, in, out);
+  for (int i = 0; i < 4; ++i) tmp[(size_t)i * 4 + 0] = out[i];
+  for (int col = 0; col < NW; ++col) {
+    row0_out[col] = tmp[(size_t)col * 4 + 0];
+    row2_out[col] = tmp[(size_t)col * 4 + 2];
+  }
+  for (int i = 0; i < 4; ++i) S->public_inputs[i] = in[i];
+  if (!S->witness.empty())
+    for (int col = 0; col < NW; ++col) {
+      S->witness[(size_t)col * S->n + 0] = row0_out[col];
+      S->witness[(size_t)col * S->n + 2] = row2_out[col];
+    }
+}
 const vx_circuit_desc* vxs_desc(vxs_circuit* c) { return &reinterpret_cast<Synth*>(c)->desc; }
 const uint64_t* vxs_witness(vxs_circuit* c) { return reinterpret_cast<Synth*>(c)->witness.data(); }
 const uint64_t* vxs_public_inputs(vxs_circuit* c) { return reinterpret_cast<Synth*>(c)->public_inputs.data(); }
