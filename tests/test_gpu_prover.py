@@ -149,3 +149,19 @@ def test_config_variants_stay_byte_identical(ctx, oracle, field, value):
     assert gp == oc.prove(sc.witness())
     assert oc.verify(gp) == ""
     gc.free()
+
+
+def test_randomized_differential_sweep(ctx, oracle):
+    """Many small circuits with different seeds / sizes / gate mixes: GPU proof bytes == oracle proof bytes.
+    (PoW bits lowered so the oracle's scalar grinding does not dominate the run time.)"""
+    rng = np.random.default_rng(2026)
+    for trial in range(100):
+        db = int(rng.integers(3, 10))
+        pct = int(rng.integers(0, 101))
+        sc = SynthCircuit(db, seed=int(rng.integers(1, 1 << 62)), poseidon_percent=pct, witness_seed=int(rng.integers(1, 1 << 62)))
+        sc.desc.pow_bits = 8
+        oc = oracle_lib.OracleCircuit(oracle, sc.desc_ptr)
+        gc = vx.Circuit(ctx, sc.desc_ptr)
+        assert gc.prove(sc.witness()) == oc.prove(sc.witness()), (trial, db, pct)
+        gc.free()
+        oc.free()
