@@ -171,7 +171,30 @@ typedef struct vx_circuit_desc {
   int32_t num_public_inputs;
   const uint32_t* pi_rows;         /* public input target = wire (pi_rows[i], pi_cols[i]) */
   const uint32_t* pi_cols;
+  /* Constraint programs: gates OUTSIDE the native set (plonky2x's U32 gates, CosetInterpolationGate, any custom
+   * gate) are supplied by the caller as straight-line programs over the row's wires and constants — the same
+   * polynomials the gate's `eval_unfiltered` computes (for extension-field gates: expanded to base-field wires).
+   * gate_types[g] = VX_GATE_PROGRAM, gate_params[g] = the gate's degree, program_offsets[g] = word offset of its
+   * program inside `programs` (-1 for native gates).  Encoding: see VX_OP_* below.  All three may be NULL/0. */
+  int32_t programs_len;            /* uint64 words in `programs` */
+  const uint64_t* programs;
+  const int32_t* program_offsets;  /* [num_gates] */
 } vx_circuit_desc;
+
+/* One instruction = one uint64:  op | dst << 8 | a << 16 | b << 32   (VX_OP_LDI is followed by one immediate word).
+ * Registers r0..r63 hold field elements.  Every VX_OP_PUSH emits the next constraint of the gate, in order. */
+#define VX_GATE_PROGRAM 5
+#define VX_PROGRAM_REGS 64
+#define VX_OP_END 0
+#define VX_OP_LDW 1  /* r[dst] = local_wires[a] */
+#define VX_OP_LDC 2  /* r[dst] = local_constants[num_selectors + a]   (the gate's own constants) */
+#define VX_OP_LDI 3  /* r[dst] = immediate (next word, canonical) */
+#define VX_OP_ADD 4  /* r[dst] = r[a] + r[b] */
+#define VX_OP_SUB 5  /* r[dst] = r[a] - r[b] */
+#define VX_OP_MUL 6  /* r[dst] = r[a] * r[b] */
+#define VX_OP_PUSH 7 /* constraint <- r[a] */
+#define VX_OP_LDP 8  /* r[dst] = public_inputs_hash[a] */
+#define VX_INS(op, dst, a, b) ((uint64_t)(op) | ((uint64_t)(dst) << 8) | ((uint64_t)(a) << 16) | ((uint64_t)(b) << 32))
 
 /* CircuitBuilder::build's prover-side tail: commit the preprocessed polynomials (kept resident in HBM
  * for every later proof of this circuit) and derive circuit_digest. */

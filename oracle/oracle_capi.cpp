@@ -139,7 +139,21 @@ struct vxo_circuit_desc {
   const uint64_t* k_is;
   int32_t num_public_inputs;
   const uint32_t *pi_rows, *pi_cols;
+  int32_t programs_len;
+  const uint64_t* programs;
+  const int32_t* program_offsets;
 };
+static void load_gate_program(const vxo_circuit_desc* d, int i, Gate& g) {
+  if (g.type != GATE_PROGRAM) return;
+  if (!d->programs || !d->program_offsets || d->program_offsets[i] < 0) throw std::runtime_error("program gate without a program");
+  for (int pc = d->program_offsets[i]; pc < d->programs_len; ++pc) {
+    u64 ins = d->programs[pc];
+    g.program.push_back(ins);
+    int op = (int)(ins & 0xFF);
+    if (op == OP_END) break;
+    if (op == OP_LDI) g.program.push_back(d->programs[++pc]);
+  }
+}
 
 void* vxo_circuit_create(const vxo_circuit_desc* d) {
   Circuit* c = new Circuit();
@@ -159,6 +173,7 @@ void* vxo_circuit_create(const vxo_circuit_desc* d) {
     g.selector_index = d->selector_indices[i];
     g.group_start = d->group_starts[i];
     g.group_end = d->group_ends[i];
+    load_gate_program(d, i, g);
     c->gates.push_back(g);
   }
   c->num_selectors = d->num_selectors;
@@ -195,6 +210,7 @@ void* vxo_circuit_create_verifier(const vxo_circuit_desc* d, const u64* cap) {
     g.selector_index = d->selector_indices[i];
     g.group_start = d->group_starts[i];
     g.group_end = d->group_ends[i];
+    load_gate_program(d, i, g);
     c->gates.push_back(g);
   }
   c->num_selectors = d->num_selectors;

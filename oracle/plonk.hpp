@@ -67,19 +67,33 @@ struct Challenger {
 // ---------------------------------------------------------------------------------------------
 // Circuit description (CommonCircuitData + the prover-only parts the hot path needs).
 // ---------------------------------------------------------------------------------------------
-enum GateType { GATE_NOOP = 0, GATE_CONSTANT = 1, GATE_PUBLIC_INPUT = 2, GATE_ARITHMETIC = 3, GATE_POSEIDON = 4 };
+enum GateType { GATE_NOOP = 0, GATE_CONSTANT = 1, GATE_PUBLIC_INPUT = 2, GATE_ARITHMETIC = 3, GATE_POSEIDON = 4, GATE_PROGRAM = 5 };
+
+// Constraint-program opcodes (same encoding as include/vxprover.h VX_OP_*; restated, not shared)
+enum ProgOp { OP_END = 0, OP_LDW = 1, OP_LDC = 2, OP_LDI = 3, OP_ADD = 4, OP_SUB = 5, OP_MUL = 6, OP_PUSH = 7, OP_LDP = 8 };
 
 struct Gate {
   int type = 0;
-  int param = 0;           // ArithmeticGate: num_ops; ConstantGate: num_consts
+  int param = 0;           // ArithmeticGate: num_ops; ConstantGate: num_consts; program gate: degree
   int selector_index = 0;  // which selector polynomial (gates/selectors.rs SelectorsInfo)
   int group_start = 0, group_end = 0;
+  std::vector<u64> program;  // GATE_PROGRAM: straight-line constraint program
   int num_constraints() const {
     switch (type) {
       case GATE_NOOP: return 0;
       case GATE_CONSTANT: return param;
       case GATE_PUBLIC_INPUT: return 4;
       case GATE_ARITHMETIC: return param;
+      case GATE_PROGRAM: {
+        int n = 0;
+        for (size_t pc = 0; pc < program.size(); ++pc) {
+          int op = (int)(program[pc] & 0xFF);
+          if (op == OP_END) break;
+          if (op == OP_PUSH) ++n;
+          if (op == OP_LDI) ++pc;
+        }
+        return n;
+      }
       default: return 123;  // PoseidonGate: 12*7 + 22 + 12 + 1 + 4
     }
   }
@@ -163,6 +177,26 @@ static void eval_gate_unfiltered(const Gate& g, const T* consts, const T* wires,
   out.clear();
   switch (g.type) {
     case GATE_NOOP: break;
+    case GATE_PROGRAM: {  // caller-supplied straight-line program: the gate's eval_unfiltered as data
+      T r[64];
+      for (size_t pc = 0; pc < g.program.size(); ++pc) {
+        const u64 ins = g.program[pc];
+        const int op = (int)(ins & 0xFF), dst = (int)((ins >> 8) & 0x3F), a = (int)((ins >> 16) & 0xFFFF), b = (int)((ins >> 32) & 0xFFFF);
+        if (op == OP_END) break;
+        switch (op) {
+          case OP_LDW: r[dst] = wires[a]; break;
+          case OP_LDC: r[dst] = consts[a]; break;
+          case OP_LDI: r[dst] = T(canon(g.program[++pc])); break;
+          case OP_ADD: r[dst] = r[a & 63] + r[b & 63]; break;
+          case OP_SUB: r[dst] = r[a & 63] - r[b & 63]; break;
+          case OP_MUL: r[dst] = r[a & 63] * r[b & 63]; break;
+          case OP_PUSH: out.push_back(r[a & 63]); break;
+          case OP_LDP: r[dst] = T(pih.e[a & 3]); break;
+          default: throw std::runtime_error("bad opcode in a constraint program");
+        }
+      }
+      break;
+    }
     case GATE_CONSTANT:  // gates/constant.rs: constants[i] - wires[i]
       for (int i = 0; i < g.param; ++i) out.push_back(consts[i] - wires[i]);
       break;

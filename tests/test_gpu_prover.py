@@ -165,3 +165,38 @@ def test_randomized_differential_sweep(ctx, oracle):
         assert gc.prove(sc.witness()) == oc.prove(sc.witness()), (trial, db, pct)
         gc.free()
         oc.free()
+
+
+@pytest.mark.parametrize("degree_bits,flags", [(4, 1), (5, 2), (6, 3), (9, 1), (11, 3), (12, 1)])
+def test_constraint_program_gates_byte_identical(ctx, oracle, degree_bits, flags):
+    """Gates supplied as constraint programs (ArithmeticExtensionGate, BaseSumGate<2>, and the ArithmeticGate itself
+    when handed over as a program) are evaluated by program_gates_kernel: proofs stay byte-identical to the oracle."""
+    sc = SynthCircuit(degree_bits, seed=500 + degree_bits, poseidon_percent=40, flags=flags)
+    oc = oracle_lib.OracleCircuit(oracle, sc.desc_ptr)
+    gc = vx.Circuit(ctx, sc.desc_ptr)
+    assert (gc.digest() == oc.digest()).all()
+    gp = gc.prove(sc.witness())
+    assert gp == oc.prove(sc.witness())
+    assert oc.verify(gp) == ""
+    if flags == 2:   # same circuit with the native ArithmeticGate: identical proof
+        native = SynthCircuit(degree_bits, seed=500 + degree_bits, poseidon_percent=40)
+        gn = vx.Circuit(ctx, native.desc_ptr)
+        assert gn.prove(native.witness()) == gp
+        gn.free()
+    gc.free()
+
+
+def test_malformed_constraint_programs_are_refused(ctx):
+    import ctypes
+    sc = SynthCircuit(5, seed=1, poseidon_percent=50, flags=1)
+    d = sc.desc
+    words = (ctypes.c_uint64 * d.programs_len).from_address(d.programs)
+    first = int(words[0])
+    words[0] = 99                       # unknown opcode
+    with pytest.raises(vx.VxError):
+        vx.Circuit(ctx, sc.desc_ptr)
+    words[0] = 1 | (0 << 8) | (500 << 16)   # LDW of wire 500
+    with pytest.raises(vx.VxError):
+        vx.Circuit(ctx, sc.desc_ptr)
+    words[0] = first
+    vx.Circuit(ctx, sc.desc_ptr).free()

@@ -104,3 +104,30 @@ def test_round_trip_other_shapes(oracle, degree_bits, pct):
     sc2 = SynthCircuit(degree_bits, seed=999, poseidon_percent=(pct + 37) % 100)  # different gate layout
     oc2 = oracle_lib.OracleCircuit(oracle, sc2.desc_ptr)
     assert oc2.verify(proof) != ""
+
+
+def test_constraint_program_gates(oracle):
+    """Gates outside the native set travel as straight-line constraint programs (include/vxprover.h VX_OP_*).
+    (1) the interpreter is validated against a native gate: the ArithmeticGate handed over as a program yields a
+        byte-identical proof;  (2) ArithmeticExtensionGate + BaseSumGate<2> exist ONLY as programs: proofs verify, a
+        non-binary limb or a wrong extension product is rejected."""
+    from vectorx_amd.synth import FLAG_ARITH_AS_PROGRAM, FLAG_PROGRAM_GATES
+    base = SynthCircuit(5, seed=3, poseidon_percent=50)
+    as_prog = SynthCircuit(5, seed=3, poseidon_percent=50, flags=FLAG_ARITH_AS_PROGRAM)
+    assert (base.witness() == as_prog.witness()).all()
+    p_native = oracle_lib.OracleCircuit(oracle, base.desc_ptr).prove(base.witness())
+    p_prog = oracle_lib.OracleCircuit(oracle, as_prog.desc_ptr).prove(as_prog.witness())
+    assert p_native == p_prog
+    pg = SynthCircuit(6, seed=4, poseidon_percent=40, flags=FLAG_PROGRAM_GATES)
+    rc = pg.row_counts()
+    assert pg.desc.num_gates == 7 and rc["arithmetic_extension"] >= 1 and rc["base_sum"] >= 1
+    oc = oracle_lib.OracleCircuit(oracle, pg.desc_ptr)
+    proof = oc.prove(pg.witness())
+    assert oc.verify(proof) == ""
+    n = 64
+    bs_row = n - rc["noop"] - 1                       # last BaseSumGate row
+    ext_row = bs_row - rc["base_sum"]                 # last ArithmeticExtensionGate row
+    for (col, row) in ((5, bs_row), (0, bs_row), (6, ext_row), (3, ext_row)):
+        w = pg.witness().copy()
+        w[col, row] = (int(w[col, row]) + 1) % P
+        assert oc.verify(oc.prove(w)) != "", (col, row)

@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256, 4) void quotient_kernel(QuotientParams p) {
   const u64 base_pw[VX_MAX_CHALLENGES] = {A.pw[0], A.pw[1]};
   for (int g = 0; g < p.num_gates; ++g) {
     const GateDev gd = p.gates[g];
-    if (gd.type == 0) continue;  // NoopGate: no constraints
+    if (gd.type == 0 || gd.type == 5) continue;  // NoopGate: no constraints; program gates: program_gates_kernel
     const u64 s = CS(gd.selector_index);
     u64 filter = 1;
     for (int q = gd.group_start; q < gd.group_end; ++q)
@@ -503,5 +503,78 @@ __global__ void gather_open_kernel(const u64* __restrict__ data, size_t stride, 
     }
     size_t node = (idx >> lvl) ^ 1;
     o[width + t] = tree[(off + node) * 4 + e];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Constraint programs (include/vxprover.h VX_OP_*): gates outside the native set arrive as straight-line
+// programs over the row's wires / constants.  One thread per LDE row interprets the program — every lane
+// executes the same instruction, so fetch and decode are wave-uniform — and ADDS
+//   zh_inv * sum_g filter_g * sum_i c_{g,i} alpha^(i + offset)
+// to the quotient values the native kernel already wrote.  The virtual register file is per-thread private
+// memory; this path is for the long tail of cold gates, the hot gates stay compiled.
+// ------------------------------------------------------------------------------------------------
+#define VX_MAX_PROGRAM_GATES 8
+struct ProgramGateDev {
+  int gate_index, selector_index, group_start, group_end, prog_off;
+};
+struct ProgramParams {
+  const u64 *cs, *wires;
+  const u64* programs;
+  size_t N;
+  int log_n, rate_bits, num_selectors, nch, num_gates;
+  ProgramGateDev gates[VX_MAX_PROGRAM_GATES];
+  u64 alphas[VX_MAX_CHALLENGES], base_pw[VX_MAX_CHALLENGES];  // base_pw = alpha^(number of terms before the gate constraints)
+  u64 pih[4];
+  u64 zh_inv[VX_MAX_RATE];
+  u64* out;  // [nch][N], accumulated into
+};
+__global__ __launch_bounds__(256) void program_gates_kernel(ProgramParams p) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= p.N) return;
+  const size_t N = p.N;
+  const u32 r = bitrev32((u32)(i >> p.log_n), p.rate_bits);
+  u64 total[VX_MAX_CHALLENGES] = {0, 0};
+  u64 R[64];
+  for (int g = 0; g < p.num_gates; ++g) {
+    const ProgramGateDev gd = p.gates[g];
+    const u64 s = p.cs[(size_t)gd.selector_index * N + i];
+    u64 filter = 1;
+    for (int q = gd.group_start; q < gd.group_end; ++q)
+      if (q != gd.gate_index) filter = gl_mul(filter, gl_sub((u64)q, s));
+    if (p.num_selectors > 1) filter = gl_mul(filter, gl_sub(UNUSED_SELECTOR_U64, s));
+    u64 acc[VX_MAX_CHALLENGES] = {0, 0}, pw[VX_MAX_CHALLENGES] = {p.base_pw[0], p.base_pw[1]};
+    const u64* __restrict__ prog = p.programs + gd.prog_off;
+    for (int pc = 0;; ++pc) {
+      const u64 ins = prog[pc];
+      const int op = (int)(ins & 0xFF), dst = (int)((ins >> 8) & 63), a = (int)((ins >> 16) & 0xFFFF), b = (int)((ins >> 32) & 0xFFFF);
+      if (op == 0) break;
+      switch (op) {
+        case 1: R[dst] = gl_canon(p.wires[(size_t)a * N + i]); break;
+        case 2: R[dst] = p.cs[(size_t)(p.num_selectors + a) * N + i]; break;
+        case 3: R[dst] = gl_canon(prog[++pc]); break;
+        case 4: R[dst] = gl_add(R[a & 63], R[b & 63]); break;
+        case 5: R[dst] = gl_sub(R[a & 63], R[b & 63]); break;
+        case 6: R[dst] = gl_mul(R[a & 63], R[b & 63]); break;
+        case 7: {
+          const u64 term = R[a & 63];
+#pragma unroll
+          for (int c = 0; c < VX_MAX_CHALLENGES; ++c) {
+            acc[c] = gl_mad(term, pw[c], acc[c]);
+            pw[c] = gl_mul(pw[c], p.alphas[c]);
+          }
+          break;
+        }
+        case 8: R[dst] = p.pih[a & 3]; break;
+        default: break;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < VX_MAX_CHALLENGES; ++c) total[c] = gl_mad(filter, acc[c], total[c]);
+  }
+  const u64 zi = p.zh_inv[r];
+  for (int ch = 0; ch < p.nch; ++ch) {
+    u64* o = p.out + (size_t)ch * N + i;
+    *o = gl_add(*o, gl_mul(total[ch], zi));
   }
 }

@@ -17,6 +17,8 @@ struct vx_circuit {
   std::vector<u64> k_is_host;
   std::vector<uint32_t> pi_rows, pi_cols;
   std::vector<int> arity_bits;
+  std::vector<int> prog_off;   // per gate: word offset into `programs`, -1 for native gates
+  u64* programs = nullptr;     // device copy of the constraint programs
   vx_batch* cs = nullptr;  // constants_sigmas commitment (resident across proofs)
   u64* sigmas = nullptr;   // [nr][n] sigma VALUES on H (natural order) for the permutation argument
   u64* k_is = nullptr;     // device copy
@@ -37,7 +39,23 @@ static int circuit_create(vx_ctx* c, const vx_circuit_desc* d, vx_circuit** out)
   if (!d->constants_sigmas || !d->k_is) return vx_fail(VX_E_INVALID, "circuit: NULL preprocessed data");
   for (int g = 0; g < d->num_gates; ++g) {
     int t = d->gate_types[g];
-    if (t < VX_GATE_NOOP || t > VX_GATE_POSEIDON) return vx_fail(VX_E_INVALID, "circuit: gate type %d is not in the supported set", t);
+    if (t < VX_GATE_NOOP || t > VX_GATE_PROGRAM) return vx_fail(VX_E_INVALID, "circuit: gate type %d is not in the supported set", t);
+    if (t == VX_GATE_PROGRAM) {
+      if (!d->programs || !d->program_offsets || d->program_offsets[g] < 0 || d->program_offsets[g] >= d->programs_len)
+        return vx_fail(VX_E_INVALID, "circuit: program gate %d has no program", g);
+      // validate: terminated, known opcodes, operands in range
+      bool ended = false;
+      for (int pc = d->program_offsets[g]; pc < d->programs_len && !ended; ++pc) {
+        const uint64_t ins = d->programs[pc];
+        const int op = (int)(ins & 0xFF), a = (int)((ins >> 16) & 0xFFFF);
+        if (op == VX_OP_END) ended = true;
+        else if (op == VX_OP_LDI) { if (++pc >= d->programs_len) return vx_fail(VX_E_INVALID, "circuit: truncated program"); }
+        else if (op == VX_OP_LDW) { if (a >= d->num_wires) return vx_fail(VX_E_INVALID, "circuit: program reads wire %d", a); }
+        else if (op == VX_OP_LDC) { if (d->num_selectors + a >= d->num_constants) return vx_fail(VX_E_INVALID, "circuit: program reads constant %d", a); }
+        else if (op < VX_OP_END || op > VX_OP_LDP) return vx_fail(VX_E_INVALID, "circuit: bad opcode %d in a constraint program", op);
+      }
+      if (!ended) return vx_fail(VX_E_INVALID, "circuit: unterminated constraint program");
+    }
     if (t == VX_GATE_POSEIDON && d->num_wires < 135) return vx_fail(VX_E_INVALID, "circuit: PoseidonGate needs 135 wires");
     if (t == VX_GATE_ARITHMETIC && 4 * d->gate_params[g] > d->num_wires) return vx_fail(VX_E_INVALID, "circuit: ArithmeticGate ops exceed the wires");
     if (d->selector_indices[g] < 0 || d->selector_indices[g] >= d->num_selectors) return vx_fail(VX_E_INVALID, "circuit: bad selector index");
@@ -57,6 +75,18 @@ static int circuit_create(vx_ctx* c, const vx_circuit_desc* d, vx_circuit** out)
   k->num_constants = d->num_constants;
   for (int g = 0; g < d->num_gates; ++g)
     k->gates.push_back(GateDev{d->gate_types[g], d->gate_params[g], d->selector_indices[g], d->group_starts[g], d->group_ends[g]});
+  {
+    int nprog = 0;
+    for (int g = 0; g < d->num_gates; ++g) {
+      k->prog_off.push_back(d->gate_types[g] == VX_GATE_PROGRAM ? d->program_offsets[g] : -1);
+      nprog += d->gate_types[g] == VX_GATE_PROGRAM;
+    }
+    if (nprog > VX_MAX_PROGRAM_GATES) { delete k; return vx_fail(VX_E_INVALID, "circuit: too many program gates"); }
+    if (nprog) {
+      if (hipMalloc(&k->programs, (size_t)d->programs_len * 8) != hipSuccess) { delete k; return vx_fail(VX_E_NOMEM, "circuit: out of device memory"); }
+      HIPCHK(hipMemcpy(k->programs, d->programs, (size_t)d->programs_len * 8, hipMemcpyHostToDevice));
+    }
+  }
   k->k_is_host.assign(d->k_is, d->k_is + d->num_routed_wires);
   for (auto& v : k->k_is_host) v = vxh::canon(v);
   k->pi_rows.assign(d->pi_rows, d->pi_rows + d->num_public_inputs);
@@ -114,6 +144,7 @@ static void circuit_free(vx_circuit* k) {
   }
   hipFree(k->sigmas);
   hipFree(k->k_is);
+  hipFree(k->programs);
   delete k;
 }
 
@@ -293,6 +324,29 @@ static int prove_impl(vx_ctx* c, vx_circuit* k, const u64* wires_in, bool wires_
       ProfScope ps(c, "quotient_eval", (double)bytes_read);
       hipLaunchKernelGGL(quotient_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, qp);
       HIPCHK(hipGetLastError());
+      if (k->programs) {  // gates supplied as constraint programs add their share to the same quotient values
+        ProgramParams pg;
+        memset(&pg, 0, sizeof pg);
+        pg.cs = k->cs->lde;
+        pg.wires = wires_b->lde;
+        pg.programs = k->programs;
+        pg.N = N;
+        pg.log_n = lg;
+        pg.rate_bits = rb;
+        pg.num_selectors = k->num_selectors;
+        pg.nch = nch;
+        for (size_t g = 0; g < k->gates.size(); ++g)
+          if (k->prog_off[g] >= 0)
+            pg.gates[pg.num_gates++] = ProgramGateDev{(int)g, k->gates[g].selector_index, k->gates[g].group_start, k->gates[g].group_end, k->prog_off[g]};
+        const u64 nterms = (u64)nch * (1 + nchunks);  // L_0 terms + partial-product checks come first
+        for (int i = 0; i < VX_MAX_CHALLENGES; ++i) pg.alphas[i] = alphas[i], pg.base_pw[i] = pow(alphas[i], nterms);
+        for (int i = 0; i < 4; ++i) pg.pih[i] = pih.e[i];
+        for (int r = 0; r < rate; ++r) pg.zh_inv[r] = qp.zh_inv[r];
+        pg.out = qv;
+        ProfScope ps2(c, "quotient_program_gates");
+        hipLaunchKernelGGL(program_gates_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, pg);
+        HIPCHK(hipGetLastError());
+      }
     }
     // per-coset inverse NTT (input rows of each block are in bit-reversed order), then the cross-coset
     // inverse DFT that separates the degree-n chunks

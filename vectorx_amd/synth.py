@@ -25,7 +25,12 @@ class CircuitDesc(ctypes.Structure):
         ("num_selectors", ctypes.c_int32), ("num_constants", ctypes.c_int32),
         ("constants_sigmas", ctypes.c_void_p), ("k_is", ctypes.c_void_p),
         ("num_public_inputs", ctypes.c_int32), ("pi_rows", ctypes.c_void_p), ("pi_cols", ctypes.c_void_p),
+        ("programs_len", ctypes.c_int32), ("programs", ctypes.c_void_p), ("program_offsets", ctypes.c_void_p),
     ]
+
+
+FLAG_PROGRAM_GATES = 1      # add ArithmeticExtensionGate + BaseSumGate rows, evaluated through constraint programs
+FLAG_ARITH_AS_PROGRAM = 2   # hand the ArithmeticGate to the prover as a constraint program instead of the native gate
 
 
 def build() -> Path:
@@ -48,6 +53,9 @@ def _load():
         L.vxs_build.argtypes = [ctypes.c_int, ctypes.c_uint64, ctypes.c_int]
         L.vxs_build2.restype = ctypes.c_void_p
         L.vxs_build2.argtypes = [ctypes.c_int, ctypes.c_uint64, ctypes.c_int, ctypes.c_uint64]
+        L.vxs_build3.restype = ctypes.c_void_p
+        L.vxs_build3.argtypes = [ctypes.c_int, ctypes.c_uint64, ctypes.c_int, ctypes.c_uint64, ctypes.c_int]
+        L.vxs_row_counts_ext.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         L.vxs_patch_public_inputs.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         L.vxs_free.argtypes = [ctypes.c_void_p]
         L.vxs_desc.restype = ctypes.POINTER(CircuitDesc)
@@ -65,10 +73,11 @@ def _load():
 class SynthCircuit:
     """A synthetic standard_recursion_config circuit with a satisfying witness."""
 
-    def __init__(self, degree_bits: int, seed: int = 0, poseidon_percent: int = 50, witness_seed: int | None = None):
-        """`seed` fixes the circuit; `witness_seed` (default = seed) only the witness values."""
+    def __init__(self, degree_bits: int, seed: int = 0, poseidon_percent: int = 50, witness_seed: int | None = None,
+                 flags: int = 0):
+        """`seed` fixes the circuit; `witness_seed` (default = seed) only the witness values; `flags`: FLAG_*."""
         L = _load()
-        self._h = L.vxs_build2(degree_bits, seed, poseidon_percent, seed if witness_seed is None else witness_seed)
+        self._h = L.vxs_build3(degree_bits, seed, poseidon_percent, seed if witness_seed is None else witness_seed, flags)
         if not self._h:
             raise ValueError("vxs_build rejected the parameters")
         self.degree_bits = degree_bits
@@ -99,7 +108,12 @@ class SynthCircuit:
     def row_counts(self) -> dict:
         out = np.zeros(3, np.uint64)
         _load().vxs_row_counts(self._h, out.ctypes.data)
-        return {"poseidon": int(out[0]), "arithmetic": int(out[1]), "noop": int(out[2]), "other": 2}
+        ext = np.zeros(5, np.uint64)
+        _load().vxs_row_counts_ext(self._h, ext.ctypes.data)
+        d = {"poseidon": int(out[0]), "arithmetic": int(out[1]), "noop": int(out[2]), "other": 2}
+        if int(ext[3]) or int(ext[4]):
+            d["arithmetic_extension"], d["base_sum"] = int(ext[3]), int(ext[4])
+        return d
 
     def release_host_buffers(self, witness=True, preprocessed=True):
         _load().vxs_release_host_buffers(self._h, int(witness), int(preprocessed))

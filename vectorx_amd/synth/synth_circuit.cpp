@@ -6,25 +6,33 @@
 // cannot be extracted without Rust, so benchmarks and parity tests use this DECLARED
 // stand-in: a standard_recursion_config circuit (135 wires, 80 routed) over the gate set
 //   NoopGate, ConstantGate{2}, PublicInputGate, ArithmeticGate{20 ops}, PoseidonGate
-// laid out as
+// (+ with VXS_FLAG_PROGRAM_GATES: ArithmeticExtensionGate{10 ops} and BaseSumGate<2>{63 limbs}, supplied to the
+//  prover as CONSTRAINT PROGRAMS — the mechanism for every gate outside the native set) laid out as
 //   row 0  PublicInputGate (wires 0..3 = public_inputs_hash)
 //   row 1  ConstantGate    (constants 0 and 1)
 //   row 2  PoseidonGate    hashing the 4 public inputs in-circuit (outputs 0..3 copy-constrained to row 0)
 //   then   P PoseidonGate rows forming a hash chain (output of one row copy-constrained to the next input),
 //          A ArithmeticGate rows (20 ops each, op k's first multiplicand copy-constrained to op k-1's output),
-//          and NoopGate padding to 2^degree_bits rows.
-// Everything is derived deterministically from (degree_bits, seed, poseidon_percent).
+//          [E ArithmeticExtensionGate rows, B BaseSumGate rows,] and NoopGate padding to 2^degree_bits rows.
+// The gate list is sorted by (degree, id) and selectors are grouped exactly as plonky2's
+// gates/selectors.rs::selector_polynomials does (max_degree = quotient_degree_factor + 1 = 9).
+// Everything is derived deterministically from (degree_bits, seed, poseidon_percent, witness_seed, flags):
+// `seed` fixes the CIRCUIT (layout, arithmetic constants, copy constraints), `witness_seed` only the witness values.
 // Built into vectorx_amd/libvxsynth.so (plain g++; no GPU code).
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include <numeric>
+#include <string>
 #include <vector>
 #include "../../include/vxprover.h"
 #include "../csrc/host_field.h"
 
 using namespace vxh;
+
+#define VXS_FLAG_PROGRAM_GATES 1     /* add ArithmeticExtensionGate + BaseSumGate rows, evaluated through constraint programs */
+#define VXS_FLAG_ARITH_AS_PROGRAM 2  /* hand the ArithmeticGate to the prover as a program instead of the native gate */
 
 namespace {
 struct SplitMix {
@@ -43,16 +51,23 @@ struct SplitMix {
   }
 };
 
+enum Key { K_NOOP, K_CONST, K_PI, K_ARITH, K_POSEIDON, K_ARITHEXT, K_BASESUM, K_COUNT };
+struct GateInfo {
+  int key, type, param, degree;
+  std::string id;
+};
+
 struct Synth {
   int degree_bits;
   size_t n;
-  std::vector<int32_t> gate_types, gate_params, selector_indices, group_starts, group_ends;
-  std::vector<u64> constants_sigmas;  // [4 + 80][n]
+  std::vector<int32_t> gate_types, gate_params, selector_indices, group_starts, group_ends, program_offsets;
+  std::vector<u64> programs;
+  std::vector<u64> constants_sigmas;  // [num_constants + 80][n]
   std::vector<u64> k_is;
   std::vector<uint32_t> pi_rows, pi_cols;
   std::vector<u64> witness;  // [135][n]
   std::vector<u64> public_inputs;
-  size_t n_poseidon = 0, n_arith = 0, n_noop = 0;
+  size_t n_poseidon = 0, n_arith = 0, n_noop = 0, n_arithext = 0, n_basesum = 0;
   vx_circuit_desc desc;
 };
 
@@ -73,8 +88,8 @@ void fill_poseidon_row(u64* w /* witness base */, size_t n, size_t row, const u6
   };
   u64 s[12];
   for (int i = 0; i < 12; ++i) W(i) = s[i] = in[i];
-  W(24) = 0;                                 // swap
-  for (int i = 0; i < 4; ++i) W(25 + i) = 0; // delta_i = swap * (rhs - lhs)
+  W(24) = 0;                                  // swap
+  for (int i = 0; i < 4; ++i) W(25 + i) = 0;  // delta_i = swap * (rhs - lhs)
   int round = 0;
   for (int r = 0; r < 4; ++r) {
     for (int i = 0; i < 12; ++i) s[i] = add(s[i], RC[12 * round + i]);
@@ -116,57 +131,190 @@ struct DSU {
     if (a != b) p[std::max(a, b)] = std::min(a, b);
   }
 };
+
+// ---- constraint programs (include/vxprover.h VX_OP_*) -----------------------------------------------------
+struct Prog {
+  std::vector<u64> w;
+  void ins(int op, int dst, int a = 0, int b = 0) { w.push_back(VX_INS(op, dst, a, b)); }
+  void ldi(int dst, u64 imm) {
+    ins(VX_OP_LDI, dst);
+    w.push_back(imm);
+  }
+};
+// gates/arithmetic_base.rs: output - (m0*m1*c0 + addend*c1), num_ops times
+Prog program_arithmetic(int num_ops) {
+  Prog p;
+  p.ins(VX_OP_LDC, 4, 0);
+  p.ins(VX_OP_LDC, 5, 1);
+  for (int i = 0; i < num_ops; ++i) {
+    for (int k = 0; k < 4; ++k) p.ins(VX_OP_LDW, k, 4 * i + k);
+    p.ins(VX_OP_MUL, 6, 0, 1);
+    p.ins(VX_OP_MUL, 6, 6, 4);
+    p.ins(VX_OP_MUL, 7, 2, 5);
+    p.ins(VX_OP_ADD, 6, 6, 7);
+    p.ins(VX_OP_SUB, 6, 3, 6);
+    p.ins(VX_OP_PUSH, 0, 6);
+  }
+  p.ins(VX_OP_END, 0);
+  return p;
+}
+// gates/arithmetic_extension.rs (D = 2, expanded to base-field wires): out - ((m0*m1)*c0 + addend*c1) in F_p[X]/(X^2-7)
+Prog program_arithmetic_extension(int num_ops) {
+  Prog p;
+  p.ins(VX_OP_LDC, 10, 0);
+  p.ins(VX_OP_LDC, 11, 1);
+  p.ldi(12, 7);
+  for (int i = 0; i < num_ops; ++i) {
+    for (int k = 0; k < 8; ++k) p.ins(VX_OP_LDW, k, 8 * i + k);  // m0 = (r0,r1) m1 = (r2,r3) addend = (r4,r5) out = (r6,r7)
+    p.ins(VX_OP_MUL, 13, 0, 2);    // m0a*m1a
+    p.ins(VX_OP_MUL, 14, 1, 3);    // m0b*m1b
+    p.ins(VX_OP_MUL, 14, 14, 12);  // *7
+    p.ins(VX_OP_ADD, 13, 13, 14);  // prod.a
+    p.ins(VX_OP_MUL, 15, 0, 3);
+    p.ins(VX_OP_MUL, 16, 1, 2);
+    p.ins(VX_OP_ADD, 15, 15, 16);  // prod.b
+    p.ins(VX_OP_MUL, 13, 13, 10);
+    p.ins(VX_OP_MUL, 17, 4, 11);
+    p.ins(VX_OP_ADD, 13, 13, 17);
+    p.ins(VX_OP_SUB, 13, 6, 13);
+    p.ins(VX_OP_PUSH, 0, 13);
+    p.ins(VX_OP_MUL, 15, 15, 10);
+    p.ins(VX_OP_MUL, 17, 5, 11);
+    p.ins(VX_OP_ADD, 15, 15, 17);
+    p.ins(VX_OP_SUB, 15, 7, 15);
+    p.ins(VX_OP_PUSH, 0, 15);
+  }
+  p.ins(VX_OP_END, 0);
+  return p;
+}
+// gates/base_sum.rs (B = 2): reduce_with_powers(limbs, 2) - sum, then limb*(limb-1) per limb
+Prog program_base_sum(int num_limbs) {
+  Prog p;
+  p.ldi(1, 2);
+  p.ldi(2, 1);
+  p.ins(VX_OP_LDW, 3, num_limbs);  // top limb = wire 1 + (num_limbs-1)
+  for (int i = num_limbs - 2; i >= 0; --i) {
+    p.ins(VX_OP_MUL, 3, 3, 1);
+    p.ins(VX_OP_LDW, 4, 1 + i);
+    p.ins(VX_OP_ADD, 3, 3, 4);
+  }
+  p.ins(VX_OP_LDW, 4, 0);
+  p.ins(VX_OP_SUB, 3, 3, 4);
+  p.ins(VX_OP_PUSH, 0, 3);
+  for (int i = 0; i < num_limbs; ++i) {
+    p.ins(VX_OP_LDW, 4, 1 + i);
+    p.ins(VX_OP_SUB, 5, 4, 2);
+    p.ins(VX_OP_MUL, 5, 5, 4);
+    p.ins(VX_OP_PUSH, 0, 5);
+  }
+  p.ins(VX_OP_END, 0);
+  return p;
+}
 }  // namespace
 
 extern "C" {
 
 typedef struct vxs_circuit vxs_circuit;
 
-vxs_circuit* vxs_build2(int degree_bits, uint64_t seed, int poseidon_percent, uint64_t witness_seed);
-vxs_circuit* vxs_build(int degree_bits, uint64_t seed, int poseidon_percent) {
-  return vxs_build2(degree_bits, seed, poseidon_percent, seed);
-}
-// `seed` fixes the CIRCUIT (gate layout, arithmetic constants, copy constraints); `witness_seed` only the witness
-// values (public inputs, free wires) — many witnesses of one circuit, as the MapReduce jobs of one map/reduce circuit.
+vxs_circuit* vxs_build3(int degree_bits, uint64_t seed, int poseidon_percent, uint64_t witness_seed, int flags);
 vxs_circuit* vxs_build2(int degree_bits, uint64_t seed, int poseidon_percent, uint64_t witness_seed) {
+  return vxs_build3(degree_bits, seed, poseidon_percent, witness_seed, 0);
+}
+vxs_circuit* vxs_build(int degree_bits, uint64_t seed, int poseidon_percent) {
+  return vxs_build3(degree_bits, seed, poseidon_percent, seed, 0);
+}
+
+vxs_circuit* vxs_build3(int degree_bits, uint64_t seed, int poseidon_percent, uint64_t witness_seed, int flags) {
   if (degree_bits < 3 || degree_bits > 24 || poseidon_percent < 0 || poseidon_percent > 100) return nullptr;
+  const bool with_prog = flags & VXS_FLAG_PROGRAM_GATES, arith_prog = flags & VXS_FLAG_ARITH_AS_PROGRAM;
+  if (with_prog && degree_bits < 4) return nullptr;
   Synth* S = new Synth();
   S->degree_bits = degree_bits;
   const size_t n = S->n = (size_t)1 << degree_bits;
-  const int NW = 135, NR = 80, NSEL = 2, NCONST = 4;
+  const int NW = 135, NR = 80;
   SplitMix rng{seed};
   SplitMix wrng{witness_seed ^ 0xA5A5A5A55A5A5A5AULL};
 
-  // gates sorted by (degree, id): Noop(0) < Constant(1) < PublicInput(1) < Arithmetic(3) < Poseidon(7);
-  // selector_polynomials(max_degree = 9): 7 + 5 - 1 > 9 so two greedy groups [0,4) and [4,5).
-  S->gate_types = {VX_GATE_NOOP, VX_GATE_CONSTANT, VX_GATE_PUBLIC_INPUT, VX_GATE_ARITHMETIC, VX_GATE_POSEIDON};
-  S->gate_params = {0, 2, 0, 20, 0};
-  S->selector_indices = {0, 0, 0, 0, 1};
-  S->group_starts = {0, 0, 0, 0, 4};
-  S->group_ends = {4, 4, 4, 4, 5};
+  // ---- gate list sorted by (degree, id) as CircuitBuilder::build does; ids are plonky2's Debug strings ----
+  std::vector<GateInfo> gates = {
+      {K_NOOP, VX_GATE_NOOP, 0, 0, "NoopGate"},
+      {K_CONST, VX_GATE_CONSTANT, 2, 1, "ConstantGate { num_consts: 2 }"},
+      {K_PI, VX_GATE_PUBLIC_INPUT, 0, 1, "PublicInputGate"},
+      {K_ARITH, arith_prog ? VX_GATE_PROGRAM : VX_GATE_ARITHMETIC, arith_prog ? 3 : 20, 3, "ArithmeticGate { num_ops: 20 }"},
+      {K_POSEIDON, VX_GATE_POSEIDON, 0, 7, "PoseidonGate(PhantomData<plonky2_field::goldilocks_field::GoldilocksField>)<WIDTH=12>"},
+  };
+  if (with_prog) {
+    gates.push_back({K_ARITHEXT, VX_GATE_PROGRAM, 3, 3, "ArithmeticExtensionGate { num_ops: 10 }"});
+    gates.push_back({K_BASESUM, VX_GATE_PROGRAM, 2, 2, "BaseSumGate { num_limbs: 63 } + Base: 2"});
+  }
+  std::sort(gates.begin(), gates.end(), [](const GateInfo& a, const GateInfo& b) {
+    return a.degree != b.degree ? a.degree < b.degree : a.id < b.id;
+  });
+  const int ng = (int)gates.size();
+  int idx_of[K_COUNT];
+  for (int k = 0; k < K_COUNT; ++k) idx_of[k] = -1;
+  for (int g = 0; g < ng; ++g) idx_of[gates[g].key] = g;
+  // gates/selectors.rs::selector_polynomials, max_degree = 9
+  const int max_degree = 9;
+  std::vector<std::pair<int, int>> groups;
+  if (gates.back().degree + ng - 1 <= max_degree) {
+    groups.push_back({0, ng});
+  } else {
+    int start = 0;
+    while (start < ng) {
+      int size = 0;
+      while (start + size < ng && size + gates[start + size].degree < max_degree) ++size;
+      groups.push_back({start, start + size});
+      start += size;
+    }
+  }
+  const int NSEL = (int)groups.size(), NCONST = NSEL + 2;
+  std::vector<int> group_of(ng);
+  for (int g = 0; g < ng; ++g)
+    for (int q = 0; q < NSEL; ++q)
+      if (g >= groups[q].first && g < groups[q].second) group_of[g] = q;
+  for (int g = 0; g < ng; ++g) {
+    S->gate_types.push_back(gates[g].type);
+    S->gate_params.push_back(gates[g].param);
+    S->selector_indices.push_back(group_of[g]);
+    S->group_starts.push_back(groups[group_of[g]].first);
+    S->group_ends.push_back(groups[group_of[g]].second);
+    S->program_offsets.push_back(-1);
+  }
+  auto attach = [&](int key, const Prog& p) {
+    S->program_offsets[idx_of[key]] = (int32_t)S->programs.size();
+    S->programs.insert(S->programs.end(), p.w.begin(), p.w.end());
+  };
+  if (arith_prog) attach(K_ARITH, program_arithmetic(20));
+  if (with_prog) {
+    attach(K_ARITHEXT, program_arithmetic_extension(10));
+    attach(K_BASESUM, program_base_sum(63));
+  }
 
+  // ---- row budget ----
   const size_t body = n - 3;
   size_t n_noop = std::max<size_t>(1, body / 64);
   if (n_noop > body) n_noop = body;
-  size_t n_pos = (body - n_noop) * (size_t)poseidon_percent / 100;
-  size_t n_arith = body - n_noop - n_pos;
+  size_t n_ext = with_prog ? std::max<size_t>(1, body / 16) : 0, n_bs = with_prog ? std::max<size_t>(1, body / 16) : 0;
+  while (n_noop + n_ext + n_bs > body && n_ext > 0) --n_ext, --n_bs;
+  size_t rest = body - n_noop - n_ext - n_bs;
+  size_t n_pos = rest * (size_t)poseidon_percent / 100;
+  size_t n_arith = rest - n_pos;
   S->n_poseidon = n_pos + 1;
   S->n_arith = n_arith;
   S->n_noop = n_noop;
+  S->n_arithext = n_ext;
+  S->n_basesum = n_bs;
 
   S->witness.assign((size_t)NW * n, 0);
   S->constants_sigmas.assign((size_t)(NCONST + NR) * n, 0);
   u64* w = S->witness.data();
-  u64* sel0 = &S->constants_sigmas[0];
-  u64* sel1 = &S->constants_sigmas[n];
-  u64* c0 = &S->constants_sigmas[2 * n];
-  u64* c1 = &S->constants_sigmas[3 * n];
+  u64* c0 = &S->constants_sigmas[(size_t)NSEL * n];
+  u64* c1 = &S->constants_sigmas[(size_t)(NSEL + 1) * n];
   const u64 UNUSED = 0xFFFFFFFFULL;
-  std::vector<int> row_gate(n);
-  auto set_gate = [&](size_t row, int g) {
-    row_gate[row] = g;
-    sel0[row] = g < 4 ? (u64)g : UNUSED;
-    sel1[row] = g == 4 ? 4 : UNUSED;
+  auto set_gate = [&](size_t row, int key) {
+    const int g = idx_of[key];
+    for (int q = 0; q < NSEL; ++q) S->constants_sigmas[(size_t)q * n + row] = group_of[g] == q ? (u64)g : UNUSED;
   };
   DSU dsu((size_t)NR * n);
   auto cell = [&](int col, size_t row) { return (uint32_t)((size_t)col * n + row); };
@@ -175,13 +323,13 @@ vxs_circuit* vxs_build2(int degree_bits, uint64_t seed, int poseidon_percent, ui
   S->public_inputs.resize(4);
   for (auto& v : S->public_inputs) v = wrng.field();
   // row 1: constants 0, 1
-  set_gate(1, 1);
+  set_gate(1, K_CONST);
   c0[1] = 0;
   c1[1] = 1;
   w[0 * n + 1] = 0;
   w[1 * n + 1] = 1;
   // row 2: in-circuit hash of the public inputs
-  set_gate(2, 4);
+  set_gate(2, K_POSEIDON);
   u64 in[12] = {0}, out[12];
   for (int i = 0; i < 4; ++i) in[i] = S->public_inputs[i];
   fill_poseidon_row(w, n, 2, in, out);
@@ -192,7 +340,7 @@ vxs_circuit* vxs_build2(int degree_bits, uint64_t seed, int poseidon_percent, ui
   for (int j = 4; j < 12; ++j) dsu.unite(cell(j, 2), cell(0, 1));  // zero padding of the sponge
   dsu.unite(cell(24, 2), cell(0, 1));                              // swap = 0
   // row 0: public input gate carries the hash
-  set_gate(0, 2);
+  set_gate(0, K_PI);
   for (int i = 0; i < 4; ++i) {
     w[(size_t)i * n + 0] = out[i];
     dsu.unite(cell(i, 0), cell(12 + i, 2));
@@ -208,7 +356,7 @@ vxs_circuit* vxs_build2(int degree_bits, uint64_t seed, int poseidon_percent, ui
     bool do_pos = pos_left * (n_arith + 1) >= ar_left * (n_pos + 1) ? pos_left > 0 : false;
     if (!do_pos && ar_left == 0) do_pos = true;
     if (do_pos) {
-      set_gate(row, 4);
+      set_gate(row, K_POSEIDON);
       if (have_prev_pos) memcpy(in, out, sizeof in);
       else for (int i = 0; i < 12; ++i) in[i] = wrng.field();
       fill_poseidon_row(w, n, row, in, out);
@@ -217,7 +365,7 @@ vxs_circuit* vxs_build2(int degree_bits, uint64_t seed, int poseidon_percent, ui
       prev_pos_row = row;
       --pos_left;
     } else {
-      set_gate(row, 3);
+      set_gate(row, K_ARITH);
       u64 k0 = rng.field(), k1 = rng.field();
       c0[row] = k0;
       c1[row] = k1;
@@ -239,7 +387,35 @@ vxs_circuit* vxs_build2(int degree_bits, uint64_t seed, int poseidon_percent, ui
     }
     ++row;
   }
-  for (; row < n; ++row) set_gate(row, 0);
+  // ArithmeticExtensionGate rows: 10 ops in F_p^2, op k's first multiplicand copy-constrained to op k-1's output
+  for (size_t e = 0; e < n_ext; ++e, ++row) {
+    set_gate(row, K_ARITHEXT);
+    const u64 k0 = rng.field(), k1 = rng.field();
+    c0[row] = k0;
+    c1[row] = k1;
+    Ext prev{0, 0};
+    for (int op = 0; op < 10; ++op) {
+      Ext m0 = op == 0 ? Ext{wrng.field(), wrng.field()} : prev;
+      Ext m1{wrng.field(), wrng.field()}, ad{wrng.field(), wrng.field()};
+      Ext pr = emul(m0, m1);
+      Ext o{add(mul(pr.a, k0), mul(ad.a, k1)), add(mul(pr.b, k0), mul(ad.b, k1))};
+      const u64 vals[8] = {m0.a, m0.b, m1.a, m1.b, ad.a, ad.b, o.a, o.b};
+      for (int k = 0; k < 8; ++k) w[(size_t)(8 * op + k) * n + row] = vals[k];
+      if (op > 0) {
+        dsu.unite(cell(8 * op, row), cell(8 * op - 2, row));
+        dsu.unite(cell(8 * op + 1, row), cell(8 * op - 1, row));
+      }
+      prev = o;
+    }
+  }
+  // BaseSumGate<2> rows: wire 0 = sum of 63 binary limbs (wires 1..63, little-endian)
+  for (size_t b = 0; b < n_bs; ++b, ++row) {
+    set_gate(row, K_BASESUM);
+    const u64 v = wrng.next() >> 1;  // < 2^63 < p
+    w[0 * n + row] = v;
+    for (int i = 0; i < 63; ++i) w[(size_t)(1 + i) * n + row] = (v >> i) & 1;
+  }
+  for (; row < n; ++row) set_gate(row, K_NOOP);
 
   // k_is = 7^j (plonk_common / circuit_builder: get_unique_coset_shifts)
   S->k_is.resize(NR);
@@ -286,7 +462,7 @@ vxs_circuit* vxs_build2(int degree_bits, uint64_t seed, int poseidon_percent, ui
   d.pow_bits = 16;
   d.num_query_rounds = 28;
   d.quotient_degree_factor = 8;
-  d.num_gates = 5;
+  d.num_gates = ng;
   d.gate_types = S->gate_types.data();
   d.gate_params = S->gate_params.data();
   d.selector_indices = S->selector_indices.data();
@@ -299,6 +475,9 @@ vxs_circuit* vxs_build2(int degree_bits, uint64_t seed, int poseidon_percent, ui
   d.num_public_inputs = 4;
   d.pi_rows = S->pi_rows.data();
   d.pi_cols = S->pi_cols.data();
+  d.programs_len = (int32_t)S->programs.size();
+  d.programs = S->programs.empty() ? nullptr : S->programs.data();
+  d.program_offsets = S->program_offsets.data();
   return reinterpret_cast<vxs_circuit*>(S);
 }
 
@@ -333,6 +512,14 @@ void vxs_row_counts(vxs_circuit* c, uint64_t out[3]) {
   out[0] = S->n_poseidon;
   out[1] = S->n_arith;
   out[2] = S->n_noop;
+}
+void vxs_row_counts_ext(vxs_circuit* c, uint64_t out[5]) {
+  Synth* S = reinterpret_cast<Synth*>(c);
+  out[0] = S->n_poseidon;
+  out[1] = S->n_arith;
+  out[2] = S->n_noop;
+  out[3] = S->n_arithext;
+  out[4] = S->n_basesum;
 }
 /* Drop the (large) sigma/witness host copies once they have been handed to a prover. */
 void vxs_release_host_buffers(vxs_circuit* c, int witness, int preprocessed) {
