@@ -131,3 +131,31 @@ def test_constraint_program_gates(oracle):
         w = pg.witness().copy()
         w[col, row] = (int(w[col, row]) + 1) % P
         assert oc.verify(oc.prove(w)) != "", (col, row)
+
+
+def test_higher_degree_program_gates_and_three_selector_groups(oracle):
+    """ExponentiationGate{66 bits} (degree 4) and RandomAccessGate{bits 4, 4 copies, 2 extra constants} (degree 5) as
+    constraint programs: with the degree-2/3 program gates the 9 gates no longer fit two selector groups
+    (gates/selectors.rs: max_degree 9), so this also covers a third selector polynomial."""
+    from vectorx_amd.synth import FLAG_MORE_PROGRAM_GATES, FLAG_PROGRAM_GATES
+    sc = SynthCircuit(6, seed=11, poseidon_percent=40, flags=FLAG_PROGRAM_GATES | FLAG_MORE_PROGRAM_GATES)
+    rc = sc.row_counts()
+    assert sc.desc.num_gates == 9 and sc.desc.num_selectors == 3 and sc.desc.num_constants == 5
+    assert rc["exponentiation"] >= 1 and rc["random_access"] >= 1
+    oc = oracle_lib.OracleCircuit(oracle, sc.desc_ptr)
+    w = sc.witness()
+    proof = oc.prove(w)
+    assert oc.verify(proof) == ""
+    n = 64
+    ra_row = n - rc["noop"] - 1                                  # last RandomAccessGate row
+    exp_row = ra_row - rc["random_access"]                       # last ExponentiationGate row
+    # the exponentiation row really computes base^exponent
+    bits = [int(w[1 + i, exp_row]) for i in range(66)]
+    assert int(w[67, exp_row]) == pow(int(w[0, exp_row]), sum(b << i for i, b in enumerate(bits)), P)
+    # the random-access row really looks up claimed = list[index]
+    idx = int(w[0, ra_row])
+    assert int(w[1, ra_row]) == int(w[2 + idx, ra_row])
+    for (col, row) in ((67, exp_row), (70, exp_row), (3, exp_row), (1, ra_row), (0, ra_row), (74, ra_row), (72, ra_row)):
+        bad = w.copy()
+        bad[col, row] = (int(bad[col, row]) + 1) % P
+        assert oc.verify(oc.prove(bad)) != "", (col, row)

@@ -13,7 +13,7 @@
 #include "ntt.hip.h"
 #include "poseidon.hip.h"
 
-#define VX_MAX_GATES 8
+#define VX_MAX_GATES 32
 #define VX_MAX_CHALLENGES 2
 #define VX_MAX_RATE 16
 
@@ -514,7 +514,7 @@ __global__ void gather_open_kernel(const u64* __restrict__ data, size_t stride, 
 // to the quotient values the native kernel already wrote.  The virtual register file is per-thread private
 // memory; this path is for the long tail of cold gates, the hot gates stay compiled.
 // ------------------------------------------------------------------------------------------------
-#define VX_MAX_PROGRAM_GATES 8
+#define VX_MAX_PROGRAM_GATES 32
 struct ProgramGateDev {
   int gate_index, selector_index, group_start, group_end, prog_off;
 };

@@ -31,6 +31,7 @@ class CircuitDesc(ctypes.Structure):
 
 FLAG_PROGRAM_GATES = 1      # add ArithmeticExtensionGate + BaseSumGate rows, evaluated through constraint programs
 FLAG_ARITH_AS_PROGRAM = 2   # hand the ArithmeticGate to the prover as a constraint program instead of the native gate
+FLAG_MORE_PROGRAM_GATES = 4  # + ExponentiationGate (degree 4) and RandomAccessGate (degree 5) as programs: 3 selector groups
 
 
 def build() -> Path:
@@ -108,11 +109,13 @@ class SynthCircuit:
     def row_counts(self) -> dict:
         out = np.zeros(3, np.uint64)
         _load().vxs_row_counts(self._h, out.ctypes.data)
-        ext = np.zeros(5, np.uint64)
+        ext = np.zeros(7, np.uint64)
         _load().vxs_row_counts_ext(self._h, ext.ctypes.data)
         d = {"poseidon": int(out[0]), "arithmetic": int(out[1]), "noop": int(out[2]), "other": 2}
         if int(ext[3]) or int(ext[4]):
             d["arithmetic_extension"], d["base_sum"] = int(ext[3]), int(ext[4])
+        if int(ext[5]) or int(ext[6]):
+            d["exponentiation"], d["random_access"] = int(ext[5]), int(ext[6])
         return d
 
     def release_host_buffers(self, witness=True, preprocessed=True):

@@ -33,6 +33,7 @@ using namespace vxh;
 
 #define VXS_FLAG_PROGRAM_GATES 1     /* add ArithmeticExtensionGate + BaseSumGate rows, evaluated through constraint programs */
 #define VXS_FLAG_ARITH_AS_PROGRAM 2  /* hand the ArithmeticGate to the prover as a program instead of the native gate */
+#define VXS_FLAG_MORE_PROGRAM_GATES 4 /* + ExponentiationGate{66 bits} (degree 4) and RandomAccessGate{bits 4} (degree 5): 3 selector groups */
 
 namespace {
 struct SplitMix {
@@ -51,7 +52,7 @@ struct SplitMix {
   }
 };
 
-enum Key { K_NOOP, K_CONST, K_PI, K_ARITH, K_POSEIDON, K_ARITHEXT, K_BASESUM, K_COUNT };
+enum Key { K_NOOP, K_CONST, K_PI, K_ARITH, K_POSEIDON, K_ARITHEXT, K_BASESUM, K_EXP, K_RANDACC, K_COUNT };
 struct GateInfo {
   int key, type, param, degree;
   std::string id;
@@ -67,7 +68,7 @@ struct Synth {
   std::vector<uint32_t> pi_rows, pi_cols;
   std::vector<u64> witness;  // [135][n]
   std::vector<u64> public_inputs;
-  size_t n_poseidon = 0, n_arith = 0, n_noop = 0, n_arithext = 0, n_basesum = 0;
+  size_t n_poseidon = 0, n_arith = 0, n_noop = 0, n_arithext = 0, n_basesum = 0, n_exp = 0, n_randacc = 0;
   vx_circuit_desc desc;
 };
 
@@ -210,6 +211,77 @@ Prog program_base_sum(int num_limbs) {
   p.ins(VX_OP_END, 0);
   return p;
 }
+// gates/exponentiation.rs: wire 0 base, wires 1..=nb power bits (LE), wire nb+1 output, then nb intermediate values
+Prog program_exponentiation(int nb) {
+  Prog p;
+  p.ldi(1, 1);                      // r1 = 1
+  p.ins(VX_OP_LDW, 2, 0);           // r2 = base
+  for (int i = 0; i < nb; ++i) {
+    if (i == 0) p.ins(VX_OP_ADD, 3, 1, 63), p.ins(VX_OP_SUB, 3, 3, 63);  // r3 = 1 (prev_intermediate for i = 0); r63 is any value
+    else {
+      p.ins(VX_OP_LDW, 3, 2 + nb + (i - 1));
+      p.ins(VX_OP_MUL, 3, 3, 3);    // intermediate[i-1]^2
+    }
+    p.ins(VX_OP_LDW, 4, 1 + (nb - i - 1));  // cur_bit (bits are LE, accumulated BE)
+    p.ins(VX_OP_SUB, 5, 1, 4);      // not_cur_bit
+    p.ins(VX_OP_MUL, 6, 4, 2);      // cur_bit * base
+    p.ins(VX_OP_ADD, 6, 6, 5);
+    p.ins(VX_OP_MUL, 6, 6, 3);      // computed intermediate
+    p.ins(VX_OP_LDW, 7, 2 + nb + i);
+    p.ins(VX_OP_SUB, 6, 6, 7);
+    p.ins(VX_OP_PUSH, 0, 6);
+  }
+  p.ins(VX_OP_LDW, 3, 1 + nb);
+  p.ins(VX_OP_LDW, 4, 2 + nb + nb - 1);
+  p.ins(VX_OP_SUB, 3, 3, 4);
+  p.ins(VX_OP_PUSH, 0, 3);
+  p.ins(VX_OP_END, 0);
+  return p;
+}
+// gates/random_access.rs: per copy [access_index, claimed, 2^bits items]; extra constants; bit wires after the routed ones
+Prog program_random_access(int bits, int copies, int extra) {
+  Prog p;
+  const int vec = 1 << bits, per = 2 + vec, routed = per * copies + extra;
+  p.ldi(1, 1);
+  for (int c = 0; c < copies; ++c) {
+    for (int i = 0; i < bits; ++i) {             // b (b - 1)
+      p.ins(VX_OP_LDW, 40 + i, routed + c * bits + i);
+      p.ins(VX_OP_SUB, 2, 40 + i, 1);
+      p.ins(VX_OP_MUL, 2, 2, 40 + i);
+      p.ins(VX_OP_PUSH, 0, 2);
+    }
+    p.ins(VX_OP_ADD, 3, 40 + bits - 1, 40 + bits - 1);  // reconstructed index: fold from the top bit: acc = 2*acc + b
+    p.ins(VX_OP_SUB, 3, 3, 40 + bits - 1);              // r3 = top bit
+    for (int i = bits - 2; i >= 0; --i) {
+      p.ins(VX_OP_ADD, 3, 3, 3);
+      p.ins(VX_OP_ADD, 3, 3, 40 + i);
+    }
+    p.ins(VX_OP_LDW, 4, per * c);
+    p.ins(VX_OP_SUB, 3, 3, 4);
+    p.ins(VX_OP_PUSH, 0, 3);
+    for (int i = 0; i < vec; ++i) p.ins(VX_OP_LDW, 8 + i, per * c + 2 + i);
+    int len = vec;
+    for (int b = 0; b < bits; ++b) {             // list'[k] = x + bit_b (y - x)
+      for (int k = 0; k < len / 2; ++k) {
+        p.ins(VX_OP_SUB, 5, 8 + 2 * k + 1, 8 + 2 * k);
+        p.ins(VX_OP_MUL, 5, 5, 40 + b);
+        p.ins(VX_OP_ADD, 8 + k, 8 + 2 * k, 5);
+      }
+      len /= 2;
+    }
+    p.ins(VX_OP_LDW, 4, per * c + 1);
+    p.ins(VX_OP_SUB, 5, 8, 4);
+    p.ins(VX_OP_PUSH, 0, 5);
+  }
+  for (int i = 0; i < extra; ++i) {
+    p.ins(VX_OP_LDC, 2, i);
+    p.ins(VX_OP_LDW, 3, per * copies + i);
+    p.ins(VX_OP_SUB, 2, 2, 3);
+    p.ins(VX_OP_PUSH, 0, 2);
+  }
+  p.ins(VX_OP_END, 0);
+  return p;
+}
 }  // namespace
 
 extern "C" {
@@ -227,7 +299,8 @@ vxs_circuit* vxs_build(int degree_bits, uint64_t seed, int poseidon_percent) {
 vxs_circuit* vxs_build3(int degree_bits, uint64_t seed, int poseidon_percent, uint64_t witness_seed, int flags) {
   if (degree_bits < 3 || degree_bits > 24 || poseidon_percent < 0 || poseidon_percent > 100) return nullptr;
   const bool with_prog = flags & VXS_FLAG_PROGRAM_GATES, arith_prog = flags & VXS_FLAG_ARITH_AS_PROGRAM;
-  if (with_prog && degree_bits < 4) return nullptr;
+  const bool more_prog = flags & VXS_FLAG_MORE_PROGRAM_GATES;
+  if ((with_prog && degree_bits < 4) || (more_prog && degree_bits < 5)) return nullptr;
   Synth* S = new Synth();
   S->degree_bits = degree_bits;
   const size_t n = S->n = (size_t)1 << degree_bits;
@@ -246,6 +319,10 @@ vxs_circuit* vxs_build3(int degree_bits, uint64_t seed, int poseidon_percent, ui
   if (with_prog) {
     gates.push_back({K_ARITHEXT, VX_GATE_PROGRAM, 3, 3, "ArithmeticExtensionGate { num_ops: 10 }"});
     gates.push_back({K_BASESUM, VX_GATE_PROGRAM, 2, 2, "BaseSumGate { num_limbs: 63 } + Base: 2"});
+  }
+  if (more_prog) {
+    gates.push_back({K_EXP, VX_GATE_PROGRAM, 4, 4, "ExponentiationGate { num_power_bits: 66, _phantom: PhantomData<plonky2_field::goldilocks_field::GoldilocksField> }<D=2>"});
+    gates.push_back({K_RANDACC, VX_GATE_PROGRAM, 5, 5, "RandomAccessGate { bits: 4, num_copies: 4, num_extra_constants: 2, _phantom: PhantomData<plonky2_field::goldilocks_field::GoldilocksField> }<D=2>"});
   }
   std::sort(gates.begin(), gates.end(), [](const GateInfo& a, const GateInfo& b) {
     return a.degree != b.degree ? a.degree < b.degree : a.id < b.id;
@@ -290,14 +367,24 @@ vxs_circuit* vxs_build3(int degree_bits, uint64_t seed, int poseidon_percent, ui
     attach(K_ARITHEXT, program_arithmetic_extension(10));
     attach(K_BASESUM, program_base_sum(63));
   }
+  if (more_prog) {
+    attach(K_EXP, program_exponentiation(66));
+    attach(K_RANDACC, program_random_access(4, 4, 2));
+  }
 
   // ---- row budget ----
   const size_t body = n - 3;
   size_t n_noop = std::max<size_t>(1, body / 64);
   if (n_noop > body) n_noop = body;
   size_t n_ext = with_prog ? std::max<size_t>(1, body / 16) : 0, n_bs = with_prog ? std::max<size_t>(1, body / 16) : 0;
-  while (n_noop + n_ext + n_bs > body && n_ext > 0) --n_ext, --n_bs;
-  size_t rest = body - n_noop - n_ext - n_bs;
+  size_t n_exp = more_prog ? std::max<size_t>(1, body / 32) : 0, n_ra = more_prog ? std::max<size_t>(1, body / 32) : 0;
+  while (n_noop + n_ext + n_bs + n_exp + n_ra > body && n_ext + n_exp > 0) {
+    if (n_ext) --n_ext, --n_bs;
+    if (n_exp) --n_exp, --n_ra;
+  }
+  size_t rest = body - n_noop - n_ext - n_bs - n_exp - n_ra;
+  S->n_exp = n_exp;
+  S->n_randacc = n_ra;
   size_t n_pos = rest * (size_t)poseidon_percent / 100;
   size_t n_arith = rest - n_pos;
   S->n_poseidon = n_pos + 1;
@@ -415,6 +502,41 @@ vxs_circuit* vxs_build3(int degree_bits, uint64_t seed, int poseidon_percent, ui
     w[0 * n + row] = v;
     for (int i = 0; i < 63; ++i) w[(size_t)(1 + i) * n + row] = (v >> i) & 1;
   }
+  // ExponentiationGate rows: output = base^(66-bit exponent), intermediates per gates/exponentiation.rs
+  for (size_t e = 0; e < n_exp; ++e, ++row) {
+    set_gate(row, K_EXP);
+    const int nb = 66;
+    const u64 base = wrng.field();
+    w[0 * n + row] = base;
+    int bits[66];
+    for (int i = 0; i < nb; ++i) bits[i] = (int)(wrng.next() & 1), w[(size_t)(1 + i) * n + row] = (u64)bits[i];
+    u64 acc = 0;
+    for (int i = 0; i < nb; ++i) {
+      u64 prev = i == 0 ? 1 : mul(acc, acc);
+      int cur = bits[nb - i - 1];
+      acc = mul(prev, cur ? base : 1);
+      w[(size_t)(2 + nb + i) * n + row] = acc;
+    }
+    w[(size_t)(1 + nb) * n + row] = acc;
+  }
+  // RandomAccessGate rows: 4 copies of a 16-entry list lookup + 2 extra constants
+  for (size_t e = 0; e < n_ra; ++e, ++row) {
+    set_gate(row, K_RANDACC);
+    const int bits = 4, vec = 16, copies = 4, per = 18, routed = per * copies + 2;
+    const u64 k0 = rng.field(), k1 = rng.field();
+    c0[row] = k0;
+    c1[row] = k1;
+    for (int c = 0; c < copies; ++c) {
+      const int idx = (int)(wrng.next() & (vec - 1));
+      u64 items[16];
+      for (int i = 0; i < vec; ++i) items[i] = wrng.field(), w[(size_t)(per * c + 2 + i) * n + row] = items[i];
+      w[(size_t)(per * c) * n + row] = (u64)idx;
+      w[(size_t)(per * c + 1) * n + row] = items[idx];
+      for (int i = 0; i < bits; ++i) w[(size_t)(routed + c * bits + i) * n + row] = (u64)((idx >> i) & 1);
+    }
+    w[(size_t)(per * copies) * n + row] = k0;
+    w[(size_t)(per * copies + 1) * n + row] = k1;
+  }
   for (; row < n; ++row) set_gate(row, K_NOOP);
 
   // k_is = 7^j (plonk_common / circuit_builder: get_unique_coset_shifts)
@@ -513,13 +635,15 @@ void vxs_row_counts(vxs_circuit* c, uint64_t out[3]) {
   out[1] = S->n_arith;
   out[2] = S->n_noop;
 }
-void vxs_row_counts_ext(vxs_circuit* c, uint64_t out[5]) {
+void vxs_row_counts_ext(vxs_circuit* c, uint64_t out[7]) {
   Synth* S = reinterpret_cast<Synth*>(c);
   out[0] = S->n_poseidon;
   out[1] = S->n_arith;
   out[2] = S->n_noop;
   out[3] = S->n_arithext;
   out[4] = S->n_basesum;
+  out[5] = S->n_exp;
+  out[6] = S->n_randacc;
 }
 /* Drop the (large) sigma/witness host copies once they have been handed to a prover. */
 void vxs_release_host_buffers(vxs_circuit* c, int witness, int preprocessed) {
