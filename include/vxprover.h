@@ -41,6 +41,7 @@ extern "C" {
 #define VX_E_HIP (-3)        /* a HIP runtime call failed */
 #define VX_E_NOMEM (-4)
 #define VX_E_PROOF (-5)      /* prover-level failure (e.g. zeta in the subgroup, unsatisfied witness check) */
+#define VX_E_COMM (-6)       /* the caller's all-gather (vx_prove_sharded) reported a failure */
 
 typedef struct vx_ctx vx_ctx;
 typedef struct vx_batch vx_batch;     /* device-resident PolynomialBatch: coeffs + LDE + Merkle tree */
@@ -215,6 +216,34 @@ int vx_prove(vx_ctx* ctx, vx_circuit* circuit, const uint64_t* wires, int wires_
              const uint64_t* pow_witness_hint, uint8_t* out_buf, size_t* out_len);
 /* Upper bound of the proof size in bytes for this circuit. */
 size_t vx_proof_size_bound(vx_circuit* circuit);
+
+/* ---- ONE proof sharded across the GPUs of a node (BASELINE.json configs[3]) -------------------
+ * `world` in {1, 2, 4, 8} ranks (one vx_ctx + one copy of the circuit each; world <= 2^rate_bits and
+ * <= 2^cap_height) produce the SAME proof bytes as vx_prove, every rank returning the full proof.  The split is by
+ * LDE COSET: in this library's bit-reversed row order rank r owns LDE rows [r*N/world, (r+1)*N/world) = whole cosets
+ * of the 8n-point domain, so the coset NTTs (PolynomialBatch::from_values' lde_values), leaf hashing and Merkle
+ * subtrees (MerkleTree::new), the quotient evaluation (compute_quotient_polys incl. its "next row" neighbour), the
+ * opening-proof LDE/combination and the first FRI layer are rank-local.  The ranks meet only in in-place
+ * all-gathers of small buffers — the per-rank Merkle cap entries, the per-coset quotient coefficients
+ * (2 * 8n * 8 bytes in total), the folded first FRI layer (N/16 F_p^2 values) and the query openings — which the
+ * HOST supplies, because the communicator is the host's: RCCL via torch.distributed in the Python mirror, or the
+ * in-process vx_group below (host threads + xGMI peer copies).  The callback is invoked on the calling thread with
+ * the context's stream idle; `dev_buf` holds world * bytes_per_rank bytes of device memory with slot `rank`
+ * filled; on return (0 = ok) every slot must hold the corresponding rank's data. */
+typedef int (*vx_allgather_fn)(void* user, void* dev_buf, size_t bytes_per_rank);
+int vx_prove_sharded(vx_ctx* ctx, vx_circuit* circuit, const uint64_t* wires, int wires_on_device, int rank, int world,
+                     vx_allgather_fn allgather, void* user, const uint64_t* pow_witness_hint, uint8_t* out_buf,
+                     size_t* out_len);
+
+/* In-process rank group: `world` host threads, one vx_ctx (normally one GPU) each.  vx_group_allgather is a
+ * vx_allgather_fn whose `user` is the member handle: each rank pulls the other ranks' slots straight out of their
+ * buffers with hipMemcpyPeerAsync (point-to-point over xGMI; every link carries one slot), between two barriers. */
+typedef struct vx_group vx_group;
+int vx_group_create(int world, vx_group** out);
+void vx_group_destroy(vx_group* g);
+int vx_group_join(vx_group* g, int rank, vx_ctx* ctx, void** member_out); /* member handle is owned by the group */
+int vx_group_allgather(void* member, void* dev_buf, size_t bytes_per_rank);
+void vx_group_abort(vx_group* g); /* wake every rank waiting in vx_group_allgather with VX_E_COMM (a rank has failed) */
 
 #ifdef __cplusplus
 }

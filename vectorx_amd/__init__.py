@@ -94,7 +94,15 @@ _SIGNATURES = {
     "vx_circuit_constants_sigmas_cap": (_i, [_vp, _vp]),
     "vx_prove": (_i, [_vp, _vp, _vp, _i, _vp, _vp, ctypes.POINTER(_sz)]),
     "vx_proof_size_bound": (_sz, [_vp]),
+    "vx_prove_sharded": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, ctypes.POINTER(_sz)]),
+    "vx_group_create": (_i, [_i, ctypes.POINTER(_vp)]),
+    "vx_group_destroy": (None, [_vp]),
+    "vx_group_join": (_i, [_vp, _i, _vp, ctypes.POINTER(_vp)]),
+    "vx_group_allgather": (_i, [_vp, _vp, _sz]),
+    "vx_group_abort": (None, [_vp]),
 }
+# vx_allgather_fn: int (*)(void* user, void* dev_buf, size_t bytes_per_rank)
+ALLGATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t)
 
 
 def lib() -> ctypes.CDLL:
@@ -395,4 +403,40 @@ class Circuit:
             src, on_dev = dev_ptr, 1
         _chk(lib().vx_prove(self.ctx._h, self._h, src, on_dev, hint.ctypes.data if hint is not None else None,
                             buf.ctypes.data, ctypes.byref(ln)))
+        return bytes(buf[:ln.value])
+
+    def prove_sharded(self, wires, rank: int, world: int, allgather, user=None, pow_witness=None, dev_ptr=None) -> bytes:
+        """`vx_prove_sharded`: this rank's part of ONE proof split across `world` GPUs by LDE coset; every rank
+        returns the full proof, byte-identical to `prove`.  `allgather` is the in-place all-gather the host supplies:
+        a Python callable `(dev_ptr, bytes_per_rank) -> None` (see vectorx_amd.sharded.TorchAllGather), or a C function
+        pointer such as `lib().vx_group_allgather` with `user` = the group member handle."""
+        cap = lib().vx_proof_size_bound(self._h)
+        buf = np.empty(cap, dtype=np.uint8)
+        ln = _sz(cap)
+        hint = np.array([pow_witness], dtype=np.uint64) if pow_witness is not None else None
+        if dev_ptr is None:
+            w = _as_u64(wires)
+            if w.shape != (self.num_wires, 1 << self.degree_bits):
+                raise VxError(VX_E_INVALID, f"witness matrix has shape {w.shape}")
+            src, on_dev = w.ctypes.data, 0
+        else:
+            src, on_dev = dev_ptr, 1
+        err = []
+        if callable(allgather) and not isinstance(allgather, ctypes._CFuncPtr):
+            def _cb(_user, dptr, nbytes):
+                try:
+                    allgather(dptr, nbytes)
+                    return 0
+                except BaseException as e:   # never unwind through the C frames
+                    err.append(e)
+                    return 1
+            fn = ALLGATHER_FN(_cb)
+        else:
+            fn = allgather
+        fn_ptr = ctypes.cast(fn, ctypes.c_void_p) if fn is not None else None
+        rc = lib().vx_prove_sharded(self.ctx._h, self._h, src, on_dev, rank, world, fn_ptr, user,
+                                    hint.ctypes.data if hint is not None else None, buf.ctypes.data, ctypes.byref(ln))
+        if err:
+            raise err[0]
+        _chk(rc)
         return bytes(buf[:ln.value])

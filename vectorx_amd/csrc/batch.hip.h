@@ -7,6 +7,11 @@
 //                  coset r (points 7*w_N^(r + 2^rate_bits * k)) is the contiguous row block
 //                  [rev(r)*n, (rev(r)+1)*n)
 //   tree   level 0 = N leaf digests (4 u64 each), then N/2, ... down to the 2^cap_height cap.
+//
+// Coset shard (vx_prove_sharded, world = 2^shard_lg ranks): coeffs are complete on every rank, but `lde` holds only
+// the rows [rank * N/world, (rank+1) * N/world) — whole cosets, 2^rate_bits / world of them — with column stride
+// N/world, and `tree` is the Merkle subtree over those leaves down to this rank's 2^(cap_height - shard_lg) cap
+// entries (the top shard_lg bits of a leaf index are the rank, so the global cap is the ranks' caps concatenated).
 #pragma once
 #include "vx_runtime.hip.h"
 
@@ -18,6 +23,12 @@ struct vx_batch {
   u64* lde = nullptr;
   u64* tree = nullptr;
   size_t cap_off = 0;  // digest index of the cap level inside `tree`
+  int shard_rank = 0, shard_lg = 0;
+  size_t n() const { return (size_t)1 << log_n; }
+  size_t rows() const { return (n() << rate_bits) >> shard_lg; }       // local LDE rows (= column stride of `lde`)
+  size_t row_base() const { return rows() * (size_t)shard_rank; }       // global index of the first local row
+  int local_cap_height() const { return cap_height - shard_lg; }
+  size_t local_cap_words() const { return (size_t)4 << local_cap_height(); }
 };
 
 __global__ void canon_kernel(u64* __restrict__ x, size_t n) {
@@ -74,15 +85,19 @@ static int ntt_natural_to_bitrev(vx_ctx* c, const u64* src, u64* dst, int log_n,
   }
 }
 
-static int batch_alloc(vx_ctx* c, int log_n, size_t ncols, int rate_bits, int cap_height, vx_batch** out) {
+static int batch_alloc(vx_ctx* c, int log_n, size_t ncols, int rate_bits, int cap_height, vx_batch** out,
+                       int shard_rank = 0, int shard_lg = 0) {
+  if (shard_lg > rate_bits || shard_lg > cap_height) return vx_fail(VX_E_INVALID, "batch_alloc: too many shards");
   vx_batch* b = new vx_batch();
   b->ctx = c;
   b->log_n = log_n;
   b->rate_bits = rate_bits;
   b->cap_height = cap_height;
   b->ncols = ncols;
-  size_t n = (size_t)1 << log_n, N = n << rate_bits;
-  size_t nd = merkle_tree_digest_count(N, cap_height);
+  b->shard_rank = shard_rank;
+  b->shard_lg = shard_lg;
+  size_t n = (size_t)1 << log_n, N = b->rows();
+  size_t nd = merkle_tree_digest_count(N, b->local_cap_height());
   if (c->pool_alloc((void**)&b->coeffs, n * ncols * 8) != hipSuccess ||
       c->pool_alloc((void**)&b->lde, N * ncols * 8) != hipSuccess ||
       c->pool_alloc((void**)&b->tree, nd * 32) != hipSuccess) {
@@ -100,12 +115,12 @@ static int batch_alloc(vx_ctx* c, int log_n, size_t ncols, int rate_bits, int ca
 static int batch_lde_and_tree(vx_ctx* c, vx_batch* b) {
   using namespace vxh;
   const int log_n = b->log_n, rb = b->rate_bits;
-  const size_t n = (size_t)1 << log_n, N = n << rb, m = b->ncols;
-  const int nz = 1 << rb;
+  const size_t n = (size_t)1 << log_n, N = b->rows(), m = b->ncols;
+  const int nz = (1 << rb) >> b->shard_lg, z0 = nz * b->shard_rank;  // local cosets [z0, z0 + nz)
   // block z of the bit-reversed LDE holds coset r = rev_rb(z): shift 7 * w_N^r
   std::vector<u64> shifts(nz);
   u64 wN = root_of_unity(log_n + rb);
-  for (int z = 0; z < nz; ++z) shifts[z] = mul(7, pow(wN, reverse_bits((size_t)z, rb)));
+  for (int z = 0; z < nz; ++z) shifts[z] = mul(7, pow(wN, reverse_bits((size_t)(z0 + z), rb)));
   int bits = log_n / 2;
   u64* tab = nullptr;
   VXCHK(get_scale_tables(c, log_n, bits, shifts, 1, &tab));
@@ -117,7 +132,7 @@ static int batch_lde_and_tree(vx_ctx* c, vx_batch* b) {
                        dim3(HASH_THREADS), 0, c->stream, b->lde, N, N, (int)m, b->tree);
     HIPCHK(hipGetLastError());
   }
-  VXCHK(build_merkle_levels(c, b->tree, N, b->cap_height, &b->cap_off));
+  VXCHK(build_merkle_levels(c, b->tree, N, b->local_cap_height(), &b->cap_off));
   return VX_OK;
 }
 

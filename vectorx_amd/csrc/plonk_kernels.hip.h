@@ -149,10 +149,11 @@ __global__ __launch_bounds__(256) void perm_write_kernel(const u64* __restrict__
 // Quotient evaluation: one thread per LDE row (bit-reversed row order, like every LDE buffer).
 // ------------------------------------------------------------------------------------------------
 struct QuotientParams {
-  const u64 *cs, *wires, *zs;  // LDE buffers, column stride N
+  const u64 *cs, *wires, *zs;  // LDE buffers: cs has column stride N and is indexed by the GLOBAL row; wires/zs/out
+                               // have column stride `stride_w` and hold rows [row_base, row_base + rows) (a coset shard)
   const u64* k_is;
   const u64 *root_lo, *root_hi;
-  size_t N;
+  size_t N, rows, row_base, stride_w;
   int log_n, rate_bits;
   int num_selectors, num_constants, nr, num_wires, nch, npp, deg;
   int num_gates;
@@ -161,7 +162,7 @@ struct QuotientParams {
   u64 pih[4];
   u64 zh[VX_MAX_RATE], zh_inv[VX_MAX_RATE];  // ZeroPolyOnCoset evals / inverses, indexed by coset r
   u64 n_field;                               // n mod p
-  u64* out;                                  // [nch][N]
+  u64* out;                                  // [nch][stride_w]
 };
 
 struct AlphaAcc {
@@ -178,20 +179,20 @@ GLD void acc_push(AlphaAcc& a, const QuotientParams& p, u64 term) {
 #define UNUSED_SELECTOR_U64 0xFFFFFFFFULL
 
 __global__ __launch_bounds__(256, 4) void quotient_kernel(QuotientParams p) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= p.N) return;
-  const size_t N = p.N;
+  const size_t il = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (il >= p.rows) return;
+  const size_t N = p.N, SW = p.stride_w, i = il + p.row_base;
   const int log_n = p.log_n, rb = p.rate_bits;
   const u32 nmask = (1u << log_n) - 1;
   const u32 z = (u32)(i >> log_n);
   const u32 r = bitrev32(z, rb);
   const u32 k = bitrev32((u32)i & nmask, log_n);
   const u32 j = (k << rb) | r;  // natural LDE index
-  const size_t i_next = ((size_t)z << log_n) | bitrev32((k + 1) & nmask, log_n);
+  const size_t il_next = (((size_t)z << log_n) | bitrev32((k + 1) & nmask, log_n)) - p.row_base;  // same coset: local
   const u64 x = gl_mul7(root_pow24(p.root_lo, p.root_hi, j << (ROOT_TABLE_LOG - log_n - rb)));
 #define CS(c) (p.cs[(size_t)(c) * N + i])
-#define WIRE(c) (p.wires[(size_t)(c) * N + i])
-#define ZS(c) (p.zs[(size_t)(c) * N + i])
+#define WIRE(c) (p.wires[(size_t)(c) * SW + il])
+#define ZS(c) (p.zs[(size_t)(c) * SW + il])
 
   AlphaAcc A;
 #pragma unroll
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(256, 4) void quotient_kernel(QuotientParams p) {
         np = gl_mul(np, gl_mad(p.k_is[jj], bx, wg));
         dp = gl_mul(dp, gl_mad(beta, CS(p.num_constants + jj), wg));
       }
-      u64 next = kk < p.npp ? ZS(p.nch + ch * p.npp + kk) : p.zs[(size_t)ch * N + i_next];
+      u64 next = kk < p.npp ? ZS(p.nch + ch * p.npp + kk) : p.zs[(size_t)ch * SW + il_next];
       acc_push(A, p, gl_sub(gl_mul(prev, np), gl_mul(next, dp)));
       prev = next;
     }
@@ -307,7 +308,7 @@ __global__ __launch_bounds__(256, 4) void quotient_kernel(QuotientParams p) {
     for (int c = 0; c < VX_MAX_CHALLENGES; ++c) A.acc[c] = gl_mad(filter, G.acc[c], A.acc[c]);
   }
   const u64 zi = p.zh_inv[r];
-  for (int ch = 0; ch < p.nch; ++ch) p.out[(size_t)ch * N + i] = gl_mul(A.acc[ch], zi);
+  for (int ch = 0; ch < p.nch; ++ch) p.out[(size_t)ch * SW + il] = gl_mul(A.acc[ch], zi);
 #undef CS
 #undef WIRE
 #undef ZS
@@ -326,6 +327,7 @@ struct ChunkParams {
   u64* t;
   const u64* inv_tab;  // [2^rb slices z][hi(2^(log_n-bits)) + lo(2^bits)] tables of s_{rev(z)}^(-j)
   int log_n, rb, bits;
+  int nch, zc;  // u is laid out [rate/zc rank blocks][nch][zc][n] (zc = cosets per rank; rate when not sharded)
   u64 w_rate_inv_pows[VX_MAX_RATE];  // w_rate^(-k)
   u64 chunk_scale[VX_MAX_RATE];      // 7^(-nc) / 2^rb
 };
@@ -341,7 +343,7 @@ __global__ __launch_bounds__(256) void quotient_chunks_kernel(ChunkParams p) {
     const u64* tab = p.inv_tab + (size_t)z * slice;
     u64 sc = gl_mul(tab[j >> p.bits], tab[((size_t)1 << (p.log_n - p.bits)) + (j & ((1u << p.bits) - 1))]);
     int r = (int)bitrev32((u32)z, p.rb);
-    U[r] = gl_mul(p.u[((size_t)ch * rate + z) * n + pos], sc);
+    U[r] = gl_mul(p.u[(((size_t)(z / p.zc) * p.nch + ch) * p.zc + (z % p.zc)) * n + pos], sc);
   }
   for (int c = 0; c < rate; ++c) {
     u64 acc = 0;
@@ -383,24 +385,24 @@ __global__ __launch_bounds__(256) void reduce_polys_kernel(ReduceParams p) {
 // final[i] = shift0 * (F0(x_i) - y0)/(x_i - z0) + (F1(x_i) - y1)/(x_i - z1)   in F_p^2, x_i on the LDE coset.
 // fl: [4][N] LDE of (F0.a, F0.b, F1.a, F1.b); out interleaved ext [N][2] (bit-reversed row order).
 struct CombineParams {
-  const u64* fl;
+  const u64* fl;  // [4][rows] (column stride = rows): LDE rows [row_base, row_base + rows)
   const u64 *root_lo, *root_hi;
-  size_t N;
+  size_t rows, row_base;
   int log_N;
   u64 y0[2], y1[2], z0[2], z1[2], shift0[2];
   u64* out;
 };
 __global__ __launch_bounds__(256) void fri_combine_kernel(CombineParams p) {
   size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= p.N) return;
-  u32 j = bitrev32((u32)i, p.log_N);
+  if (i >= p.rows) return;
+  u32 j = bitrev32((u32)(i + p.row_base), p.log_N);
   u64 x = gl_mul7(root_pow24(p.root_lo, p.root_hi, j << (ROOT_TABLE_LOG - p.log_N)));
   ext2 d0 = ext_make(gl_sub(x, p.z0[0]), gl_neg(p.z0[1]));
   ext2 d1 = ext_make(gl_sub(x, p.z1[0]), gl_neg(p.z1[1]));
   ext2 inv01 = ext_inv(ext_mul(d0, d1));
   ext2 i0 = ext_mul(inv01, d1), i1 = ext_mul(inv01, d0);
-  ext2 n0 = ext_make(gl_sub(p.fl[i], p.y0[0]), gl_sub(p.fl[p.N + i], p.y0[1]));
-  ext2 n1 = ext_make(gl_sub(p.fl[2 * p.N + i], p.y1[0]), gl_sub(p.fl[3 * p.N + i], p.y1[1]));
+  ext2 n0 = ext_make(gl_sub(p.fl[i], p.y0[0]), gl_sub(p.fl[p.rows + i], p.y0[1]));
+  ext2 n1 = ext_make(gl_sub(p.fl[2 * p.rows + i], p.y1[0]), gl_sub(p.fl[3 * p.rows + i], p.y1[1]));
   ext2 q0 = ext_mul(n0, i0), q1 = ext_mul(n1, i1);
   ext2 res = ext_add(ext_mul(q0, ext_make(p.shift0[0], p.shift0[1])), q1);
   reinterpret_cast<ulonglong2*>(p.out)[i] = make_ulonglong2(res.a, res.b);
@@ -416,8 +418,9 @@ struct FoldParams {
   const u64* in;  // [M][2]
   u64* out;       // [M >> arity_bits][2]
   const u64 *root_lo, *root_hi;
-  size_t M;
-  int log_M, arity_bits;
+  size_t M;       // number of input values handled here (a shard of the layer when k_base != 0 or M < layer size)
+  size_t k_base;  // global index of the first output
+  int log_M, arity_bits;  // log_M = log2 of the WHOLE layer
   u64 beta[2];
   u64 shift_inv;        // (7^(16^round))^-1
   u64 w_inv_pows[16];   // w_arity^(-k)
@@ -436,7 +439,7 @@ __global__ __launch_bounds__(256) void fri_fold_kernel(FoldParams p) {
     e[bitrev32((u32)t, p.arity_bits)] = ext_make(v.x, v.y);
   }
   // y0^-1 = shift^-1 * w_M^(-rev(k))
-  u32 kr = bitrev32((u32)k, log_Mo);
+  u32 kr = bitrev32((u32)(k + p.k_base), log_Mo);
   u32 ex = kr << (ROOT_TABLE_LOG - p.log_M);
   ex = ((1u << ROOT_TABLE_LOG) - ex) & ((1u << ROOT_TABLE_LOG) - 1);
   u64 y0inv = gl_mul(p.shift_inv, root_pow24(p.root_lo, p.root_hi, ex));
@@ -519,9 +522,9 @@ struct ProgramGateDev {
   int gate_index, selector_index, group_start, group_end, prog_off;
 };
 struct ProgramParams {
-  const u64 *cs, *wires;
+  const u64 *cs, *wires;  // as in QuotientParams: cs global rows / stride N; wires, out local rows / stride_w
   const u64* programs;
-  size_t N;
+  size_t N, rows, row_base, stride_w;
   int log_n, rate_bits, num_selectors, nch, num_gates;
   ProgramGateDev gates[VX_MAX_PROGRAM_GATES];
   u64 alphas[VX_MAX_CHALLENGES], base_pw[VX_MAX_CHALLENGES];  // base_pw = alpha^(number of terms before the gate constraints)
@@ -530,9 +533,9 @@ struct ProgramParams {
   u64* out;  // [nch][N], accumulated into
 };
 __global__ __launch_bounds__(256) void program_gates_kernel(ProgramParams p) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= p.N) return;
-  const size_t N = p.N;
+  const size_t il = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (il >= p.rows) return;
+  const size_t N = p.N, SW = p.stride_w, i = il + p.row_base;
   const u32 r = bitrev32((u32)(i >> p.log_n), p.rate_bits);
   u64 total[VX_MAX_CHALLENGES] = {0, 0};
   u64 R[64];
@@ -550,7 +553,7 @@ __global__ __launch_bounds__(256) void program_gates_kernel(ProgramParams p) {
       const int op = (int)(ins & 0xFF), dst = (int)((ins >> 8) & 63), a = (int)((ins >> 16) & 0xFFFF), b = (int)((ins >> 32) & 0xFFFF);
       if (op == 0) break;
       switch (op) {
-        case 1: R[dst] = gl_canon(p.wires[(size_t)a * N + i]); break;
+        case 1: R[dst] = gl_canon(p.wires[(size_t)a * SW + il]); break;
         case 2: R[dst] = p.cs[(size_t)(p.num_selectors + a) * N + i]; break;
         case 3: R[dst] = gl_canon(prog[++pc]); break;
         case 4: R[dst] = gl_add(R[a & 63], R[b & 63]); break;
@@ -574,7 +577,7 @@ __global__ __launch_bounds__(256) void program_gates_kernel(ProgramParams p) {
   }
   const u64 zi = p.zh_inv[r];
   for (int ch = 0; ch < p.nch; ++ch) {
-    u64* o = p.out + (size_t)ch * N + i;
+    u64* o = p.out + (size_t)ch * SW + il;
     *o = gl_add(*o, gl_mul(total[ch], zi));
   }
 }

@@ -192,14 +192,47 @@ struct Scratch {
   }
 };
 
+// One proof split across `world` ranks by LDE coset (include/vxprover.h vx_prove_sharded).  world == 1: plain vx_prove.
+struct Shard {
+  int rank = 0, world = 1, lg = 0;
+  vx_allgather_fn fn = nullptr;
+  void* user = nullptr;
+};
+// In-place all-gather of a device buffer of world * bytes_per_rank bytes whose slot `rank` is filled.
+static int shard_allgather(vx_ctx* c, const Shard& sh, void* dev, size_t bytes_per_rank, const char* what) {
+  if (sh.world == 1) return VX_OK;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  int rc = sh.fn(sh.user, dev, bytes_per_rank);
+  if (rc) return vx_fail(VX_E_COMM, "prove: all-gather of %s failed on rank %d (callback returned %d)", what, sh.rank, rc);
+  return VX_OK;
+}
+// The 2^cap_height cap of a (possibly sharded) tree, on the host: the ranks' local caps concatenated in rank order.
+static int gather_cap(vx_ctx* c, const Shard& sh, Scratch& S, const u64* local_cap_dev, size_t local_words, std::vector<u64>& cap) {
+  cap.resize(local_words * sh.world);
+  const u64* src = local_cap_dev;
+  if (sh.world > 1) {
+    u64* x = S.get(cap.size());
+    if (!x) return vx_fail(VX_E_NOMEM, "prove: out of device memory (cap exchange)");
+    HIPCHK(hipMemcpyAsync(x + local_words * sh.rank, local_cap_dev, local_words * 8, hipMemcpyDeviceToDevice, c->stream));
+    VXCHK(shard_allgather(c, sh, x, local_words * 8, "Merkle cap"));
+    src = x;
+  }
+  HIPCHK(hipMemcpyAsync(cap.data(), src, cap.size() * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return VX_OK;
+}
+
 static int prove_impl(vx_ctx* c, vx_circuit* k, const u64* wires_in, bool wires_on_device, const u64* pow_hint,
-                      std::vector<uint8_t>& proof_out) {
+                      std::vector<uint8_t>& proof_out, const Shard& sh = Shard()) {
   using namespace vxh;
   const size_t n = k->n();
   const int lg = k->degree_bits, rb = k->rate_bits, LG = lg + rb;
   const size_t N = (size_t)1 << LG;
   const int nch = k->nch, npp = k->npp(), nchunks = npp + 1, qdf = k->qdf, rate = 1 << rb;
   const size_t cap_words = (size_t)4 << k->cap_height;
+  // this rank's share of every LDE: rows [row_base, row_base + Nl) = cosets [z0, z0 + zc) in bit-reversed order
+  const size_t Nl = N >> sh.lg, row_base = Nl * (size_t)sh.rank;
+  const int zc = rate >> sh.lg, z0 = zc * sh.rank;
   Scratch S(c);
   vx_batch *wires_b = nullptr, *zs_b = nullptr, *quot_b = nullptr;
   struct Cleanup {
@@ -232,11 +265,10 @@ static int prove_impl(vx_ctx* c, vx_circuit* k, const u64* wires_in, bool wires_
   Hash4 pih = hash_no_pad(public_inputs.data(), public_inputs.size());
 
   // ---- wires commitment ----
-  VXCHK(batch_alloc(c, lg, k->num_wires, rb, k->cap_height, &wires_b));
+  VXCHK(batch_alloc(c, lg, k->num_wires, rb, k->cap_height, &wires_b, sh.rank, sh.lg));
   VXCHK(batch_commit_device(c, wires_b, d_wires, n, false));
-  std::vector<u64> wires_cap(cap_words), zs_cap(cap_words), quot_cap(cap_words);
-  HIPCHK(hipMemcpyAsync(wires_cap.data(), wires_b->tree + wires_b->cap_off * 4, cap_words * 8, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
+  std::vector<u64> wires_cap, zs_cap, quot_cap;
+  VXCHK(gather_cap(c, sh, S, wires_b->tree + wires_b->cap_off * 4, wires_b->local_cap_words(), wires_cap));
 
   Challenger ch;
   ch.observe_elements(k->digest.e, 4);
@@ -275,18 +307,17 @@ static int prove_impl(vx_ctx* c, vx_circuit* k, const u64* wires_in, bool wires_
       hipLaunchKernelGGL(perm_write_kernel, dim3((unsigned)nblocks, nch), dim3(256), 0, c->stream, cp, n, nchunks, nch, bp, zs_vals);
       HIPCHK(hipGetLastError());
     }
-    VXCHK(batch_alloc(c, lg, (size_t)nch * (1 + npp), rb, k->cap_height, &zs_b));
+    VXCHK(batch_alloc(c, lg, (size_t)nch * (1 + npp), rb, k->cap_height, &zs_b, sh.rank, sh.lg));
     VXCHK(batch_commit_device(c, zs_b, zs_vals, n, false));
   }
-  HIPCHK(hipMemcpyAsync(zs_cap.data(), zs_b->tree + zs_b->cap_off * 4, cap_words * 8, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
+  VXCHK(gather_cap(c, sh, S, zs_b->tree + zs_b->cap_off * 4, zs_b->local_cap_words(), zs_cap));
   ch.observe_elements(zs_cap.data(), cap_words);
   for (int i = 0; i < nch; ++i) alphas[i] = ch.get_challenge();
 
   // ---- quotient polynomials ----
   {
-    u64* qv = S.get((size_t)nch * N);
-    u64* qu = S.get((size_t)nch * N);
+    u64* qv = S.get((size_t)nch * Nl);  // quotient values on the local cosets
+    u64* qu = S.get((size_t)nch * N);   // per-coset coefficients of ALL cosets: [world][nch][zc][n]
     if (!qv || !qu) return vx_fail(VX_E_NOMEM, "prove: out of device memory (quotient)");
     {
       QuotientParams qp;
@@ -298,6 +329,9 @@ static int prove_impl(vx_ctx* c, vx_circuit* k, const u64* wires_in, bool wires_
       qp.root_lo = c->root_lo;
       qp.root_hi = c->root_hi;
       qp.N = N;
+      qp.rows = Nl;
+      qp.row_base = row_base;
+      qp.stride_w = Nl;
       qp.log_n = lg;
       qp.rate_bits = rb;
       qp.num_selectors = k->num_selectors;
@@ -320,9 +354,9 @@ static int prove_impl(vx_ctx* c, vx_circuit* k, const u64* wires_in, bool wires_
       }
       qp.n_field = (u64)n % P;
       qp.out = qv;
-      size_t bytes_read = 8ull * N * ((size_t)k->num_constants + k->nr + k->num_wires + (size_t)nch * (2 + npp));
+      size_t bytes_read = 8ull * Nl * ((size_t)k->num_constants + k->nr + k->num_wires + (size_t)nch * (2 + npp));
       ProfScope ps(c, "quotient_eval", (double)bytes_read);
-      hipLaunchKernelGGL(quotient_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, qp);
+      hipLaunchKernelGGL(quotient_kernel, dim3((unsigned)((Nl + 255) / 256)), dim3(256), 0, c->stream, qp);
       HIPCHK(hipGetLastError());
       if (k->programs) {  // gates supplied as constraint programs add their share to the same quotient values
         ProgramParams pg;
@@ -331,6 +365,9 @@ static int prove_impl(vx_ctx* c, vx_circuit* k, const u64* wires_in, bool wires_
         pg.wires = wires_b->lde;
         pg.programs = k->programs;
         pg.N = N;
+        pg.rows = Nl;
+        pg.row_base = row_base;
+        pg.stride_w = Nl;
         pg.log_n = lg;
         pg.rate_bits = rb;
         pg.num_selectors = k->num_selectors;
@@ -344,15 +381,17 @@ static int prove_impl(vx_ctx* c, vx_circuit* k, const u64* wires_in, bool wires_
         for (int r = 0; r < rate; ++r) pg.zh_inv[r] = qp.zh_inv[r];
         pg.out = qv;
         ProfScope ps2(c, "quotient_program_gates");
-        hipLaunchKernelGGL(program_gates_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, pg);
+        hipLaunchKernelGGL(program_gates_kernel, dim3((unsigned)((Nl + 255) / 256)), dim3(256), 0, c->stream, pg);
         HIPCHK(hipGetLastError());
       }
     }
     // per-coset inverse NTT (input rows of each block are in bit-reversed order), then the cross-coset
     // inverse DFT that separates the degree-n chunks
     u64 ninv = inv((u64)n % P);
-    VXCHK(run_ntt(c, qv, qu, N, N, n, n, lg, nch, rate, true, true, nullptr, 0, ninv, "quotient_intt", 16.0 * N * nch));
-    VXCHK(batch_alloc(c, lg, (size_t)nch * qdf, rb, k->cap_height, &quot_b));
+    VXCHK(run_ntt(c, qv, qu + (size_t)sh.rank * nch * Nl, Nl, Nl, n, n, lg, nch, zc, true, true, nullptr, 0, ninv, "quotient_intt",
+                  16.0 * Nl * nch));
+    VXCHK(shard_allgather(c, sh, qu, (size_t)nch * Nl * 8, "quotient coset coefficients"));
+    VXCHK(batch_alloc(c, lg, (size_t)nch * qdf, rb, k->cap_height, &quot_b, sh.rank, sh.lg));
     {
       std::vector<u64> inv_shifts(rate);
       u64 wN = root_of_unity(LG);
@@ -368,6 +407,8 @@ static int prove_impl(vx_ctx* c, vx_circuit* k, const u64* wires_in, bool wires_
       cp.log_n = lg;
       cp.rb = rb;
       cp.bits = bits;
+      cp.nch = nch;
+      cp.zc = zc;
       u64 wr_inv = inv(root_of_unity(rb)), pw = 1;
       for (int i = 0; i < rate; ++i) {
         cp.w_rate_inv_pows[i] = pw;
@@ -385,8 +426,7 @@ static int prove_impl(vx_ctx* c, vx_circuit* k, const u64* wires_in, bool wires_
     }
     VXCHK(batch_lde_and_tree(c, quot_b));
   }
-  HIPCHK(hipMemcpyAsync(quot_cap.data(), quot_b->tree + quot_b->cap_off * 4, cap_words * 8, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
+  VXCHK(gather_cap(c, sh, S, quot_b->tree + quot_b->cap_off * 4, quot_b->local_cap_words(), quot_cap));
   ch.observe_elements(quot_cap.data(), cap_words);
   Ext zeta = ch.get_extension_challenge();
   {
@@ -436,7 +476,7 @@ static int prove_impl(vx_ctx* c, vx_circuit* k, const u64* wires_in, bool wires_
   for (size_t j = nb0; j-- > 0;) y0 = eadd(emul(y0, alpha), batch0[j]);
   for (size_t j = nb1; j-- > 0;) y1 = eadd(emul(y1, alpha), batch1[j]);
   u64* fcoef = S.get(4 * n);
-  u64* flde = S.get(4 * N);
+  u64* flde = S.get(4 * Nl);
   u64* d_apows = S.get(2 * nb0);
   if (!fcoef || !flde || !d_apows) return vx_fail(VX_E_NOMEM, "prove: out of device memory (opening proof)");
   HIPCHK(hipMemcpyAsync(d_apows, apows.data(), apows.size() * 8, hipMemcpyHostToDevice, c->stream));
@@ -464,13 +504,13 @@ static int prove_impl(vx_ctx* c, vx_circuit* k, const u64* wires_in, bool wires_
   }
   // LDE of (F0.a, F0.b, F1.a, F1.b): an F_p^2 NTT with base-field roots is two F_p NTTs
   {
-    std::vector<u64> shifts(rate);
+    std::vector<u64> shifts(zc);
     u64 wN = root_of_unity(LG);
-    for (int z = 0; z < rate; ++z) shifts[z] = mul(7, pow(wN, reverse_bits((size_t)z, rb)));
+    for (int z = 0; z < zc; ++z) shifts[z] = mul(7, pow(wN, reverse_bits((size_t)(z0 + z), rb)));
     int bits = lg / 2;
     u64* tab = nullptr;
     VXCHK(get_scale_tables(c, lg, bits, shifts, 1, &tab));
-    VXCHK(run_ntt(c, fcoef, flde, n, N, 0, n, lg, 4, rate, false, true, tab, bits, 1, "fri_lde", 4.0 * 8.0 * ((double)n + N)));
+    VXCHK(run_ntt(c, fcoef, flde, n, Nl, 0, n, lg, 4, zc, false, true, tab, bits, 1, "fri_lde", 4.0 * 8.0 * ((double)n + Nl)));
   }
   // FRI value arrays per round (interleaved ext, bit-reversed order) and their trees
   const size_t R = k->arity_bits.size();
@@ -488,45 +528,49 @@ static int prove_impl(vx_ctx* c, vx_circuit* k, const u64* wires_in, bool wires_
     cp.fl = flde;
     cp.root_lo = c->root_lo;
     cp.root_hi = c->root_hi;
-    cp.N = N;
+    cp.rows = Nl;
+    cp.row_base = row_base;
     cp.log_N = LG;
     cp.y0[0] = y0.a, cp.y0[1] = y0.b, cp.y1[0] = y1.a, cp.y1[1] = y1.b;
     cp.z0[0] = zeta.a, cp.z0[1] = zeta.b, cp.z1[0] = gzeta.a, cp.z1[1] = gzeta.b;
     Ext sh = epow(alpha, nb1);  // alpha.shift_poly: *= alpha^|batch 1|
     cp.shift0[0] = sh.a, cp.shift0[1] = sh.b;
-    cp.out = fvals[0];
-    ProfScope ps(c, "fri_combine", 48.0 * N);
-    hipLaunchKernelGGL(fri_combine_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, cp);
+    cp.out = fvals[0] + 2 * row_base;
+    ProfScope ps(c, "fri_combine", 48.0 * Nl);
+    hipLaunchKernelGGL(fri_combine_kernel, dim3((unsigned)((Nl + 255) / 256)), dim3(256), 0, c->stream, cp);
     HIPCHK(hipGetLastError());
   }
+  if (R == 0) VXCHK(shard_allgather(c, sh, fvals[0], 16 * Nl, "FRI values"));
   // ---- FRI commit phase ----
   std::vector<std::vector<u64>> commit_caps;
   {
     u64 shift = 7;
     for (size_t r = 0; r < R; ++r) {
       const int ab = k->arity_bits[r];
-      const size_t M = flen[r], leaves = M >> ab;
-      const int width = 2 << ab;
-      size_t nd = merkle_tree_digest_count(leaves, k->cap_height);
+      // the first layer is sharded like every LDE (rows [row_base, row_base + Nl)); later layers are replicated
+      const Shard shr = r == 0 ? sh : Shard();
+      const size_t M = flen[r] >> shr.lg, leaves = M >> ab, in_base = r == 0 ? row_base : 0;
+      const int width = 2 << ab, ch_l = k->cap_height - shr.lg;
+      size_t nd = merkle_tree_digest_count(leaves, ch_l);
       ftrees[r] = S.get(nd * 4);
       if (!ftrees[r]) return vx_fail(VX_E_NOMEM, "prove: out of device memory (FRI trees)");
       {
         ProfScope ps(c, "fri_hash_leaves", 16.0 * M);
         hipLaunchKernelGGL(hash_leaves_rowmajor_kernel, dim3((unsigned)((leaves + HASH_THREADS - 1) / HASH_THREADS)),
-                           dim3(HASH_THREADS), 0, c->stream, fvals[r], leaves, width, ftrees[r]);
+                           dim3(HASH_THREADS), 0, c->stream, fvals[r] + 2 * in_base, leaves, width, ftrees[r]);
         HIPCHK(hipGetLastError());
       }
-      VXCHK(build_merkle_levels(c, ftrees[r], leaves, k->cap_height, &fcapoff[r]));
-      std::vector<u64> cap(cap_words);
-      HIPCHK(hipMemcpyAsync(cap.data(), ftrees[r] + fcapoff[r] * 4, cap_words * 8, hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(hipStreamSynchronize(c->stream));
+      VXCHK(build_merkle_levels(c, ftrees[r], leaves, ch_l, &fcapoff[r]));
+      std::vector<u64> cap;
+      VXCHK(gather_cap(c, shr, S, ftrees[r] + fcapoff[r] * 4, (size_t)4 << ch_l, cap));
       ch.observe_elements(cap.data(), cap_words);
       commit_caps.push_back(cap);
       Ext beta = ch.get_extension_challenge();
       FoldParams fp;
       memset(&fp, 0, sizeof fp);
-      fp.in = fvals[r];
-      fp.out = fvals[r + 1];
+      fp.in = fvals[r] + 2 * in_base;
+      fp.out = fvals[r + 1] + 2 * (in_base >> ab);
+      fp.k_base = in_base >> ab;
       fp.root_lo = c->root_lo;
       fp.root_hi = c->root_hi;
       fp.M = M;
@@ -546,6 +590,7 @@ static int prove_impl(vx_ctx* c, vx_circuit* k, const u64* wires_in, bool wires_
         hipLaunchKernelGGL(fri_fold_kernel, dim3((unsigned)((leaves + 255) / 256)), dim3(256), 0, c->stream, fp);
         HIPCHK(hipGetLastError());
       }
+      VXCHK(shard_allgather(c, shr, fvals[r + 1], 16 * leaves, "folded FRI layer"));
       shift = pow(shift, (u64)1 << ab);
     }
     // final polynomial: the last value array (bit-reversed, on the coset shift*H) -> coefficients, on the host
@@ -622,45 +667,68 @@ static int prove_impl(vx_ctx* c, vx_circuit* k, const u64* wires_in, bool wires_
     std::vector<u64> x_indices(nq);
     for (int q = 0; q < nq; ++q) x_indices[q] = ch.get_challenge() % (u64)N;
     const int depth0 = LG - k->cap_height;
+    // A sharded tree (wires / Z / quotient oracles, first FRI layer) is opened by the rank that owns the leaf — the
+    // top shard_lg bits of the index — and the rows are all-gathered: slot `owner[q]` holds query q's real opening.
     std::vector<std::vector<u64>> init_out(4);
     std::vector<std::vector<u64>> step_out(R);
+    std::vector<int> owner(nq, 0);
+    auto slot_of = [&](bool sharded, int q) { return sharded ? (size_t)owner[q] : (size_t)0; };
     {
       ProfScope ps(c, "query_gather");
-      u64* d_idx = S.get((size_t)nq * (R + 1));
+      u64* d_idx = S.get((size_t)nq * (R + 3));
       if (!d_idx) return vx_fail(VX_E_NOMEM, "prove: out of device memory (queries)");
-      std::vector<u64> idx_host((size_t)nq * (R + 1));
+      std::vector<u64> idx_host((size_t)nq * (R + 3));
+      u64* loc_x = &idx_host[(R + 1) * nq];   // local leaf index in a sharded oracle (0 when another rank owns it)
+      u64* loc_f0 = &idx_host[(R + 2) * nq];  // local leaf index in the first FRI layer's tree
       for (int q = 0; q < nq; ++q) {
         u64 xi = x_indices[q];
         idx_host[q] = xi;
+        owner[q] = (int)(xi >> (LG - sh.lg));
+        const bool mine = owner[q] == sh.rank;
+        loc_x[q] = mine ? xi - row_base : 0;
+        loc_f0[q] = mine && R > 0 ? (xi >> k->arity_bits[0]) - (row_base >> k->arity_bits[0]) : 0;
         for (size_t r = 0; r < R; ++r) {
           xi >>= k->arity_bits[r];
           idx_host[(r + 1) * nq + q] = xi;
         }
       }
       HIPCHK(hipMemcpyAsync(d_idx, idx_host.data(), idx_host.size() * 8, hipMemcpyHostToDevice, c->stream));
+      std::vector<u64*> pending_dev;
+      std::vector<std::vector<u64>*> pending_host;
       for (int o = 0; o < 4; ++o) {
-        size_t rowlen = oracles[o]->ncols + 4 * (size_t)depth0;
-        u64* d_out = S.get(rowlen * nq);
+        const bool sharded = oracles[o]->shard_lg > 0;
+        const size_t rowlen = oracles[o]->ncols + 4 * (size_t)depth0, slots = sharded ? sh.world : 1;
+        u64* d_out = S.get(rowlen * nq * slots);
         if (!d_out) return vx_fail(VX_E_NOMEM, "prove: out of device memory (queries)");
-        hipLaunchKernelGGL(gather_open_kernel, dim3(nq), dim3(128), 0, c->stream, oracles[o]->lde, N, (int)oracles[o]->ncols, 1,
-                           oracles[o]->tree, N, depth0, d_idx, d_out);
-        init_out[o].resize(rowlen * nq);
-        HIPCHK(hipMemcpyAsync(init_out[o].data(), d_out, rowlen * nq * 8, hipMemcpyDeviceToHost, c->stream));
+        const size_t rows_o = oracles[o]->rows();
+        hipLaunchKernelGGL(gather_open_kernel, dim3(nq), dim3(128), 0, c->stream, oracles[o]->lde, rows_o, (int)oracles[o]->ncols, 1,
+                           oracles[o]->tree, rows_o, depth0, sharded ? d_idx + (R + 1) * nq : d_idx,
+                           d_out + (sharded ? rowlen * nq * sh.rank : 0));
+        if (sharded) VXCHK(shard_allgather(c, sh, d_out, rowlen * nq * 8, "query openings"));
+        init_out[o].resize(rowlen * nq * slots);
+        pending_dev.push_back(d_out);
+        pending_host.push_back(&init_out[o]);
       }
       for (size_t r = 0; r < R; ++r) {
         const int ab = k->arity_bits[r];
-        const size_t leaves = flen[r] >> ab;
+        const bool sharded = r == 0 && sh.world > 1;
+        const size_t leaves_all = flen[r] >> ab, leaves = sharded ? leaves_all >> sh.lg : leaves_all, slots = sharded ? sh.world : 1;
         int depth = 0;
-        while (((size_t)1 << (depth + k->cap_height)) < leaves) ++depth;
+        while (((size_t)1 << (depth + k->cap_height)) < leaves_all) ++depth;
         const int width = 2 << ab;
         size_t rowlen = width + 4 * (size_t)depth;
-        u64* d_out = S.get(rowlen * nq);
+        u64* d_out = S.get(rowlen * nq * slots);
         if (!d_out) return vx_fail(VX_E_NOMEM, "prove: out of device memory (queries)");
-        hipLaunchKernelGGL(gather_open_kernel, dim3(nq), dim3(128), 0, c->stream, fvals[r], 0, width, 0, ftrees[r], leaves, depth,
-                           d_idx + (r + 1) * nq, d_out);
-        step_out[r].resize(rowlen * nq);
-        HIPCHK(hipMemcpyAsync(step_out[r].data(), d_out, rowlen * nq * 8, hipMemcpyDeviceToHost, c->stream));
+        hipLaunchKernelGGL(gather_open_kernel, dim3(nq), dim3(128), 0, c->stream, fvals[r] + (sharded ? 2 * row_base : 0), 0, width, 0,
+                           ftrees[r], leaves, depth, sharded ? d_idx + (R + 2) * nq : d_idx + (r + 1) * nq,
+                           d_out + (sharded ? rowlen * nq * sh.rank : 0));
+        if (sharded) VXCHK(shard_allgather(c, sh, d_out, rowlen * nq * 8, "FRI query openings"));
+        step_out[r].resize(rowlen * nq * slots);
+        pending_dev.push_back(d_out);
+        pending_host.push_back(&step_out[r]);
       }
+      for (size_t i = 0; i < pending_dev.size(); ++i)
+        HIPCHK(hipMemcpyAsync(pending_host[i]->data(), pending_dev[i], pending_host[i]->size() * 8, hipMemcpyDeviceToHost, c->stream));
       HIPCHK(hipGetLastError());
       HIPCHK(hipStreamSynchronize(c->stream));
     }
@@ -682,7 +750,7 @@ static int prove_impl(vx_ctx* c, vx_circuit* k, const u64* wires_in, bool wires_
     for (int q = 0; q < nq; ++q) {
       for (int o = 0; o < 4; ++o) {
         size_t width = oracles[o]->ncols, rowlen = width + 4 * (size_t)depth0;
-        const u64* row = &init_out[o][rowlen * q];
+        const u64* row = &init_out[o][rowlen * (slot_of(oracles[o]->shard_lg > 0, q) * nq + q)];
         w.words(row, width);
         w.u8((uint8_t)depth0);
         w.words(row + width, 4 * (size_t)depth0);
@@ -693,7 +761,7 @@ static int prove_impl(vx_ctx* c, vx_circuit* k, const u64* wires_in, bool wires_
         int depth = 0;
         while (((size_t)1 << (depth + k->cap_height)) < leaves) ++depth;
         size_t width = (size_t)2 << ab, rowlen = width + 4 * (size_t)depth;
-        const u64* row = &step_out[r][rowlen * q];
+        const u64* row = &step_out[r][rowlen * (slot_of(r == 0 && sh.world > 1, q) * nq + q)];
         w.words(row, width);
         w.u8((uint8_t)depth);
         w.words(row + width, 4 * (size_t)depth);

@@ -3,6 +3,8 @@
 // point returns VX_E_NO_DEVICE.
 #include "vx_runtime.hip.h"
 #include "batch.hip.h"
+#include <condition_variable>
+#include <mutex>
 #include "prover.hip.h"
 
 extern "C" {
@@ -503,6 +505,133 @@ int vx_prove(vx_ctx* c, vx_circuit* k, const uint64_t* wires, int wires_on_devic
   }
   memcpy(out_buf, proof.data(), proof.size());
   *out_len = proof.size();
+  return VX_OK;
+}
+
+int vx_prove_sharded(vx_ctx* c, vx_circuit* k, const uint64_t* wires, int wires_on_device, int rank, int world,
+                     vx_allgather_fn allgather, void* user, const uint64_t* pow_witness_hint, uint8_t* out_buf, size_t* out_len) {
+  if (!c || !k || !wires || !out_buf || !out_len) return vx_fail(VX_E_INVALID, "vx_prove_sharded: NULL argument");
+  if (k->ctx != c) return vx_fail(VX_E_INVALID, "vx_prove_sharded: circuit belongs to a different context");
+  Shard sh;
+  sh.rank = rank;
+  sh.world = world;
+  while ((1 << sh.lg) < world) ++sh.lg;
+  if (world < 1 || (1 << sh.lg) != world || sh.lg > k->rate_bits || sh.lg > k->cap_height)
+    return vx_fail(VX_E_INVALID, "vx_prove_sharded: world=%d must be a power of two <= 2^rate_bits and <= 2^cap_height", world);
+  if (rank < 0 || rank >= world) return vx_fail(VX_E_INVALID, "vx_prove_sharded: rank %d outside [0, %d)", rank, world);
+  if (world > 1 && !allgather) return vx_fail(VX_E_INVALID, "vx_prove_sharded: world > 1 needs an all-gather callback");
+  sh.fn = allgather;
+  sh.user = user;
+  HIPCHK(hipSetDevice(c->device));
+  std::vector<uint8_t> proof;
+  int rc = prove_impl(c, k, wires, wires_on_device != 0, pow_witness_hint, proof, sh);
+  if (rc != VX_OK) {
+    hipStreamSynchronize(c->stream);
+    return rc;
+  }
+  if (proof.size() > *out_len) {
+    *out_len = proof.size();
+    return vx_fail(VX_E_INVALID, "vx_prove_sharded: output buffer too small, need %zu bytes", proof.size());
+  }
+  memcpy(out_buf, proof.data(), proof.size());
+  *out_len = proof.size();
+  return VX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// In-process rank group: host threads + peer copies (include/vxprover.h)
+// ---------------------------------------------------------------------------------------------
+struct vx_group_member {
+  vx_group* g;
+  int rank;
+  vx_ctx* ctx;
+};
+struct vx_group {
+  int world = 0;
+  std::mutex mu;
+  std::condition_variable cv;
+  int waiting = 0;
+  uint64_t generation = 0;
+  bool aborted = false;
+  std::vector<vx_group_member> members;
+  std::vector<void*> bufs;
+  std::vector<size_t> sizes;
+  // returns false when the group was aborted
+  bool barrier() {
+    std::unique_lock<std::mutex> lk(mu);
+    if (aborted) return false;
+    const uint64_t gen = generation;
+    if (++waiting == world) {
+      waiting = 0;
+      ++generation;
+      cv.notify_all();
+      return true;
+    }
+    cv.wait(lk, [&] { return generation != gen || aborted; });
+    return !aborted;
+  }
+};
+
+int vx_group_create(int world, vx_group** out) {
+  if (!out || world < 1 || world > 64) return vx_fail(VX_E_INVALID, "vx_group_create: bad argument");
+  vx_group* g = new vx_group();
+  g->world = world;
+  g->members.resize(world);
+  g->bufs.assign(world, nullptr);
+  g->sizes.assign(world, 0);
+  for (int r = 0; r < world; ++r) g->members[r] = vx_group_member{g, r, nullptr};
+  *out = g;
+  return VX_OK;
+}
+void vx_group_destroy(vx_group* g) { delete g; }
+void vx_group_abort(vx_group* g) {
+  if (!g) return;
+  std::lock_guard<std::mutex> lk(g->mu);
+  g->aborted = true;
+  g->cv.notify_all();
+}
+int vx_group_join(vx_group* g, int rank, vx_ctx* ctx, void** member_out) {
+  if (!g || !ctx || !member_out || rank < 0 || rank >= g->world) return vx_fail(VX_E_INVALID, "vx_group_join: bad argument");
+  {
+    std::lock_guard<std::mutex> lk(g->mu);
+    g->members[rank].ctx = ctx;
+  }
+  *member_out = &g->members[rank];
+  return VX_OK;
+}
+int vx_group_allgather(void* member, void* dev_buf, size_t bytes_per_rank) {
+  vx_group_member* m = (vx_group_member*)member;
+  if (!m || !m->g || !m->ctx || !dev_buf) return vx_fail(VX_E_INVALID, "vx_group_allgather: bad argument");
+  vx_group* g = m->g;
+  {
+    std::lock_guard<std::mutex> lk(g->mu);
+    g->bufs[m->rank] = dev_buf;
+    g->sizes[m->rank] = bytes_per_rank;
+  }
+  if (!g->barrier()) return vx_fail(VX_E_COMM, "vx_group_allgather: group aborted");
+  // every rank's buffer is published and its producer stream is idle: pull the other ranks' slots
+  HIPCHK(hipSetDevice(m->ctx->device));
+  for (int s = 0; s < g->world; ++s) {
+    if (s == m->rank) continue;
+    if (g->sizes[s] != bytes_per_rank) {
+      vx_group_abort(g);
+      return vx_fail(VX_E_COMM, "vx_group_allgather: rank %d offers %zu bytes, rank %d %zu", s, g->sizes[s], m->rank, bytes_per_rank);
+    }
+    const char* src = (const char*)g->bufs[s] + (size_t)s * bytes_per_rank;
+    char* dst = (char*)dev_buf + (size_t)s * bytes_per_rank;
+    hipError_t e = hipMemcpyPeerAsync(dst, m->ctx->device, src, g->members[s].ctx->device, bytes_per_rank, m->ctx->stream);
+    if (e != hipSuccess) {
+      vx_group_abort(g);
+      return vx_fail(VX_E_HIP, "vx_group_allgather: hipMemcpyPeerAsync: %s", hipGetErrorString(e));
+    }
+  }
+  hipError_t e = hipStreamSynchronize(m->ctx->stream);
+  if (e != hipSuccess) {
+    vx_group_abort(g);
+    return vx_fail(VX_E_HIP, "vx_group_allgather: %s", hipGetErrorString(e));
+  }
+  // nobody may overwrite its slot before all ranks have read it
+  if (!g->barrier()) return vx_fail(VX_E_COMM, "vx_group_allgather: group aborted");
   return VX_OK;
 }
 

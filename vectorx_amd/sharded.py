@@ -1,4 +1,19 @@
-"""Sharded `PolynomialBatch::from_values` across the G GPUs of one node (BASELINE.json configs[3]).
+"""Sharding ONE proof across the G GPUs of one node (BASELINE.json configs[3]).
+
+Two things live here:
+
+* `prove_sharded_processes` / `prove_sharded_threads` — the whole proof, split by LDE COSET (`vx_prove_sharded`,
+  include/vxprover.h): rank r owns LDE rows [r*N/G, (r+1)*N/G) of every committed polynomial, which in this library's
+  bit-reversed row order are whole cosets, so coset NTTs, leaf hashing, Merkle subtrees, the quotient evaluation and
+  the first FRI layer are rank-local and the ranks only all-gather small buffers (cap entries, 2*8n quotient coset
+  coefficients, N/16 folded FRI values, query openings).  No LDE-sized exchange is needed at all, because the
+  coefficients (n per column) are cheap to replicate and each rank extends them to ITS cosets only.
+* `commit_sharded` — the row-chunk formulation BASELINE.json configs[3] names (column-sharded LDE, then ONE
+  all-to-all that re-shards the LDE by row); kept as the L2 building block for hosts that hold the columns
+  distributed, and as the comparison point: it moves the whole LDE (18 GB at n = 2^21) where the coset split moves
+  0.3 GB.
+
+---- commit_sharded: sharded `PolynomialBatch::from_values` ----
 
 The commitment has exactly ONE exchange step:
 
@@ -101,3 +116,93 @@ def commit_sharded(backend, dist, local_values, ncols_total: int, log_n: int, ra
     else:
         cap = local_cap
     return cap, rows
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Whole-proof sharding (vx_prove_sharded)
+# ---------------------------------------------------------------------------------------------------------------
+class _DeviceView:
+    """Expose a raw device pointer to torch through __cuda_array_interface__ (no copy)."""
+
+    def __init__(self, ptr: int, nbytes: int):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+class TorchAllGather:
+    """The in-place all-gather `vx_prove_sharded` asks its host for, on `torch.distributed`:
+    backend "nccl" (= RCCL over xGMI) gathers straight into the library's device buffer; any other backend (gloo in
+    the tests) stages the slots through host memory."""
+
+    def __init__(self, ctx, dist, device=None):
+        import torch
+        self.ctx, self.dist, self.torch = ctx, dist, torch
+        self.device = device
+        self.calls, self.bytes = 0, 0
+
+    def __call__(self, dptr: int, nbytes: int):
+        dist, torch = self.dist, self.torch
+        world, rank = dist.get_world_size(), dist.get_rank()
+        self.calls += 1
+        self.bytes += nbytes * (world - 1)
+        if dist.get_backend() == "nccl":
+            full = torch.as_tensor(_DeviceView(dptr, nbytes * world), device=self.device)
+            mine = full[rank * nbytes:(rank + 1) * nbytes].clone()
+            dist.all_gather_into_tensor(full, mine)
+            torch.cuda.synchronize(self.device)
+            return
+        mine = torch.from_numpy(self.ctx.download(dptr + rank * nbytes, nbytes).view(np.uint8).copy())
+        slots = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(slots, mine)
+        for r, t in enumerate(slots):
+            if r != rank:
+                self.ctx.upload(dptr + r * nbytes, t.numpy())
+
+
+def prove_sharded_processes(circuit, wires, dist, device=None, pow_witness=None) -> bytes:
+    """One process per GPU (`torch.distributed` already initialised): returns the proof on every rank."""
+    world = dist.get_world_size() if dist is not None else 1
+    if world == 1:
+        return circuit.prove(wires, pow_witness=pow_witness)
+    ag = TorchAllGather(circuit.ctx, dist, device)
+    return circuit.prove_sharded(wires, dist.get_rank(), world, ag, pow_witness=pow_witness)
+
+
+def prove_sharded_threads(circuits, wires, pow_witness=None):
+    """One process, one host thread + one `vx_ctx` (GPU) per rank, exchanging through the library's own `vx_group`
+    (peer copies over xGMI) — the shape a Rust host with 8 worker threads uses.  `circuits[r]` is rank r's copy of
+    the circuit (its own context).  Returns the list of per-rank proofs (all identical)."""
+    import ctypes
+    import threading
+
+    from . import VxError, _chk, lib
+
+    world = len(circuits)
+    L = lib()
+    g = ctypes.c_void_p()
+    _chk(L.vx_group_create(world, ctypes.byref(g)))
+    out, errs = [None] * world, [None] * world
+    try:
+        members = []
+        for r, c in enumerate(circuits):
+            m = ctypes.c_void_p()
+            _chk(L.vx_group_join(g, r, c.ctx._h, ctypes.byref(m)))
+            members.append(m)
+
+        def run(r):
+            try:
+                out[r] = circuits[r].prove_sharded(wires, r, world, L.vx_group_allgather, members[r], pow_witness=pow_witness)
+            except BaseException as e:
+                errs[r] = e
+                L.vx_group_abort(g)
+
+        threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+    finally:
+        L.vx_group_destroy(g)
+    real = [e for e in errs if e is not None and not (isinstance(e, VxError) and "aborted" in str(e))]
+    if real or any(errs):
+        raise (real or [e for e in errs if e is not None])[0]
+    return out
