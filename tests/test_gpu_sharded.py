@@ -1,0 +1,172 @@
+"""ONE proof split across several GPUs by LDE coset (vx_prove_sharded; BASELINE.json configs[3]).
+
+The bar is the same as everywhere: byte-identical proofs.  The test boxes have a single GPU, so the G ranks all use
+device 0 — as G host threads exchanging through the library's vx_group (peer copies), and as G processes exchanging
+through torch.distributed (gloo, host-staged; backend nccl on a real node)."""
+import ctypes
+import json
+import os
+import socket
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import oracle_lib
+import vectorx_amd as vx
+from vectorx_amd import sharded
+from vectorx_amd.synth import SynthCircuit
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _rank_circuits(sc, world):
+    ctxs = [vx.Context(0) for _ in range(world)]
+    return ctxs, [vx.Circuit(c, sc.desc_ptr) for c in ctxs]
+
+
+def _free(ctxs, circuits):
+    for c in circuits:
+        c.free()
+    for c in ctxs:
+        c.close()
+
+
+@pytest.mark.parametrize("degree_bits,world,flags", [(3, 2, 0), (4, 8, 0), (5, 4, 0), (6, 2, 0), (6, 8, 7), (8, 4, 1), (10, 8, 0),
+                                                     (11, 2, 7), (13, 4, 0), (13, 8, 0)])
+def test_sharded_proof_is_byte_identical(oracle, degree_bits, world, flags):
+    sc = SynthCircuit(degree_bits, seed=900 + degree_bits, poseidon_percent=40, flags=flags)
+    sc.desc.pow_bits = 8
+    w = sc.witness()
+    expect = oracle_lib.OracleCircuit(oracle, sc.desc_ptr).prove(w)
+    ctxs, circuits = _rank_circuits(sc, world)
+    try:
+        proofs = sharded.prove_sharded_threads(circuits, w)
+        assert len(proofs) == world
+        for r, p in enumerate(proofs):
+            assert p == expect, f"rank {r} of {world}"
+    finally:
+        _free(ctxs, circuits)
+
+
+def test_sharded_proof_full_size_verifies(oracle):
+    """n = 2^16, 8 ranks: identical to the unsharded GPU proof, accepted by the oracle's verifier."""
+    sc = SynthCircuit(16, seed=5, poseidon_percent=50)
+    w = sc.witness()
+    ctx = vx.Context(0)
+    single_c = vx.Circuit(ctx, sc.desc_ptr)
+    single = single_c.prove(w)
+    ctxs, circuits = _rank_circuits(sc, 8)
+    try:
+        proofs = sharded.prove_sharded_threads(circuits, w)
+        assert all(p == single for p in proofs)
+        ov = oracle_lib.OracleCircuit(oracle, sc.desc_ptr, verifier_cap=single_c.constants_sigmas_cap())
+        assert ov.verify(proofs[3]) == ""
+    finally:
+        _free(ctxs, circuits)
+        single_c.free()
+        ctx.close()
+
+
+def test_sharded_proof_accepts_pow_hint_and_device_witness():
+    sc = SynthCircuit(8, seed=31, poseidon_percent=30)
+    sc.desc.pow_bits = 6
+    w = sc.witness()
+    ctxs, circuits = _rank_circuits(sc, 2)
+    try:
+        ref = circuits[0].prove(w)
+        pw = int(np.frombuffer(ref[-40:-32], dtype="<u8")[0])
+        assert all(p == ref for p in sharded.prove_sharded_threads(circuits, w, pow_witness=pw))
+    finally:
+        _free(ctxs, circuits)
+
+
+def test_unsatisfied_witness_behaves_like_the_unsharded_prover(oracle):
+    """same outcome on every rank as vx_prove — a VX_E_PROOF error or a proof the verifier rejects — and no deadlock"""
+    sc = SynthCircuit(7, seed=12, poseidon_percent=50)
+    sc.desc.pow_bits = 4
+    w = sc.witness().copy()
+    w[3, 9] = (int(w[3, 9]) + 1) % oracle_lib.P
+    ctxs, circuits = _rank_circuits(sc, 4)
+    try:
+        try:
+            single = circuits[0].prove(w)
+        except vx.VxError as e:
+            single = e.code
+        try:
+            proofs = sharded.prove_sharded_threads(circuits, w)
+        except vx.VxError as e:
+            assert single == e.code == vx.VX_E_PROOF
+        else:
+            assert all(p == single for p in proofs)
+            assert oracle_lib.OracleCircuit(oracle, sc.desc_ptr).verify(proofs[0]) != ""
+    finally:
+        _free(ctxs, circuits)
+
+
+def test_sharded_argument_checks(ctx):
+    sc = SynthCircuit(5, seed=1, poseidon_percent=50)
+    c = vx.Circuit(ctx, sc.desc_ptr)
+    w = sc.witness()
+    noop = lambda ptr, nbytes: None  # noqa: E731
+    for rank, world in ((0, 3), (0, 16), (2, 2), (-1, 2), (0, 0)):
+        with pytest.raises(vx.VxError) as e:
+            c.prove_sharded(w, rank, world, noop)
+        assert e.value.code == vx.VX_E_INVALID
+    with pytest.raises(vx.VxError):
+        c.prove_sharded(w, 0, 2, None)                      # world > 1 without a callback
+    assert c.prove_sharded(w, 0, 1, None) == c.prove(w)      # world 1 needs none
+
+    def boom(ptr, nbytes):
+        raise RuntimeError("link down")
+    with pytest.raises(RuntimeError, match="link down"):     # a failing exchange surfaces, the library returns VX_E_COMM
+        c.prove_sharded(w, 0, 2, boom)
+    assert c.prove(w) == c.prove_sharded(w, 0, 1, None)      # and the context stays usable
+    c.free()
+
+
+def test_group_abort_wakes_waiting_ranks(ctx):
+    L = vx.lib()
+    g = ctypes.c_void_p()
+    assert L.vx_group_create(2, ctypes.byref(g)) == 0
+    m = ctypes.c_void_p()
+    assert L.vx_group_join(g, 0, ctx._h, ctypes.byref(m)) == 0
+    import threading
+    rc = []
+    buf = ctypes.c_void_p()
+    assert L.vx_dev_alloc(ctx._h, 64, ctypes.byref(buf)) == 0
+    t = threading.Thread(target=lambda: rc.append(L.vx_group_allgather(m, buf, 32)))
+    t.start()
+    t.join(0.3)
+    assert t.is_alive()                                      # rank 1 never arrives: rank 0 is waiting
+    L.vx_group_abort(g)
+    t.join(10)
+    assert not t.is_alive() and rc == [vx.VX_E_COMM]
+    L.vx_dev_free(ctx._h, buf)
+    L.vx_group_destroy(g)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("world,degree_bits,flags", [(2, 9, 0), (4, 7, 5)])
+def test_sharded_proof_across_processes_torch_distributed(world, degree_bits, flags):
+    env = dict(os.environ, OMP_NUM_THREADS="1", VX_TEST_DEGREE_BITS=str(degree_bits), VX_TEST_FLAGS=str(flags),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), str(ROOT / "tests" / "_mp_sharded_prove_worker.py")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=str(ROOT))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["world"] == world
+    res = sorted(out["results"])
+    assert [x[0] for x in res] == list(range(world))
+    assert all(x[1] for x in res)                            # every rank's proof == its own unsharded proof
+    assert len({x[2] for x in res}) == 1                     # and all ranks hold the same bytes
+    assert all(x[3] >= 7 for x in res)                       # caps x3, quotient coefficients, FRI cap + layer, openings

@@ -82,3 +82,12 @@ def test_dag_spec_header_range_512():
     from vectorx_amd.mapreduce import DagSpec
     s = DagSpec()
     assert s.num_proofs() == 128 and [len(j) for _, j in s.layers()] == [64, 32, 16, 8, 4, 2, 1, 1]
+
+
+def test_torch_allgather_gloo():
+    """the in-place all-gather vx_prove_sharded calls back into, host-staged over gloo (world 2 and 4)"""
+    for world in (2, 4):
+        out = _run_workers("_mp_allgather_worker.py", world)
+        assert out["world"] == world
+        assert all(ok for _, ok, _, _ in out["results"])
+        assert all(calls == 3 and nbytes == (4 + 64 + 1000) * 8 * (world - 1) for _, _, calls, nbytes in out["results"])

@@ -23,7 +23,7 @@ _PKG = Path(__file__).resolve().parent
 _LIB_PATH = Path(os.environ.get("VXPROVER_LIB", _PKG / "libvxprover.so"))  # override = kernel A/B experiments only
 P = 0xFFFFFFFF00000001
 
-VX_OK, VX_E_INVALID, VX_E_NO_DEVICE, VX_E_HIP, VX_E_NOMEM, VX_E_PROOF = 0, -1, -2, -3, -4, -5
+VX_OK, VX_E_INVALID, VX_E_NO_DEVICE, VX_E_HIP, VX_E_NOMEM, VX_E_PROOF, VX_E_COMM = 0, -1, -2, -3, -4, -5, -6
 NTT_FFT, NTT_IFFT, NTT_COSET_FFT, NTT_COSET_IFFT = 0, 1, 2, 3
 
 
