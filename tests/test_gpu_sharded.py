@@ -169,4 +169,33 @@ def test_sharded_proof_across_processes_torch_distributed(world, degree_bits, fl
     assert [x[0] for x in res] == list(range(world))
     assert all(x[1] for x in res)                            # every rank's proof == its own unsharded proof
     assert len({x[2] for x in res}) == 1                     # and all ranks hold the same bytes
-    assert all(x[3] >= 7 for x in res)                       # caps x3, quotient coefficients, FRI cap + layer, openings
+    assert all(x[3] >= 8 for x in res)                       # witness, caps x3, quotient coefficients, FRI cap + layer, openings
+
+
+def test_torch_allgather_on_device_memory_nccl_world1():
+    """The production exchange path (backend nccl = RCCL): torch views the library's device buffer in place.  With one
+    GPU only world 1 can run here; it still proves that the zero-copy view of a vx_dev_alloc pointer works."""
+    env = dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0", VX_FORCE_DIST="1", RANK="0", WORLD_SIZE="1",
+               LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import numpy as np, torch, torch.distributed as dist\n"
+        "import vectorx_amd as vx\n"
+        "from vectorx_amd import sharded\n"
+        "torch.cuda.set_device(0)\n"
+        "dist.init_process_group('nccl', device_id=torch.device('cuda', 0))\n"
+        "ctx = vx.Context(0)\n"
+        "p = ctx.alloc(4096)\n"
+        "a = np.arange(512, dtype=np.uint64) * 7\n"
+        "ctx.upload(p, a)\n"
+        "ag = sharded.TorchAllGather(ctx, dist, torch.device('cuda', 0))\n"
+        "ag(p, 4096)\n"
+        "assert (ctx.download(p, 4096) == a).all()\n"
+        "v = torch.as_tensor(sharded._DeviceView(p, 4096), device=torch.device('cuda', 0))\n"
+        "v[:8] = 0\n"
+        "torch.cuda.synchronize()\n"
+        "assert int(ctx.download(p, 4096)[0]) == 0 and int(ctx.download(p, 4096)[1]) == 7\n"
+        "ctx.free(p); ctx.close(); dist.destroy_process_group(); print('OK')\n"
+    ) % str(ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=str(ROOT))
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]

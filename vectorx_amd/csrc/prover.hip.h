@@ -248,10 +248,16 @@ static int prove_impl(vx_ctx* c, vx_circuit* k, const u64* wires_in, bool wires_
   // ---- witness on device ----
   const u64* d_wires = wires_in;
   if (!wires_on_device) {
-    ProfScope ps(c, "h2d_witness");
-    u64* w = S.get((size_t)k->num_wires * n);
+    // each rank uploads 1/world of the columns over its own PCIe link; the ranks then all-gather the matrix
+    const size_t per = ((size_t)k->num_wires + sh.world - 1) / sh.world;
+    u64* w = S.get(per * sh.world * n);
     if (!w) return vx_fail(VX_E_NOMEM, "prove: out of device memory (witness)");
-    HIPCHK(hipMemcpyAsync(w, wires_in, (size_t)k->num_wires * n * 8, hipMemcpyHostToDevice, c->stream));
+    const size_t c0 = std::min((size_t)k->num_wires, per * sh.rank), c1 = std::min((size_t)k->num_wires, c0 + per);
+    {
+      ProfScope ps(c, "h2d_witness");
+      if (c1 > c0) HIPCHK(hipMemcpyAsync(w + c0 * n, wires_in + c0 * n, (c1 - c0) * n * 8, hipMemcpyHostToDevice, c->stream));
+    }
+    VXCHK(shard_allgather(c, sh, w, per * n * 8, "witness columns"));
     d_wires = w;
   }
   // public inputs = witness.get_targets(public_inputs); public_inputs_hash = hash_no_pad(..)
