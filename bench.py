@@ -35,6 +35,9 @@ def parse():
     ap.add_argument("--log-n", type=int, default=21, help="log2 trace rows (21 = header_range_512 stand-in)")
     ap.add_argument("--ncols", type=int, default=135)
     ap.add_argument("--workload", default="prove", choices=["commit", "prove"])
+    ap.add_argument("--mode", default="throughput", choices=["throughput", "sharded"],
+                    help="N>1 only. throughput (default, BASELINE configs[4]): one proof per GPU, weak scaling.  sharded "
+                         "(configs[3]): ALL GPUs work on one proof (vx_prove_sharded, coset split, RCCL all-gathers), strong scaling")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-log-n", type=int, default=None,
                     help="rows (log2) of the bounded CPU-baseline sample (default 16 for prove, 17 for commit)")
@@ -99,7 +102,7 @@ def main():
         cleanup = lambda: ctx.free(d_in)
     else:
         import bench_prove
-        step, metric, unit, wl_name, cleanup = bench_prove.make_step(ctx, args, rank)
+        step, metric, unit, wl_name, cleanup = bench_prove.make_step(ctx, args, rank, dist, torch.device("cuda", local_rank))
 
     def sync():
         ctx.sync()
@@ -148,13 +151,17 @@ def main():
             alu = {"kernel": "hash_leaves_colmajor_kernel", "bound": "integer ALU (VALU issue)", "perms_per_proof": perms,
                    "ms_per_proof": round(ms, 2), "gperms_per_s": round(perms / (ms * 1e-3) / 1e9, 3),
                    "valu_insts_per_perm": 22060, "source": "profiles/r01_history + DESIGN.md §3 (SQ_INSTS_VALU / permutations)"}
-        agg = H.aggregate(world, args.steps, dt)
+        sharded_mode = args.mode == "sharded" and world > 1 and args.workload == "prove"
+        agg = H.aggregate(1 if sharded_mode else world, args.steps, dt)   # sharded: the N ranks finish ONE proof per step
         out = {
             "metric": metric, "value": agg["value"], "unit": unit,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": agg["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": agg["ms_per_step"], "higher_is_better": True, "scaling": "strong" if sharded_mode else "weak",
             "vs_baseline": None, "dtype": "u64 (Goldilocks field, integer modular arithmetic)", "data": "synthetic",
-            "config": {"workload": wl_name, "parallelism": f"proof-level x{world} (one witness per GPU, no collective)"},
+            "config": {"workload": wl_name,
+                       "parallelism": (f"one proof coset-sharded x{world} (vx_prove_sharded; RCCL all-gathers of caps, quotient coset "
+                                       f"coefficients, first FRI layer, openings)" if sharded_mode else
+                                       f"proof-level x{world} (one witness per GPU, no collective)")},
             "roofline": roof,
             "alu_bound_dominant_kernel": alu,
             "stage_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in prof.items()},

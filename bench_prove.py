@@ -5,11 +5,13 @@ import time
 import numpy as np
 
 
-def make_step(ctx, args, rank):
+def make_step(ctx, args, rank, dist=None, device=None):
     import vectorx_amd as vx
     from vectorx_amd.synth import SynthCircuit
 
-    sc = SynthCircuit(args.log_n, seed=0x5EED0000 + rank, poseidon_percent=args.poseidon_percent)
+    sharded_mode = getattr(args, "mode", "throughput") == "sharded" and dist is not None
+    # throughput mode: every rank proves its OWN witness; sharded mode: all ranks work on the SAME proof
+    sc = SynthCircuit(args.log_n, seed=0x5EED0000 + (0 if sharded_mode else rank), poseidon_percent=args.poseidon_percent)
     counts = sc.row_counts()
     circuit = vx.Circuit(ctx, sc.desc_ptr)   # constants_sigmas commitment stays resident (per-circuit, not per-proof)
     w = sc.witness()
@@ -19,9 +21,18 @@ def make_step(ctx, args, rank):
     sc.release_host_buffers(witness=True, preprocessed=True)
     state = {"proof": None}
 
-    def step():
-        state["proof"] = circuit.prove(dev_ptr=d_w)
-        return state["proof"]
+    if sharded_mode:
+        from vectorx_amd.sharded import TorchAllGather
+        ag = TorchAllGather(ctx, dist, device)
+        world = dist.get_world_size()
+
+        def step():
+            state["proof"] = circuit.prove_sharded(None, rank, world, ag, dev_ptr=d_w)
+            return state["proof"]
+    else:
+        def step():
+            state["proof"] = circuit.prove(dev_ptr=d_w)
+            return state["proof"]
 
     metric = "header_range_512 proofs/sec"
     unit = "proofs/sec"
