@@ -85,6 +85,38 @@ __global__ __launch_bounds__(HASH_THREADS) void merkle_level_kernel(const u64* _
   o[1] = make_ulonglong2(s[2], s[3]);
 }
 
+// Lane-cooperative forms (poseidon.hip.h): 16 lanes per node / leaf, for launches too small to fill the chip.
+#define COOP_MAX_NODES 16384   /* below this a level is latency-bound in the one-thread-per-node form */
+#define COOP_MAX_LEAVES 8192
+__global__ __launch_bounds__(HASH_THREADS) void merkle_level_coop_kernel(const u64* __restrict__ children,
+                                                                         u64* __restrict__ parents, size_t n_parents) {
+  const size_t t = (size_t)blockIdx.x * HASH_THREADS + threadIdx.x;
+  const size_t node = t >> 4;
+  const int g = (int)(t & 15), group_base = (int)(threadIdx.x & 63) & ~15;
+  const bool live = node < n_parents;
+  u64 v = (live && g < 8) ? children[node * 8 + g] : 0;
+  v = poseidon_permute_coop_nc(v, g, group_base);
+  if (live && g < 4) parents[node * 4 + g] = gl_canon(v);
+}
+__global__ __launch_bounds__(HASH_THREADS) void hash_leaves_rowmajor_coop_kernel(
+    const u64* __restrict__ leaves, size_t nrows, int width, u64* __restrict__ digests) {
+  const size_t t = (size_t)blockIdx.x * HASH_THREADS + threadIdx.x;
+  const size_t row = t >> 4;
+  const int g = (int)(t & 15), group_base = (int)(threadIdx.x & 63) & ~15;
+  const bool live = row < nrows;
+  const u64* src = leaves + (live ? row : 0) * (size_t)width;
+  u64 v = 0;
+  if (width <= 4) {
+    if (g < width) v = src[g];
+  } else {
+    for (int c = 0; c < width; c += 8) {   // overwrite-mode sponge: rate lanes take the next 8 inputs
+      if (g < 8 && c + g < width) v = gl_canon(src[c + g]);
+      v = poseidon_permute_coop_nc(v, g, group_base);
+    }
+  }
+  if (live && g < 4) digests[row * 4 + g] = gl_canon(v);
+}
+
 __global__ void poseidon_permute_kernel(u64* __restrict__ states, size_t count) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count) return;

@@ -166,3 +166,44 @@ GLD void poseidon_two_to_one(const u64* l, const u64* r, u64* out) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) out[i] = gl_canon(s[i]);
 }
+
+// ------------------------------------------------------------------------------------------------
+// Lane-cooperative permutation for LATENCY-bound launches (the small levels of a Merkle tree, small FRI layers):
+// 16 lanes per state, lane g < 12 holds s[g] (lanes 12..15 of a group shadow lanes 0..3 and are ignored), so one
+// wavefront carries 4 states and a permutation is ~30 x (S-box + 12 cross-lane multiply-adds) = ~4k instructions
+// deep instead of ~22k.  Below ~16k states a launch of the one-thread-per-state form costs one full permutation
+// latency (~60 us) whatever its size; this form costs ~1/5 of that.  Plain (non-"fast") partial rounds: every lane
+// adds its round constant, lane 0 takes the S-box, then the same cross-lane MDS as in the full rounds.
+// ------------------------------------------------------------------------------------------------
+GLD u64 poseidon_coop_mds_nc(u64 v, int g, int group_base) {
+  const u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+  const u32 lo = (u32)v, hi = (u32)(v >> 32);
+  u64 al = 0, ah = 0;
+  int idx = g < 12 ? g : g - 12;
+#pragma unroll
+  for (int i = 0; i < 12; ++i) {
+    const int src = group_base + idx;
+    al += (u64)C[i] * (u32)__shfl((int)lo, src, 64);
+    ah += (u64)C[i] * (u32)__shfl((int)hi, src, 64);
+    idx = idx == 11 ? 0 : idx + 1;
+  }
+  if (g == 0) {
+    al += (u64)8 * lo;
+    ah += (u64)8 * hi;
+  }
+  const u64 l = al + (ah << 32);
+  const u64 h = (ah >> 32) + (l < al ? 1 : 0);
+  return gl_reduce128_nc(l, h);
+}
+// v: this lane's state element (any u64 representative); returns the permuted element (NOT canonical).
+GLD u64 poseidon_permute_coop_nc(u64 v, int g, int group_base) {
+  const int gi = g < 12 ? g : g - 12;
+#pragma unroll 1
+  for (int r = 0; r < 30; ++r) {
+    v = gl_add_nc_c(v, POSEIDON_RC[r * 12 + gi]);
+    const bool full = r < 4 || r >= 26;
+    if (full || g == 0) v = poseidon_sbox_nc(v);
+    v = poseidon_coop_mds_nc(v, g, group_base);
+  }
+  return v;
+}

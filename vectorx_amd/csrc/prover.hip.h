@@ -562,8 +562,12 @@ static int prove_impl(vx_ctx* c, vx_circuit* k, const u64* wires_in, bool wires_
       if (!ftrees[r]) return vx_fail(VX_E_NOMEM, "prove: out of device memory (FRI trees)");
       {
         ProfScope ps(c, "fri_hash_leaves", 16.0 * M);
-        hipLaunchKernelGGL(hash_leaves_rowmajor_kernel, dim3((unsigned)((leaves + HASH_THREADS - 1) / HASH_THREADS)),
-                           dim3(HASH_THREADS), 0, c->stream, fvals[r] + 2 * in_base, leaves, width, ftrees[r]);
+        if (leaves <= COOP_MAX_LEAVES)
+          hipLaunchKernelGGL(hash_leaves_rowmajor_coop_kernel, dim3((unsigned)((leaves * 16 + HASH_THREADS - 1) / HASH_THREADS)),
+                             dim3(HASH_THREADS), 0, c->stream, fvals[r] + 2 * in_base, leaves, width, ftrees[r]);
+        else
+          hipLaunchKernelGGL(hash_leaves_rowmajor_kernel, dim3((unsigned)((leaves + HASH_THREADS - 1) / HASH_THREADS)),
+                             dim3(HASH_THREADS), 0, c->stream, fvals[r] + 2 * in_base, leaves, width, ftrees[r]);
         HIPCHK(hipGetLastError());
       }
       VXCHK(build_merkle_levels(c, ftrees[r], leaves, ch_l, &fcapoff[r]));
@@ -651,13 +655,16 @@ static int prove_impl(vx_ctx* c, vx_circuit* k, const u64* wires_in, bool wires_
         unsigned long long* d_res = (unsigned long long*)S.get(1);
         if (!d_res) return vx_fail(VX_E_NOMEM, "prove: out of device memory (pow)");
         pp.result = d_res;
-        const u64 batch = (u64)1 << 22;
+        // Candidates are searched in increasing ranges and the smallest hit of a range wins, so the witness does not
+        // depend on the range sizes.  The first range is sized to succeed with probability ~1 - e^-2 at the cost of a
+        // couple of waves per SIMD; later ranges grow to keep the launch count logarithmic.
+        u64 batch = (u64)2 << std::min(k->pow_bits, 21);
         unsigned long long res = ~0ull;
         ProfScope ps(c, "pow_grind");
-        for (u64 base = 0; res == ~0ull; base += batch) {
+        for (u64 base = 0; res == ~0ull; base += batch, batch = std::min(batch * 4, (u64)1 << 24)) {
           HIPCHK(hipMemsetAsync(d_res, 0xFF, 8, c->stream));
           pp.base = base;
-          hipLaunchKernelGGL(pow_grind_kernel, dim3((unsigned)(batch / 256)), dim3(256), 0, c->stream, pp);
+          hipLaunchKernelGGL(pow_grind_kernel, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, c->stream, pp);
           HIPCHK(hipMemcpyAsync(&res, d_res, 8, hipMemcpyDeviceToHost, c->stream));
           HIPCHK(hipStreamSynchronize(c->stream));
           if (base > ((u64)1 << 44)) return vx_fail(VX_E_PROOF, "Proof of work failed. This is highly unlikely!");

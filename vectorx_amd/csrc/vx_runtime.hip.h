@@ -380,8 +380,12 @@ static int build_merkle_levels(vx_ctx* c, u64* tree, size_t n_leaves, int cap_he
   size_t off = 0, n = n_leaves;
   while (n > ((size_t)1 << cap_height)) {
     size_t np = n >> 1;
-    hipLaunchKernelGGL(merkle_level_kernel, dim3((unsigned)((np + HASH_THREADS - 1) / HASH_THREADS)),
-                       dim3(HASH_THREADS), 0, c->stream, tree + off * 4, tree + (off + n) * 4, np);
+    if (np <= COOP_MAX_NODES)  // latency-bound level: 16 lanes per node
+      hipLaunchKernelGGL(merkle_level_coop_kernel, dim3((unsigned)((np * 16 + HASH_THREADS - 1) / HASH_THREADS)),
+                         dim3(HASH_THREADS), 0, c->stream, tree + off * 4, tree + (off + n) * 4, np);
+    else
+      hipLaunchKernelGGL(merkle_level_kernel, dim3((unsigned)((np + HASH_THREADS - 1) / HASH_THREADS)),
+                         dim3(HASH_THREADS), 0, c->stream, tree + off * 4, tree + (off + n) * 4, np);
     off += n;
     n = np;
   }
