@@ -162,18 +162,22 @@ struct QuotientParams {
   u64 pih[4];
   u64 zh[VX_MAX_RATE], zh_inv[VX_MAX_RATE];  // ZeroPolyOnCoset evals / inverses, indexed by coset r
   u64 n_field;                               // n mod p
+  const u64* __restrict__ alpha_pows;        // [VX_MAX_CHALLENGES][VX_ALPHA_POWS]: alpha_c^i
   u64* out;                                  // [nch][stride_w]
 };
 
+// reduce_with_powers: acc += term * alpha^idx per challenge.  The powers come from a table built on the host
+// (alpha_pows[c * VX_ALPHA_POWS + idx]); idx is wave-uniform, so the loads are scalar and the running-power
+// multiply of the naive form disappears.
+#define VX_ALPHA_POWS 512
 struct AlphaAcc {
-  u64 acc[VX_MAX_CHALLENGES], pw[VX_MAX_CHALLENGES];
+  u64 acc[VX_MAX_CHALLENGES];
+  int idx;
 };
 GLD void acc_push(AlphaAcc& a, const QuotientParams& p, u64 term) {
 #pragma unroll
-  for (int c = 0; c < VX_MAX_CHALLENGES; ++c) {
-    a.acc[c] = gl_mad(term, a.pw[c], a.acc[c]);
-    a.pw[c] = gl_mul(a.pw[c], p.alphas[c]);
-  }
+  for (int c = 0; c < VX_MAX_CHALLENGES; ++c) a.acc[c] = gl_mad(term, p.alpha_pows[c * VX_ALPHA_POWS + a.idx], a.acc[c]);
+  ++a.idx;
 }
 
 #define UNUSED_SELECTOR_U64 0xFFFFFFFFULL
@@ -196,7 +200,8 @@ __global__ __launch_bounds__(256, 4) void quotient_kernel(QuotientParams p) {
 
   AlphaAcc A;
 #pragma unroll
-  for (int c = 0; c < VX_MAX_CHALLENGES; ++c) A.acc[c] = 0, A.pw[c] = 1;
+  for (int c = 0; c < VX_MAX_CHALLENGES; ++c) A.acc[c] = 0;
+  A.idx = 0;
 
   // (1) L_0(x) (Z(x) - 1) per challenge;  eval_l_0 = Z_H(x) / (n (x - 1))
   const u64 l0 = gl_mul(p.zh[r], gl_inv(gl_mul(p.n_field, gl_sub(x, 1))));
@@ -221,7 +226,7 @@ __global__ __launch_bounds__(256, 4) void quotient_kernel(QuotientParams p) {
     }
   }
   // (3) gate constraints: sum_g filter_g * sum_i c_{g,i} alpha^(i + offset)
-  const u64 base_pw[VX_MAX_CHALLENGES] = {A.pw[0], A.pw[1]};
+  const int base_idx = A.idx;
   for (int g = 0; g < p.num_gates; ++g) {
     const GateDev gd = p.gates[g];
     if (gd.type == 0 || gd.type == 5) continue;  // NoopGate: no constraints; program gates: program_gates_kernel
@@ -232,7 +237,8 @@ __global__ __launch_bounds__(256, 4) void quotient_kernel(QuotientParams p) {
     if (p.num_selectors > 1) filter = gl_mul(filter, gl_sub(UNUSED_SELECTOR_U64, s));
     AlphaAcc G;
 #pragma unroll
-    for (int c = 0; c < VX_MAX_CHALLENGES; ++c) G.acc[c] = 0, G.pw[c] = base_pw[c];
+    for (int c = 0; c < VX_MAX_CHALLENGES; ++c) G.acc[c] = 0;
+    G.idx = base_idx;
     const int c0 = p.num_selectors;  // gate constants start after the selectors
     if (gd.type == 1) {              // ConstantGate
       for (int q = 0; q < gd.param; ++q) acc_push(G, p, gl_sub(CS(c0 + q), WIRE(q)));
@@ -246,6 +252,8 @@ __global__ __launch_bounds__(256, 4) void quotient_kernel(QuotientParams p) {
         acc_push(G, p, gl_sub(o, rhs));
       }
     } else if (gd.type == 4) {  // PoseidonGate (gates/poseidon.rs wire layout)
+      // The running state is kept as arbitrary u64 representatives ("nc", poseidon.hip.h): wires are canonical, so
+      // state - wire and state + constant need one carry fix each, and acc_push's multiply-add takes any representative.
       const u64 swap = WIRE(24);
       acc_push(G, p, gl_mul(swap, gl_sub(swap, 1)));
       u64 st[12];
@@ -262,47 +270,47 @@ __global__ __launch_bounds__(256, 4) void quotient_kernel(QuotientParams p) {
 #pragma unroll 1
       for (int rr = 0; rr < 4; ++rr) {
 #pragma unroll
-        for (int q = 0; q < 12; ++q) st[q] = gl_add(st[q], POSEIDON_RC[12 * round + q]);
+        for (int q = 0; q < 12; ++q) st[q] = gl_add_nc_c(st[q], POSEIDON_RC[12 * round + q]);
         if (rr != 0) {
 #pragma unroll
           for (int q = 0; q < 12; ++q) {
             u64 in = WIRE(29 + 12 * (rr - 1) + q);
-            acc_push(G, p, gl_sub(st[q], in));
+            acc_push(G, p, gl_sub_nc_c(st[q], in));
             st[q] = in;
           }
         }
 #pragma unroll
-        for (int q = 0; q < 12; ++q) st[q] = poseidon_sbox(st[q]);
-        poseidon_mds(st);
+        for (int q = 0; q < 12; ++q) st[q] = poseidon_sbox_nc(st[q]);
+        poseidon_mds_nc(st);
         ++round;
       }
 #pragma unroll 1
       for (int rr = 0; rr < 22; ++rr) {
 #pragma unroll
-        for (int q = 0; q < 12; ++q) st[q] = gl_add(st[q], POSEIDON_RC[12 * round + q]);
+        for (int q = 0; q < 12; ++q) st[q] = gl_add_nc_c(st[q], POSEIDON_RC[12 * round + q]);
         u64 in = WIRE(65 + rr);
-        acc_push(G, p, gl_sub(st[0], in));
-        st[0] = poseidon_sbox(in);
-        poseidon_mds(st);
+        acc_push(G, p, gl_sub_nc_c(st[0], in));
+        st[0] = poseidon_sbox_nc(in);
+        poseidon_mds_nc(st);
         ++round;
       }
 #pragma unroll 1
       for (int rr = 0; rr < 4; ++rr) {
 #pragma unroll
-        for (int q = 0; q < 12; ++q) st[q] = gl_add(st[q], POSEIDON_RC[12 * round + q]);
+        for (int q = 0; q < 12; ++q) st[q] = gl_add_nc_c(st[q], POSEIDON_RC[12 * round + q]);
 #pragma unroll
         for (int q = 0; q < 12; ++q) {
           u64 in = WIRE(87 + 12 * rr + q);
-          acc_push(G, p, gl_sub(st[q], in));
+          acc_push(G, p, gl_sub_nc_c(st[q], in));
           st[q] = in;
         }
 #pragma unroll
-        for (int q = 0; q < 12; ++q) st[q] = poseidon_sbox(st[q]);
-        poseidon_mds(st);
+        for (int q = 0; q < 12; ++q) st[q] = poseidon_sbox_nc(st[q]);
+        poseidon_mds_nc(st);
         ++round;
       }
 #pragma unroll
-      for (int q = 0; q < 12; ++q) acc_push(G, p, gl_sub(st[q], WIRE(12 + q)));
+      for (int q = 0; q < 12; ++q) acc_push(G, p, gl_sub_nc_c(st[q], WIRE(12 + q)));
     }
 #pragma unroll
     for (int c = 0; c < VX_MAX_CHALLENGES; ++c) A.acc[c] = gl_mad(filter, G.acc[c], A.acc[c]);

@@ -36,6 +36,12 @@ GLD u64 gl_add_nc_c(u64 a, u64 b) {
   if (s < a) s += GL_EPS;
   return s;
 }
+// a: any u64, b: CANONICAL  ->  a - b (nc).  On a borrow the wrapped difference is >= 2^64 - (p-1) = EPS, so one fix suffices.
+GLD u64 gl_sub_nc_c(u64 a, u64 b) {
+  u64 d = a - b;
+  if (a < b) d -= GL_EPS;
+  return d;
+}
 GLD u64 poseidon_sbox_nc(u64 x) {
   const u64 x2 = gl_mul_nc(x, x), x4 = gl_mul_nc(x2, x2), x3 = gl_mul_nc(x, x2);
   return gl_mul_nc(x3, x4);

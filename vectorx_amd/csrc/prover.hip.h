@@ -359,6 +359,22 @@ static int prove_impl(vx_ctx* c, vx_circuit* k, const u64* wires_in, bool wires_
         pw = mul(pw, g_rate);
       }
       qp.n_field = (u64)n % P;
+      {
+        // alpha powers for reduce_with_powers: L_0 terms, partial-product checks, then the widest gate (123 constraints)
+        if ((size_t)nch * (1 + nchunks) + 160 > VX_ALPHA_POWS) return vx_fail(VX_E_INVALID, "prove: too many constraint terms");
+        std::vector<u64> ap((size_t)VX_MAX_CHALLENGES * VX_ALPHA_POWS, 0);
+        for (int cI = 0; cI < nch; ++cI) {
+          u64 pw = 1;
+          for (int i = 0; i < VX_ALPHA_POWS; ++i) {
+            ap[(size_t)cI * VX_ALPHA_POWS + i] = pw;
+            pw = mul(pw, alphas[cI]);
+          }
+        }
+        u64* d_ap = S.get(ap.size());
+        if (!d_ap) return vx_fail(VX_E_NOMEM, "prove: out of device memory (alpha powers)");
+        HIPCHK(hipMemcpy(d_ap, ap.data(), ap.size() * 8, hipMemcpyHostToDevice));
+        qp.alpha_pows = d_ap;
+      }
       qp.out = qv;
       size_t bytes_read = 8ull * Nl * ((size_t)k->num_constants + k->nr + k->num_wires + (size_t)nch * (2 + npp));
       ProfScope ps(c, "quotient_eval", (double)bytes_read);
