@@ -215,10 +215,10 @@ __global__ __launch_bounds__(256, 4) void quotient_kernel(QuotientParams p) {
     for (int kk = 0; kk < nchunks; ++kk) {
       u64 np = 1, dp = 1;
       const int j1 = min(p.nr, (kk + 1) * p.deg);
-      for (int jj = kk * p.deg; jj < j1; ++jj) {
+      for (int jj = kk * p.deg; jj < j1; ++jj) {   // products kept as arbitrary u64 representatives until the end
         u64 wg = gl_add(WIRE(jj), gamma);
-        np = gl_mul(np, gl_mad(p.k_is[jj], bx, wg));
-        dp = gl_mul(dp, gl_mad(beta, CS(p.num_constants + jj), wg));
+        np = gl_mul_nc(np, gl_mad_nc(p.k_is[jj], bx, wg));
+        dp = gl_mul_nc(dp, gl_mad_nc(beta, CS(p.num_constants + jj), wg));
       }
       u64 next = kk < p.npp ? ZS(p.nch + ch * p.npp + kk) : p.zs[(size_t)ch * SW + il_next];
       acc_push(A, p, gl_sub(gl_mul(prev, np), gl_mul(next, dp)));
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256, 4) void quotient_kernel(QuotientParams p) {
       const u64 k0 = CS(c0), k1 = CS(c0 + 1);
       for (int q = 0; q < gd.param; ++q) {
         u64 m0 = WIRE(4 * q), m1 = WIRE(4 * q + 1), ad = WIRE(4 * q + 2), o = WIRE(4 * q + 3);
-        u64 rhs = gl_mad(gl_mul(m0, m1), k0, gl_mul(ad, k1));
+        u64 rhs = gl_mad(gl_mul_nc(m0, m1), k0, gl_mul_nc(ad, k1));
         acc_push(G, p, gl_sub(o, rhs));
       }
     } else if (gd.type == 4) {  // PoseidonGate (gates/poseidon.rs wire layout)
