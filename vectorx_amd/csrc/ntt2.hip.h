@@ -153,6 +153,10 @@ struct Ntt2Params {
   const u64* pre;  // [z][2^(log_n-pre_bits) + 2^pre_bits] or null
   int pre_bits;
   u64 post_scale;
+  // nz_fold > 0: the coset (z) dimension is folded into blockIdx.x so that the nz blocks that read the SAME
+  // coefficient tile (one per coset of an LDE) are dispatched back to back on the SAME XCD — workgroups go to XCDs
+  // round-robin, so block id = ((tile / 8) * nz + z) * 8 + tile % 8 — and 7 of the 8 reads hit that XCD's L2.
+  int nz_fold;
 };
 
 // LDS index of tile element (m, t): strided tiles are [m][t], contiguous tiles are [t][m]
@@ -213,7 +217,13 @@ __global__ __launch_bounds__(NTT2_THREADS) void ntt2_pass_kernel(Ntt2Params p) {
     W[j] = root_pow24(p.root_lo, p.root_hi, e);
   }
 
-  const size_t tile_id = blockIdx.x;
+  u32 bz = blockIdx.z;
+  size_t tile_id = blockIdx.x;
+  if (p.nz_fold > 0) {
+    const u32 rest = blockIdx.x >> 3;
+    bz = rest % (u32)p.nz_fold;
+    tile_id = (size_t)(rest / (u32)p.nz_fold) * 8 + (blockIdx.x & 7);
+  }
   size_t base;
   if constexpr (STRIDED) {
     const size_t tiles_per_span = (size_t)1 << (p.b_lo - T_LOG);
@@ -223,8 +233,8 @@ __global__ __launch_bounds__(NTT2_THREADS) void ntt2_pass_kernel(Ntt2Params p) {
   } else {
     base = tile_id << NTT2_TILE_LOG;
   }
-  const u64* __restrict__ in = p.in + (size_t)blockIdx.y * p.in_col_stride + (size_t)blockIdx.z * p.in_z_stride;
-  u64* __restrict__ out = p.out + (size_t)blockIdx.y * p.out_col_stride + (size_t)blockIdx.z * p.out_z_stride;
+  const u64* __restrict__ in = p.in + (size_t)blockIdx.y * p.in_col_stride + (size_t)bz * p.in_z_stride;
+  u64* __restrict__ out = p.out + (size_t)blockIdx.y * p.out_col_stride + (size_t)bz * p.out_z_stride;
 
   // ---------------- round 1: stage bits [R_LOG-4, R_LOG), fed from global memory ----------------
   {
@@ -256,7 +266,7 @@ __global__ __launch_bounds__(NTT2_THREADS) void ntt2_pass_kernel(Ntt2Params p) {
       }
       u64 v = gl_canon(in[gi]);
       if constexpr (PRE) {
-        const u64* pre = p.pre + (size_t)blockIdx.z * (((size_t)1 << (p.log_n - p.pre_bits)) + ((size_t)1 << p.pre_bits));
+        const u64* pre = p.pre + (size_t)bz * (((size_t)1 << (p.log_n - p.pre_bits)) + ((size_t)1 << p.pre_bits));
         const u64 s = gl_mul(pre[j >> p.pre_bits], pre[((size_t)1 << (p.log_n - p.pre_bits)) + (j & (((size_t)1 << p.pre_bits) - 1))]);
         v = gl_mul(v, s);
       }

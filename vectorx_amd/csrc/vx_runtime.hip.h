@@ -263,6 +263,11 @@ static hipError_t launch_ntt2_pass(const NttPass& ps, const NttPassParams& p, di
   q.pre = p.pre;
   q.pre_bits = p.pre_bits;
   q.post_scale = p.post_scale;
+  q.nz_fold = 0;
+  if (p.pre && grid.z > 1 && p.in_z_stride == 0 && grid.x % 8 == 0 && !getenv("VX_NTT_NO_ZFOLD")) {  // coset LDE from shared coefficients
+    q.nz_fold = (int)grid.z;
+    grid = dim3(grid.x * grid.z, grid.y, 1);
+  }
   if (ps.b_lo > 0) {
     switch (ps.r_log) {
       case 8: return launch_ntt2_r<8, 4, 0, true>(p, q, grid, s);
