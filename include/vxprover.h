@@ -204,6 +204,12 @@ void vx_circuit_free(vx_circuit* c);
 int vx_circuit_digest(vx_circuit* c, uint64_t digest_out[4]);
 int vx_circuit_constants_sigmas_cap(vx_circuit* c, uint64_t* cap_out /* [2^cap_height][4] */);
 
+/* Constraint programs are compiled to native gfx950 code when the circuit is created (hiprtc; a gate whose program
+ * cannot be compiled — hiprtc missing, VX_NO_JIT=1 — is evaluated by the on-GPU interpreter instead, with identical
+ * results).  Reports how many VX_GATE_PROGRAM gates the circuit has, how many of them were compiled, and why the
+ * others were not (note_out, optional). */
+int vx_circuit_program_gates(vx_circuit* c, int* total_out, int* compiled_out, char* note_out, size_t note_cap);
+
 /* plonky2::plonk::prover::prove_with_partition_witness.  `wires` is the finished witness matrix,
  * column-major [num_wires][2^degree_bits] (Witness.wire_values), host pointer or (wires_on_device)
  * a device pointer from vx_dev_alloc.  pow_witness_hint (optional): use this FRI proof-of-work witness

@@ -100,7 +100,7 @@ def test_ntt_argument_errors(ctx):
 
 @pytest.mark.parametrize("n_leaves,width,cap_h", [(1, 5, 0), (2, 1, 0), (2, 4, 1), (16, 3, 4), (64, 8, 2), (64, 9, 0),
                                                    (256, 135, 4), (1024, 20, 4), (4096, 16, 4), (512, 32, 4),
-                                                   (128, 86, 7)])
+                                                   (128, 86, 7), (65536, 4, 0), (131072, 2, 3), (32768, 9, 4)])
 def test_merkle_matches_oracle(ctx, oracle, n_leaves, width, cap_h):
     rng = np.random.default_rng(n_leaves * 1000 + width)
     leaves = rand_field(rng, (n_leaves, width))

@@ -188,6 +188,39 @@ def test_constraint_program_gates_byte_identical(ctx, oracle, degree_bits, flags
     gc.free()
 
 
+def test_program_gates_are_compiled_to_native_code_and_match_the_interpreter(ctx, oracle):
+    """vx_circuit_create compiles every constraint program with hiprtc (jit.hip.h); VX_NO_JIT=1 keeps the on-GPU
+    interpreter.  Both must give the oracle's proof, byte for byte."""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    sc = SynthCircuit(8, seed=77, poseidon_percent=40, flags=7)
+    sc.desc.pow_bits = 6
+    gc = vx.Circuit(ctx, sc.desc_ptr)
+    total, compiled, note = gc.program_gates()
+    assert total == 5 and compiled == 5, note                       # Arithmetic, ArithmeticExtension, BaseSum, Exponentiation, RandomAccess
+    proof = gc.prove(sc.witness())
+    assert proof == oracle_lib.OracleCircuit(oracle, sc.desc_ptr).prove(sc.witness())
+    gc.free()
+    code = (
+        "import sys, hashlib; sys.path.insert(0, %r)\n"
+        "import vectorx_amd as vx\n"
+        "from vectorx_amd.synth import SynthCircuit\n"
+        "sc = SynthCircuit(8, seed=77, poseidon_percent=40, flags=7); sc.desc.pow_bits = 6\n"
+        "ctx = vx.Context(0); c = vx.Circuit(ctx, sc.desc_ptr)\n"
+        "t, n, note = c.program_gates(); assert (t, n) == (5, 0), (t, n, note)\n"
+        "print('SHA', hashlib.sha256(c.prove(sc.witness())).hexdigest()); c.free(); ctx.close()\n"
+    ) % str(root)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, VX_NO_JIT="1"), cwd=str(root))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    sha = [l for l in r.stdout.splitlines() if l.startswith("SHA ")][-1].split()[1]
+    assert sha == hashlib.sha256(proof).hexdigest()
+
+
 def test_malformed_constraint_programs_are_refused(ctx):
     import ctypes
     sc = SynthCircuit(5, seed=1, poseidon_percent=50, flags=1)
@@ -198,6 +231,9 @@ def test_malformed_constraint_programs_are_refused(ctx):
     with pytest.raises(vx.VxError):
         vx.Circuit(ctx, sc.desc_ptr)
     words[0] = 1 | (0 << 8) | (500 << 16)   # LDW of wire 500
+    with pytest.raises(vx.VxError):
+        vx.Circuit(ctx, sc.desc_ptr)
+    words[0] = 4 | (3 << 8) | (40 << 16) | (41 << 32)   # ADD r3 = r40 + r41: registers never written
     with pytest.raises(vx.VxError):
         vx.Circuit(ctx, sc.desc_ptr)
     words[0] = first

@@ -94,6 +94,7 @@ _SIGNATURES = {
     "vx_circuit_constants_sigmas_cap": (_i, [_vp, _vp]),
     "vx_prove": (_i, [_vp, _vp, _vp, _i, _vp, _vp, ctypes.POINTER(_sz)]),
     "vx_proof_size_bound": (_sz, [_vp]),
+    "vx_circuit_program_gates": (_i, [_vp, ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.c_char_p, _sz]),
     "vx_prove_sharded": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, ctypes.POINTER(_sz)]),
     "vx_group_create": (_i, [_i, ctypes.POINTER(_vp)]),
     "vx_group_destroy": (None, [_vp]),
@@ -404,6 +405,13 @@ class Circuit:
         _chk(lib().vx_prove(self.ctx._h, self._h, src, on_dev, hint.ctypes.data if hint is not None else None,
                             buf.ctypes.data, ctypes.byref(ln)))
         return bytes(buf[:ln.value])
+
+    def program_gates(self):
+        """(number of VX_GATE_PROGRAM gates, how many were compiled to native code, why the others were not)"""
+        total, compiled = _i(), _i()
+        note = ctypes.create_string_buffer(1024)
+        _chk(lib().vx_circuit_program_gates(self._h, ctypes.byref(total), ctypes.byref(compiled), note, 1024))
+        return total.value, compiled.value, note.value.decode(errors="replace")
 
     def prove_sharded(self, wires, rank: int, world: int, allgather, user=None, pow_witness=None, dev_ptr=None) -> bytes:
         """`vx_prove_sharded`: this rank's part of ONE proof split across `world` GPUs by LDE coset; every rank

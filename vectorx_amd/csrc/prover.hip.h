@@ -19,6 +19,8 @@ struct vx_circuit {
   std::vector<int> arity_bits;
   std::vector<int> prog_off;   // per gate: word offset into `programs`, -1 for native gates
   u64* programs = nullptr;     // device copy of the constraint programs
+  std::vector<hipFunction_t> jit_fn;  // per gate: the program compiled to native code (jit.hip.h), or nullptr -> interpreter
+  std::string jit_note;               // why a program gate stayed on the interpreter (diagnostics)
   vx_batch* cs = nullptr;  // constants_sigmas commitment (resident across proofs)
   u64* sigmas = nullptr;   // [nr][n] sigma VALUES on H (natural order) for the permutation argument
   u64* k_is = nullptr;     // device copy
@@ -43,16 +45,21 @@ static int circuit_create(vx_ctx* c, const vx_circuit_desc* d, vx_circuit** out)
     if (t == VX_GATE_PROGRAM) {
       if (!d->programs || !d->program_offsets || d->program_offsets[g] < 0 || d->program_offsets[g] >= d->programs_len)
         return vx_fail(VX_E_INVALID, "circuit: program gate %d has no program", g);
-      // validate: terminated, known opcodes, operands in range
+      // validate: terminated, known opcodes, operands in range, no register read before it is written
       bool ended = false;
+      uint64_t defined = 0;
       for (int pc = d->program_offsets[g]; pc < d->programs_len && !ended; ++pc) {
         const uint64_t ins = d->programs[pc];
-        const int op = (int)(ins & 0xFF), a = (int)((ins >> 16) & 0xFFFF);
+        const int op = (int)(ins & 0xFF), dst = (int)((ins >> 8) & 63), a = (int)((ins >> 16) & 0xFFFF), b = (int)((ins >> 32) & 0xFFFF);
+        auto is_def = [&](int r) { return (defined >> (r & 63)) & 1; };
         if (op == VX_OP_END) ended = true;
         else if (op == VX_OP_LDI) { if (++pc >= d->programs_len) return vx_fail(VX_E_INVALID, "circuit: truncated program"); }
         else if (op == VX_OP_LDW) { if (a >= d->num_wires) return vx_fail(VX_E_INVALID, "circuit: program reads wire %d", a); }
         else if (op == VX_OP_LDC) { if (d->num_selectors + a >= d->num_constants) return vx_fail(VX_E_INVALID, "circuit: program reads constant %d", a); }
+        else if (op == VX_OP_ADD || op == VX_OP_SUB || op == VX_OP_MUL) { if (!is_def(a) || !is_def(b)) return vx_fail(VX_E_INVALID, "circuit: program reads a register before writing it"); }
+        else if (op == VX_OP_PUSH) { if (!is_def(a)) return vx_fail(VX_E_INVALID, "circuit: program pushes a register before writing it"); }
         else if (op < VX_OP_END || op > VX_OP_LDP) return vx_fail(VX_E_INVALID, "circuit: bad opcode %d in a constraint program", op);
+        if (op != VX_OP_END && op != VX_OP_PUSH) defined |= (uint64_t)1 << dst;
       }
       if (!ended) return vx_fail(VX_E_INVALID, "circuit: unterminated constraint program");
     }
@@ -85,6 +92,22 @@ static int circuit_create(vx_ctx* c, const vx_circuit_desc* d, vx_circuit** out)
     if (nprog) {
       if (hipMalloc(&k->programs, (size_t)d->programs_len * 8) != hipSuccess) { delete k; return vx_fail(VX_E_NOMEM, "circuit: out of device memory"); }
       HIPCHK(hipMemcpy(k->programs, d->programs, (size_t)d->programs_len * 8, hipMemcpyHostToDevice));
+    }
+    // compile every program to native code (jit.hip.h); a gate whose program cannot be compiled stays on the interpreter
+    k->jit_fn.assign(d->num_gates, nullptr);
+    const int nterms = d->num_challenges * (1 + (d->num_routed_wires + d->quotient_degree_factor - 1) / d->quotient_degree_factor + 1);
+    for (int g = 0; g < d->num_gates; ++g) {
+      if (k->prog_off[g] < 0) continue;
+      const uint64_t* prog = d->programs + k->prog_off[g];
+      int pushes = 0;
+      for (int pc = 0; (prog[pc] & 0xFF) != VX_OP_END; ++pc) {
+        if ((prog[pc] & 0xFF) == VX_OP_PUSH) ++pushes;
+        if ((prog[pc] & 0xFF) == VX_OP_LDI) ++pc;
+      }
+      std::string why;
+      if (nterms + pushes > VX_ALPHA_POWS) why = "more constraints than the alpha-power table holds";
+      else k->jit_fn[g] = jit_get(prog, d->num_challenges, c->device, &why);
+      if (!k->jit_fn[g]) k->jit_note += "gate " + std::to_string(g) + ": " + why + "; ";
     }
   }
   k->k_is_host.assign(d->k_is, d->k_is + d->num_routed_wires);
@@ -381,6 +404,36 @@ static int prove_impl(vx_ctx* c, vx_circuit* k, const u64* wires_in, bool wires_
       hipLaunchKernelGGL(quotient_kernel, dim3((unsigned)((Nl + 255) / 256)), dim3(256), 0, c->stream, qp);
       HIPCHK(hipGetLastError());
       if (k->programs) {  // gates supplied as constraint programs add their share to the same quotient values
+        const u64 nterms_before = (u64)nch * (1 + nchunks);  // L_0 terms + partial-product checks come first
+        {
+          JitGateParams jp;
+          memset(&jp, 0, sizeof jp);
+          jp.cs = k->cs->lde;
+          jp.wires = wires_b->lde;
+          jp.alpha_pows = qp.alpha_pows;
+          jp.out = qv;
+          jp.N = N;
+          jp.rows = Nl;
+          jp.row_base = row_base;
+          jp.stride_w = Nl;
+          jp.log_n = lg;
+          jp.rate_bits = rb;
+          jp.num_selectors = k->num_selectors;
+          jp.nch = nch;
+          jp.base_idx = (int)nterms_before;
+          for (int i = 0; i < 4; ++i) jp.pih[i] = pih.e[i];
+          for (int r = 0; r < rate; ++r) jp.zh_inv[r] = qp.zh_inv[r];
+          ProfScope psj(c, "quotient_program_gates_jit");
+          for (size_t g = 0; g < k->gates.size(); ++g) {
+            if (k->prog_off[g] < 0 || !k->jit_fn[g]) continue;
+            jp.gate_index = (int)g;
+            jp.selector_index = k->gates[g].selector_index;
+            jp.group_start = k->gates[g].group_start;
+            jp.group_end = k->gates[g].group_end;
+            void* args[] = {&jp};
+            HIPCHK(hipModuleLaunchKernel(k->jit_fn[g], (unsigned)((Nl + 255) / 256), 1, 1, 256, 1, 1, 0, c->stream, args, nullptr));
+          }
+        }
         ProgramParams pg;
         memset(&pg, 0, sizeof pg);
         pg.cs = k->cs->lde;
@@ -395,16 +448,17 @@ static int prove_impl(vx_ctx* c, vx_circuit* k, const u64* wires_in, bool wires_
         pg.num_selectors = k->num_selectors;
         pg.nch = nch;
         for (size_t g = 0; g < k->gates.size(); ++g)
-          if (k->prog_off[g] >= 0)
+          if (k->prog_off[g] >= 0 && !k->jit_fn[g])  // not compiled: interpreter
             pg.gates[pg.num_gates++] = ProgramGateDev{(int)g, k->gates[g].selector_index, k->gates[g].group_start, k->gates[g].group_end, k->prog_off[g]};
-        const u64 nterms = (u64)nch * (1 + nchunks);  // L_0 terms + partial-product checks come first
-        for (int i = 0; i < VX_MAX_CHALLENGES; ++i) pg.alphas[i] = alphas[i], pg.base_pw[i] = pow(alphas[i], nterms);
+        for (int i = 0; i < VX_MAX_CHALLENGES; ++i) pg.alphas[i] = alphas[i], pg.base_pw[i] = pow(alphas[i], nterms_before);
         for (int i = 0; i < 4; ++i) pg.pih[i] = pih.e[i];
         for (int r = 0; r < rate; ++r) pg.zh_inv[r] = qp.zh_inv[r];
         pg.out = qv;
-        ProfScope ps2(c, "quotient_program_gates");
-        hipLaunchKernelGGL(program_gates_kernel, dim3((unsigned)((Nl + 255) / 256)), dim3(256), 0, c->stream, pg);
-        HIPCHK(hipGetLastError());
+        if (pg.num_gates) {
+          ProfScope ps2(c, "quotient_program_gates");
+          hipLaunchKernelGGL(program_gates_kernel, dim3((unsigned)((Nl + 255) / 256)), dim3(256), 0, c->stream, pg);
+          HIPCHK(hipGetLastError());
+        }
       }
     }
     // per-coset inverse NTT (input rows of each block are in bit-reversed order), then the cross-coset

@@ -5,6 +5,8 @@
 #include "batch.hip.h"
 #include <condition_variable>
 #include <mutex>
+#include "plonk_kernels.hip.h"
+#include "jit.hip.h"
 #include "prover.hip.h"
 
 extern "C" {
@@ -487,6 +489,22 @@ int vx_circuit_constants_sigmas_cap(vx_circuit* k, uint64_t* cap_out) {
   return vx_batch_cap(k->cs, cap_out);
 }
 size_t vx_proof_size_bound(vx_circuit* k) { return k ? proof_size_bound(k) : 0; }
+int vx_circuit_program_gates(vx_circuit* k, int* total_out, int* compiled_out, char* note_out, size_t note_cap) {
+  if (!k) return vx_fail(VX_E_INVALID, "vx_circuit_program_gates: NULL argument");
+  int total = 0, compiled = 0;
+  for (size_t g = 0; g < k->prog_off.size(); ++g)
+    if (k->prog_off[g] >= 0) {
+      ++total;
+      compiled += g < k->jit_fn.size() && k->jit_fn[g] != nullptr;
+    }
+  if (total_out) *total_out = total;
+  if (compiled_out) *compiled_out = compiled;
+  if (note_out && note_cap) {
+    strncpy(note_out, k->jit_note.c_str(), note_cap - 1);
+    note_out[note_cap - 1] = 0;
+  }
+  return VX_OK;
+}
 
 int vx_prove(vx_ctx* c, vx_circuit* k, const uint64_t* wires, int wires_on_device, const uint64_t* pow_witness_hint,
              uint8_t* out_buf, size_t* out_len) {

@@ -217,7 +217,7 @@ Prog program_exponentiation(int nb) {
   p.ldi(1, 1);                      // r1 = 1
   p.ins(VX_OP_LDW, 2, 0);           // r2 = base
   for (int i = 0; i < nb; ++i) {
-    if (i == 0) p.ins(VX_OP_ADD, 3, 1, 63), p.ins(VX_OP_SUB, 3, 3, 63);  // r3 = 1 (prev_intermediate for i = 0); r63 is any value
+    if (i == 0) p.ins(VX_OP_MUL, 3, 1, 1);  // r3 = 1 (prev_intermediate for i = 0)
     else {
       p.ins(VX_OP_LDW, 3, 2 + nb + (i - 1));
       p.ins(VX_OP_MUL, 3, 3, 3);    // intermediate[i-1]^2
