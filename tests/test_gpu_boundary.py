@@ -99,3 +99,17 @@ def test_mapreduce_dag_on_one_gpu_matches_the_oracle_dag(ctx, oracle):
         assert g["my_proofs"][k] == o["my_proofs"][k], k
     for p in gp:
         p.free()
+    # the same DAG with 3 jobs of a layer in flight on the GPU (3 contexts / host threads): same proofs
+    lanes = [vx.Context(0), vx.Context(0)]
+    gp2 = []
+
+    def make_lanes(kind, log_n, jobs):
+        p = mr.GpuProver(ctx, kind, log_n, jobs, extra_lanes=lanes)
+        gp2.append(p)
+        return p
+    g2 = mr.run_dag(spec, make_lanes, None, ctx.sync, in_flight=3)
+    assert g2["root"] == o["root"] and g2["my_proofs"] == o["my_proofs"]
+    for p in gp2:
+        p.free()
+    for l in lanes:
+        l.close()

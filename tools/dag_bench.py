@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--map-log-n", type=int, default=18)
     ap.add_argument("--reduce-log-n", type=int, default=16)
     ap.add_argument("--outer-log-n", type=int, default=19)
+    ap.add_argument("--in-flight", type=int, default=1, help="jobs of a layer kept in flight per GPU (contexts / host threads)")
     args = ap.parse_args()
     import torch
     import vectorx_amd as vx
@@ -33,19 +34,22 @@ def main():
     rank, world, local_rank = H.env_rank()
     dist = H.init("nccl", local_rank)
     ctx = vx.Context(local_rank)
+    lanes = [vx.Context(local_rank) for _ in range(args.in_flight - 1)]
     spec = mr.DagSpec(args.num_map, args.map_log_n, args.reduce_log_n, args.outer_log_n)
     provers = []
 
     def make(kind, log_n, jobs):
-        p = mr.GpuProver(ctx, kind, log_n, jobs, spec.poseidon_percent)
+        p = mr.GpuProver(ctx, kind, log_n, jobs, spec.poseidon_percent, extra_lanes=lanes)
         provers.append(p)
         return p
 
     def sync():
         ctx.sync()
+        for l in lanes:
+            l.sync()
         torch.cuda.synchronize()
 
-    res = mr.run_dag(spec, make, dist, sync)
+    res = mr.run_dag(spec, make, dist, sync, in_flight=args.in_flight)
     secs = res["seconds"]
     if dist is not None:
         t = torch.tensor([secs], dtype=torch.float64, device=f"cuda:{local_rank}")
@@ -59,12 +63,15 @@ def main():
             "root": res["root"].hex(),
             "per_layer_ms": [(l["kind"], l["jobs"], round(l["ms"], 1)) for l in res["per_layer"]],
             "config": {"num_map": args.num_map, "map_log_n": args.map_log_n, "reduce_log_n": args.reduce_log_n,
-                       "outer_log_n": args.outer_log_n, "note": "circuit sizes are synthetic stand-ins"}}), flush=True)
+                       "outer_log_n": args.outer_log_n, "in_flight_per_gpu": args.in_flight,
+                       "note": "circuit sizes are synthetic stand-ins"}}), flush=True)
     for p in provers:
         p.free()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    for l in lanes:
+        l.close()
     ctx.close()
 
 

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Experiment: does keeping 2 proofs in flight on one GPU (2 contexts / 2 host threads) raise throughput?"""
+"""Experiment: proofs in flight on one GPU (one context + host thread each) vs throughput, by proof size.
+usage: dev_inflight_bench.py [log_n] [max_in_flight]"""
 import sys
 import threading
 import time
@@ -11,7 +12,8 @@ import vectorx_amd as vx  # noqa: E402
 from vectorx_amd.synth import SynthCircuit  # noqa: E402
 
 log_n = int(sys.argv[1]) if len(sys.argv) > 1 else 21
-K = 6
+max_f = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+K = 24 if log_n <= 18 else 6
 
 
 def setup(seed):
@@ -26,23 +28,21 @@ def setup(seed):
     return ctx, c, d
 
 
-a = setup(1)
-t0 = time.perf_counter()
-for _ in range(K):
-    a[1].prove(dev_ptr=a[2])
-t1 = time.perf_counter() - t0
-print(f"1 in flight: {K / t1:.3f} proofs/s ({t1 / K * 1e3:.1f} ms)")
-b = setup(2)
-
-
 def run(x, k):
     for _ in range(k):
         x[1].prove(dev_ptr=x[2])
 
 
-t0 = time.perf_counter()
-ths = [threading.Thread(target=run, args=(x, K // 2)) for x in (a, b)]
-[t.start() for t in ths]
-[t.join() for t in ths]
-t2 = time.perf_counter() - t0
-print(f"2 in flight: {K / t2:.3f} proofs/s ({t2 / K * 1e3:.1f} ms per proof)")
+slots = []
+f = 1
+while f <= max_f:
+    while len(slots) < f:
+        slots.append(setup(len(slots) + 1))
+    t0 = time.perf_counter()
+    ths = [threading.Thread(target=run, args=(x, K // f)) for x in slots[:f]]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    dt = time.perf_counter() - t0
+    n = (K // f) * f
+    print(f"2^{log_n}: {f} in flight: {n / dt:.2f} proofs/s ({dt / n * 1e3:.2f} ms per proof)", flush=True)
+    f *= 2

@@ -66,9 +66,12 @@ def child_inputs(layer_idx: int, job: int, prev_digests: dict) -> np.ndarray:
     return digest_to_field(hashlib.sha256(prev_digests[2 * job] + prev_digests[2 * job + 1]).digest())
 
 
-def run_dag(spec: DagSpec, make_prover, dist=None, sync=lambda: None):
-    """make_prover(kind, log_n, job_ids) -> object with .prove(job, public_inputs) -> proof bytes, prepared (circuit
-    loaded, per-job witnesses resident) BEFORE the timed region; witness generation is outside the hot path (U9).
+def run_dag(spec: DagSpec, make_prover, dist=None, sync=lambda: None, in_flight: int = 1):
+    """make_prover(kind, log_n, job_ids) -> object with .prove(job, public_inputs[, lane]) -> proof bytes, prepared
+    (circuit loaded, per-job witnesses resident) BEFORE the timed region; witness generation is outside the hot path
+    (U9).  in_flight > 1: this rank keeps that many jobs of a layer in flight on its GPU (host threads, one prover
+    lane = one context/stream each) — the map/reduce proofs are small enough (2^16..2^18 rows) that a single proof
+    leaves the chip partly idle in its latency-bound stages.
     Returns dict(root=<digest of the outer proof>, seconds=<timed DAG wall time>, proofs=<count>, per_layer=[...])."""
     world = dist.get_world_size() if dist is not None else 1
     rank = dist.get_rank() if dist is not None else 0
@@ -93,11 +96,41 @@ def run_dag(spec: DagSpec, make_prover, dist=None, sync=lambda: None):
     for li, (kind, jobs) in enumerate(layers):
         tl = time.perf_counter()
         mine = {}
-        for j in my_jobs[li]:
-            pi = child_inputs(li, j, prev)
-            proof = provers[kind].prove((li, j), pi)
-            mine[j] = hashlib.sha256(proof).digest()
-            all_proofs[(li, j)] = proof
+        if in_flight > 1 and len(my_jobs[li]) > 1:
+            import queue
+            import threading
+            todo = queue.Queue()
+            for j in my_jobs[li]:
+                todo.put(j)
+            errors = []
+
+            def lane_main(lane):
+                while True:
+                    try:
+                        j = todo.get_nowait()
+                    except queue.Empty:
+                        return
+                    try:
+                        proof = provers[kind].prove((li, j), child_inputs(li, j, prev), lane)
+                        mine[j] = hashlib.sha256(proof).digest()
+                        all_proofs[(li, j)] = proof
+                    except BaseException as e:   # surfaces after the join
+                        errors.append(e)
+                        return
+
+            threads = [threading.Thread(target=lane_main, args=(lane,)) for lane in range(min(in_flight, len(my_jobs[li])))]
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+            if errors:
+                raise errors[0]
+        else:
+            for j in my_jobs[li]:
+                pi = child_inputs(li, j, prev)
+                proof = provers[kind].prove((li, j), pi)
+                mine[j] = hashlib.sha256(proof).digest()
+                all_proofs[(li, j)] = proof
         sync()
         if dist is not None:          # layer barrier: all-gather of the digests (32 B per proof)
             gathered = [None] * world
@@ -117,13 +150,20 @@ class GpuProver:
     """One circuit kind on one GPU: circuit loaded once (constants_sigmas resident), one device-resident witness per
     job; `prove` patches the two witness rows that depend on the public inputs and calls vx_prove."""
 
-    def __init__(self, ctx, kind, log_n, jobs, poseidon_percent=50):
+    def __init__(self, ctx, kind, log_n, jobs, poseidon_percent=50, extra_lanes=()):
+        """extra_lanes: more contexts on the SAME GPU; lane k proves on its own stream with its own copy of the circuit
+        (run_dag(in_flight=...)); witnesses are device-global and shared."""
+        import threading
+
         import vectorx_amd as vx
         from vectorx_amd.synth import SynthCircuit
         self.ctx, self.n = ctx, 1 << log_n
+        self.lanes = [ctx] + list(extra_lanes)
+        self._lock = threading.Lock()
         circuit_seed = {"map": 101, "reduce": 202, "outer": 303}[kind]
         self.sc = SynthCircuit(log_n, seed=circuit_seed, poseidon_percent=poseidon_percent, witness_seed=0)
-        self.circuit = vx.Circuit(ctx, self.sc.desc_ptr)
+        self.circuits = [vx.Circuit(c, self.sc.desc_ptr) for c in self.lanes]
+        self.circuit = self.circuits[0]
         self.wit = {}
         for (li, j) in jobs:
             sj = SynthCircuit(log_n, seed=circuit_seed, poseidon_percent=poseidon_percent, witness_seed=1000 * li + j + 1)
@@ -134,15 +174,18 @@ class GpuProver:
             sj.free()
         self.sc.release_host_buffers(witness=True, preprocessed=True)
 
-    def prove(self, key, public_inputs):
+    def prove(self, key, public_inputs, lane=0):
         d = self.wit[key]
-        r0, r2 = self.sc.patch_public_inputs(public_inputs)
-        self.ctx.upload_row(d, self.n, 0, r0)
-        self.ctx.upload_row(d, self.n, 2, r2)
-        return self.circuit.prove(dev_ptr=d)
+        with self._lock:                      # the generator keeps the current public inputs: one caller at a time
+            r0, r2 = self.sc.patch_public_inputs(public_inputs)
+        ctx = self.lanes[lane]
+        ctx.upload_row(d, self.n, 0, r0)
+        ctx.upload_row(d, self.n, 2, r2)
+        return self.circuits[lane].prove(dev_ptr=d)
 
     def free(self):
         for d in self.wit.values():
             self.ctx.free(d)
-        self.circuit.free()
+        for c in self.circuits:
+            c.free()
         self.sc.free()
