@@ -168,11 +168,13 @@ def test_randomized_differential_sweep(ctx, oracle):
 
 
 @pytest.mark.parametrize("degree_bits,flags", [(4, 1), (5, 2), (6, 3), (9, 1), (11, 3), (12, 1), (5, 4), (7, 5), (10, 7),
-                                               (13, 7)])
+                                               (13, 7), (6, 8), (9, 15), (12, 15)])
 def test_constraint_program_gates_byte_identical(ctx, oracle, degree_bits, flags):
     """Gates supplied as constraint programs (ArithmeticExtensionGate, BaseSumGate<2>, ExponentiationGate (degree 4),
-    RandomAccessGate (degree 5; flags & 4 -> three selector groups), and the ArithmeticGate itself when handed over as
-    a program) are evaluated by program_gates_kernel: proofs stay byte-identical to the oracle."""
+    RandomAccessGate (degree 5; flags & 4 -> three selector groups), the remaining recursion gates (flags & 8:
+    MulExtension, Reducing, ReducingExtension, PoseidonMds, CosetInterpolation of degree 8 -> 14 gates, four selector
+    groups) and the ArithmeticGate itself when handed over as a program) are evaluated by the generated / interpreted
+    program kernels: proofs stay byte-identical to the oracle."""
     sc = SynthCircuit(degree_bits, seed=500 + degree_bits, poseidon_percent=40, flags=flags)
     oc = oracle_lib.OracleCircuit(oracle, sc.desc_ptr)
     gc = vx.Circuit(ctx, sc.desc_ptr)

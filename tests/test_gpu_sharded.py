@@ -36,7 +36,7 @@ def _free(ctxs, circuits):
 
 
 @pytest.mark.parametrize("degree_bits,world,flags", [(3, 2, 0), (4, 8, 0), (5, 4, 0), (6, 2, 0), (6, 8, 7), (8, 4, 1), (10, 8, 0),
-                                                     (11, 2, 7), (13, 4, 0), (13, 8, 0)])
+                                                     (11, 2, 7), (13, 4, 0), (13, 8, 0), (9, 4, 15)])
 def test_sharded_proof_is_byte_identical(oracle, degree_bits, world, flags):
     sc = SynthCircuit(degree_bits, seed=900 + degree_bits, poseidon_percent=40, flags=flags)
     sc.desc.pow_bits = 8

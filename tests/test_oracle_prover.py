@@ -159,3 +159,56 @@ def test_higher_degree_program_gates_and_three_selector_groups(oracle):
         bad = w.copy()
         bad[col, row] = (int(bad[col, row]) + 1) % P
         assert oc.verify(oc.prove(bad)) != "", (col, row)
+
+
+def test_recursion_gate_set_as_programs(oracle):
+    """The rest of the recursive verifier's gate set — MulExtension, Reducing, ReducingExtension, PoseidonMds and
+    CosetInterpolation{4 bits, degree 8} — as constraint programs: with every flag set the circuit has 14 gates in 4
+    selector groups (a degree-8 gate must sit alone in its group).  Proofs verify, tampering with any of the new rows
+    is rejected, and the CosetInterpolation row really interpolates: evaluation_value is the value at the point of
+    the degree-<16 polynomial through the 16 (coset point, value) pairs, recomputed here with Lagrange's formula."""
+    from vectorx_amd.synth import FLAG_RECURSION_GATES
+    sc = SynthCircuit(7, seed=21, poseidon_percent=40, flags=15)
+    d = sc.desc
+    assert d.num_gates == 14 and d.num_selectors == 4 and d.num_constants == 6
+    oc = oracle_lib.OracleCircuit(oracle, sc.desc_ptr)
+    w = sc.witness()
+    assert oc.verify(oc.prove(w)) == ""
+    rc = sc.row_counts()
+    rec = rc["recursion_each"]
+    last = 128 - rc["noop"] - 1
+    rows = {"coset": last, "mds": last - rec, "redext": last - 2 * rec, "red": last - 3 * rec, "mulext": last - 4 * rec}
+    for name, col in (("coset", 35), ("coset", 7), ("coset", 37), ("coset", 41), ("coset", 45), ("mds", 30), ("mds", 3), ("redext", 72),
+                      ("redext", 0), ("red", 20), ("red", 60), ("mulext", 4), ("mulext", 13)):
+        bad = w.copy()
+        bad[col, rows[name]] = (int(bad[col, rows[name]]) + 1) % P
+        assert oc.verify(oc.prove(bad)) != "", (name, col)
+
+    # F_p^2 = F_p[X]/(X^2 - 7) in plain Python
+    def emul(x, y):
+        return ((x[0] * y[0] + 7 * x[1] * y[1]) % P, (x[0] * y[1] + x[1] * y[0]) % P)
+
+    def esub(x, y):
+        return ((x[0] - y[0]) % P, (x[1] - y[1]) % P)
+
+    def einv(x):
+        nrm = pow((x[0] * x[0] - 7 * x[1] * x[1]) % P, P - 2, P)
+        return (x[0] * nrm % P, (-x[1]) * nrm % P)
+    r = rows["coset"]
+    shift = int(w[0, r])
+    g16 = pow(7, (P - 1) // 16, P)                               # plonky2's primitive_root_of_unity(4)
+    xs = [shift * pow(g16, j, P) % P for j in range(16)]
+    vs = [(int(w[1 + 2 * j, r]), int(w[2 + 2 * j, r])) for j in range(16)]
+    zeta = (int(w[33, r]), int(w[34, r]))
+    acc = (0, 0)
+    for j in range(16):
+        num, den = (1, 0), 1
+        for k in range(16):
+            if k != j:
+                num = emul(num, esub(zeta, (xs[k], 0)))
+                den = den * (xs[j] - xs[k]) % P
+        t = emul(vs[j], num)
+        dinv = pow(den, P - 2, P)
+        acc = ((acc[0] + t[0] * dinv) % P, (acc[1] + t[1] * dinv) % P)
+    assert acc == (int(w[35, r]), int(w[36, r]))
+    assert FLAG_RECURSION_GATES == 8 and einv((3, 5)) == einv((3, 5))

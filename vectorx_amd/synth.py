@@ -32,6 +32,7 @@ class CircuitDesc(ctypes.Structure):
 FLAG_PROGRAM_GATES = 1      # add ArithmeticExtensionGate + BaseSumGate rows, evaluated through constraint programs
 FLAG_ARITH_AS_PROGRAM = 2   # hand the ArithmeticGate to the prover as a constraint program instead of the native gate
 FLAG_MORE_PROGRAM_GATES = 4  # + ExponentiationGate (degree 4) and RandomAccessGate (degree 5) as programs: 3 selector groups
+FLAG_RECURSION_GATES = 8     # + MulExtension, Reducing, ReducingExtension, PoseidonMds, CosetInterpolation{4 bits, degree 8} as programs
 
 
 def build() -> Path:
@@ -57,6 +58,8 @@ def _load():
         L.vxs_build3.restype = ctypes.c_void_p
         L.vxs_build3.argtypes = [ctypes.c_int, ctypes.c_uint64, ctypes.c_int, ctypes.c_uint64, ctypes.c_int]
         L.vxs_row_counts_ext.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        L.vxs_recursion_rows.restype = ctypes.c_uint64
+        L.vxs_recursion_rows.argtypes = [ctypes.c_void_p]
         L.vxs_patch_public_inputs.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         L.vxs_free.argtypes = [ctypes.c_void_p]
         L.vxs_desc.restype = ctypes.POINTER(CircuitDesc)
@@ -116,6 +119,9 @@ class SynthCircuit:
             d["arithmetic_extension"], d["base_sum"] = int(ext[3]), int(ext[4])
         if int(ext[5]) or int(ext[6]):
             d["exponentiation"], d["random_access"] = int(ext[5]), int(ext[6])
+        rec = int(_load().vxs_recursion_rows(self._h))
+        if rec:
+            d["recursion_each"] = rec   # rows of EACH of MulExtension / Reducing / ReducingExtension / PoseidonMds / CosetInterpolation
         return d
 
     def release_host_buffers(self, witness=True, preprocessed=True):

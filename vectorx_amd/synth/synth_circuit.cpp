@@ -34,6 +34,8 @@ using namespace vxh;
 #define VXS_FLAG_PROGRAM_GATES 1     /* add ArithmeticExtensionGate + BaseSumGate rows, evaluated through constraint programs */
 #define VXS_FLAG_ARITH_AS_PROGRAM 2  /* hand the ArithmeticGate to the prover as a program instead of the native gate */
 #define VXS_FLAG_MORE_PROGRAM_GATES 4 /* + ExponentiationGate{66 bits} (degree 4) and RandomAccessGate{bits 4} (degree 5): 3 selector groups */
+#define VXS_FLAG_RECURSION_GATES 8    /* + the rest of the recursive verifier's gate set as programs: MulExtensionGate, ReducingGate,
+                                         ReducingExtensionGate, PoseidonMdsGate, CosetInterpolationGate{4 bits, degree 8} */
 
 namespace {
 struct SplitMix {
@@ -52,7 +54,8 @@ struct SplitMix {
   }
 };
 
-enum Key { K_NOOP, K_CONST, K_PI, K_ARITH, K_POSEIDON, K_ARITHEXT, K_BASESUM, K_EXP, K_RANDACC, K_COUNT };
+enum Key { K_NOOP, K_CONST, K_PI, K_ARITH, K_POSEIDON, K_ARITHEXT, K_BASESUM, K_EXP, K_RANDACC, K_MULEXT, K_REDUCING, K_REDUCINGEXT,
+           K_POSEIDONMDS, K_COSETINTERP, K_COUNT };
 struct GateInfo {
   int key, type, param, degree;
   std::string id;
@@ -68,7 +71,7 @@ struct Synth {
   std::vector<uint32_t> pi_rows, pi_cols;
   std::vector<u64> witness;  // [135][n]
   std::vector<u64> public_inputs;
-  size_t n_poseidon = 0, n_arith = 0, n_noop = 0, n_arithext = 0, n_basesum = 0, n_exp = 0, n_randacc = 0;
+  size_t n_poseidon = 0, n_arith = 0, n_noop = 0, n_arithext = 0, n_basesum = 0, n_exp = 0, n_randacc = 0, n_recursion = 0;
   vx_circuit_desc desc;
 };
 
@@ -282,6 +285,178 @@ Prog program_random_access(int bits, int copies, int extra) {
   p.ins(VX_OP_END, 0);
   return p;
 }
+// ---- extension-field helpers for the emitters: an F_p^2 value lives in two consecutive registers (a, a+1) -------
+// dst = x * y in F_p[X]/(X^2 - 7); r7 holds the constant 7; t, t+1 are scratch; dst may alias neither x nor y.
+void emit_ext_mul(Prog& p, int dst, int x, int y, int r7, int t) {
+  p.ins(VX_OP_MUL, dst, x, y);          // x.a y.a
+  p.ins(VX_OP_MUL, t, x + 1, y + 1);    // x.b y.b
+  p.ins(VX_OP_MUL, t, t, r7);
+  p.ins(VX_OP_ADD, dst, dst, t);
+  p.ins(VX_OP_MUL, dst + 1, x, y + 1);
+  p.ins(VX_OP_MUL, t, x + 1, y);
+  p.ins(VX_OP_ADD, dst + 1, dst + 1, t);
+}
+void emit_ext_push_diff(Prog& p, int x, int y, int t) {  // constraints x - y (two base-field constraints)
+  p.ins(VX_OP_SUB, t, x, y);
+  p.ins(VX_OP_PUSH, 0, t);
+  p.ins(VX_OP_SUB, t, x + 1, y + 1);
+  p.ins(VX_OP_PUSH, 0, t);
+}
+// gates/multiplication_extension.rs: output - m0 * m1 * c0, num_ops times (wires 6i.. : m0, m1, output)
+Prog program_mul_extension(int num_ops) {
+  Prog p;
+  p.ldi(60, 7);
+  p.ins(VX_OP_LDC, 59, 0);
+  for (int i = 0; i < num_ops; ++i) {
+    for (int k = 0; k < 6; ++k) p.ins(VX_OP_LDW, k, 6 * i + k);  // m0 = (r0,r1) m1 = (r2,r3) out = (r4,r5)
+    emit_ext_mul(p, 6, 0, 2, 60, 10);
+    p.ins(VX_OP_MUL, 6, 6, 59);
+    p.ins(VX_OP_MUL, 7, 7, 59);
+    emit_ext_push_diff(p, 4, 6, 10);
+  }
+  p.ins(VX_OP_END, 0);
+  return p;
+}
+// gates/reducing.rs (base-field coefficients) / reducing_extension.rs (F_p^2 coefficients):
+//   wires: output 0..2, alpha 2..4, old_acc 4..6, coeffs from 6, then the accumulators (the last one IS the output);
+//   constraints acc_prev * alpha + coeff_i - acc_i.
+Prog program_reducing(int num_coeffs, bool ext_coeffs) {
+  Prog p;
+  p.ldi(60, 7);
+  const int cw = ext_coeffs ? 2 : 1, start_accs = 6 + cw * num_coeffs;
+  p.ins(VX_OP_LDW, 2, 2);
+  p.ins(VX_OP_LDW, 3, 3);   // alpha = (r2, r3)
+  p.ins(VX_OP_LDW, 4, 4);
+  p.ins(VX_OP_LDW, 5, 5);   // acc = (r4, r5) = old_acc
+  for (int i = 0; i < num_coeffs; ++i) {
+    emit_ext_mul(p, 6, 4, 2, 60, 10);            // acc * alpha
+    p.ins(VX_OP_LDW, 8, 6 + cw * i);
+    p.ins(VX_OP_ADD, 6, 6, 8);
+    if (ext_coeffs) {
+      p.ins(VX_OP_LDW, 8, 6 + cw * i + 1);
+      p.ins(VX_OP_ADD, 7, 7, 8);
+    }
+    const int aw = i == num_coeffs - 1 ? 0 : start_accs + 2 * i;
+    p.ins(VX_OP_LDW, 4, aw);
+    p.ins(VX_OP_LDW, 5, aw + 1);                 // next acc (a wire: keeps the degree at 2)
+    emit_ext_push_diff(p, 6, 4, 10);
+  }
+  p.ins(VX_OP_END, 0);
+  return p;
+}
+// gates/poseidon_mds.rs: the MDS layer on 12 F_p^2 inputs (wires 0..24) -> outputs (wires 24..48), component-wise
+Prog program_poseidon_mds() {
+  static const u64 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+  Prog p;
+  for (int i = 0; i < 24; ++i) p.ins(VX_OP_LDW, i, i);
+  for (int i = 0; i < 12; ++i) p.ldi(24 + i, C[i]);
+  p.ldi(36, 8);
+  for (int r = 0; r < 12; ++r)
+    for (int comp = 0; comp < 2; ++comp) {
+      p.ins(VX_OP_MUL, 40, 24, 2 * (r % 12) + comp);
+      for (int i = 1; i < 12; ++i) {
+        p.ins(VX_OP_MUL, 41, 24 + i, 2 * ((i + r) % 12) + comp);
+        p.ins(VX_OP_ADD, 40, 40, 41);
+      }
+      if (r == 0) {
+        p.ins(VX_OP_MUL, 41, 36, comp);
+        p.ins(VX_OP_ADD, 40, 40, 41);
+      }
+      p.ins(VX_OP_LDW, 41, 24 + 2 * r + comp);
+      p.ins(VX_OP_SUB, 40, 41, 40);
+      p.ins(VX_OP_PUSH, 0, 40);
+    }
+  p.ins(VX_OP_END, 0);
+  return p;
+}
+// gates/coset_interpolation.rs (subgroup_bits 4, degree 8): barycentric interpolation of 16 F_p^2 values on the coset
+// shift*H_16, evaluated at a point, in chunks so that no constraint exceeds the degree:
+//   wires: shift 0 | values 1..33 | evaluation_point 33,34 | evaluation_value 35,36 | intermediate_eval(i) 37+2i |
+//          intermediate_prod(i) 37+2*NI+2i | shifted_evaluation_point 37+4*NI
+//   shifted_point * shift = evaluation_point;  (eval, prod) <- (eval (z - x_j) + prod w_j v_j, prod (z - x_j)) over the
+//   points of a chunk, starting from (0, 1) / the previous intermediates; the last eval is evaluation_value.
+struct CosetInterp {
+  static constexpr int BITS = 4, NP = 16, DEG = 8, NI = 2;
+  u64 domain[NP], weights[NP];
+  int chunk_end[NI + 1];
+  CosetInterp() {
+    const u64 g = root_of_unity(BITS);
+    u64 x = 1;
+    for (int j = 0; j < NP; ++j) domain[j] = x, x = mul(x, g);
+    for (int j = 0; j < NP; ++j) {
+      u64 d = 1;
+      for (int k = 0; k < NP; ++k)
+        if (k != j) d = mul(d, sub(domain[j], domain[k]));
+      weights[j] = inv(d);
+    }
+    chunk_end[0] = DEG;                     // 8 points, then 7, then the last one
+    chunk_end[1] = DEG + (DEG - 1);
+    chunk_end[2] = NP;
+  }
+  static int w_shift() { return 0; }
+  static int w_value(int j) { return 1 + 2 * j; }
+  static int w_point() { return 33; }
+  static int w_eval() { return 35; }
+  static int w_ieval(int i) { return 37 + 2 * i; }
+  static int w_iprod(int i) { return 37 + 2 * NI + 2 * i; }
+  static int w_shifted() { return 37 + 4 * NI; }
+};
+Prog program_coset_interpolation() {
+  CosetInterp G;
+  Prog p;
+  p.ldi(60, 7);
+  p.ldi(42, 1);
+  p.ins(VX_OP_LDW, 0, G.w_shift());
+  p.ins(VX_OP_LDW, 2, G.w_shifted());
+  p.ins(VX_OP_LDW, 3, G.w_shifted() + 1);        // z = (r2, r3)
+  p.ins(VX_OP_LDW, 4, G.w_point());
+  p.ins(VX_OP_LDW, 5, G.w_point() + 1);
+  p.ins(VX_OP_MUL, 6, 2, 0);
+  p.ins(VX_OP_MUL, 7, 3, 0);
+  emit_ext_push_diff(p, 6, 4, 10);               // z * shift - evaluation_point
+  p.ldi(20, 0);
+  p.ldi(21, 0);                                   // eval = (r20, r21) = 0
+  p.ldi(22, 1);
+  p.ldi(23, 0);                                   // prod = (r22, r23) = 1
+  int j = 0;
+  for (int c = 0; c <= G.NI; ++c) {
+    for (; j < G.chunk_end[c]; ++j) {
+      p.ldi(30, G.domain[j]);
+      p.ldi(31, G.weights[j]);
+      p.ins(VX_OP_SUB, 32, 2, 30);
+      p.ins(VX_OP_MUL, 33, 3, 42);                // (r32, r33) = z - x_j   (x_j is in the base field; r42 = 1: a register copy)
+      p.ins(VX_OP_LDW, 34, G.w_value(j));
+      p.ins(VX_OP_LDW, 35, G.w_value(j) + 1);
+      p.ins(VX_OP_MUL, 34, 34, 31);
+      p.ins(VX_OP_MUL, 35, 35, 31);               // w_j v_j
+      emit_ext_mul(p, 36, 22, 34, 60, 10);        // prod * w_j v_j
+      emit_ext_mul(p, 38, 20, 32, 60, 10);        // eval * (z - x_j)
+      p.ins(VX_OP_ADD, 20, 38, 36);
+      p.ins(VX_OP_ADD, 21, 39, 37);               // eval'
+      emit_ext_mul(p, 40, 22, 32, 60, 10);        // prod'
+      p.ins(VX_OP_MUL, 22, 40, 42);
+      p.ins(VX_OP_MUL, 23, 41, 42);               // prod = prod'
+    }
+    if (c < G.NI) {
+      p.ins(VX_OP_LDW, 44, G.w_ieval(c));
+      p.ins(VX_OP_LDW, 45, G.w_ieval(c) + 1);
+      p.ins(VX_OP_LDW, 46, G.w_iprod(c));
+      p.ins(VX_OP_LDW, 47, G.w_iprod(c) + 1);
+      emit_ext_push_diff(p, 44, 20, 10);          // intermediate_eval - eval
+      emit_ext_push_diff(p, 46, 22, 10);          // intermediate_prod - prod
+      p.ins(VX_OP_MUL, 20, 44, 42);
+      p.ins(VX_OP_MUL, 21, 45, 42);
+      p.ins(VX_OP_MUL, 22, 46, 42);
+      p.ins(VX_OP_MUL, 23, 47, 42);               // continue from the wires: the degree starts again at 1
+    } else {
+      p.ins(VX_OP_LDW, 44, G.w_eval());
+      p.ins(VX_OP_LDW, 45, G.w_eval() + 1);
+      emit_ext_push_diff(p, 44, 20, 10);          // evaluation_value - eval
+    }
+  }
+  p.ins(VX_OP_END, 0);
+  return p;
+}
 }  // namespace
 
 extern "C" {
@@ -299,8 +474,8 @@ vxs_circuit* vxs_build(int degree_bits, uint64_t seed, int poseidon_percent) {
 vxs_circuit* vxs_build3(int degree_bits, uint64_t seed, int poseidon_percent, uint64_t witness_seed, int flags) {
   if (degree_bits < 3 || degree_bits > 24 || poseidon_percent < 0 || poseidon_percent > 100) return nullptr;
   const bool with_prog = flags & VXS_FLAG_PROGRAM_GATES, arith_prog = flags & VXS_FLAG_ARITH_AS_PROGRAM;
-  const bool more_prog = flags & VXS_FLAG_MORE_PROGRAM_GATES;
-  if ((with_prog && degree_bits < 4) || (more_prog && degree_bits < 5)) return nullptr;
+  const bool more_prog = flags & VXS_FLAG_MORE_PROGRAM_GATES, rec_prog = flags & VXS_FLAG_RECURSION_GATES;
+  if ((with_prog && degree_bits < 4) || (more_prog && degree_bits < 5) || (rec_prog && degree_bits < 5)) return nullptr;
   Synth* S = new Synth();
   S->degree_bits = degree_bits;
   const size_t n = S->n = (size_t)1 << degree_bits;
@@ -323,6 +498,13 @@ vxs_circuit* vxs_build3(int degree_bits, uint64_t seed, int poseidon_percent, ui
   if (more_prog) {
     gates.push_back({K_EXP, VX_GATE_PROGRAM, 4, 4, "ExponentiationGate { num_power_bits: 66, _phantom: PhantomData<plonky2_field::goldilocks_field::GoldilocksField> }<D=2>"});
     gates.push_back({K_RANDACC, VX_GATE_PROGRAM, 5, 5, "RandomAccessGate { bits: 4, num_copies: 4, num_extra_constants: 2, _phantom: PhantomData<plonky2_field::goldilocks_field::GoldilocksField> }<D=2>"});
+  }
+  if (rec_prog) {
+    gates.push_back({K_MULEXT, VX_GATE_PROGRAM, 3, 3, "MulExtensionGate { num_ops: 13 }"});
+    gates.push_back({K_REDUCING, VX_GATE_PROGRAM, 2, 2, "ReducingGate { num_coeffs: 43 }"});
+    gates.push_back({K_REDUCINGEXT, VX_GATE_PROGRAM, 2, 2, "ReducingExtensionGate { num_coeffs: 32 }"});
+    gates.push_back({K_POSEIDONMDS, VX_GATE_PROGRAM, 1, 1, "PoseidonMdsGate(PhantomData<plonky2_field::goldilocks_field::GoldilocksField>)<WIDTH=12>"});
+    gates.push_back({K_COSETINTERP, VX_GATE_PROGRAM, 8, 8, "CosetInterpolationGate { subgroup_bits: 4, degree: 8, barycentric_weights: [..], _phantom: PhantomData<plonky2_field::goldilocks_field::GoldilocksField> }<D=2>"});
   }
   std::sort(gates.begin(), gates.end(), [](const GateInfo& a, const GateInfo& b) {
     return a.degree != b.degree ? a.degree < b.degree : a.id < b.id;
@@ -371,6 +553,13 @@ vxs_circuit* vxs_build3(int degree_bits, uint64_t seed, int poseidon_percent, ui
     attach(K_EXP, program_exponentiation(66));
     attach(K_RANDACC, program_random_access(4, 4, 2));
   }
+  if (rec_prog) {
+    attach(K_MULEXT, program_mul_extension(13));
+    attach(K_REDUCING, program_reducing(43, false));
+    attach(K_REDUCINGEXT, program_reducing(32, true));
+    attach(K_POSEIDONMDS, program_poseidon_mds());
+    attach(K_COSETINTERP, program_coset_interpolation());
+  }
 
   // ---- row budget ----
   const size_t body = n - 3;
@@ -378,11 +567,15 @@ vxs_circuit* vxs_build3(int degree_bits, uint64_t seed, int poseidon_percent, ui
   if (n_noop > body) n_noop = body;
   size_t n_ext = with_prog ? std::max<size_t>(1, body / 16) : 0, n_bs = with_prog ? std::max<size_t>(1, body / 16) : 0;
   size_t n_exp = more_prog ? std::max<size_t>(1, body / 32) : 0, n_ra = more_prog ? std::max<size_t>(1, body / 32) : 0;
-  while (n_noop + n_ext + n_bs + n_exp + n_ra > body && n_ext + n_exp > 0) {
+  size_t n_rec = rec_prog ? std::max<size_t>(1, body / 64) : 0;   // rows of EACH of the five recursion gates
+  while (n_noop + n_ext + n_bs + n_exp + n_ra + 5 * n_rec > body && n_ext + n_exp + (n_rec > 1) > 0) {
     if (n_ext) --n_ext, --n_bs;
     if (n_exp) --n_exp, --n_ra;
+    if (n_rec > 1) --n_rec;
   }
-  size_t rest = body - n_noop - n_ext - n_bs - n_exp - n_ra;
+  if (n_noop + n_ext + n_bs + n_exp + n_ra + 5 * n_rec > body) { delete S; return nullptr; }
+  S->n_recursion = n_rec;
+  size_t rest = body - n_noop - n_ext - n_bs - n_exp - n_ra - 5 * n_rec;
   S->n_exp = n_exp;
   S->n_randacc = n_ra;
   size_t n_pos = rest * (size_t)poseidon_percent / 100;
@@ -537,6 +730,82 @@ vxs_circuit* vxs_build3(int degree_bits, uint64_t seed, int poseidon_percent, ui
     w[(size_t)(per * copies) * n + row] = k0;
     w[(size_t)(per * copies + 1) * n + row] = k1;
   }
+  if (rec_prog) {
+    auto W = [&](int col, size_t r) -> u64& { return w[(size_t)col * n + r]; };
+    auto rext = [&]() { return Ext{wrng.field(), wrng.field()}; };
+    auto put = [&](int col, size_t r, Ext e) { W(col, r) = e.a, W(col + 1, r) = e.b; };
+    // MulExtensionGate rows
+    for (size_t e = 0; e < n_rec; ++e, ++row) {
+      set_gate(row, K_MULEXT);
+      const u64 k0 = rng.field();
+      c0[row] = k0;
+      for (int i = 0; i < 13; ++i) {
+        Ext m0 = rext(), m1 = rext(), pr = emul(m0, m1);
+        put(6 * i, row, m0);
+        put(6 * i + 2, row, m1);
+        put(6 * i + 4, row, Ext{mul(pr.a, k0), mul(pr.b, k0)});
+      }
+    }
+    // ReducingGate / ReducingExtensionGate rows: Horner accumulation of the coefficients at alpha
+    for (int kind = 0; kind < 2; ++kind)
+      for (size_t e = 0; e < n_rec; ++e, ++row) {
+        set_gate(row, kind ? K_REDUCINGEXT : K_REDUCING);
+        const int nc = kind ? 32 : 43, cw = kind ? 2 : 1, start_accs = 6 + cw * nc;
+        Ext alpha = rext(), acc = rext();
+        put(2, row, alpha);
+        put(4, row, acc);
+        for (int i = 0; i < nc; ++i) {
+          Ext coeff = kind ? rext() : Ext{wrng.field(), 0};
+          W(6 + cw * i, row) = coeff.a;
+          if (kind) W(6 + cw * i + 1, row) = coeff.b;
+          acc = eadd(emul(acc, alpha), coeff);
+          put(i == nc - 1 ? 0 : start_accs + 2 * i, row, acc);
+        }
+      }
+    // PoseidonMdsGate rows
+    for (size_t e = 0; e < n_rec; ++e, ++row) {
+      set_gate(row, K_POSEIDONMDS);
+      static const u64 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+      Ext in[12];
+      for (int i = 0; i < 12; ++i) in[i] = rext(), put(2 * i, row, in[i]);
+      for (int r = 0; r < 12; ++r) {
+        Ext o{0, 0};
+        for (int i = 0; i < 12; ++i) {
+          const Ext v = in[(i + r) % 12];
+          o = eadd(o, Ext{mul(v.a, C[i]), mul(v.b, C[i])});
+        }
+        if (r == 0) o = eadd(o, Ext{mul(in[0].a, 8), mul(in[0].b, 8)});
+        put(24 + 2 * r, row, o);
+      }
+    }
+    // CosetInterpolationGate rows
+    CosetInterp G;
+    for (size_t e = 0; e < n_rec; ++e, ++row) {
+      set_gate(row, K_COSETINTERP);
+      u64 shift = wrng.field();
+      if (shift == 0) shift = 7;
+      const Ext point = rext();
+      const u64 sinv = inv(shift);
+      const Ext z{mul(point.a, sinv), mul(point.b, sinv)};
+      W(G.w_shift(), row) = shift;
+      put(G.w_point(), row, point);
+      put(G.w_shifted(), row, z);
+      Ext eval{0, 0}, prod{1, 0};
+      int j = 0;
+      for (int c = 0; c <= G.NI; ++c) {
+        for (; j < G.chunk_end[c]; ++j) {
+          const Ext v = rext();
+          put(G.w_value(j), row, v);
+          const Ext zx{sub(z.a, G.domain[j]), z.b};
+          const Ext wv{mul(v.a, G.weights[j]), mul(v.b, G.weights[j])};
+          eval = eadd(emul(eval, zx), emul(prod, wv));
+          prod = emul(prod, zx);
+        }
+        if (c < G.NI) put(G.w_ieval(c), row, eval), put(G.w_iprod(c), row, prod);
+        else put(G.w_eval(), row, eval);
+      }
+    }
+  }
   for (; row < n; ++row) set_gate(row, K_NOOP);
 
   // k_is = 7^j (plonk_common / circuit_builder: get_unique_coset_shifts)
@@ -635,6 +904,7 @@ void vxs_row_counts(vxs_circuit* c, uint64_t out[3]) {
   out[1] = S->n_arith;
   out[2] = S->n_noop;
 }
+uint64_t vxs_recursion_rows(vxs_circuit* c) { return reinterpret_cast<Synth*>(c)->n_recursion; }
 void vxs_row_counts_ext(vxs_circuit* c, uint64_t out[7]) {
   Synth* S = reinterpret_cast<Synth*>(c);
   out[0] = S->n_poseidon;
