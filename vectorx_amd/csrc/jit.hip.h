@@ -6,11 +6,13 @@
 // more than the whole native quotient kernel.  So vx_circuit_create turns every program into HIP source — the same
 // field primitives (goldilocks.hip.h, embedded at build time as jit_prelude.inc), one line per instruction, virtual
 // registers as a local array with constant indices that the compiler promotes to VGPRs — compiles it with hiprtc for
-// gfx950 and loads it as a code-object module; prove() then launches one such kernel per program gate.  Everything
-// that differs between circuits using the same gate (selector column, group range, position of the gate's constraints
-// in the alpha-power table, ...) is a RUNTIME argument, so a program is compiled once per process, whatever circuit it
-// appears in.  hiprtc is reached through dlopen: when it is missing, or VX_NO_JIT=1, or a compile fails, the gate
-// stays on the interpreter — still on the GPU, same values (tests/test_gpu_prover.py compares the two paths).
+// gfx950 and loads it as a code-object module.  ALL program gates of a circuit go into ONE kernel, one block of code
+// per gate: evaluated gate by gate in separate launches the kernels are bound by re-reading the wire columns from HBM
+// (each gate touches 60-130 of the 135 columns), fused they share one pass over the row.  Everything that differs
+// between circuits using the same gate set (selector columns, group ranges, position of the constraints in the
+// alpha-power table, ...) is a RUNTIME argument, so a gate set is compiled once per process.  hiprtc is reached
+// through dlopen: when it is missing, or VX_NO_JIT=1, or the compile fails, the gates stay on the interpreter —
+// still on the GPU, same values (tests/test_gpu_prover.py compares the two paths).
 #pragma once
 #include <dlfcn.h>
 #include <hip/hiprtc.h>
@@ -20,15 +22,19 @@
 #include <string>
 #include <vector>
 
-struct JitGateParams {  // mirrored textually in jit_source_header()
+struct JitGateRt {
+  int gate_index, selector_index, group_start, group_end;
+};
+struct JitGateParams {  // mirrored textually in jit_source()
   const u64 *cs, *wires;
   const u64* alpha_pows;
   u64* out;
   size_t N, rows, row_base, stride_w;
   int log_n, rate_bits, num_selectors, nch;
-  int gate_index, selector_index, group_start, group_end, base_idx, pad;
+  int base_idx, ngates;
   u64 pih[4];
   u64 zh_inv[VX_MAX_RATE];
+  JitGateRt g[VX_MAX_PROGRAM_GATES];
 };
 
 static const char* JIT_PRELUDE =
@@ -70,21 +76,138 @@ static JitApi& jit_api() {
   return api;
 }
 
-// HIP source of one program (the words up to and including VX_OP_END; already validated by circuit_create).
-static std::string jit_source(const uint64_t* prog, int nch) {
+// HIP source of one gate's block (the words up to and including VX_OP_END; already validated by circuit_create).
+static void jit_gate_block(std::ostringstream& s, const uint64_t* prog, int nch, int slot) {
+  s << "  {  // program gate, slot " << slot << "\n"
+       "    const JitGateRt G = p.g[" << slot << "];\n"
+       "    const u64 s = CS[(size_t)G.selector_index * N + i];\n"
+       "    u64 filter = 1;\n"
+       "    for (int q = G.group_start; q < G.group_end; ++q)\n"
+       "      if (q != G.gate_index) filter = gl_mul(filter, gl_sub((u64)q, s));\n"
+       "    if (nsel > 1) filter = gl_mul(filter, gl_sub(0xFFFFFFFFULL, s));\n"
+       "    u64 a0 = 0, a1 = 0;\n"
+       "    u64 R[64];\n";
+  // ---- decode, then two straight-line optimisations before emitting ----------------------------------------
+  //  (1) multiply-add fusion: a MUL whose result is read exactly once, by an ADD, becomes one gl_mad at the ADD
+  //      (the F_p^2 products the emitters produce are chains of exactly this shape);
+  //  (2) lazy canonicalisation: products stay arbitrary u64 representatives (gl_mul_nc / gl_mad_nc accept and return
+  //      them, PUSH accepts them); a register is canonicalised only when an ADD / SUB is about to read it.
+  struct Ins { int op, dst, a, b; uint64_t imm; bool skip; int fa, fb; };  // fa/fb: multiplicands folded into an ADD
+  std::vector<Ins> code;
+  for (int pc = 0;; ++pc) {
+    const uint64_t ins = prog[pc];
+    Ins I{(int)(ins & 0xFF), (int)((ins >> 8) & 63), (int)((ins >> 16) & 0xFFFF), (int)((ins >> 32) & 0xFFFF), 0, false, -1, -1};
+    if (I.op == VX_OP_END) break;
+    if (I.op == VX_OP_LDI) I.imm = vxh::canon(prog[++pc]);
+    if (I.op == VX_OP_ADD || I.op == VX_OP_SUB || I.op == VX_OP_MUL) I.a &= 63, I.b &= 63;
+    if (I.op == VX_OP_PUSH) I.a &= 63;
+    code.push_back(I);
+  }
+  auto reads = [](const Ins& I, int r) {
+    if (I.op == VX_OP_ADD || I.op == VX_OP_SUB || I.op == VX_OP_MUL) return (I.a == r) + (I.b == r);
+    if (I.op == VX_OP_PUSH) return (int)(I.a == r);
+    return 0;
+  };
+  auto writes = [](const Ins& I, int r) { return I.op != VX_OP_PUSH && I.dst == r; };
+  for (size_t i = 0; i < code.size(); ++i) {
+    if (code[i].op != VX_OP_MUL) continue;
+    const int d = code[i].dst, ma = code[i].a, mb = code[i].b;
+    if (ma == d || mb == d) continue;  // the product overwrites one of its own factors: cannot be re-materialised later
+    // the product must be read exactly once before d is overwritten (or the program ends), by an ADD, with the
+    // multiplicands untouched in between
+    int uses = 0;
+    size_t use_at = 0;
+    bool operands_live = true, ok = true;
+    for (size_t j = i + 1; j < code.size(); ++j) {
+      const int rd = reads(code[j], d);
+      if (rd) {
+        uses += rd;
+        if (uses == 1) {
+          use_at = j;
+          ok = operands_live && code[j].op == VX_OP_ADD && code[j].fa < 0 && code[j].a != code[j].b;
+        }
+      }
+      if (writes(code[j], d)) break;
+      if (writes(code[j], ma) || writes(code[j], mb)) operands_live = false;
+    }
+    if (uses != 1 || !ok) continue;
+    Ins& A = code[use_at];
+    const int other = A.a == d ? A.b : A.a;
+    A.fa = ma, A.fb = mb;
+    A.a = other;  // the addend
+    code[i].skip = true;
+  }
+  bool canon_reg[64];
+  for (bool& c : canon_reg) c = true;
+  auto need_canon = [&](int r) {
+    if (!canon_reg[r]) {
+      s << "  R[" << r << "] = gl_canon(R[" << r << "]);\n";
+      canon_reg[r] = true;
+    }
+  };
+  int k = 0;
+  for (const Ins& I : code) {
+    if (I.skip) continue;
+    switch (I.op) {
+      case VX_OP_LDW: s << "  R[" << I.dst << "] = gl_canon(W[(size_t)" << I.a << " * SW + il]);\n"; canon_reg[I.dst] = true; break;
+      case VX_OP_LDC: s << "  R[" << I.dst << "] = CS[(size_t)(nsel + " << I.a << ") * N + i];\n"; canon_reg[I.dst] = true; break;
+      case VX_OP_LDI: s << "  R[" << I.dst << "] = " << I.imm << "ULL;\n"; canon_reg[I.dst] = true; break;
+      case VX_OP_ADD:
+        if (I.fa >= 0) {  // fused multiply-add: any representatives in, one out
+          s << "  R[" << I.dst << "] = gl_mad_nc(R[" << I.fa << "], R[" << I.fb << "], R[" << I.a << "]);\n";
+          canon_reg[I.dst] = false;
+        } else {
+          need_canon(I.a);
+          need_canon(I.b);
+          s << "  R[" << I.dst << "] = gl_add(R[" << I.a << "], R[" << I.b << "]);\n";
+          canon_reg[I.dst] = true;
+        }
+        break;
+      case VX_OP_SUB:
+        need_canon(I.a);
+        need_canon(I.b);
+        s << "  R[" << I.dst << "] = gl_sub(R[" << I.a << "], R[" << I.b << "]);\n";
+        canon_reg[I.dst] = true;
+        break;
+      case VX_OP_MUL: s << "  R[" << I.dst << "] = gl_mul_nc(R[" << I.a << "], R[" << I.b << "]);\n"; canon_reg[I.dst] = false; break;
+      case VX_OP_PUSH:
+        s << "  a0 = gl_mad(R[" << I.a << "], AP[" << k << "], a0);\n";
+        if (nch > 1) s << "  a1 = gl_mad(R[" << I.a << "], AP[" << (VX_ALPHA_POWS + k) << "], a1);\n";
+        ++k;
+        break;
+      case VX_OP_LDP: s << "  R[" << I.dst << "] = p.pih[" << (I.a & 3) << "];\n"; canon_reg[I.dst] = true; break;
+      default: break;
+    }
+  }
+  s << "    t0 = gl_mad(filter, a0, t0);\n";
+  if (nch > 1) s << "    t1 = gl_mad(filter, a1, t1);\n";
+  s << "  }\n";
+}
+
+// HIP source of the kernel that evaluates all program gates of a circuit.
+static std::string jit_source(const std::vector<const uint64_t*>& progs, int nch) {
   std::ostringstream s;
-  s << "typedef unsigned long long uint64_t;\ntypedef unsigned int uint32_t;\n" << JIT_PRELUDE << R"VXJIT(
+  // Occupancy bound: without one the compiler keeps every wire it has loaded live across the gate blocks, takes >256
+  // VGPRs and runs one wave per SIMD (measured: 15.9 ms for 1947 program words at n = 2^20); 4 blocks per CU (<= 128
+  // VGPRs, like the native quotient kernel) gives 6.7 ms.
+  const char* bpc = getenv("VX_JIT_BLOCKS_PER_CU");
+  s << "typedef unsigned long long uint64_t;\ntypedef unsigned int uint32_t;\n#define VX_JIT_BLOCKS_PER_CU " << (bpc ? atoi(bpc) : 4) << "\n"
+    << JIT_PRELUDE << R"VXJIT(
+struct JitGateRt {
+  int gate_index, selector_index, group_start, group_end;
+};
 struct JitGateParams {
   const u64 *cs, *wires;
   const u64* alpha_pows;
   u64* out;
   size_t N, rows, row_base, stride_w;
   int log_n, rate_bits, num_selectors, nch;
-  int gate_index, selector_index, group_start, group_end, base_idx, pad;
+  int base_idx, ngates;
   u64 pih[4];
   u64 zh_inv[16];
+  JitGateRt g[32];
 };
-extern "C" __global__ __launch_bounds__(256) void vx_program_gate(JitGateParams p) {
+extern "C" __global__ __launch_bounds__(256, VX_JIT_BLOCKS_PER_CU) void vx_program_gates(JitGateParams p) {
   const size_t il = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (il >= p.rows) return;
   const size_t N = p.N, SW = p.stride_w, i = il + p.row_base;
@@ -93,39 +216,13 @@ extern "C" __global__ __launch_bounds__(256) void vx_program_gate(JitGateParams 
   const u64* __restrict__ CS = p.cs;
   const u64* __restrict__ W = p.wires;
   const u64* __restrict__ AP = p.alpha_pows + p.base_idx;
-  const u64 s = CS[(size_t)p.selector_index * N + i];
-  u64 filter = 1;
-  for (int q = p.group_start; q < p.group_end; ++q)
-    if (q != p.gate_index) filter = gl_mul(filter, gl_sub((u64)q, s));
-  if (p.num_selectors > 1) filter = gl_mul(filter, gl_sub(0xFFFFFFFFULL, s));
   const int nsel = p.num_selectors;
-  u64 a0 = 0, a1 = 0;
-  u64 R[64];
+  u64 t0 = 0, t1 = 0;
 )VXJIT";
-  int k = 0;
-  for (int pc = 0;; ++pc) {
-    const uint64_t ins = prog[pc];
-    const int op = (int)(ins & 0xFF), dst = (int)((ins >> 8) & 63), a = (int)((ins >> 16) & 0xFFFF), b = (int)((ins >> 32) & 0xFFFF);
-    if (op == VX_OP_END) break;
-    switch (op) {
-      case VX_OP_LDW: s << "  R[" << dst << "] = gl_canon(W[(size_t)" << a << " * SW + il]);\n"; break;
-      case VX_OP_LDC: s << "  R[" << dst << "] = CS[(size_t)(nsel + " << a << ") * N + i];\n"; break;
-      case VX_OP_LDI: s << "  R[" << dst << "] = " << vxh::canon(prog[++pc]) << "ULL;\n"; break;
-      case VX_OP_ADD: s << "  R[" << dst << "] = gl_add(R[" << (a & 63) << "], R[" << (b & 63) << "]);\n"; break;
-      case VX_OP_SUB: s << "  R[" << dst << "] = gl_sub(R[" << (a & 63) << "], R[" << (b & 63) << "]);\n"; break;
-      case VX_OP_MUL: s << "  R[" << dst << "] = gl_mul(R[" << (a & 63) << "], R[" << (b & 63) << "]);\n"; break;
-      case VX_OP_PUSH:
-        s << "  a0 = gl_mad(R[" << (a & 63) << "], AP[" << k << "], a0);\n";
-        if (nch > 1) s << "  a1 = gl_mad(R[" << (a & 63) << "], AP[" << (VX_ALPHA_POWS + k) << "], a1);\n";
-        ++k;
-        break;
-      case VX_OP_LDP: s << "  R[" << dst << "] = p.pih[" << (a & 3) << "];\n"; break;
-      default: break;
-    }
-  }
+  for (size_t q = 0; q < progs.size(); ++q) jit_gate_block(s, progs[q], nch, (int)q);
   s << "  const u64 zi = p.zh_inv[r];\n"
-       "  { u64* o = p.out + il; *o = gl_add(*o, gl_mul(gl_mul(filter, a0), zi)); }\n";
-  if (nch > 1) s << "  { u64* o = p.out + SW + il; *o = gl_add(*o, gl_mul(gl_mul(filter, a1), zi)); }\n";
+       "  { u64* o = p.out + il; *o = gl_add(*o, gl_mul(t0, zi)); }\n";
+  if (nch > 1) s << "  { u64* o = p.out + SW + il; *o = gl_add(*o, gl_mul(t1, zi)); }\n";
   s << "}\n";
   return s.str();
 }
@@ -140,8 +237,8 @@ static JitCache& jit_cache() {
   return c;
 }
 
-// Returns the kernel for this program on `device`, or nullptr (with *why set) when it cannot be compiled / loaded.
-static hipFunction_t jit_get(const uint64_t* prog, int nch, int device, std::string* why) {
+// Returns the kernel for this gate set on `device`, or nullptr (with *why set) when it cannot be compiled / loaded.
+static hipFunction_t jit_get(const std::vector<const uint64_t*>& progs, int nch, int device, std::string* why) {
   if (getenv("VX_NO_JIT")) {
     *why = "VX_NO_JIT is set";
     return nullptr;
@@ -151,7 +248,7 @@ static hipFunction_t jit_get(const uint64_t* prog, int nch, int device, std::str
     *why = "libhiprtc.so not available";
     return nullptr;
   }
-  const std::string src = jit_source(prog, nch);
+  const std::string src = jit_source(progs, nch);
   JitCache& C = jit_cache();
   std::lock_guard<std::mutex> lk(C.mu);
   auto fit = C.functions.find({src, device});
@@ -159,7 +256,7 @@ static hipFunction_t jit_get(const uint64_t* prog, int nch, int device, std::str
   auto cit = C.code.find(src);
   if (cit == C.code.end()) {
     hiprtcProgram pr;
-    if (api.create(&pr, src.c_str(), "vx_program_gate.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
+    if (api.create(&pr, src.c_str(), "vx_program_gates.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
       *why = "hiprtcCreateProgram failed";
       return nullptr;
     }
@@ -188,7 +285,7 @@ static hipFunction_t jit_get(const uint64_t* prog, int nch, int device, std::str
     return nullptr;
   }
   hipFunction_t fn;
-  if (hipModuleGetFunction(&fn, mod, "vx_program_gate") != hipSuccess) {
+  if (hipModuleGetFunction(&fn, mod, "vx_program_gates") != hipSuccess) {
     (void)hipGetLastError();
     *why = "hipModuleGetFunction failed";
     return nullptr;

@@ -19,8 +19,9 @@ struct vx_circuit {
   std::vector<int> arity_bits;
   std::vector<int> prog_off;   // per gate: word offset into `programs`, -1 for native gates
   u64* programs = nullptr;     // device copy of the constraint programs
-  std::vector<hipFunction_t> jit_fn;  // per gate: the program compiled to native code (jit.hip.h), or nullptr -> interpreter
-  std::string jit_note;               // why a program gate stayed on the interpreter (diagnostics)
+  hipFunction_t jit_fn = nullptr;     // all programs compiled into one native kernel (jit.hip.h), or nullptr -> interpreter
+  std::vector<int> jit_gates;         // gate index of each block of that kernel, in order
+  std::string jit_note;               // why the program gates stayed on the interpreter (diagnostics)
   vx_batch* cs = nullptr;  // constants_sigmas commitment (resident across proofs)
   u64* sigmas = nullptr;   // [nr][n] sigma VALUES on H (natural order) for the permutation argument
   u64* k_is = nullptr;     // device copy
@@ -93,21 +94,29 @@ static int circuit_create(vx_ctx* c, const vx_circuit_desc* d, vx_circuit** out)
       if (hipMalloc(&k->programs, (size_t)d->programs_len * 8) != hipSuccess) { delete k; return vx_fail(VX_E_NOMEM, "circuit: out of device memory"); }
       HIPCHK(hipMemcpy(k->programs, d->programs, (size_t)d->programs_len * 8, hipMemcpyHostToDevice));
     }
-    // compile every program to native code (jit.hip.h); a gate whose program cannot be compiled stays on the interpreter
-    k->jit_fn.assign(d->num_gates, nullptr);
-    const int nterms = d->num_challenges * (1 + (d->num_routed_wires + d->quotient_degree_factor - 1) / d->quotient_degree_factor + 1);
-    for (int g = 0; g < d->num_gates; ++g) {
-      if (k->prog_off[g] < 0) continue;
-      const uint64_t* prog = d->programs + k->prog_off[g];
-      int pushes = 0;
-      for (int pc = 0; (prog[pc] & 0xFF) != VX_OP_END; ++pc) {
-        if ((prog[pc] & 0xFF) == VX_OP_PUSH) ++pushes;
-        if ((prog[pc] & 0xFF) == VX_OP_LDI) ++pc;
-      }
+    // compile the programs to native code (jit.hip.h): one kernel for the whole gate set; on any failure the gates
+    // stay on the interpreter
+    if (nprog) {
+      const int nterms = d->num_challenges * (1 + (d->num_routed_wires + d->quotient_degree_factor - 1) / d->quotient_degree_factor + 1);
+      std::vector<const uint64_t*> progs;
       std::string why;
-      if (nterms + pushes > VX_ALPHA_POWS) why = "more constraints than the alpha-power table holds";
-      else k->jit_fn[g] = jit_get(prog, d->num_challenges, c->device, &why);
-      if (!k->jit_fn[g]) k->jit_note += "gate " + std::to_string(g) + ": " + why + "; ";
+      for (int g = 0; g < d->num_gates && why.empty(); ++g) {
+        if (k->prog_off[g] < 0) continue;
+        const uint64_t* prog = d->programs + k->prog_off[g];
+        int pushes = 0;
+        for (int pc = 0; (prog[pc] & 0xFF) != VX_OP_END; ++pc) {
+          if ((prog[pc] & 0xFF) == VX_OP_PUSH) ++pushes;
+          if ((prog[pc] & 0xFF) == VX_OP_LDI) ++pc;
+        }
+        if (nterms + pushes > VX_ALPHA_POWS) why = "gate " + std::to_string(g) + " has more constraints than the alpha-power table holds";
+        progs.push_back(prog);
+        k->jit_gates.push_back(g);
+      }
+      if (why.empty()) k->jit_fn = jit_get(progs, d->num_challenges, c->device, &why);
+      if (!k->jit_fn) {
+        k->jit_note = why;
+        k->jit_gates.clear();
+      }
     }
   }
   k->k_is_host.assign(d->k_is, d->k_is + d->num_routed_wires);
@@ -423,15 +432,15 @@ static int prove_impl(vx_ctx* c, vx_circuit* k, const u64* wires_in, bool wires_
           jp.base_idx = (int)nterms_before;
           for (int i = 0; i < 4; ++i) jp.pih[i] = pih.e[i];
           for (int r = 0; r < rate; ++r) jp.zh_inv[r] = qp.zh_inv[r];
-          ProfScope psj(c, "quotient_program_gates_jit");
-          for (size_t g = 0; g < k->gates.size(); ++g) {
-            if (k->prog_off[g] < 0 || !k->jit_fn[g]) continue;
-            jp.gate_index = (int)g;
-            jp.selector_index = k->gates[g].selector_index;
-            jp.group_start = k->gates[g].group_start;
-            jp.group_end = k->gates[g].group_end;
+          if (k->jit_fn) {
+            jp.ngates = (int)k->jit_gates.size();
+            for (int q = 0; q < jp.ngates; ++q) {
+              const int g = k->jit_gates[q];
+              jp.g[q] = JitGateRt{g, k->gates[g].selector_index, k->gates[g].group_start, k->gates[g].group_end};
+            }
+            ProfScope psj(c, "quotient_program_gates_jit");
             void* args[] = {&jp};
-            HIPCHK(hipModuleLaunchKernel(k->jit_fn[g], (unsigned)((Nl + 255) / 256), 1, 1, 256, 1, 1, 0, c->stream, args, nullptr));
+            HIPCHK(hipModuleLaunchKernel(k->jit_fn, (unsigned)((Nl + 255) / 256), 1, 1, 256, 1, 1, 0, c->stream, args, nullptr));
           }
         }
         ProgramParams pg;
@@ -448,7 +457,7 @@ static int prove_impl(vx_ctx* c, vx_circuit* k, const u64* wires_in, bool wires_
         pg.num_selectors = k->num_selectors;
         pg.nch = nch;
         for (size_t g = 0; g < k->gates.size(); ++g)
-          if (k->prog_off[g] >= 0 && !k->jit_fn[g])  // not compiled: interpreter
+          if (k->prog_off[g] >= 0 && !k->jit_fn)  // not compiled: interpreter
             pg.gates[pg.num_gates++] = ProgramGateDev{(int)g, k->gates[g].selector_index, k->gates[g].group_start, k->gates[g].group_end, k->prog_off[g]};
         for (int i = 0; i < VX_MAX_CHALLENGES; ++i) pg.alphas[i] = alphas[i], pg.base_pw[i] = pow(alphas[i], nterms_before);
         for (int i = 0; i < 4; ++i) pg.pih[i] = pih.e[i];

@@ -495,7 +495,7 @@ int vx_circuit_program_gates(vx_circuit* k, int* total_out, int* compiled_out, c
   for (size_t g = 0; g < k->prog_off.size(); ++g)
     if (k->prog_off[g] >= 0) {
       ++total;
-      compiled += g < k->jit_fn.size() && k->jit_fn[g] != nullptr;
+      compiled += k->jit_fn != nullptr;
     }
   if (total_out) *total_out = total;
   if (compiled_out) *compiled_out = compiled;
