@@ -111,6 +111,57 @@ GLD u64 acc_reduce_nc(const acc192& A) {
   return r < sub ? d - GL_EPS : d;  // wrapped d + p
 }
 
+// ---- dot products with full-size constants, carry-free -----------------------------------------------------------
+// sum_i a_i * b_i with a_i any u64 and b_i a 64-bit constant: the constant is pre-split into limbs of 22 + 22 + 20
+// bits, the state into its two 32-bit halves, so each of the 2 x 3 partial-product classes is a sum of <= 13 products
+// below 2^54 — it accumulates in a plain 64-bit register with ONE v_mad_u64_u32 per product and no carry handling.
+// The classes are recombined once per dot product:  V = L + 2^32 H,  L = S00 + 2^22 S01 + 2^44 S02 (same for H);
+// 2^32 * (h_lo + 2^64 h_hi) = 2^32 h_lo - h_hi (mod p).  6 multiply-adds per term instead of a 64x64->128 product
+// (4 multiplies + 4 pair-forming moves + 1 add) followed by a 5-instruction carry chain.
+struct Limbs3 {
+  u32 l[3];
+};
+template <int R, int C>
+struct Limbs3Table {
+  Limbs3 v[R][C];
+};
+template <int R, int C>
+constexpr Limbs3Table<R, C> make_limbs3(const u64 (&raw)[R][C]) {
+  Limbs3Table<R, C> t{};
+  for (int r = 0; r < R; ++r)
+    for (int c = 0; c < C; ++c) {
+      t.v[r][c].l[0] = (u32)(raw[r][c] & 0x3FFFFFu);
+      t.v[r][c].l[1] = (u32)((raw[r][c] >> 22) & 0x3FFFFFu);
+      t.v[r][c].l[2] = (u32)(raw[r][c] >> 44);
+    }
+  return t;
+}
+constexpr u64 POSEIDON_FAST_INIT_RAW[11][11] = VX_FAST_PARTIAL_INITIAL_MATRIX_INIT;
+constexpr u64 POSEIDON_FAST_W_HATS_RAW[22][11] = VX_FAST_PARTIAL_W_HATS_INIT;
+__constant__ Limbs3Table<11, 11> POSEIDON_FAST_INIT3 = make_limbs3<11, 11>(POSEIDON_FAST_INIT_RAW);
+__constant__ Limbs3Table<22, 11> POSEIDON_FAST_W_HATS3 = make_limbs3<22, 11>(POSEIDON_FAST_W_HATS_RAW);
+
+struct dot6 {
+  u64 s00, s01, s02, s10, s11, s12;
+};
+GLD void dot6_mac(dot6& D, u64 a, const Limbs3& b) {
+  const u32 a0 = (u32)a, a1 = (u32)(a >> 32);
+  D.s00 += (u64)a0 * b.l[0];
+  D.s01 += (u64)a0 * b.l[1];
+  D.s02 += (u64)a0 * b.l[2];
+  D.s10 += (u64)a1 * b.l[0];
+  D.s11 += (u64)a1 * b.l[1];
+  D.s12 += (u64)a1 * b.l[2];
+}
+GLD u64 dot6_reduce_nc(const dot6& D) {
+  typedef unsigned __int128 u128;
+  const u128 L = (u128)D.s00 + ((u128)D.s01 << 22) + ((u128)D.s02 << 44);
+  const u128 H = (u128)D.s10 + ((u128)D.s11 << 22) + ((u128)D.s12 << 44);  // < 2^101
+  const u64 h_lo = (u64)H, h_hi = (u64)(H >> 64);                           // h_hi < 2^37: canonical
+  const u128 V = L + ((u128)h_lo << 32);
+  return gl_sub_nc_c(gl_reduce128_nc((u64)V, (u64)(V >> 64)), h_hi);
+}
+
 // Permutation on arbitrary-u64 lanes; outputs are arbitrary u64 representatives (NOT canonical).
 GLD void poseidon_permute_nc(u64 (&s)[12]) {
 #pragma unroll 1
@@ -126,10 +177,10 @@ GLD void poseidon_permute_nc(u64 (&s)[12]) {
     u64 t[11];
 #pragma unroll 1
     for (int r = 0; r < 11; ++r) {
-      acc192 A = {0, 0, 0};
+      dot6 D = {0, 0, 0, 0, 0, 0};
 #pragma unroll
-      for (int c = 0; c < 11; ++c) acc_mul_add(A, s[1 + c], POSEIDON_FAST_INIT[r][c]);
-      t[r] = acc_reduce_nc(A);
+      for (int c = 0; c < 11; ++c) dot6_mac(D, s[1 + c], POSEIDON_FAST_INIT3.v[r][c]);
+      t[r] = dot6_reduce_nc(D);
     }
 #pragma unroll
     for (int r = 0; r < 11; ++r) s[1 + r] = t[r];
@@ -137,13 +188,12 @@ GLD void poseidon_permute_nc(u64 (&s)[12]) {
 #pragma unroll 1
   for (int r = 0; r < 22; ++r) {
     const u64 s0 = gl_add_nc_c(poseidon_sbox_nc(s[0]), POSEIDON_FAST_K[r]);
-    acc192 A = {0, 0, 0};
-    acc_mul_add(A, s0, 25);  // M[0][0] = CIRC[0] + DIAG[0]
+    dot6 D = {(u64)(u32)s0 * 25u, 0, 0, (u64)(u32)(s0 >> 32) * 25u, 0, 0};  // M[0][0] = CIRC[0] + DIAG[0] = 25
 #pragma unroll
-    for (int i = 0; i < 11; ++i) acc_mul_add(A, s[1 + i], POSEIDON_FAST_W_HATS[r][i]);
+    for (int i = 0; i < 11; ++i) dot6_mac(D, s[1 + i], POSEIDON_FAST_W_HATS3.v[r][i]);
 #pragma unroll
     for (int i = 0; i < 11; ++i) s[1 + i] = gl_mad_nc(s0, POSEIDON_FAST_VS[r][i], s[1 + i]);
-    s[0] = acc_reduce_nc(A);
+    s[0] = dot6_reduce_nc(D);
   }
 #pragma unroll 1
   for (int r = 26; r < 30; ++r) {
