@@ -11,7 +11,7 @@
  *   plonky2_field::fft::{fft, ifft}, polynomial::{coset_fft, coset_ifft}   -> vx_ntt_batch
  *   plonky2::hash::poseidon::Poseidon::poseidon                            -> vx_poseidon_permute
  *   plonky2::plonk::prover::prove_with_partition_witness                   -> vx_prove
- *   plonky2::plonk::circuit_data::CircuitData::verify                      -> (host side)
+ *   plonky2::plonk::circuit_data::CircuitData::verify                      -> vx_verify (host code)
  * INTEGRATION.md shows the Rust `extern "C"` block a maintainer adds on the reference side.
  *
  * Conventions (all entry points):
@@ -222,6 +222,13 @@ int vx_prove(vx_ctx* ctx, vx_circuit* circuit, const uint64_t* wires, int wires_
              const uint64_t* pow_witness_hint, uint8_t* out_buf, size_t* out_len);
 /* Upper bound of the proof size in bytes for this circuit. */
 size_t vx_proof_size_bound(vx_circuit* circuit);
+
+/* plonky2::plonk::circuit_data::CircuitData::verify (plonk/verifier.rs + fri/verifier.rs) on a serialised
+ * ProofWithPublicInputs — the call the reference makes after every prove
+ * (/root/reference/circuits/header_range.rs:167-170).  Host code (milliseconds; the reference verifies on the CPU too):
+ * it uses only the verifier's view of the circuit — parameters, gate list, k_is, the constants_sigmas cap and the
+ * digest.  Returns VX_OK, or VX_E_PROOF with the failing check in vx_last_error(). */
+int vx_verify(vx_circuit* circuit, const uint8_t* proof, size_t proof_len);
 
 /* ---- ONE proof sharded across the GPUs of a node (BASELINE.json configs[3]) -------------------
  * `world` in {1, 2, 4, 8} ranks (one vx_ctx + one copy of the circuit each; world <= 2^rate_bits and

@@ -57,6 +57,10 @@ int main(int argc, char** argv) {
   CHECK(vx_dev_upload(ctx, dw, wires, wbytes));
   CHECK(vx_prove(ctx, circuit, (const uint64_t*)dw, 1, NULL, p2, &len2));
   if (len1 != len2 || memcmp(p1, p2, len1)) { fprintf(stderr, "host- and device-witness proofs differ\n"); return 1; }
+  /* circuit.verify(&proof): accepted as produced, rejected with one bit flipped */
+  CHECK(vx_verify(circuit, p1, len1));
+  p2[len2 / 2] ^= 1;
+  if (vx_verify(circuit, p2, len2) != VX_E_PROOF) { fprintf(stderr, "a tampered proof was not rejected\n"); return 1; }
   /* too-small output buffer: required size reported, nothing written past the buffer */
   size_t small = 16;
   uint8_t tiny[16];

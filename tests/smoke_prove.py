@@ -14,5 +14,6 @@ def run(ctx, oracle):
     op = oc.prove(sc.witness())
     assert gp == op, "GPU proof bytes differ from the oracle's proof"
     assert oc.verify(gp) == "", "restated verifier rejects the GPU proof"
+    gc.verify(gp)   # the product library's own CircuitData::verify
     gc.free()
     print(f"smoke ok: vx_prove (n=2^8, {len(gp)} bytes) is byte-identical to the oracle proof and verifies")

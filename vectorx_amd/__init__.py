@@ -94,6 +94,7 @@ _SIGNATURES = {
     "vx_circuit_constants_sigmas_cap": (_i, [_vp, _vp]),
     "vx_prove": (_i, [_vp, _vp, _vp, _i, _vp, _vp, ctypes.POINTER(_sz)]),
     "vx_proof_size_bound": (_sz, [_vp]),
+    "vx_verify": (_i, [_vp, _vp, _sz]),
     "vx_circuit_program_gates": (_i, [_vp, ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.c_char_p, _sz]),
     "vx_prove_sharded": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, ctypes.POINTER(_sz)]),
     "vx_group_create": (_i, [_i, ctypes.POINTER(_vp)]),
@@ -405,6 +406,11 @@ class Circuit:
         _chk(lib().vx_prove(self.ctx._h, self._h, src, on_dev, hint.ctypes.data if hint is not None else None,
                             buf.ctypes.data, ctypes.byref(ln)))
         return bytes(buf[:ln.value])
+
+    def verify(self, proof: bytes) -> None:
+        """`vx_verify` (CircuitData::verify): raises VxError(VX_E_PROOF, reason) when the proof is not valid."""
+        buf = np.frombuffer(proof, dtype=np.uint8) if len(proof) else np.zeros(1, np.uint8)
+        _chk(lib().vx_verify(self._h, buf.ctypes.data, len(proof)))
 
     def program_gates(self):
         """(number of VX_GATE_PROGRAM gates, how many were compiled to native code, why the others were not)"""

@@ -21,6 +21,8 @@ struct vx_circuit {
   u64* programs = nullptr;     // device copy of the constraint programs
   hipFunction_t jit_fn = nullptr;     // all programs compiled into one native kernel (jit.hip.h), or nullptr -> interpreter
   std::vector<int> jit_gates;         // gate index of each block of that kernel, in order
+  std::vector<uint64_t> programs_host;  // host copy of the programs (vx_verify evaluates gates at zeta on the host)
+  std::vector<u64> cs_cap_host;         // constants_sigmas cap (verifier data)
   std::string jit_note;               // why the program gates stayed on the interpreter (diagnostics)
   vx_batch* cs = nullptr;  // constants_sigmas commitment (resident across proofs)
   u64* sigmas = nullptr;   // [nr][n] sigma VALUES on H (natural order) for the permutation argument
@@ -91,6 +93,7 @@ static int circuit_create(vx_ctx* c, const vx_circuit_desc* d, vx_circuit** out)
     }
     if (nprog > VX_MAX_PROGRAM_GATES) { delete k; return vx_fail(VX_E_INVALID, "circuit: too many program gates"); }
     if (nprog) {
+      k->programs_host.assign(d->programs, d->programs + d->programs_len);
       if (hipMalloc(&k->programs, (size_t)d->programs_len * 8) != hipSuccess) { delete k; return vx_fail(VX_E_NOMEM, "circuit: out of device memory"); }
       HIPCHK(hipMemcpy(k->programs, d->programs, (size_t)d->programs_len * 8, hipMemcpyHostToDevice));
     }
@@ -160,6 +163,7 @@ static int circuit_create(vx_ctx* c, const vx_circuit_desc* d, vx_circuit** out)
   HIPCHK(hipMemcpy(pre.data(), k->cs->tree + k->cs->cap_off * 4, (size_t)32 << k->cap_height, hipMemcpyDeviceToHost));
   pre.back() = (u64)k->degree_bits;
   k->digest = vxh::hash_no_pad(pre.data(), pre.size());
+  k->cs_cap_host.assign(pre.begin(), pre.end() - 1);
   *out = k;
   return VX_OK;
 }

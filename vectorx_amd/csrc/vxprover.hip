@@ -8,6 +8,7 @@
 #include "plonk_kernels.hip.h"
 #include "jit.hip.h"
 #include "prover.hip.h"
+#include "verifier.h"
 
 extern "C" {
 
@@ -523,6 +524,38 @@ int vx_prove(vx_ctx* c, vx_circuit* k, const uint64_t* wires, int wires_on_devic
   }
   memcpy(out_buf, proof.data(), proof.size());
   *out_len = proof.size();
+  return VX_OK;
+}
+
+int vx_verify(vx_circuit* k, const uint8_t* proof, size_t proof_len) {
+  if (!k || !proof) return vx_fail(VX_E_INVALID, "vx_verify: NULL argument");
+  vxv::CircuitV v;
+  v.degree_bits = k->degree_bits;
+  v.num_wires = k->num_wires;
+  v.num_routed = k->nr;
+  v.num_challenges = k->nch;
+  v.rate_bits = k->rate_bits;
+  v.cap_height = k->cap_height;
+  v.pow_bits = k->pow_bits;
+  v.num_queries = k->num_queries;
+  v.qdf = k->qdf;
+  v.num_selectors = k->num_selectors;
+  v.num_constants = k->num_constants;
+  v.num_public_inputs = (int)k->pi_rows.size();
+  for (size_t g = 0; g < k->gates.size(); ++g)
+    v.gates.push_back(vxv::GateV{k->gates[g].type, k->gates[g].param, k->gates[g].selector_index, k->gates[g].group_start,
+                                 k->gates[g].group_end, k->prog_off[g] >= 0 ? k->programs_host.data() + k->prog_off[g] : nullptr});
+  v.arity_bits = k->arity_bits;
+  v.k_is = k->k_is_host.data();
+  v.cs_cap = k->cs_cap_host.data();
+  v.digest = k->digest;
+  std::string why;
+  try {
+    why = vxv::verify(v, proof, proof_len);
+  } catch (const std::exception& e) {  // never unwind across the ABI
+    why = std::string("exception: ") + e.what();
+  }
+  if (!why.empty()) return vx_fail(VX_E_PROOF, "vx_verify: %s", why.c_str());
   return VX_OK;
 }
 
