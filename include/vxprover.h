@@ -229,6 +229,11 @@ size_t vx_proof_size_bound(vx_circuit* circuit);
  * it uses only the verifier's view of the circuit — parameters, gate list, k_is, the constants_sigmas cap and the
  * digest.  Returns VX_OK, or VX_E_PROOF with the failing check in vx_last_error(). */
 int vx_verify(vx_circuit* circuit, const uint8_t* proof, size_t proof_len);
+/* The same check from verifier data alone — no vx_ctx, no GPU: `desc` as for vx_circuit_create (its constants_sigmas
+ * may be NULL: a verifier never sees the preprocessed polynomials) plus the 2^cap_height x 4 constants_sigmas cap
+ * (vx_circuit_constants_sigmas_cap of the prover's circuit = plonky2's VerifierOnlyCircuitData); the circuit digest is
+ * recomputed from the cap. */
+int vx_verify_standalone(const vx_circuit_desc* desc, const uint64_t* constants_sigmas_cap, const uint8_t* proof, size_t proof_len);
 
 /* ---- ONE proof sharded across the GPUs of a node (BASELINE.json configs[3]) -------------------
  * `world` in {1, 2, 4, 8} ranks (one vx_ctx + one copy of the circuit each; world <= 2^rate_bits and

@@ -95,6 +95,7 @@ _SIGNATURES = {
     "vx_prove": (_i, [_vp, _vp, _vp, _i, _vp, _vp, ctypes.POINTER(_sz)]),
     "vx_proof_size_bound": (_sz, [_vp]),
     "vx_verify": (_i, [_vp, _vp, _sz]),
+    "vx_verify_standalone": (_i, [_vp, _vp, _vp, _sz]),
     "vx_circuit_program_gates": (_i, [_vp, ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.c_char_p, _sz]),
     "vx_prove_sharded": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, ctypes.POINTER(_sz)]),
     "vx_group_create": (_i, [_i, ctypes.POINTER(_vp)]),
@@ -352,6 +353,14 @@ class PolynomialBatch:
         out = np.empty((self.ncols, 2), dtype=np.uint64)
         _chk(lib().vx_batch_eval_ext(self._h, z.ctypes.data, out.ctypes.data))
         return out
+
+
+def verify_standalone(desc_ptr, constants_sigmas_cap, proof: bytes) -> None:
+    """`vx_verify_standalone`: CircuitData::verify from verifier data alone (no GPU, no context).  `desc_ptr` as for
+    Circuit(), `constants_sigmas_cap` = [2^cap_height][4] u64.  Raises VxError(VX_E_PROOF, reason) on an invalid proof."""
+    cap = _as_u64(constants_sigmas_cap)
+    buf = np.frombuffer(proof, dtype=np.uint8) if len(proof) else np.zeros(1, np.uint8)
+    _chk(lib().vx_verify_standalone(ctypes.cast(desc_ptr, _vp), cap.ctypes.data, buf.ctypes.data, len(proof)))
 
 
 class Circuit:
