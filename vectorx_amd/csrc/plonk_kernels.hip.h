@@ -182,7 +182,10 @@ GLD void acc_push(AlphaAcc& a, const QuotientParams& p, u64 term) {
 
 #define UNUSED_SELECTOR_U64 0xFFFFFFFFULL
 
-__global__ __launch_bounds__(256, 4) void quotient_kernel(QuotientParams p) {
+#ifndef VX_QUOTIENT_BLOCKS
+#define VX_QUOTIENT_BLOCKS 4
+#endif
+__global__ __launch_bounds__(256, VX_QUOTIENT_BLOCKS) void quotient_kernel(QuotientParams p) {
   const size_t il = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (il >= p.rows) return;
   const size_t N = p.N, SW = p.stride_w, i = il + p.row_base;
