@@ -12,7 +12,7 @@
 #define HASH_THREADS 256
 
 // digests[row] = hash_or_noop(row of `ncols` values), column-major source.
-__global__ __launch_bounds__(HASH_THREADS) void hash_leaves_colmajor_kernel(
+__global__ __launch_bounds__(HASH_THREADS, 4) void hash_leaves_colmajor_kernel(
     const u64* __restrict__ cols, size_t col_stride, size_t nrows, int ncols, u64* __restrict__ digests) {
   size_t row = (size_t)blockIdx.x * HASH_THREADS + threadIdx.x;
   if (row >= nrows) return;
@@ -42,7 +42,7 @@ __global__ __launch_bounds__(HASH_THREADS) void hash_leaves_colmajor_kernel(
 
 // Row-major leaves [nrows][width] (C-ABI vx_merkle_cap and the FRI commit-phase trees, whose leaves
 // are 16 consecutive F_p^2 values = 32 contiguous u64).
-__global__ __launch_bounds__(HASH_THREADS) void hash_leaves_rowmajor_kernel(
+__global__ __launch_bounds__(HASH_THREADS, 4) void hash_leaves_rowmajor_kernel(
     const u64* __restrict__ leaves, size_t nrows, int width, u64* __restrict__ digests) {
   size_t row = (size_t)blockIdx.x * HASH_THREADS + threadIdx.x;
   if (row >= nrows) return;
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(HASH_THREADS) void hash_leaves_rowmajor_kernel(
 }
 
 // parents[i] = two_to_one(children[2i], children[2i+1])
-__global__ __launch_bounds__(HASH_THREADS) void merkle_level_kernel(const u64* __restrict__ children,
+__global__ __launch_bounds__(HASH_THREADS, 4) void merkle_level_kernel(const u64* __restrict__ children,
                                                                     u64* __restrict__ parents, size_t n_parents) {
   size_t i = (size_t)blockIdx.x * HASH_THREADS + threadIdx.x;
   if (i >= n_parents) return;

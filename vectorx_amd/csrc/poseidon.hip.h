@@ -127,27 +127,33 @@ GLD u64 acc_reduce_nc(const acc192& A) {
 }
 
 // ---- dot products with full-size constants, carry-free -----------------------------------------------------------
-// sum_i a_i * b_i with a_i any u64 and b_i a 64-bit constant: the constant is pre-split into limbs of 22 + 22 + 20
-// bits, the state into its two 32-bit halves, so each of the 2 x 3 partial-product classes is a sum of <= 13 products
-// below 2^54 — it accumulates in a plain 64-bit register with ONE v_mad_u64_u32 per product and no carry handling.
-// The classes are recombined once per dot product:  V = L + 2^32 H,  L = S00 + 2^22 S01 + 2^44 S02 (same for H);
-// 2^32 * (h_lo + 2^64 h_hi) = 2^32 h_lo - h_hi (mod p).  6 multiply-adds per term instead of a 64x64->128 product
-// (4 multiplies + 4 pair-forming moves + 1 add) followed by a 5-instruction carry chain.
-struct Limbs3 {
-  u32 l[3];
+// sum_i a_i * b_i with a_i any u64 and b_i a 64-bit constant.  a = a0 + 2^32 a1, so a*b = a0*b + a1*b' with the
+// second constant b' = 2^32 b mod p; both constants are pre-split into limbs of 22 + 22 + 20 bits.  Limb k of b
+// meets a0 and limb k of b' meets a1 in the SAME accumulator S_k: <= 26 products below 2^54 each, so a plain 64-bit
+// register and ONE v_mad_u64_u32 per product suffice — no carries anywhere — and the result is
+// S_0 + 2^22 S_1 + 2^44 S_2 < 2^104, recombined and reduced once per dot product.  6 multiply-adds per term instead
+// of a 64x64->128 product (4 multiplies + 4 pair-forming moves + 1 add) followed by a 5-instruction carry chain.
+struct Limbs3x2 {
+  u32 lo[3];  // limbs of b      (multiply the low  half of the state element)
+  u32 hi[3];  // limbs of 2^32 b (multiply the high half)
 };
 template <int R, int C>
 struct Limbs3Table {
-  Limbs3 v[R][C];
+  Limbs3x2 v[R][C];
 };
+constexpr u64 gl_mul_2_32_const(u64 b) { return (u64)((((unsigned __int128)b) << 32) % (unsigned __int128)GL_P); }
 template <int R, int C>
 constexpr Limbs3Table<R, C> make_limbs3(const u64 (&raw)[R][C]) {
   Limbs3Table<R, C> t{};
   for (int r = 0; r < R; ++r)
     for (int c = 0; c < C; ++c) {
-      t.v[r][c].l[0] = (u32)(raw[r][c] & 0x3FFFFFu);
-      t.v[r][c].l[1] = (u32)((raw[r][c] >> 22) & 0x3FFFFFu);
-      t.v[r][c].l[2] = (u32)(raw[r][c] >> 44);
+      const u64 b = raw[r][c] % GL_P, bh = gl_mul_2_32_const(b);
+      t.v[r][c].lo[0] = (u32)(b & 0x3FFFFFu);
+      t.v[r][c].lo[1] = (u32)((b >> 22) & 0x3FFFFFu);
+      t.v[r][c].lo[2] = (u32)(b >> 44);
+      t.v[r][c].hi[0] = (u32)(bh & 0x3FFFFFu);
+      t.v[r][c].hi[1] = (u32)((bh >> 22) & 0x3FFFFFu);
+      t.v[r][c].hi[2] = (u32)(bh >> 44);
     }
   return t;
 }
@@ -156,25 +162,22 @@ constexpr u64 POSEIDON_FAST_W_HATS_RAW[22][11] = VX_FAST_PARTIAL_W_HATS_INIT;
 __constant__ Limbs3Table<11, 11> POSEIDON_FAST_INIT3 = make_limbs3<11, 11>(POSEIDON_FAST_INIT_RAW);
 __constant__ Limbs3Table<22, 11> POSEIDON_FAST_W_HATS3 = make_limbs3<22, 11>(POSEIDON_FAST_W_HATS_RAW);
 
-struct dot6 {
-  u64 s00, s01, s02, s10, s11, s12;
+struct dot3 {
+  u64 s0, s1, s2;
 };
-GLD void dot6_mac(dot6& D, u64 a, const Limbs3& b) {
+GLD void dot3_mac(dot3& D, u64 a, const Limbs3x2& b) {
   const u32 a0 = (u32)a, a1 = (u32)(a >> 32);
-  D.s00 += (u64)a0 * b.l[0];
-  D.s01 += (u64)a0 * b.l[1];
-  D.s02 += (u64)a0 * b.l[2];
-  D.s10 += (u64)a1 * b.l[0];
-  D.s11 += (u64)a1 * b.l[1];
-  D.s12 += (u64)a1 * b.l[2];
+  D.s0 += (u64)a0 * b.lo[0];
+  D.s1 += (u64)a0 * b.lo[1];
+  D.s2 += (u64)a0 * b.lo[2];
+  D.s0 += (u64)a1 * b.hi[0];
+  D.s1 += (u64)a1 * b.hi[1];
+  D.s2 += (u64)a1 * b.hi[2];
 }
-GLD u64 dot6_reduce_nc(const dot6& D) {
+GLD u64 dot3_reduce_nc(const dot3& D) {
   typedef unsigned __int128 u128;
-  const u128 L = (u128)D.s00 + ((u128)D.s01 << 22) + ((u128)D.s02 << 44);
-  const u128 H = (u128)D.s10 + ((u128)D.s11 << 22) + ((u128)D.s12 << 44);  // < 2^101
-  const u64 h_lo = (u64)H, h_hi = (u64)(H >> 64);                           // h_hi < 2^37: canonical
-  const u128 V = L + ((u128)h_lo << 32);
-  return gl_sub_nc_c(gl_reduce128_nc((u64)V, (u64)(V >> 64)), h_hi);
+  const u128 V = (u128)D.s0 + ((u128)D.s1 << 22) + ((u128)D.s2 << 44);  // < 2^104
+  return gl_reduce128_nc((u64)V, (u64)(V >> 64));
 }
 
 // Permutation on arbitrary-u64 lanes; outputs are arbitrary u64 representatives (NOT canonical).
@@ -192,10 +195,10 @@ GLD void poseidon_permute_nc(u64 (&s)[12]) {
     u64 t[11];
 #pragma unroll 1
     for (int r = 0; r < 11; ++r) {
-      dot6 D = {0, 0, 0, 0, 0, 0};
+      dot3 D = {0, 0, 0};
 #pragma unroll
-      for (int c = 0; c < 11; ++c) dot6_mac(D, s[1 + c], POSEIDON_FAST_INIT3.v[r][c]);
-      t[r] = dot6_reduce_nc(D);
+      for (int c = 0; c < 11; ++c) dot3_mac(D, s[1 + c], POSEIDON_FAST_INIT3.v[r][c]);
+      t[r] = dot3_reduce_nc(D);
     }
 #pragma unroll
     for (int r = 0; r < 11; ++r) s[1 + r] = t[r];
@@ -203,12 +206,13 @@ GLD void poseidon_permute_nc(u64 (&s)[12]) {
 #pragma unroll 1
   for (int r = 0; r < 22; ++r) {
     const u64 s0 = gl_add_nc_c(poseidon_sbox_nc(s[0]), POSEIDON_FAST_K[r]);
-    dot6 D = {(u64)(u32)s0 * 25u, 0, 0, (u64)(u32)(s0 >> 32) * 25u, 0, 0};  // M[0][0] = CIRC[0] + DIAG[0] = 25
+    // M[0][0] = CIRC[0] + DIAG[0] = 25:  25 s0 = 25 lo(s0) + 2^22 * (25 * 2^10) hi(s0)
+    dot3 D = {(u64)(u32)s0 * 25u, (u64)(u32)(s0 >> 32) * 25600u, 0};
 #pragma unroll
-    for (int i = 0; i < 11; ++i) dot6_mac(D, s[1 + i], POSEIDON_FAST_W_HATS3.v[r][i]);
+    for (int i = 0; i < 11; ++i) dot3_mac(D, s[1 + i], POSEIDON_FAST_W_HATS3.v[r][i]);
 #pragma unroll
     for (int i = 0; i < 11; ++i) s[1 + i] = gl_mad_nc(s0, POSEIDON_FAST_VS[r][i], s[1 + i]);
-    s[0] = dot6_reduce_nc(D);
+    s[0] = dot3_reduce_nc(D);
   }
 #pragma unroll 1
   for (int r = 26; r < 30; ++r) {
