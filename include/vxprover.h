@@ -146,8 +146,10 @@ size_t vx_merkle_digest_count(size_t n_leaves, int cap_height);
  * (gates/selectors.rs SelectorsInfo), the coset shifts k_is, the public-input targets, and the VALUES
  * of the preprocessed polynomials [selectors.., constants.., sigmas..] on H (column-major, natural
  * row order) from which constants_sigmas_commitment and circuit_digest are derived at load time.
- * Gate set of this round: NoopGate, ConstantGate, PublicInputGate, ArithmeticGate (base), PoseidonGate
- * (SURVEY.md §8 f-4 lists the remaining recursion gates as "next"). */
+ * Gates with hand-written kernels: NoopGate, ConstantGate, PublicInputGate, ArithmeticGate (base), PoseidonGate.
+ * Every other gate is handed over as a constraint program (VX_GATE_PROGRAM below), which vx_circuit_create compiles
+ * to native code; the recursive verifier's whole gate set has been exercised that way.  Limits: 32
+ * gates per circuit, degree_bits + rate_bits <= 24, no lookup tables. */
 #define VX_GATE_NOOP 0
 #define VX_GATE_CONSTANT 1
 #define VX_GATE_PUBLIC_INPUT 2
