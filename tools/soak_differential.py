@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""One-off soak: random circuits (size, gate mix, flags, config variants, rank counts) proven on the GPU and by the
+oracle; proofs must be byte-identical, `vx_verify` must accept them and reject a random bit flip.
+
+    python tools/soak_differential.py [seconds] [seed] > gpurun_out/soak.jsonl
+"""
+import json
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+import oracle_lib  # noqa: E402  (checker only)
+import vectorx_amd as vx  # noqa: E402
+from vectorx_amd import sharded  # noqa: E402
+from vectorx_amd.synth import SynthCircuit  # noqa: E402
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
+oracle = oracle_lib.load()
+oracle.L.vxo_set_num_threads(8)
+ctx = vx.Context(0)
+lanes = [vx.Context(0) for _ in range(7)]
+t_end = time.time() + budget
+n_ok, n_bad, by_kind = 0, 0, {}
+while time.time() < t_end:
+    flags = int(rng.choice([0, 0, 1, 2, 3, 4, 5, 7, 8, 15]))
+    lo = 5 if flags & 12 else (4 if flags & 1 else 3)
+    db = int(rng.integers(lo, 14))
+    pct = int(rng.integers(0, 101))
+    sc = SynthCircuit(db, seed=int(rng.integers(1, 1 << 30)), poseidon_percent=pct, witness_seed=int(rng.integers(1, 1 << 30)), flags=flags)
+    sc.desc.pow_bits = int(rng.choice([0, 3, 8, 12]))
+    if rng.random() < 0.3:
+        sc.desc.num_challenges = 1
+    if rng.random() < 0.3:
+        sc.desc.cap_height = int(rng.choice([0, 1, 2, 3]))
+    if rng.random() < 0.3:
+        sc.desc.num_query_rounds = int(rng.choice([1, 5, 40]))
+    world = int(rng.choice([1, 1, 2, 4, 8]))
+    if world > (1 << sc.desc.cap_height):
+        world = 1 << sc.desc.cap_height
+    w = sc.witness()
+    oc = oracle_lib.OracleCircuit(oracle, sc.desc_ptr)
+    want = oc.prove(w)
+    cs = [vx.Circuit(c, sc.desc_ptr) for c in [ctx] + lanes[:world - 1]]
+    got = sharded.prove_sharded_threads(cs, w) if world > 1 else [cs[0].prove(w)]
+    ok = all(p == want for p in got)
+    try:
+        cs[0].verify(got[0])
+    except vx.VxError:
+        ok = False
+    bad = bytearray(got[0])
+    bad[int(rng.integers(0, len(bad)))] ^= 1 << int(rng.integers(0, 8))
+    try:
+        cs[0].verify(bytes(bad))
+        ok = False
+    except vx.VxError:
+        pass
+    key = f"flags{flags}/world{world}"
+    by_kind[key] = by_kind.get(key, 0) + 1
+    if ok:
+        n_ok += 1
+    else:
+        n_bad += 1
+        print(json.dumps({"FAIL": {"degree_bits": db, "flags": flags, "pct": pct, "world": world, "pow_bits": sc.desc.pow_bits,
+                                   "nch": sc.desc.num_challenges, "cap_height": sc.desc.cap_height, "queries": sc.desc.num_query_rounds}}), flush=True)
+    for c in cs:
+        c.free()
+    oc.free()
+    sc.free()
+print(json.dumps({"cases": n_ok + n_bad, "identical_and_verified": n_ok, "failures": n_bad, "seconds": budget, "by_kind": by_kind}), flush=True)
