@@ -2,7 +2,7 @@
 """One-off soak: random circuits (size, gate mix, flags, config variants, rank counts) proven on the GPU and by the
 oracle; proofs must be byte-identical, `vx_verify` must accept them and reject a random bit flip.
 
-    python tools/soak_differential.py [seconds] [seed] > gpurun_out/soak.jsonl
+    python tools/soak_differential.py [seconds] [seed] [min_degree_bits] [max_degree_bits] > gpurun_out/soak.jsonl
 """
 import json
 import sys
@@ -21,8 +21,10 @@ from vectorx_amd.synth import SynthCircuit  # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
+db_min = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+db_max = int(sys.argv[4]) if len(sys.argv) > 4 else 13
 oracle = oracle_lib.load()
-oracle.L.vxo_set_num_threads(8)
+oracle.L.vxo_set_num_threads(16 if db_max > 13 else 8)
 ctx = vx.Context(0)
 lanes = [vx.Context(0) for _ in range(7)]
 t_end = time.time() + budget
@@ -30,7 +32,7 @@ n_ok, n_bad, by_kind = 0, 0, {}
 while time.time() < t_end:
     flags = int(rng.choice([0, 0, 1, 2, 3, 4, 5, 7, 8, 15]))
     lo = 5 if flags & 12 else (4 if flags & 1 else 3)
-    db = int(rng.integers(lo, 14))
+    db = int(rng.integers(max(lo, db_min), db_max + 1))
     pct = int(rng.integers(0, 101))
     sc = SynthCircuit(db, seed=int(rng.integers(1, 1 << 30)), poseidon_percent=pct, witness_seed=int(rng.integers(1, 1 << 30)), flags=flags)
     sc.desc.pow_bits = int(rng.choice([0, 3, 8, 12]))
@@ -72,4 +74,4 @@ while time.time() < t_end:
         c.free()
     oc.free()
     sc.free()
-print(json.dumps({"cases": n_ok + n_bad, "identical_and_verified": n_ok, "failures": n_bad, "seconds": budget, "by_kind": by_kind}), flush=True)
+print(json.dumps({"degree_bits": [db_min, db_max], "cases": n_ok + n_bad, "identical_and_verified": n_ok, "failures": n_bad, "seconds": budget, "by_kind": by_kind}), flush=True)
