@@ -22,13 +22,9 @@ __global__ __launch_bounds__(HASH_THREADS, 4) void hash_leaves_colmajor_kernel(
   if (ncols <= 4) {
     for (int c = 0; c < ncols; ++c) s[c] = gl_canon(cols[(size_t)c * col_stride + row]);
   } else {
-    int c = 0;
-    for (; c + 8 <= ncols; c += 8) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) s[i] = gl_canon(cols[(size_t)(c + i) * col_stride + row]);
-      poseidon_permute_nc(s);
-    }
-    if (c < ncols) {
+    // one call site of the (inlined, ~28 KB) permutation; the tail chunk is handled by the uniform bound check
+#pragma unroll 1
+    for (int c = 0; c < ncols; c += 8) {
 #pragma unroll
       for (int i = 0; i < 8; ++i)
         if (c + i < ncols) s[i] = gl_canon(cols[(size_t)(c + i) * col_stride + row]);
@@ -53,13 +49,8 @@ __global__ __launch_bounds__(HASH_THREADS, 4) void hash_leaves_rowmajor_kernel(
   if (width <= 4) {
     for (int c = 0; c < width; ++c) s[c] = gl_canon(src[c]);
   } else {
-    int c = 0;
-    for (; c + 8 <= width; c += 8) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) s[i] = gl_canon(src[c + i]);
-      poseidon_permute_nc(s);
-    }
-    if (c < width) {
+#pragma unroll 1
+    for (int c = 0; c < width; c += 8) {
 #pragma unroll
       for (int i = 0; i < 8; ++i)
         if (c + i < width) s[i] = gl_canon(src[c + i]);
