@@ -19,7 +19,7 @@ P = oracle_lib.P
 
 
 @pytest.mark.parametrize("degree_bits,pct", [(3, 50), (4, 100), (5, 0), (6, 50), (7, 70), (9, 50), (10, 20), (12, 50), (13, 50),
-                                             (15, 50), (16, 40), (17, 60), (18, 50)])
+                                             (15, 50), (16, 40), (17, 60)])
 def test_proof_bytes_identical_to_oracle(ctx, oracle, degree_bits, pct):
     sc = SynthCircuit(degree_bits, seed=1000 + degree_bits, poseidon_percent=pct)
     oc = oracle_lib.OracleCircuit(oracle, sc.desc_ptr)

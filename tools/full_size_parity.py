@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One-off parity check at the benchmark sizes: the GPU proof of the header_range_256 / header_range_512 stand-ins
 (n = 2^20, 2^21) against the ORACLE's proof of the same circuit and witness, byte for byte.  The oracle needs minutes
-per proof on the box's 16 cores, so this is not part of the test suite (which checks byte identity up to 2^18 and the
+per proof on the box's 16 cores, so this is not part of the test suite (which checks byte identity up to 2^17 and the
 verifiers at 2^20 / 2^21); the outcome is recorded in profiles/.
 
     python tools/full_size_parity.py 20 21 > gpurun_out/full_size_parity.jsonl
