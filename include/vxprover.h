@@ -208,8 +208,9 @@ int vx_circuit_constants_sigmas_cap(vx_circuit* c, uint64_t* cap_out /* [2^cap_h
 
 /* Constraint programs are compiled to native gfx950 code when the circuit is created (hiprtc; a gate whose program
  * cannot be compiled — hiprtc missing, VX_NO_JIT=1 — is evaluated by the on-GPU interpreter instead, with identical
- * results).  Reports how many VX_GATE_PROGRAM gates the circuit has, how many of them were compiled, and why the
- * others were not (note_out, optional). */
+ * results).  Compiled code objects are cached per process, and across processes when the environment variable
+ * VX_JIT_CACHE_DIR names a writable directory.  Reports how many VX_GATE_PROGRAM gates the circuit has, how many of
+ * them were compiled, and why the others were not (note_out, optional). */
 int vx_circuit_program_gates(vx_circuit* c, int* total_out, int* compiled_out, char* note_out, size_t note_cap);
 
 /* plonky2::plonk::prover::prove_with_partition_witness.  `wires` is the finished witness matrix,

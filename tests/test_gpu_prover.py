@@ -224,6 +224,35 @@ def test_program_gates_are_compiled_to_native_code_and_match_the_interpreter(ctx
     assert sha == hashlib.sha256(proof).hexdigest()
 
 
+def test_jit_code_objects_are_cached_on_disk(tmp_path):
+    """VX_JIT_CACHE_DIR: the first process compiles the gate set and stores the code object; the second loads it
+    (no hiprtc compile: circuit creation is much faster) and proves the same bytes."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    code = (
+        "import sys, time, hashlib; sys.path.insert(0, %r)\n"
+        "import vectorx_amd as vx\n"
+        "from vectorx_amd.synth import SynthCircuit\n"
+        "sc = SynthCircuit(7, seed=5, poseidon_percent=40, flags=15); sc.desc.pow_bits = 4\n"
+        "ctx = vx.Context(0); t = time.time(); c = vx.Circuit(ctx, sc.desc_ptr); dt = time.time() - t\n"
+        "assert c.program_gates()[:2] == (10, 10), c.program_gates()\n"
+        "print('RESULT', dt, hashlib.sha256(c.prove(sc.witness())).hexdigest()); c.free(); ctx.close()\n"
+    ) % str(root)
+    env = dict(os.environ, VX_JIT_CACHE_DIR=str(tmp_path))
+    runs = []
+    for _ in range(2):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env, cwd=str(root))
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        _, dt, sha = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1].split()
+        runs.append((float(dt), sha))
+        assert len(list(tmp_path.glob("vxjit-*.hsaco"))) == 1
+    assert runs[0][1] == runs[1][1]
+    assert runs[1][0] < 0.5 * runs[0][0], runs           # second creation skipped the compile
+
+
 def test_malformed_constraint_programs_are_refused(ctx):
     import ctypes
     sc = SynthCircuit(5, seed=1, poseidon_percent=50, flags=1)

@@ -15,6 +15,7 @@
 // still on the GPU, same values (tests/test_gpu_prover.py compares the two paths).
 #pragma once
 #include <dlfcn.h>
+#include <unistd.h>
 #include <hip/hiprtc.h>
 #include <map>
 #include <mutex>
@@ -254,6 +255,25 @@ static hipFunction_t jit_get(const std::vector<const uint64_t*>& progs, int nch,
   auto fit = C.functions.find({src, device});
   if (fit != C.functions.end()) return fit->second;
   auto cit = C.code.find(src);
+  // optional on-disk cache of code objects (VX_JIT_CACHE_DIR): a host that restarts does not recompile its circuits
+  std::string cache_file;
+  if (const char* dir = getenv("VX_JIT_CACHE_DIR")) {
+    uint64_t h = 1469598103934665603ULL;  // FNV-1a over the source (which embeds the prelude, so a library update misses)
+    for (unsigned char ch : src) h = (h ^ ch) * 1099511628211ULL;
+    char name[64];
+    snprintf(name, sizeof name, "/vxjit-%016llx-%zu.hsaco", (unsigned long long)h, src.size());
+    cache_file = std::string(dir) + name;
+    if (cit == C.code.end()) {
+      if (FILE* f = fopen(cache_file.c_str(), "rb")) {
+        std::vector<char> code;
+        char buf[65536];
+        size_t n;
+        while ((n = fread(buf, 1, sizeof buf, f)) > 0) code.insert(code.end(), buf, buf + n);
+        fclose(f);
+        if (code.size() > 64) cit = C.code.emplace(src, std::move(code)).first;
+      }
+    }
+  }
   if (cit == C.code.end()) {
     hiprtcProgram pr;
     if (api.create(&pr, src.c_str(), "vx_program_gates.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
@@ -276,6 +296,14 @@ static hipFunction_t jit_get(const std::vector<const uint64_t*>& progs, int nch,
     std::vector<char> code(cs);
     api.code(pr, code.data());
     api.destroy(&pr);
+    if (!cache_file.empty()) {  // write-then-rename so that a concurrent reader never sees a partial file
+      const std::string tmp = cache_file + ".tmp" + std::to_string((long)getpid());
+      if (FILE* f = fopen(tmp.c_str(), "wb")) {
+        const bool ok = fwrite(code.data(), 1, code.size(), f) == code.size();
+        fclose(f);
+        if (!ok || rename(tmp.c_str(), cache_file.c_str()) != 0) remove(tmp.c_str());
+      }
+    }
     cit = C.code.emplace(src, std::move(code)).first;
   }
   hipModule_t mod;
