@@ -249,6 +249,30 @@ __global__ __launch_bounds__(NTT2_THREADS) void ntt2_pass_kernel(Ntt2Params p) {
       t = g >> LO;
     }
     u64 x[16];
+    if constexpr (STRIDED && IN_BITREV) {
+      // bit-reversed input: the 16 operands of this thread's radix-16 DFT (q = the top 4 bits of m) are the 16
+      // CONSECUTIVE words at rev(base_low) * 16 of chunk t, in the order rev4(q): eight 16-byte loads instead of
+      // sixteen 8-byte ones (x[q] and x[q + 8] are neighbours)
+      const size_t l = (base & (((size_t)1 << p.b_lo) - 1)) + t;
+      const size_t g0 = ((size_t)bitrev32((u32)l, p.b_lo) << R_LOG) | bitrev32(base_low, R_LOG);
+      const ulonglong2* __restrict__ src = reinterpret_cast<const ulonglong2*>(in + g0);
+#pragma unroll
+      for (int h = 0; h < 8; ++h) {
+        const ulonglong2 v = src[h];                 // positions 2h, 2h+1 = rev4(q), rev4(q + 8) with q = rev3(h)
+        const int q = (int)rev_c<3>((u32)h);
+        x[q] = gl_canon(v.x);
+        x[q + 8] = gl_canon(v.y);
+      }
+      if constexpr (PRE) {
+        const u64* pre = p.pre + (size_t)bz * (((size_t)1 << (p.log_n - p.pre_bits)) + ((size_t)1 << p.pre_bits));
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const size_t j = ((size_t)(base_low | ((u32)q << LO)) << p.b_lo) | l;
+          const u64 sc = gl_mul(pre[j >> p.pre_bits], pre[((size_t)1 << (p.log_n - p.pre_bits)) + (j & (((size_t)1 << p.pre_bits) - 1))]);
+          x[q] = gl_mul(x[q], sc);
+        }
+      }
+    } else {
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       const u32 m = base_low | ((u32)q << LO);
@@ -271,6 +295,7 @@ __global__ __launch_bounds__(NTT2_THREADS) void ntt2_pass_kernel(Ntt2Params p) {
         v = gl_mul(v, s);
       }
       x[q] = v;
+    }
     }
     dft_regs<4, INV>(x);
     __syncthreads();  // W table complete
