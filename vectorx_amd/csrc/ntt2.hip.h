@@ -151,6 +151,7 @@ struct Ntt2Params {
   int log_n, b_lo;
   const u64 *root_lo, *root_hi;
   const u64* pre;  // [z][2^(log_n-pre_bits) + 2^pre_bits] or null
+  const u64* pre_beta;  // [z][16]: shift_z^(q * n/16), behind the slices of `pre`
   int pre_bits;
   u64 post_scale;
   // nz_fold > 0: the coset (z) dimension is folded into blockIdx.x so that the nz blocks that read the SAME
@@ -264,13 +265,15 @@ __global__ __launch_bounds__(NTT2_THREADS) void ntt2_pass_kernel(Ntt2Params p) {
         x[q + 8] = gl_canon(v.y);
       }
       if constexpr (PRE) {
+        // shift^j for j = ((base_low | q << LO) << b_lo) | l  =  shift^j0 * (shift^(n/16))^q: one composed table
+        // product per thread, then the 16 per-coset factors, which are wave-uniform (scalar loads)
         const u64* pre = p.pre + (size_t)bz * (((size_t)1 << (p.log_n - p.pre_bits)) + ((size_t)1 << p.pre_bits));
+        const u64* __restrict__ beta = p.pre_beta + (size_t)bz * 16;
+        const size_t j0 = ((size_t)base_low << p.b_lo) | l;
+        const u64 c0 = gl_mul(pre[j0 >> p.pre_bits], pre[((size_t)1 << (p.log_n - p.pre_bits)) + (j0 & (((size_t)1 << p.pre_bits) - 1))]);
+        x[0] = gl_mul(x[0], c0);
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const size_t j = ((size_t)(base_low | ((u32)q << LO)) << p.b_lo) | l;
-          const u64 sc = gl_mul(pre[j >> p.pre_bits], pre[((size_t)1 << (p.log_n - p.pre_bits)) + (j & (((size_t)1 << p.pre_bits) - 1))]);
-          x[q] = gl_mul(x[q], sc);
-        }
+        for (int q = 1; q < 16; ++q) x[q] = gl_mul(x[q], gl_mul(c0, beta[q]));
       }
     } else {
 #pragma unroll

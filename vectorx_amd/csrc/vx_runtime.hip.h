@@ -261,6 +261,7 @@ static hipError_t launch_ntt2_pass(const NttPass& ps, const NttPassParams& p, di
   q.root_lo = p.root_lo;
   q.root_hi = p.root_hi;
   q.pre = p.pre;
+  q.pre_beta = p.pre ? p.pre + (size_t)grid.z * (((size_t)1 << (p.log_n - p.pre_bits)) + ((size_t)1 << p.pre_bits)) : nullptr;
   q.pre_bits = p.pre_bits;
   q.post_scale = p.post_scale;
   q.nz_fold = 0;
@@ -285,7 +286,15 @@ static int build_scale_tables(vx_ctx* c, int log_n, int bits, const std::vector<
                               u64** dptr_out) {
   using namespace vxh;
   size_t nh = (size_t)1 << (log_n - bits), nl = (size_t)1 << bits;
-  std::vector<u64> host(shifts.size() * (nh + nl));
+  // after the per-slice [hi][lo] tables: 16 entries per slice, shift^(q * n/16) — the factor between the 16 operands
+  // of a first-round radix-16 DFT (ntt2.hip.h), so that a thread composes ONE table product and walks these
+  std::vector<u64> host(shifts.size() * (nh + nl + 16));
+  for (size_t z = 0; z < shifts.size(); ++z) {
+    u64* beta = &host[shifts.size() * (nh + nl) + z * 16];
+    const u64 b1 = log_n >= 4 ? pow(shifts[z], (u64)1 << (log_n - 4)) : 1;
+    beta[0] = 1;
+    for (int q = 1; q < 16; ++q) beta[q] = mul(beta[q - 1], b1);
+  }
   for (size_t z = 0; z < shifts.size(); ++z) {
     u64* hi = &host[z * (nh + nl)];
     u64* lo = hi + nh;
