@@ -317,26 +317,36 @@ __global__ __launch_bounds__(NTT2_THREADS) void ntt2_pass_kernel(Ntt2Params p) {
   if constexpr (STRIDED) {
     // straight to global, with the inter-pass ("four-step") twiddle w_{2^span}^(l * rev(m'))
     constexpr u32 n_groups = 1u << (NTT2_TILE_LOG - EL);
+    // w^(l * rev(m0 | q)) = w^(l * rev(m0)) * (w^(l * 2^(R-EL)))^rev_EL(q): l belongs to the thread (t does not change
+    // over the loop), so the 2^EL - 1 step factors are composed once per thread and every group costs ONE table
+    // composition (two gathers) instead of 2^EL of them
+    const u32 t = threadIdx.x & ((1u << T_LOG) - 1);
+    const u64 l = (base & (((size_t)1 << p.b_lo) - 1)) + t;
+    auto root_at = [&](u64 ex) {
+      u32 e = (u32)((ex & (((u64)1 << span_log) - 1)) << (ROOT_TABLE_LOG - span_log));
+      if (INV) e = ((1u << ROOT_TABLE_LOG) - e) & ((1u << ROOT_TABLE_LOG) - 1);
+      return root_pow24(p.root_lo, p.root_hi, e);
+    };
+    u64 step[1 << EL];
+#pragma unroll
+    for (int k = 1; k < (1 << EL); ++k) step[k] = root_at(l * ((u64)k << (R_LOG - EL)));
 #pragma unroll
     for (u32 g0 = 0; g0 < n_groups; g0 += NTT2_THREADS) {
       const u32 g = g0 + threadIdx.x;
-      const u32 t = g & ((1u << T_LOG) - 1);
       const u32 base_high = g >> T_LOG;
       const u32 m0 = base_high << EL;
       u64 x[1 << EL];
 #pragma unroll
       for (int q = 0; q < (1 << EL); ++q) x[q] = tile[tile_idx<R_LOG, true>(m0 | (u32)q, t)];
       dft_regs<EL, INV>(x);
-      const u64 l = (base & (((size_t)1 << p.b_lo) - 1)) + t;
+      u64 tw0 = root_at(l * (u64)bitrev32(m0, R_LOG));
+      if (p.post_scale != 1) tw0 = gl_mul(tw0, p.post_scale);
 #pragma unroll
       for (int q = 0; q < (1 << EL); ++q) {
         const u32 m = m0 | (u32)q;
-        const u64 ex = (l * (u64)bitrev32(m, R_LOG)) & (((u64)1 << span_log) - 1);
-        u32 e = (u32)(ex << (ROOT_TABLE_LOG - span_log));
-        if (INV) e = ((1u << ROOT_TABLE_LOG) - e) & ((1u << ROOT_TABLE_LOG) - 1);
-        u64 v = gl_mul(x[q], root_pow24(p.root_lo, p.root_hi, e));
-        if (p.post_scale != 1) v = gl_mul(v, p.post_scale);
-        out[base + ((size_t)m << p.b_lo) + t] = v;
+        const u32 k = rev_c<EL>((u32)q);
+        const u64 tw = k ? gl_mul(tw0, step[k]) : tw0;
+        out[base + ((size_t)m << p.b_lo) + t] = gl_mul(x[q], tw);
       }
     }
   } else {
