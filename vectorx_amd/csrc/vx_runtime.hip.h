@@ -361,7 +361,9 @@ static int run_ntt(vx_ctx* c, const u64* in, u64* out, size_t in_col_stride, siz
     p.root_hi = c->root_hi;
     p.pre = first ? pre : nullptr;
     p.pre_bits = pre_bits;
-    p.post_scale = last ? post_scale : 1;
+    // the scale commutes with the passes: in a multi-pass transform it rides on the FIRST (strided) pass, where it is
+    // folded into the inter-pass twiddle for free, instead of costing a multiply per element in the last pass
+    p.post_scale = (plan.size() > 1 ? first : last) ? post_scale : 1;
     size_t tile = (size_t)1 << (ps_.r_log + ps_.t_log);
     size_t lds = (tile + (tile >> 5) + (tile >> 9) + 1 + ((size_t)1 << (ps_.r_log - 1 > 0 ? ps_.r_log - 1 : 0))) * 8 + 16;
     dim3 grid((unsigned)((size_t)1 << (log_n - ps_.r_log - ps_.t_log)), (unsigned)ncols, (unsigned)nz);
