@@ -352,10 +352,10 @@ __global__ __launch_bounds__(NTT2_THREADS) void ntt2_pass_kernel(Ntt2Params p) {
   } else {
     ntt2_round_lds<R_LOG, 0, EL, false, INV>(tile, W);
     __syncthreads();
-    for (u32 idx = threadIdx.x; idx < TILE; idx += NTT2_THREADS) {
-      u64 v = tile[lds_pad(idx)];
-      if (p.post_scale != 1) v = gl_mul(v, p.post_scale);
-      out[base + idx] = v;
+    for (u32 idx = threadIdx.x * 2; idx < TILE; idx += NTT2_THREADS * 2) {  // 16 bytes per lane
+      u64 v0 = tile[lds_pad(idx)], v1 = tile[lds_pad(idx + 1)];
+      if (p.post_scale != 1) v0 = gl_mul(v0, p.post_scale), v1 = gl_mul(v1, p.post_scale);
+      *reinterpret_cast<ulonglong2*>(out + base + idx) = make_ulonglong2(v0, v1);
     }
   }
 }
