@@ -111,11 +111,11 @@ static int batch_alloc(vx_ctx* c, int log_n, size_t ncols, int rate_bits, int ca
   return VX_OK;
 }
 
-// coefficients (bit-reversed, device) -> LDE -> leaf digests -> Merkle levels
-static int batch_lde_and_tree(vx_ctx* c, vx_batch* b) {
+// coefficients (bit-reversed, device) -> LDE of the columns [col0, col0 + ncols)
+static int batch_lde_cols(vx_ctx* c, vx_batch* b, size_t col0, size_t ncols) {
   using namespace vxh;
   const int log_n = b->log_n, rb = b->rate_bits;
-  const size_t n = (size_t)1 << log_n, N = b->rows(), m = b->ncols;
+  const size_t n = (size_t)1 << log_n, N = b->rows();
   const int nz = (1 << rb) >> b->shard_lg, z0 = nz * b->shard_rank;  // local cosets [z0, z0 + nz)
   // block z of the bit-reversed LDE holds coset r = rev_rb(z): shift 7 * w_N^r
   std::vector<u64> shifts(nz);
@@ -124,8 +124,12 @@ static int batch_lde_and_tree(vx_ctx* c, vx_batch* b) {
   int bits = log_n / 2;
   u64* tab = nullptr;
   VXCHK(get_scale_tables(c, log_n, bits, shifts, 1, &tab));
-  VXCHK(run_ntt(c, b->coeffs, b->lde, n, N, 0, n, log_n, m, nz, false, true, tab, bits, 1, "lde",
-                (double)m * 8.0 * ((double)n + (double)N)));
+  return run_ntt(c, b->coeffs + col0 * n, b->lde + col0 * N, n, N, 0, n, log_n, ncols, nz, false, true, tab, bits, 1, "lde",
+                 (double)ncols * 8.0 * ((double)n + (double)N));
+}
+// LDE -> leaf digests -> Merkle levels
+static int batch_hash_tree(vx_ctx* c, vx_batch* b) {
+  const size_t N = b->rows(), m = b->ncols;
   {
     ProfScope ps(c, "hash_leaves", (double)m * 8.0 * (double)N);
     hipLaunchKernelGGL(hash_leaves_colmajor_kernel, dim3((unsigned)((N + HASH_THREADS - 1) / HASH_THREADS)),
@@ -134,6 +138,10 @@ static int batch_lde_and_tree(vx_ctx* c, vx_batch* b) {
   }
   VXCHK(build_merkle_levels(c, b->tree, N, b->local_cap_height(), &b->cap_off));
   return VX_OK;
+}
+static int batch_lde_and_tree(vx_ctx* c, vx_batch* b) {
+  VXCHK(batch_lde_cols(c, b, 0, b->ncols));
+  return batch_hash_tree(c, b);
 }
 
 static int batch_commit_device(vx_ctx* c, vx_batch* b, const u64* src, size_t n, bool is_coeffs) {

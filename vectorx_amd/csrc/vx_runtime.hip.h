@@ -49,6 +49,7 @@ struct ProfPending {
 struct vx_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t copy_stream = nullptr;  // host->device witness upload, overlapped with the first transforms (prover.hip.h)
   u64* root_lo = nullptr;  // w_{2^24}^k
   u64* root_hi = nullptr;  // w_{2^24}^(4096k)
   bool prof_on = false;

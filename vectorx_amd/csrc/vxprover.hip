@@ -68,6 +68,7 @@ void vx_ctx_destroy(vx_ctx* c) {
   for (auto& kv : c->live_blocks) hipFree(kv.first);
   hipFree(c->root_lo);
   hipFree(c->root_hi);
+  if (c->copy_stream) hipStreamDestroy(c->copy_stream);
   hipStreamDestroy(c->stream);
   delete c;
 }
