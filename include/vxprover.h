@@ -109,7 +109,9 @@ int vx_field_op(vx_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, uint6
  * (is_coeffs = 1: coefficients, natural order).  cols: column-major [ncols][2^log_n]; src_on_device
  * selects whether `cols` is a host pointer or a device pointer obtained from vx_dev_alloc.
  * Afterwards the batch owns device copies of the coefficients, the 2^rate_bits blow-up LDE on the
- * coset 7*H' in bit-reversed row order, all leaf digests and the Merkle tree down to the cap. */
+ * coset 7*H' in bit-reversed row order, all leaf digests and the Merkle tree down to the cap.
+ * A host matrix is uploaded in column blocks on a second stream while the transforms of the previous block run
+ * (vx_prove does the same with a host witness), so the PCIe transfer is almost entirely hidden. */
 int vx_batch_commit(vx_ctx* ctx, const uint64_t* cols, int src_on_device, int log_n, size_t ncols, int rate_bits,
                     int cap_height, int is_coeffs, vx_batch** out);
 void vx_batch_free(vx_batch* b);

@@ -160,6 +160,43 @@ static int batch_commit_device(vx_ctx* c, vx_batch* b, const u64* src, size_t n,
   return batch_lde_and_tree(c, b);
 }
 
+// The same from a HOST matrix, with the upload hidden: the matrix crosses PCIe in 16-column blocks on the context's
+// copy stream while the interpolation (or bit-reversal) and coset extension of the previous block run on the main
+// stream — columns are independent polynomials; only the leaf hashing needs them all.  The host loop is "copy k,
+// launch k", so the overlap also happens with pageable memory, whose asynchronous copies block the host.
+// `dev` ([m][n], caller-owned) receives the uploaded matrix.
+static int batch_commit_host(vx_ctx* c, vx_batch* b, const u64* host, u64* dev, bool is_coeffs) {
+  using namespace vxh;
+  const size_t n = b->n(), m = b->ncols;
+  if (!c->copy_stream) HIPCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+  HIPCHK(hipStreamSynchronize(c->stream));  // `dev` and the batch buffers may be recycled blocks the main stream still owns
+  const size_t block = 16, nblocks = (m + block - 1) / block;
+  std::vector<hipEvent_t> ev(nblocks, nullptr);
+  const u64 ninv = inv((u64)n % P);
+  int rc = VX_OK;
+  for (size_t bk = 0; bk < nblocks && rc == VX_OK; ++bk) {
+    const size_t c0 = bk * block, nc = std::min(block, m - c0);
+    if (hipEventCreateWithFlags(&ev[bk], hipEventDisableTiming) != hipSuccess ||
+        hipMemcpyAsync(dev + c0 * n, host + c0 * n, nc * n * 8, hipMemcpyHostToDevice, c->copy_stream) != hipSuccess ||
+        hipEventRecord(ev[bk], c->copy_stream) != hipSuccess || hipStreamWaitEvent(c->stream, ev[bk], 0) != hipSuccess)
+      rc = vx_fail(VX_E_HIP, "upload of a column block failed");
+    if (rc == VX_OK && is_coeffs) {
+      ProfScope ps(c, "bitrev_permute", 16.0 * (double)n * (double)nc);
+      hipLaunchKernelGGL(bitrev_permute_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)nc), dim3(256), 0, c->stream, dev + c0 * n,
+                         b->coeffs + c0 * n, b->log_n, n, n);
+    } else if (rc == VX_OK) {
+      rc = run_ntt(c, dev + c0 * n, b->coeffs + c0 * n, n, n, 0, 0, b->log_n, nc, 1, true, false, nullptr, 0, ninv, "intt",
+                   16.0 * (double)n * (double)nc);
+    }
+    if (rc == VX_OK) rc = batch_lde_cols(c, b, c0, nc);
+  }
+  hipStreamSynchronize(c->copy_stream);
+  for (hipEvent_t e : ev)
+    if (e) hipEventDestroy(e);
+  VXCHK(rc);
+  return batch_hash_tree(c, b);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Evaluation of every column at an extension point (plonk/proof.rs OpeningSet::new ->
 // PolynomialCoeffs::to_extension().eval(zeta)).  Coefficients are in bit-reversed order, so the

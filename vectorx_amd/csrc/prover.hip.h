@@ -286,35 +286,13 @@ static int prove_impl(vx_ctx* c, vx_circuit* k, const u64* wires_in, bool wires_
   bool wires_committed = false;
   std::vector<u64> public_inputs(k->pi_rows.size());
   if (!wires_on_device && sh.world == 1 && !getenv("VX_NO_UPLOAD_OVERLAP")) {
-    // Host witness, one GPU: the upload (2.27 GB at n = 2^21, ~40 ms over PCIe) is cut into column blocks on a second
-    // stream, and the interpolation + coset extension of block k run while block k+1 is in flight — columns are
-    // independent polynomials; only the leaf hashing needs all of them.  The host side is interleaved (copy k, then
-    // launch k) so that the overlap also happens with pageable memory, whose "async" copies block the host.
-    if (!c->copy_stream) HIPCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    // Host witness, one GPU: the upload (2.27 GB at n = 2^21, ~40 ms over PCIe) is hidden behind the interpolation and
+    // coset extension of the wires (batch_commit_host)
     u64* w = S.get((size_t)k->num_wires * n);
     if (!w) return vx_fail(VX_E_NOMEM, "prove: out of device memory (witness)");
     for (size_t i = 0; i < public_inputs.size(); ++i) public_inputs[i] = wires_in[(size_t)k->pi_cols[i] * n + k->pi_rows[i]];
     VXCHK(batch_alloc(c, lg, k->num_wires, rb, k->cap_height, &wires_b, 0, 0));
-    HIPCHK(hipStreamSynchronize(c->stream));  // w and the batch buffers may be recycled blocks the main stream still owns
-    const size_t block = 16, nblocks = ((size_t)k->num_wires + block - 1) / block;
-    std::vector<hipEvent_t> ev(nblocks);
-    const u64 ninv = inv((u64)n % P);
-    int rc = VX_OK;
-    for (size_t bk = 0; bk < nblocks && rc == VX_OK; ++bk) {
-      const size_t c0 = bk * block, nc = std::min(block, (size_t)k->num_wires - c0);
-      hipEventCreateWithFlags(&ev[bk], hipEventDisableTiming);
-      if (hipMemcpyAsync(w + c0 * n, wires_in + c0 * n, nc * n * 8, hipMemcpyHostToDevice, c->copy_stream) != hipSuccess ||
-          hipEventRecord(ev[bk], c->copy_stream) != hipSuccess || hipStreamWaitEvent(c->stream, ev[bk], 0) != hipSuccess)
-        rc = vx_fail(VX_E_HIP, "prove: witness upload failed");
-      if (rc == VX_OK)
-        rc = run_ntt(c, w + c0 * n, wires_b->coeffs + c0 * n, n, n, 0, 0, lg, nc, 1, true, false, nullptr, 0, ninv, "intt", 16.0 * (double)n * (double)nc);
-      if (rc == VX_OK) rc = batch_lde_cols(c, wires_b, c0, nc);
-    }
-    hipStreamSynchronize(c->copy_stream);
-    for (size_t bk = 0; bk < nblocks; ++bk)
-      if (ev[bk]) hipEventDestroy(ev[bk]);
-    VXCHK(rc);
-    VXCHK(batch_hash_tree(c, wires_b));
+    VXCHK(batch_commit_host(c, wires_b, wires_in, w, false));
     d_wires = w;
     wires_committed = true;
   } else if (!wires_on_device) {

@@ -316,15 +316,19 @@ int vx_batch_commit(vx_ctx* c, const uint64_t* cols, int src_on_device, int log_
   int rc = batch_alloc(c, log_n, ncols, rate_bits, cap_height, &b);
   if (rc) return rc;
   size_t n = (size_t)1 << log_n;
-  const u64* src = cols;
   u64* staging = nullptr;
-  if (!src_on_device) {
-    // stage the host matrix in the LDE buffer's tail?  Keep it simple: separate staging buffer.
+  if (src_on_device) {
+    rc = batch_commit_device(c, b, cols, n, is_coeffs != 0);
+  } else {
     if (hipMalloc(&staging, n * ncols * 8) != hipSuccess) { vx_batch_free(b); return vx_fail(VX_E_NOMEM, "vx_batch_commit: staging alloc failed"); }
-    if (hipMemcpyAsync(staging, cols, n * ncols * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess) { hipFree(staging); vx_batch_free(b); return vx_fail(VX_E_HIP, "vx_batch_commit: upload failed"); }
-    src = staging;
+    if (!getenv("VX_NO_UPLOAD_OVERLAP")) {
+      rc = batch_commit_host(c, b, cols, staging, is_coeffs != 0);  // the upload is hidden behind the transforms
+    } else if (hipMemcpyAsync(staging, cols, n * ncols * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess) {
+      rc = vx_fail(VX_E_HIP, "vx_batch_commit: upload failed");
+    } else {
+      rc = batch_commit_device(c, b, staging, n, is_coeffs != 0);
+    }
   }
-  rc = batch_commit_device(c, b, src, n, is_coeffs != 0);
   hipError_t e = hipStreamSynchronize(c->stream);
   if (staging) hipFree(staging);
   if (rc == VX_OK && e != hipSuccess) rc = vx_fail(VX_E_HIP, "vx_batch_commit: %s", hipGetErrorString(e));
