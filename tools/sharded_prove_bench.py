@@ -5,7 +5,7 @@ lock and gives it up inside every all-gather, so each rank's busy time is what i
 i.e. the per-rank COMPUTE latency of the sharded proof on a real G-GPU node.  The exchanges themselves (device-local
 copies here) are not representative; their volume is reported instead so the xGMI time can be bounded.
 
-usage: python tools/sharded_prove_bench.py [degree_bits] [worlds, e.g. 1,2,4,8]
+usage: python tools/sharded_prove_bench.py [degree_bits] [worlds, e.g. 1,2,4,8] [dev]      ("dev": witness already in HBM)
 """
 import ctypes
 import json
@@ -19,7 +19,7 @@ import vectorx_amd as vx  # noqa: E402
 from vectorx_amd.synth import SynthCircuit  # noqa: E402
 
 
-def run(sc, w, world, reps=2):
+def run(sc, w, world, reps=2, dev_witness=False):
     L = vx.lib()
     ctxs = [vx.Context(0) for _ in range(world)]
     circuits = [vx.Circuit(c, sc.desc_ptr) for c in ctxs]
@@ -36,6 +36,10 @@ def run(sc, w, world, reps=2):
     xcalls = [0] * world
     proofs = [None] * world
     ctxs[0].prof_enable(True)
+    d_w = None
+    if dev_witness:            # one copy in HBM, visible to every context of this GPU
+        d_w = ctxs[0].alloc(w.nbytes)
+        ctxs[0].upload(d_w, w)
 
     def rank_main(r):
         for rep in range(reps):
@@ -58,7 +62,7 @@ def run(sc, w, world, reps=2):
             turn.acquire()
             state["t"] = time.perf_counter()
             try:
-                proofs[r] = circuits[r].prove_sharded(w, r, world, ag if world > 1 else None)
+                proofs[r] = circuits[r].prove_sharded(None if dev_witness else w, r, world, ag if world > 1 else None, dev_ptr=d_w)
             finally:
                 busy[rep][r] += time.perf_counter() - state["t"]
                 turn.release()
@@ -69,6 +73,8 @@ def run(sc, w, world, reps=2):
     for t in ts:
         t.join()
     prof = ctxs[0].prof()
+    if d_w is not None:
+        ctxs[0].free(d_w)
     L.vx_group_destroy(g)
     for c in circuits:
         c.free()
@@ -80,16 +86,17 @@ def run(sc, w, world, reps=2):
 def main():
     db = int(sys.argv[1]) if len(sys.argv) > 1 else 21
     worlds = [int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "1,2,4,8").split(",")]
+    dev = len(sys.argv) > 3 and sys.argv[3] == "dev"
     sc = SynthCircuit(db, seed=0, poseidon_percent=50)
     w = sc.witness()
     ref = None
     for world in worlds:
-        proofs, busy, xb, xc, prof = run(sc, w, world)
+        proofs, busy, xb, xc, prof = run(sc, w, world, dev_witness=dev)
         if ref is None:
             ref = proofs[0]
         same = all(p == ref for p in proofs)
         stages = {k: round(v["ms"], 2) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:12]}
-        print(json.dumps({"degree_bits": db, "world": world, "identical_to_first": same,
+        print(json.dumps({"degree_bits": db, "world": world, "witness": "hbm" if dev else "host", "identical_to_first": same,
                           "per_rank_busy_ms": [round(b * 1e3, 1) for b in busy], "max_busy_ms": round(max(busy) * 1e3, 1),
                           "exchange_calls": xc[0], "exchange_bytes_in_per_rank": xb[0], "rank0_stage_ms": stages}), flush=True)
 
