@@ -162,6 +162,45 @@ constexpr u64 POSEIDON_FAST_W_HATS_RAW[22][11] = VX_FAST_PARTIAL_W_HATS_INIT;
 __constant__ Limbs3Table<11, 11> POSEIDON_FAST_INIT3 = make_limbs3<11, 11>(POSEIDON_FAST_INIT_RAW);
 __constant__ Limbs3Table<22, 11> POSEIDON_FAST_W_HATS3 = make_limbs3<22, 11>(POSEIDON_FAST_W_HATS_RAW);
 
+// Blocked partial rounds: inside a block of PB rounds the 11 passive lanes are NOT updated; round r's dot product is
+// taken on the block's starting state plus cross terms y_q * KK[r][q] (y_q = the S-box outputs of the block's earlier
+// rounds, KK[r][q] = sum_i w_hat_r[i] v_q[i]), and the lanes are brought up to date once per block with an 11-term
+// dot product each.  That trades the 11 multiply-add-reduce per round for carry-free multiply-adds.
+#ifndef POSEIDON_PB
+#define POSEIDON_PB 5
+#endif
+constexpr u64 gl_mulmod_const(u64 a, u64 b) { return (u64)(((unsigned __int128)a * b) % (unsigned __int128)GL_P); }
+constexpr u64 POSEIDON_FAST_VS_RAW[22][11] = VX_FAST_PARTIAL_VS_INIT;
+struct PoseidonBlockTables {
+  Limbs3x2 kk[22][POSEIDON_PB];  // kk[r][q]: cross term of round r with the q-th round of its block (q < r - block start)
+  Limbs3x2 vs[22][11];           // v_r[i]
+};
+constexpr Limbs3x2 make_limbs3x2(u64 b) {
+  Limbs3x2 t{};
+  const u64 bh = gl_mul_2_32_const(b);
+  t.lo[0] = (u32)(b & 0x3FFFFFu), t.lo[1] = (u32)((b >> 22) & 0x3FFFFFu), t.lo[2] = (u32)(b >> 44);
+  t.hi[0] = (u32)(bh & 0x3FFFFFu), t.hi[1] = (u32)((bh >> 22) & 0x3FFFFFu), t.hi[2] = (u32)(bh >> 44);
+  return t;
+}
+constexpr PoseidonBlockTables make_block_tables() {
+  PoseidonBlockTables t{};
+  for (int r = 0; r < 22; ++r) {
+    const int r0 = (r / POSEIDON_PB) * POSEIDON_PB;
+    for (int q = 0; q < POSEIDON_PB; ++q) {
+      u64 acc = 0;
+      if (r0 + q < r)
+        for (int i = 0; i < 11; ++i) {
+          const u64 term = gl_mulmod_const(POSEIDON_FAST_W_HATS_RAW[r][i] % GL_P, POSEIDON_FAST_VS_RAW[r0 + q][i] % GL_P);
+          acc = (u64)(((unsigned __int128)acc + term) % (unsigned __int128)GL_P);
+        }
+      t.kk[r][q] = make_limbs3x2(acc);
+    }
+    for (int i = 0; i < 11; ++i) t.vs[r][i] = make_limbs3x2(POSEIDON_FAST_VS_RAW[r][i] % GL_P);
+  }
+  return t;
+}
+__constant__ PoseidonBlockTables POSEIDON_BLOCK = make_block_tables();
+
 struct dot3 {
   u64 s0, s1, s2;
 };
@@ -177,6 +216,11 @@ GLD void dot3_mac(dot3& D, u64 a, const Limbs3x2& b) {
 GLD u64 dot3_reduce_nc(const dot3& D) {
   typedef unsigned __int128 u128;
   const u128 V = (u128)D.s0 + ((u128)D.s1 << 22) + ((u128)D.s2 << 44);  // < 2^104
+  return gl_reduce128_nc((u64)V, (u64)(V >> 64));
+}
+GLD u64 dot3_reduce_add_nc(const dot3& D, u64 addend) {
+  typedef unsigned __int128 u128;
+  const u128 V = (u128)D.s0 + ((u128)D.s1 << 22) + ((u128)D.s2 << 44) + (u128)addend;
   return gl_reduce128_nc((u64)V, (u64)(V >> 64));
 }
 
@@ -204,15 +248,32 @@ GLD void poseidon_permute_nc(u64 (&s)[12]) {
     for (int r = 0; r < 11; ++r) s[1 + r] = t[r];
   }
 #pragma unroll 1
-  for (int r = 0; r < 22; ++r) {
-    const u64 s0 = gl_add_nc_c(poseidon_sbox_nc(s[0]), POSEIDON_FAST_K[r]);
-    // M[0][0] = CIRC[0] + DIAG[0] = 25:  25 s0 = 25 lo(s0) + 2^22 * (25 * 2^10) hi(s0)
-    dot3 D = {(u64)(u32)s0 * 25u, (u64)(u32)(s0 >> 32) * 25600u, 0};
+  for (int r0 = 0; r0 < 22; r0 += POSEIDON_PB) {
+    const int nb = 22 - r0 < POSEIDON_PB ? 22 - r0 : POSEIDON_PB;  // the last block may be shorter
+    u64 y[POSEIDON_PB];
 #pragma unroll
-    for (int i = 0; i < 11; ++i) dot3_mac(D, s[1 + i], POSEIDON_FAST_W_HATS3.v[r][i]);
+    for (int j = 0; j < POSEIDON_PB; ++j) {
+      y[j] = 0;
+      if (j < nb) {
+        const u64 yj = gl_add_nc_c(poseidon_sbox_nc(s[0]), POSEIDON_FAST_K[r0 + j]);
+        y[j] = yj;
+        // M[0][0] = CIRC[0] + DIAG[0] = 25:  25 y = 25 lo(y) + 2^22 * (25 * 2^10) hi(y)
+        dot3 D = {(u64)(u32)yj * 25u, (u64)(u32)(yj >> 32) * 25600u, 0};
 #pragma unroll
-    for (int i = 0; i < 11; ++i) s[1 + i] = gl_mad_nc(s0, POSEIDON_FAST_VS[r][i], s[1 + i]);
-    s[0] = dot3_reduce_nc(D);
+        for (int i = 0; i < 11; ++i) dot3_mac(D, s[1 + i], POSEIDON_FAST_W_HATS3.v[r0 + j][i]);
+#pragma unroll
+        for (int q = 0; q < j; ++q) dot3_mac(D, y[q], POSEIDON_BLOCK.kk[r0 + j][q]);
+        s[0] = dot3_reduce_nc(D);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 11; ++i) {
+      dot3 D = {0, 0, 0};
+#pragma unroll
+      for (int j = 0; j < POSEIDON_PB; ++j)
+        if (j < nb) dot3_mac(D, y[j], POSEIDON_BLOCK.vs[r0 + j][i]);
+      s[1 + i] = dot3_reduce_add_nc(D, s[1 + i]);
+    }
   }
 #pragma unroll 1
   for (int r = 26; r < 30; ++r) {
