@@ -163,6 +163,7 @@ struct QuotientParams {
   u64 zh[VX_MAX_RATE], zh_inv[VX_MAX_RATE];  // ZeroPolyOnCoset evals / inverses, indexed by coset r
   u64 n_field;                               // n mod p
   const u64* __restrict__ alpha_pows;        // [VX_MAX_CHALLENGES][VX_ALPHA_POWS]: alpha_c^i
+  const Limbs3x2* __restrict__ alpha_limbs;  // the same powers pre-split for carry-free accumulation (poseidon.hip.h dot3)
   u64* out;                                  // [nch][stride_w]
 };
 
@@ -171,12 +172,12 @@ struct QuotientParams {
 // multiply of the naive form disappears.
 #define VX_ALPHA_POWS 512
 struct AlphaAcc {
-  u64 acc[VX_MAX_CHALLENGES];
+  dot3 acc[VX_MAX_CHALLENGES];  // sum_i term_i alpha^i as three limb-class sums (<= 1024 terms: no carries, no reductions)
   int idx;
 };
 GLD void acc_push(AlphaAcc& a, const QuotientParams& p, u64 term) {
 #pragma unroll
-  for (int c = 0; c < VX_MAX_CHALLENGES; ++c) a.acc[c] = gl_mad(term, p.alpha_pows[c * VX_ALPHA_POWS + a.idx], a.acc[c]);
+  for (int c = 0; c < VX_MAX_CHALLENGES; ++c) dot3_mac(a.acc[c], term, p.alpha_limbs[c * VX_ALPHA_POWS + a.idx]);
   ++a.idx;
 }
 
@@ -203,8 +204,9 @@ __global__ __launch_bounds__(256, VX_QUOTIENT_BLOCKS) void quotient_kernel(Quoti
 
   AlphaAcc A;
 #pragma unroll
-  for (int c = 0; c < VX_MAX_CHALLENGES; ++c) A.acc[c] = 0;
+  for (int c = 0; c < VX_MAX_CHALLENGES; ++c) A.acc[c] = dot3{0, 0, 0};
   A.idx = 0;
+  u64 gates_sum[VX_MAX_CHALLENGES] = {0, 0};  // sum_g filter_g * (the gate's alpha-weighted constraints)
 
   // (1) L_0(x) (Z(x) - 1) per challenge;  eval_l_0 = Z_H(x) / (n (x - 1))
   const u64 l0 = gl_mul(p.zh[r], gl_inv(gl_mul(p.n_field, gl_sub(x, 1))));
@@ -240,7 +242,7 @@ __global__ __launch_bounds__(256, VX_QUOTIENT_BLOCKS) void quotient_kernel(Quoti
     if (p.num_selectors > 1) filter = gl_mul(filter, gl_sub(UNUSED_SELECTOR_U64, s));
     AlphaAcc G;
 #pragma unroll
-    for (int c = 0; c < VX_MAX_CHALLENGES; ++c) G.acc[c] = 0;
+    for (int c = 0; c < VX_MAX_CHALLENGES; ++c) G.acc[c] = dot3{0, 0, 0};
     G.idx = base_idx;
     const int c0 = p.num_selectors;  // gate constants start after the selectors
     if (gd.type == 1) {              // ConstantGate
@@ -316,10 +318,10 @@ __global__ __launch_bounds__(256, VX_QUOTIENT_BLOCKS) void quotient_kernel(Quoti
       for (int q = 0; q < 12; ++q) acc_push(G, p, gl_sub_nc_c(st[q], WIRE(12 + q)));
     }
 #pragma unroll
-    for (int c = 0; c < VX_MAX_CHALLENGES; ++c) A.acc[c] = gl_mad(filter, G.acc[c], A.acc[c]);
+    for (int c = 0; c < VX_MAX_CHALLENGES; ++c) gates_sum[c] = gl_mad(filter, dot3_reduce_nc(G.acc[c]), gates_sum[c]);
   }
   const u64 zi = p.zh_inv[r];
-  for (int ch = 0; ch < p.nch; ++ch) p.out[(size_t)ch * SW + il] = gl_mul(A.acc[ch], zi);
+  for (int ch = 0; ch < p.nch; ++ch) p.out[(size_t)ch * SW + il] = gl_mul(gl_add(gl_canon(dot3_reduce_nc(A.acc[ch])), gates_sum[ch]), zi);
 #undef CS
 #undef WIRE
 #undef ZS

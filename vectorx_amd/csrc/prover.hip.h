@@ -425,6 +425,17 @@ static int prove_impl(vx_ctx* c, vx_circuit* k, const u64* wires_in, bool wires_
         if (!d_ap) return vx_fail(VX_E_NOMEM, "prove: out of device memory (alpha powers)");
         HIPCHK(hipMemcpy(d_ap, ap.data(), ap.size() * 8, hipMemcpyHostToDevice));
         qp.alpha_pows = d_ap;
+        // the same powers split for the quotient kernel's carry-free accumulation: limbs of a and of 2^32 a
+        std::vector<Limbs3x2> al(ap.size());
+        for (size_t i = 0; i < ap.size(); ++i) {
+          const u64 bb = ap[i], bh = mul(bb, (u64)1 << 32);
+          al[i].lo[0] = (u32)(bb & 0x3FFFFFu), al[i].lo[1] = (u32)((bb >> 22) & 0x3FFFFFu), al[i].lo[2] = (u32)(bb >> 44);
+          al[i].hi[0] = (u32)(bh & 0x3FFFFFu), al[i].hi[1] = (u32)((bh >> 22) & 0x3FFFFFu), al[i].hi[2] = (u32)(bh >> 44);
+        }
+        Limbs3x2* d_al = (Limbs3x2*)S.get((al.size() * sizeof(Limbs3x2) + 7) / 8);
+        if (!d_al) return vx_fail(VX_E_NOMEM, "prove: out of device memory (alpha powers)");
+        HIPCHK(hipMemcpy(d_al, al.data(), al.size() * sizeof(Limbs3x2), hipMemcpyHostToDevice));
+        qp.alpha_limbs = d_al;
       }
       qp.out = qv;
       size_t bytes_read = 8ull * Nl * ((size_t)k->num_constants + k->nr + k->num_wires + (size_t)nch * (2 + npp));
