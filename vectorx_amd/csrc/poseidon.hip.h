@@ -224,15 +224,13 @@ GLD u64 dot3_reduce_add_nc(const dot3& D, u64 addend) {
   return gl_reduce128_nc((u64)V, (u64)(V >> 64));
 }
 
-// Permutation on arbitrary-u64 lanes; outputs are arbitrary u64 representatives (NOT canonical).
-GLD void poseidon_permute_nc(u64 (&s)[12]) {
-#pragma unroll 1
-  for (int r = 0; r < 4; ++r) {
-#pragma unroll
-    for (int i = 0; i < 12; ++i) s[i] = poseidon_sbox_nc(gl_add_nc_c(s[i], POSEIDON_RC[r * 12 + i]));
-    poseidon_mds_nc(s);
-  }
-  // ---- partial rounds, fast form ----
+// The 22 partial rounds (fast form, blocks of POSEIDON_PB).  `lane0(r, x)` is handed the S-box INPUT x of partial round r
+// and returns the value that actually goes through the S-box: the identity for the permutation.  (A PoseidonGate
+// evaluation could pass the wire the gate constrains to equal x — the recurrences are linear in everything but the
+// S-box outputs — and that is byte-identical, but in the quotient kernel the extra live registers cost more than the
+// dense MDS it saves: 23.7 -> 27.1 ms, so the gate keeps the naive rounds.)
+template <class F>
+GLD void poseidon_partial_rounds_nc(u64 (&s)[12], F&& lane0) {
 #pragma unroll
   for (int i = 0; i < 12; ++i) s[i] = gl_add_nc_c(s[i], POSEIDON_FAST_FIRST[i]);
   {
@@ -255,7 +253,7 @@ GLD void poseidon_permute_nc(u64 (&s)[12]) {
     for (int j = 0; j < POSEIDON_PB; ++j) {
       y[j] = 0;
       if (j < nb) {
-        const u64 yj = gl_add_nc_c(poseidon_sbox_nc(s[0]), POSEIDON_FAST_K[r0 + j]);
+        const u64 yj = gl_add_nc_c(poseidon_sbox_nc(lane0(r0 + j, s[0])), POSEIDON_FAST_K[r0 + j]);
         y[j] = yj;
         // M[0][0] = CIRC[0] + DIAG[0] = 25:  25 y = 25 lo(y) + 2^22 * (25 * 2^10) hi(y)
         dot3 D = {(u64)(u32)yj * 25u, (u64)(u32)(yj >> 32) * 25600u, 0};
@@ -275,6 +273,17 @@ GLD void poseidon_permute_nc(u64 (&s)[12]) {
       s[1 + i] = dot3_reduce_add_nc(D, s[1 + i]);
     }
   }
+}
+
+// Permutation on arbitrary-u64 lanes; outputs are arbitrary u64 representatives (NOT canonical).
+GLD void poseidon_permute_nc(u64 (&s)[12]) {
+#pragma unroll 1
+  for (int r = 0; r < 4; ++r) {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) s[i] = poseidon_sbox_nc(gl_add_nc_c(s[i], POSEIDON_RC[r * 12 + i]));
+    poseidon_mds_nc(s);
+  }
+  poseidon_partial_rounds_nc(s, [](int, u64 x) { return x; });
 #pragma unroll 1
   for (int r = 26; r < 30; ++r) {
 #pragma unroll
