@@ -150,7 +150,7 @@ def main():
             ms = hl["ms"] / args.steps
             alu = {"kernel": "hash_leaves_colmajor_kernel", "bound": "integer ALU (VALU issue)", "perms_per_proof": perms,
                    "ms_per_proof": round(ms, 2), "gperms_per_s": round(perms / (ms * 1e-3) / 1e9, 3),
-                   "valu_insts_per_perm": 18805, "source": "profiles/r01_pmc_sq.md (SQ_INSTS_VALU / permutations) + DESIGN.md §3"}
+                   "valu_insts_per_perm": 17446, "source": "profiles/r01_pmc_sq.md (SQ_INSTS_VALU / permutations) + DESIGN.md §3"}
         sharded_mode = args.mode == "sharded" and world > 1 and args.workload == "prove"
         agg = H.aggregate(1 if sharded_mode else world, args.steps, dt)   # sharded: the N ranks finish ONE proof per step
         out = {
