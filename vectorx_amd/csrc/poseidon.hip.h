@@ -22,9 +22,6 @@
 __constant__ u64 POSEIDON_RC[VX_POSEIDON_N_ROUND_CONSTANTS] = VX_POSEIDON_ROUND_CONSTANTS_INIT;
 __constant__ u64 POSEIDON_FAST_FIRST[12] = VX_FAST_PARTIAL_FIRST_ROUND_CONSTANT_INIT;
 __constant__ u64 POSEIDON_FAST_K[22] = VX_FAST_PARTIAL_ROUND_CONSTANTS_INIT;
-__constant__ u64 POSEIDON_FAST_INIT[11][11] = VX_FAST_PARTIAL_INITIAL_MATRIX_INIT;
-__constant__ u64 POSEIDON_FAST_W_HATS[22][11] = VX_FAST_PARTIAL_W_HATS_INIT;
-__constant__ u64 POSEIDON_FAST_VS[22][11] = VX_FAST_PARTIAL_VS_INIT;
 
 #define POSEIDON_WIDTH 12
 #define POSEIDON_RATE 8
@@ -96,34 +93,6 @@ GLD void poseidon_mds(u64 (&s)[12]) {
   poseidon_mds_nc(s);
 #pragma unroll
   for (int i = 0; i < 12; ++i) s[i] = gl_canon(s[i]);
-}
-
-// 192-bit accumulator for dot products with full-size constants
-struct acc192 {
-  u64 lo, hi;
-  u32 c;
-};
-GLD void acc_mul_add(acc192& A, u64 a, u64 b) {
-  u64 lo, hi;
-  gl_mul128(a, b, lo, hi);
-  // 160-bit add with one carry chain through SGPR lane masks (5 instructions)
-  u32 l0, l1, h0, h1, cc;
-  u64 c0, c1, c2, c3, c4;
-  asm("v_add_co_u32_e64 %0, %1, %2, %3" : "=v"(l0), "=s"(c0) : "v"((u32)A.lo), "v"((u32)lo));
-  asm("v_addc_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(l1), "=s"(c1) : "v"((u32)(A.lo >> 32)), "v"((u32)(lo >> 32)), "s"(c0));
-  asm("v_addc_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(h0), "=s"(c2) : "v"((u32)A.hi), "v"((u32)hi), "s"(c1));
-  asm("v_addc_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(h1), "=s"(c3) : "v"((u32)(A.hi >> 32)), "v"((u32)(hi >> 32)), "s"(c2));
-  asm("v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(cc), "=s"(c4) : "v"(A.c), "s"(c3));
-  A.lo = gl_pack(l0, l1);
-  A.hi = gl_pack(h0, h1);
-  A.c = cc;
-}
-// lo + hi*2^64 + c*2^128,  2^128 = -2^32 (mod p)
-GLD u64 acc_reduce_nc(const acc192& A) {
-  u64 r = gl_reduce128_nc(A.lo, A.hi);
-  const u64 sub = (u64)A.c << 32;  // < 2^37
-  const u64 d = r - sub;
-  return r < sub ? d - GL_EPS : d;  // wrapped d + p
 }
 
 // ---- dot products with full-size constants, carry-free -----------------------------------------------------------
