@@ -8,8 +8,11 @@
 //  * lanes are kept as arbitrary u64 representatives (not canonical) between operations; one
 //    conditional subtraction at the very end canonicalises;
 //  * the 22 partial rounds use the "fast" sparse form (one dense 11x11 matrix up front, then per round a
-//    12-term dot product and 11 multiply-adds instead of a dense 12x12 MDS) — constants re-derived and
-//    proven equivalent in tools/gen_poseidon_fast_constants.py (the role of upstream's FAST_PARTIAL_*);
+//    12-term dot product and a rank-one update of the 11 passive lanes instead of a dense 12x12 MDS) — constants
+//    re-derived and proven equivalent in tools/gen_poseidon_fast_constants.py (the role of upstream's
+//    FAST_PARTIAL_*) — and run in BLOCKS: the passive lanes are only brought up to date once per block;
+//  * every dot product with full-size constants is carry-free (constants pre-split into 22-bit limbs, one
+//    v_mad_u64_u32 per partial product into plain 64-bit accumulators, one recombination per dot product);
 //  * the dense MDS of the 8 full rounds multiplies the low/high 32-bit halves by the <2^6 circulant
 //    entries with v_mad_u64_u32 (a 32x32+64 multiply-accumulate in ONE instruction) and folds once.
 // The 12-lane state lives in VGPRs; round constants sit in constant memory and, because the loops
