@@ -184,7 +184,7 @@ GLD void acc_push(AlphaAcc& a, const QuotientParams& p, u64 term) {
 #define UNUSED_SELECTOR_U64 0xFFFFFFFFULL
 
 #ifndef VX_QUOTIENT_BLOCKS
-#define VX_QUOTIENT_BLOCKS 4
+#define VX_QUOTIENT_BLOCKS 5
 #endif
 __global__ __launch_bounds__(256, VX_QUOTIENT_BLOCKS) void quotient_kernel(QuotientParams p) {
   const size_t il = (size_t)blockIdx.x * 256 + threadIdx.x;
