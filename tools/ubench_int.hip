@@ -35,6 +35,9 @@ __global__ void k(uint64_t* out, uint32_t seed) {
       if (OP == 13) asm volatile("v_sub_co_u32 %0, vcc, %0, %1" : "+v"(a[i]) : "v"(b) : "vcc");
       if (OP == 14) asm volatile("v_lshl_or_b32 %0, %0, 3, %1" : "+v"(a[i]) : "v"(b));
       if (OP == 15) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+      if (OP == 16) asm volatile("v_dot4_u32_u8 %0, %1, %2, %0" : "+v"(a[i]) : "v"(b), "v"(c));
+      if (OP == 17) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+      if (OP == 18) asm volatile("v_alignbit_b32 %0, %0, %1, 10" : "+v"(a[i]) : "v"(b));
     }
   }
   uint64_t s = b;
@@ -77,6 +80,9 @@ int main() {
   run<4>("v_lshl_add_u32", 1);
   run<14>("v_lshl_or_b32", 1);
   run<15>("v_and_or_b32", 1);
+  run<16>("v_dot4_u32_u8", 1);
+  run<17>("v_perm_b32", 1);
+  run<18>("v_alignbit_b32", 1);
   run<5>("v_add_u32", 1);
   run<6>("v_add_co+v_addc_co (pair)", 2);
   run<13>("v_sub_co_u32", 1);
