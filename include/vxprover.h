@@ -184,7 +184,23 @@ typedef struct vx_circuit_desc {
   int32_t programs_len;            /* uint64 words in `programs` */
   const uint64_t* programs;
   const int32_t* program_offsets;  /* [num_gates] */
+  /* ---- values the caller already HOLDS (plonky2 plonk/circuit_data.rs: CommonCircuitData, VerifierOnlyCircuitData,
+   * FriParams — what `circuit.prove(&input)` at /root/reference/circuits/header_range.rs:167 carries).  Set the bit in
+   * override_flags and the library uses the caller's value VERBATIM in the transcript, the FRI commit phase, the
+   * proof layout and vx_verify; leave it clear (a zero-initialised tail) and the library derives the value itself
+   * with the rule named below.  Passing them removes the library's own restatement of those rules from the path. */
+  uint32_t override_flags;               /* VX_DESC_HAS_* */
+  int32_t hiding;                        /* FriParams::hiding = config.zero_knowledge; must be 0 (not supported) */
+  uint64_t circuit_digest[4];            /* VX_DESC_HAS_CIRCUIT_DIGEST: VerifierOnlyCircuitData::circuit_digest (else:
+                                          * hash_no_pad(constants_sigmas_cap || [degree_bits]), empty domain separator) */
+  int32_t num_fri_reduction_arity_bits;  /* VX_DESC_HAS_FRI_ARITIES: FriParams::reduction_arity_bits, each in [1, 4] */
+  int32_t num_partial_products;          /* VX_DESC_HAS_NUM_PARTIAL_PRODUCTS: CommonCircuitData::num_partial_products;
+                                          * must equal ceil(num_routed_wires / quotient_degree_factor) - 1 or the call fails */
+  const int32_t* fri_reduction_arity_bits; /* (else: ConstantArityBits(4, 5) of standard_recursion_config) */
 } vx_circuit_desc;
+#define VX_DESC_HAS_CIRCUIT_DIGEST 1u
+#define VX_DESC_HAS_FRI_ARITIES 2u
+#define VX_DESC_HAS_NUM_PARTIAL_PRODUCTS 4u
 
 /* One instruction = one uint64:  op | dst << 8 | a << 16 | b << 32   (VX_OP_LDI is followed by one immediate word).
  * Registers r0..r63 hold field elements.  Every VX_OP_PUSH emits the next constraint of the gate, in order. */

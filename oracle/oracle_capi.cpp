@@ -142,7 +142,26 @@ struct vxo_circuit_desc {
   int32_t programs_len;
   const uint64_t* programs;
   const int32_t* program_offsets;
+  uint32_t override_flags;  // 1: circuit_digest, 2: fri_reduction_arity_bits, 4: num_partial_products
+  int32_t hiding;
+  uint64_t circuit_digest[4];
+  int32_t num_fri_reduction_arity_bits;
+  int32_t num_partial_products;
+  const int32_t* fri_reduction_arity_bits;
 };
+static void load_overrides(const vxo_circuit_desc* d, Circuit* c) {
+  if (d->hiding) throw std::runtime_error("zero-knowledge circuits are not restated");
+  if (d->override_flags & 1) {
+    c->has_digest_override = true;
+    for (int i = 0; i < 4; ++i) c->digest_override.e[i] = canon(d->circuit_digest[i]);
+  }
+  if (d->override_flags & 2) {
+    c->has_arity_override = true;
+    c->arity_override.assign(d->fri_reduction_arity_bits, d->fri_reduction_arity_bits + d->num_fri_reduction_arity_bits);
+  }
+  if ((d->override_flags & 4) && d->num_partial_products != c->num_partial_products())
+    throw std::runtime_error("num_partial_products disagrees with ceil(num_routed_wires / quotient_degree_factor) - 1");
+}
 static void load_gate_program(const vxo_circuit_desc* d, int i, Gate& g) {
   if (g.type != GATE_PROGRAM) return;
   if (!d->programs || !d->program_offsets || d->program_offsets[i] < 0) throw std::runtime_error("program gate without a program");
@@ -186,6 +205,7 @@ void* vxo_circuit_create(const vxo_circuit_desc* d) {
     cols[k].assign(d->constants_sigmas + k * n, d->constants_sigmas + (k + 1) * n);
     for (auto& x : cols[k]) x = canon(x);
   }
+  load_overrides(d, c);
   c->finalize(std::move(cols));
   return c;
 }
@@ -219,6 +239,7 @@ void* vxo_circuit_create_verifier(const vxo_circuit_desc* d, const u64* cap) {
   for (int i = 0; i < d->num_public_inputs; ++i) c->public_inputs.push_back({d->pi_rows[i], d->pi_cols[i]});
   c->num_gate_constraints = 0;
   for (const Gate& g : c->gates) c->num_gate_constraints = std::max(c->num_gate_constraints, g.num_constraints());
+  load_overrides(d, c);
   c->compute_fri_params();
   std::vector<Hash> capv((size_t)1 << d->cap_height);
   std::vector<u64> pre;
@@ -231,7 +252,7 @@ void* vxo_circuit_create_verifier(const vxo_circuit_desc* d, const u64* cap) {
   c->constants_sigmas.tree.layers.clear();
   c->constants_sigmas.tree.layers.push_back(capv);
   c->constants_sigmas.tree.cap_height = d->cap_height;
-  c->circuit_digest = hash_no_pad(pre.data(), pre.size());
+  c->circuit_digest = c->has_digest_override ? c->digest_override : hash_no_pad(pre.data(), pre.size());
   return c;
 }
 void vxo_circuit_free(void* c) { delete (Circuit*)c; }

@@ -116,6 +116,10 @@ struct Circuit {
   std::vector<int> reduction_arity_bits;
   PolynomialBatch constants_sigmas;  // [selectors.., constants.., sigmas(80)]
   Hash circuit_digest;
+  // values the caller holds in CommonCircuitData / VerifierOnlyCircuitData and may pass instead of having them derived
+  bool has_digest_override = false, has_arity_override = false;
+  Hash digest_override;
+  std::vector<int> arity_override;
 
   size_t n() const { return (size_t)1 << degree_bits; }
   int num_partial_products() const { return (num_routed_wires + quotient_degree_factor - 1) / quotient_degree_factor - 1; }
@@ -126,6 +130,10 @@ struct Circuit {
   // fri/reduction_strategies.rs: ConstantArityBits(4, 5)
   void compute_fri_params() {
     reduction_arity_bits.clear();
+    if (has_arity_override) {  // FriParams::reduction_arity_bits as given by the caller
+      reduction_arity_bits = arity_override;
+      return;
+    }
     int db = degree_bits;
     const int arity_bits = 4, final_poly_bits = 5;
     while (db > final_poly_bits && db + rate_bits - arity_bits >= cap_height) {
@@ -145,7 +153,7 @@ struct Circuit {
     for (const Hash& h : constants_sigmas.tree.cap())
       for (int i = 0; i < 4; ++i) pre.push_back(h.e[i]);
     pre.push_back((u64)degree_bits);
-    circuit_digest = hash_no_pad(pre.data(), pre.size());
+    circuit_digest = has_digest_override ? digest_override : hash_no_pad(pre.data(), pre.size());
   }
 };
 

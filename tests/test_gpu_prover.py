@@ -270,3 +270,75 @@ def test_malformed_constraint_programs_are_refused(ctx):
         vx.Circuit(ctx, sc.desc_ptr)
     words[0] = first
     vx.Circuit(ctx, sc.desc_ptr).free()
+
+
+@pytest.mark.parametrize("degree_bits,arities", [(7, [2, 1, 3]), (10, [4, 3]), (12, [1, 2, 3, 4]), (9, [])])
+def test_caller_supplied_digest_and_fri_arities(ctx, oracle, degree_bits, arities):
+    """vx_circuit_desc carries what the Rust side holds (VerifierOnlyCircuitData::circuit_digest, FriParams::
+    reduction_arity_bits, CommonCircuitData::num_partial_products): the GPU prover must follow the caller's values —
+    byte-identical to the oracle driven by the same description, different from the proof under derived values."""
+    sc = SynthCircuit(degree_bits, seed=400 + degree_bits, poseidon_percent=50)
+    sc.desc.pow_bits = 6
+    w = sc.witness()
+    g0 = vx.Circuit(ctx, sc.desc_ptr)
+    p0 = g0.prove(w)
+    derived = [int(x) for x in g0.digest()]
+    digest = [(d + 7 * (i + 1)) % P for i, d in enumerate(derived)]
+    sc.set_circuit_digest(digest)
+    sc.set_fri_reduction_arity_bits(arities)
+    sc.set_num_partial_products(9)
+    oc = oracle_lib.OracleCircuit(oracle, sc.desc_ptr)
+    gc = vx.Circuit(ctx, sc.desc_ptr)
+    assert [int(x) for x in gc.digest()] == digest == [int(x) for x in oc.digest()]
+    assert (gc.constants_sigmas_cap() == oc.cap()).all() and (gc.constants_sigmas_cap() == g0.constants_sigmas_cap()).all()
+    gp, op = gc.prove(w), oc.prove(w)
+    assert gp == op and gp != p0
+    assert oc.verify(gp) == ""
+    gc.verify(gp)                                     # product verifier follows the same values
+    vx.verify_standalone(sc.desc_ptr, gc.constants_sigmas_cap(), gp)
+    with pytest.raises(vx.VxError):
+        g0.verify(gp)                                 # ... and the derived-value circuit rejects it
+    with pytest.raises(vx.VxError):
+        gc.verify(p0)
+    sc.set_num_partial_products(7)                    # disagreeing CommonCircuitData is refused loudly
+    with pytest.raises(vx.VxError) as e:
+        vx.Circuit(ctx, sc.desc_ptr)
+    assert e.value.code == vx.VX_E_INVALID
+    gc.free()
+    g0.free()
+
+
+def test_circuit_create_refuses_malformed_descriptions(ctx):
+    """cap_height, num_query_rounds, selector / group ranges, gate parameters are validated by the
+    shared checker before any device work; nothing unwinds across the ABI."""
+    import ctypes
+    sc = SynthCircuit(5, seed=77, poseidon_percent=50, flags=1)
+    d = sc.desc
+    n = d.num_gates
+
+    def refused():
+        with pytest.raises(vx.VxError) as e:
+            vx.Circuit(ctx, sc.desc_ptr)
+        assert e.value.code == vx.VX_E_INVALID, str(e.value)
+
+    for field, value in [("cap_height", -1), ("cap_height", 9), ("num_query_rounds", 0), ("num_query_rounds", -3),
+                         ("num_selectors", d.num_constants + 1), ("num_public_inputs", -1), ("hiding", 1), ("override_flags", 128)]:
+        old = getattr(d, field)
+        setattr(d, field, value)
+        refused()
+        setattr(d, field, old)
+    for name, bad in [("group_starts", n), ("group_ends", 0), ("selector_indices", d.num_selectors), ("gate_types", 9)]:
+        arr = (ctypes.c_int32 * n).from_address(getattr(d, name))
+        old, arr[n - 1] = arr[n - 1], bad
+        refused()
+        arr[n - 1] = old
+    types = (ctypes.c_int32 * n).from_address(d.gate_types)
+    params = (ctypes.c_int32 * n).from_address(d.gate_params)
+    for g in range(n):
+        if types[g] in (vx.VX_GATE_ARITHMETIC, vx.VX_GATE_CONSTANT):
+            old, params[g] = params[g], 100_000
+            refused()
+            params[g] = old
+    gc = vx.Circuit(ctx, sc.desc_ptr)                 # the restored description loads and proves
+    assert len(gc.prove(sc.witness())) > 0
+    gc.free()

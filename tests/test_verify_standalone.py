@@ -80,3 +80,90 @@ def test_standalone_verifier_argument_checks(oracle):
     assert e.value.code == vx.VX_E_INVALID
     sc.desc.num_gates = keep
     vx.verify_standalone(sc.desc_ptr, oc.cap(), proof)
+
+
+def test_caller_supplied_digest_and_fri_arities_drive_the_transcript(oracle):
+    """vx_circuit_desc may carry the values the Rust side holds in CommonCircuitData / VerifierOnlyCircuitData
+    (circuit_digest, FriParams::reduction_arity_bits, num_partial_products).  When present, prover, oracle and the product
+    verifier must all follow THEM, not their own derivation."""
+    sc = SynthCircuit(7, seed=31, poseidon_percent=40)
+    sc.desc.pow_bits = 5
+    base = oracle_lib.OracleCircuit(oracle, sc.desc_ptr)
+    cap = base.cap()
+    p_base = base.prove(sc.witness())
+    assert _verdict(sc, cap, p_base) == ""
+    # 1. a caller-supplied digest: different transcript, verifies only against the same digest
+    digest = [(0x1234567 * (i + 1)) % P for i in range(4)]
+    sc.set_circuit_digest(digest)
+    oc = oracle_lib.OracleCircuit(oracle, sc.desc_ptr)
+    assert [int(x) for x in oc.digest()] == digest
+    p_dig = oc.prove(sc.witness())
+    assert p_dig != p_base and oc.verify(p_dig) == "" and _verdict(sc, cap, p_dig) == ""
+    assert _verdict(sc, cap, p_base) != ""                      # the derived-digest proof no longer verifies
+    # 2. caller-supplied FRI arities (degree 2^7: derived = [4]; supplied = [2, 1, 3], final poly of 2 coefficients)
+    sc.set_fri_reduction_arity_bits([2, 1, 3])
+    sc.set_num_partial_products(9)
+    oc2 = oracle_lib.OracleCircuit(oracle, sc.desc_ptr)
+    p_ar = oc2.prove(sc.witness())
+    assert len(p_ar) != len(p_dig) and oc2.verify(p_ar) == "" and _verdict(sc, cap, p_ar) == ""
+    assert oc.verify(p_ar) != "" and _verdict(sc, cap, p_dig) != ""   # each proof only under its own parameters
+    # 3. a disagreeing num_partial_products is refused, not silently mis-laid-out
+    sc.set_num_partial_products(8)
+    with pytest.raises(vx.VxError) as e:
+        vx.verify_standalone(sc.desc_ptr, cap, p_ar)
+    assert e.value.code == vx.VX_E_INVALID and "num_partial_products" in str(e.value)
+
+
+def test_malformed_descriptions_are_refused_before_any_read(oracle):
+    """every field later used as an index, shift or size is range-checked by the shared validator
+    (csrc/desc_check.h) — by vx_verify_standalone here, by vx_circuit_create on the GPU (tests/test_gpu_prover.py)."""
+    sc = SynthCircuit(4, seed=3, poseidon_percent=50, flags=1)
+    oc = oracle_lib.OracleCircuit(oracle, sc.desc_ptr)
+    proof, cap = oc.prove(sc.witness()), oc.cap()
+    vx.verify_standalone(sc.desc_ptr, cap, proof)
+    d = sc.desc
+
+    def refused(field, value):
+        old = getattr(d, field)
+        setattr(d, field, value)
+        try:
+            with pytest.raises(vx.VxError) as e:
+                vx.verify_standalone(sc.desc_ptr, cap, proof)
+            assert e.value.code == vx.VX_E_INVALID, (field, value, str(e.value))
+        finally:
+            setattr(d, field, old)
+
+    for field, value in [("cap_height", -1), ("cap_height", 99), ("num_query_rounds", 0), ("num_query_rounds", -5),
+                         ("num_query_rounds", 1 << 20), ("num_selectors", 0), ("num_selectors", d.num_constants + 1),
+                         ("num_public_inputs", -1), ("num_wires", 0), ("num_routed_wires", d.num_wires + 1),
+                         ("degree_bits", 0), ("degree_bits", 40), ("rate_bits", 0), ("num_challenges", 3), ("pow_bits", 64),
+                         ("quotient_degree_factor", 4), ("hiding", 1), ("override_flags", 64), ("programs_len", -1)]:
+        refused(field, value)
+    # per-gate arrays: patch one entry of the int32 arrays in place
+    import ctypes
+    n = d.num_gates
+    for name, bad in [("gate_types", 17), ("gate_types", -1), ("selector_indices", d.num_selectors), ("selector_indices", -1),
+                      ("group_starts", n), ("group_ends", 0), ("group_ends", n + 1)]:
+        arr = (ctypes.c_int32 * n).from_address(getattr(d, name))
+        for g in (0, n - 1):
+            old = arr[g]
+            arr[g] = bad
+            try:
+                with pytest.raises(vx.VxError) as e:
+                    vx.verify_standalone(sc.desc_ptr, cap, proof)
+                assert e.value.code == vx.VX_E_INVALID, (name, g, bad)
+            finally:
+                arr[g] = old
+    # gate parameters: an ArithmeticGate with more ops than wires, a ConstantGate with more constants than exist
+    types = (ctypes.c_int32 * n).from_address(d.gate_types)
+    params = (ctypes.c_int32 * n).from_address(d.gate_params)
+    for g in range(n):
+        if types[g] in (vx.VX_GATE_ARITHMETIC, vx.VX_GATE_CONSTANT):
+            old = params[g]
+            for bad in (-1, 10_000):
+                params[g] = bad
+                with pytest.raises(vx.VxError) as e:
+                    vx.verify_standalone(sc.desc_ptr, cap, proof)
+                assert e.value.code == vx.VX_E_INVALID
+            params[g] = old
+    vx.verify_standalone(sc.desc_ptr, cap, proof)   # restored description still verifies

@@ -24,6 +24,7 @@ _LIB_PATH = Path(os.environ.get("VXPROVER_LIB", _PKG / "libvxprover.so"))  # ove
 P = 0xFFFFFFFF00000001
 
 VX_OK, VX_E_INVALID, VX_E_NO_DEVICE, VX_E_HIP, VX_E_NOMEM, VX_E_PROOF, VX_E_COMM = 0, -1, -2, -3, -4, -5, -6
+VX_GATE_NOOP, VX_GATE_CONSTANT, VX_GATE_PUBLIC_INPUT, VX_GATE_ARITHMETIC, VX_GATE_POSEIDON, VX_GATE_PROGRAM = 0, 1, 2, 3, 4, 5
 NTT_FFT, NTT_IFFT, NTT_COSET_FFT, NTT_COSET_IFFT = 0, 1, 2, 3
 
 

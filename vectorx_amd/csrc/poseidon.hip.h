@@ -2,29 +2,25 @@
 // Replaces plonky2::hash::poseidon / poseidon_goldilocks and the AVX2/NEON hand-scheduled forms
 // (plonky2 v0.2.0, un-vendored: /root/reference/Cargo.lock:4848-4905; algorithm per SURVEY.md A.2).
 //
-// This path is bound by the integer ALU, not HBM (measured: tools/ubench_int.hip — on gfx950 every
-// multiply-class / VOP3 instruction, v_mad_u64_u32 included, issues at ~4.4-5.2 cycles per wavefront, a
-// plain v_add_u32 at ~2.8), so the design minimises the INSTRUCTION COUNT per permutation:
+// This path is bound by the integer ALU, not HBM.  Measured (tools/ubench_int.hip, profiles/r02_ubench_int.md): on
+// gfx950 v_mad_u64_u32, v_mul_*, EVERY carry-producing add/sub (VOP2 forms included), v_cndmask_b32_e64, v_lshl_add_u64,
+// 64-bit shifts and compares all issue at ~4.4 shader cycles per wavefront per SIMD; only plain 32-bit VOP1/VOP2 ops
+// reach ~2.5, and only in runs.  So time = instruction count, and the design minimises the INSTRUCTION COUNT:
 //  * lanes are kept as arbitrary u64 representatives (not canonical) between operations; one
 //    conditional subtraction at the very end canonicalises;
-//  * the 22 partial rounds use the "fast" sparse form (one dense 11x11 matrix up front, then per round a
-//    12-term dot product and a rank-one update of the 11 passive lanes instead of a dense 12x12 MDS) — constants
-//    re-derived and proven equivalent in tools/gen_poseidon_fast_constants.py (the role of upstream's
-//    FAST_PARTIAL_*) — and run in BLOCKS: the passive lanes are only brought up to date once per block;
-//  * every dot product with full-size constants is carry-free (constants pre-split into 22-bit limbs, one
-//    v_mad_u64_u32 per partial product into plain 64-bit accumulators, one recombination per dot product);
-//  * the dense MDS of the 8 full rounds multiplies the low/high 32-bit halves by the <2^6 circulant
-//    entries with v_mad_u64_u32 (a 32x32+64 multiply-accumulate in ONE instruction) and folds once.
-// The 12-lane state lives in VGPRs; round constants sit in constant memory and, because the loops
-// are unrolled, are fetched with scalar loads shared by the whole wavefront.
+//  * every linear layer works on the 32-bit halves of a lane with SMALL INTEGER multipliers (one v_mad_u64_u32 per
+//    half per term into plain 64-bit accumulators — no carries) and folds once per output (5 instructions);
+//  * round constants are never added on their own: they are the initial values of the accumulators of the linear
+//    layer in front of them;
+//  * the 22 partial rounds run in blocks of 3 through integer powers of the MDS matrix (below) — upstream's "fast"
+//    sparse form needs full-size constants, i.e. six multiply-adds per term instead of two.
+// The 12-lane state lives in VGPRs; constants sit in constant memory and, because the loops are unrolled, are fetched
+// with scalar loads shared by the whole wavefront.
 #pragma once
 #include "goldilocks.hip.h"
 #include "poseidon_constants.h"
-#include "poseidon_fast_constants.h"
 
 __constant__ u64 POSEIDON_RC[VX_POSEIDON_N_ROUND_CONSTANTS] = VX_POSEIDON_ROUND_CONSTANTS_INIT;
-__constant__ u64 POSEIDON_FAST_FIRST[12] = VX_FAST_PARTIAL_FIRST_ROUND_CONSTANT_INIT;
-__constant__ u64 POSEIDON_FAST_K[22] = VX_FAST_PARTIAL_ROUND_CONSTANTS_INIT;
 
 #define POSEIDON_WIDTH 12
 #define POSEIDON_RATE 8
@@ -129,24 +125,6 @@ constexpr Limbs3Table<R, C> make_limbs3(const u64 (&raw)[R][C]) {
     }
   return t;
 }
-constexpr u64 POSEIDON_FAST_INIT_RAW[11][11] = VX_FAST_PARTIAL_INITIAL_MATRIX_INIT;
-constexpr u64 POSEIDON_FAST_W_HATS_RAW[22][11] = VX_FAST_PARTIAL_W_HATS_INIT;
-__constant__ Limbs3Table<11, 11> POSEIDON_FAST_INIT3 = make_limbs3<11, 11>(POSEIDON_FAST_INIT_RAW);
-__constant__ Limbs3Table<22, 11> POSEIDON_FAST_W_HATS3 = make_limbs3<22, 11>(POSEIDON_FAST_W_HATS_RAW);
-
-// Blocked partial rounds: inside a block of PB rounds the 11 passive lanes are NOT updated; round r's dot product is
-// taken on the block's starting state plus cross terms y_q * KK[r][q] (y_q = the S-box outputs of the block's earlier
-// rounds, KK[r][q] = sum_i w_hat_r[i] v_q[i]), and the lanes are brought up to date once per block with an 11-term
-// dot product each.  That trades the 11 multiply-add-reduce per round for carry-free multiply-adds.
-#ifndef POSEIDON_PB
-#define POSEIDON_PB 5
-#endif
-constexpr u64 gl_mulmod_const(u64 a, u64 b) { return (u64)(((unsigned __int128)a * b) % (unsigned __int128)GL_P); }
-constexpr u64 POSEIDON_FAST_VS_RAW[22][11] = VX_FAST_PARTIAL_VS_INIT;
-struct PoseidonBlockTables {
-  Limbs3x2 kk[22][POSEIDON_PB];  // kk[r][q]: cross term of round r with the q-th round of its block (q < r - block start)
-  Limbs3x2 vs[22][11];           // v_r[i]
-};
 constexpr Limbs3x2 make_limbs3x2(u64 b) {
   Limbs3x2 t{};
   const u64 bh = gl_mul_2_32_const(b);
@@ -154,25 +132,6 @@ constexpr Limbs3x2 make_limbs3x2(u64 b) {
   t.hi[0] = (u32)(bh & 0x3FFFFFu), t.hi[1] = (u32)((bh >> 22) & 0x3FFFFFu), t.hi[2] = (u32)(bh >> 44);
   return t;
 }
-constexpr PoseidonBlockTables make_block_tables() {
-  PoseidonBlockTables t{};
-  for (int r = 0; r < 22; ++r) {
-    const int r0 = (r / POSEIDON_PB) * POSEIDON_PB;
-    for (int q = 0; q < POSEIDON_PB; ++q) {
-      u64 acc = 0;
-      if (r0 + q < r)
-        for (int i = 0; i < 11; ++i) {
-          const u64 term = gl_mulmod_const(POSEIDON_FAST_W_HATS_RAW[r][i] % GL_P, POSEIDON_FAST_VS_RAW[r0 + q][i] % GL_P);
-          acc = (u64)(((unsigned __int128)acc + term) % (unsigned __int128)GL_P);
-        }
-      t.kk[r][q] = make_limbs3x2(acc);
-    }
-    for (int i = 0; i < 11; ++i) t.vs[r][i] = make_limbs3x2(POSEIDON_FAST_VS_RAW[r][i] % GL_P);
-  }
-  return t;
-}
-__constant__ PoseidonBlockTables POSEIDON_BLOCK = make_block_tables();
-
 struct dot3 {
   u64 s0, s1, s2;
 };
@@ -196,71 +155,200 @@ GLD u64 dot3_reduce_add_nc(const dot3& D, u64 addend) {
   return gl_reduce128_nc((u64)V, (u64)(V >> 64));
 }
 
-// The 22 partial rounds (fast form, blocks of POSEIDON_PB).  `lane0(r, x)` is handed the S-box INPUT x of partial round r
-// and returns the value that actually goes through the S-box: the identity for the permutation.  (A PoseidonGate
-// evaluation could pass the wire the gate constrains to equal x — the recurrences are linear in everything but the
-// S-box outputs — and that is byte-identical, but in the quotient kernel the extra live registers cost more than the
-// dense MDS it saves: 23.7 -> 27.1 ms, so the gate keeps the naive rounds.)
-template <class F>
-GLD void poseidon_partial_rounds_nc(u64 (&s)[12], F&& lane0) {
-#pragma unroll
-  for (int i = 0; i < 12; ++i) s[i] = gl_add_nc_c(s[i], POSEIDON_FAST_FIRST[i]);
-  {
-    u64 t[11];
-#pragma unroll 1
-    for (int r = 0; r < 11; ++r) {
-      dot3 D = {0, 0, 0};
-#pragma unroll
-      for (int c = 0; c < 11; ++c) dot3_mac(D, s[1 + c], POSEIDON_FAST_INIT3.v[r][c]);
-      t[r] = dot3_reduce_nc(D);
-    }
-#pragma unroll
-    for (int r = 0; r < 11; ++r) s[1 + r] = t[r];
+// ---- the 22 partial rounds in INTEGER-POWER BLOCKS ---------------------------------------------------------------
+// Only lane 0 is non-linear in a partial round, and the MDS entries are tiny (< 2^6), so a block of B rounds is a
+// handful of dot products with SMALL INTEGER coefficients — 32-bit multipliers, two v_mad_u64_u32 per term on the
+// 32-bit halves of a lane, no carries, one 5-instruction fold per dot product — instead of B dense layers (or the
+// "fast" sparse form, whose full-size constants cost six multiply-adds per term):
+//   M = MDS (integers), Q = M with row 0 zeroed;  the block starts from u (round constants of its first round already
+//   added), w = (y_0, u_1 .. u_11) with y_0 = u_0^7;
+//   S-box input of round j:   x_j = row0(M) Q^(j-1) . w  +  sum_{1<=i<j} y_i (row0(M) Q^(j-1-i))[0]  + kappa_j
+//   state after the block:    u'  = M Q^(B-1) w  +  sum_{1<=i<B} y_i (M Q^(B-1-i)) e_0  +  K
+// (lane 0 is REPLACED by the S-box output before each layer, hence Q: no subtraction appears).  kappa_j and K collect the
+// round constants (K also those of the round that follows the block) and ride in as the accumulators' initial values.
+// B = 3: entries of M Q^2 < 2^20.4, every accumulator < 2^57.  (B = 4 still fits 32-bit multipliers — row sums
+// < 2^31.72 — but its accumulators reach 2^63.7 and the fold needs a second carry fix; measured gain would be ~2 %.)
+// Equivalence to the naive rounds is exact integer algebra mod p; tests: the permutation KATs, 2.4 M iterated
+// permutations against the oracle, every Merkle / proof parity test.
+#define POSEIDON_NBLOCKS 8
+constexpr int POSEIDON_SCHED[POSEIDON_NBLOCKS] = {3, 3, 3, 3, 3, 3, 3, 1};
+struct PoseidonIntBlock {
+  u32 A[3][12];   // A[j][i]: coefficient of w_i in x_j   (1 <= j < B)
+  u32 b[3][3];    // b[j][i]: coefficient of y_i in x_j   (1 <= i < j)
+  u32 C[12][12];  // M Q^(B-1)
+  u32 c[3][12];   // c[i][r]: coefficient of y_i in u'_r  (1 <= i < B)
+};
+struct PoseidonMat {
+  u64 m[12][12];
+};
+constexpr PoseidonMat poseidon_mds_int() {
+  const u64 CIRC[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+  PoseidonMat M{};
+  for (int r = 0; r < 12; ++r)
+    for (int i = 0; i < 12; ++i) M.m[r][(i + r) % 12] += CIRC[i];
+  M.m[0][0] += 8;
+  return M;
+}
+constexpr PoseidonMat poseidon_mat_mul(const PoseidonMat& X, const PoseidonMat& Y) {  // exact integers (entries stay < 2^40)
+  PoseidonMat R{};
+  for (int i = 0; i < 12; ++i)
+    for (int j = 0; j < 12; ++j)
+      for (int t = 0; t < 12; ++t) R.m[i][j] += X.m[i][t] * Y.m[t][j];
+  return R;
+}
+constexpr PoseidonMat poseidon_q_pow(int k) {
+  PoseidonMat Q = poseidon_mds_int(), R{};
+  for (int j = 0; j < 12; ++j) Q.m[0][j] = 0;
+  for (int i = 0; i < 12; ++i) R.m[i][i] = 1;
+  for (int t = 0; t < k; ++t) R = poseidon_mat_mul(Q, R);
+  return R;
+}
+constexpr PoseidonIntBlock make_int_block(int B) {
+  PoseidonIntBlock T{};
+  const PoseidonMat M = poseidon_mds_int();
+  for (int j = 1; j < B; ++j) {
+    const PoseidonMat X = poseidon_mat_mul(M, poseidon_q_pow(j - 1));
+    for (int i = 0; i < 12; ++i) T.A[j][i] = (u32)X.m[0][i];
+    for (int i = 1; i < j; ++i) T.b[j][i] = (u32)poseidon_mat_mul(M, poseidon_q_pow(j - 1 - i)).m[0][0];
   }
-#pragma unroll 1
-  for (int r0 = 0; r0 < 22; r0 += POSEIDON_PB) {
-    const int nb = 22 - r0 < POSEIDON_PB ? 22 - r0 : POSEIDON_PB;  // the last block may be shorter
-    u64 y[POSEIDON_PB];
-#pragma unroll
-    for (int j = 0; j < POSEIDON_PB; ++j) {
-      y[j] = 0;
-      if (j < nb) {
-        const u64 yj = gl_add_nc_c(poseidon_sbox_nc(lane0(r0 + j, s[0])), POSEIDON_FAST_K[r0 + j]);
-        y[j] = yj;
-        // M[0][0] = CIRC[0] + DIAG[0] = 25:  25 y = 25 lo(y) + 2^22 * (25 * 2^10) hi(y)
-        dot3 D = {(u64)(u32)yj * 25u, (u64)(u32)(yj >> 32) * 25600u, 0};
-#pragma unroll
-        for (int i = 0; i < 11; ++i) dot3_mac(D, s[1 + i], POSEIDON_FAST_W_HATS3.v[r0 + j][i]);
-#pragma unroll
-        for (int q = 0; q < j; ++q) dot3_mac(D, y[q], POSEIDON_BLOCK.kk[r0 + j][q]);
-        s[0] = dot3_reduce_nc(D);
+  const PoseidonMat CC = poseidon_mat_mul(M, poseidon_q_pow(B - 1));
+  for (int r = 0; r < 12; ++r)
+    for (int i = 0; i < 12; ++i) T.C[r][i] = (u32)CC.m[r][i];
+  for (int i = 1; i < B; ++i) {
+    const PoseidonMat X = poseidon_mat_mul(M, poseidon_q_pow(B - 1 - i));
+    for (int r = 0; r < 12; ++r) T.c[i][r] = (u32)X.m[r][0];
+  }
+  return T;
+}
+// Round constants of the blocks: kappa[blk][j] (S-box input of the block's round j >= 1) and K[blk][r] (state after the
+// block, INCLUDING the constants of the round that follows it).
+struct PoseidonBlockConsts {
+  u64 kappa[POSEIDON_NBLOCKS][3];
+  u64 K[POSEIDON_NBLOCKS][12];
+};
+constexpr u64 gl_mulmod_const(u64 a, u64 b) { return (u64)(((unsigned __int128)a * b) % (unsigned __int128)GL_P); }
+constexpr u64 POSEIDON_RC_RAW[VX_POSEIDON_N_ROUND_CONSTANTS] = VX_POSEIDON_ROUND_CONSTANTS_INIT;
+constexpr u64 gl_addmod_const(u64 a, u64 b) { return (u64)(((unsigned __int128)a + b) % (unsigned __int128)GL_P); }
+constexpr PoseidonBlockConsts make_block_consts() {
+  PoseidonBlockConsts R{};
+  const PoseidonMat M = poseidon_mds_int();
+  int r0 = 4;
+  for (int blk = 0; blk < POSEIDON_NBLOCKS; ++blk) {
+    const int B = POSEIDON_SCHED[blk];
+    u64 cv[12] = {};  // constant part of w^(j) (the block's first-round constants are already inside u)
+    for (int j = 1; j <= B; ++j) {
+      u64 t[12] = {};
+      for (int i = 0; i < 12; ++i) {
+        u64 acc = 0;
+        for (int q = 0; q < 12; ++q) acc = gl_addmod_const(acc, gl_mulmod_const(M.m[i][q], cv[q]));
+        t[i] = gl_addmod_const(acc, POSEIDON_RC_RAW[(r0 + j) * 12 + i] % GL_P);  // r0 + B <= 26: always a real round
+      }
+      if (j < B) {
+        R.kappa[blk][j] = t[0];
+        cv[0] = 0;
+        for (int i = 1; i < 12; ++i) cv[i] = t[i];
+      } else {
+        for (int i = 0; i < 12; ++i) R.K[blk][i] = t[i];
       }
     }
-#pragma unroll
-    for (int i = 0; i < 11; ++i) {
-      dot3 D = {0, 0, 0};
-#pragma unroll
-      for (int j = 0; j < POSEIDON_PB; ++j)
-        if (j < nb) dot3_mac(D, y[j], POSEIDON_BLOCK.vs[r0 + j][i]);
-      s[1 + i] = dot3_reduce_add_nc(D, s[1 + i]);
-    }
+    r0 += B;
   }
+  return R;
+}
+static_assert(POSEIDON_SCHED[0] + POSEIDON_SCHED[1] + POSEIDON_SCHED[2] + POSEIDON_SCHED[3] + POSEIDON_SCHED[4] + POSEIDON_SCHED[5] +
+                      POSEIDON_SCHED[6] + POSEIDON_SCHED[7] == 22, "the blocks must cover the 22 partial rounds");
+__constant__ PoseidonBlockConsts POSEIDON_BLK = make_block_consts();
+// round constants with one all-zero round appended, so "the constants of the next round" exists after round 29 too
+struct PoseidonRcExt {
+  u64 v[31 * 12];
+};
+constexpr PoseidonRcExt make_rc_ext() {
+  PoseidonRcExt R{};
+  for (int i = 0; i < 360; ++i) R.v[i] = POSEIDON_RC_RAW[i] % GL_P;
+  return R;
+}
+__constant__ PoseidonRcExt POSEIDON_RC_EXT = make_rc_ext();
+
+GLD void poseidon_mac32(u64& al, u64& ah, u64 x, u32 c) {
+  al += (u64)(u32)x * c;
+  ah += (u64)(u32)(x >> 32) * c;
+}
+// Dense MDS layer with the NEXT round's constants folded in: they are the accumulators' initial values (free).
+GLD void poseidon_mds_rc_nc(u64 (&s)[12], const u64* __restrict__ rc_next) {
+  const u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+  u32 lo[12], hi[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) {
+    lo[i] = (u32)s[i];
+    hi[i] = (u32)(s[i] >> 32);
+  }
+#pragma unroll
+  for (int r = 0; r < 12; ++r) {
+    const u64 k = rc_next[r];
+    u64 al = (u32)k, ah = k >> 32;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      al += (u64)C[i] * lo[(i + r) % 12];
+      ah += (u64)C[i] * hi[(i + r) % 12];
+    }
+    if (r == 0) {
+      al += (u64)8 * lo[0];
+      ah += (u64)8 * hi[0];
+    }
+    s[r] = mds_fold_nc(al, ah);  // al, ah < 2^43
+  }
+}
+// One block of B partial rounds (see above).  `lane0(j, x)` is handed the S-box INPUT of the block's round j and returns
+// the value that goes through the S-box: the identity for the permutation.
+template <int B>
+GLD void poseidon_partial_block_nc(u64 (&s)[12], const u64* __restrict__ kappa, const u64* __restrict__ K) {
+  constexpr PoseidonIntBlock T = make_int_block(B);
+  u64 y[B];
+  y[0] = poseidon_sbox_nc(s[0]);
+  s[0] = y[0];  // s is now w = (y_0, u_1 .. u_11)
+#pragma unroll
+  for (int j = 1; j < B; ++j) {
+    const u64 k = kappa[j];
+    u64 al = (u32)k, ah = k >> 32;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) poseidon_mac32(al, ah, s[i], T.A[j][i]);
+#pragma unroll
+    for (int i = 1; i < j; ++i) poseidon_mac32(al, ah, y[i], T.b[j][i]);
+    y[j] = poseidon_sbox_nc(mds_fold_nc(al, ah));
+  }
+  u64 out[12];
+#pragma unroll
+  for (int r = 0; r < 12; ++r) {
+    const u64 k = K[r];
+    u64 al = (u32)k, ah = k >> 32;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) poseidon_mac32(al, ah, s[i], T.C[r][i]);
+#pragma unroll
+    for (int i = 1; i < B; ++i) poseidon_mac32(al, ah, y[i], T.c[i][r]);
+    out[r] = mds_fold_nc(al, ah);  // al, ah < 2^57
+  }
+#pragma unroll
+  for (int r = 0; r < 12; ++r) s[r] = out[r];
 }
 
 // Permutation on arbitrary-u64 lanes; outputs are arbitrary u64 representatives (NOT canonical).
 GLD void poseidon_permute_nc(u64 (&s)[12]) {
+#pragma unroll
+  for (int i = 0; i < 12; ++i) s[i] = gl_add_nc_c(s[i], POSEIDON_RC_EXT.v[i]);
 #pragma unroll 1
   for (int r = 0; r < 4; ++r) {
 #pragma unroll
-    for (int i = 0; i < 12; ++i) s[i] = poseidon_sbox_nc(gl_add_nc_c(s[i], POSEIDON_RC[r * 12 + i]));
-    poseidon_mds_nc(s);
+    for (int i = 0; i < 12; ++i) s[i] = poseidon_sbox_nc(s[i]);
+    poseidon_mds_rc_nc(s, POSEIDON_RC_EXT.v + (r + 1) * 12);
   }
-  poseidon_partial_rounds_nc(s, [](int, u64 x) { return x; });
+#pragma unroll 1
+  for (int blk = 0; blk < POSEIDON_NBLOCKS - 1; ++blk) poseidon_partial_block_nc<3>(s, POSEIDON_BLK.kappa[blk], POSEIDON_BLK.K[blk]);
+  poseidon_partial_block_nc<1>(s, POSEIDON_BLK.kappa[POSEIDON_NBLOCKS - 1], POSEIDON_BLK.K[POSEIDON_NBLOCKS - 1]);
 #pragma unroll 1
   for (int r = 26; r < 30; ++r) {
 #pragma unroll
-    for (int i = 0; i < 12; ++i) s[i] = poseidon_sbox_nc(gl_add_nc_c(s[i], POSEIDON_RC[r * 12 + i]));
-    poseidon_mds_nc(s);
+    for (int i = 0; i < 12; ++i) s[i] = poseidon_sbox_nc(s[i]);
+    poseidon_mds_rc_nc(s, POSEIDON_RC_EXT.v + (r + 1) * 12);
   }
 }
 

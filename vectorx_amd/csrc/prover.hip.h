@@ -8,6 +8,7 @@
 #include "batch.hip.h"
 #include "challenger.h"
 #include "plonk_kernels.hip.h"
+#include "desc_check.h"
 
 struct vx_circuit {
   vx_ctx* ctx = nullptr;
@@ -32,45 +33,53 @@ struct vx_circuit {
   size_t n() const { return (size_t)1 << degree_bits; }
 };
 
-static int circuit_create(vx_ctx* c, const vx_circuit_desc* d, vx_circuit** out) {
-  if (d->degree_bits < 1 || d->degree_bits + d->rate_bits > ROOT_TABLE_LOG) return vx_fail(VX_E_INVALID, "circuit: degree_bits=%d rate_bits=%d unsupported", d->degree_bits, d->rate_bits);
-  if (d->num_challenges < 1 || d->num_challenges > VX_MAX_CHALLENGES) return vx_fail(VX_E_INVALID, "circuit: num_challenges %d unsupported", d->num_challenges);
-  if (d->num_gates < 1 || d->num_gates > VX_MAX_GATES) return vx_fail(VX_E_INVALID, "circuit: num_gates %d unsupported", d->num_gates);
-  if (d->rate_bits < 1 || (1 << d->rate_bits) > VX_MAX_RATE) return vx_fail(VX_E_INVALID, "circuit: rate_bits %d unsupported", d->rate_bits);
-  if (d->quotient_degree_factor != (1 << d->rate_bits)) return vx_fail(VX_E_INVALID, "circuit: quotient_degree_factor must equal the blow-up (standard_recursion_config: 8)");
-  if (d->num_routed_wires > d->num_wires || d->num_routed_wires < 1) return vx_fail(VX_E_INVALID, "circuit: bad wire counts");
-  if ((d->num_routed_wires + d->quotient_degree_factor - 1) / d->quotient_degree_factor > PERM_MAX_CHUNKS) return vx_fail(VX_E_INVALID, "circuit: too many partial-product chunks");
-  if (d->pow_bits < 0 || d->pow_bits > 40) return vx_fail(VX_E_INVALID, "circuit: pow_bits %d unsupported", d->pow_bits);
-  if (!d->constants_sigmas || !d->k_is) return vx_fail(VX_E_INVALID, "circuit: NULL preprocessed data");
-  for (int g = 0; g < d->num_gates; ++g) {
-    int t = d->gate_types[g];
-    if (t < VX_GATE_NOOP || t > VX_GATE_PROGRAM) return vx_fail(VX_E_INVALID, "circuit: gate type %d is not in the supported set", t);
-    if (t == VX_GATE_PROGRAM) {
-      if (!d->programs || !d->program_offsets || d->program_offsets[g] < 0 || d->program_offsets[g] >= d->programs_len)
-        return vx_fail(VX_E_INVALID, "circuit: program gate %d has no program", g);
-      // validate: terminated, known opcodes, operands in range, no register read before it is written
-      bool ended = false;
-      uint64_t defined = 0;
-      for (int pc = d->program_offsets[g]; pc < d->programs_len && !ended; ++pc) {
-        const uint64_t ins = d->programs[pc];
-        const int op = (int)(ins & 0xFF), dst = (int)((ins >> 8) & 63), a = (int)((ins >> 16) & 0xFFFF), b = (int)((ins >> 32) & 0xFFFF);
-        auto is_def = [&](int r) { return (defined >> (r & 63)) & 1; };
-        if (op == VX_OP_END) ended = true;
-        else if (op == VX_OP_LDI) { if (++pc >= d->programs_len) return vx_fail(VX_E_INVALID, "circuit: truncated program"); }
-        else if (op == VX_OP_LDW) { if (a >= d->num_wires) return vx_fail(VX_E_INVALID, "circuit: program reads wire %d", a); }
-        else if (op == VX_OP_LDC) { if (d->num_selectors + a >= d->num_constants) return vx_fail(VX_E_INVALID, "circuit: program reads constant %d", a); }
-        else if (op == VX_OP_ADD || op == VX_OP_SUB || op == VX_OP_MUL) { if (!is_def(a) || !is_def(b)) return vx_fail(VX_E_INVALID, "circuit: program reads a register before writing it"); }
-        else if (op == VX_OP_PUSH) { if (!is_def(a)) return vx_fail(VX_E_INVALID, "circuit: program pushes a register before writing it"); }
-        else if (op < VX_OP_END || op > VX_OP_LDP) return vx_fail(VX_E_INVALID, "circuit: bad opcode %d in a constraint program", op);
-        if (op != VX_OP_END && op != VX_OP_PUSH) defined |= (uint64_t)1 << dst;
-      }
-      if (!ended) return vx_fail(VX_E_INVALID, "circuit: unterminated constraint program");
-    }
-    if (t == VX_GATE_POSEIDON && d->num_wires < 135) return vx_fail(VX_E_INVALID, "circuit: PoseidonGate needs 135 wires");
-    if (t == VX_GATE_ARITHMETIC && 4 * d->gate_params[g] > d->num_wires) return vx_fail(VX_E_INVALID, "circuit: ArithmeticGate ops exceed the wires");
-    if (d->selector_indices[g] < 0 || d->selector_indices[g] >= d->num_selectors) return vx_fail(VX_E_INVALID, "circuit: bad selector index");
+// VerifierOnlyCircuitData::circuit_digest.  The caller's value when it passes one (VX_DESC_HAS_CIRCUIT_DIGEST) — the Rust
+// side holds it, and then no recalled convention of this library is involved; otherwise THE one place the rule is
+// restated (plonk/circuit_builder.rs, recalled): hash_no_pad(constants_sigmas_cap || domain_separator || [degree_bits])
+// with plonky2x's default EMPTY domain separator.  Open question kept here on purpose: whether v0.2.0 hashes the raw
+// (empty) separator, as below, or a padded form — a real circuit answers it by passing its digest.
+static vxh::Hash4 circuit_digest_of(const vx_circuit_desc* d, const u64* cap_and_degree, size_t len) {
+  if (d->override_flags & VX_DESC_HAS_CIRCUIT_DIGEST) {
+    vxh::Hash4 h;
+    for (int i = 0; i < 4; ++i) h.e[i] = vxh::canon(d->circuit_digest[i]);
+    return h;
   }
+  return vxh::hash_no_pad(cap_and_degree, len);
+}
+
+static void circuit_free(vx_circuit* k) {
+  if (!k) return;
+  hipSetDevice(k->ctx->device);
+  hipStreamSynchronize(k->ctx->stream);
+  if (k->cs) {
+    k->ctx->pool_free(k->cs->coeffs);
+    k->ctx->pool_free(k->cs->lde);
+    k->ctx->pool_free(k->cs->tree);
+    delete k->cs;
+  }
+  hipFree(k->sigmas);
+  hipFree(k->k_is);
+  hipFree(k->programs);
+  delete k;
+}
+
+static int circuit_create(vx_ctx* c, const vx_circuit_desc* d, vx_circuit** out) {
+  DescResolved res;
+  {
+    const std::string why = desc_check(d, /*need_preprocessed=*/true, &res);
+    if (!why.empty()) return vx_fail(VX_E_INVALID, "%s", why.c_str());
+  }
+  // every failure below goes through circuit_free(k) (and frees the staging buffer): nothing leaks on an early return
   vx_circuit* k = new vx_circuit();
+  u64* staging = nullptr;
+  struct Guard {
+    vx_circuit*& k;
+    u64*& staging;
+    ~Guard() {
+      if (staging) hipFree(staging);
+      if (k) circuit_free(k);
+    }
+  } guard{k, staging};
   k->ctx = c;
   k->degree_bits = d->degree_bits;
   k->num_wires = d->num_wires;
@@ -83,6 +92,7 @@ static int circuit_create(vx_ctx* c, const vx_circuit_desc* d, vx_circuit** out)
   k->qdf = d->quotient_degree_factor;
   k->num_selectors = d->num_selectors;
   k->num_constants = d->num_constants;
+  k->arity_bits = res.arity_bits;  // the caller's FriParams::reduction_arity_bits, or ConstantArityBits(4, 5)
   for (int g = 0; g < d->num_gates; ++g)
     k->gates.push_back(GateDev{d->gate_types[g], d->gate_params[g], d->selector_indices[g], d->group_starts[g], d->group_ends[g]});
   {
@@ -91,10 +101,9 @@ static int circuit_create(vx_ctx* c, const vx_circuit_desc* d, vx_circuit** out)
       k->prog_off.push_back(d->gate_types[g] == VX_GATE_PROGRAM ? d->program_offsets[g] : -1);
       nprog += d->gate_types[g] == VX_GATE_PROGRAM;
     }
-    if (nprog > VX_MAX_PROGRAM_GATES) { delete k; return vx_fail(VX_E_INVALID, "circuit: too many program gates"); }
     if (nprog) {
       k->programs_host.assign(d->programs, d->programs + d->programs_len);
-      if (hipMalloc(&k->programs, (size_t)d->programs_len * 8) != hipSuccess) { delete k; return vx_fail(VX_E_NOMEM, "circuit: out of device memory"); }
+      if (hipMalloc(&k->programs, (size_t)d->programs_len * 8) != hipSuccess) return vx_fail(VX_E_NOMEM, "circuit: out of device memory");
       HIPCHK(hipMemcpy(k->programs, d->programs, (size_t)d->programs_len * 8, hipMemcpyHostToDevice));
     }
     // compile the programs to native code (jit.hip.h): one kernel for the whole gate set; on any failure the gates
@@ -126,62 +135,29 @@ static int circuit_create(vx_ctx* c, const vx_circuit_desc* d, vx_circuit** out)
   for (auto& v : k->k_is_host) v = vxh::canon(v);
   k->pi_rows.assign(d->pi_rows, d->pi_rows + d->num_public_inputs);
   k->pi_cols.assign(d->pi_cols, d->pi_cols + d->num_public_inputs);
-  for (int i = 0; i < d->num_public_inputs; ++i)
-    if (k->pi_rows[i] >= k->n() || (int)k->pi_cols[i] >= k->num_wires) {
-      delete k;
-      return vx_fail(VX_E_INVALID, "circuit: public input target out of range");
-    }
-  // fri/reduction_strategies.rs ConstantArityBits(4, 5)
-  {
-    int db = k->degree_bits;
-    while (db > 5 && db + k->rate_bits - 4 >= k->cap_height) {
-      k->arity_bits.push_back(4);
-      db -= 4;
-    }
-  }
   const size_t n = k->n();
   const size_t m = (size_t)k->num_constants + k->nr;
   int rc = batch_alloc(c, k->degree_bits, m, k->rate_bits, k->cap_height, &k->cs);
-  if (rc) { delete k; return rc; }
-  u64* staging = nullptr;
+  if (rc) return rc;
   if (hipMalloc(&staging, m * n * 8) != hipSuccess || hipMalloc(&k->sigmas, (size_t)k->nr * n * 8) != hipSuccess ||
-      hipMalloc(&k->k_is, k->nr * 8) != hipSuccess) {
-    hipFree(staging);
+      hipMalloc(&k->k_is, k->nr * 8) != hipSuccess)
     return vx_fail(VX_E_NOMEM, "circuit: out of device memory");
-  }
   HIPCHK(hipMemcpyAsync(staging, d->constants_sigmas, m * n * 8, hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(k->k_is, k->k_is_host.data(), k->nr * 8, hipMemcpyHostToDevice, c->stream));
   hipLaunchKernelGGL(canon_kernel, dim3((unsigned)((m * n + 255) / 256)), dim3(256), 0, c->stream, staging, m * n);
   HIPCHK(hipMemcpyAsync(k->sigmas, staging + (size_t)k->num_constants * n, (size_t)k->nr * n * 8, hipMemcpyDeviceToDevice, c->stream));
   rc = batch_commit_device(c, k->cs, staging, n, false);
   hipError_t e = hipStreamSynchronize(c->stream);
-  hipFree(staging);
   if (rc == VX_OK && e != hipSuccess) rc = vx_fail(VX_E_HIP, "circuit: %s", hipGetErrorString(e));
   if (rc) return rc;
-  // circuit_digest = hash_no_pad(cap || [degree_bits])   (empty domain separator)
   std::vector<u64> pre(((size_t)4 << k->cap_height) + 1);
   HIPCHK(hipMemcpy(pre.data(), k->cs->tree + k->cs->cap_off * 4, (size_t)32 << k->cap_height, hipMemcpyDeviceToHost));
   pre.back() = (u64)k->degree_bits;
-  k->digest = vxh::hash_no_pad(pre.data(), pre.size());
   k->cs_cap_host.assign(pre.begin(), pre.end() - 1);
+  k->digest = circuit_digest_of(d, pre.data(), pre.size());
   *out = k;
+  k = nullptr;  // ownership passes to the caller
   return VX_OK;
-}
-
-static void circuit_free(vx_circuit* k) {
-  if (!k) return;
-  hipSetDevice(k->ctx->device);
-  hipStreamSynchronize(k->ctx->stream);
-  if (k->cs) {
-    k->ctx->pool_free(k->cs->coeffs);
-    k->ctx->pool_free(k->cs->lde);
-    k->ctx->pool_free(k->cs->tree);
-    delete k->cs;
-  }
-  hipFree(k->sigmas);
-  hipFree(k->k_is);
-  hipFree(k->programs);
-  delete k;
 }
 
 static void batch_release(vx_ctx* c, vx_batch* b) {
@@ -270,6 +246,9 @@ static int prove_impl(vx_ctx* c, vx_circuit* k, const u64* wires_in, bool wires_
   const size_t Nl = N >> sh.lg, row_base = Nl * (size_t)sh.rank;
   const int zc = rate >> sh.lg, z0 = zc * sh.rank;
   Scratch S(c);
+  // host sources of asynchronous uploads on the context's stream: they must outlive the copies, so they live as long as the proof
+  std::vector<u64> ap;
+  std::vector<Limbs3x2> al;
   vx_batch *wires_b = nullptr, *zs_b = nullptr, *quot_b = nullptr;
   struct Cleanup {
     vx_ctx* c;
@@ -413,7 +392,7 @@ static int prove_impl(vx_ctx* c, vx_circuit* k, const u64* wires_in, bool wires_
       {
         // alpha powers for reduce_with_powers: L_0 terms, partial-product checks, then the widest gate (123 constraints)
         if ((size_t)nch * (1 + nchunks) + 160 > VX_ALPHA_POWS) return vx_fail(VX_E_INVALID, "prove: too many constraint terms");
-        std::vector<u64> ap((size_t)VX_MAX_CHALLENGES * VX_ALPHA_POWS, 0);
+        ap.assign((size_t)VX_MAX_CHALLENGES * VX_ALPHA_POWS, 0);
         for (int cI = 0; cI < nch; ++cI) {
           u64 pw = 1;
           for (int i = 0; i < VX_ALPHA_POWS; ++i) {
@@ -423,10 +402,10 @@ static int prove_impl(vx_ctx* c, vx_circuit* k, const u64* wires_in, bool wires_
         }
         u64* d_ap = S.get(ap.size());
         if (!d_ap) return vx_fail(VX_E_NOMEM, "prove: out of device memory (alpha powers)");
-        HIPCHK(hipMemcpy(d_ap, ap.data(), ap.size() * 8, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpyAsync(d_ap, ap.data(), ap.size() * 8, hipMemcpyHostToDevice, c->stream));
         qp.alpha_pows = d_ap;
         // the same powers split for the quotient kernel's carry-free accumulation: limbs of a and of 2^32 a
-        std::vector<Limbs3x2> al(ap.size());
+        al.assign(ap.size(), Limbs3x2{});
         for (size_t i = 0; i < ap.size(); ++i) {
           const u64 bb = ap[i], bh = mul(bb, (u64)1 << 32);
           al[i].lo[0] = (u32)(bb & 0x3FFFFFu), al[i].lo[1] = (u32)((bb >> 22) & 0x3FFFFFu), al[i].lo[2] = (u32)(bb >> 44);
@@ -434,7 +413,7 @@ static int prove_impl(vx_ctx* c, vx_circuit* k, const u64* wires_in, bool wires_
         }
         Limbs3x2* d_al = (Limbs3x2*)S.get((al.size() * sizeof(Limbs3x2) + 7) / 8);
         if (!d_al) return vx_fail(VX_E_NOMEM, "prove: out of device memory (alpha powers)");
-        HIPCHK(hipMemcpy(d_al, al.data(), al.size() * sizeof(Limbs3x2), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpyAsync(d_al, al.data(), al.size() * sizeof(Limbs3x2), hipMemcpyHostToDevice, c->stream));
         qp.alpha_limbs = d_al;
       }
       qp.out = qv;

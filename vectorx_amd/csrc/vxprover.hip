@@ -482,7 +482,13 @@ int vx_circuit_create(vx_ctx* c, const vx_circuit_desc* desc, vx_circuit** out) 
   if (!c || !desc || !out) return vx_fail(VX_E_INVALID, "vx_circuit_create: NULL argument");
   *out = nullptr;
   HIPCHK(hipSetDevice(c->device));
-  return circuit_create(c, desc, out);
+  try {  // nothing unwinds across the ABI
+    return circuit_create(c, desc, out);
+  } catch (const std::bad_alloc&) {
+    return vx_fail(VX_E_NOMEM, "vx_circuit_create: out of host memory");
+  } catch (const std::exception& e) {
+    return vx_fail(VX_E_INVALID, "vx_circuit_create: %s", e.what());
+  }
 }
 void vx_circuit_free(vx_circuit* k) { circuit_free(k); }
 int vx_circuit_digest(vx_circuit* k, uint64_t digest_out[4]) {
@@ -518,7 +524,14 @@ int vx_prove(vx_ctx* c, vx_circuit* k, const uint64_t* wires, int wires_on_devic
   if (k->ctx != c) return vx_fail(VX_E_INVALID, "vx_prove: circuit belongs to a different context");
   HIPCHK(hipSetDevice(c->device));
   std::vector<uint8_t> proof;
-  int rc = prove_impl(c, k, wires, wires_on_device != 0, pow_witness_hint, proof);
+  int rc;
+  try {  // nothing unwinds across the ABI
+    rc = prove_impl(c, k, wires, wires_on_device != 0, pow_witness_hint, proof);
+  } catch (const std::bad_alloc&) {
+    rc = vx_fail(VX_E_NOMEM, "vx_prove: out of host memory");
+  } catch (const std::exception& e) {
+    rc = vx_fail(VX_E_INVALID, "vx_prove: %s", e.what());
+  }
   if (rc != VX_OK) {
     hipStreamSynchronize(c->stream);
     return rc;
@@ -566,66 +579,46 @@ int vx_verify(vx_circuit* k, const uint8_t* proof, size_t proof_len) {
 
 int vx_verify_standalone(const vx_circuit_desc* d, const uint64_t* cs_cap, const uint8_t* proof, size_t proof_len) {
   if (!d || !cs_cap || !proof) return vx_fail(VX_E_INVALID, "vx_verify_standalone: NULL argument");
-  if (d->num_gates < 1 || d->num_gates > VX_MAX_GATES || !d->gate_types || !d->gate_params || !d->selector_indices || !d->group_starts ||
-      !d->group_ends || !d->k_is || d->degree_bits < 1 || d->degree_bits + d->rate_bits > ROOT_TABLE_LOG || d->cap_height < 0 ||
-      d->cap_height > d->degree_bits + d->rate_bits || d->quotient_degree_factor < 1 || d->num_challenges < 1 ||
-      d->num_challenges > VX_MAX_CHALLENGES || d->num_routed_wires < 1 || d->num_routed_wires > d->num_wires || d->pow_bits < 0 || d->pow_bits > 40)
-    return vx_fail(VX_E_INVALID, "vx_verify_standalone: bad circuit description");
-  vxv::CircuitV v;
-  v.degree_bits = d->degree_bits;
-  v.num_wires = d->num_wires;
-  v.num_routed = d->num_routed_wires;
-  v.num_challenges = d->num_challenges;
-  v.rate_bits = d->rate_bits;
-  v.cap_height = d->cap_height;
-  v.pow_bits = d->pow_bits;
-  v.num_queries = d->num_query_rounds;
-  v.qdf = d->quotient_degree_factor;
-  v.num_selectors = d->num_selectors;
-  v.num_constants = d->num_constants;
-  v.num_public_inputs = d->num_public_inputs;
-  for (int g = 0; g < d->num_gates; ++g) {
-    const uint64_t* prog = nullptr;
-    if (d->gate_types[g] == VX_GATE_PROGRAM) {
-      if (!d->programs || !d->program_offsets || d->program_offsets[g] < 0 || d->program_offsets[g] >= d->programs_len)
-        return vx_fail(VX_E_INVALID, "vx_verify_standalone: program gate %d has no program", g);
-      bool ended = false;  // the evaluator walks to VX_OP_END: make sure there is one inside the buffer
-      for (int pc = d->program_offsets[g]; pc < d->programs_len && !ended; ++pc) {
-        const int op = (int)(d->programs[pc] & 0xFF);
-        if (op == VX_OP_END) ended = true;
-        else if (op == VX_OP_LDI) ++pc;
-        else if (op == VX_OP_LDW && (int)((d->programs[pc] >> 16) & 0xFFFF) >= d->num_wires) return vx_fail(VX_E_INVALID, "vx_verify_standalone: program reads a wire out of range");
-        else if (op == VX_OP_LDC && d->num_selectors + (int)((d->programs[pc] >> 16) & 0xFFFF) >= d->num_constants) return vx_fail(VX_E_INVALID, "vx_verify_standalone: program reads a constant out of range");
-      }
-      if (!ended) return vx_fail(VX_E_INVALID, "vx_verify_standalone: unterminated constraint program");
-      prog = d->programs + d->program_offsets[g];
-    }
-    v.gates.push_back(vxv::GateV{d->gate_types[g], d->gate_params[g], d->selector_indices[g], d->group_starts[g], d->group_ends[g], prog});
-  }
-  {  // the FRI reduction strategy ConstantArityBits(4, 5), as in circuit_create
-    int db = d->degree_bits;
-    while (db > 5 && db + d->rate_bits - 4 >= d->cap_height) {
-      v.arity_bits.push_back(4);
-      db -= 4;
-    }
-  }
-  std::vector<u64> k_is(d->k_is, d->k_is + d->num_routed_wires);
-  for (auto& x : k_is) x = vxh::canon(x);
-  v.k_is = k_is.data();
-  const size_t cap_words = (size_t)4 << d->cap_height;
-  std::vector<u64> pre(cap_words + 1);
-  for (size_t i = 0; i < cap_words; ++i) pre[i] = vxh::canon(cs_cap[i]);
-  pre.back() = (u64)d->degree_bits;
-  v.cs_cap = pre.data();
-  v.digest = vxh::hash_no_pad(pre.data(), pre.size());
-  std::string why;
   try {
-    why = vxv::verify(v, proof, proof_len);
-  } catch (const std::exception& e) {
-    why = std::string("exception: ") + e.what();
+    DescResolved res;
+    {  // the same validation vx_circuit_create runs (desc_check.h); a verifier holds no preprocessed polynomials
+      const std::string why = desc_check(d, /*need_preprocessed=*/false, &res);
+      if (!why.empty()) return vx_fail(VX_E_INVALID, "vx_verify_standalone: %s", why.c_str());
+    }
+    vxv::CircuitV v;
+    v.degree_bits = d->degree_bits;
+    v.num_wires = d->num_wires;
+    v.num_routed = d->num_routed_wires;
+    v.num_challenges = d->num_challenges;
+    v.rate_bits = d->rate_bits;
+    v.cap_height = d->cap_height;
+    v.pow_bits = d->pow_bits;
+    v.num_queries = d->num_query_rounds;
+    v.qdf = d->quotient_degree_factor;
+    v.num_selectors = d->num_selectors;
+    v.num_constants = d->num_constants;
+    v.num_public_inputs = d->num_public_inputs;
+    for (int g = 0; g < d->num_gates; ++g)
+      v.gates.push_back(vxv::GateV{d->gate_types[g], d->gate_params[g], d->selector_indices[g], d->group_starts[g], d->group_ends[g],
+                                   d->gate_types[g] == VX_GATE_PROGRAM ? d->programs + d->program_offsets[g] : nullptr});
+    v.arity_bits = res.arity_bits;
+    std::vector<u64> k_is(d->k_is, d->k_is + d->num_routed_wires);
+    for (auto& x : k_is) x = vxh::canon(x);
+    v.k_is = k_is.data();
+    const size_t cap_words = (size_t)4 << d->cap_height;
+    std::vector<u64> pre(cap_words + 1);
+    for (size_t i = 0; i < cap_words; ++i) pre[i] = vxh::canon(cs_cap[i]);
+    pre.back() = (u64)d->degree_bits;
+    v.cs_cap = pre.data();
+    v.digest = circuit_digest_of(d, pre.data(), pre.size());
+    const std::string why = vxv::verify(v, proof, proof_len);
+    if (!why.empty()) return vx_fail(VX_E_PROOF, "vx_verify: %s", why.c_str());
+    return VX_OK;
+  } catch (const std::bad_alloc&) {
+    return vx_fail(VX_E_NOMEM, "vx_verify_standalone: out of host memory");
+  } catch (const std::exception& e) {  // never unwind across the ABI
+    return vx_fail(VX_E_PROOF, "vx_verify: exception: %s", e.what());
   }
-  if (!why.empty()) return vx_fail(VX_E_PROOF, "vx_verify: %s", why.c_str());
-  return VX_OK;
 }
 
 int vx_prove_sharded(vx_ctx* c, vx_circuit* k, const uint64_t* wires, int wires_on_device, int rank, int world,
@@ -644,7 +637,14 @@ int vx_prove_sharded(vx_ctx* c, vx_circuit* k, const uint64_t* wires, int wires_
   sh.user = user;
   HIPCHK(hipSetDevice(c->device));
   std::vector<uint8_t> proof;
-  int rc = prove_impl(c, k, wires, wires_on_device != 0, pow_witness_hint, proof, sh);
+  int rc;
+  try {  // nothing unwinds across the ABI
+    rc = prove_impl(c, k, wires, wires_on_device != 0, pow_witness_hint, proof, sh);
+  } catch (const std::bad_alloc&) {
+    rc = vx_fail(VX_E_NOMEM, "vx_prove_sharded: out of host memory");
+  } catch (const std::exception& e) {
+    rc = vx_fail(VX_E_INVALID, "vx_prove_sharded: %s", e.what());
+  }
   if (rc != VX_OK) {
     hipStreamSynchronize(c->stream);
     return rc;

@@ -26,7 +26,16 @@ class CircuitDesc(ctypes.Structure):
         ("constants_sigmas", ctypes.c_void_p), ("k_is", ctypes.c_void_p),
         ("num_public_inputs", ctypes.c_int32), ("pi_rows", ctypes.c_void_p), ("pi_cols", ctypes.c_void_p),
         ("programs_len", ctypes.c_int32), ("programs", ctypes.c_void_p), ("program_offsets", ctypes.c_void_p),
+        # values the caller holds (CommonCircuitData / VerifierOnlyCircuitData); zero-initialised = derive
+        ("override_flags", ctypes.c_uint32), ("hiding", ctypes.c_int32), ("circuit_digest", ctypes.c_uint64 * 4),
+        ("num_fri_reduction_arity_bits", ctypes.c_int32), ("num_partial_products", ctypes.c_int32),
+        ("fri_reduction_arity_bits", ctypes.c_void_p),
     ]
+
+
+DESC_HAS_CIRCUIT_DIGEST = 1
+DESC_HAS_FRI_ARITIES = 2
+DESC_HAS_NUM_PARTIAL_PRODUCTS = 4
 
 
 FLAG_PROGRAM_GATES = 1      # add ArithmeticExtensionGate + BaseSumGate rows, evaluated through constraint programs
@@ -123,6 +132,24 @@ class SynthCircuit:
         if rec:
             d["recursion_each"] = rec   # rows of EACH of MulExtension / Reducing / ReducingExtension / PoseidonMds / CosetInterpolation
         return d
+
+    # ---- overrides: what a plonky2 caller takes from CommonCircuitData / VerifierOnlyCircuitData (vxprover.h VX_DESC_HAS_*)
+    def set_circuit_digest(self, digest) -> None:
+        """Use this circuit_digest (4 field elements) instead of the library's own derivation."""
+        for i in range(4):
+            self.desc.circuit_digest[i] = int(digest[i])
+        self.desc.override_flags |= DESC_HAS_CIRCUIT_DIGEST
+
+    def set_fri_reduction_arity_bits(self, arities) -> None:
+        """Use FriParams::reduction_arity_bits = `arities` instead of ConstantArityBits(4, 5)."""
+        self._arities = (ctypes.c_int32 * max(1, len(arities)))(*arities)   # keep the buffer alive
+        self.desc.fri_reduction_arity_bits = ctypes.cast(self._arities, ctypes.c_void_p).value
+        self.desc.num_fri_reduction_arity_bits = len(arities)
+        self.desc.override_flags |= DESC_HAS_FRI_ARITIES
+
+    def set_num_partial_products(self, npp: int) -> None:
+        self.desc.num_partial_products = int(npp)
+        self.desc.override_flags |= DESC_HAS_NUM_PARTIAL_PRODUCTS
 
     def release_host_buffers(self, witness=True, preprocessed=True):
         _load().vxs_release_host_buffers(self._h, int(witness), int(preprocessed))
