@@ -40,8 +40,10 @@ def parse():
                          "(configs[3]): ALL GPUs work on one proof (vx_prove_sharded, coset split, RCCL all-gathers), strong scaling")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-log-n", type=int, default=None,
-                    help="rows (log2) of the bounded CPU-baseline sample (default 16 for prove, 17 for commit)")
+                    help="rows (log2) of the bounded CPU-baseline sample (default 18 for prove: ~20 s on 16 cores; 17 for commit)")
     ap.add_argument("--poseidon-percent", type=int, default=50, help="share of PoseidonGate rows in the synthetic circuit")
+    ap.add_argument("--no-host-witness-leg", action="store_true",
+                    help="skip the extra (untimed-by-the-contract) leg that proves from a pinned HOST witness (PCIe-inclusive rate)")
     return ap.parse_args()
 
 
@@ -82,7 +84,7 @@ def main():
     ctx = vx.Context(local_rank)  # no CPU fallback: raises if the HIP library / GPU is missing
     n = 1 << args.log_n
     if args.cpu_sample_log_n is None:
-        args.cpu_sample_log_n = 16 if args.workload == "prove" else 17
+        args.cpu_sample_log_n = 18 if args.workload == "prove" else 17
     keep = []
 
     if args.workload == "commit":
@@ -115,6 +117,13 @@ def main():
     dt = H.run_timed(step, args.steps, args.warmup, sync, dist, device=f"cuda:{local_rank}", before_timed=before_timed)
     prof = ctx.prof()
     ctx.prof_enable(False)
+
+    # Extra leg, OUTSIDE the contract's timed region (`value` stays "inputs resident in HBM"): the same K proofs from a
+    # page-locked HOST witness — SURVEY.md §8d's end-to-end definition (witness in host memory -> proof bytes, PCIe included).
+    host_leg = None
+    if args.workload == "prove" and world == 1 and not args.no_host_witness_leg:
+        import bench_prove
+        host_leg = bench_prove.host_witness_leg(ctx, args, sync)
 
     if rank == 0:
         lde = prof.get("lde", {"ms": 0.0, "calls": 0, "alg_bytes": 0.0})
@@ -149,8 +158,26 @@ def main():
             perms = N * (17 + 3 + 2)   # ceil(135/8) + ceil(20/8) + ceil(16/8) sponge permutations per LDE row
             ms = hl["ms"] / args.steps
             alu = {"kernel": "hash_leaves_colmajor_kernel", "bound": "integer ALU (VALU issue)", "perms_per_proof": perms,
-                   "ms_per_proof": round(ms, 2), "gperms_per_s": round(perms / (ms * 1e-3) / 1e9, 3),
-                   "valu_insts_per_perm": 17446, "source": "profiles/r01_pmc_sq.md (SQ_INSTS_VALU / permutations) + DESIGN.md §3"}
+                   "ms_per_proof": round(ms, 2), "gperms_per_s": round(perms / (ms * 1e-3) / 1e9, 3)}
+            try:
+                # per-permutation VALU instruction count: PMC-measured (SQ_INSTS_VALU), reproduced by the loop-weighted static
+                # histogram of the gfx950 assembly (tools/alu_ceiling.py -> profiles/r02_alu_ceiling.json)
+                ceil_info = json.loads((ROOT / "profiles" / "r02_alu_ceiling.json").read_text())
+                ipp = float(ceil_info["valu_insts_per_perm_pmc"] or ceil_info["valu_insts_per_perm_static"])
+                ghz = ctx.clock_ghz()          # measured NOW, on this device, under a VALU-saturating load
+                achieved = perms / (ms * 1e-3) * ipp / 64.0
+                # ceiling: one VALU instruction per wavefront per SIMD per QUAD-cycle — the unit the SQ's own counters use
+                # (SQ_ACTIVE_INST_VALU == SQ_INSTS_VALU for this kernel); single-opcode loops of its instruction classes
+                # measure 4.4 cycles (profiles/r02_ubench_int.md), mixed streams 3.8-4.1: 4.0 is the issue model.
+                ceiling = ceil_info["simds"] * ghz * 1e9 / 4.0
+                alu.update({"valu_insts_per_perm": ipp, "clock_ghz_measured_in_run": round(ghz, 3),
+                            "achieved_wave_inst_per_s": achieved, "ceiling_wave_inst_per_s": ceiling,
+                            "frac": round(achieved / ceiling, 4),
+                            "ceiling_model": "1024 SIMDs x measured clock / 4 cycles per wavefront-instruction (quad-cycle VALU issue)",
+                            "ubench_cycles_per_inst": ceil_info["cycles"],
+                            "source": "profiles/r02_alu_ceiling.json (tools/alu_ceiling.py), profiles/r02_ubench_int.md, profiles/r02_pmc_sq.md"})
+            except Exception as e:  # the bench line must not die on a missing evidence file
+                alu["ceiling_error"] = repr(e)
         sharded_mode = args.mode == "sharded" and world > 1 and args.workload == "prove"
         agg = H.aggregate(1 if sharded_mode else world, args.steps, dt)   # sharded: the N ranks finish ONE proof per step
         out = {
@@ -160,7 +187,8 @@ def main():
             "vs_baseline": None, "dtype": "u64 (Goldilocks field, integer modular arithmetic)", "data": "synthetic",
             "config": {"workload": wl_name,
                        "parallelism": (f"one proof coset-sharded x{world} (vx_prove_sharded; RCCL all-gathers of caps, quotient coset "
-                                       f"coefficients, first FRI layer, openings)" if sharded_mode else
+                                       f"coefficients, first FRI layer, openings; NO row-chunk all-to-all NTT in this mode — that "
+                                       f"formulation exists for the commitment only: sharded.commit_sharded)" if sharded_mode else
                                        f"proof-level x{world} (one witness per GPU, no collective)")},
             "roofline": roof,
             "alu_bound_dominant_kernel": alu,
@@ -168,6 +196,8 @@ def main():
             "stage_alg_GBps": {k: round(v["alg_bytes"] / (v["ms"] * 1e-3) / 1e9, 1) for k, v in prof.items()
                                if v["alg_bytes"] and v["ms"]},
         }
+        if host_leg is not None:
+            out["value_from_host_witness"] = host_leg
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline_commit(args) if args.workload == "commit" else bench_prove.cpu_baseline(args)
         print(json.dumps(out), flush=True)

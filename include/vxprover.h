@@ -57,6 +57,11 @@ int vx_ctx_sync(vx_ctx* ctx);
 /* Opaque hipStream_t of the context (so a harness can record its own events on the right stream). */
 void* vx_ctx_stream(vx_ctx* ctx);
 
+/* Effective shader clock (GHz) under a VALU-saturating load, measured on the device itself: a ~1 ms kernel whose waves read
+ * s_memtime (shader-clock ticks) and s_memrealtime (constant 100 MHz) around a multiply-add loop.  The clock follows the
+ * power budget (1.9 - 2.4 GHz on MI355X), so an instruction-issue roofline must use the measured value. */
+int vx_clock_probe(vx_ctx* ctx, double* ghz_out);
+
 /* Per-kernel-family HIP-event timing.  enable=1 brackets every launch family with events on the
  * context's stream; vx_prof_get returns accumulated milliseconds and launch counts since the last
  * vx_prof_reset.  names/ms/calls may be NULL to query the entry count. */
@@ -280,7 +285,10 @@ int vx_prove_sharded(vx_ctx* ctx, vx_circuit* circuit, const uint64_t* wires, in
 typedef struct vx_group vx_group;
 int vx_group_create(int world, vx_group** out);
 void vx_group_destroy(vx_group* g);
+/* Joining enables peer access (hipDeviceEnablePeerAccess, both directions) between the joining context's device and the
+ * device of every member that joined before it, so the slots travel over xGMI directly. */
 int vx_group_join(vx_group* g, int rank, vx_ctx* ctx, void** member_out); /* member handle is owned by the group */
+int vx_group_peer_staged(vx_group* g); /* 1 if some pair of member devices has no peer access (copies are host-staged) */
 int vx_group_allgather(void* member, void* dev_buf, size_t bytes_per_rank);
 void vx_group_abort(vx_group* g); /* wake every rank waiting in vx_group_allgather with VX_E_COMM (a rank has failed) */
 

@@ -75,7 +75,8 @@ def test_mapreduce_dag_is_partition_independent():
     assert one["proofs"] == two["proofs"] == 8
     assert one["layers"] == [["map", 4], ["reduce", 2], ["reduce", 1], ["outer", 1]]
     assert one["root"] == two["root"]
-    assert one["per_rank"] == [8] and sorted(two["per_rank"]) == [2, 6] or sum(two["per_rank"]) == 8
+    assert one["per_rank"] == [8]
+    assert sum(two["per_rank"]) == 8 and min(two["per_rank"]) >= 3, two["per_rank"]   # round-robin per layer: 5 + 3
 
 
 def test_dag_spec_header_range_512():

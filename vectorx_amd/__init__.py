@@ -61,6 +61,7 @@ _SIGNATURES = {
     "vx_ctx_destroy": (None, [_vp]),
     "vx_ctx_sync": (_i, [_vp]),
     "vx_ctx_stream": (_vp, [_vp]),
+    "vx_clock_probe": (_i, [_vp, ctypes.POINTER(ctypes.c_double)]),
     "vx_prof_enable": (_i, [_vp, _i]),
     "vx_prof_reset": (_i, [_vp]),
     "vx_prof_count": (_i, [_vp]),
@@ -102,6 +103,7 @@ _SIGNATURES = {
     "vx_group_create": (_i, [_i, ctypes.POINTER(_vp)]),
     "vx_group_destroy": (None, [_vp]),
     "vx_group_join": (_i, [_vp, _i, _vp, ctypes.POINTER(_vp)]),
+    "vx_group_peer_staged": (_i, [_vp]),
     "vx_group_allgather": (_i, [_vp, _vp, _sz]),
     "vx_group_abort": (None, [_vp]),
 }
@@ -149,12 +151,24 @@ class Context:
     """One (device, HIP stream) pair — `vx_ctx`."""
 
     def __init__(self, device: int = 0):
+        import weakref
         self._h = _vp()
         _chk(lib().vx_ctx_create(device, ctypes.byref(self._h)))
         self.device = device
+        # handles created on this context (Circuit, PolynomialBatch): vx_ctx_destroy releases the pool blocks they point
+        # into, so close() frees the live ones FIRST — a later child.free() / __del__ then finds a null handle (no-op)
+        self._children = weakref.WeakSet()
+
+    def _adopt(self, child):
+        self._children.add(child)
 
     def close(self):
         if self._h:
+            for child in list(self._children):
+                try:
+                    child.free()
+                except Exception:
+                    pass
             lib().vx_ctx_destroy(self._h)
             self._h = _vp()
 
@@ -170,6 +184,12 @@ class Context:
     @property
     def stream(self) -> int:
         return lib().vx_ctx_stream(self._h)
+
+    def clock_ghz(self) -> float:
+        """effective shader clock under a VALU-saturating load, measured on the device (vx_clock_probe)"""
+        g = ctypes.c_double()
+        _chk(lib().vx_clock_probe(self._h, ctypes.byref(g)))
+        return g.value
 
     # ---- profiling ----
     def prof_enable(self, on: bool = True):
@@ -223,6 +243,11 @@ class Context:
         _chk(lib().vx_dev_download(self._h, out.ctypes.data, dptr, nbytes))
         return out
 
+    def download_into(self, host: np.ndarray, dptr: int):
+        """device -> an existing (e.g. page-locked) contiguous host array"""
+        assert host.flags["C_CONTIGUOUS"]
+        _chk(lib().vx_dev_download(self._h, host.ctypes.data, dptr, host.nbytes))
+
     # ---- L1 (plonky2_field::fft / hash::poseidon / hash::merkle_tree) ----
     def ntt_batch(self, cols: np.ndarray, kind: int, shift: int = 7) -> np.ndarray:
         """cols: [ncols][n] column-major; returns the transformed copy, natural order (fft.rs)."""
@@ -274,6 +299,7 @@ class PolynomialBatch:
     def __init__(self, ctx: Context, handle, log_n, ncols, rate_bits, cap_height):
         self.ctx, self._h = ctx, handle
         self.log_n, self.ncols, self.rate_bits, self.cap_height = log_n, ncols, rate_bits, cap_height
+        ctx._adopt(self)
 
     @classmethod
     def _commit(cls, ctx, cols, rate_bits, cap_height, is_coeffs, dev_ptr=None, log_n=None, ncols=None):
@@ -376,6 +402,7 @@ class Circuit:
         self.ctx = ctx
         self._h = _vp()
         _chk(lib().vx_circuit_create(ctx._h, ctypes.cast(desc_ptr, _vp), ctypes.byref(self._h)))
+        ctx._adopt(self)
         d = ctypes.cast(desc_ptr, ctypes.POINTER(ctypes.c_int32))
         self.degree_bits, self.num_wires, self.cap_height = int(d[0]), int(d[1]), int(d[5])
 

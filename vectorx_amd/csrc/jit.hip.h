@@ -15,6 +15,7 @@
 // still on the GPU, same values (tests/test_gpu_prover.py compares the two paths).
 #pragma once
 #include <dlfcn.h>
+#include <sys/stat.h>
 #include <unistd.h>
 #include <hip/hiprtc.h>
 #include <map>
@@ -51,6 +52,7 @@ struct JitApi {
   hiprtcResult (*code_size)(hiprtcProgram, size_t*) = nullptr;
   hiprtcResult (*code)(hiprtcProgram, char*) = nullptr;
   hiprtcResult (*destroy)(hiprtcProgram*) = nullptr;
+  hiprtcResult (*version)(int*, int*) = nullptr;  // optional (cache key only)
   bool ok = false;
 };
 static JitApi& jit_api() {
@@ -71,6 +73,7 @@ static JitApi& jit_api() {
     VX_JIT_SYM(code_size, "hiprtcGetCodeSize");
     VX_JIT_SYM(code, "hiprtcGetCode");
     VX_JIT_SYM(destroy, "hiprtcDestroyProgram");
+    VX_JIT_SYM(version, "hiprtcVersion");
 #undef VX_JIT_SYM
     api.ok = api.create && api.compile && api.log_size && api.log && api.code_size && api.code && api.destroy;
   });
@@ -238,6 +241,39 @@ static JitCache& jit_cache() {
   return c;
 }
 
+// hiprtc-compile one source to a gfx950 code object; empty vector + *why on failure.
+static std::vector<char> jit_compile(JitApi& api, const std::string& src, std::string* why) {
+  hiprtcProgram pr;
+  if (api.create(&pr, src.c_str(), "vx_program_gates.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
+    *why = "hiprtcCreateProgram failed";
+    return {};
+  }
+  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
+  hiprtcResult rc = api.compile(pr, 3, opts);
+  if (rc != HIPRTC_SUCCESS) {
+    size_t ls = 0;
+    api.log_size(pr, &ls);
+    std::string log(ls, 0);
+    if (ls) api.log(pr, &log[0]);
+    *why = "hiprtc compile failed: " + log.substr(0, 400);
+    api.destroy(&pr);
+    return {};
+  }
+  size_t cs = 0;
+  api.code_size(pr, &cs);
+  std::vector<char> code(cs);
+  api.code(pr, code.data());
+  api.destroy(&pr);
+  return code;
+}
+// The on-disk cache is only used when the directory is the caller's own and closed to others (mode 0700, owner = euid):
+// a code object read from it is executed on the GPU, so a directory other users can write to would let them inject code.
+static bool jit_cache_dir_ok(const char* dir) {
+  struct stat st;
+  if (stat(dir, &st) != 0 || !S_ISDIR(st.st_mode)) return false;
+  return st.st_uid == geteuid() && (st.st_mode & 0077) == 0;
+}
+
 // Returns the kernel for this gate set on `device`, or nullptr (with *why set) when it cannot be compiled / loaded.
 static hipFunction_t jit_get(const std::vector<const uint64_t*>& progs, int nch, int device, std::string* why) {
   if (getenv("VX_NO_JIT")) {
@@ -257,60 +293,68 @@ static hipFunction_t jit_get(const std::vector<const uint64_t*>& progs, int nch,
   auto cit = C.code.find(src);
   // optional on-disk cache of code objects (VX_JIT_CACHE_DIR): a host that restarts does not recompile its circuits
   std::string cache_file;
+  bool from_disk = false;
   if (const char* dir = getenv("VX_JIT_CACHE_DIR")) {
-    uint64_t h = 1469598103934665603ULL;  // FNV-1a over the source (which embeds the prelude, so a library update misses)
-    for (unsigned char ch : src) h = (h ^ ch) * 1099511628211ULL;
-    char name[64];
-    snprintf(name, sizeof name, "/vxjit-%016llx-%zu.hsaco", (unsigned long long)h, src.size());
-    cache_file = std::string(dir) + name;
-    if (cit == C.code.end()) {
-      if (FILE* f = fopen(cache_file.c_str(), "rb")) {
-        std::vector<char> code;
-        char buf[65536];
-        size_t n;
-        while ((n = fread(buf, 1, sizeof buf, f)) > 0) code.insert(code.end(), buf, buf + n);
-        fclose(f);
-        if (code.size() > 64) cit = C.code.emplace(src, std::move(code)).first;
+    if (jit_cache_dir_ok(dir)) {
+      // key: FNV-1a over the source (which embeds the prelude, so a library update misses) + the hiprtc version and the
+      // offload arch the blob was built with/for, so a ROCm upgrade never reuses a stale code object
+      uint64_t h = 1469598103934665603ULL;
+      for (unsigned char ch : src) h = (h ^ ch) * 1099511628211ULL;
+      int rtc_major = 0, rtc_minor = 0;
+      if (api.version) api.version(&rtc_major, &rtc_minor);
+      char name[128];
+      snprintf(name, sizeof name, "/vxjit-gfx950-rtc%d.%d-%016llx-%zu.hsaco", rtc_major, rtc_minor, (unsigned long long)h, src.size());
+      cache_file = std::string(dir) + name;
+      if (cit == C.code.end()) {
+        if (FILE* f = fopen(cache_file.c_str(), "rb")) {
+          std::vector<char> code;
+          char buf[65536];
+          size_t n;
+          while ((n = fread(buf, 1, sizeof buf, f)) > 0) code.insert(code.end(), buf, buf + n);
+          fclose(f);
+          if (code.size() > 64) {
+            cit = C.code.emplace(src, std::move(code)).first;
+            from_disk = true;
+          }
+        }
       }
     }
   }
+  auto write_cache = [&](const std::vector<char>& code) {
+    if (cache_file.empty()) return;  // write-then-rename so that a concurrent reader never sees a partial file
+    const std::string tmp = cache_file + ".tmp" + std::to_string((long)getpid());
+    if (FILE* f = fopen(tmp.c_str(), "wb")) {
+      const bool ok = fwrite(code.data(), 1, code.size(), f) == code.size();
+      fclose(f);
+      if (!ok || rename(tmp.c_str(), cache_file.c_str()) != 0) remove(tmp.c_str());
+    }
+  };
   if (cit == C.code.end()) {
-    hiprtcProgram pr;
-    if (api.create(&pr, src.c_str(), "vx_program_gates.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
-      *why = "hiprtcCreateProgram failed";
-      return nullptr;
-    }
-    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
-    hiprtcResult rc = api.compile(pr, 3, opts);
-    if (rc != HIPRTC_SUCCESS) {
-      size_t ls = 0;
-      api.log_size(pr, &ls);
-      std::string log(ls, 0);
-      if (ls) api.log(pr, &log[0]);
-      *why = "hiprtc compile failed: " + log.substr(0, 400);
-      api.destroy(&pr);
-      return nullptr;
-    }
-    size_t cs = 0;
-    api.code_size(pr, &cs);
-    std::vector<char> code(cs);
-    api.code(pr, code.data());
-    api.destroy(&pr);
-    if (!cache_file.empty()) {  // write-then-rename so that a concurrent reader never sees a partial file
-      const std::string tmp = cache_file + ".tmp" + std::to_string((long)getpid());
-      if (FILE* f = fopen(tmp.c_str(), "wb")) {
-        const bool ok = fwrite(code.data(), 1, code.size(), f) == code.size();
-        fclose(f);
-        if (!ok || rename(tmp.c_str(), cache_file.c_str()) != 0) remove(tmp.c_str());
-      }
-    }
+    std::vector<char> code = jit_compile(api, src, why);
+    if (code.empty()) return nullptr;
+    write_cache(code);
     cit = C.code.emplace(src, std::move(code)).first;
   }
   hipModule_t mod;
   if (hipModuleLoadData(&mod, cit->second.data()) != hipSuccess) {
     (void)hipGetLastError();
-    *why = "hipModuleLoadData failed";
-    return nullptr;
+    if (!from_disk) {
+      *why = "hipModuleLoadData failed";
+      return nullptr;
+    }
+    // a stale or corrupt blob from the disk cache: drop it (file and memory), compile afresh, try once more — otherwise
+    // this gate set would stay on the ~60x slower interpreter in every process that shares the cache
+    remove(cache_file.c_str());
+    C.code.erase(cit);
+    std::vector<char> code = jit_compile(api, src, why);
+    if (code.empty()) return nullptr;
+    write_cache(code);
+    cit = C.code.emplace(src, std::move(code)).first;
+    if (hipModuleLoadData(&mod, cit->second.data()) != hipSuccess) {
+      (void)hipGetLastError();
+      *why = "hipModuleLoadData failed";
+      return nullptr;
+    }
   }
   hipFunction_t fn;
   if (hipModuleGetFunction(&fn, mod, "vx_program_gates") != hipSuccess) {

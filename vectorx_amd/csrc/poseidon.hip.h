@@ -38,9 +38,46 @@ GLD u64 gl_sub_nc_c(u64 a, u64 b) {
   if (a < b) d -= GL_EPS;
   return d;
 }
-GLD u64 poseidon_sbox_nc(u64 x) {
+// The fused multiply-reduce of goldilocks.hip.h (gl_mul_nc) as ONE asm block with the adjacent carries chained through
+// VCC (implicit-VCC VOP2 forms): same 16 VALU + 2 SALU instructions, but no hazard nops between dependent statements
+// and measurably faster — 61.3 instead of 66.3 shader cycles per multiply per SIMD (profiles/r02_ubench_int.md).
+// AMDGPU inline asm cannot name the halves of a 64-bit operand, so the three temporaries whose halves are used
+// separately live in FIXED registers v[118:123] (clobbered; free for the compiler outside the block).  Poseidon-only:
+// kernels with a tight VGPR budget (the NTT passes run at 40 VGPRs) keep gl_mul_nc.
+#ifndef POSEIDON_NO_FX
+GLD u64 gl_mul_nc_fx(u64 a, u64 b) {
+  u64 r, p01, sM, sT, m1, m2;
+  asm("v_mad_u64_u32 v[118:119], vcc, %[a0], %[b0], 0\n"               // p00
+      "v_mad_u64_u32 %[p01], vcc, %[a0], %[b1], 0\n"                     // p01
+      "v_mad_u64_u32 v[120:121], vcc, %[a1], %[b1], 0\n"                 // p11
+      "v_mad_u64_u32 v[122:123], %[sM], %[a1], %[b0], %[p01]\n"          // p10 = a1 b0 + p01, carry cM (worth 2^96 = -1)
+      "v_add_co_u32_e32 v119, vcc, v119, v122\n"                         // lo64 = (p00_lo, p00_hi + p10_lo)
+      "v_addc_co_u32_e32 v120, vcc, v120, v123, vcc\n"                   // hl
+      "v_addc_co_u32_e32 v121, vcc, 0, v121, vcc\n"                      // hh
+      "v_mad_u64_u32 v[118:119], %[sT], v120, -1, v[118:119]\n"          // T = hl * EPS + lo64, carry cT
+      "v_subb_co_u32_e64 v118, vcc, v118, v121, %[sM]\n"                 // u = T - hh - cM
+      "v_subbrev_co_u32_e32 v119, vcc, 0, v119, vcc\n"                   // borrow bw in vcc
+      "s_andn2_b64 %[m1], %[sT], vcc\n"                                  // cT & ~bw : + EPS
+      "s_andn2_b64 %[m2], vcc, %[sT]\n"                                  // bw & ~cT : - EPS
+      "v_cndmask_b32_e64 v122, 0, -1, %[m1]\n"
+      "v_cndmask_b32_e64 v123, 0, -1, %[m2]\n"
+      "v_cndmask_b32_e64 v122, v122, 1, %[m2]\n"
+      "v_lshl_add_u64 %[r], v[118:119], 0, v[122:123]\n"
+      : [r] "=v"(r), [p01] "=&v"(p01), [sM] "=&s"(sM), [sT] "=&s"(sT), [m1] "=&s"(m1), [m2] "=&s"(m2)
+      : [a0] "v"((u32)a), [a1] "v"((u32)(a >> 32)), [b0] "v"((u32)b), [b1] "v"((u32)(b >> 32))
+      : "vcc", "scc", "v118", "v119", "v120", "v121", "v122", "v123");
+  return r;
+}
+#else
+GLD u64 gl_mul_nc_fx(u64 a, u64 b) { return gl_mul_nc(a, b); }
+#endif
+GLD u64 poseidon_sbox_nc(u64 x) {  // generic form (quotient kernel's PoseidonGate, lane-cooperative permutation)
   const u64 x2 = gl_mul_nc(x, x), x4 = gl_mul_nc(x2, x2), x3 = gl_mul_nc(x, x2);
   return gl_mul_nc(x3, x4);
+}
+GLD u64 poseidon_sbox_fx(u64 x) {  // one-thread-per-state permutation only (kernels with >= 124 VGPRs to their name)
+  const u64 x2 = gl_mul_nc_fx(x, x), x4 = gl_mul_nc_fx(x2, x2), x3 = gl_mul_nc_fx(x, x2);
+  return gl_mul_nc_fx(x3, x4);
 }
 GLD u64 poseidon_sbox(u64 x) { return gl_canon(poseidon_sbox_nc(x)); }
 
@@ -304,7 +341,7 @@ template <int B>
 GLD void poseidon_partial_block_nc(u64 (&s)[12], const u64* __restrict__ kappa, const u64* __restrict__ K) {
   constexpr PoseidonIntBlock T = make_int_block(B);
   u64 y[B];
-  y[0] = poseidon_sbox_nc(s[0]);
+  y[0] = poseidon_sbox_fx(s[0]);
   s[0] = y[0];  // s is now w = (y_0, u_1 .. u_11)
 #pragma unroll
   for (int j = 1; j < B; ++j) {
@@ -314,7 +351,7 @@ GLD void poseidon_partial_block_nc(u64 (&s)[12], const u64* __restrict__ kappa, 
     for (int i = 0; i < 12; ++i) poseidon_mac32(al, ah, s[i], T.A[j][i]);
 #pragma unroll
     for (int i = 1; i < j; ++i) poseidon_mac32(al, ah, y[i], T.b[j][i]);
-    y[j] = poseidon_sbox_nc(mds_fold_nc(al, ah));
+    y[j] = poseidon_sbox_fx(mds_fold_nc(al, ah));
   }
   u64 out[12];
 #pragma unroll
@@ -338,7 +375,7 @@ GLD void poseidon_permute_nc(u64 (&s)[12]) {
 #pragma unroll 1
   for (int r = 0; r < 4; ++r) {
 #pragma unroll
-    for (int i = 0; i < 12; ++i) s[i] = poseidon_sbox_nc(s[i]);
+    for (int i = 0; i < 12; ++i) s[i] = poseidon_sbox_fx(s[i]);
     poseidon_mds_rc_nc(s, POSEIDON_RC_EXT.v + (r + 1) * 12);
   }
 #pragma unroll 1
@@ -347,7 +384,7 @@ GLD void poseidon_permute_nc(u64 (&s)[12]) {
 #pragma unroll 1
   for (int r = 26; r < 30; ++r) {
 #pragma unroll
-    for (int i = 0; i < 12; ++i) s[i] = poseidon_sbox_nc(s[i]);
+    for (int i = 0; i < 12; ++i) s[i] = poseidon_sbox_fx(s[i]);
     poseidon_mds_rc_nc(s, POSEIDON_RC_EXT.v + (r + 1) * 12);
   }
 }

@@ -10,6 +10,32 @@
 #include "prover.hip.h"
 #include "verifier.h"
 
+
+// ---- shader-clock probe (vx_clock_probe): every wave runs a VALU-saturating multiply-add loop between two readings of
+// s_memtime (shader-clock ticks) and s_memrealtime (constant 100 MHz); effective clock = ticks / realtime.  bench.py
+// prices the integer-ALU roofline with the clock measured in its own run instead of the 2.4 GHz nameplate.
+__global__ __launch_bounds__(256) void clock_probe_kernel(uint64_t* __restrict__ out, int iters) {
+  uint64_t t0, r0, t1, r1;
+  asm volatile("s_memtime %0\n s_memrealtime %1\n s_waitcnt lgkmcnt(0)" : "=s"(t0), "=s"(r0));
+  u64 acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = threadIdx.x + i;
+  const u32 m = (u32)threadIdx.x * 2654435761u + 12345u;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = (u64)(u32)acc[i] * m + acc[i];
+  }
+  asm volatile("s_memtime %0\n s_memrealtime %1\n s_waitcnt lgkmcnt(0)" : "=s"(t1), "=s"(r1));
+  u64 x = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) x ^= acc[i];
+  if ((threadIdx.x & 63) == 0 || x == 0x123456789ull) {
+    const size_t w = ((size_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+    out[2 * w] = t1 - t0;
+    out[2 * w + 1] = r1 - r0;
+  }
+}
+
 extern "C" {
 
 const char* vx_last_error(void) { return g_err; }
@@ -79,6 +105,25 @@ int vx_ctx_sync(vx_ctx* c) {
   return VX_OK;
 }
 void* vx_ctx_stream(vx_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int vx_clock_probe(vx_ctx* c, double* ghz_out) {
+  if (!c || !ghz_out) return vx_fail(VX_E_INVALID, "vx_clock_probe: NULL argument");
+  HIPCHK(hipSetDevice(c->device));
+  const int blocks = c->props.multiProcessorCount * 8, waves = blocks * 4;
+  void* d = nullptr;
+  if (c->pool_alloc(&d, (size_t)waves * 16) != hipSuccess) return vx_fail(VX_E_NOMEM, "vx_clock_probe: out of device memory");
+  hipLaunchKernelGGL(clock_probe_kernel, dim3(blocks), dim3(256), 0, c->stream, (uint64_t*)d, 1 << 15);
+  std::vector<uint64_t> h((size_t)waves * 2);
+  hipError_t e = hipMemcpyAsync(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost, c->stream);
+  hipError_t e2 = hipStreamSynchronize(c->stream);
+  c->pool_free(d);
+  if (e != hipSuccess || e2 != hipSuccess) return vx_fail(VX_E_HIP, "vx_clock_probe: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+  double ticks = 0, rt = 0;
+  for (int w = 0; w < waves; ++w) ticks += (double)h[2 * w], rt += (double)h[2 * w + 1];
+  if (rt <= 0) return vx_fail(VX_E_HIP, "vx_clock_probe: s_memrealtime did not advance");
+  *ghz_out = ticks / (rt / 100e6) / 1e9;
+  return VX_OK;
+}
 
 int vx_prof_enable(vx_ctx* c, int enable) {
   if (!c) return vx_fail(VX_E_INVALID, "ctx is NULL");
@@ -673,6 +718,7 @@ struct vx_group {
   int waiting = 0;
   uint64_t generation = 0;
   bool aborted = false;
+  bool peer_staged = false;  // some pair of member devices has no direct peer access: its copies are host-staged
   std::vector<vx_group_member> members;
   std::vector<void*> bufs;
   std::vector<size_t> sizes;
@@ -715,10 +761,31 @@ int vx_group_join(vx_group* g, int rank, vx_ctx* ctx, void** member_out) {
   {
     std::lock_guard<std::mutex> lk(g->mu);
     g->members[rank].ctx = ctx;
+    // Direct xGMI peer copies need peer access enabled in BOTH directions between every pair of distinct devices of
+    // the group (without it hipMemcpyPeerAsync is staged through host memory).  Enable it against every member that
+    // has joined so far; "already enabled" is fine.  A pair without peer capability keeps working through the staged path.
+    for (int r = 0; r < g->world; ++r) {
+      vx_ctx* o = g->members[r].ctx;
+      if (!o || r == rank || o->device == ctx->device) continue;
+      const int pairs[2][2] = {{ctx->device, o->device}, {o->device, ctx->device}};
+      for (auto& pr : pairs) {
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, pr[0], pr[1]) != hipSuccess || !can) {
+          g->peer_staged = true;
+          continue;
+        }
+        if (hipSetDevice(pr[0]) != hipSuccess) return vx_fail(VX_E_HIP, "vx_group_join: hipSetDevice(%d) failed", pr[0]);
+        hipError_t e = hipDeviceEnablePeerAccess(pr[1], 0);
+        if (e == hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();  // clear the sticky error
+        else if (e != hipSuccess) return vx_fail(VX_E_HIP, "vx_group_join: hipDeviceEnablePeerAccess(%d -> %d): %s", pr[0], pr[1], hipGetErrorString(e));
+      }
+    }
+    (void)hipSetDevice(ctx->device);
   }
   *member_out = &g->members[rank];
   return VX_OK;
 }
+int vx_group_peer_staged(vx_group* g) { return g && g->peer_staged ? 1 : 0; }
 int vx_group_allgather(void* member, void* dev_buf, size_t bytes_per_rank) {
   vx_group_member* m = (vx_group_member*)member;
   if (!m || !m->g || !m->ctx || !dev_buf) return vx_fail(VX_E_INVALID, "vx_group_allgather: bad argument");
