@@ -226,6 +226,21 @@ typedef struct vx_circuit_desc {
  * for every later proof of this circuit) and derive circuit_digest. */
 int vx_circuit_create(vx_ctx* ctx, const vx_circuit_desc* desc, vx_circuit** out);
 void vx_circuit_free(vx_circuit* c);
+
+/* `.vxcircuit`: the library's self-describing container for a compiled circuit — the role plonky2x's ./build/*.circuit files
+ * play for `build` / `prove` (/root/reference/succinct.json:7-8,17-18; save -> load round trip as in
+ * `circuit.test_serializers`, /root/reference/circuits/header_range.rs:117-126).  Layout: vectorx_amd/csrc/circuit_io.h.
+ * All four are host code (no vx_ctx, no GPU); every description is validated exactly like vx_circuit_create's.
+ *   vx_circuit_serialize: description (+ the 2^cap_height x 4 constants_sigmas cap when non-NULL = verifier data,
+ *     + the preprocessed values when with_preprocessed) -> bytes; *len is capacity in / size out.
+ *   vx_circuit_parse: bytes -> a description owned by the library (vx_circuit_desc_free); its constants_sigmas points INTO
+ *     `bytes` when that buffer is 8-byte aligned, so `bytes` must outlive the description; *cap_out = the stored cap or NULL.
+ *   vx_circuit_load = parse + vx_circuit_create (the `prove` side of the CLI contract). */
+size_t vx_circuit_serialized_size(const vx_circuit_desc* desc, int with_cap, int with_preprocessed);
+int vx_circuit_serialize(const vx_circuit_desc* desc, const uint64_t* constants_sigmas_cap, int with_preprocessed, uint8_t* out, size_t* len);
+int vx_circuit_parse(const uint8_t* bytes, size_t len, const vx_circuit_desc** desc_out, const uint64_t** cap_out);
+void vx_circuit_desc_free(const vx_circuit_desc* desc);
+int vx_circuit_load(vx_ctx* ctx, const uint8_t* bytes, size_t len, vx_circuit** out);
 int vx_circuit_digest(vx_circuit* c, uint64_t digest_out[4]);
 int vx_circuit_constants_sigmas_cap(vx_circuit* c, uint64_t* cap_out /* [2^cap_height][4] */);
 

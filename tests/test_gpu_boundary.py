@@ -113,3 +113,53 @@ def test_mapreduce_dag_on_one_gpu_matches_the_oracle_dag(ctx, oracle):
         p.free()
     for l in lanes:
         l.close()
+
+
+@pytest.mark.parametrize("degree_bits,flags", [(6, 0), (9, 15), (12, 1)])
+def test_vxcircuit_save_load_gives_identical_proofs(ctx, oracle, degree_bits, flags):
+    """`.vxcircuit` round trip on the device (vx_circuit_serialize -> vx_circuit_load): same digest, same cap, byte-identical
+    proofs — the analogue of `circuit.test_serializers` (/root/reference/circuits/header_range.rs:117-126) followed by the
+    prove/verify pair of :167-170."""
+    import vectorx_amd as vx
+    from vectorx_amd.synth import SynthCircuit
+    import oracle_lib
+    sc = SynthCircuit(degree_bits, seed=4400 + degree_bits, poseidon_percent=50, flags=flags)
+    sc.desc.pow_bits = 7
+    g0 = vx.Circuit(ctx, sc.desc_ptr)
+    cap = g0.constants_sigmas_cap()
+    blob = vx.circuit_serialize(sc.desc_ptr, cap, with_preprocessed=True)
+    g1 = vx.Circuit.load(ctx, blob)
+    assert (g1.digest() == g0.digest()).all() and (g1.constants_sigmas_cap() == cap).all()
+    w = sc.witness()
+    p0, p1 = g0.prove(w), g1.prove(w)
+    assert p0 == p1 == oracle_lib.OracleCircuit(oracle, sc.desc_ptr).prove(w)
+    g1.verify(p0)
+    assert g1.program_gates()[0] == g0.program_gates()[0]
+    # a verifier-only file cannot be loaded as a prover key
+    with pytest.raises(vx.VxError):
+        vx.Circuit.load(ctx, vx.circuit_serialize(sc.desc_ptr, cap, with_preprocessed=False))
+    bad = bytearray(blob)
+    bad[len(bad) // 2] ^= 4
+    with pytest.raises(vx.VxError):
+        vx.Circuit.load(ctx, bytes(bad))
+    g0.free()
+    g1.free()
+
+
+def test_function_cli_build_and_prove_on_the_gpu(tmp_path):
+    """`build` then `prove input.json` -> output.json with the real GpuBackend; the result equals the one the CPU test
+    backend produces from the same request (tests/test_function_cli.py)."""
+    import json
+    from vectorx_amd import function as fn
+    from test_function_cli import OracleBackend, _header_range_input, _request
+    for function, extra, raw in [("rotate", ["--rotate-log-n", "8"], b"\x00" * 7 + b"\x2a" + bytes(range(32))),
+                                 ("header_range_256", ["--map-log-n", "6", "--reduce-log-n", "5", "--outer-log-n", "7"], _header_range_input())]:
+        b = tmp_path / ("build_" + function)
+        req, outp = tmp_path / f"{function}.input.json", tmp_path / f"{function}.output.json"
+        req.write_text(_request(raw))
+        assert fn.main(["build", "--function", function, "--build-dir", str(b), *extra]) == 0
+        assert fn.main(["prove", str(req), "--function", function, "--build-dir", str(b), "--output", str(outp)]) == 0
+        res = json.loads(outp.read_text())
+        proof_cpu, out_cpu, stats = fn.prove(function, raw, b, OracleBackend())    # same build artefacts, CPU checker
+        assert res["data"]["proof"] == "0x" + proof_cpu.hex() and res["data"]["output"] == "0x" + out_cpu.hex()
+        assert stats["proofs"] == (1 if function == "rotate" else 64)

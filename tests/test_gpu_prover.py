@@ -355,7 +355,6 @@ def test_header_range_256_sized_proof_bytes_identical_to_oracle(ctx, oracle):
     gp = gc.prove(w)
     gc.free()
     oc = oracle_lib.OracleCircuit(oracle, sc.desc_ptr)
-    assert (oc.digest() == np.frombuffer(np.asarray(oc.digest()).tobytes(), dtype=np.uint64)).all()
     op = oc.prove(w)
     assert len(gp) == len(op)
     assert hashlib.sha256(gp).hexdigest() == hashlib.sha256(op).hexdigest()

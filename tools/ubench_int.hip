@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256, 4) void k_seq(WaveStamp* stamps, uint64_t* sin
 #pragma unroll
       for (int i = 0; i < 12; ++i) s[i] = poseidon_sbox_nc_v2(s[i]);
     }
-    if (SEQ == SEQ_MDS_RC) poseidon_mds_rc_nc(s, POSEIDON_RC_EXT.v + 12 * (it & 15));
+    if (SEQ == SEQ_MDS_RC) poseidon_mds_rc_nc(s, it & 15);
     if (SEQ == SEQ_BLOCK3) poseidon_partial_block_nc<3>(s, POSEIDON_BLK.kappa[it & 3], POSEIDON_BLK.K[it & 3]);
     if (SEQ == SEQ_MDS) poseidon_mds_nc(s);
     if (SEQ == SEQ_PERM) poseidon_permute_nc(s);

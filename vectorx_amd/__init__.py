@@ -92,6 +92,11 @@ _SIGNATURES = {
     "vx_merkle_digest_count": (_sz, [_sz, _i]),
     "vx_circuit_create": (_i, [_vp, _vp, ctypes.POINTER(_vp)]),
     "vx_circuit_free": (None, [_vp]),
+    "vx_circuit_serialized_size": (_sz, [_vp, _i, _i]),
+    "vx_circuit_serialize": (_i, [_vp, _vp, _i, _vp, ctypes.POINTER(_sz)]),
+    "vx_circuit_parse": (_i, [_vp, _sz, ctypes.POINTER(_vp), ctypes.POINTER(_vp)]),
+    "vx_circuit_desc_free": (None, [_vp]),
+    "vx_circuit_load": (_i, [_vp, _vp, _sz, ctypes.POINTER(_vp)]),
     "vx_circuit_digest": (_i, [_vp, _vp]),
     "vx_circuit_constants_sigmas_cap": (_i, [_vp, _vp]),
     "vx_prove": (_i, [_vp, _vp, _vp, _i, _vp, _vp, ctypes.POINTER(_sz)]),
@@ -390,6 +395,49 @@ def verify_standalone(desc_ptr, constants_sigmas_cap, proof: bytes) -> None:
     _chk(lib().vx_verify_standalone(ctypes.cast(desc_ptr, _vp), cap.ctypes.data, buf.ctypes.data, len(proof)))
 
 
+def circuit_serialize(desc_ptr, constants_sigmas_cap=None, with_preprocessed=True) -> bytes:
+    """`vx_circuit_serialize`: a circuit description (+ cap = verifier data, + preprocessed values = prover data) as the
+    bytes of a `.vxcircuit` file (csrc/circuit_io.h) — the `build` side of the reference's CLI contract."""
+    L = lib()
+    cap = None if constants_sigmas_cap is None else _as_u64(constants_sigmas_cap)
+    need = L.vx_circuit_serialized_size(ctypes.cast(desc_ptr, _vp), int(cap is not None), int(with_preprocessed))
+    if need == 0:
+        raise VxError(VX_E_INVALID, L.vx_last_error().decode(errors="replace"))
+    buf = np.empty(need, dtype=np.uint8)
+    n = _sz(need)
+    _chk(L.vx_circuit_serialize(ctypes.cast(desc_ptr, _vp), None if cap is None else cap.ctypes.data, int(with_preprocessed),
+                                buf.ctypes.data, ctypes.byref(n)))
+    return buf[:n.value].tobytes()
+
+
+class ParsedCircuit:
+    """`vx_circuit_parse`: a description read back from `.vxcircuit` bytes (host only).  `.desc_ptr` can be handed to
+    Circuit(), verify_standalone() or the oracle; `.cap` is the stored constants_sigmas cap or None."""
+
+    def __init__(self, data: bytes):
+        self._buf = np.frombuffer(data, dtype=np.uint8).copy()      # 8-byte aligned, kept alive: the description borrows it
+        d, cap = _vp(), _vp()
+        _chk(lib().vx_circuit_parse(self._buf.ctypes.data, self._buf.size, ctypes.byref(d), ctypes.byref(cap)))
+        self.desc_ptr = d
+        from .synth import CircuitDesc
+        self.desc = ctypes.cast(d, ctypes.POINTER(CircuitDesc)).contents
+        self.cap = None
+        if cap.value:
+            n = 1 << self.desc.cap_height
+            self.cap = np.frombuffer((ctypes.c_uint64 * (4 * n)).from_address(cap.value), dtype=np.uint64).reshape(n, 4).copy()
+
+    def free(self):
+        if self.desc_ptr:
+            lib().vx_circuit_desc_free(self.desc_ptr)
+            self.desc_ptr = _vp()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 class Circuit:
     """Device-resident prover key — `vx_circuit` (plonky2 `CircuitData`: common + prover-only parts).
 
@@ -398,13 +446,26 @@ class Circuit:
     at the level of plonky2's `prove_with_partition_witness`: finished witness in, proof bytes out.
     """
 
-    def __init__(self, ctx: Context, desc_ptr):
+    def __init__(self, ctx: Context, desc_ptr, _handle=None, _shape=None):
         self.ctx = ctx
         self._h = _vp()
-        _chk(lib().vx_circuit_create(ctx._h, ctypes.cast(desc_ptr, _vp), ctypes.byref(self._h)))
+        if _handle is not None:
+            self._h = _handle
+            self.degree_bits, self.num_wires, self.cap_height = _shape
+        else:
+            _chk(lib().vx_circuit_create(ctx._h, ctypes.cast(desc_ptr, _vp), ctypes.byref(self._h)))
+            d = ctypes.cast(desc_ptr, ctypes.POINTER(ctypes.c_int32))
+            self.degree_bits, self.num_wires, self.cap_height = int(d[0]), int(d[1]), int(d[5])
         ctx._adopt(self)
-        d = ctypes.cast(desc_ptr, ctypes.POINTER(ctypes.c_int32))
-        self.degree_bits, self.num_wires, self.cap_height = int(d[0]), int(d[1]), int(d[5])
+
+    @classmethod
+    def load(cls, ctx: Context, data: bytes) -> "Circuit":
+        """`vx_circuit_load`: `.vxcircuit` bytes -> a device-resident prover key (the `prove` side of the CLI contract)."""
+        buf = np.frombuffer(data, dtype=np.uint8)
+        hdr = np.frombuffer(data[16:16 + 24], dtype="<i4")
+        h = _vp()
+        _chk(lib().vx_circuit_load(ctx._h, buf.ctypes.data, buf.size, ctypes.byref(h)))
+        return cls(ctx, None, _handle=h, _shape=(int(hdr[0]), int(hdr[1]), int(hdr[5])))
 
     def free(self):
         if self._h:

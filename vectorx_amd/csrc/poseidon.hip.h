@@ -262,6 +262,7 @@ constexpr PoseidonIntBlock make_int_block(int B) {
 struct PoseidonBlockConsts {
   u64 kappa[POSEIDON_NBLOCKS][3];
   u64 K[POSEIDON_NBLOCKS][12];
+  u64 Ksplit[POSEIDON_NBLOCKS][12][2];  // {low dword, high dword} of K: accumulator seeds for the asm MDS rows
 };
 constexpr u64 gl_mulmod_const(u64 a, u64 b) { return (u64)(((unsigned __int128)a * b) % (unsigned __int128)GL_P); }
 constexpr u64 POSEIDON_RC_RAW[VX_POSEIDON_N_ROUND_CONSTANTS] = VX_POSEIDON_ROUND_CONSTANTS_INIT;
@@ -285,7 +286,11 @@ constexpr PoseidonBlockConsts make_block_consts() {
         cv[0] = 0;
         for (int i = 1; i < 12; ++i) cv[i] = t[i];
       } else {
-        for (int i = 0; i < 12; ++i) R.K[blk][i] = t[i];
+        for (int i = 0; i < 12; ++i) {
+          R.K[blk][i] = t[i];
+          R.Ksplit[blk][i][0] = t[i] & 0xFFFFFFFFull;
+          R.Ksplit[blk][i][1] = t[i] >> 32;
+        }
       }
     }
     r0 += B;
@@ -295,13 +300,20 @@ constexpr PoseidonBlockConsts make_block_consts() {
 static_assert(POSEIDON_SCHED[0] + POSEIDON_SCHED[1] + POSEIDON_SCHED[2] + POSEIDON_SCHED[3] + POSEIDON_SCHED[4] + POSEIDON_SCHED[5] +
                       POSEIDON_SCHED[6] + POSEIDON_SCHED[7] == 22, "the blocks must cover the 22 partial rounds");
 __constant__ PoseidonBlockConsts POSEIDON_BLK = make_block_consts();
-// round constants with one all-zero round appended, so "the constants of the next round" exists after round 29 too
+// round constants with one all-zero round appended, so "the constants of the next round" exists after round 29 too; stored
+// pre-split — {low dword, high dword} as two u64 — because each half seeds its own 64-bit accumulator: a scalar load puts
+// it into an SGPR pair that is the 64-bit ADDEND of the row's first v_mad_u64_u32 (no instruction spent on the constant)
 struct PoseidonRcExt {
   u64 v[31 * 12];
+  u64 split[31 * 12][2];
 };
 constexpr PoseidonRcExt make_rc_ext() {
   PoseidonRcExt R{};
-  for (int i = 0; i < 360; ++i) R.v[i] = POSEIDON_RC_RAW[i] % GL_P;
+  for (int i = 0; i < 360; ++i) {
+    R.v[i] = POSEIDON_RC_RAW[i] % GL_P;
+    R.split[i][0] = R.v[i] & 0xFFFFFFFFull;
+    R.split[i][1] = R.v[i] >> 32;
+  }
   return R;
 }
 __constant__ PoseidonRcExt POSEIDON_RC_EXT = make_rc_ext();
@@ -310,30 +322,19 @@ GLD void poseidon_mac32(u64& al, u64& ah, u64 x, u32 c) {
   al += (u64)(u32)x * c;
   ah += (u64)(u32)(x >> 32) * c;
 }
-// Dense MDS layer with the NEXT round's constants folded in: they are the accumulators' initial values (free).
-GLD void poseidon_mds_rc_nc(u64 (&s)[12], const u64* __restrict__ rc_next) {
-  const u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+// Dense MDS layer with the NEXT round's constants folded in: each row is one asm block (poseidon_mds_asm.inc, generated) —
+// 24 v_mad_u64_u32 whose first pair takes the pre-split constant as its 64-bit addend straight from an SGPR pair, and
+// the 5-instruction fold.  (Left to hipcc, the row sum is re-associated: the constant costs a v_lshl_add_u64 per accumulator
+// and the x16 / x2 terms become shift-adds with pair-forming moves.)  `round_next` indexes POSEIDON_RC_EXT (30 = all-zero).
+#include "poseidon_mds_asm.inc"
+GLD void poseidon_mds_rc_nc(u64 (&s)[12], int round_next) {
   u32 lo[12], hi[12];
 #pragma unroll
   for (int i = 0; i < 12; ++i) {
     lo[i] = (u32)s[i];
     hi[i] = (u32)(s[i] >> 32);
   }
-#pragma unroll
-  for (int r = 0; r < 12; ++r) {
-    const u64 k = rc_next[r];
-    u64 al = (u32)k, ah = k >> 32;
-#pragma unroll
-    for (int i = 0; i < 12; ++i) {
-      al += (u64)C[i] * lo[(i + r) % 12];
-      ah += (u64)C[i] * hi[(i + r) % 12];
-    }
-    if (r == 0) {
-      al += (u64)8 * lo[0];
-      ah += (u64)8 * hi[0];
-    }
-    s[r] = mds_fold_nc(al, ah);  // al, ah < 2^43
-  }
+  poseidon_mds_rows_asm(s, lo, hi, POSEIDON_RC_EXT.split + round_next * 12);
 }
 // One block of B partial rounds (see above).  `lane0(j, x)` is handed the S-box INPUT of the block's round j and returns
 // the value that goes through the S-box: the identity for the permutation.
@@ -376,16 +377,25 @@ GLD void poseidon_permute_nc(u64 (&s)[12]) {
   for (int r = 0; r < 4; ++r) {
 #pragma unroll
     for (int i = 0; i < 12; ++i) s[i] = poseidon_sbox_fx(s[i]);
-    poseidon_mds_rc_nc(s, POSEIDON_RC_EXT.v + (r + 1) * 12);
+    poseidon_mds_rc_nc(s, r + 1);
   }
 #pragma unroll 1
   for (int blk = 0; blk < POSEIDON_NBLOCKS - 1; ++blk) poseidon_partial_block_nc<3>(s, POSEIDON_BLK.kappa[blk], POSEIDON_BLK.K[blk]);
-  poseidon_partial_block_nc<1>(s, POSEIDON_BLK.kappa[POSEIDON_NBLOCKS - 1], POSEIDON_BLK.K[POSEIDON_NBLOCKS - 1]);
+  {  // the 22nd partial round on its own (block of 1): S-box on lane 0, then a dense layer seeded with K (asm rows)
+    s[0] = poseidon_sbox_fx(s[0]);
+    u32 lo[12], hi[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      lo[i] = (u32)s[i];
+      hi[i] = (u32)(s[i] >> 32);
+    }
+    poseidon_mds_rows_asm(s, lo, hi, POSEIDON_BLK.Ksplit[POSEIDON_NBLOCKS - 1]);
+  }
 #pragma unroll 1
   for (int r = 26; r < 30; ++r) {
 #pragma unroll
     for (int i = 0; i < 12; ++i) s[i] = poseidon_sbox_fx(s[i]);
-    poseidon_mds_rc_nc(s, POSEIDON_RC_EXT.v + (r + 1) * 12);
+    poseidon_mds_rc_nc(s, r + 1);
   }
 }
 

@@ -8,6 +8,9 @@
 #include "plonk_kernels.hip.h"
 #include "jit.hip.h"
 #include "prover.hip.h"
+#include "circuit_io.h"
+#include <memory>
+#include <cstddef>
 #include "verifier.h"
 
 
@@ -534,6 +537,67 @@ int vx_circuit_create(vx_ctx* c, const vx_circuit_desc* desc, vx_circuit** out) 
   } catch (const std::exception& e) {
     return vx_fail(VX_E_INVALID, "vx_circuit_create: %s", e.what());
   }
+}
+// ---- .vxcircuit: the compiled-circuit container (circuit_io.h); host code, no device needed except vx_circuit_load ----
+size_t vx_circuit_serialized_size(const vx_circuit_desc* d, int with_cap, int with_preprocessed) {
+  if (!d) return 0;
+  const std::string why = desc_check(d, with_preprocessed != 0, nullptr);
+  if (!why.empty()) {
+    vx_fail(VX_E_INVALID, "vx_circuit_serialized_size: %s", why.c_str());
+    return 0;
+  }
+  return vxio::sizes_of(d, with_cap != 0, with_preprocessed != 0).total;
+}
+int vx_circuit_serialize(const vx_circuit_desc* d, const uint64_t* constants_sigmas_cap, int with_preprocessed, uint8_t* out, size_t* len) {
+  if (!d || !out || !len) return vx_fail(VX_E_INVALID, "vx_circuit_serialize: NULL argument");
+  try {
+    const std::string why = desc_check(d, with_preprocessed != 0, nullptr);
+    if (!why.empty()) return vx_fail(VX_E_INVALID, "vx_circuit_serialize: %s", why.c_str());
+    const size_t need = vxio::sizes_of(d, constants_sigmas_cap != nullptr, with_preprocessed != 0).total;
+    if (*len < need) {
+      *len = need;
+      return vx_fail(VX_E_INVALID, "vx_circuit_serialize: output buffer too small, need %zu bytes", need);
+    }
+    vxio::serialize(d, constants_sigmas_cap, with_preprocessed != 0, out);
+    *len = need;
+    return VX_OK;
+  } catch (const std::exception& e) {
+    return vx_fail(VX_E_NOMEM, "vx_circuit_serialize: %s", e.what());
+  }
+}
+int vx_circuit_parse(const uint8_t* bytes, size_t len, const vx_circuit_desc** desc_out, const uint64_t** cap_out) {
+  if (!bytes || !desc_out) return vx_fail(VX_E_INVALID, "vx_circuit_parse: NULL argument");
+  *desc_out = nullptr;
+  if (cap_out) *cap_out = nullptr;
+  try {
+    std::unique_ptr<vxio::Parsed> P(new vxio::Parsed());
+    std::string why = vxio::parse(bytes, len, P.get());
+    if (why.empty()) why = desc_check(&P->desc, P->desc.constants_sigmas != nullptr, nullptr);
+    if (!why.empty()) return vx_fail(VX_E_INVALID, "vx_circuit_parse: %s", why.c_str());
+    if (cap_out) *cap_out = P->cap;
+    *desc_out = &P.release()->desc;  // desc is the first member: vx_circuit_desc_free casts back
+    return VX_OK;
+  } catch (const std::exception& e) {
+    return vx_fail(VX_E_NOMEM, "vx_circuit_parse: %s", e.what());
+  }
+}
+void vx_circuit_desc_free(const vx_circuit_desc* d) {
+  static_assert(offsetof(vxio::Parsed, desc) == 0, "desc must be the first member");
+  delete reinterpret_cast<vxio::Parsed*>(const_cast<vx_circuit_desc*>(d));
+}
+int vx_circuit_load(vx_ctx* c, const uint8_t* bytes, size_t len, vx_circuit** out) {
+  if (!c || !bytes || !out) return vx_fail(VX_E_INVALID, "vx_circuit_load: NULL argument");
+  *out = nullptr;
+  const vx_circuit_desc* d = nullptr;
+  int rc = vx_circuit_parse(bytes, len, &d, nullptr);
+  if (rc) return rc;
+  if (!d->constants_sigmas) {
+    vx_circuit_desc_free(d);
+    return vx_fail(VX_E_INVALID, "vx_circuit_load: the file holds verifier data only (no preprocessed polynomial values)");
+  }
+  rc = vx_circuit_create(c, d, out);
+  vx_circuit_desc_free(d);
+  return rc;
 }
 void vx_circuit_free(vx_circuit* k) { circuit_free(k); }
 int vx_circuit_digest(vx_circuit* k, uint64_t digest_out[4]) {

@@ -57,16 +57,16 @@ def digest_to_field(d: bytes) -> np.ndarray:
     return np.array([int.from_bytes(d[8 * i:8 * i + 8], "little") % P for i in range(4)], dtype=np.uint64)
 
 
-def child_inputs(layer_idx: int, job: int, prev_digests: dict) -> np.ndarray:
-    """Public inputs of a job: H(layer, job) for map jobs, H(left child digest || right child digest) above."""
+def child_inputs(layer_idx: int, job: int, prev_digests: dict, input_seed: bytes = b"") -> np.ndarray:
+    """Public inputs of a job: H(request input, job) for map jobs, H(left child digest || right child digest) above."""
     if layer_idx == 0:
-        return digest_to_field(hashlib.sha256(b"map" + job.to_bytes(4, "little")).digest())
+        return digest_to_field(hashlib.sha256(b"map" + input_seed + job.to_bytes(4, "little")).digest())
     if len(prev_digests) == 1:      # outer proof: single child (the root reduce proof)
         return digest_to_field(hashlib.sha256(b"outer" + prev_digests[0]).digest())
     return digest_to_field(hashlib.sha256(prev_digests[2 * job] + prev_digests[2 * job + 1]).digest())
 
 
-def run_dag(spec: DagSpec, make_prover, dist=None, sync=lambda: None, in_flight: int = 1):
+def run_dag(spec: DagSpec, make_prover, dist=None, sync=lambda: None, in_flight: int = 1, input_seed: bytes = b""):
     """make_prover(kind, log_n, job_ids) -> object with .prove(job, public_inputs[, lane]) -> proof bytes, prepared
     (circuit loaded, per-job witnesses resident) BEFORE the timed region; witness generation is outside the hot path
     (U9).  in_flight > 1: this rank keeps that many jobs of a layer in flight on its GPU (host threads, one prover
@@ -111,7 +111,7 @@ def run_dag(spec: DagSpec, make_prover, dist=None, sync=lambda: None, in_flight:
                     except queue.Empty:
                         return
                     try:
-                        proof = provers[kind].prove((li, j), child_inputs(li, j, prev), lane)
+                        proof = provers[kind].prove((li, j), child_inputs(li, j, prev, input_seed), lane)
                         mine[j] = hashlib.sha256(proof).digest()
                         all_proofs[(li, j)] = proof
                     except BaseException as e:   # surfaces after the join
@@ -127,7 +127,7 @@ def run_dag(spec: DagSpec, make_prover, dist=None, sync=lambda: None, in_flight:
                 raise errors[0]
         else:
             for j in my_jobs[li]:
-                pi = child_inputs(li, j, prev)
+                pi = child_inputs(li, j, prev, input_seed)
                 proof = provers[kind].prove((li, j), pi)
                 mine[j] = hashlib.sha256(proof).digest()
                 all_proofs[(li, j)] = proof
