@@ -220,6 +220,12 @@ typedef struct vx_circuit_desc {
 #define VX_OP_MUL 6  /* r[dst] = r[a] * r[b] */
 #define VX_OP_PUSH 7 /* constraint <- r[a] */
 #define VX_OP_LDP 8  /* r[dst] = public_inputs_hash[a] */
+#define VX_OP_LDN 9  /* AIR programs only (vx_stark_*): r[dst] = next_row_values[a]; VX_OP_LDW reads the local row, VX_OP_LDP public input a */
+/* AIR programs: the b field of VX_OP_PUSH is the constraint kind (starky ConstraintConsumer) */
+#define VX_AIR_ALL_ROWS 0   /* constraint(c) */
+#define VX_AIR_TRANSITION 1 /* constraint_transition(c): c * (x - g^-1) */
+#define VX_AIR_FIRST_ROW 2  /* constraint_first_row(c):  c * L_first(x) */
+#define VX_AIR_LAST_ROW 3   /* constraint_last_row(c):   c * L_last(x) */
 #define VX_INS(op, dst, a, b) ((uint64_t)(op) | ((uint64_t)(dst) << 8) | ((uint64_t)(a) << 16) | ((uint64_t)(b) << 32))
 
 /* CircuitBuilder::build's prover-side tail: commit the preprocessed polynomials (kept resident in HBM
@@ -227,7 +233,7 @@ typedef struct vx_circuit_desc {
 int vx_circuit_create(vx_ctx* ctx, const vx_circuit_desc* desc, vx_circuit** out);
 void vx_circuit_free(vx_circuit* c);
 
-/* `.vxcircuit`: the library's self-describing container for a compiled circuit — the role plonky2x's ./build/*.circuit files
+/* `.vxcircuit`: the library's self-describing container for a compiled circuit — the role plonky2x's ./build/<name>.circuit files
  * play for `build` / `prove` (/root/reference/succinct.json:7-8,17-18; save -> load round trip as in
  * `circuit.test_serializers`, /root/reference/circuits/header_range.rs:117-126).  Layout: vectorx_amd/csrc/circuit_io.h.
  * All four are host code (no vx_ctx, no GPU); every description is validated exactly like vx_circuit_create's.
@@ -275,6 +281,28 @@ int vx_verify(vx_circuit* circuit, const uint8_t* proof, size_t proof_len);
  * (vx_circuit_constants_sigmas_cap of the prover's circuit = plonky2's VerifierOnlyCircuitData); the circuit digest is
  * recomputed from the cap. */
 int vx_verify_standalone(const vx_circuit_desc* desc, const uint64_t* constants_sigmas_cap, const uint8_t* proof, size_t proof_len);
+
+/* ---- STARKs on the same primitives (SURVEY.md §8 f-3 scoping spike; vectorx_amd/csrc/stark.hip.h) -----------------------------
+ * The Curta / starkyx STARKs inside every real map and outer proof (BLAKE2b: /root/reference/circuits/builder/header.rs:18,
+ * SHA-256 / Ed25519: circuits/builder/justification.rs:140-156, 237) are proven with the primitives above plus an AIR
+ * constraint evaluator over two adjacent rows.  The AIR arrives as a constraint program: VX_OP_LDW = local row, VX_OP_LDN =
+ * next row, VX_OP_LDP = public input, PUSH kind = VX_AIR_*.  Transcript and quotient follow plonky2's `starky` prover
+ * (trace cap -> alphas -> quotient on the coset of size n * 2^ceil(log2(max(1, degree - 1))) -> zeta -> openings at zeta
+ * and g zeta -> FRI); no permutation / cross-table arguments.  Proof bytes: trace_cap | quotient_cap | local | next | quotient
+ * openings | FriProof | public inputs.  vx_stark_verify is host code. */
+typedef struct vx_stark_desc {
+  int32_t degree_bits, num_columns, num_public_inputs;
+  int32_t rate_bits, cap_height, pow_bits, num_query_rounds, num_challenges; /* starky standard_fast_config: 1, 4, 16, 84, 2 */
+  int32_t constraint_degree;              /* quotient_degree_factor = max(1, constraint_degree - 1) */
+  int32_t program_len;
+  const uint64_t* program;
+  uint32_t override_flags;                /* VX_DESC_HAS_FRI_ARITIES or 0 (then ConstantArityBits(4, 5)) */
+  int32_t num_fri_reduction_arity_bits;
+  const int32_t* fri_reduction_arity_bits;
+} vx_stark_desc;
+int vx_stark_prove(vx_ctx* ctx, const vx_stark_desc* desc, const uint64_t* trace /* [num_columns][2^degree_bits] */, int trace_on_device,
+                   const uint64_t* public_inputs, const uint64_t* pow_witness_hint, uint8_t* out_buf, size_t* out_len);
+int vx_stark_verify(const vx_stark_desc* desc, const uint64_t* public_inputs, const uint8_t* proof, size_t proof_len);
 
 /* ---- ONE proof sharded across the GPUs of a node (BASELINE.json configs[3]) -------------------
  * `world` in {1, 2, 4, 8} ranks (one vx_ctx + one copy of the circuit each; world <= 2^rate_bits and

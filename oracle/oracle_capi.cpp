@@ -312,3 +312,53 @@ int vxo_verify(void* cv, const uint8_t* proof, size_t len, char* err, size_t err
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// STARK spike (stark.hpp): the checker of vx_stark_prove
+// ---------------------------------------------------------------------------------------------
+#include "stark.hpp"
+
+extern "C" {
+// Same layout as vx_stark_desc in include/vxprover.h (declared again: the oracle shares no code with the product).
+struct vxo_stark_desc {
+  int32_t degree_bits, num_columns, num_public_inputs;
+  int32_t rate_bits, cap_height, pow_bits, num_query_rounds, num_challenges;
+  int32_t constraint_degree;
+  int32_t program_len;
+  const uint64_t* program;
+  uint32_t override_flags;
+  int32_t num_fri_reduction_arity_bits;
+  const int32_t* fri_reduction_arity_bits;
+};
+long long vxo_stark_prove(const vxo_stark_desc* d, const u64* trace, const u64* pis, const u64* pow_hint, uint8_t* out, size_t cap,
+                          char* err, size_t err_cap) {
+  try {
+    StarkDesc s;
+    s.degree_bits = d->degree_bits, s.num_columns = d->num_columns, s.num_public_inputs = d->num_public_inputs;
+    s.rate_bits = d->rate_bits, s.cap_height = d->cap_height, s.pow_bits = d->pow_bits, s.num_query_rounds = d->num_query_rounds;
+    s.num_challenges = d->num_challenges, s.constraint_degree = d->constraint_degree;
+    s.program.assign(d->program, d->program + d->program_len);
+    if (d->override_flags & 2) s.arity_bits.assign(d->fri_reduction_arity_bits, d->fri_reduction_arity_bits + d->num_fri_reduction_arity_bits);
+    else s.default_arities();
+    const size_t n = (size_t)1 << d->degree_bits;
+    std::vector<std::vector<u64>> tr(d->num_columns);
+    for (int c = 0; c < d->num_columns; ++c) {
+      tr[c].assign(trace + (size_t)c * n, trace + (size_t)(c + 1) * n);
+      for (auto& x : tr[c]) x = canon(x);
+    }
+    std::vector<u64> pi(pis, pis + d->num_public_inputs);
+    ProveOptions opt;
+    if (pow_hint) opt.has_pow_hint = true, opt.pow_hint = *pow_hint;
+    std::vector<uint8_t> bytes = serialize_stark_proof(stark_prove(s, tr, pi, opt));
+    if (bytes.size() > cap) {
+      snprintf(err, err_cap, "output buffer too small: need %zu bytes", bytes.size());
+      return -1;
+    }
+    memcpy(out, bytes.data(), bytes.size());
+    return (long long)bytes.size();
+  } catch (const std::exception& e) {
+    snprintf(err, err_cap, "%s", e.what());
+    return -1;
+  }
+}
+}  // extern "C"

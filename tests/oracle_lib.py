@@ -198,6 +198,23 @@ class OracleCircuit:
 _cached = None
 
 
+def stark_prove(oracle, stark, trace, public_inputs, pow_hint=None) -> bytes:
+    """oracle/stark.hpp::stark_prove on a `vectorx_amd.Stark` description (same vx_stark_desc layout)."""
+    L = oracle.L
+    L.vxo_stark_prove.restype = ctypes.c_longlong
+    L.vxo_stark_prove.argtypes = [_vp, _vp, _vp, _vp, _vp, _sz, ctypes.c_char_p, _sz]
+    t = np.ascontiguousarray(trace, dtype=np.uint64)
+    pi = np.ascontiguousarray(public_inputs, dtype=np.uint64)
+    hint = np.array([pow_hint], dtype=np.uint64) if pow_hint is not None else None
+    buf = np.empty(1 << 24, dtype=np.uint8)
+    err = ctypes.create_string_buffer(512)
+    r = L.vxo_stark_prove(ctypes.cast(stark.desc_ptr, _vp), t.ctypes.data, pi.ctypes.data, hint.ctypes.data if hint is not None else None,
+                          buf.ctypes.data, buf.size, err, 512)
+    if r < 0:
+        raise RuntimeError(err.value.decode())
+    return buf[:r].tobytes()
+
+
 def load() -> Oracle:
     global _cached
     if _cached is None:

@@ -1,0 +1,59 @@
+"""STARK spike on the GPU: `vx_stark_prove` — trace commitment, AIR quotient (constraint program
+interpreted per row), openings and FRI on the same kernels as vx_prove — must give BYTE-IDENTICAL proofs to the oracle's
+restated starky prover (oracle/stark.hpp), and the product's host verifier must accept them."""
+import numpy as np
+import pytest
+
+import oracle_lib
+import vectorx_amd as vx
+from stark_airs import cubic, fibonacci
+
+pytestmark = pytest.mark.gpu
+P = oracle_lib.P
+
+
+@pytest.mark.parametrize("make,degree_bits,cfg", [(fibonacci, 3, {}), (fibonacci, 5, {}), (fibonacci, 8, {}), (fibonacci, 12, {}),
+                                                  (fibonacci, 10, dict(rate_bits=2, num_query_rounds=20)),
+                                                  (fibonacci, 9, dict(rate_bits=3, num_challenges=1, cap_height=2)),
+                                                  (cubic, 5, dict(rate_bits=1)), (cubic, 9, dict(rate_bits=1)), (cubic, 11, dict(rate_bits=2)),
+                                                  (cubic, 7, dict(rate_bits=3, num_query_rounds=10, fri_arities=[2, 3])),
+                                                  (fibonacci, 16, {})])
+def test_stark_proof_bytes_identical_to_oracle(ctx, oracle, make, degree_bits, cfg):
+    cfg = dict(pow_bits=8, **cfg)
+    stark, trace, pis = make(degree_bits, **cfg)
+    gp = stark.prove(ctx, trace, pis)
+    op = oracle_lib.stark_prove(oracle, stark, trace, pis)
+    assert len(gp) == len(op)
+    assert gp == op
+    stark.verify(pis, gp)
+    assert stark.prove(ctx, trace, pis) == gp                    # deterministic
+    bad = bytearray(gp)
+    bad[len(bad) // 3] ^= 2
+    with pytest.raises(vx.VxError):
+        stark.verify(pis, bytes(bad))
+
+
+def test_stark_pow_hint_and_noncanonical_trace(ctx, oracle):
+    stark, trace, pis = fibonacci(7, pow_bits=6)
+    ref = stark.prove(ctx, trace, pis)
+    pw = int(np.frombuffer(ref[-32:-24], dtype="<u8")[0])           # pow_witness sits before the 3 public inputs
+    assert stark.prove(ctx, trace, pis, pow_witness=pw) == ref
+    for cand in range(max(0, pw - 2), pw):
+        with pytest.raises(vx.VxError):
+            stark.prove(ctx, trace, pis, pow_witness=cand)
+    t = trace.copy()
+    small = t < np.uint64(2**32 - 1)
+    t[small] = t[small] + np.uint64(P)                               # x + p: same field element
+    assert stark.prove(ctx, t, pis) == ref
+
+
+def test_stark_violated_air_is_refused_or_rejected(ctx):
+    stark, trace, pis = fibonacci(6, pow_bits=4)
+    t = trace.copy()
+    t[0, 9] = (int(t[0, 9]) + 5) % P
+    try:
+        proof = stark.prove(ctx, t, pis)
+    except vx.VxError:
+        return
+    with pytest.raises(vx.VxError):
+        stark.verify(pis, proof)

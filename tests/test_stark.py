@@ -1,0 +1,62 @@
+"""STARK spike, CPU side: the oracle's restated starky prover (oracle/stark.hpp) makes proofs of toy
+two-row-window AIRs; the PRODUCT's host verifier (`vx_stark_verify`, csrc/stark.hip.h — written independently of the
+oracle) must accept them and reject every tampered byte.  The GPU prover is held to the same bytes in
+tests/test_gpu_stark.py."""
+import numpy as np
+import pytest
+
+import oracle_lib
+import vectorx_amd as vx
+from stark_airs import cubic, fibonacci
+
+P = oracle_lib.P
+
+
+@pytest.mark.parametrize("make,degree_bits,cfg", [(fibonacci, 3, {}), (fibonacci, 6, {}), (fibonacci, 9, dict(rate_bits=2, num_query_rounds=20)),
+                                                  (cubic, 5, dict(rate_bits=1)), (cubic, 7, dict(rate_bits=3, num_query_rounds=10, fri_arities=[2, 3])),
+                                                  (fibonacci, 8, dict(num_challenges=1, cap_height=2, pow_bits=5))])
+def test_oracle_stark_proofs_are_accepted_by_the_product_verifier(oracle, make, degree_bits, cfg):
+    cfg = dict(pow_bits=6, **cfg) if "pow_bits" not in cfg else cfg
+    stark, trace, pis = make(degree_bits, **cfg)
+    proof = oracle_lib.stark_prove(oracle, stark, trace, pis)
+    stark.verify(pis, proof)
+    assert oracle_lib.stark_prove(oracle, stark, trace, pis) == proof          # deterministic (smallest PoW witness)
+    rng = np.random.default_rng(5)
+    for off in [0, 40, 300, len(proof) // 2, len(proof) - 1, len(proof) - 30] + [int(x) for x in rng.integers(0, len(proof), 25)]:
+        bad = bytearray(proof)
+        bad[off] ^= 1 << int(rng.integers(0, 8))
+        with pytest.raises(vx.VxError):
+            stark.verify(pis, bytes(bad))
+    with pytest.raises(vx.VxError):
+        stark.verify((pis + np.uint64(1)) % np.uint64(P), proof)                 # other public inputs
+    for bad in (proof[:-1], proof + b"\0", b""):
+        with pytest.raises(vx.VxError):
+            stark.verify(pis, bad)
+
+
+def test_a_trace_that_violates_the_air_cannot_be_proven(oracle):
+    stark, trace, pis = fibonacci(5, pow_bits=4)
+    t = trace.copy()
+    t[1, 17] = (int(t[1, 17]) + 1) % P
+    # the quotient is not a polynomial of degree < n: the restated prover still outputs bytes, the verifier rejects them
+    try:
+        proof = oracle_lib.stark_prove(oracle, stark, t, pis)
+    except RuntimeError:
+        return
+    with pytest.raises(vx.VxError):
+        stark.verify(pis, proof)
+
+
+def test_stark_description_checks(oracle):
+    stark, trace, pis = fibonacci(4, pow_bits=3)
+    proof = oracle_lib.stark_prove(oracle, stark, trace, pis)
+    stark.verify(pis, proof)
+    for field, value in [("degree_bits", 0), ("rate_bits", 0), ("num_columns", 0), ("num_query_rounds", 0), ("cap_height", 40),
+                         ("constraint_degree", 9), ("num_challenges", 3), ("program_len", 3), ("override_flags", 1)]:
+        old = getattr(stark.desc, field)
+        setattr(stark.desc, field, value)
+        with pytest.raises(vx.VxError) as e:
+            stark.verify(pis, proof)
+        assert e.value.code == vx.VX_E_INVALID, field
+        setattr(stark.desc, field, old)
+    stark.verify(pis, proof)

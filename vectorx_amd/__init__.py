@@ -103,6 +103,8 @@ _SIGNATURES = {
     "vx_proof_size_bound": (_sz, [_vp]),
     "vx_verify": (_i, [_vp, _vp, _sz]),
     "vx_verify_standalone": (_i, [_vp, _vp, _vp, _sz]),
+    "vx_stark_prove": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, ctypes.POINTER(_sz)]),
+    "vx_stark_verify": (_i, [_vp, _vp, _vp, _sz]),
     "vx_circuit_program_gates": (_i, [_vp, ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.c_char_p, _sz]),
     "vx_prove_sharded": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, ctypes.POINTER(_sz)]),
     "vx_group_create": (_i, [_i, ctypes.POINTER(_vp)]),
@@ -393,6 +395,63 @@ def verify_standalone(desc_ptr, constants_sigmas_cap, proof: bytes) -> None:
     cap = _as_u64(constants_sigmas_cap)
     buf = np.frombuffer(proof, dtype=np.uint8) if len(proof) else np.zeros(1, np.uint8)
     _chk(lib().vx_verify_standalone(ctypes.cast(desc_ptr, _vp), cap.ctypes.data, buf.ctypes.data, len(proof)))
+
+
+class StarkDesc(ctypes.Structure):
+    """ctypes mirror of `vx_stark_desc` (include/vxprover.h)."""
+    _fields_ = [("degree_bits", ctypes.c_int32), ("num_columns", ctypes.c_int32), ("num_public_inputs", ctypes.c_int32),
+                ("rate_bits", ctypes.c_int32), ("cap_height", ctypes.c_int32), ("pow_bits", ctypes.c_int32),
+                ("num_query_rounds", ctypes.c_int32), ("num_challenges", ctypes.c_int32), ("constraint_degree", ctypes.c_int32),
+                ("program_len", ctypes.c_int32), ("program", ctypes.c_void_p), ("override_flags", ctypes.c_uint32),
+                ("num_fri_reduction_arity_bits", ctypes.c_int32), ("fri_reduction_arity_bits", ctypes.c_void_p)]
+
+
+VX_OP_END, VX_OP_LDW, VX_OP_LDC, VX_OP_LDI, VX_OP_ADD, VX_OP_SUB, VX_OP_MUL, VX_OP_PUSH, VX_OP_LDP, VX_OP_LDN = range(10)
+VX_AIR_ALL_ROWS, VX_AIR_TRANSITION, VX_AIR_FIRST_ROW, VX_AIR_LAST_ROW = range(4)
+
+
+def vx_ins(op, dst=0, a=0, b=0) -> int:
+    """VX_INS of include/vxprover.h"""
+    return op | (dst << 8) | (a << 16) | (b << 32)
+
+
+class Stark:
+    """An AIR as a constraint program + its STARK configuration (`vx_stark_desc`).  Defaults = starky's
+    StarkConfig::standard_fast_config (rate_bits 1, cap_height 4, 16 PoW bits, 84 queries, 2 challenges)."""
+
+    def __init__(self, degree_bits, num_columns, num_public_inputs, program, constraint_degree, rate_bits=1, cap_height=4, pow_bits=16,
+                 num_query_rounds=84, num_challenges=2, fri_arities=None):
+        self._prog = (ctypes.c_uint64 * len(program))(*program)
+        self.desc = StarkDesc(degree_bits, num_columns, num_public_inputs, rate_bits, cap_height, pow_bits, num_query_rounds, num_challenges,
+                              constraint_degree, len(program), ctypes.cast(self._prog, ctypes.c_void_p).value, 0, 0, None)
+        if fri_arities is not None:
+            self._ar = (ctypes.c_int32 * max(1, len(fri_arities)))(*fri_arities)
+            self.desc.override_flags = 2
+            self.desc.num_fri_reduction_arity_bits = len(fri_arities)
+            self.desc.fri_reduction_arity_bits = ctypes.cast(self._ar, ctypes.c_void_p).value
+        self.desc_ptr = ctypes.pointer(self.desc)
+
+    def prove(self, ctx, trace, public_inputs, pow_witness=None) -> bytes:
+        """`vx_stark_prove`: trace [num_columns][2^degree_bits] (host) -> proof bytes"""
+        t = _as_u64(trace)
+        if t.shape != (self.desc.num_columns, 1 << self.desc.degree_bits):
+            raise VxError(VX_E_INVALID, f"trace has shape {t.shape}")
+        pi = _as_u64(public_inputs)
+        cap = 1 << 24
+        out = np.empty(cap, dtype=np.uint8)
+        n = _sz(cap)
+        hint = None
+        if pow_witness is not None:
+            hint = ctypes.c_uint64(pow_witness)
+        _chk(lib().vx_stark_prove(ctx._h, ctypes.cast(self.desc_ptr, _vp), t.ctypes.data, 0, pi.ctypes.data,
+                                  None if hint is None else ctypes.cast(ctypes.pointer(hint), _vp), out.ctypes.data, ctypes.byref(n)))
+        return out[:n.value].tobytes()
+
+    def verify(self, public_inputs, proof: bytes):
+        """`vx_stark_verify` (host): raises VxError(VX_E_PROOF, reason) when the proof is not valid."""
+        pi = _as_u64(public_inputs)
+        buf = np.frombuffer(proof, dtype=np.uint8)
+        _chk(lib().vx_stark_verify(ctypes.cast(self.desc_ptr, _vp), pi.ctypes.data, buf.ctypes.data if buf.size else None, buf.size))
 
 
 def circuit_serialize(desc_ptr, constants_sigmas_cap=None, with_preprocessed=True) -> bytes:

@@ -289,20 +289,31 @@ __global__ __launch_bounds__(256, VX_QUOTIENT_BLOCKS) void quotient_kernel(Quoti
         poseidon_mds_nc(st);
         ++round;
       }
-#pragma unroll 1
-      for (int rr = 0; rr < 22; ++rr) {
+      // the 22 partial rounds in integer-power blocks (poseidon.hip.h): the S-box input of every round is a short dot
+      // product on the block's starting state; the gate constrains it to equal the wire sbox_in and continues from the
+      // wire (gates/poseidon.rs), which is what `lane0` does.  The blocks' K constants already contain the NEXT round's
+      // round constants, so only the first partial round adds its own.
 #pragma unroll
-        for (int q = 0; q < 12; ++q) st[q] = gl_add_nc_c(st[q], POSEIDON_RC[12 * round + q]);
-        u64 in = WIRE(65 + rr);
-        acc_push(G, p, gl_sub_nc_c(st[0], in));
-        st[0] = poseidon_sbox_nc(in);
-        poseidon_mds_nc(st);
-        ++round;
+      for (int q = 0; q < 12; ++q) st[q] = gl_add_nc_c(st[q], POSEIDON_RC[12 * round + q]);
+      {
+        int r0 = 0;
+        auto sbox = [](u64 x) { return poseidon_sbox_nc(x); };
+        auto lane0 = [&](int j, u64 x) {
+          const u64 in = WIRE(65 + r0 + j);
+          acc_push(G, p, gl_sub_nc_c(x, in));
+          return in;
+        };
+#pragma unroll 1
+        for (int blk = 0; blk < POSEIDON_NBLOCKS - 1; ++blk, r0 += 3) poseidon_partial_block_g<3>(st, POSEIDON_BLK.kappa[blk], POSEIDON_BLK.K[blk], sbox, lane0);
+        poseidon_partial_block_g<1>(st, POSEIDON_BLK.kappa[POSEIDON_NBLOCKS - 1], POSEIDON_BLK.K[POSEIDON_NBLOCKS - 1], sbox, lane0);
       }
+      round += 22;
 #pragma unroll 1
       for (int rr = 0; rr < 4; ++rr) {
+        if (rr != 0) {  // round 26's constants came in through the last block's K
 #pragma unroll
-        for (int q = 0; q < 12; ++q) st[q] = gl_add_nc_c(st[q], POSEIDON_RC[12 * round + q]);
+          for (int q = 0; q < 12; ++q) st[q] = gl_add_nc_c(st[q], POSEIDON_RC[12 * round + q]);
+        }
 #pragma unroll
         for (int q = 0; q < 12; ++q) {
           u64 in = WIRE(87 + 12 * rr + q);

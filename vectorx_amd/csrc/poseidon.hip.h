@@ -336,13 +336,15 @@ GLD void poseidon_mds_rc_nc(u64 (&s)[12], int round_next) {
   }
   poseidon_mds_rows_asm(s, lo, hi, POSEIDON_RC_EXT.split + round_next * 12);
 }
-// One block of B partial rounds (see above).  `lane0(j, x)` is handed the S-box INPUT of the block's round j and returns
-// the value that goes through the S-box: the identity for the permutation.
-template <int B>
-GLD void poseidon_partial_block_nc(u64 (&s)[12], const u64* __restrict__ kappa, const u64* __restrict__ K) {
+// One block of B partial rounds (see above).  `sbox(x)` is the S-box; `lane0(j, x)` is handed the S-box INPUT x of the
+// block's round j and returns the value that actually goes through the S-box: the identity for the permutation; the
+// quotient kernel's PoseidonGate passes the wire the gate constrains to equal x (and pushes x - wire as a constraint) —
+// the recurrences are linear in everything but the S-box outputs, so that is exactly the gate's eval_unfiltered.
+template <int B, class SBOX, class LANE0>
+GLD void poseidon_partial_block_g(u64 (&s)[12], const u64* __restrict__ kappa, const u64* __restrict__ K, SBOX&& sbox, LANE0&& lane0) {
   constexpr PoseidonIntBlock T = make_int_block(B);
   u64 y[B];
-  y[0] = poseidon_sbox_fx(s[0]);
+  y[0] = sbox(lane0(0, s[0]));
   s[0] = y[0];  // s is now w = (y_0, u_1 .. u_11)
 #pragma unroll
   for (int j = 1; j < B; ++j) {
@@ -352,7 +354,7 @@ GLD void poseidon_partial_block_nc(u64 (&s)[12], const u64* __restrict__ kappa, 
     for (int i = 0; i < 12; ++i) poseidon_mac32(al, ah, s[i], T.A[j][i]);
 #pragma unroll
     for (int i = 1; i < j; ++i) poseidon_mac32(al, ah, y[i], T.b[j][i]);
-    y[j] = poseidon_sbox_fx(mds_fold_nc(al, ah));
+    y[j] = sbox(lane0(j, mds_fold_nc(al, ah)));
   }
   u64 out[12];
 #pragma unroll
@@ -367,6 +369,10 @@ GLD void poseidon_partial_block_nc(u64 (&s)[12], const u64* __restrict__ kappa, 
   }
 #pragma unroll
   for (int r = 0; r < 12; ++r) s[r] = out[r];
+}
+template <int B>
+GLD void poseidon_partial_block_nc(u64 (&s)[12], const u64* __restrict__ kappa, const u64* __restrict__ K) {
+  poseidon_partial_block_g<B>(s, kappa, K, [](u64 x) { return poseidon_sbox_fx(x); }, [](int, u64 x) { return x; });
 }
 
 // Permutation on arbitrary-u64 lanes; outputs are arbitrary u64 representatives (NOT canonical).

@@ -234,6 +234,364 @@ static int gather_cap(vx_ctx* c, const Shard& sh, Scratch& S, const u64* local_c
   return VX_OK;
 }
 
+// fri::oracle::PolynomialBatch::prove_openings + fri::prover::fri_proof for TWO opening points (plonky2's and starky's
+// FriInstanceInfo shape): batch 0 = EVERY column of every oracle, opened at z0; batch 1 = the listed column ranges, opened
+// at z1 (plonk: Z polynomials [+ lookup polynomials] at g*zeta; a STARK: the whole trace at g*zeta).  The caller has
+// observed the openings; this draws alpha, combines, commits the FRI layers, grinds, answers the queries.  Sharded like
+// every LDE (Shard).  Result: the pieces of FriProof, serialised by write_fri_proof.
+struct FriProverParams {
+  int degree_bits = 0, rate_bits = 0, cap_height = 0, pow_bits = 0, num_queries = 0;
+  std::vector<int> arity_bits;
+};
+struct FriRange {
+  int oracle;
+  size_t col0, ncols;
+};
+struct FriParts {
+  std::vector<std::vector<u64>> commit_caps;
+  std::vector<vxh::Ext> final_poly;
+  u64 pow_witness = 0;
+  std::vector<std::vector<u64>> init_out, step_out;  // query openings: [oracle] / [round], row-major per (slot, query)
+  std::vector<int> owner;                              // rank that owns query q's leaf in the sharded trees
+  std::vector<size_t> flen;
+  int depth0 = 0;
+};
+static int fri_prove_openings(vx_ctx* c, const FriProverParams& fpp, const std::vector<vx_batch*>& oracles, const std::vector<FriRange>& batch1_ranges,
+                              vxh::Ext zeta, vxh::Ext gzeta, const std::vector<vxh::Ext>& batch0, const std::vector<vxh::Ext>& batch1,
+                              vxh::Challenger& ch, const u64* pow_hint, const Shard& sh, Scratch& S, FriParts& out) {
+  using namespace vxh;
+  const int lg = fpp.degree_bits, rb = fpp.rate_bits, LG = lg + rb, rate = 1 << rb;
+  const size_t n = (size_t)1 << lg, N = (size_t)1 << LG;
+  const size_t cap_words = (size_t)4 << fpp.cap_height;
+  const size_t Nl = N >> sh.lg, row_base = Nl * (size_t)sh.rank;
+  const int zc = rate >> sh.lg, z0 = zc * sh.rank;
+  Ext alpha = ch.get_extension_challenge();
+  const size_t nb0 = batch0.size(), nb1 = batch1.size();
+  std::vector<u64> apows(2 * nb0);
+  {
+    Ext a{1, 0};
+    for (size_t j = 0; j < nb0; ++j) {
+      apows[2 * j] = a.a;
+      apows[2 * j + 1] = a.b;
+      a = emul(a, alpha);
+    }
+  }
+  // F_b(z_b) = sum_j alpha^j opening_j   (= the verifier's PrecomputedReducedOpenings)
+  Ext y0{0, 0}, y1{0, 0};
+  for (size_t j = nb0; j-- > 0;) y0 = eadd(emul(y0, alpha), batch0[j]);
+  for (size_t j = nb1; j-- > 0;) y1 = eadd(emul(y1, alpha), batch1[j]);
+  u64* fcoef = S.get(4 * n);
+  u64* flde = S.get(4 * Nl);
+  u64* d_apows = S.get(2 * nb0);
+  if (!fcoef || !flde || !d_apows) return vx_fail(VX_E_NOMEM, "prove: out of device memory (opening proof)");
+  HIPCHK(hipMemcpyAsync(d_apows, apows.data(), apows.size() * 8, hipMemcpyHostToDevice, c->stream));
+  {
+    ReduceParams rp;
+    memset(&rp, 0, sizeof rp);
+    if (oracles.size() > REDUCE_MAX_GROUPS) return vx_fail(VX_E_INVALID, "fri: too many oracles");
+    rp.ngroups = (int)oracles.size();
+    size_t total = 0;
+    for (size_t o = 0; o < oracles.size(); ++o) {
+      rp.cols[o] = oracles[o]->coeffs;
+      rp.ncols[o] = (int)oracles[o]->ncols;
+      total += oracles[o]->ncols;
+    }
+    rp.alpha_pows = d_apows;
+    rp.n = n;
+    rp.out = fcoef;
+    ProfScope ps(c, "reduce_polys", 8.0 * n * total);
+    hipLaunchKernelGGL(reduce_polys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, rp);
+    if (batch1_ranges.size() > REDUCE_MAX_GROUPS) return vx_fail(VX_E_INVALID, "fri: too many column ranges in the second opening batch");
+    rp.ngroups = (int)batch1_ranges.size();
+    for (size_t g = 0; g < batch1_ranges.size(); ++g) {
+      rp.cols[g] = oracles[batch1_ranges[g].oracle]->coeffs + batch1_ranges[g].col0 * n;
+      rp.ncols[g] = (int)batch1_ranges[g].ncols;
+    }
+    rp.out = fcoef + 2 * n;
+    hipLaunchKernelGGL(reduce_polys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, rp);
+    HIPCHK(hipGetLastError());
+  }
+  // LDE of (F0.a, F0.b, F1.a, F1.b): an F_p^2 NTT with base-field roots is two F_p NTTs
+  {
+    std::vector<u64> shifts(zc);
+    u64 wN = root_of_unity(LG);
+    for (int z = 0; z < zc; ++z) shifts[z] = mul(7, pow(wN, reverse_bits((size_t)(z0 + z), rb)));
+    int bits = lg / 2;
+    u64* tab = nullptr;
+    VXCHK(get_scale_tables(c, lg, bits, shifts, 1, &tab));
+    VXCHK(run_ntt(c, fcoef, flde, n, Nl, 0, n, lg, 4, zc, false, true, tab, bits, 1, "fri_lde", 4.0 * 8.0 * ((double)n + Nl)));
+  }
+  // FRI value arrays per round (interleaved ext, bit-reversed order) and their trees
+  const size_t R = fpp.arity_bits.size();
+  std::vector<u64*> fvals(R + 1, nullptr), ftrees(R, nullptr);
+  std::vector<size_t> flen(R + 1), fcapoff(R, 0);
+  flen[0] = N;
+  for (size_t r = 0; r < R; ++r) flen[r + 1] = flen[r] >> fpp.arity_bits[r];
+  for (size_t r = 0; r <= R; ++r) {
+    fvals[r] = S.get(2 * flen[r]);
+    if (!fvals[r]) return vx_fail(VX_E_NOMEM, "prove: out of device memory (FRI)");
+  }
+  {
+    CombineParams cp;
+    memset(&cp, 0, sizeof cp);
+    cp.fl = flde;
+    cp.root_lo = c->root_lo;
+    cp.root_hi = c->root_hi;
+    cp.rows = Nl;
+    cp.row_base = row_base;
+    cp.log_N = LG;
+    cp.y0[0] = y0.a, cp.y0[1] = y0.b, cp.y1[0] = y1.a, cp.y1[1] = y1.b;
+    cp.z0[0] = zeta.a, cp.z0[1] = zeta.b, cp.z1[0] = gzeta.a, cp.z1[1] = gzeta.b;
+    Ext sh = epow(alpha, nb1);  // alpha.shift_poly: *= alpha^|batch 1|
+    cp.shift0[0] = sh.a, cp.shift0[1] = sh.b;
+    cp.out = fvals[0] + 2 * row_base;
+    ProfScope ps(c, "fri_combine", 48.0 * Nl);
+    hipLaunchKernelGGL(fri_combine_kernel, dim3((unsigned)((Nl + 255) / 256)), dim3(256), 0, c->stream, cp);
+    HIPCHK(hipGetLastError());
+  }
+  if (R == 0) VXCHK(shard_allgather(c, sh, fvals[0], 16 * Nl, "FRI values"));
+  // ---- FRI commit phase ----
+  std::vector<std::vector<u64>>& commit_caps = out.commit_caps;
+  commit_caps.clear();
+  {
+    u64 shift = 7;
+    for (size_t r = 0; r < R; ++r) {
+      const int ab = fpp.arity_bits[r];
+      // the first layer is sharded like every LDE (rows [row_base, row_base + Nl)); later layers are replicated
+      const Shard shr = r == 0 ? sh : Shard();
+      const size_t M = flen[r] >> shr.lg, leaves = M >> ab, in_base = r == 0 ? row_base : 0;
+      const int width = 2 << ab, ch_l = fpp.cap_height - shr.lg;
+      size_t nd = merkle_tree_digest_count(leaves, ch_l);
+      ftrees[r] = S.get(nd * 4);
+      if (!ftrees[r]) return vx_fail(VX_E_NOMEM, "prove: out of device memory (FRI trees)");
+      {
+        ProfScope ps(c, "fri_hash_leaves", 16.0 * M);
+        if (leaves <= COOP_MAX_LEAVES)
+          hipLaunchKernelGGL(hash_leaves_rowmajor_coop_kernel, dim3((unsigned)((leaves * 16 + HASH_THREADS - 1) / HASH_THREADS)),
+                             dim3(HASH_THREADS), 0, c->stream, fvals[r] + 2 * in_base, leaves, width, ftrees[r]);
+        else
+          hipLaunchKernelGGL(hash_leaves_rowmajor_kernel, dim3((unsigned)((leaves + HASH_THREADS - 1) / HASH_THREADS)),
+                             dim3(HASH_THREADS), 0, c->stream, fvals[r] + 2 * in_base, leaves, width, ftrees[r]);
+        HIPCHK(hipGetLastError());
+      }
+      VXCHK(build_merkle_levels(c, ftrees[r], leaves, ch_l, &fcapoff[r]));
+      std::vector<u64> cap;
+      VXCHK(gather_cap(c, shr, S, ftrees[r] + fcapoff[r] * 4, (size_t)4 << ch_l, cap));
+      ch.observe_elements(cap.data(), cap_words);
+      commit_caps.push_back(cap);
+      Ext beta = ch.get_extension_challenge();
+      FoldParams fp;
+      memset(&fp, 0, sizeof fp);
+      fp.in = fvals[r] + 2 * in_base;
+      fp.out = fvals[r + 1] + 2 * (in_base >> ab);
+      fp.k_base = in_base >> ab;
+      fp.root_lo = c->root_lo;
+      fp.root_hi = c->root_hi;
+      fp.M = M;
+      fp.log_M = LG;
+      for (size_t q = 0; q < r; ++q) fp.log_M -= fpp.arity_bits[q];
+      fp.arity_bits = ab;
+      fp.beta[0] = beta.a, fp.beta[1] = beta.b;
+      fp.shift_inv = inv(shift);
+      u64 wa_inv = inv(root_of_unity(ab)), pw = 1;
+      for (int q = 0; q < (1 << ab); ++q) {
+        fp.w_inv_pows[q] = pw;
+        pw = mul(pw, wa_inv);
+      }
+      fp.arity_inv = inv((u64)1 << ab);
+      {
+        ProfScope ps(c, "fri_fold", 16.0 * M);
+        hipLaunchKernelGGL(fri_fold_kernel, dim3((unsigned)((leaves + 255) / 256)), dim3(256), 0, c->stream, fp);
+        HIPCHK(hipGetLastError());
+      }
+      VXCHK(shard_allgather(c, shr, fvals[r + 1], 16 * leaves, "folded FRI layer"));
+      shift = pow(shift, (u64)1 << ab);
+    }
+    // final polynomial: the last value array (bit-reversed, on the coset shift*H) -> coefficients, on the host
+    const size_t Mf = flen[R];
+    const int lMf = [&] { int l = 0; while (((size_t)1 << l) < Mf) ++l; return l; }();
+    std::vector<u64> hv(2 * Mf);
+    HIPCHK(hipMemcpyAsync(hv.data(), fvals[R], hv.size() * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    std::vector<Ext>& coeffs = out.final_poly;
+    coeffs.assign(Mf, Ext{0, 0});
+    {
+      // coefficient j = shift^-j / Mf * sum_k v_k w^(-jk), v_k at natural index k = rev(position)
+      u64 w_inv = inv(root_of_unity(lMf)), s_inv = inv(shift), m_inv = inv((u64)Mf % P);
+      std::vector<u64> wp(Mf);
+      wp[0] = 1;
+      for (size_t i = 1; i < Mf; ++i) wp[i] = mul(wp[i - 1], w_inv);
+      u64 sj = m_inv;
+      for (size_t j = 0; j < Mf; ++j) {
+        u64 a = 0, b = 0;
+        for (size_t pos = 0; pos < Mf; ++pos) {
+          size_t kk = reverse_bits(pos, lMf);
+          u64 w = wp[(j * kk) & (Mf - 1)];
+          a = add(a, mul(hv[2 * pos], w));
+          b = add(b, mul(hv[2 * pos + 1], w));
+        }
+        coeffs[j] = Ext{mul(a, sj), mul(b, sj)};
+        sj = mul(sj, s_inv);
+      }
+    }
+    const size_t keep = Mf >> rb;
+    for (size_t j = keep; j < Mf; ++j)
+      if (coeffs[j].a || coeffs[j].b) return vx_fail(VX_E_PROOF, "FRI final polynomial has non-zero high coefficients (witness does not satisfy the circuit?)");
+    coeffs.resize(keep);
+    for (Ext e : coeffs) ch.observe_ext(e);
+    // ---- proof of work ----
+    u64& pow_witness = out.pow_witness;
+    pow_witness = 0;
+    {
+      auto check = [&](u64 cand) {
+        Challenger c2 = ch;
+        c2.observe_element(cand);
+        return (c2.get_challenge() >> (64 - fpp.pow_bits)) == 0;
+      };
+      if (pow_hint) {
+        pow_witness = canon(*pow_hint);
+        if (fpp.pow_bits > 0 && !check(pow_witness)) return vx_fail(VX_E_INVALID, "pow_witness hint does not satisfy the proof-of-work condition");
+      } else if (fpp.pow_bits > 0) {
+        PowParams pp;
+        memset(&pp, 0, sizeof pp);
+        for (int q = 0; q < 12; ++q) pp.state[q] = ch.sponge[q];
+        for (size_t q = 0; q < ch.input.size(); ++q) pp.state[q] = ch.input[q];
+        pp.pos = (int)ch.input.size();
+        pp.pow_bits = fpp.pow_bits;
+        unsigned long long* d_res = (unsigned long long*)S.get(1);
+        if (!d_res) return vx_fail(VX_E_NOMEM, "prove: out of device memory (pow)");
+        pp.result = d_res;
+        // Candidates are searched in increasing ranges and the smallest hit of a range wins, so the witness does not
+        // depend on the range sizes.  The first range is sized to succeed with probability ~1 - e^-2 at the cost of a
+        // couple of waves per SIMD; later ranges grow to keep the launch count logarithmic.
+        u64 batch = (u64)2 << std::min(fpp.pow_bits, 21);
+        unsigned long long res = ~0ull;
+        ProfScope ps(c, "pow_grind");
+        for (u64 base = 0; res == ~0ull; base += batch, batch = std::min(batch * 4, (u64)1 << 24)) {
+          HIPCHK(hipMemsetAsync(d_res, 0xFF, 8, c->stream));
+          pp.base = base;
+          hipLaunchKernelGGL(pow_grind_kernel, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, c->stream, pp);
+          HIPCHK(hipMemcpyAsync(&res, d_res, 8, hipMemcpyDeviceToHost, c->stream));
+          HIPCHK(hipStreamSynchronize(c->stream));
+          if (base > ((u64)1 << 44)) return vx_fail(VX_E_PROOF, "Proof of work failed. This is highly unlikely!");
+        }
+        pow_witness = res;
+        if (!check(pow_witness)) return vx_fail(VX_E_PROOF, "internal error: GPU proof-of-work witness rejected by the host transcript");
+      }
+      ch.observe_element(pow_witness);
+      (void)ch.get_challenge();  // pow_response
+    }
+    // ---- query rounds ----
+    const int nq = fpp.num_queries;
+    std::vector<u64> x_indices(nq);
+    for (int q = 0; q < nq; ++q) x_indices[q] = ch.get_challenge() % (u64)N;
+    const int depth0 = LG - fpp.cap_height;
+    // A sharded tree (wires / Z / quotient oracles, first FRI layer) is opened by the rank that owns the leaf — the
+    // top shard_lg bits of the index — and the rows are all-gathered: slot `owner[q]` holds query q's real opening.
+    out.init_out.assign(oracles.size(), std::vector<u64>());
+    std::vector<std::vector<u64>>& init_out = out.init_out;
+    out.step_out.assign(R, std::vector<u64>());
+    std::vector<std::vector<u64>>& step_out = out.step_out;
+    out.owner.assign(nq, 0);
+    std::vector<int>& owner = out.owner;
+    {
+      ProfScope ps(c, "query_gather");
+      u64* d_idx = S.get((size_t)nq * (R + 3));
+      if (!d_idx) return vx_fail(VX_E_NOMEM, "prove: out of device memory (queries)");
+      std::vector<u64> idx_host((size_t)nq * (R + 3));
+      u64* loc_x = &idx_host[(R + 1) * nq];   // local leaf index in a sharded oracle (0 when another rank owns it)
+      u64* loc_f0 = &idx_host[(R + 2) * nq];  // local leaf index in the first FRI layer's tree
+      for (int q = 0; q < nq; ++q) {
+        u64 xi = x_indices[q];
+        idx_host[q] = xi;
+        owner[q] = (int)(xi >> (LG - sh.lg));
+        const bool mine = owner[q] == sh.rank;
+        loc_x[q] = mine ? xi - row_base : 0;
+        loc_f0[q] = mine && R > 0 ? (xi >> fpp.arity_bits[0]) - (row_base >> fpp.arity_bits[0]) : 0;
+        for (size_t r = 0; r < R; ++r) {
+          xi >>= fpp.arity_bits[r];
+          idx_host[(r + 1) * nq + q] = xi;
+        }
+      }
+      HIPCHK(hipMemcpyAsync(d_idx, idx_host.data(), idx_host.size() * 8, hipMemcpyHostToDevice, c->stream));
+      std::vector<u64*> pending_dev;
+      std::vector<std::vector<u64>*> pending_host;
+      for (size_t o = 0; o < oracles.size(); ++o) {
+        const bool sharded = oracles[o]->shard_lg > 0;
+        const size_t rowlen = oracles[o]->ncols + 4 * (size_t)depth0, slots = sharded ? sh.world : 1;
+        u64* d_out = S.get(rowlen * nq * slots);
+        if (!d_out) return vx_fail(VX_E_NOMEM, "prove: out of device memory (queries)");
+        const size_t rows_o = oracles[o]->rows();
+        hipLaunchKernelGGL(gather_open_kernel, dim3(nq), dim3(128), 0, c->stream, oracles[o]->lde, rows_o, (int)oracles[o]->ncols, 1,
+                           oracles[o]->tree, rows_o, depth0, sharded ? d_idx + (R + 1) * nq : d_idx,
+                           d_out + (sharded ? rowlen * nq * sh.rank : 0));
+        if (sharded) VXCHK(shard_allgather(c, sh, d_out, rowlen * nq * 8, "query openings"));
+        init_out[o].resize(rowlen * nq * slots);
+        pending_dev.push_back(d_out);
+        pending_host.push_back(&init_out[o]);
+      }
+      for (size_t r = 0; r < R; ++r) {
+        const int ab = fpp.arity_bits[r];
+        const bool sharded = r == 0 && sh.world > 1;
+        const size_t leaves_all = flen[r] >> ab, leaves = sharded ? leaves_all >> sh.lg : leaves_all, slots = sharded ? sh.world : 1;
+        int depth = 0;
+        while (((size_t)1 << (depth + fpp.cap_height)) < leaves_all) ++depth;
+        const int width = 2 << ab;
+        size_t rowlen = width + 4 * (size_t)depth;
+        u64* d_out = S.get(rowlen * nq * slots);
+        if (!d_out) return vx_fail(VX_E_NOMEM, "prove: out of device memory (queries)");
+        hipLaunchKernelGGL(gather_open_kernel, dim3(nq), dim3(128), 0, c->stream, fvals[r] + (sharded ? 2 * row_base : 0), 0, width, 0,
+                           ftrees[r], leaves, depth, sharded ? d_idx + (R + 2) * nq : d_idx + (r + 1) * nq,
+                           d_out + (sharded ? rowlen * nq * sh.rank : 0));
+        if (sharded) VXCHK(shard_allgather(c, sh, d_out, rowlen * nq * 8, "FRI query openings"));
+        step_out[r].resize(rowlen * nq * slots);
+        pending_dev.push_back(d_out);
+        pending_host.push_back(&step_out[r]);
+      }
+      for (size_t i = 0; i < pending_dev.size(); ++i)
+        HIPCHK(hipMemcpyAsync(pending_host[i]->data(), pending_dev[i], pending_host[i]->size() * 8, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    out.flen = flen;
+    out.depth0 = depth0;
+  }
+  return VX_OK;
+}
+
+// FriProof part of util/serialization::write_proof: commit-phase caps, query rounds, final polynomial, pow witness.
+static void write_fri_proof(ByteSink& w, const FriProverParams& fp, const std::vector<vx_batch*>& oracles, const FriParts& f, const Shard& sh) {
+  const size_t cap_words = (size_t)4 << fp.cap_height, R = fp.arity_bits.size();
+  const int nq = fp.num_queries;
+  auto slot_of = [&](bool sharded, int q) { return sharded ? (size_t)f.owner[q] : (size_t)0; };
+  for (auto& cp : f.commit_caps) w.words(cp.data(), cap_words);
+  for (int q = 0; q < nq; ++q) {
+    for (size_t o = 0; o < oracles.size(); ++o) {
+      size_t width = oracles[o]->ncols, rowlen = width + 4 * (size_t)f.depth0;
+      const u64* row = &f.init_out[o][rowlen * (slot_of(oracles[o]->shard_lg > 0, q) * nq + q)];
+      w.words(row, width);
+      w.u8((uint8_t)f.depth0);
+      w.words(row + width, 4 * (size_t)f.depth0);
+    }
+    for (size_t r = 0; r < R; ++r) {
+      const int ab = fp.arity_bits[r];
+      const size_t leaves = f.flen[r] >> ab;
+      int depth = 0;
+      while (((size_t)1 << (depth + fp.cap_height)) < leaves) ++depth;
+      size_t width = (size_t)2 << ab, rowlen = width + 4 * (size_t)depth;
+      const u64* row = &f.step_out[r][rowlen * (slot_of(r == 0 && sh.world > 1, q) * nq + q)];
+      w.words(row, width);
+      w.u8((uint8_t)depth);
+      w.words(row + width, 4 * (size_t)depth);
+    }
+  }
+  for (vxh::Ext e : f.final_poly) {
+    w.f(e.a);
+    w.f(e.b);
+  }
+  w.f(f.pow_witness);
+}
+
 static int prove_impl(vx_ctx* c, vx_circuit* k, const u64* wires_in, bool wires_on_device, const u64* pow_hint,
                       std::vector<uint8_t>& proof_out, const Shard& sh = Shard()) {
   using namespace vxh;
@@ -244,7 +602,7 @@ static int prove_impl(vx_ctx* c, vx_circuit* k, const u64* wires_in, bool wires_
   const size_t cap_words = (size_t)4 << k->cap_height;
   // this rank's share of every LDE: rows [row_base, row_base + Nl) = cosets [z0, z0 + zc) in bit-reversed order
   const size_t Nl = N >> sh.lg, row_base = Nl * (size_t)sh.rank;
-  const int zc = rate >> sh.lg, z0 = zc * sh.rank;
+  const int zc = rate >> sh.lg;
   Scratch S(c);
   // host sources of asynchronous uploads on the context's stream: they must outlive the copies, so they live as long as the proof
   std::vector<u64> ap;
@@ -553,286 +911,15 @@ static int prove_impl(vx_ctx* c, vx_circuit* k, const u64* wires_in, bool wires_
   for (Ext e : batch0) ch.observe_ext(e);
   for (Ext e : batch1) ch.observe_ext(e);
 
-  // ---- prove_openings ----
-  Ext alpha = ch.get_extension_challenge();
-  const size_t nb0 = batch0.size(), nb1 = batch1.size();
-  std::vector<u64> apows(2 * nb0);
+  // ---- prove_openings + fri_proof ----
+  FriProverParams fp;
+  fp.degree_bits = lg, fp.rate_bits = rb, fp.cap_height = k->cap_height, fp.pow_bits = k->pow_bits, fp.num_queries = k->num_queries;
+  fp.arity_bits = k->arity_bits;
+  std::vector<vx_batch*> fri_oracles(oracles, oracles + 4);
+  std::vector<FriRange> batch1_ranges = {FriRange{2, 0, (size_t)nch}};  // plonk_zs_next: the Z polynomials lead the zs_partial_products batch
+  FriParts fri;
+  VXCHK(fri_prove_openings(c, fp, fri_oracles, batch1_ranges, zeta, gzeta, batch0, batch1, ch, pow_hint, sh, S, fri));
   {
-    Ext a{1, 0};
-    for (size_t j = 0; j < nb0; ++j) {
-      apows[2 * j] = a.a;
-      apows[2 * j + 1] = a.b;
-      a = emul(a, alpha);
-    }
-  }
-  // F_b(z_b) = sum_j alpha^j opening_j   (= the verifier's PrecomputedReducedOpenings)
-  Ext y0{0, 0}, y1{0, 0};
-  for (size_t j = nb0; j-- > 0;) y0 = eadd(emul(y0, alpha), batch0[j]);
-  for (size_t j = nb1; j-- > 0;) y1 = eadd(emul(y1, alpha), batch1[j]);
-  u64* fcoef = S.get(4 * n);
-  u64* flde = S.get(4 * Nl);
-  u64* d_apows = S.get(2 * nb0);
-  if (!fcoef || !flde || !d_apows) return vx_fail(VX_E_NOMEM, "prove: out of device memory (opening proof)");
-  HIPCHK(hipMemcpyAsync(d_apows, apows.data(), apows.size() * 8, hipMemcpyHostToDevice, c->stream));
-  {
-    ReduceParams rp;
-    memset(&rp, 0, sizeof rp);
-    rp.ngroups = 4;
-    size_t total = 0;
-    for (int o = 0; o < 4; ++o) {
-      rp.cols[o] = oracles[o]->coeffs;
-      rp.ncols[o] = (int)oracles[o]->ncols;
-      total += oracles[o]->ncols;
-    }
-    rp.alpha_pows = d_apows;
-    rp.n = n;
-    rp.out = fcoef;
-    ProfScope ps(c, "reduce_polys", 8.0 * n * total);
-    hipLaunchKernelGGL(reduce_polys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, rp);
-    rp.ngroups = 1;
-    rp.cols[0] = zs_b->coeffs;
-    rp.ncols[0] = nch;
-    rp.out = fcoef + 2 * n;
-    hipLaunchKernelGGL(reduce_polys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, rp);
-    HIPCHK(hipGetLastError());
-  }
-  // LDE of (F0.a, F0.b, F1.a, F1.b): an F_p^2 NTT with base-field roots is two F_p NTTs
-  {
-    std::vector<u64> shifts(zc);
-    u64 wN = root_of_unity(LG);
-    for (int z = 0; z < zc; ++z) shifts[z] = mul(7, pow(wN, reverse_bits((size_t)(z0 + z), rb)));
-    int bits = lg / 2;
-    u64* tab = nullptr;
-    VXCHK(get_scale_tables(c, lg, bits, shifts, 1, &tab));
-    VXCHK(run_ntt(c, fcoef, flde, n, Nl, 0, n, lg, 4, zc, false, true, tab, bits, 1, "fri_lde", 4.0 * 8.0 * ((double)n + Nl)));
-  }
-  // FRI value arrays per round (interleaved ext, bit-reversed order) and their trees
-  const size_t R = k->arity_bits.size();
-  std::vector<u64*> fvals(R + 1, nullptr), ftrees(R, nullptr);
-  std::vector<size_t> flen(R + 1), fcapoff(R, 0);
-  flen[0] = N;
-  for (size_t r = 0; r < R; ++r) flen[r + 1] = flen[r] >> k->arity_bits[r];
-  for (size_t r = 0; r <= R; ++r) {
-    fvals[r] = S.get(2 * flen[r]);
-    if (!fvals[r]) return vx_fail(VX_E_NOMEM, "prove: out of device memory (FRI)");
-  }
-  {
-    CombineParams cp;
-    memset(&cp, 0, sizeof cp);
-    cp.fl = flde;
-    cp.root_lo = c->root_lo;
-    cp.root_hi = c->root_hi;
-    cp.rows = Nl;
-    cp.row_base = row_base;
-    cp.log_N = LG;
-    cp.y0[0] = y0.a, cp.y0[1] = y0.b, cp.y1[0] = y1.a, cp.y1[1] = y1.b;
-    cp.z0[0] = zeta.a, cp.z0[1] = zeta.b, cp.z1[0] = gzeta.a, cp.z1[1] = gzeta.b;
-    Ext sh = epow(alpha, nb1);  // alpha.shift_poly: *= alpha^|batch 1|
-    cp.shift0[0] = sh.a, cp.shift0[1] = sh.b;
-    cp.out = fvals[0] + 2 * row_base;
-    ProfScope ps(c, "fri_combine", 48.0 * Nl);
-    hipLaunchKernelGGL(fri_combine_kernel, dim3((unsigned)((Nl + 255) / 256)), dim3(256), 0, c->stream, cp);
-    HIPCHK(hipGetLastError());
-  }
-  if (R == 0) VXCHK(shard_allgather(c, sh, fvals[0], 16 * Nl, "FRI values"));
-  // ---- FRI commit phase ----
-  std::vector<std::vector<u64>> commit_caps;
-  {
-    u64 shift = 7;
-    for (size_t r = 0; r < R; ++r) {
-      const int ab = k->arity_bits[r];
-      // the first layer is sharded like every LDE (rows [row_base, row_base + Nl)); later layers are replicated
-      const Shard shr = r == 0 ? sh : Shard();
-      const size_t M = flen[r] >> shr.lg, leaves = M >> ab, in_base = r == 0 ? row_base : 0;
-      const int width = 2 << ab, ch_l = k->cap_height - shr.lg;
-      size_t nd = merkle_tree_digest_count(leaves, ch_l);
-      ftrees[r] = S.get(nd * 4);
-      if (!ftrees[r]) return vx_fail(VX_E_NOMEM, "prove: out of device memory (FRI trees)");
-      {
-        ProfScope ps(c, "fri_hash_leaves", 16.0 * M);
-        if (leaves <= COOP_MAX_LEAVES)
-          hipLaunchKernelGGL(hash_leaves_rowmajor_coop_kernel, dim3((unsigned)((leaves * 16 + HASH_THREADS - 1) / HASH_THREADS)),
-                             dim3(HASH_THREADS), 0, c->stream, fvals[r] + 2 * in_base, leaves, width, ftrees[r]);
-        else
-          hipLaunchKernelGGL(hash_leaves_rowmajor_kernel, dim3((unsigned)((leaves + HASH_THREADS - 1) / HASH_THREADS)),
-                             dim3(HASH_THREADS), 0, c->stream, fvals[r] + 2 * in_base, leaves, width, ftrees[r]);
-        HIPCHK(hipGetLastError());
-      }
-      VXCHK(build_merkle_levels(c, ftrees[r], leaves, ch_l, &fcapoff[r]));
-      std::vector<u64> cap;
-      VXCHK(gather_cap(c, shr, S, ftrees[r] + fcapoff[r] * 4, (size_t)4 << ch_l, cap));
-      ch.observe_elements(cap.data(), cap_words);
-      commit_caps.push_back(cap);
-      Ext beta = ch.get_extension_challenge();
-      FoldParams fp;
-      memset(&fp, 0, sizeof fp);
-      fp.in = fvals[r] + 2 * in_base;
-      fp.out = fvals[r + 1] + 2 * (in_base >> ab);
-      fp.k_base = in_base >> ab;
-      fp.root_lo = c->root_lo;
-      fp.root_hi = c->root_hi;
-      fp.M = M;
-      fp.log_M = LG;
-      for (size_t q = 0; q < r; ++q) fp.log_M -= k->arity_bits[q];
-      fp.arity_bits = ab;
-      fp.beta[0] = beta.a, fp.beta[1] = beta.b;
-      fp.shift_inv = inv(shift);
-      u64 wa_inv = inv(root_of_unity(ab)), pw = 1;
-      for (int q = 0; q < (1 << ab); ++q) {
-        fp.w_inv_pows[q] = pw;
-        pw = mul(pw, wa_inv);
-      }
-      fp.arity_inv = inv((u64)1 << ab);
-      {
-        ProfScope ps(c, "fri_fold", 16.0 * M);
-        hipLaunchKernelGGL(fri_fold_kernel, dim3((unsigned)((leaves + 255) / 256)), dim3(256), 0, c->stream, fp);
-        HIPCHK(hipGetLastError());
-      }
-      VXCHK(shard_allgather(c, shr, fvals[r + 1], 16 * leaves, "folded FRI layer"));
-      shift = pow(shift, (u64)1 << ab);
-    }
-    // final polynomial: the last value array (bit-reversed, on the coset shift*H) -> coefficients, on the host
-    const size_t Mf = flen[R];
-    const int lMf = [&] { int l = 0; while (((size_t)1 << l) < Mf) ++l; return l; }();
-    std::vector<u64> hv(2 * Mf);
-    HIPCHK(hipMemcpyAsync(hv.data(), fvals[R], hv.size() * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    std::vector<Ext> coeffs(Mf);
-    {
-      // coefficient j = shift^-j / Mf * sum_k v_k w^(-jk), v_k at natural index k = rev(position)
-      u64 w_inv = inv(root_of_unity(lMf)), s_inv = inv(shift), m_inv = inv((u64)Mf % P);
-      std::vector<u64> wp(Mf);
-      wp[0] = 1;
-      for (size_t i = 1; i < Mf; ++i) wp[i] = mul(wp[i - 1], w_inv);
-      u64 sj = m_inv;
-      for (size_t j = 0; j < Mf; ++j) {
-        u64 a = 0, b = 0;
-        for (size_t pos = 0; pos < Mf; ++pos) {
-          size_t kk = reverse_bits(pos, lMf);
-          u64 w = wp[(j * kk) & (Mf - 1)];
-          a = add(a, mul(hv[2 * pos], w));
-          b = add(b, mul(hv[2 * pos + 1], w));
-        }
-        coeffs[j] = Ext{mul(a, sj), mul(b, sj)};
-        sj = mul(sj, s_inv);
-      }
-    }
-    const size_t keep = Mf >> rb;
-    for (size_t j = keep; j < Mf; ++j)
-      if (coeffs[j].a || coeffs[j].b) return vx_fail(VX_E_PROOF, "FRI final polynomial has non-zero high coefficients (witness does not satisfy the circuit?)");
-    coeffs.resize(keep);
-    for (Ext e : coeffs) ch.observe_ext(e);
-    // ---- proof of work ----
-    u64 pow_witness = 0;
-    {
-      auto check = [&](u64 cand) {
-        Challenger c2 = ch;
-        c2.observe_element(cand);
-        return (c2.get_challenge() >> (64 - k->pow_bits)) == 0;
-      };
-      if (pow_hint) {
-        pow_witness = canon(*pow_hint);
-        if (k->pow_bits > 0 && !check(pow_witness)) return vx_fail(VX_E_INVALID, "pow_witness hint does not satisfy the proof-of-work condition");
-      } else if (k->pow_bits > 0) {
-        PowParams pp;
-        memset(&pp, 0, sizeof pp);
-        for (int q = 0; q < 12; ++q) pp.state[q] = ch.sponge[q];
-        for (size_t q = 0; q < ch.input.size(); ++q) pp.state[q] = ch.input[q];
-        pp.pos = (int)ch.input.size();
-        pp.pow_bits = k->pow_bits;
-        unsigned long long* d_res = (unsigned long long*)S.get(1);
-        if (!d_res) return vx_fail(VX_E_NOMEM, "prove: out of device memory (pow)");
-        pp.result = d_res;
-        // Candidates are searched in increasing ranges and the smallest hit of a range wins, so the witness does not
-        // depend on the range sizes.  The first range is sized to succeed with probability ~1 - e^-2 at the cost of a
-        // couple of waves per SIMD; later ranges grow to keep the launch count logarithmic.
-        u64 batch = (u64)2 << std::min(k->pow_bits, 21);
-        unsigned long long res = ~0ull;
-        ProfScope ps(c, "pow_grind");
-        for (u64 base = 0; res == ~0ull; base += batch, batch = std::min(batch * 4, (u64)1 << 24)) {
-          HIPCHK(hipMemsetAsync(d_res, 0xFF, 8, c->stream));
-          pp.base = base;
-          hipLaunchKernelGGL(pow_grind_kernel, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, c->stream, pp);
-          HIPCHK(hipMemcpyAsync(&res, d_res, 8, hipMemcpyDeviceToHost, c->stream));
-          HIPCHK(hipStreamSynchronize(c->stream));
-          if (base > ((u64)1 << 44)) return vx_fail(VX_E_PROOF, "Proof of work failed. This is highly unlikely!");
-        }
-        pow_witness = res;
-        if (!check(pow_witness)) return vx_fail(VX_E_PROOF, "internal error: GPU proof-of-work witness rejected by the host transcript");
-      }
-      ch.observe_element(pow_witness);
-      (void)ch.get_challenge();  // pow_response
-    }
-    // ---- query rounds ----
-    const int nq = k->num_queries;
-    std::vector<u64> x_indices(nq);
-    for (int q = 0; q < nq; ++q) x_indices[q] = ch.get_challenge() % (u64)N;
-    const int depth0 = LG - k->cap_height;
-    // A sharded tree (wires / Z / quotient oracles, first FRI layer) is opened by the rank that owns the leaf — the
-    // top shard_lg bits of the index — and the rows are all-gathered: slot `owner[q]` holds query q's real opening.
-    std::vector<std::vector<u64>> init_out(4);
-    std::vector<std::vector<u64>> step_out(R);
-    std::vector<int> owner(nq, 0);
-    auto slot_of = [&](bool sharded, int q) { return sharded ? (size_t)owner[q] : (size_t)0; };
-    {
-      ProfScope ps(c, "query_gather");
-      u64* d_idx = S.get((size_t)nq * (R + 3));
-      if (!d_idx) return vx_fail(VX_E_NOMEM, "prove: out of device memory (queries)");
-      std::vector<u64> idx_host((size_t)nq * (R + 3));
-      u64* loc_x = &idx_host[(R + 1) * nq];   // local leaf index in a sharded oracle (0 when another rank owns it)
-      u64* loc_f0 = &idx_host[(R + 2) * nq];  // local leaf index in the first FRI layer's tree
-      for (int q = 0; q < nq; ++q) {
-        u64 xi = x_indices[q];
-        idx_host[q] = xi;
-        owner[q] = (int)(xi >> (LG - sh.lg));
-        const bool mine = owner[q] == sh.rank;
-        loc_x[q] = mine ? xi - row_base : 0;
-        loc_f0[q] = mine && R > 0 ? (xi >> k->arity_bits[0]) - (row_base >> k->arity_bits[0]) : 0;
-        for (size_t r = 0; r < R; ++r) {
-          xi >>= k->arity_bits[r];
-          idx_host[(r + 1) * nq + q] = xi;
-        }
-      }
-      HIPCHK(hipMemcpyAsync(d_idx, idx_host.data(), idx_host.size() * 8, hipMemcpyHostToDevice, c->stream));
-      std::vector<u64*> pending_dev;
-      std::vector<std::vector<u64>*> pending_host;
-      for (int o = 0; o < 4; ++o) {
-        const bool sharded = oracles[o]->shard_lg > 0;
-        const size_t rowlen = oracles[o]->ncols + 4 * (size_t)depth0, slots = sharded ? sh.world : 1;
-        u64* d_out = S.get(rowlen * nq * slots);
-        if (!d_out) return vx_fail(VX_E_NOMEM, "prove: out of device memory (queries)");
-        const size_t rows_o = oracles[o]->rows();
-        hipLaunchKernelGGL(gather_open_kernel, dim3(nq), dim3(128), 0, c->stream, oracles[o]->lde, rows_o, (int)oracles[o]->ncols, 1,
-                           oracles[o]->tree, rows_o, depth0, sharded ? d_idx + (R + 1) * nq : d_idx,
-                           d_out + (sharded ? rowlen * nq * sh.rank : 0));
-        if (sharded) VXCHK(shard_allgather(c, sh, d_out, rowlen * nq * 8, "query openings"));
-        init_out[o].resize(rowlen * nq * slots);
-        pending_dev.push_back(d_out);
-        pending_host.push_back(&init_out[o]);
-      }
-      for (size_t r = 0; r < R; ++r) {
-        const int ab = k->arity_bits[r];
-        const bool sharded = r == 0 && sh.world > 1;
-        const size_t leaves_all = flen[r] >> ab, leaves = sharded ? leaves_all >> sh.lg : leaves_all, slots = sharded ? sh.world : 1;
-        int depth = 0;
-        while (((size_t)1 << (depth + k->cap_height)) < leaves_all) ++depth;
-        const int width = 2 << ab;
-        size_t rowlen = width + 4 * (size_t)depth;
-        u64* d_out = S.get(rowlen * nq * slots);
-        if (!d_out) return vx_fail(VX_E_NOMEM, "prove: out of device memory (queries)");
-        hipLaunchKernelGGL(gather_open_kernel, dim3(nq), dim3(128), 0, c->stream, fvals[r] + (sharded ? 2 * row_base : 0), 0, width, 0,
-                           ftrees[r], leaves, depth, sharded ? d_idx + (R + 2) * nq : d_idx + (r + 1) * nq,
-                           d_out + (sharded ? rowlen * nq * sh.rank : 0));
-        if (sharded) VXCHK(shard_allgather(c, sh, d_out, rowlen * nq * 8, "FRI query openings"));
-        step_out[r].resize(rowlen * nq * slots);
-        pending_dev.push_back(d_out);
-        pending_host.push_back(&step_out[r]);
-      }
-      for (size_t i = 0; i < pending_dev.size(); ++i)
-        HIPCHK(hipMemcpyAsync(pending_host[i]->data(), pending_dev[i], pending_host[i]->size() * 8, hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(hipGetLastError());
-      HIPCHK(hipStreamSynchronize(c->stream));
-    }
     // ---- serialise (util/serialization::write_proof_with_public_inputs) ----
     ByteSink w;
     w.b.reserve(proof_size_bound(k));
@@ -847,32 +934,7 @@ static int prove_impl(vx_ctx* c, vx_circuit* k, const u64* wires_in, bool wires_
     w.words(zs_next.data(), 2 * (size_t)nch);
     w.words(ev[2].data() + 2 * (size_t)nch, ev[2].size() - 2 * (size_t)nch);
     w.words(ev[3].data(), ev[3].size());
-    for (auto& cp : commit_caps) w.words(cp.data(), cap_words);
-    for (int q = 0; q < nq; ++q) {
-      for (int o = 0; o < 4; ++o) {
-        size_t width = oracles[o]->ncols, rowlen = width + 4 * (size_t)depth0;
-        const u64* row = &init_out[o][rowlen * (slot_of(oracles[o]->shard_lg > 0, q) * nq + q)];
-        w.words(row, width);
-        w.u8((uint8_t)depth0);
-        w.words(row + width, 4 * (size_t)depth0);
-      }
-      for (size_t r = 0; r < R; ++r) {
-        const int ab = k->arity_bits[r];
-        const size_t leaves = flen[r] >> ab;
-        int depth = 0;
-        while (((size_t)1 << (depth + k->cap_height)) < leaves) ++depth;
-        size_t width = (size_t)2 << ab, rowlen = width + 4 * (size_t)depth;
-        const u64* row = &step_out[r][rowlen * (slot_of(r == 0 && sh.world > 1, q) * nq + q)];
-        w.words(row, width);
-        w.u8((uint8_t)depth);
-        w.words(row + width, 4 * (size_t)depth);
-      }
-    }
-    for (Ext e : coeffs) {
-      w.f(e.a);
-      w.f(e.b);
-    }
-    w.f(pow_witness);
+    write_fri_proof(w, fp, fri_oracles, fri, sh);
     w.words(public_inputs.data(), public_inputs.size());
     proof_out.swap(w.b);
   }

@@ -9,6 +9,7 @@
 #include "jit.hip.h"
 #include "prover.hip.h"
 #include "circuit_io.h"
+#include "stark.hip.h"
 #include <memory>
 #include <cstddef>
 #include "verifier.h"
@@ -727,6 +728,48 @@ int vx_verify_standalone(const vx_circuit_desc* d, const uint64_t* cs_cap, const
     return vx_fail(VX_E_NOMEM, "vx_verify_standalone: out of host memory");
   } catch (const std::exception& e) {  // never unwind across the ABI
     return vx_fail(VX_E_PROOF, "vx_verify: exception: %s", e.what());
+  }
+}
+
+// ---- STARK spike (stark.hip.h) ----
+int vx_stark_prove(vx_ctx* c, const vx_stark_desc* d, const uint64_t* trace, int trace_on_device, const uint64_t* public_inputs,
+                   const uint64_t* pow_witness_hint, uint8_t* out_buf, size_t* out_len) {
+  if (!c || !d || !trace || !out_buf || !out_len || (d->num_public_inputs > 0 && !public_inputs)) return vx_fail(VX_E_INVALID, "vx_stark_prove: NULL argument");
+  HIPCHK(hipSetDevice(c->device));
+  std::vector<uint8_t> proof;
+  int rc;
+  try {
+    rc = stark_prove_impl(c, d, trace, trace_on_device != 0, public_inputs, pow_witness_hint, proof);
+  } catch (const std::bad_alloc&) {
+    rc = vx_fail(VX_E_NOMEM, "vx_stark_prove: out of host memory");
+  } catch (const std::exception& e) {
+    rc = vx_fail(VX_E_INVALID, "vx_stark_prove: %s", e.what());
+  }
+  if (rc != VX_OK) {
+    hipStreamSynchronize(c->stream);
+    return rc;
+  }
+  if (proof.size() > *out_len) {
+    *out_len = proof.size();
+    return vx_fail(VX_E_INVALID, "vx_stark_prove: output buffer too small, need %zu bytes", proof.size());
+  }
+  memcpy(out_buf, proof.data(), proof.size());
+  *out_len = proof.size();
+  return VX_OK;
+}
+int vx_stark_verify(const vx_stark_desc* d, const uint64_t* public_inputs, const uint8_t* proof, size_t proof_len) {
+  if (!d || !proof || (d->num_public_inputs > 0 && !public_inputs)) return vx_fail(VX_E_INVALID, "vx_stark_verify: NULL argument");
+  try {
+    StarkShape sh;
+    std::string why = stark_check(d, &sh);
+    if (!why.empty()) return vx_fail(VX_E_INVALID, "vx_stark_verify: %s", why.c_str());
+    why = vxsv::verify(d, sh, public_inputs, proof, proof_len);
+    if (!why.empty()) return vx_fail(VX_E_PROOF, "vx_stark_verify: %s", why.c_str());
+    return VX_OK;
+  } catch (const std::bad_alloc&) {
+    return vx_fail(VX_E_NOMEM, "vx_stark_verify: out of host memory");
+  } catch (const std::exception& e) {
+    return vx_fail(VX_E_PROOF, "vx_stark_verify: exception: %s", e.what());
   }
 }
 

@@ -28,8 +28,8 @@ the meaning of the output bytes: the map jobs' public inputs are derived from th
 `output` is derived from the outer proof's digest, so the output is a deterministic function of the input that can
 only be produced by proving the whole DAG.
 
-The proving backend is injected (`GpuBackend` by default).  Nothing in this module touches oracle/: the CPU tests pass
-their own backend (tests/test_function_cli.py).
+The proving backend is injected (`GpuBackend` by default).  The CPU tests inject their own backend
+(tests/test_function_cli.py); this module imports the product library only.
 """
 from __future__ import annotations
 
