@@ -162,6 +162,9 @@ size_t vx_merkle_digest_count(size_t n_leaves, int cap_height);
 #define VX_GATE_PUBLIC_INPUT 2
 #define VX_GATE_ARITHMETIC 3
 #define VX_GATE_POSEIDON 4
+/* 5 = VX_GATE_PROGRAM (below) */
+#define VX_GATE_LOOKUP 6       /* LookupGate { num_slots }: wires (2i, 2i+1) = (looking input, output); no gate constraints */
+#define VX_GATE_LOOKUP_TABLE 7 /* LookupTableGate { num_slots }: wires (3i, 3i+1, 3i+2) = (looked input, output, multiplicity) */
 
 typedef struct vx_circuit_desc {
   int32_t degree_bits;
@@ -202,6 +205,17 @@ typedef struct vx_circuit_desc {
   int32_t num_partial_products;          /* VX_DESC_HAS_NUM_PARTIAL_PRODUCTS: CommonCircuitData::num_partial_products;
                                           * must equal ceil(num_routed_wires / quotient_degree_factor) - 1 or the call fails */
   const int32_t* fri_reduction_arity_bits; /* (else: ConstantArityBits(4, 5) of standard_recursion_config) */
+  /* ---- lookup argument (plonky2 v0.2.0 gates/lookup.rs, gates/lookup_table.rs, plonk/vanishing_poly.rs
+   * check_lookup_constraints; used by plonky2x's byte / u32 range tables).  num_luts = 0 (a zero tail): no lookups.
+   * With lookups the preprocessed columns are [selectors | lookup selectors | gate constants | sigmas]:
+   * num_lookup_selectors = 4 + num_luts columns (TransSre, TransLdc, InitSre, LastLdc, then one "ends" selector per
+   * table) sit between the gate selectors and the gate constants, and num_constants counts them. */
+  int32_t num_luts;
+  int32_t num_lookup_selectors;
+  const int32_t* lut_lens;        /* [num_luts] entries of each table */
+  const uint16_t* lut_inputs;     /* CommonCircuitData::luts, concatenated: (input, output) pairs */
+  const uint16_t* lut_outputs;
+  const int32_t* lookup_rows;     /* [num_luts][3] = (last_lu_gate, last_lut_gate, first_lut_gate): ProverOnlyCircuitData::lookup_rows */
 } vx_circuit_desc;
 #define VX_DESC_HAS_CIRCUIT_DIGEST 1u
 #define VX_DESC_HAS_FRI_ARITIES 2u

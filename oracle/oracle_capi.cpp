@@ -148,9 +148,23 @@ struct vxo_circuit_desc {
   int32_t num_fri_reduction_arity_bits;
   int32_t num_partial_products;
   const int32_t* fri_reduction_arity_bits;
+  int32_t num_luts, num_lookup_selectors;
+  const int32_t* lut_lens;
+  const uint16_t *lut_inputs, *lut_outputs;
+  const int32_t* lookup_rows;
 };
 static void load_overrides(const vxo_circuit_desc* d, Circuit* c) {
   if (d->hiding) throw std::runtime_error("zero-knowledge circuits are not restated");
+  if (d->num_luts > 0) {  // lookup argument
+    c->num_lookup_selectors = d->num_lookup_selectors;
+    size_t off = 0;
+    for (int t = 0; t < d->num_luts; ++t) {
+      std::vector<std::pair<u64, u64>> lut;
+      for (int k = 0; k < d->lut_lens[t]; ++k, ++off) lut.push_back({d->lut_inputs[off], d->lut_outputs[off]});
+      c->luts.push_back(std::move(lut));
+      c->lookup_rows.push_back({(size_t)d->lookup_rows[3 * t], (size_t)d->lookup_rows[3 * t + 1], (size_t)d->lookup_rows[3 * t + 2]});
+    }
+  }
   if (d->override_flags & 1) {
     c->has_digest_override = true;
     for (int i = 0; i < 4; ++i) c->digest_override.e[i] = canon(d->circuit_digest[i]);

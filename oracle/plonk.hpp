@@ -111,6 +111,20 @@ struct Circuit {
   int num_constants = 0;  // selectors + gate constants (CommonCircuitData::num_constants)
   std::vector<u64> k_is;
   std::vector<std::pair<uint32_t, uint32_t>> public_inputs;  // (row, wire) targets
+  // lookup argument (gates/lookup.rs, gates/lookup_table.rs, circuit_builder.rs::add_all_lookups); num_luts = 0: none
+  int num_lookup_selectors = 0;                                 // LookupSelectors::StartEnd (= 4) + number of tables
+  std::vector<std::vector<std::pair<u64, u64>>> luts;          // CommonCircuitData::luts: (input, output) pairs
+  struct LookupWire {
+    size_t last_lu_gate, last_lut_gate, first_lut_gate;
+  };
+  std::vector<LookupWire> lookup_rows;                          // ProverOnlyCircuitData::lookup_rows
+  bool has_lookup() const { return !luts.empty(); }
+  int num_lu_slots() const { return num_routed_wires / 2; }     // LookupGate::num_slots
+  int num_lut_slots() const { return num_routed_wires / 3; }    // LookupTableGate::num_slots
+  int lookup_degree() const { return quotient_degree_factor - 1; }
+  int num_sldc_polys() const { return (num_lu_slots() + lookup_degree() - 1) / lookup_degree(); }
+  int num_lookup_polys() const { return has_lookup() ? 1 + num_sldc_polys() : 0; }   // per challenge: RE + partial Sum/LDCs
+  int gate_const_base() const { return num_selectors + num_lookup_selectors; }       // gates see constants after BOTH selector kinds
   // derived
   int num_gate_constraints = 0;
   std::vector<int> reduction_arity_bits;
@@ -124,7 +138,8 @@ struct Circuit {
   size_t n() const { return (size_t)1 << degree_bits; }
   int num_partial_products() const { return (num_routed_wires + quotient_degree_factor - 1) / quotient_degree_factor - 1; }
   int num_preprocessed() const { return num_constants + num_routed_wires; }
-  int num_zs_pp() const { return num_challenges * (1 + num_partial_products()); }
+  int num_zs_pp() const { return num_challenges * (1 + num_partial_products()); }                 // Z + partial products
+  int num_zs_pp_lookup() const { return num_zs_pp() + num_challenges * num_lookup_polys(); }       // ... + lookup polynomials (one batch)
   int num_quotient() const { return num_challenges * quotient_degree_factor; }
 
   // fri/reduction_strategies.rs: ConstantArityBits(4, 5)
@@ -286,19 +301,86 @@ static void evaluate_gate_constraints(const Circuit& c, const T* local_constants
   for (size_t gi = 0; gi < c.gates.size(); ++gi) {
     const Gate& g = c.gates[gi];
     T filter = compute_filter<T>((int)gi, g, local_constants[g.selector_index], c.num_selectors > 1);
-    eval_gate_unfiltered<T>(g, local_constants + c.num_selectors, wires, pih, tmp);
+    eval_gate_unfiltered<T>(g, local_constants + c.gate_const_base(), wires, pih, tmp);
     for (size_t i = 0; i < tmp.size(); ++i) constraints[i] = constraints[i] + filter * tmp[i];
   }
 }
 
+// vanishing_poly.rs::get_lut_poly: the table as a polynomial in delta — sum_k (inp_k + b out_k) delta^(degree-1-k)
+static u64 get_lut_poly(const Circuit& c, int lut_index, const u64* deltas, size_t degree) {
+  const u64 b = deltas[1], delta = deltas[3];
+  const auto& lut = c.luts[lut_index];
+  u64 acc = 0;  // coefficients reversed: Horner over k = 0 .. degree-1 with zero padding after the table
+  for (size_t k = 0; k < degree; ++k) {
+    const u64 coeff = k < lut.size() ? add(lut[k].first % P, mul(b, lut[k].second % P)) : 0;
+    acc = add(mul(acc, delta), coeff);
+  }
+  return acc;
+}
+
+// vanishing_poly.rs::check_lookup_constraints for ONE challenge (deltas = [a, b, alpha, delta] of that challenge).
+// lookup_selectors: TransSre, TransLdc, InitSre, LastLdc, then one "ends" selector per table.
+// local_zs / next_zs: [RE, SLDC_0 .. SLDC_{k-1}] at x and g x.  Appends 4 + num_luts + 2 k constraints.
+template <class T>
+static void check_lookup_constraints(const Circuit& c, const T* lookup_selectors, const T* wires, const T* local_zs, const T* next_zs,
+                                     const u64* deltas, std::vector<T>& out) {
+  const int num_lu_slots = c.num_lu_slots(), num_lut_slots = c.num_lut_slots(), lu_degree = c.lookup_degree();
+  const int num_sldc = c.num_sldc_polys(), lut_degree = (num_lut_slots + num_sldc - 1) / num_sldc;
+  const T z_re = local_zs[0], next_z_re = next_zs[0];
+  const T* z_x = local_zs + 1;
+  const T* z_gx = next_zs + 1;
+  const u64 da = deltas[0], db = deltas[1], dalpha = deltas[2], ddelta = deltas[3];
+  // combos: looking (LookupGate wires 2i, 2i+1), looked for Sum (a) and for RE (b) (LookupTableGate wires 3i, 3i+1)
+  std::vector<T> looking(num_lu_slots), looked(num_lut_slots), looked_re(num_lut_slots);
+  for (int i = 0; i < num_lu_slots; ++i) looking[i] = wires[2 * i] + scale(wires[2 * i + 1], da);
+  for (int i = 0; i < num_lut_slots; ++i) {
+    looked[i] = wires[3 * i] + scale(wires[3 * i + 1], da);
+    looked_re[i] = wires[3 * i] + scale(wires[3 * i + 1], db);
+  }
+  // LDC ends at zero; Sum and RE start from zero
+  out.push_back(lookup_selectors[3] * z_x[num_sldc - 1]);
+  out.push_back(lookup_selectors[2] * z_x[0]);
+  out.push_back(lookup_selectors[2] * z_re);
+  // RE on a table's last row equals the table polynomial
+  for (size_t r = 0; r < c.luts.size(); ++r) {
+    const size_t rows = (c.luts[r].size() + num_lut_slots - 1) / num_lut_slots;
+    out.push_back(lookup_selectors[4 + r] * (z_re - T(get_lut_poly(c, (int)r, deltas, (size_t)num_lut_slots * rows))));
+  }
+  // RE row transition
+  {
+    T cur = next_z_re;
+    for (int i = 0; i < num_lut_slots; ++i) cur = scale(cur, ddelta) + looked_re[i];
+    out.push_back(lookup_selectors[0] * (z_re - cur));
+  }
+  for (int poly = 0; poly < num_sldc; ++poly) {
+    const int t0 = poly * lut_degree, t1 = std::min((poly + 1) * lut_degree, num_lut_slots);
+    const int u0 = poly * lu_degree, u1 = std::min((poly + 1) * lu_degree, num_lu_slots);
+    auto prod_except = [&](const std::vector<T>& v, int lo, int hi, int skip) {
+      T acc = T(1);
+      for (int j = lo; j < hi; ++j)
+        if (j != skip) acc = acc * (T(dalpha) - v[j]);
+      return acc;
+    };
+    const T lut_prod = prod_except(looked, t0, t1, -1), lu_prod = prod_except(looking, u0, u1, -1);
+    T lu_sum = T(0), lut_sum_mul = T(0);
+    for (int i = u0; i < u1; ++i) lu_sum = lu_sum + prod_except(looking, u0, u1, i);
+    for (int i = t0; i < t1; ++i) lut_sum_mul = lut_sum_mul + wires[3 * i + 2] * prod_except(looked, t0, t1, i);
+    const T prev = poly == 0 ? z_gx[num_sldc - 1] : z_x[poly - 1];
+    out.push_back(lookup_selectors[0] * (lut_prod * (z_x[poly] - prev) - lut_sum_mul));   // Sum transition
+    out.push_back(lookup_selectors[1] * (lu_prod * (z_x[poly] - prev) + lu_sum));         // LDC transition
+  }
+}
+
 // vanishing_poly.rs::eval_vanishing_poly (one point).  x: the point; l0: L_0(x).
-// local_constants: num_constants values; s_sigmas: 80; zs/next_zs: per challenge; pps: challenge-major.
+// local_constants: num_constants values; s_sigmas: 80; zs/next_zs: per challenge; pps: challenge-major;
+// lookup_zs / next_lookup_zs: challenge-major [RE, SLDCs]; deltas: 4 per challenge.
 template <class T>
 static void eval_vanishing(const Circuit& c, T x, T l0, const T* local_constants, const T* s_sigmas, const T* wires,
                            const T* zs, const T* next_zs, const T* pps, const Hash& pih, const u64* betas,
-                           const u64* gammas, const T* alphas, T* out /* num_challenges */) {
+                           const u64* gammas, const T* alphas, T* out /* num_challenges */, const T* lookup_zs = nullptr,
+                           const T* next_lookup_zs = nullptr, const u64* deltas = nullptr) {
   const int npp = c.num_partial_products(), deg = c.quotient_degree_factor, nr = c.num_routed_wires;
-  std::vector<T> z1_terms, pp_terms, gate_terms;
+  std::vector<T> z1_terms, pp_terms, lookup_terms, gate_terms;
   for (int ch = 0; ch < c.num_challenges; ++ch) {
     z1_terms.push_back(l0 * (zs[ch] - T(1)));
     std::vector<T> num(nr), den(nr);
@@ -321,11 +403,17 @@ static void eval_vanishing(const Circuit& c, T x, T l0, const T* local_constants
       }
       pp_terms.push_back(accs[chunk] * np - accs[chunk + 1] * dp);
     }
+    if (c.has_lookup()) {
+      const int nlp = c.num_lookup_polys();
+      check_lookup_constraints<T>(c, local_constants + c.num_selectors, wires, lookup_zs + ch * nlp, next_lookup_zs + ch * nlp, deltas + 4 * ch,
+                                  lookup_terms);
+    }
   }
   evaluate_gate_constraints<T>(c, local_constants, wires, pih, gate_terms);
   std::vector<T> terms;
   terms.insert(terms.end(), z1_terms.begin(), z1_terms.end());
   terms.insert(terms.end(), pp_terms.begin(), pp_terms.end());
+  terms.insert(terms.end(), lookup_terms.begin(), lookup_terms.end());
   terms.insert(terms.end(), gate_terms.begin(), gate_terms.end());
   // plonk_common.rs::reduce_with_powers_multi: sum_i term_i alpha^i (Horner from the last term)
   for (int ch = 0; ch < c.num_challenges; ++ch) {
@@ -339,7 +427,7 @@ static void eval_vanishing(const Circuit& c, T x, T l0, const T* local_constants
 // Proof objects (plonk/proof.rs, fri/proof.rs)
 // ---------------------------------------------------------------------------------------------
 struct OpeningSet {
-  std::vector<Ext> constants, plonk_sigmas, wires, plonk_zs, plonk_zs_next, partial_products, quotient_polys;
+  std::vector<Ext> constants, plonk_sigmas, wires, plonk_zs, plonk_zs_next, partial_products, quotient_polys, lookup_zs, lookup_zs_next;
 };
 struct FriInitialTreeProof {
   std::vector<std::vector<u64>> evals;        // per oracle: leaf values
@@ -404,7 +492,8 @@ static std::vector<uint8_t> serialize_proof(const Proof& p) {
   w.extvec(o.plonk_zs_next);
   w.extvec(o.partial_products);
   w.extvec(o.quotient_polys);
-  // lookup_zs, lookup_zs_next: empty (no lookup gates in the supported gate set)
+  w.extvec(o.lookup_zs);
+  w.extvec(o.lookup_zs_next);
   for (const auto& c : p.fri.commit_phase_caps) w.cap(c);
   for (const FriQueryRound& q : p.fri.query_rounds) {
     for (size_t t = 0; t < q.initial.evals.size(); ++t) {
@@ -476,6 +565,48 @@ static std::vector<std::vector<u64>> compute_zs_partial_products(const Circuit& 
   return out;
 }
 
+// prover.rs::compute_lookup_polys for ONE challenge (deltas = [a, b, alpha, delta]): [RE, SLDC_0 .. SLDC_{k-1}] as values on H
+static std::vector<std::vector<u64>> compute_lookup_polys(const Circuit& c, const std::vector<std::vector<u64>>& w, const u64* deltas) {
+  const size_t n = c.n();
+  const int num_lu_slots = c.num_lu_slots(), max_lookup_degree = c.lookup_degree(), num_partial = c.num_sldc_polys();
+  const int num_lut_slots = c.num_lut_slots(), max_lut_degree = (num_lut_slots + num_partial - 1) / num_partial;
+  const u64 da = deltas[0], db = deltas[1], dalpha = deltas[2], ddelta = deltas[3];
+  std::vector<std::vector<u64>> polys(num_partial + 1, std::vector<u64>(n, 0));
+  for (const auto& lr : c.lookup_rows) {
+    // table rows, from first_lut_gate down to last_lut_gate: partial Sums and RE
+    for (size_t row = lr.first_lut_gate + 1; row-- > lr.last_lut_gate;) {
+      std::vector<u64> inv_a(num_lut_slots);
+      u64 new_re = polys[0][row + 1];
+      for (int s2 = 0; s2 < num_lut_slots; ++s2) {
+        const u64 inp = w[3 * s2][row], out = w[3 * s2 + 1][row];
+        inv_a[s2] = sub(dalpha, add(inp, mul(da, out)));
+        new_re = add(mul(new_re, ddelta), add(inp, mul(db, out)));
+      }
+      batch_inverse(inv_a.data(), inv_a.size());
+      polys[0][row] = new_re;
+      for (int slot = 0; slot < num_partial; ++slot) {
+        u64 acc = slot != 0 ? polys[slot][row] : polys[num_partial][row + 1];
+        for (int s2 = slot * max_lut_degree; s2 < std::min((slot + 1) * max_lut_degree, num_lut_slots); ++s2)
+          acc = add(acc, mul(w[3 * s2 + 2][row], inv_a[s2]));
+        polys[slot + 1][row] = acc;
+      }
+    }
+    // looking rows, from last_lut_gate - 1 down to last_lu_gate: partial LDCs
+    for (size_t row = lr.last_lut_gate; row-- > lr.last_lu_gate;) {
+      std::vector<u64> inv_a(num_lu_slots);
+      for (int s2 = 0; s2 < num_lu_slots; ++s2) inv_a[s2] = sub(dalpha, add(w[2 * s2][row], mul(da, w[2 * s2 + 1][row])));
+      batch_inverse(inv_a.data(), inv_a.size());
+      for (int slot = 0; slot < num_partial; ++slot) {
+        const u64 prev = slot == 0 ? polys[num_partial][row + 1] : polys[slot][row];
+        u64 sum = 0;
+        for (int s2 = slot * max_lookup_degree; s2 < std::min((slot + 1) * max_lookup_degree, num_lu_slots); ++s2) sum = add(sum, inv_a[s2]);
+        polys[slot + 1][row] = sub(prev, sum);
+      }
+    }
+  }
+  return polys;
+}
+
 struct ProveOptions {
   bool has_pow_hint = false;  // use this pow_witness instead of grinding (upstream's choice is nondeterministic)
   u64 pow_hint = 0;
@@ -519,9 +650,20 @@ static Proof prove(const Circuit& c, const std::vector<std::vector<u64>>& wire_v
       fft_inplace(sigma_values[j].data(), lg);
     }
   }
+  // lookup challenges (prover.rs): 4 per challenge; the first 2 * num_challenges of them ARE the betas and gammas,
+  // the rest is drawn now
+  std::vector<u64> deltas;
+  const int nlp = c.num_lookup_polys();
+  if (c.has_lookup()) {
+    deltas = betas;
+    deltas.insert(deltas.end(), gammas.begin(), gammas.end());
+    for (int i = 0; i < 2 * nch; ++i) deltas.push_back(ch.get_challenge());
+  }
   PolynomialBatch zs_b;
   {
     auto cols = compute_zs_partial_products(c, wire_values, sigma_values, betas.data(), gammas.data());
+    for (int k = 0; k < nch && c.has_lookup(); ++k)
+      for (auto& col : compute_lookup_polys(c, wire_values, deltas.data() + 4 * k)) cols.push_back(std::move(col));
     if (tm) tm->zs_pp = now_s() - t0, t0 = now_s();
     zs_b.from_values(std::move(cols), rb, c.cap_height);
   }
@@ -547,6 +689,7 @@ static Proof prove(const Circuit& c, const std::vector<std::vector<u64>>& wire_v
 #pragma omp parallel
     {
       std::vector<Fp> lc(c.num_constants), ss(c.num_routed_wires), lw(c.num_wires), zs(nch), nzs(nch), pps(nch * npp), al(nch), res(nch);
+      std::vector<Fp> lzs(nch * nlp + 1), nlzs(nch * nlp + 1);
       for (int i = 0; i < nch; ++i) al[i] = Fp(alphas[i]);
 #pragma omp for schedule(static)
       for (long long i = 0; i < NN; ++i) {
@@ -560,10 +703,11 @@ static Proof prove(const Circuit& c, const std::vector<std::vector<u64>>& wire_v
         for (int k = 0; k < c.num_wires; ++k) lw[k] = Fp(wv[k]);
         for (int k = 0; k < nch; ++k) zs[k] = Fp(zv[k]), nzs[k] = Fp(zn[k]);
         for (int k = 0; k < nch * npp; ++k) pps[k] = Fp(zv[nch + k]);
+        for (int k = 0; k < nch * nlp; ++k) lzs[k] = Fp(zv[nch * (1 + npp) + k]), nlzs[k] = Fp(zn[nch * (1 + npp) + k]);
         // eval_l_0(i, x) = Z_H(x) / (n (x - 1))
         u64 l0 = mul(zh[i % rate], inv(mul((u64)n % P, sub(x, 1))));
         eval_vanishing<Fp>(c, Fp(x), Fp(l0), lc.data(), ss.data(), lw.data(), zs.data(), nzs.data(), pps.data(), pih,
-                           betas.data(), gammas.data(), al.data(), res.data());
+                           betas.data(), gammas.data(), al.data(), res.data(), lzs.data(), nlzs.data(), deltas.data());
         for (int k = 0; k < nch; ++k) qvals[k][i] = mul(res[k].v, zh_inv[i % rate]);
       }
     }
@@ -609,12 +753,15 @@ static Proof prove(const Circuit& c, const std::vector<std::vector<u64>>& wire_v
     o.wires = eval_batch(wires_b, zeta);
     o.plonk_zs.assign(zp.begin(), zp.begin() + nch);
     o.plonk_zs_next.assign(zpn.begin(), zpn.begin() + nch);
-    o.partial_products.assign(zp.begin() + nch, zp.end());
+    o.partial_products.assign(zp.begin() + nch, zp.begin() + c.num_zs_pp());
+    o.lookup_zs.assign(zp.begin() + c.num_zs_pp(), zp.end());
+    o.lookup_zs_next.assign(zpn.begin() + c.num_zs_pp(), zpn.end());
     o.quotient_polys = eval_batch(quot_b, zeta);
     // challenger.observe_openings(to_fri_openings): batch 0 then batch 1
-    for (auto* v : {&o.constants, &o.plonk_sigmas, &o.wires, &o.plonk_zs, &o.partial_products, &o.quotient_polys})
+    for (auto* v : {&o.constants, &o.plonk_sigmas, &o.wires, &o.plonk_zs, &o.partial_products, &o.quotient_polys, &o.lookup_zs})
       for (Ext e : *v) ch.observe_ext(e);
-    for (Ext e : o.plonk_zs_next) ch.observe_ext(e);
+    for (auto* v : {&o.plonk_zs_next, &o.lookup_zs_next})
+      for (Ext e : *v) ch.observe_ext(e);
   }
   if (tm) tm->openings = now_s() - t0, t0 = now_s();
   proof.wires_cap = wires_b.tree.cap();
@@ -627,11 +774,18 @@ static Proof prove(const Circuit& c, const std::vector<std::vector<u64>>& wire_v
   for (int batch = 0; batch < 2; ++batch) {
     // batch 0: all polys of oracles 0..3 at zeta; batch 1: the Z polys (oracle 2, first nch) at g*zeta
     std::vector<const std::vector<u64>*> polys;
+    // circuit_data.rs::get_fri_instance: fri_all_polys = [preprocessed, wires, zs + partial products, quotient, lookup polys];
+    // fri_next_batch_polys = [zs, lookup polys] — the lookup polynomials are the TAIL of the zs_partial_products oracle
+    const size_t zs_pp = (size_t)c.num_zs_pp();
     if (batch == 0) {
-      for (int o = 0; o < 4; ++o)
-        for (size_t k = 0; k < oracles[o]->ncols; ++k) polys.push_back(&oracles[o]->coeffs[k]);
+      for (size_t k = 0; k < oracles[0]->ncols; ++k) polys.push_back(&oracles[0]->coeffs[k]);
+      for (size_t k = 0; k < oracles[1]->ncols; ++k) polys.push_back(&oracles[1]->coeffs[k]);
+      for (size_t k = 0; k < zs_pp; ++k) polys.push_back(&zs_b.coeffs[k]);
+      for (size_t k = 0; k < oracles[3]->ncols; ++k) polys.push_back(&oracles[3]->coeffs[k]);
+      for (size_t k = zs_pp; k < zs_b.ncols; ++k) polys.push_back(&zs_b.coeffs[k]);
     } else {
       for (int k = 0; k < nch; ++k) polys.push_back(&zs_b.coeffs[k]);
+      for (size_t k = zs_pp; k < zs_b.ncols; ++k) polys.push_back(&zs_b.coeffs[k]);
     }
     Ext point = batch == 0 ? zeta : gzeta;
     // alpha.reduce_polys_base: sum_j alpha^j f_j
@@ -788,7 +942,8 @@ static std::string verify(const Circuit& c, const Proof& p) {
   const OpeningSet& o = p.openings;
   if ((int)o.constants.size() != c.num_constants || (int)o.plonk_sigmas.size() != c.num_routed_wires ||
       (int)o.wires.size() != c.num_wires || (int)o.plonk_zs.size() != nch || (int)o.plonk_zs_next.size() != nch ||
-      (int)o.partial_products.size() != nch * npp || (int)o.quotient_polys.size() != nch * qdf)
+      (int)o.partial_products.size() != nch * npp || (int)o.quotient_polys.size() != nch * qdf ||
+      (int)o.lookup_zs.size() != nch * c.num_lookup_polys() || o.lookup_zs_next.size() != o.lookup_zs.size())
     return "opening set has the wrong shape";
   if (p.public_inputs.size() != c.public_inputs.size()) return "wrong number of public inputs";
   Hash pih = hash_no_pad(p.public_inputs.data(), p.public_inputs.size());
@@ -800,13 +955,20 @@ static std::string verify(const Circuit& c, const Proof& p) {
   std::vector<u64> betas(nch), gammas(nch), alphas(nch);
   for (int i = 0; i < nch; ++i) betas[i] = ch.get_challenge();
   for (int i = 0; i < nch; ++i) gammas[i] = ch.get_challenge();
+  std::vector<u64> deltas;
+  if (c.has_lookup()) {
+    deltas = betas;
+    deltas.insert(deltas.end(), gammas.begin(), gammas.end());
+    for (int i = 0; i < 2 * nch; ++i) deltas.push_back(ch.get_challenge());
+  }
   ch.observe_cap(p.zs_pp_cap);
   for (int i = 0; i < nch; ++i) alphas[i] = ch.get_challenge();
   ch.observe_cap(p.quotient_cap);
   Ext zeta = ch.get_extension_challenge();
-  for (auto* v : {&o.constants, &o.plonk_sigmas, &o.wires, &o.plonk_zs, &o.partial_products, &o.quotient_polys})
+  for (auto* v : {&o.constants, &o.plonk_sigmas, &o.wires, &o.plonk_zs, &o.partial_products, &o.quotient_polys, &o.lookup_zs})
     for (Ext e : *v) ch.observe_ext(e);
-  for (Ext e : o.plonk_zs_next) ch.observe_ext(e);
+  for (auto* v : {&o.plonk_zs_next, &o.lookup_zs_next})
+    for (Ext e : *v) ch.observe_ext(e);
   Ext fri_alpha = ch.get_extension_challenge();
   if (p.fri.commit_phase_caps.size() != c.reduction_arity_bits.size()) return "wrong number of FRI commit-phase caps";
   std::vector<Ext> fri_betas;
@@ -831,7 +993,7 @@ static std::string verify(const Circuit& c, const Proof& p) {
     for (int i = 0; i < nch; ++i) al[i] = Ext(alphas[i]);
     eval_vanishing<Ext>(c, zeta, l0, o.constants.data(), o.plonk_sigmas.data(), o.wires.data(), o.plonk_zs.data(),
                         o.plonk_zs_next.data(), o.partial_products.data(), pih, betas.data(), gammas.data(), al.data(),
-                        res.data());
+                        res.data(), o.lookup_zs.data(), o.lookup_zs_next.data(), deltas.data());
     for (int i = 0; i < nch; ++i) {
       Ext acc;  // reduce_with_powers(chunk, zeta^n)
       for (int k = qdf; k-- > 0;) acc = acc * zeta_pow_n + o.quotient_polys[i * qdf + k];
@@ -848,9 +1010,10 @@ static std::string verify(const Circuit& c, const Proof& p) {
   Ext g = Ext(root_of_unity(lg));
   Ext points[2] = {zeta, zeta * g};
   std::vector<Ext> batch_vals[2];
-  for (auto* v : {&o.constants, &o.plonk_sigmas, &o.wires, &o.plonk_zs, &o.partial_products, &o.quotient_polys})
+  for (auto* v : {&o.constants, &o.plonk_sigmas, &o.wires, &o.plonk_zs, &o.partial_products, &o.quotient_polys, &o.lookup_zs})
     batch_vals[0].insert(batch_vals[0].end(), v->begin(), v->end());
   batch_vals[1] = o.plonk_zs_next;
+  batch_vals[1].insert(batch_vals[1].end(), o.lookup_zs_next.begin(), o.lookup_zs_next.end());
   Ext reduced_openings[2];
   for (int b = 0; b < 2; ++b) {
     Ext acc;
@@ -858,7 +1021,8 @@ static std::string verify(const Circuit& c, const Proof& p) {
     reduced_openings[b] = acc;
   }
   const std::vector<Hash>* caps[4] = {&c.constants_sigmas.tree.cap(), &p.wires_cap, &p.zs_pp_cap, &p.quotient_cap};
-  const size_t widths[4] = {(size_t)c.num_preprocessed(), (size_t)c.num_wires, (size_t)c.num_zs_pp(), (size_t)c.num_quotient()};
+  const size_t widths[4] = {(size_t)c.num_preprocessed(), (size_t)c.num_wires, (size_t)c.num_zs_pp_lookup(), (size_t)c.num_quotient()};
+  const size_t zs_pp = (size_t)c.num_zs_pp();
   u64 wN = root_of_unity(LG);
   for (int q = 0; q < c.num_query_rounds; ++q) {
     const FriQueryRound& qr = p.fri.query_rounds[q];
@@ -874,10 +1038,17 @@ static std::string verify(const Circuit& c, const Proof& p) {
     Ext sum;
     for (int b = 0; b < 2; ++b) {
       std::vector<u64> ev;
-      if (b == 0)
-        for (int t = 0; t < 4; ++t) ev.insert(ev.end(), qr.initial.evals[t].begin(), qr.initial.evals[t].end());
-      else
-        ev.assign(qr.initial.evals[2].begin(), qr.initial.evals[2].begin() + nch);
+      const std::vector<u64>& zl = qr.initial.evals[2];  // [zs, partial products, lookup polys]
+      if (b == 0) {
+        ev.insert(ev.end(), qr.initial.evals[0].begin(), qr.initial.evals[0].end());
+        ev.insert(ev.end(), qr.initial.evals[1].begin(), qr.initial.evals[1].end());
+        ev.insert(ev.end(), zl.begin(), zl.begin() + zs_pp);
+        ev.insert(ev.end(), qr.initial.evals[3].begin(), qr.initial.evals[3].end());
+        ev.insert(ev.end(), zl.begin() + zs_pp, zl.end());
+      } else {
+        ev.assign(zl.begin(), zl.begin() + nch);
+        ev.insert(ev.end(), zl.begin() + zs_pp, zl.end());
+      }
       Ext red;
       for (size_t i = ev.size(); i-- > 0;) red = red * fri_alpha + Ext(ev[i]);
       Ext numer = red - reduced_openings[b];
@@ -974,9 +1145,11 @@ static bool deserialize_proof(const Circuit& c, const uint8_t* bytes, size_t len
   o.plonk_zs_next = r.extvec(nch);
   o.partial_products = r.extvec((size_t)nch * c.num_partial_products());
   o.quotient_polys = r.extvec(c.num_quotient());
+  o.lookup_zs = r.extvec((size_t)nch * c.num_lookup_polys());
+  o.lookup_zs_next = r.extvec((size_t)nch * c.num_lookup_polys());
   p.fri.commit_phase_caps.clear();
   for (size_t i = 0; i < c.reduction_arity_bits.size(); ++i) p.fri.commit_phase_caps.push_back(r.cap(c.cap_height));
-  const size_t widths[4] = {(size_t)c.num_preprocessed(), (size_t)c.num_wires, (size_t)c.num_zs_pp(), (size_t)c.num_quotient()};
+  const size_t widths[4] = {(size_t)c.num_preprocessed(), (size_t)c.num_wires, (size_t)c.num_zs_pp_lookup(), (size_t)c.num_quotient()};
   p.fri.query_rounds.clear();
   for (int q = 0; q < c.num_query_rounds && r.ok; ++q) {
     FriQueryRound qr;

@@ -53,11 +53,30 @@ static inline std::string desc_check(const vx_circuit_desc* d, bool need_preproc
   for (int i = 0; i < d->num_public_inputs; ++i)
     if ((uint64_t)d->pi_rows[i] >= ((uint64_t)1 << d->degree_bits) || (int64_t)d->pi_cols[i] >= d->num_wires) return bad("public input target out of range", i);
   if (d->programs_len < 0 || (d->programs_len && !d->programs)) return bad("bad programs_len", d->programs_len);
-  const int gate_consts = d->num_constants - d->num_selectors;  // constants a gate may read: local_constants[num_selectors + q]
+  // lookup argument: sizes first, the gate constants start after BOTH kinds of selectors
+  if (d->num_luts < 0 || d->num_luts > 64) return bad("num_luts unsupported", d->num_luts);
+  const int nls = d->num_luts > 0 ? d->num_lookup_selectors : 0;
+  if (d->num_luts > 0) {
+    if (d->num_lookup_selectors != 4 + d->num_luts) return bad("num_lookup_selectors must be 4 + num_luts (TransSre, TransLdc, InitSre, LastLdc + one per table)", d->num_lookup_selectors);
+    if (!d->lut_lens || !d->lut_inputs || !d->lut_outputs || !d->lookup_rows) return "circuit: NULL lookup table data";
+    if (d->num_selectors + nls > d->num_constants) return bad("lookup selectors exceed num_constants", nls);
+    if (d->num_routed_wires < 6 || d->quotient_degree_factor < 2) return "circuit: lookups need >= 6 routed wires and quotient_degree_factor >= 2";
+    const long long nrows = (long long)1 << d->degree_bits;
+    for (int t = 0; t < d->num_luts; ++t) {
+      if (d->lut_lens[t] < 1 || d->lut_lens[t] > (1 << 20)) return bad("bad lookup table length", d->lut_lens[t]);
+      const long long lu = d->lookup_rows[3 * t], lut = d->lookup_rows[3 * t + 1], first = d->lookup_rows[3 * t + 2];
+      if (lu < 0 || lu > lut || lut > first || first + 1 >= nrows) return bad("lookup rows out of order / out of range (need last_lu <= last_lut <= first_lut < n - 1)", t);
+      if ((first - lut + 1) * (long long)(d->num_routed_wires / 3) < d->lut_lens[t]) return bad("lookup table does not fit its LookupTableGate rows", t);
+    }
+  } else if (d->num_lookup_selectors != 0) return bad("lookup selectors without lookup tables", d->num_lookup_selectors);
+  const int gate_consts = d->num_constants - d->num_selectors - nls;  // constants a gate may read: local_constants[num_selectors + num_lookup_selectors + q]
   int nprog = 0;
   for (int g = 0; g < d->num_gates; ++g) {
     const int t = d->gate_types[g], prm = d->gate_params[g];
-    if (t < VX_GATE_NOOP || t > VX_GATE_PROGRAM) return bad("gate type is not in the supported set", t);
+    if (t < VX_GATE_NOOP || t > VX_GATE_LOOKUP_TABLE) return bad("gate type is not in the supported set", t);
+    if ((t == VX_GATE_LOOKUP || t == VX_GATE_LOOKUP_TABLE) && d->num_luts < 1) return bad("lookup gate without a lookup table", g);
+    if (t == VX_GATE_LOOKUP && prm != d->num_routed_wires / 2) return bad("LookupGate num_slots must be num_routed_wires / 2", prm);
+    if (t == VX_GATE_LOOKUP_TABLE && prm != d->num_routed_wires / 3) return bad("LookupTableGate num_slots must be num_routed_wires / 3", prm);
     if (d->selector_indices[g] < 0 || d->selector_indices[g] >= d->num_selectors) return bad("bad selector index of gate", g);
     if (d->group_starts[g] < 0 || d->group_starts[g] > g || d->group_ends[g] <= g || d->group_ends[g] > d->num_gates) return bad("gate outside its selector group [start, end)", g);
     if (t == VX_GATE_CONSTANT && (prm < 0 || prm > gate_consts || prm > d->num_wires)) return bad("ConstantGate num_consts exceeds the constants / wires", prm);

@@ -29,6 +29,13 @@ struct vx_circuit {
   u64* sigmas = nullptr;   // [nr][n] sigma VALUES on H (natural order) for the permutation argument
   u64* k_is = nullptr;     // device copy
   vxh::Hash4 digest;
+  // lookup argument (host copies of CommonCircuitData::luts / ProverOnlyCircuitData::lookup_rows); num_luts = 0: none
+  int num_luts = 0, num_lookup_selectors = 0;
+  std::vector<int32_t> lut_lens, lookup_rows;
+  std::vector<uint16_t> lut_inputs, lut_outputs;
+  int num_sldc() const { return (nr / 2 + (qdf - 1) - 1) / (qdf - 1); }
+  int nlp() const { return num_luts > 0 ? 1 + num_sldc() : 0; }   // lookup polynomials per challenge: RE + partial Sum/LDCs
+  int const_base() const { return num_selectors + num_lookup_selectors; }
   int npp() const { return (nr + qdf - 1) / qdf - 1; }
   size_t n() const { return (size_t)1 << degree_bits; }
 };
@@ -93,6 +100,16 @@ static int circuit_create(vx_ctx* c, const vx_circuit_desc* d, vx_circuit** out)
   k->num_selectors = d->num_selectors;
   k->num_constants = d->num_constants;
   k->arity_bits = res.arity_bits;  // the caller's FriParams::reduction_arity_bits, or ConstantArityBits(4, 5)
+  if (d->num_luts > 0) {
+    k->num_luts = d->num_luts;
+    k->num_lookup_selectors = d->num_lookup_selectors;
+    size_t total = 0;
+    for (int t = 0; t < d->num_luts; ++t) total += (size_t)d->lut_lens[t];
+    k->lut_lens.assign(d->lut_lens, d->lut_lens + d->num_luts);
+    k->lookup_rows.assign(d->lookup_rows, d->lookup_rows + 3 * d->num_luts);
+    k->lut_inputs.assign(d->lut_inputs, d->lut_inputs + total);
+    k->lut_outputs.assign(d->lut_outputs, d->lut_outputs + total);
+  }
   for (int g = 0; g < d->num_gates; ++g)
     k->gates.push_back(GateDev{d->gate_types[g], d->gate_params[g], d->selector_indices[g], d->group_starts[g], d->group_ends[g]});
   {

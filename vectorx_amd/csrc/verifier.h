@@ -103,7 +103,14 @@ struct CircuitV {
   const u64* k_is;
   const u64* cs_cap;  // [2^cap_height][4]
   vxh::Hash4 digest;
+  // lookup argument (vanishing_poly.rs check_lookup_constraints); num_luts = 0: none
+  int num_luts = 0, num_lookup_selectors = 0;
+  const int32_t* lut_lens = nullptr;
+  const uint16_t *lut_inputs = nullptr, *lut_outputs = nullptr;
   int npp() const { return (num_routed + qdf - 1) / qdf - 1; }
+  int num_sldc() const { return (num_routed / 2 + (qdf - 1) - 1) / (qdf - 1); }
+  int num_lookup_polys() const { return num_luts > 0 ? 1 + num_sldc() : 0; }
+  int gate_const_base() const { return num_selectors + num_lookup_selectors; }
 };
 
 static const u64 MDS_C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
@@ -127,6 +134,8 @@ static bool eval_gate(const GateV& g, const E* consts, const E* w, const vxh::Ha
   out.clear();
   switch (g.type) {
     case VX_GATE_NOOP: return true;
+    case VX_GATE_LOOKUP: return true;        // gates/lookup.rs, lookup_table.rs: no gate constraints — the lookup
+    case VX_GATE_LOOKUP_TABLE: return true;  // argument lives in the vanishing polynomial (lookup_terms below)
     case VX_GATE_CONSTANT:
       for (int i = 0; i < g.param; ++i) out.push_back(consts[i] - w[i]);
       return true;
@@ -193,18 +202,66 @@ static bool eval_gate(const GateV& g, const E* consts, const E* w, const vxh::Ha
   return false;
 }
 
+// vanishing_poly.rs::check_lookup_constraints at an extension point for ONE challenge: lookup selectors sel[0..4 + num_luts)
+// = TransSre, TransLdc, InitSre, LastLdc, one "ends" selector per table; zs / zs_next = [RE, SLDC_0 ..]; d = [a, b, alpha, delta].
+static void lookup_terms(const CircuitV& c, const E* sel, const E* w, const E* zs, const E* zs_next, const u64* d, std::vector<E>& out) {
+  const int lu_slots = c.num_routed / 2, lut_slots = c.num_routed / 3, lu_deg = c.qdf - 1, nsl = c.num_sldc(), lut_deg = (lut_slots + nsl - 1) / nsl;
+  const E* zx = zs + 1;
+  const E* zgx = zs_next + 1;
+  std::vector<E> looking(lu_slots), looked(lut_slots), looked_re(lut_slots);
+  for (int i = 0; i < lu_slots; ++i) looking[i] = w[2 * i] + scale(w[2 * i + 1], d[0]);
+  for (int i = 0; i < lut_slots; ++i) looked[i] = w[3 * i] + scale(w[3 * i + 1], d[0]), looked_re[i] = w[3 * i] + scale(w[3 * i + 1], d[1]);
+  out.push_back(sel[3] * zx[nsl - 1]);
+  out.push_back(sel[2] * zx[0]);
+  out.push_back(sel[2] * zs[0]);
+  size_t off = 0;
+  for (int t = 0; t < c.num_luts; ++t) {  // get_lut_poly: sum_k (inp_k + b out_k) delta^(degree - 1 - k), zero-padded to whole rows
+    const size_t len = (size_t)c.lut_lens[t], degree = (len + lut_slots - 1) / lut_slots * lut_slots;
+    u64 acc = 0;
+    for (size_t k = 0; k < degree; ++k) {
+      const u64 coeff = k < len ? vxh::add((u64)c.lut_inputs[off + k], vxh::mul(d[1], (u64)c.lut_outputs[off + k])) : 0;
+      acc = vxh::add(vxh::mul(acc, d[3]), coeff);
+    }
+    off += len;
+    out.push_back(sel[4 + t] * (zs[0] - E(acc)));
+  }
+  {
+    E cur = zs_next[0];
+    for (int i = 0; i < lut_slots; ++i) cur = scale(cur, d[3]) + looked_re[i];
+    out.push_back(sel[0] * (zs[0] - cur));
+  }
+  const E alpha(d[2]);
+  for (int p = 0; p < nsl; ++p) {
+    const int t0 = p * lut_deg, t1 = std::min((p + 1) * lut_deg, lut_slots), u0 = p * lu_deg, u1 = std::min((p + 1) * lu_deg, lu_slots);
+    auto prod_except = [&](const std::vector<E>& v, int lo, int hi, int skip) {
+      E acc(1);
+      for (int j = lo; j < hi; ++j)
+        if (j != skip) acc = acc * (alpha - v[j]);
+      return acc;
+    };
+    E lu_sum, lut_sum;
+    for (int i = u0; i < u1; ++i) lu_sum = lu_sum + prod_except(looking, u0, u1, i);
+    for (int i = t0; i < t1; ++i) lut_sum = lut_sum + w[3 * i + 2] * prod_except(looked, t0, t1, i);
+    const E prev = p == 0 ? zgx[nsl - 1] : zx[p - 1];
+    out.push_back(sel[0] * (prod_except(looked, t0, t1, -1) * (zx[p] - prev) - lut_sum));
+    out.push_back(sel[1] * (prod_except(looking, u0, u1, -1) * (zx[p] - prev) + lu_sum));
+  }
+}
+
 // Returns "" when the proof is valid, else the reason.
 static std::string verify(const CircuitV& c, const uint8_t* bytes, size_t len) {
   const int lg = c.degree_bits, rb = c.rate_bits, LG = lg + rb, nch = c.num_challenges, npp = c.npp(), qdf = c.qdf;
   const size_t n = (size_t)1 << lg, N = (size_t)1 << LG, cap_len = (size_t)1 << c.cap_height, R = c.arity_bits.size();
-  const size_t widths[4] = {(size_t)c.num_constants + c.num_routed, (size_t)c.num_wires, (size_t)nch * (1 + npp), (size_t)nch * qdf};
+  const int nlp = c.num_lookup_polys();
+  const size_t zs_pp = (size_t)nch * (1 + npp);
+  const size_t widths[4] = {(size_t)c.num_constants + c.num_routed, (size_t)c.num_wires, zs_pp + (size_t)nch * nlp, (size_t)nch * qdf};
   Reader r{bytes, len};
   // ---- parse (read_proof_with_public_inputs; every length is implied by the circuit) ----
   std::vector<u64> wires_cap, zs_cap, quot_cap;
   r.words(wires_cap, 4 * cap_len);
   r.words(zs_cap, 4 * cap_len);
   r.words(quot_cap, 4 * cap_len);
-  std::vector<E> o_const, o_sigma, o_wires, o_zs, o_zs_next, o_pp, o_quot;
+  std::vector<E> o_const, o_sigma, o_wires, o_zs, o_zs_next, o_pp, o_quot, o_lzs, o_lzs_next;
   r.exts(o_const, c.num_constants);
   r.exts(o_sigma, c.num_routed);
   r.exts(o_wires, c.num_wires);
@@ -212,6 +269,8 @@ static std::string verify(const CircuitV& c, const uint8_t* bytes, size_t len) {
   r.exts(o_zs_next, nch);
   r.exts(o_pp, (size_t)nch * npp);
   r.exts(o_quot, (size_t)nch * qdf);
+  r.exts(o_lzs, (size_t)nch * nlp);
+  r.exts(o_lzs_next, (size_t)nch * nlp);
   std::vector<std::vector<u64>> commit_caps(R);
   for (auto& cp : commit_caps) r.words(cp, 4 * cap_len);
   struct Query {
@@ -251,13 +310,20 @@ static std::string verify(const CircuitV& c, const uint8_t* bytes, size_t len) {
   std::vector<u64> betas(nch), gammas(nch), alphas(nch);
   for (auto& v : betas) v = ch.get_challenge();
   for (auto& v : gammas) v = ch.get_challenge();
+  std::vector<u64> deltas;  // lookup challenges: 4 per challenge; the first 2 nch of them are the betas and gammas
+  if (c.num_luts > 0) {
+    deltas = betas;
+    deltas.insert(deltas.end(), gammas.begin(), gammas.end());
+    for (int i = 0; i < 2 * nch; ++i) deltas.push_back(ch.get_challenge());
+  }
   ch.observe_elements(zs_cap.data(), zs_cap.size());
   for (auto& v : alphas) v = ch.get_challenge();
   ch.observe_elements(quot_cap.data(), quot_cap.size());
   const E zeta = ch.get_extension_challenge();
-  for (auto* v : {&o_const, &o_sigma, &o_wires, &o_zs, &o_pp, &o_quot})
+  for (auto* v : {&o_const, &o_sigma, &o_wires, &o_zs, &o_pp, &o_quot, &o_lzs})
     for (E e : *v) ch.observe_ext(e.x());
-  for (E e : o_zs_next) ch.observe_ext(e.x());
+  for (auto* v : {&o_zs_next, &o_lzs_next})
+    for (E e : *v) ch.observe_ext(e.x());
   const E fri_alpha = ch.get_extension_challenge();
   std::vector<E> fri_betas;
   for (auto& cp : commit_caps) {
@@ -293,6 +359,9 @@ static std::string verify(const CircuitV& c, const uint8_t* bytes, size_t len) {
         terms.push_back(accs[chunk] * np - accs[chunk + 1] * dp);
       }
     }
+    for (int k = 0; k < nch && c.num_luts > 0; ++k)
+      lookup_terms(c, o_const.data() + c.num_selectors, o_wires.data(), o_lzs.data() + (size_t)k * nlp, o_lzs_next.data() + (size_t)k * nlp,
+                   deltas.data() + 4 * k, terms);
     std::vector<E> gate_terms, tmp;
     for (size_t gi = 0; gi < c.gates.size(); ++gi) {
       const GateV& g = c.gates[gi];
@@ -301,7 +370,7 @@ static std::string verify(const CircuitV& c, const uint8_t* bytes, size_t len) {
       for (int q = g.group_start; q < g.group_end; ++q)
         if (q != (int)gi) filter = filter * (E((u64)q) - s);
       if (c.num_selectors > 1) filter = filter * (E(0xFFFFFFFFULL) - s);
-      if (!eval_gate(g, o_const.data() + c.num_selectors, o_wires.data(), pih, tmp)) return "a gate could not be evaluated";
+      if (!eval_gate(g, o_const.data() + c.gate_const_base(), o_wires.data(), pih, tmp)) return "a gate could not be evaluated";
       if (tmp.size() > gate_terms.size()) gate_terms.resize(tmp.size());
       for (size_t i = 0; i < tmp.size(); ++i) gate_terms[i] = gate_terms[i] + filter * tmp[i];
     }
@@ -320,9 +389,11 @@ static std::string verify(const CircuitV& c, const uint8_t* bytes, size_t len) {
   E reduced[2];
   {
     std::vector<E> b0;
-    for (auto* v : {&o_const, &o_sigma, &o_wires, &o_zs, &o_pp, &o_quot}) b0.insert(b0.end(), v->begin(), v->end());
+    for (auto* v : {&o_const, &o_sigma, &o_wires, &o_zs, &o_pp, &o_quot, &o_lzs}) b0.insert(b0.end(), v->begin(), v->end());
     for (size_t i = b0.size(); i-- > 0;) reduced[0] = reduced[0] * fri_alpha + b0[i];
-    for (size_t i = o_zs_next.size(); i-- > 0;) reduced[1] = reduced[1] * fri_alpha + o_zs_next[i];
+    std::vector<E> b1(o_zs_next);
+    b1.insert(b1.end(), o_lzs_next.begin(), o_lzs_next.end());
+    for (size_t i = b1.size(); i-- > 0;) reduced[1] = reduced[1] * fri_alpha + b1[i];
   }
   const u64* caps[4] = {c.cs_cap, wires_cap.data(), zs_cap.data(), quot_cap.data()};
   const u64 wN = vxh::root_of_unity(LG);
@@ -338,10 +409,17 @@ static std::string verify(const CircuitV& c, const uint8_t* bytes, size_t len) {
     E sum;
     for (int b = 0; b < 2; ++b) {
       std::vector<u64> ev;
-      if (b == 0)
-        for (int t = 0; t < 4; ++t) ev.insert(ev.end(), q.leaf[t].begin(), q.leaf[t].end());
-      else
-        ev.assign(q.leaf[2].begin(), q.leaf[2].begin() + nch);
+      const std::vector<u64>& zl = q.leaf[2];  // [zs, partial products | lookup polys]: the lookup tail is opened AFTER the quotient
+      if (b == 0) {
+        ev.insert(ev.end(), q.leaf[0].begin(), q.leaf[0].end());
+        ev.insert(ev.end(), q.leaf[1].begin(), q.leaf[1].end());
+        ev.insert(ev.end(), zl.begin(), zl.begin() + zs_pp);
+        ev.insert(ev.end(), q.leaf[3].begin(), q.leaf[3].end());
+        ev.insert(ev.end(), zl.begin() + zs_pp, zl.end());
+      } else {
+        ev.assign(zl.begin(), zl.begin() + nch);
+        ev.insert(ev.end(), zl.begin() + zs_pp, zl.end());
+      }
       E red;
       for (size_t i = ev.size(); i-- > 0;) red = red * fri_alpha + E(ev[i]);
       sum = sum * E(vxh::epow(fri_alpha.x(), ev.size())) + (red - reduced[b]) * inv(E(sx) - points[b]);

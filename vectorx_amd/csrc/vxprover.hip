@@ -674,6 +674,8 @@ int vx_verify(vx_circuit* k, const uint8_t* proof, size_t proof_len) {
     v.gates.push_back(vxv::GateV{k->gates[g].type, k->gates[g].param, k->gates[g].selector_index, k->gates[g].group_start,
                                  k->gates[g].group_end, k->prog_off[g] >= 0 ? k->programs_host.data() + k->prog_off[g] : nullptr});
   v.arity_bits = k->arity_bits;
+  v.num_luts = k->num_luts, v.num_lookup_selectors = k->num_lookup_selectors;
+  v.lut_lens = k->lut_lens.data(), v.lut_inputs = k->lut_inputs.data(), v.lut_outputs = k->lut_outputs.data();
   v.k_is = k->k_is_host.data();
   v.cs_cap = k->cs_cap_host.data();
   v.digest = k->digest;
@@ -712,6 +714,10 @@ int vx_verify_standalone(const vx_circuit_desc* d, const uint64_t* cs_cap, const
       v.gates.push_back(vxv::GateV{d->gate_types[g], d->gate_params[g], d->selector_indices[g], d->group_starts[g], d->group_ends[g],
                                    d->gate_types[g] == VX_GATE_PROGRAM ? d->programs + d->program_offsets[g] : nullptr});
     v.arity_bits = res.arity_bits;
+    if (d->num_luts > 0) {
+      v.num_luts = d->num_luts, v.num_lookup_selectors = d->num_lookup_selectors;
+      v.lut_lens = d->lut_lens, v.lut_inputs = d->lut_inputs, v.lut_outputs = d->lut_outputs;
+    }
     std::vector<u64> k_is(d->k_is, d->k_is + d->num_routed_wires);
     for (auto& x : k_is) x = vxh::canon(x);
     v.k_is = k_is.data();

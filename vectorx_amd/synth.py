@@ -30,6 +30,9 @@ class CircuitDesc(ctypes.Structure):
         ("override_flags", ctypes.c_uint32), ("hiding", ctypes.c_int32), ("circuit_digest", ctypes.c_uint64 * 4),
         ("num_fri_reduction_arity_bits", ctypes.c_int32), ("num_partial_products", ctypes.c_int32),
         ("fri_reduction_arity_bits", ctypes.c_void_p),
+        # lookup argument (zero tail = none)
+        ("num_luts", ctypes.c_int32), ("num_lookup_selectors", ctypes.c_int32), ("lut_lens", ctypes.c_void_p),
+        ("lut_inputs", ctypes.c_void_p), ("lut_outputs", ctypes.c_void_p), ("lookup_rows", ctypes.c_void_p),
     ]
 
 
@@ -41,6 +44,7 @@ DESC_HAS_NUM_PARTIAL_PRODUCTS = 4
 FLAG_PROGRAM_GATES = 1      # add ArithmeticExtensionGate + BaseSumGate rows, evaluated through constraint programs
 FLAG_ARITH_AS_PROGRAM = 2   # hand the ArithmeticGate to the prover as a constraint program instead of the native gate
 FLAG_MORE_PROGRAM_GATES = 4  # + ExponentiationGate (degree 4) and RandomAccessGate (degree 5) as programs: 3 selector groups
+FLAG_LOOKUP = 16             # + one lookup table (LookupTableGate rows) and LookupGate rows looking values up in it
 FLAG_RECURSION_GATES = 8     # + MulExtension, Reducing, ReducingExtension, PoseidonMds, CosetInterpolation{4 bits, degree 8} as programs
 
 

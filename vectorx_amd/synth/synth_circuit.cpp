@@ -34,6 +34,7 @@ using namespace vxh;
 #define VXS_FLAG_PROGRAM_GATES 1     /* add ArithmeticExtensionGate + BaseSumGate rows, evaluated through constraint programs */
 #define VXS_FLAG_ARITH_AS_PROGRAM 2  /* hand the ArithmeticGate to the prover as a program instead of the native gate */
 #define VXS_FLAG_MORE_PROGRAM_GATES 4 /* + ExponentiationGate{66 bits} (degree 4) and RandomAccessGate{bits 4} (degree 5): 3 selector groups */
+#define VXS_FLAG_LOOKUP 16            /* + one lookup table: LookupTableGate rows holding it, LookupGate rows looking values up (gates/lookup*.rs) */
 #define VXS_FLAG_RECURSION_GATES 8    /* + the rest of the recursive verifier's gate set as programs: MulExtensionGate, ReducingGate,
                                          ReducingExtensionGate, PoseidonMdsGate, CosetInterpolationGate{4 bits, degree 8} */
 
@@ -55,7 +56,7 @@ struct SplitMix {
 };
 
 enum Key { K_NOOP, K_CONST, K_PI, K_ARITH, K_POSEIDON, K_ARITHEXT, K_BASESUM, K_EXP, K_RANDACC, K_MULEXT, K_REDUCING, K_REDUCINGEXT,
-           K_POSEIDONMDS, K_COSETINTERP, K_COUNT };
+           K_POSEIDONMDS, K_COSETINTERP, K_LOOKUP, K_LOOKUPTABLE, K_COUNT };
 struct GateInfo {
   int key, type, param, degree;
   std::string id;
@@ -72,6 +73,9 @@ struct Synth {
   std::vector<u64> witness;  // [135][n]
   std::vector<u64> public_inputs;
   size_t n_poseidon = 0, n_arith = 0, n_noop = 0, n_arithext = 0, n_basesum = 0, n_exp = 0, n_randacc = 0, n_recursion = 0;
+  size_t n_lookup = 0, n_lookup_table = 0;
+  std::vector<int32_t> lut_lens, lookup_rows;
+  std::vector<uint16_t> lut_inputs, lut_outputs;
   vx_circuit_desc desc;
 };
 
@@ -475,7 +479,8 @@ vxs_circuit* vxs_build3(int degree_bits, uint64_t seed, int poseidon_percent, ui
   if (degree_bits < 3 || degree_bits > 24 || poseidon_percent < 0 || poseidon_percent > 100) return nullptr;
   const bool with_prog = flags & VXS_FLAG_PROGRAM_GATES, arith_prog = flags & VXS_FLAG_ARITH_AS_PROGRAM;
   const bool more_prog = flags & VXS_FLAG_MORE_PROGRAM_GATES, rec_prog = flags & VXS_FLAG_RECURSION_GATES;
-  if ((with_prog && degree_bits < 4) || (more_prog && degree_bits < 5) || (rec_prog && degree_bits < 5)) return nullptr;
+  const bool with_lookup = flags & VXS_FLAG_LOOKUP;
+  if ((with_prog && degree_bits < 4) || (more_prog && degree_bits < 5) || (rec_prog && degree_bits < 5) || (with_lookup && degree_bits < 5)) return nullptr;
   Synth* S = new Synth();
   S->degree_bits = degree_bits;
   const size_t n = S->n = (size_t)1 << degree_bits;
@@ -506,6 +511,10 @@ vxs_circuit* vxs_build3(int degree_bits, uint64_t seed, int poseidon_percent, ui
     gates.push_back({K_POSEIDONMDS, VX_GATE_PROGRAM, 1, 1, "PoseidonMdsGate(PhantomData<plonky2_field::goldilocks_field::GoldilocksField>)<WIDTH=12>"});
     gates.push_back({K_COSETINTERP, VX_GATE_PROGRAM, 8, 8, "CosetInterpolationGate { subgroup_bits: 4, degree: 8, barycentric_weights: [..], _phantom: PhantomData<plonky2_field::goldilocks_field::GoldilocksField> }<D=2>"});
   }
+  if (with_lookup) {
+    gates.push_back({K_LOOKUP, VX_GATE_LOOKUP, 40, 0, "LookupGate {num_slots: 40, lut_hash: [..]}"});
+    gates.push_back({K_LOOKUPTABLE, VX_GATE_LOOKUP_TABLE, 26, 0, "LookupTableGate {num_slots: 26, lut_hash: [..], last_lut_row: ..}"});
+  }
   std::sort(gates.begin(), gates.end(), [](const GateInfo& a, const GateInfo& b) {
     return a.degree != b.degree ? a.degree < b.degree : a.id < b.id;
   });
@@ -527,7 +536,10 @@ vxs_circuit* vxs_build3(int degree_bits, uint64_t seed, int poseidon_percent, ui
       start += size;
     }
   }
-  const int NSEL = (int)groups.size(), NCONST = NSEL + 2;
+  // with lookups the lookup selectors (TransSre, TransLdc, InitSre, LastLdc + one "ends" selector per table) sit between
+  // the gate selectors and the gate constants (gates/selectors.rs::selectors_lookup, selector_ends_lookups)
+  const int NLS = with_lookup ? 4 + 1 : 0;
+  const int NSEL = (int)groups.size(), NCONST = NSEL + NLS + 2;
   std::vector<int> group_of(ng);
   for (int g = 0; g < ng; ++g)
     for (int q = 0; q < NSEL; ++q)
@@ -568,14 +580,21 @@ vxs_circuit* vxs_build3(int degree_bits, uint64_t seed, int poseidon_percent, ui
   size_t n_ext = with_prog ? std::max<size_t>(1, body / 16) : 0, n_bs = with_prog ? std::max<size_t>(1, body / 16) : 0;
   size_t n_exp = more_prog ? std::max<size_t>(1, body / 32) : 0, n_ra = more_prog ? std::max<size_t>(1, body / 32) : 0;
   size_t n_rec = rec_prog ? std::max<size_t>(1, body / 64) : 0;   // rows of EACH of the five recursion gates
-  while (n_noop + n_ext + n_bs + n_exp + n_ra + 5 * n_rec > body && n_ext + n_exp + (n_rec > 1) > 0) {
+  // lookup argument: a table of L (input, output) pairs in ceil(L / 26) LookupTableGate rows, n_lu LookupGate rows, and the
+  // all-zero NoopGate row that must follow the table (circuit_builder.rs::add_all_lookups)
+  const size_t lut_len = with_lookup ? std::min<size_t>(200, 26 * std::max<size_t>(1, body / 32)) : 0;
+  const size_t n_lut = with_lookup ? (lut_len + 25) / 26 : 0, n_lu = with_lookup ? std::max<size_t>(1, body / 32) : 0;
+  const size_t lookup_total = with_lookup ? n_lu + n_lut + 1 : 0;
+  while (n_noop + n_ext + n_bs + n_exp + n_ra + 5 * n_rec + lookup_total > body && n_ext + n_exp + (n_rec > 1) > 0) {
     if (n_ext) --n_ext, --n_bs;
     if (n_exp) --n_exp, --n_ra;
     if (n_rec > 1) --n_rec;
   }
-  if (n_noop + n_ext + n_bs + n_exp + n_ra + 5 * n_rec > body) { delete S; return nullptr; }
+  if (n_noop + n_ext + n_bs + n_exp + n_ra + 5 * n_rec + lookup_total > body) { delete S; return nullptr; }
   S->n_recursion = n_rec;
-  size_t rest = body - n_noop - n_ext - n_bs - n_exp - n_ra - 5 * n_rec;
+  S->n_lookup = n_lu;
+  S->n_lookup_table = n_lut;
+  size_t rest = body - n_noop - n_ext - n_bs - n_exp - n_ra - 5 * n_rec - lookup_total;
   S->n_exp = n_exp;
   S->n_randacc = n_ra;
   size_t n_pos = rest * (size_t)poseidon_percent / 100;
@@ -589,8 +608,8 @@ vxs_circuit* vxs_build3(int degree_bits, uint64_t seed, int poseidon_percent, ui
   S->witness.assign((size_t)NW * n, 0);
   S->constants_sigmas.assign((size_t)(NCONST + NR) * n, 0);
   u64* w = S->witness.data();
-  u64* c0 = &S->constants_sigmas[(size_t)NSEL * n];
-  u64* c1 = &S->constants_sigmas[(size_t)(NSEL + 1) * n];
+  u64* c0 = &S->constants_sigmas[(size_t)(NSEL + NLS) * n];
+  u64* c1 = &S->constants_sigmas[(size_t)(NSEL + NLS + 1) * n];
   const u64 UNUSED = 0xFFFFFFFFULL;
   auto set_gate = [&](size_t row, int key) {
     const int g = idx_of[key];
@@ -806,6 +825,49 @@ vxs_circuit* vxs_build3(int degree_bits, uint64_t seed, int poseidon_percent, ui
       }
     }
   }
+  if (with_lookup) {
+    // rows [last_lu_row, last_lut_row) = LookupGate, [last_lut_row, first_lut_row] = LookupTableGate, first_lut_row + 1 = Noop (zeros)
+    const size_t last_lu_row = row, last_lut_row = row + n_lu, first_lut_row = last_lut_row + n_lut - 1;
+    for (size_t i = 0; i < lut_len; ++i) {
+      S->lut_inputs.push_back((uint16_t)i);
+      S->lut_outputs.push_back((uint16_t)((i * i * 31 + 7 * i + 3) & 0xFFFF));
+    }
+    S->lut_lens.push_back((int32_t)lut_len);
+    S->lookup_rows = {(int32_t)last_lu_row, (int32_t)last_lut_row, (int32_t)first_lut_row};
+    std::vector<u64> mult(lut_len, 0);
+    for (size_t r = last_lu_row; r < last_lut_row; ++r) {
+      set_gate(r, K_LOOKUP);
+      for (int sl = 0; sl < 40; ++sl) {
+        // the last slots of the last LookupGate row stay "unused": plonky2 fills them with the table's first entry
+        const bool unused = r + 1 == last_lut_row && sl >= 33;
+        const size_t e = unused ? 0 : (size_t)(wrng.next() % lut_len);
+        w[(size_t)(2 * sl) * n + r] = S->lut_inputs[e];
+        w[(size_t)(2 * sl + 1) * n + r] = S->lut_outputs[e];
+        ++mult[e];
+      }
+    }
+    for (size_t r = last_lut_row; r <= first_lut_row; ++r) {
+      set_gate(r, K_LOOKUPTABLE);
+      for (int sl = 0; sl < 26; ++sl) {
+        const size_t e = (first_lut_row - r) * 26 + sl;   // LookupTableGenerator: entries run from first_lut_row downwards
+        if (e < lut_len) {
+          w[(size_t)(3 * sl) * n + r] = S->lut_inputs[e];
+          w[(size_t)(3 * sl + 1) * n + r] = S->lut_outputs[e];
+          w[(size_t)(3 * sl + 2) * n + r] = mult[e];
+        }
+      }
+    }
+    // lookup selectors: TransSre on the table rows, TransLdc on the looking rows, InitSre on the row after the table,
+    // LastLdc on the last looking row; the table's "ends" selector on last_lut_row
+    u64* ls = &S->constants_sigmas[(size_t)NSEL * n];
+    for (size_t r = last_lut_row; r <= first_lut_row; ++r) ls[0 * n + r] = 1;
+    for (size_t r = last_lu_row; r < last_lut_row; ++r) ls[1 * n + r] = 1;
+    ls[2 * n + first_lut_row + 1] = 1;
+    ls[3 * n + last_lu_row] = 1;
+    ls[4 * n + last_lut_row] = 1;
+    row = first_lut_row + 1;
+    set_gate(row++, K_NOOP);
+  }
   for (; row < n; ++row) set_gate(row, K_NOOP);
 
   // k_is = 7^j (plonk_common / circuit_builder: get_unique_coset_shifts)
@@ -869,6 +931,14 @@ vxs_circuit* vxs_build3(int degree_bits, uint64_t seed, int poseidon_percent, ui
   d.programs_len = (int32_t)S->programs.size();
   d.programs = S->programs.empty() ? nullptr : S->programs.data();
   d.program_offsets = S->program_offsets.data();
+  if (with_lookup) {
+    d.num_luts = 1;
+    d.num_lookup_selectors = NLS;
+    d.lut_lens = S->lut_lens.data();
+    d.lut_inputs = S->lut_inputs.data();
+    d.lut_outputs = S->lut_outputs.data();
+    d.lookup_rows = S->lookup_rows.data();
+  }
   return reinterpret_cast<vxs_circuit*>(S);
 }
 
