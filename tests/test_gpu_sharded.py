@@ -242,3 +242,17 @@ def test_bench_two_gpus_under_torchrun(mode):
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["value"] > 0
     assert line["scaling"] == ("strong" if mode == "sharded" else "weak")
+
+
+@pytest.mark.parametrize("degree_bits,world,flags", [(7, 2, 16), (9, 4, 16 | 1), (11, 8, 16)])
+def test_sharded_proof_with_lookup_argument(oracle, degree_bits, world, flags):
+    sc = SynthCircuit(degree_bits, seed=1900 + degree_bits, poseidon_percent=40, flags=flags)
+    sc.desc.pow_bits = 6
+    w = sc.witness()
+    expect = oracle_lib.OracleCircuit(oracle, sc.desc_ptr).prove(w)
+    ctxs, circuits = _rank_circuits(sc, world)
+    try:
+        for p in sharded.prove_sharded_threads(circuits, w):
+            assert p == expect
+    finally:
+        _free(ctxs, circuits)

@@ -167,3 +167,41 @@ def test_malformed_descriptions_are_refused_before_any_read(oracle):
                 assert e.value.code == vx.VX_E_INVALID
             params[g] = old
     vx.verify_standalone(sc.desc_ptr, cap, proof)   # restored description still verifies
+
+
+@pytest.mark.parametrize("degree_bits,flags", [(5, 16), (6, 16 | 1), (8, 16), (9, 16 | 15)])
+def test_lookup_argument_oracle_prover_and_product_verifier_agree(oracle, degree_bits, flags):
+    """Lookup argument (plonky2 v0.2.0 gates/lookup.rs, gates/lookup_table.rs, vanishing_poly.rs::check_lookup_constraints):
+    a circuit with one lookup table + LookupGate rows.  The oracle's prover and verifier and the product's independent
+    verifier agree on the valid proof and on every way of breaking the lookup."""
+    import ctypes
+    from vectorx_amd.synth import FLAG_LOOKUP
+    assert flags & FLAG_LOOKUP
+    sc = SynthCircuit(degree_bits, seed=90 + degree_bits, poseidon_percent=40, flags=flags)
+    sc.desc.pow_bits = 5
+    assert sc.desc.num_luts == 1 and sc.desc.num_lookup_selectors == 5
+    oc = oracle_lib.OracleCircuit(oracle, sc.desc_ptr)
+    cap = oc.cap()
+    w = sc.witness()
+    proof = oc.prove(w)
+    assert oc.verify(proof) == "" and _verdict(sc, cap, proof) == ""
+    last_lu, last_lut, first_lut = (ctypes.c_int32 * 3).from_address(sc.desc.lookup_rows)
+    # (a) a looked-up pair that is not in the table, (b) a wrong multiplicity, (c) a changed table entry: all unprovable
+    for col, row in [(1, last_lu), (3 * 2 + 2, last_lut), (3 * 1 + 1, first_lut)]:
+        bad_w = w.copy()
+        bad_w[col, row] = (int(bad_w[col, row]) + 1) % P
+        bad = oc.prove(bad_w)
+        assert oc.verify(bad) != "" and _verdict(sc, cap, bad) != "", (col, row)
+    # tampering with the lookup openings (they follow the quotient openings) is caught by both verifiers
+    d = sc.desc
+    off_lookup = 3 * (32 << d.cap_height) + 16 * (d.num_constants + 80 + 135 + 2 + 2 + 18 + 16)
+    for off in (off_lookup + 3, off_lookup + 16 * 14 + 9):
+        bad = bytearray(proof)
+        bad[off] ^= 1
+        assert oc.verify(bytes(bad)) != "" and _verdict(sc, cap, bytes(bad)) != ""
+    # the table itself is part of the verifier's data: another table refuses the proof
+    outs = (ctypes.c_uint16 * 1).from_address(d.lut_outputs)
+    outs[0] ^= 1
+    assert _verdict(sc, cap, proof) != ""
+    outs[0] ^= 1
+    assert _verdict(sc, cap, proof) == ""

@@ -34,6 +34,7 @@ struct JitGateParams {  // mirrored textually in jit_source()
   size_t N, rows, row_base, stride_w;
   int log_n, rate_bits, num_selectors, nch;
   int base_idx, ngates;
+  int const_base, pad_;  // first gate constant among the preprocessed columns: num_selectors + num_lookup_selectors
   u64 pih[4];
   u64 zh_inv[VX_MAX_RATE];
   JitGateRt g[VX_MAX_PROGRAM_GATES];
@@ -154,7 +155,7 @@ static void jit_gate_block(std::ostringstream& s, const uint64_t* prog, int nch,
     if (I.skip) continue;
     switch (I.op) {
       case VX_OP_LDW: s << "  R[" << I.dst << "] = gl_canon(W[(size_t)" << I.a << " * SW + il]);\n"; canon_reg[I.dst] = true; break;
-      case VX_OP_LDC: s << "  R[" << I.dst << "] = CS[(size_t)(nsel + " << I.a << ") * N + i];\n"; canon_reg[I.dst] = true; break;
+      case VX_OP_LDC: s << "  R[" << I.dst << "] = CS[(size_t)(cbase + " << I.a << ") * N + i];\n"; canon_reg[I.dst] = true; break;
       case VX_OP_LDI: s << "  R[" << I.dst << "] = " << I.imm << "ULL;\n"; canon_reg[I.dst] = true; break;
       case VX_OP_ADD:
         if (I.fa >= 0) {  // fused multiply-add: any representatives in, one out
@@ -207,6 +208,7 @@ struct JitGateParams {
   size_t N, rows, row_base, stride_w;
   int log_n, rate_bits, num_selectors, nch;
   int base_idx, ngates;
+  int const_base, pad_;
   u64 pih[4];
   u64 zh_inv[16];
   JitGateRt g[32];
@@ -220,7 +222,7 @@ extern "C" __global__ __launch_bounds__(256, VX_JIT_BLOCKS_PER_CU) void vx_progr
   const u64* __restrict__ CS = p.cs;
   const u64* __restrict__ W = p.wires;
   const u64* __restrict__ AP = p.alpha_pows + p.base_idx;
-  const int nsel = p.num_selectors;
+  const int nsel = p.num_selectors, cbase = p.const_base;
   u64 t0 = 0, t1 = 0;
 )VXJIT";
   for (size_t q = 0; q < progs.size(); ++q) jit_gate_block(s, progs[q], nch, (int)q);

@@ -157,6 +157,8 @@ struct QuotientParams {
   int log_n, rate_bits;
   int num_selectors, num_constants, nr, num_wires, nch, npp, deg;
   int num_gates;
+  int const_base;    // first gate constant among the preprocessed columns: num_selectors + num_lookup_selectors
+  int extra_terms;   // constraints that sit between the partial-product checks and the gate constraints (lookup argument)
   GateDev gates[VX_MAX_GATES];
   u64 betas[VX_MAX_CHALLENGES], gammas[VX_MAX_CHALLENGES], alphas[VX_MAX_CHALLENGES];
   u64 pih[4];
@@ -231,10 +233,10 @@ __global__ __launch_bounds__(256, VX_QUOTIENT_BLOCKS) void quotient_kernel(Quoti
     }
   }
   // (3) gate constraints: sum_g filter_g * sum_i c_{g,i} alpha^(i + offset)
-  const int base_idx = A.idx;
+  const int base_idx = A.idx + p.extra_terms;
   for (int g = 0; g < p.num_gates; ++g) {
     const GateDev gd = p.gates[g];
-    if (gd.type == 0 || gd.type == 5) continue;  // NoopGate: no constraints; program gates: program_gates_kernel
+    if (gd.type == 0 || gd.type >= 5) continue;  // NoopGate / lookup gates: no constraints; program gates: program_gates_kernel
     const u64 s = CS(gd.selector_index);
     u64 filter = 1;
     for (int q = gd.group_start; q < gd.group_end; ++q)
@@ -244,7 +246,7 @@ __global__ __launch_bounds__(256, VX_QUOTIENT_BLOCKS) void quotient_kernel(Quoti
 #pragma unroll
     for (int c = 0; c < VX_MAX_CHALLENGES; ++c) G.acc[c] = dot3{0, 0, 0};
     G.idx = base_idx;
-    const int c0 = p.num_selectors;  // gate constants start after the selectors
+    const int c0 = p.const_base;  // gate constants start after the selectors (and the lookup selectors)
     if (gd.type == 1) {              // ConstantGate
       for (int q = 0; q < gd.param; ++q) acc_push(G, p, gl_sub(CS(c0 + q), WIRE(q)));
     } else if (gd.type == 2) {  // PublicInputGate
@@ -380,7 +382,7 @@ __global__ __launch_bounds__(256) void quotient_chunks_kernel(ChunkParams p) {
 // Opening proof: F[pos] = sum_j alpha^j f_j[pos] over a list of column groups (reduce_polys_base).
 // out: 2 columns (a then b), each n.  Column groups are (ptr, ncols) with column stride n.
 // ------------------------------------------------------------------------------------------------
-#define REDUCE_MAX_GROUPS 4
+#define REDUCE_MAX_GROUPS 8
 struct ReduceParams {
   const u64* cols[REDUCE_MAX_GROUPS];
   int ncols[REDUCE_MAX_GROUPS];
@@ -534,6 +536,107 @@ __global__ void gather_open_kernel(const u64* __restrict__ data, size_t stride, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Lookup argument (plonk/vanishing_poly.rs::check_lookup_constraints): one thread per LDE row ADDS
+//   zh_inv * sum_t lookup_term_t * alpha^(base_idx + t)
+// to the quotient values, for the terms of every challenge in order: LastLdc * SLDC_last, InitSre * SLDC_0, InitSre * RE,
+// one "ends" check per table, the RE row transition, then per partial polynomial the Sum and the LDC transition.
+// Wire layout: LookupGate slots (2i, 2i+1) = (input, output); LookupTableGate slots (3i, 3i+1, 3i+2) = (input, output,
+// multiplicity).  Products of (alpha - combo) over a slot group and its leave-one-out sums are formed with prefix /
+// suffix products (groups have at most quotient_degree_factor - 1 = 7 members).
+// ------------------------------------------------------------------------------------------------
+#define VX_MAX_LUTS 8
+#define VX_LOOKUP_GROUP_MAX 16
+struct LookupParams {
+  const u64 *cs, *wires, *zs;  // as in QuotientParams (cs: global rows, stride N; wires / zs / out: local rows, stride_w)
+  const u64* alpha_pows;       // [VX_MAX_CHALLENGES][VX_ALPHA_POWS]
+  u64* out;
+  size_t N, rows, row_base, stride_w;
+  int log_n, rate_bits, nch;
+  int sel_base;   // column of the first lookup selector = num_selectors
+  int zs_base;    // column of challenge 0's RE polynomial inside the zs batch = nch * (1 + npp)
+  int nlp;        // lookup polynomials per challenge = 1 + num_sldc
+  int lu_slots, lut_slots, lu_deg, lut_deg, num_luts, base_idx;
+  u64 deltas[VX_MAX_CHALLENGES][4];
+  u64 lut_poly[VX_MAX_CHALLENGES][VX_MAX_LUTS];  // get_lut_poly per challenge and table
+  u64 zh_inv[VX_MAX_RATE];
+};
+// prod_j (alpha - v_j) and sum_i w_i prod_{j != i} (alpha - v_j) over k <= VX_LOOKUP_GROUP_MAX members (w_i = 1 when w == nullptr)
+GLD void lookup_group(const u64* f, const u64* w, int k, u64& prod, u64& sum) {
+  u64 pre[VX_LOOKUP_GROUP_MAX + 1];
+  pre[0] = 1;
+  for (int j = 0; j < k; ++j) pre[j + 1] = gl_mul(pre[j], f[j]);
+  prod = pre[k];
+  u64 suf = 1, acc = 0;
+  for (int j = k - 1; j >= 0; --j) {
+    const u64 lo = gl_mul(pre[j], suf);
+    acc = gl_add(acc, w ? gl_mul(w[j], lo) : lo);
+    suf = gl_mul(suf, f[j]);
+  }
+  sum = acc;
+}
+__global__ __launch_bounds__(256) void lookup_terms_kernel(LookupParams p) {
+  const size_t il = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (il >= p.rows) return;
+  const size_t N = p.N, SW = p.stride_w, i = il + p.row_base;
+  const int log_n = p.log_n;
+  const u32 nmask = (1u << log_n) - 1;
+  const u32 z = (u32)(i >> log_n);
+  const u32 r = bitrev32(z, p.rate_bits);
+  const u32 k = bitrev32((u32)i & nmask, log_n);
+  const size_t il_next = (((size_t)z << log_n) | bitrev32((k + 1) & nmask, log_n)) - p.row_base;
+#define LW(c) gl_canon(p.wires[(size_t)(c) * SW + il])
+  const int nsl = p.nlp - 1;
+  u64 sel[4 + VX_MAX_LUTS];
+  for (int q = 0; q < 4 + p.num_luts; ++q) sel[q] = p.cs[(size_t)(p.sel_base + q) * N + i];
+  u64 total[VX_MAX_CHALLENGES] = {0, 0};
+  int idx = p.base_idx;
+  auto push = [&](u64 term) {
+#pragma unroll
+    for (int c = 0; c < VX_MAX_CHALLENGES; ++c) total[c] = gl_mad(term, p.alpha_pows[c * VX_ALPHA_POWS + idx], total[c]);
+    ++idx;
+  };
+  for (int ch = 0; ch < p.nch; ++ch) {
+    const u64 da = p.deltas[ch][0], db = p.deltas[ch][1], dalpha = p.deltas[ch][2], ddelta = p.deltas[ch][3];
+    const u64* zl = p.zs + (size_t)(p.zs_base + ch * p.nlp) * SW;
+    auto Z = [&](int q) { return zl[(size_t)q * SW + il]; };
+    auto ZN = [&](int q) { return zl[(size_t)q * SW + il_next]; };
+    const u64 z_re = Z(0);
+    push(gl_mul(sel[3], Z(nsl)));      // LastLdc * SLDC_{last}
+    push(gl_mul(sel[2], Z(1)));        // InitSre * SLDC_0
+    push(gl_mul(sel[2], z_re));        // InitSre * RE
+    for (int t = 0; t < p.num_luts; ++t) push(gl_mul(sel[4 + t], gl_sub(z_re, p.lut_poly[ch][t])));
+    {
+      u64 cur = ZN(0);                 // RE row transition: Horner over the looked combos with challenge b
+      for (int s2 = 0; s2 < p.lut_slots; ++s2) cur = gl_add(gl_mul(cur, ddelta), gl_mad(db, LW(3 * s2 + 1), LW(3 * s2)));
+      push(gl_mul(sel[0], gl_sub(z_re, cur)));
+    }
+    for (int poly = 0; poly < nsl; ++poly) {
+      const int t0 = poly * p.lut_deg, t1 = min((poly + 1) * p.lut_deg, p.lut_slots);
+      const int u0 = poly * p.lu_deg, u1 = min((poly + 1) * p.lu_deg, p.lu_slots);
+      u64 f[VX_LOOKUP_GROUP_MAX], w[VX_LOOKUP_GROUP_MAX];
+      u64 lut_prod, lut_sum, lu_prod, lu_sum;
+      for (int s2 = t0; s2 < t1; ++s2) {
+        f[s2 - t0] = gl_sub(dalpha, gl_mad(da, LW(3 * s2 + 1), LW(3 * s2)));
+        w[s2 - t0] = LW(3 * s2 + 2);
+      }
+      lookup_group(f, w, t1 - t0, lut_prod, lut_sum);
+      for (int s2 = u0; s2 < u1; ++s2) f[s2 - u0] = gl_sub(dalpha, gl_mad(da, LW(2 * s2 + 1), LW(2 * s2)));
+      lookup_group(f, nullptr, u1 - u0, lu_prod, lu_sum);
+      const u64 prev = poly == 0 ? ZN(nsl) : Z(poly);
+      const u64 d = gl_sub(Z(poly + 1), prev);
+      push(gl_mul(sel[0], gl_sub(gl_mul(lut_prod, d), lut_sum)));   // Sum transition
+      push(gl_mul(sel[1], gl_add(gl_mul(lu_prod, d), lu_sum)));     // LDC transition
+    }
+  }
+#undef LW
+  const u64 zi = p.zh_inv[r];
+  for (int ch = 0; ch < p.nch; ++ch) {
+    u64* o = p.out + (size_t)ch * SW + il;
+    *o = gl_add(*o, gl_mul(total[ch], zi));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Constraint programs (include/vxprover.h VX_OP_*): gates outside the native set arrive as straight-line
 // programs over the row's wires / constants.  One thread per LDE row interprets the program — every lane
 // executes the same instruction, so fetch and decode are wave-uniform — and ADDS
@@ -550,6 +653,7 @@ struct ProgramParams {
   const u64* programs;
   size_t N, rows, row_base, stride_w;
   int log_n, rate_bits, num_selectors, nch, num_gates;
+  int const_base;
   ProgramGateDev gates[VX_MAX_PROGRAM_GATES];
   u64 alphas[VX_MAX_CHALLENGES], base_pw[VX_MAX_CHALLENGES];  // base_pw = alpha^(number of terms before the gate constraints)
   u64 pih[4];
@@ -578,7 +682,7 @@ __global__ __launch_bounds__(256) void program_gates_kernel(ProgramParams p) {
       if (op == 0) break;
       switch (op) {
         case 1: R[dst] = gl_canon(p.wires[(size_t)a * SW + il]); break;
-        case 2: R[dst] = p.cs[(size_t)(p.num_selectors + a) * N + i]; break;
+        case 2: R[dst] = p.cs[(size_t)(p.const_base + a) * N + i]; break;
         case 3: R[dst] = gl_canon(prog[++pc]); break;
         case 4: R[dst] = gl_add(R[a & 63], R[b & 63]); break;
         case 5: R[dst] = gl_sub(R[a & 63], R[b & 63]); break;

@@ -199,8 +199,8 @@ struct ByteSink {
 static size_t proof_size_bound(const vx_circuit* k) {
   size_t cap = (size_t)32 << k->cap_height;
   size_t depth0 = k->degree_bits + k->rate_bits - k->cap_height;
-  size_t widths = (size_t)k->num_constants + k->nr + k->num_wires + (size_t)k->nch * (1 + k->npp()) + (size_t)k->nch * k->qdf;
-  size_t open = 16 * (widths + k->nch);
+  size_t widths = (size_t)k->num_constants + k->nr + k->num_wires + (size_t)k->nch * (1 + k->npp() + k->nlp()) + (size_t)k->nch * k->qdf;
+  size_t open = 16 * (widths + k->nch * (1 + k->nlp()));
   size_t per_query = 8 * widths + 4 * (1 + 32 * depth0) + k->arity_bits.size() * (16 * 16 + 1 + 32 * depth0);
   return (3 + k->arity_bits.size()) * cap + open + k->num_queries * per_query + 16 * 256 + 8 + 8 * k->pi_rows.size() + 4096;
 }
@@ -273,7 +273,8 @@ struct FriParts {
   std::vector<size_t> flen;
   int depth0 = 0;
 };
-static int fri_prove_openings(vx_ctx* c, const FriProverParams& fpp, const std::vector<vx_batch*>& oracles, const std::vector<FriRange>& batch1_ranges,
+static int fri_prove_openings(vx_ctx* c, const FriProverParams& fpp, const std::vector<vx_batch*>& oracles, const std::vector<FriRange>& batch0_ranges,
+                              const std::vector<FriRange>& batch1_ranges,
                               vxh::Ext zeta, vxh::Ext gzeta, const std::vector<vxh::Ext>& batch0, const std::vector<vxh::Ext>& batch1,
                               vxh::Challenger& ch, const u64* pow_hint, const Shard& sh, Scratch& S, FriParts& out) {
   using namespace vxh;
@@ -305,14 +306,15 @@ static int fri_prove_openings(vx_ctx* c, const FriProverParams& fpp, const std::
   {
     ReduceParams rp;
     memset(&rp, 0, sizeof rp);
-    if (oracles.size() > REDUCE_MAX_GROUPS) return vx_fail(VX_E_INVALID, "fri: too many oracles");
-    rp.ngroups = (int)oracles.size();
+    if (batch0_ranges.size() > REDUCE_MAX_GROUPS) return vx_fail(VX_E_INVALID, "fri: too many column ranges in the first opening batch");
+    rp.ngroups = (int)batch0_ranges.size();
     size_t total = 0;
-    for (size_t o = 0; o < oracles.size(); ++o) {
-      rp.cols[o] = oracles[o]->coeffs;
-      rp.ncols[o] = (int)oracles[o]->ncols;
-      total += oracles[o]->ncols;
+    for (size_t g = 0; g < batch0_ranges.size(); ++g) {
+      rp.cols[g] = oracles[batch0_ranges[g].oracle]->coeffs + batch0_ranges[g].col0 * n;
+      rp.ncols[g] = (int)batch0_ranges[g].ncols;
+      total += batch0_ranges[g].ncols;
     }
+    if (total != batch0.size()) return vx_fail(VX_E_INVALID, "fri: opening batch 0 has %zu values for %zu polynomials", batch0.size(), total);
     rp.alpha_pows = d_apows;
     rp.n = n;
     rp.out = fcoef;
@@ -609,6 +611,60 @@ static void write_fri_proof(ByteSink& w, const FriProverParams& fp, const std::v
   w.f(f.pow_witness);
 }
 
+// prover.rs::compute_lookup_polys for every challenge: the polynomials [RE, SLDC_0 .. SLDC_{k-1}] are zero outside the
+// lookup rows [last_lu_row, first_lut_row] of each table, and inside them they are short recurrences ACROSS rows (RE is a
+// Horner chain down the table rows, the partial Sums / LDCs running sums) over at most a few thousand rows — so the rows
+// are gathered from the device-resident witness (80 routed columns x the row range), the recurrences run on the host,
+// and only the non-zero row range of the nch * nlp columns is written back.  dst: [nch * nlp][n] on the device.
+static int lookup_polys_to_device(vx_ctx* c, const vx_circuit* k, const u64* d_wires, const std::vector<u64>& deltas, u64* dst) {
+  using namespace vxh;
+  const size_t n = k->n();
+  const int nch = k->nch, nlp = k->nlp(), nsl = nlp - 1;
+  const int lu_slots = k->nr / 2, lut_slots = k->nr / 3, lu_deg = k->qdf - 1, lut_deg = (lut_slots + nsl - 1) / nsl;
+  HIPCHK(hipMemsetAsync(dst, 0, (size_t)nch * nlp * n * 8, c->stream));
+  for (int t = 0; t < k->num_luts; ++t) {
+    const size_t last_lu = (size_t)k->lookup_rows[3 * t], last_lut = (size_t)k->lookup_rows[3 * t + 1], first_lut = (size_t)k->lookup_rows[3 * t + 2];
+    const size_t R = first_lut - last_lu + 1;
+    std::vector<u64> w((size_t)k->nr * R);  // [col][row - last_lu]
+    HIPCHK(hipMemcpy2DAsync(w.data(), R * 8, d_wires + last_lu, n * 8, R * 8, (size_t)k->nr, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (auto& v : w) v = canon(v);
+    auto W = [&](int col, size_t row) { return w[(size_t)col * R + (row - last_lu)]; };
+    std::vector<u64> polys((size_t)nch * nlp * (R + 1), 0);  // [(ch, poly)][row - last_lu], one extra zero row above first_lut
+    for (int cI = 0; cI < nch; ++cI) {
+      const u64 da = deltas[4 * cI], db = deltas[4 * cI + 1], dalpha = deltas[4 * cI + 2], ddelta = deltas[4 * cI + 3];
+      auto PV = [&](int poly, size_t row) -> u64& { return polys[((size_t)cI * nlp + poly) * (R + 1) + (row - last_lu)]; };
+      std::vector<u64> den(std::max(lu_slots, lut_slots));
+      for (size_t row = first_lut + 1; row-- > last_lut;) {   // table rows: RE and the partial Sums
+        u64 re = PV(0, row + 1);
+        for (int s2 = 0; s2 < lut_slots; ++s2) {
+          const u64 inp = W(3 * s2, row), out = W(3 * s2 + 1, row);
+          den[s2] = inv(sub(dalpha, add(inp, mul(da, out))));
+          re = add(mul(re, ddelta), add(inp, mul(db, out)));
+        }
+        PV(0, row) = re;
+        for (int slot = 0; slot < nsl; ++slot) {
+          u64 acc = slot ? PV(slot, row) : PV(nsl, row + 1);
+          for (int s2 = slot * lut_deg; s2 < std::min((slot + 1) * lut_deg, lut_slots); ++s2) acc = add(acc, mul(W(3 * s2 + 2, row), den[s2]));
+          PV(slot + 1, row) = acc;
+        }
+      }
+      for (size_t row = last_lut; row-- > last_lu;) {        // looking rows: the partial LDCs
+        for (int s2 = 0; s2 < lu_slots; ++s2) den[s2] = inv(sub(dalpha, add(W(2 * s2, row), mul(da, W(2 * s2 + 1, row)))));
+        for (int slot = 0; slot < nsl; ++slot) {
+          const u64 prev = slot ? PV(slot, row) : PV(nsl, row + 1);
+          u64 sum = 0;
+          for (int s2 = slot * lu_deg; s2 < std::min((slot + 1) * lu_deg, lu_slots); ++s2) sum = add(sum, den[s2]);
+          PV(slot + 1, row) = sub(prev, sum);
+        }
+      }
+    }
+    HIPCHK(hipMemcpy2DAsync(dst + last_lu, n * 8, polys.data(), (R + 1) * 8, R * 8, (size_t)nch * nlp, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));  // `polys` and `w` are stack-scoped sources / sinks of the copies
+  }
+  return VX_OK;
+}
+
 static int prove_impl(vx_ctx* c, vx_circuit* k, const u64* wires_in, bool wires_on_device, const u64* pow_hint,
                       std::vector<uint8_t>& proof_out, const Shard& sh = Shard()) {
   using namespace vxh;
@@ -688,13 +744,21 @@ static int prove_impl(vx_ctx* c, vx_circuit* k, const u64* wires_in, bool wires_
   u64 betas[VX_MAX_CHALLENGES] = {0}, gammas[VX_MAX_CHALLENGES] = {0}, alphas[VX_MAX_CHALLENGES] = {0};
   for (int i = 0; i < nch; ++i) betas[i] = ch.get_challenge();
   for (int i = 0; i < nch; ++i) gammas[i] = ch.get_challenge();
+  // lookup challenges (prover.rs): NUM_COINS_LOOKUP = 4 per challenge; the first 2 nch of them ARE the betas and gammas
+  const int nlp = k->nlp(), nlook = nch * nlp;
+  std::vector<u64> deltas;
+  if (k->num_luts > 0) {
+    deltas.assign(betas, betas + nch);
+    deltas.insert(deltas.end(), gammas, gammas + nch);
+    for (int i = 0; i < 2 * nch; ++i) deltas.push_back(ch.get_challenge());
+  }
 
   // ---- Z and partial products ----
   {
     const size_t nblocks = (n + 255) / 256;
     u64* cp = S.get((size_t)nch * nchunks * n);
     u64* bp = S.get((size_t)nch * nblocks);
-    u64* zs_vals = S.get((size_t)nch * (1 + npp) * n);
+    u64* zs_vals = S.get(((size_t)nch * (1 + npp) + nlook) * n);
     if (!cp || !bp || !zs_vals) return vx_fail(VX_E_NOMEM, "prove: out of device memory (permutation argument)");
     {
       ProfScope ps(c, "perm_z_partial_products", (double)nch * 8.0 * n * (2.0 * k->nr + 1 + npp));
@@ -718,7 +782,8 @@ static int prove_impl(vx_ctx* c, vx_circuit* k, const u64* wires_in, bool wires_
       hipLaunchKernelGGL(perm_write_kernel, dim3((unsigned)nblocks, nch), dim3(256), 0, c->stream, cp, n, nchunks, nch, bp, zs_vals);
       HIPCHK(hipGetLastError());
     }
-    VXCHK(batch_alloc(c, lg, (size_t)nch * (1 + npp), rb, k->cap_height, &zs_b, sh.rank, sh.lg));
+    if (k->num_luts > 0) VXCHK(lookup_polys_to_device(c, k, d_wires, deltas, zs_vals + (size_t)nch * (1 + npp) * n));
+    VXCHK(batch_alloc(c, lg, (size_t)nch * (1 + npp) + nlook, rb, k->cap_height, &zs_b, sh.rank, sh.lg));
     VXCHK(batch_commit_device(c, zs_b, zs_vals, n, false));
   }
   VXCHK(gather_cap(c, sh, S, zs_b->tree + zs_b->cap_off * 4, zs_b->local_cap_words(), zs_cap));
@@ -746,6 +811,9 @@ static int prove_impl(vx_ctx* c, vx_circuit* k, const u64* wires_in, bool wires_
       qp.log_n = lg;
       qp.rate_bits = rb;
       qp.num_selectors = k->num_selectors;
+      qp.const_base = k->const_base();
+      const int lookup_terms = k->num_luts > 0 ? nch * (4 + k->num_luts + 2 * k->num_sldc()) : 0;
+      qp.extra_terms = lookup_terms;
       qp.num_constants = k->num_constants;
       qp.nr = k->nr;
       qp.num_wires = k->num_wires;
@@ -766,7 +834,7 @@ static int prove_impl(vx_ctx* c, vx_circuit* k, const u64* wires_in, bool wires_
       qp.n_field = (u64)n % P;
       {
         // alpha powers for reduce_with_powers: L_0 terms, partial-product checks, then the widest gate (123 constraints)
-        if ((size_t)nch * (1 + nchunks) + 160 > VX_ALPHA_POWS) return vx_fail(VX_E_INVALID, "prove: too many constraint terms");
+        if ((size_t)nch * (1 + nchunks) + (size_t)lookup_terms + 160 > VX_ALPHA_POWS) return vx_fail(VX_E_INVALID, "prove: too many constraint terms");
         ap.assign((size_t)VX_MAX_CHALLENGES * VX_ALPHA_POWS, 0);
         for (int cI = 0; cI < nch; ++cI) {
           u64 pw = 1;
@@ -796,8 +864,42 @@ static int prove_impl(vx_ctx* c, vx_circuit* k, const u64* wires_in, bool wires_
       ProfScope ps(c, "quotient_eval", (double)bytes_read);
       hipLaunchKernelGGL(quotient_kernel, dim3((unsigned)((Nl + 255) / 256)), dim3(256), 0, c->stream, qp);
       HIPCHK(hipGetLastError());
+      if (k->num_luts > 0) {  // the lookup argument's terms sit between the partial-product checks and the gate constraints
+        LookupParams lp;
+        memset(&lp, 0, sizeof lp);
+        lp.cs = k->cs->lde, lp.wires = wires_b->lde, lp.zs = zs_b->lde;
+        lp.alpha_pows = qp.alpha_pows;
+        lp.out = qv;
+        lp.N = N, lp.rows = Nl, lp.row_base = row_base, lp.stride_w = Nl;
+        lp.log_n = lg, lp.rate_bits = rb, lp.nch = nch;
+        lp.sel_base = k->num_selectors;
+        lp.zs_base = nch * (1 + npp);
+        lp.nlp = nlp;
+        lp.lu_slots = k->nr / 2, lp.lut_slots = k->nr / 3, lp.lu_deg = qdf - 1;
+        lp.lut_deg = (lp.lut_slots + k->num_sldc() - 1) / k->num_sldc();
+        lp.num_luts = k->num_luts;
+        lp.base_idx = nch * (1 + nchunks);
+        for (int cI = 0; cI < nch; ++cI) {
+          for (int q = 0; q < 4; ++q) lp.deltas[cI][q] = deltas[4 * cI + q];
+          size_t off = 0;
+          for (int t = 0; t < k->num_luts; ++t) {  // vanishing_poly.rs::get_lut_poly, zero-padded to whole table rows
+            const size_t len = (size_t)k->lut_lens[t], degree = (len + lp.lut_slots - 1) / lp.lut_slots * lp.lut_slots;
+            u64 acc = 0;
+            for (size_t e = 0; e < degree; ++e) {
+              const u64 coeff = e < len ? add((u64)k->lut_inputs[off + e], mul(deltas[4 * cI + 1], (u64)k->lut_outputs[off + e])) : 0;
+              acc = add(mul(acc, deltas[4 * cI + 3]), coeff);
+            }
+            off += len;
+            lp.lut_poly[cI][t] = acc;
+          }
+        }
+        for (int r = 0; r < rate; ++r) lp.zh_inv[r] = qp.zh_inv[r];
+        ProfScope psl(c, "quotient_lookup_terms");
+        hipLaunchKernelGGL(lookup_terms_kernel, dim3((unsigned)((Nl + 255) / 256)), dim3(256), 0, c->stream, lp);
+        HIPCHK(hipGetLastError());
+      }
       if (k->programs) {  // gates supplied as constraint programs add their share to the same quotient values
-        const u64 nterms_before = (u64)nch * (1 + nchunks);  // L_0 terms + partial-product checks come first
+        const u64 nterms_before = (u64)nch * (1 + nchunks) + (u64)lookup_terms;  // L_0 terms, partial-product checks [, lookup terms] come first
         {
           JitGateParams jp;
           memset(&jp, 0, sizeof jp);
@@ -812,6 +914,7 @@ static int prove_impl(vx_ctx* c, vx_circuit* k, const u64* wires_in, bool wires_
           jp.log_n = lg;
           jp.rate_bits = rb;
           jp.num_selectors = k->num_selectors;
+          jp.const_base = k->const_base();
           jp.nch = nch;
           jp.base_idx = (int)nterms_before;
           for (int i = 0; i < 4; ++i) jp.pih[i] = pih.e[i];
@@ -839,6 +942,7 @@ static int prove_impl(vx_ctx* c, vx_circuit* k, const u64* wires_in, bool wires_
         pg.log_n = lg;
         pg.rate_bits = rb;
         pg.num_selectors = k->num_selectors;
+        pg.const_base = k->const_base();
         pg.nch = nch;
         for (size_t g = 0; g < k->gates.size(); ++g)
           if (k->prog_off[g] >= 0 && !k->jit_fn)  // not compiled: interpreter
@@ -908,7 +1012,8 @@ static int prove_impl(vx_ctx* c, vx_circuit* k, const u64* wires_in, bool wires_
 
   // ---- openings ----
   vx_batch* oracles[4] = {k->cs, wires_b, zs_b, quot_b};
-  std::vector<u64> ev[4], zs_next(2 * (size_t)nch);
+  std::vector<u64> ev[4], zs_next(2 * (size_t)nch), lzs_next(2 * (size_t)nlook);
+  const size_t zs_pp = (size_t)nch * (1 + npp);
   {
     u64* ztab = S.get(2 * n);
     if (!ztab) return vx_fail(VX_E_NOMEM, "prove: out of device memory (openings)");
@@ -919,12 +1024,18 @@ static int prove_impl(vx_ctx* c, vx_circuit* k, const u64* wires_in, bool wires_
     }
     VXCHK(build_zeta_table(c, gzeta, lg, ztab));
     VXCHK(batch_eval_ext(c, zs_b->coeffs, n, lg, nch, ztab, zs_next.data()));
+    if (nlook) VXCHK(batch_eval_ext(c, zs_b->coeffs + zs_pp * n, n, lg, nlook, ztab, lzs_next.data()));
   }
-  // to_fri_openings: batch 0 = [constants, sigmas, wires, zs, partial products, quotient], batch 1 = [zs_next]
+  // to_fri_openings: batch 0 = [constants, sigmas, wires, zs, partial products, quotient, lookup_zs], batch 1 = [zs_next,
+  // lookup_zs_next] — the lookup polynomials are the TAIL of the zs_partial_products oracle but are opened after the quotient
   std::vector<Ext> batch0, batch1;
-  for (int o = 0; o < 4; ++o)
-    for (size_t i = 0; i < oracles[o]->ncols; ++i) batch0.push_back(Ext{ev[o][2 * i], ev[o][2 * i + 1]});
+  for (int o = 0; o < 4; ++o) {
+    const size_t cnt = o == 2 ? zs_pp : oracles[o]->ncols;
+    for (size_t i = 0; i < cnt; ++i) batch0.push_back(Ext{ev[o][2 * i], ev[o][2 * i + 1]});
+  }
+  for (size_t i = zs_pp; i < zs_pp + nlook; ++i) batch0.push_back(Ext{ev[2][2 * i], ev[2][2 * i + 1]});
   for (int i = 0; i < nch; ++i) batch1.push_back(Ext{zs_next[2 * i], zs_next[2 * i + 1]});
+  for (int i = 0; i < nlook; ++i) batch1.push_back(Ext{lzs_next[2 * i], lzs_next[2 * i + 1]});
   for (Ext e : batch0) ch.observe_ext(e);
   for (Ext e : batch1) ch.observe_ext(e);
 
@@ -933,9 +1044,17 @@ static int prove_impl(vx_ctx* c, vx_circuit* k, const u64* wires_in, bool wires_
   fp.degree_bits = lg, fp.rate_bits = rb, fp.cap_height = k->cap_height, fp.pow_bits = k->pow_bits, fp.num_queries = k->num_queries;
   fp.arity_bits = k->arity_bits;
   std::vector<vx_batch*> fri_oracles(oracles, oracles + 4);
+  // circuit_data.rs::get_fri_instance: fri_all_polys = [preprocessed, wires, zs + partial products, quotient, lookup polys],
+  // fri_next_batch_polys = [zs, lookup polys]
+  std::vector<FriRange> batch0_ranges = {FriRange{0, 0, oracles[0]->ncols}, FriRange{1, 0, oracles[1]->ncols}, FriRange{2, 0, zs_pp},
+                                         FriRange{3, 0, oracles[3]->ncols}};
   std::vector<FriRange> batch1_ranges = {FriRange{2, 0, (size_t)nch}};  // plonk_zs_next: the Z polynomials lead the zs_partial_products batch
+  if (nlook) {
+    batch0_ranges.push_back(FriRange{2, zs_pp, (size_t)nlook});
+    batch1_ranges.push_back(FriRange{2, zs_pp, (size_t)nlook});
+  }
   FriParts fri;
-  VXCHK(fri_prove_openings(c, fp, fri_oracles, batch1_ranges, zeta, gzeta, batch0, batch1, ch, pow_hint, sh, S, fri));
+  VXCHK(fri_prove_openings(c, fp, fri_oracles, batch0_ranges, batch1_ranges, zeta, gzeta, batch0, batch1, ch, pow_hint, sh, S, fri));
   {
     // ---- serialise (util/serialization::write_proof_with_public_inputs) ----
     ByteSink w;
@@ -949,8 +1068,10 @@ static int prove_impl(vx_ctx* c, vx_circuit* k, const u64* wires_in, bool wires_
     w.words(ev[1].data(), ev[1].size());
     w.words(ev[2].data(), 2 * (size_t)nch);
     w.words(zs_next.data(), 2 * (size_t)nch);
-    w.words(ev[2].data() + 2 * (size_t)nch, ev[2].size() - 2 * (size_t)nch);
+    w.words(ev[2].data() + 2 * (size_t)nch, 2 * (zs_pp - (size_t)nch));
     w.words(ev[3].data(), ev[3].size());
+    w.words(ev[2].data() + 2 * zs_pp, 2 * (size_t)nlook);   // lookup_zs
+    w.words(lzs_next.data(), lzs_next.size());               // lookup_zs_next
     write_fri_proof(w, fp, fri_oracles, fri, sh);
     w.words(public_inputs.data(), public_inputs.size());
     proof_out.swap(w.b);

@@ -313,9 +313,10 @@ static int stark_prove_impl(vx_ctx* c, const vx_stark_desc* d, const u64* trace_
   fp.degree_bits = lg, fp.rate_bits = rb, fp.cap_height = d->cap_height, fp.pow_bits = d->pow_bits, fp.num_queries = d->num_query_rounds;
   fp.arity_bits = sh.arity_bits;
   std::vector<vx_batch*> oracles = {trace_b, quot_b};
+  std::vector<FriRange> batch0_ranges = {FriRange{0, 0, (size_t)ncols}, FriRange{1, 0, quot_b->ncols}};
   std::vector<FriRange> batch1_ranges = {FriRange{0, 0, (size_t)ncols}};
   FriParts fri;
-  VXCHK(fri_prove_openings(c, fp, oracles, batch1_ranges, zeta, gzeta, batch0, batch1, ch, pow_hint, one, S, fri));
+  VXCHK(fri_prove_openings(c, fp, oracles, batch0_ranges, batch1_ranges, zeta, gzeta, batch0, batch1, ch, pow_hint, one, S, fri));
   ByteSink w;
   w.words(trace_cap.data(), cap_words);
   w.words(quot_cap.data(), cap_words);
