@@ -155,8 +155,10 @@ size_t vx_merkle_digest_count(size_t n_leaves, int cap_height);
  * row order) from which constants_sigmas_commitment and circuit_digest are derived at load time.
  * Gates with hand-written kernels: NoopGate, ConstantGate, PublicInputGate, ArithmeticGate (base), PoseidonGate.
  * Every other gate is handed over as a constraint program (VX_GATE_PROGRAM below), which vx_circuit_create compiles
- * to native code; the recursive verifier's whole gate set has been exercised that way.  Limits: 32
- * gates per circuit, degree_bits + rate_bits <= 24, no lookup tables. */
+ * to native code; the recursive verifier's whole gate set has been exercised that way.  The lookup
+ * argument (LookupGate / LookupTableGate, tables in the description's tail) is supported.  Limits: 64 gates per circuit,
+ * degree_bits + rate_bits <= 24, quotient_degree_factor = 2^rate_bits (standard_recursion_config; every circuit with a
+ * PoseidonGate has 8). */
 #define VX_GATE_NOOP 0
 #define VX_GATE_CONSTANT 1
 #define VX_GATE_PUBLIC_INPUT 2

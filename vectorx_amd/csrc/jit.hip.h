@@ -211,7 +211,7 @@ struct JitGateParams {
   int const_base, pad_;
   u64 pih[4];
   u64 zh_inv[16];
-  JitGateRt g[32];
+  JitGateRt g[64];
 };
 extern "C" __global__ __launch_bounds__(256, VX_JIT_BLOCKS_PER_CU) void vx_program_gates(JitGateParams p) {
   const size_t il = (size_t)blockIdx.x * 256 + threadIdx.x;

@@ -13,7 +13,7 @@
 #include "ntt.hip.h"
 #include "poseidon.hip.h"
 
-#define VX_MAX_GATES 32
+#define VX_MAX_GATES 64          /* gates per circuit (kernel-argument table: 20 B each); plonky2x registers ~40 gate types in total */
 #define VX_MAX_CHALLENGES 2
 #define VX_MAX_RATE 16
 
@@ -644,7 +644,7 @@ __global__ __launch_bounds__(256) void lookup_terms_kernel(LookupParams p) {
 // to the quotient values the native kernel already wrote.  The virtual register file is per-thread private
 // memory; this path is for the long tail of cold gates, the hot gates stay compiled.
 // ------------------------------------------------------------------------------------------------
-#define VX_MAX_PROGRAM_GATES 32
+#define VX_MAX_PROGRAM_GATES 64
 struct ProgramGateDev {
   int gate_index, selector_index, group_start, group_end, prog_off;
 };
