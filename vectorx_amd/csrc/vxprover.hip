@@ -15,26 +15,24 @@
 #include "verifier.h"
 
 
-// ---- shader-clock probe (vx_clock_probe): every wave runs a VALU-saturating multiply-add loop between two readings of
-// s_memtime (shader-clock ticks) and s_memrealtime (constant 100 MHz); effective clock = ticks / realtime.  bench.py
-// prices the integer-ALU roofline with the clock measured in its own run instead of the 2.4 GHz nameplate.
-__global__ __launch_bounds__(256) void clock_probe_kernel(uint64_t* __restrict__ out, int iters) {
+// ---- shader-clock probe (vx_clock_probe): every wave runs Poseidon permutations — the instruction mix of the kernels that
+// take > 65 % of a proof, at the same 4 waves per SIMD — between two readings of s_memtime (shader-clock ticks) and
+// s_memrealtime (constant 100 MHz); effective clock = ticks / realtime.  The clock follows the power budget and therefore
+// the instruction mix (a pure multiply-add loop settles ~0.4 GHz lower than the permutation), so bench.py prices the
+// integer-ALU roofline with the clock measured in its own run under the permutation's own load.
+__global__ __launch_bounds__(HASH_THREADS, 4) void clock_probe_kernel(uint64_t* __restrict__ out, int iters) {
   uint64_t t0, r0, t1, r1;
+  u64 s[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) s[i] = (u64)threadIdx.x * 0x9E3779B97F4A7C15ull + i;
   asm volatile("s_memtime %0\n s_memrealtime %1\n s_waitcnt lgkmcnt(0)" : "=s"(t0), "=s"(r0));
-  u64 acc[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) acc[i] = threadIdx.x + i;
-  const u32 m = (u32)threadIdx.x * 2654435761u + 12345u;
-  for (int it = 0; it < iters; ++it) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = (u64)(u32)acc[i] * m + acc[i];
-  }
+  for (int it = 0; it < iters; ++it) poseidon_permute_nc(s);
   asm volatile("s_memtime %0\n s_memrealtime %1\n s_waitcnt lgkmcnt(0)" : "=s"(t1), "=s"(r1));
   u64 x = 0;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) x ^= acc[i];
+  for (int i = 0; i < 12; ++i) x ^= s[i];
   if ((threadIdx.x & 63) == 0 || x == 0x123456789ull) {
-    const size_t w = ((size_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const size_t w = ((size_t)blockIdx.x * HASH_THREADS + threadIdx.x) >> 6;
     out[2 * w] = t1 - t0;
     out[2 * w + 1] = r1 - r0;
   }
@@ -113,10 +111,11 @@ void* vx_ctx_stream(vx_ctx* c) { return c ? (void*)c->stream : nullptr; }
 int vx_clock_probe(vx_ctx* c, double* ghz_out) {
   if (!c || !ghz_out) return vx_fail(VX_E_INVALID, "vx_clock_probe: NULL argument");
   HIPCHK(hipSetDevice(c->device));
-  const int blocks = c->props.multiProcessorCount * 8, waves = blocks * 4;
+  const int blocks = c->props.multiProcessorCount * 4, waves = blocks * (HASH_THREADS / 64);
   void* d = nullptr;
   if (c->pool_alloc(&d, (size_t)waves * 16) != hipSuccess) return vx_fail(VX_E_NOMEM, "vx_clock_probe: out of device memory");
-  hipLaunchKernelGGL(clock_probe_kernel, dim3(blocks), dim3(256), 0, c->stream, (uint64_t*)d, 1 << 15);
+  hipLaunchKernelGGL(clock_probe_kernel, dim3(blocks), dim3(HASH_THREADS), 0, c->stream, (uint64_t*)d, 8);   // warm the clock up
+  hipLaunchKernelGGL(clock_probe_kernel, dim3(blocks), dim3(HASH_THREADS), 0, c->stream, (uint64_t*)d, 48);  // ~1.3 ms, measured
   std::vector<uint64_t> h((size_t)waves * 2);
   hipError_t e = hipMemcpyAsync(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost, c->stream);
   hipError_t e2 = hipStreamSynchronize(c->stream);
