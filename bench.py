@@ -116,6 +116,7 @@ def main():
 
     dt = H.run_timed(step, args.steps, args.warmup, sync, dist, device=f"cuda:{local_rank}", before_timed=before_timed)
     prof = ctx.prof()
+    hash_clock_ghz = ctx.clock_ghz() if args.workload == "prove" else None   # before anything else runs: the timed region's own samples
     ctx.prof_enable(False)
 
     # Extra leg, OUTSIDE the contract's timed region (`value` stays "inputs resident in HBM"): the same K proofs from a
@@ -164,13 +165,13 @@ def main():
                 # histogram of the gfx950 assembly (tools/alu_ceiling.py -> profiles/r02_alu_ceiling.json)
                 ceil_info = json.loads((ROOT / "profiles" / "r02_alu_ceiling.json").read_text())
                 ipp = float(ceil_info["valu_insts_per_perm_pmc"] or ceil_info["valu_insts_per_perm_static"])
-                ghz = ctx.clock_ghz()          # measured NOW, on this device, under a VALU-saturating load
+                ghz = hash_clock_ghz           # sampled INSIDE the timed hash_leaves launches (s_memtime / s_memrealtime per sampled wave)
                 achieved = perms / (ms * 1e-3) * ipp / 64.0
                 # ceiling: one VALU instruction per wavefront per SIMD per QUAD-cycle — the unit the SQ's own counters use
                 # (SQ_ACTIVE_INST_VALU == SQ_INSTS_VALU for this kernel); single-opcode loops of its instruction classes
                 # measure 4.4 cycles (profiles/r02_ubench_int.md), mixed streams 3.8-4.1: 4.0 is the issue model.
                 ceiling = ceil_info["simds"] * ghz * 1e9 / 4.0
-                alu.update({"valu_insts_per_perm": ipp, "clock_ghz_measured_in_run": round(ghz, 3),
+                alu.update({"valu_insts_per_perm": ipp, "clock_ghz_measured_in_kernel": round(ghz, 3),
                             "achieved_wave_inst_per_s": achieved, "ceiling_wave_inst_per_s": ceiling,
                             "frac": round(achieved / ceiling, 4),
                             "ceiling_model": "1024 SIMDs x measured clock / 4 cycles per wavefront-instruction (quad-cycle VALU issue)",

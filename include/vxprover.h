@@ -57,10 +57,12 @@ int vx_ctx_sync(vx_ctx* ctx);
 /* Opaque hipStream_t of the context (so a harness can record its own events on the right stream). */
 void* vx_ctx_stream(vx_ctx* ctx);
 
-/* Effective shader clock (GHz) under the Poseidon permutation's own instruction mix, measured on the device itself: a ~1 ms
- * kernel whose waves read s_memtime (shader-clock ticks) and s_memrealtime (constant 100 MHz) around a run of
- * permutations.  The clock follows the power budget (1.9 - 2.4 GHz on MI355X, by instruction mix), so an
- * instruction-issue roofline must use a measured value. */
+/* Effective shader clock (GHz) of the leaf-hashing kernel, measured on the device itself from s_memtime (shader-clock ticks)
+ * over s_memrealtime (constant 100 MHz): with profiling on (vx_prof_enable) every 1024th block of every
+ * hash_leaves_colmajor_kernel launch records its first wave's ticks, and this call averages the samples taken since the last
+ * vx_prof_reset — the clock the timed launches really ran at.  Without samples it runs a ~4 ms stand-alone probe of Poseidon
+ * permutations.  The clock follows the power budget (1.9 - 2.4 GHz on MI355X), so an instruction-issue roofline must use a
+ * measured value. */
 int vx_clock_probe(vx_ctx* ctx, double* ghz_out);
 
 /* Per-kernel-family HIP-event timing.  enable=1 brackets every launch family with events on the

@@ -24,7 +24,7 @@ import re
 import sys
 from collections import Counter
 
-KERNEL = "_Z27hash_leaves_colmajor_kernelPKmmmiPm"
+KERNEL = "_Z27hash_leaves_colmajor_kernel"   # mangled-name prefix
 NCOLS = 135
 PERMS = (NCOLS + 7) // 8  # sponge permutations per row
 
@@ -34,8 +34,9 @@ FAST = {"v_mov_b32_e32", "v_add_u32_e32", "v_sub_u32_e32", "v_subrev_u32_e32", "
 
 
 def kernel_text(asm, name):
-    a = asm.index(name + ":")
-    return asm[a:asm.index("s_endpgm", a)]
+    m = re.search(r"^" + re.escape(name) + r"\w*:", asm, re.M)
+    a = m.start()
+    return asm[a:asm.index(".Lfunc_end", a)]
 
 
 def weighted_histogram(text):

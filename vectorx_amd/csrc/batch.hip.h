@@ -133,7 +133,7 @@ static int batch_hash_tree(vx_ctx* c, vx_batch* b) {
   {
     ProfScope ps(c, "hash_leaves", (double)m * 8.0 * (double)N);
     hipLaunchKernelGGL(hash_leaves_colmajor_kernel, dim3((unsigned)((N + HASH_THREADS - 1) / HASH_THREADS)),
-                       dim3(HASH_THREADS), 0, c->stream, b->lde, N, N, (int)m, b->tree);
+                       dim3(HASH_THREADS), 0, c->stream, b->lde, N, N, (int)m, b->tree, c->prof_on ? c->hash_clk : nullptr);
     HIPCHK(hipGetLastError());
   }
   VXCHK(build_merkle_levels(c, b->tree, N, b->local_cap_height(), &b->cap_off));

@@ -12,9 +12,16 @@
 #define HASH_THREADS 256
 
 // digests[row] = hash_or_noop(row of `ncols` values), column-major source.
+// clk (optional, profiling only): every 1024th block's first wave records {shader-clock ticks, 100 MHz ticks} it spent in
+// the kernel into clk[2 * slot] — the clock this kernel actually sustains (it follows the power budget), read by
+// vx_clock_probe for the integer-ALU roofline.  Two scalar timestamp reads per sampled wave: no measurable cost.
+#define HASH_CLK_SLOTS 64
 __global__ __launch_bounds__(HASH_THREADS, 4) void hash_leaves_colmajor_kernel(
-    const u64* __restrict__ cols, size_t col_stride, size_t nrows, int ncols, u64* __restrict__ digests) {
+    const u64* __restrict__ cols, size_t col_stride, size_t nrows, int ncols, u64* __restrict__ digests, u64* __restrict__ clk) {
   size_t row = (size_t)blockIdx.x * HASH_THREADS + threadIdx.x;
+  const bool sample = clk != nullptr && (blockIdx.x & 1023) == 512 && threadIdx.x < 64;   // wave-uniform
+  uint64_t t0 = 0, r0 = 0;
+  if (sample) asm volatile("s_memtime %0\n s_memrealtime %1\n s_waitcnt lgkmcnt(0)" : "=s"(t0), "=s"(r0));
   if (row >= nrows) return;
   u64 s[12];
 #pragma unroll
@@ -34,6 +41,15 @@ __global__ __launch_bounds__(HASH_THREADS, 4) void hash_leaves_colmajor_kernel(
   u64* d = digests + row * 4;
 #pragma unroll
   for (int i = 0; i < 4; ++i) d[i] = gl_canon(s[i]);
+  if (sample) {
+    uint64_t t1, r1;
+    asm volatile("s_memtime %0\n s_memrealtime %1\n s_waitcnt lgkmcnt(0)" : "=s"(t1), "=s"(r1));
+    if (threadIdx.x == 0) {
+      const unsigned slot = (blockIdx.x >> 10) % HASH_CLK_SLOTS;
+      clk[2 * slot] = t1 - t0;
+      clk[2 * slot + 1] = r1 - r0;
+    }
+  }
 }
 
 // Row-major leaves [nrows][width] (C-ABI vx_merkle_cap and the FRI commit-phase trees, whose leaves

@@ -52,6 +52,7 @@ struct vx_ctx {
   hipStream_t copy_stream = nullptr;  // host->device witness upload, overlapped with the first transforms (prover.hip.h)
   u64* root_lo = nullptr;  // w_{2^24}^k
   u64* root_hi = nullptr;  // w_{2^24}^(4096k)
+  u64* hash_clk = nullptr; // {shader ticks, 100 MHz ticks} samples written by hash_leaves_colmajor_kernel while profiling
   bool prof_on = false;
   std::vector<ProfPending> pending;
   std::vector<hipEvent_t> event_pool;
