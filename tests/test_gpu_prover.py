@@ -391,3 +391,17 @@ def test_lookup_argument_proof_bytes_identical_to_oracle(ctx, oracle, degree_bit
     assert g2.prove(w) == gp
     g2.free()
     gc.free()
+
+
+def test_proof_size_bound_covers_a_long_final_polynomial(ctx, oracle):
+    """Found by tools/soak_differential.py (round 2): with a caller-supplied arity list that folds little, the final
+    polynomial stays long (here 2^11 / 2 coefficients) and vx_proof_size_bound must account for it."""
+    sc = SynthCircuit(11, seed=31337, poseidon_percent=30)
+    sc.desc.pow_bits = 4
+    for arities in ([], [1], [2, 1]):
+        sc.set_fri_reduction_arity_bits(arities)
+        gc = vx.Circuit(ctx, sc.desc_ptr)
+        gp = gc.prove(sc.witness())
+        assert gp == oracle_lib.OracleCircuit(oracle, sc.desc_ptr).prove(sc.witness())
+        gc.verify(gp)
+        gc.free()

@@ -30,8 +30,8 @@ lanes = [vx.Context(0) for _ in range(7)]
 t_end = time.time() + budget
 n_ok, n_bad, by_kind = 0, 0, {}
 while time.time() < t_end:
-    flags = int(rng.choice([0, 0, 1, 2, 3, 4, 5, 7, 8, 15]))
-    lo = 5 if flags & 12 else (4 if flags & 1 else 3)
+    flags = int(rng.choice([0, 0, 1, 2, 3, 4, 5, 7, 8, 15, 16, 16, 17, 19, 21, 31]))   # 16 = lookup table + LookupGate rows
+    lo = 5 if flags & 28 else (4 if flags & 1 else 3)
     db = int(rng.integers(max(lo, db_min), db_max + 1))
     pct = int(rng.integers(0, 101))
     sc = SynthCircuit(db, seed=int(rng.integers(1, 1 << 30)), poseidon_percent=pct, witness_seed=int(rng.integers(1, 1 << 30)), flags=flags)
@@ -42,6 +42,24 @@ while time.time() < t_end:
         sc.desc.cap_height = int(rng.choice([0, 1, 2, 3]))
     if rng.random() < 0.3:
         sc.desc.num_query_rounds = int(rng.choice([1, 5, 40]))
+    # values the caller holds (vx_circuit_desc tail, round 2): a caller-supplied digest / FRI arity list / num_partial_products
+    overrides = ""
+    if rng.random() < 0.25:
+        sc.set_circuit_digest([int(x) for x in rng.integers(0, 1 << 62, 4)])
+        overrides += "D"
+    if rng.random() < 0.25:
+        ar, left = [], db
+        while left > 0 and len(ar) < 6 and rng.random() < 0.8:
+            a = int(rng.integers(1, min(4, left) + 1))
+            if db + 3 - sum(ar) - a < sc.desc.cap_height:
+                break
+            ar.append(a)
+            left -= a
+        sc.set_fri_reduction_arity_bits(ar)
+        overrides += "A"
+    if rng.random() < 0.25:
+        sc.set_num_partial_products(9)
+        overrides += "P"
     world = int(rng.choice([1, 1, 2, 4, 8]))
     if world > (1 << sc.desc.cap_height):
         world = 1 << sc.desc.cap_height
@@ -62,14 +80,14 @@ while time.time() < t_end:
         ok = False
     except vx.VxError:
         pass
-    key = f"flags{flags}/world{world}"
+    key = f"flags{flags}/world{world}" + (f"/{overrides}" if overrides else "")
     by_kind[key] = by_kind.get(key, 0) + 1
     if ok:
         n_ok += 1
     else:
         n_bad += 1
         print(json.dumps({"FAIL": {"degree_bits": db, "flags": flags, "pct": pct, "world": world, "pow_bits": sc.desc.pow_bits,
-                                   "nch": sc.desc.num_challenges, "cap_height": sc.desc.cap_height, "queries": sc.desc.num_query_rounds}}), flush=True)
+                                   "nch": sc.desc.num_challenges, "cap_height": sc.desc.cap_height, "queries": sc.desc.num_query_rounds, "overrides": overrides}}), flush=True)
     for c in cs:
         c.free()
     oc.free()

@@ -306,8 +306,9 @@ __global__ __launch_bounds__(256, VX_QUOTIENT_BLOCKS) void quotient_kernel(Quoti
           return in;
         };
 #pragma unroll 1
-        for (int blk = 0; blk < POSEIDON_NBLOCKS - 1; ++blk, r0 += 3) poseidon_partial_block_g<3>(st, POSEIDON_BLK.kappa[blk], POSEIDON_BLK.K[blk], sbox, lane0);
-        poseidon_partial_block_g<1>(st, POSEIDON_BLK.kappa[POSEIDON_NBLOCKS - 1], POSEIDON_BLK.K[POSEIDON_NBLOCKS - 1], sbox, lane0);
+        for (int blk = 0; blk < POSEIDON_NBLOCKS - 1; ++blk, r0 += POSEIDON_BLOCK_B)
+          poseidon_partial_block_g<POSEIDON_BLOCK_B>(st, POSEIDON_BLK.kappa[blk], POSEIDON_BLK.K[blk], sbox, lane0);
+        poseidon_partial_block_g<2>(st, POSEIDON_BLK.kappa[POSEIDON_NBLOCKS - 1], POSEIDON_BLK.K[POSEIDON_NBLOCKS - 1], sbox, lane0);
       }
       round += 22;
 #pragma unroll 1

@@ -99,6 +99,23 @@ GLD u64 mds_fold_nc(u64 al, u64 ah) {
   return gl_pack(l2, h2);
 }
 
+// The same fold for accumulators of ANY size below 2^64 (the final layer of a block of 4 partial rounds reaches 2^63.8):
+//   X = ah_hi * EPS + al may carry (cX), adding ah_lo * 2^32 may carry (c2); each lost 2^64 is worth EPS, so
+//   Y = (cX + c2) * EPS + wrapped value — one more v_mad_u64_u32 — whose own carry is fixed by a last + EPS (the wrapped
+//   Y is < 2^34 then, so that cannot overflow).  8 VALU instructions.
+GLD u64 mds_fold_wide_nc(u64 al, u64 ah) {
+  const u32 eps = 0xFFFFFFFFu;
+  u64 X, cX, c2, cj, Y, c3;
+  asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(X), "=s"(cX) : "v"((u32)(ah >> 32)), "v"(eps), "v"(al));
+  u32 h, k, d;
+  asm("v_add_co_u32_e64 %0, %1, %2, %3" : "=v"(h), "=s"(c2) : "v"((u32)(X >> 32)), "v"((u32)ah));
+  asm("v_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(k) : "s"(c2));
+  asm("v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(k), "=s"(cj) : "v"(k), "s"(cX));
+  asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(Y), "=s"(c3) : "v"(k), "v"(eps), "v"(gl_pack((u32)X, h)));
+  asm("v_cndmask_b32_e64 %0, 0, -1, %1" : "=v"(d) : "s"(c3));
+  return Y + (u64)d;
+}
+
 // Dense MDS layer: out[r] = sum_i CIRC[i] * v[(i+r) % 12] + DIAG[r]*v[r]; entries < 2^6, so the low and
 // high 32-bit halves are accumulated separately (< 2^42 each) and folded once:  lo + hi*2^32 (mod p).
 GLD void poseidon_mds_nc(u64 (&s)[12]) {
@@ -203,17 +220,21 @@ GLD u64 dot3_reduce_add_nc(const dot3& D, u64 addend) {
 //   state after the block:    u'  = M Q^(B-1) w  +  sum_{1<=i<B} y_i (M Q^(B-1-i)) e_0  +  K
 // (lane 0 is REPLACED by the S-box output before each layer, hence Q: no subtraction appears).  kappa_j and K collect the
 // round constants (K also those of the round that follows the block) and ride in as the accumulators' initial values.
-// B = 3: entries of M Q^2 < 2^20.4, every accumulator < 2^57.  (B = 4 still fits 32-bit multipliers — row sums
-// < 2^31.72 — but its accumulators reach 2^63.7 and the fold needs a second carry fix; measured gain would be ~2 %.)
+// Schedule: 5 blocks of 4 + 1 block of 2.  B = 4 is the longest block whose coefficients still fit 32-bit multipliers
+// (entries of M Q^3 < 2^28.3) and whose accumulators still fit 64 bits (row sums incl. the y terms < 2^31.72 — checked by
+// static_assert below); the final layer's accumulators then reach 2^63.8 and are folded by mds_fold_wide_nc.  B = 5 would
+// need 37-bit coefficients.
 // Equivalence to the naive rounds is exact integer algebra mod p; tests: the permutation KATs, 2.4 M iterated
 // permutations against the oracle, every Merkle / proof parity test.
-#define POSEIDON_NBLOCKS 8
-constexpr int POSEIDON_SCHED[POSEIDON_NBLOCKS] = {3, 3, 3, 3, 3, 3, 3, 1};
+#define POSEIDON_NBLOCKS 6
+#define POSEIDON_BLOCK_B 4
+constexpr int POSEIDON_SCHED[POSEIDON_NBLOCKS] = {4, 4, 4, 4, 4, 2};
 struct PoseidonIntBlock {
-  u32 A[3][12];   // A[j][i]: coefficient of w_i in x_j   (1 <= j < B)
-  u32 b[3][3];    // b[j][i]: coefficient of y_i in x_j   (1 <= i < j)
+  u32 A[4][12];   // A[j][i]: coefficient of w_i in x_j   (1 <= j < B)
+  u32 b[4][4];    // b[j][i]: coefficient of y_i in x_j   (1 <= i < j)
   u32 C[12][12];  // M Q^(B-1)
-  u32 c[3][12];   // c[i][r]: coefficient of y_i in u'_r  (1 <= i < B)
+  u32 c[4][12];   // c[i][r]: coefficient of y_i in u'_r  (1 <= i < B)
+  u64 max_row_sum;  // max over rows of sum_i C[r][i] + sum_i c[i][r]: bounds the accumulators
 };
 struct PoseidonMat {
   u64 m[12][12];
@@ -255,12 +276,25 @@ constexpr PoseidonIntBlock make_int_block(int B) {
     const PoseidonMat X = poseidon_mat_mul(M, poseidon_q_pow(B - 1 - i));
     for (int r = 0; r < 12; ++r) T.c[i][r] = (u32)X.m[r][0];
   }
+  T.max_row_sum = 0;
+  for (int r = 0; r < 12; ++r) {
+    u64 sum = 0;
+    for (int i = 0; i < 12; ++i) sum += CC.m[r][i];
+    for (int i = 1; i < B; ++i) sum += T.c[i][r];
+    if (sum > T.max_row_sum) T.max_row_sum = sum;
+  }
+  for (int r = 0; r < 12; ++r)
+    for (int i = 0; i < 12; ++i)
+      if (CC.m[r][i] >> 32) T.max_row_sum = ~(u64)0;  // a coefficient that does not fit a 32-bit multiplier: unusable block length
   return T;
 }
+// every accumulator is sum_i c_i * (32-bit half) + (32-bit constant half) <= max_row_sum * (2^32 - 1) + 2^32 - 1 < 2^64
+static_assert(make_int_block(POSEIDON_BLOCK_B).max_row_sum < ((u64)1 << 32) - 1, "block too long: the accumulators would overflow 64 bits");
+static_assert(make_int_block(2).max_row_sum < ((u64)1 << 25), "block of 2: simple fold range");
 // Round constants of the blocks: kappa[blk][j] (S-box input of the block's round j >= 1) and K[blk][r] (state after the
 // block, INCLUDING the constants of the round that follows it).
 struct PoseidonBlockConsts {
-  u64 kappa[POSEIDON_NBLOCKS][3];
+  u64 kappa[POSEIDON_NBLOCKS][4];
   u64 K[POSEIDON_NBLOCKS][12];
   u64 Ksplit[POSEIDON_NBLOCKS][12][2];  // {low dword, high dword} of K: accumulator seeds for the asm MDS rows
 };
@@ -297,8 +331,8 @@ constexpr PoseidonBlockConsts make_block_consts() {
   }
   return R;
 }
-static_assert(POSEIDON_SCHED[0] + POSEIDON_SCHED[1] + POSEIDON_SCHED[2] + POSEIDON_SCHED[3] + POSEIDON_SCHED[4] + POSEIDON_SCHED[5] +
-                      POSEIDON_SCHED[6] + POSEIDON_SCHED[7] == 22, "the blocks must cover the 22 partial rounds");
+static_assert(POSEIDON_SCHED[0] + POSEIDON_SCHED[1] + POSEIDON_SCHED[2] + POSEIDON_SCHED[3] + POSEIDON_SCHED[4] + POSEIDON_SCHED[5] == 22,
+              "the blocks must cover the 22 partial rounds");
 __constant__ PoseidonBlockConsts POSEIDON_BLK = make_block_consts();
 // round constants with one all-zero round appended, so "the constants of the next round" exists after round 29 too; stored
 // pre-split — {low dword, high dword} as two u64 — because each half seeds its own 64-bit accumulator: a scalar load puts
@@ -365,7 +399,8 @@ GLD void poseidon_partial_block_g(u64 (&s)[12], const u64* __restrict__ kappa, c
     for (int i = 0; i < 12; ++i) poseidon_mac32(al, ah, s[i], T.C[r][i]);
 #pragma unroll
     for (int i = 1; i < B; ++i) poseidon_mac32(al, ah, y[i], T.c[i][r]);
-    out[r] = mds_fold_nc(al, ah);  // al, ah < 2^57
+    // B <= 3: al, ah < 2^57 and the 5-instruction fold applies; B = 4: up to 2^63.8, the fold must survive two carries
+    out[r] = B >= 4 ? mds_fold_wide_nc(al, ah) : mds_fold_nc(al, ah);
   }
 #pragma unroll
   for (int r = 0; r < 12; ++r) s[r] = out[r];
@@ -386,17 +421,8 @@ GLD void poseidon_permute_nc(u64 (&s)[12]) {
     poseidon_mds_rc_nc(s, r + 1);
   }
 #pragma unroll 1
-  for (int blk = 0; blk < POSEIDON_NBLOCKS - 1; ++blk) poseidon_partial_block_nc<3>(s, POSEIDON_BLK.kappa[blk], POSEIDON_BLK.K[blk]);
-  {  // the 22nd partial round on its own (block of 1): S-box on lane 0, then a dense layer seeded with K (asm rows)
-    s[0] = poseidon_sbox_fx(s[0]);
-    u32 lo[12], hi[12];
-#pragma unroll
-    for (int i = 0; i < 12; ++i) {
-      lo[i] = (u32)s[i];
-      hi[i] = (u32)(s[i] >> 32);
-    }
-    poseidon_mds_rows_asm(s, lo, hi, POSEIDON_BLK.Ksplit[POSEIDON_NBLOCKS - 1]);
-  }
+  for (int blk = 0; blk < POSEIDON_NBLOCKS - 1; ++blk) poseidon_partial_block_nc<POSEIDON_BLOCK_B>(s, POSEIDON_BLK.kappa[blk], POSEIDON_BLK.K[blk]);
+  poseidon_partial_block_nc<2>(s, POSEIDON_BLK.kappa[POSEIDON_NBLOCKS - 1], POSEIDON_BLK.K[POSEIDON_NBLOCKS - 1]);
 #pragma unroll 1
   for (int r = 26; r < 30; ++r) {
 #pragma unroll

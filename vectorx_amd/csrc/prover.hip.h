@@ -202,7 +202,9 @@ static size_t proof_size_bound(const vx_circuit* k) {
   size_t widths = (size_t)k->num_constants + k->nr + k->num_wires + (size_t)k->nch * (1 + k->npp() + k->nlp()) + (size_t)k->nch * k->qdf;
   size_t open = 16 * (widths + k->nch * (1 + k->nlp()));
   size_t per_query = 8 * widths + 4 * (1 + 32 * depth0) + k->arity_bits.size() * (16 * 16 + 1 + 32 * depth0);
-  return (3 + k->arity_bits.size()) * cap + open + k->num_queries * per_query + 16 * 256 + 8 + 8 * k->pi_rows.size() + 4096;
+  size_t final_len = k->n();  // final polynomial: n >> (sum of the reduction arities) coefficients in F_p^2 (caller-supplied arities may leave it long)
+  for (int ab : k->arity_bits) final_len >>= ab;
+  return (3 + k->arity_bits.size()) * cap + open + k->num_queries * per_query + 16 * final_len + 8 + 8 * k->pi_rows.size() + 4096;
 }
 
 // One device scratch allocation that is returned to the pool when the proof ends.
