@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256, 4) void k_seq(WaveStamp* stamps, uint64_t* sin
       for (int i = 0; i < 12; ++i) s[i] = poseidon_sbox_nc_v2(s[i]);
     }
     if (SEQ == SEQ_MDS_RC) poseidon_mds_rc_nc(s, it & 15);
-    if (SEQ == SEQ_BLOCK3) poseidon_partial_block_nc<3>(s, POSEIDON_BLK.kappa[it & 3], POSEIDON_BLK.K[it & 3]);
+    if (SEQ == SEQ_BLOCK3) poseidon_partial_block_nc<POSEIDON_BLOCK_B>(s, POSEIDON_BLK.kappa[it & 3], POSEIDON_BLK.K[it & 3]);
     if (SEQ == SEQ_MDS) poseidon_mds_nc(s);
     if (SEQ == SEQ_PERM) poseidon_permute_nc(s);
     if (SEQ == SEQ_ADD_NC) {
@@ -420,7 +420,7 @@ int main() {
   run_seq<SEQ_MUL_V2>("gl_mul_nc_v2 = one asm block (per multiply)", 12, 1024, "muls");
   run_seq<SEQ_SBOX>("poseidon_sbox_nc x^7 (per S-box)", 12, 512, "sboxes");
   run_seq<SEQ_MDS_RC>("poseidon_mds_rc_nc, constants folded (per 12x12 layer)", 1, 1024, "layers");
-  run_seq<SEQ_BLOCK3>("poseidon_partial_block_nc<3> (per block of 3 partial rounds)", 1, 512, "blocks");
+  run_seq<SEQ_BLOCK3>("poseidon_partial_block_nc<4> (per block of 4 partial rounds)", 1, 512, "blocks");
   run_seq<SEQ_SBOX_V2>("x^7 on gl_mul_nc_v2 (per S-box)", 12, 512, "sboxes");
   run_seq<SEQ_MDS>("poseidon_mds_nc (per 12x12 layer)", 1, 1024, "layers");
   run_seq<SEQ_PERM>("poseidon_permute_nc (per permutation)", 1, 64, "perms");

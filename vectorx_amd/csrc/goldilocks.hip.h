@@ -15,32 +15,51 @@ typedef uint32_t u32;
 
 #define GLD __device__ __forceinline__
 
-GLD u64 gl_canon(u64 x) { return x >= GL_P ? x - GL_P : x; }
 
 // ---- instruction-count-minimal building blocks (gfx950: every VOP3 / multiply-class instruction costs
 // about the same issue time, so fewer instructions is the only lever; see tools/ubench_int.hip).
 // Carries travel in SGPR pairs (lane masks) produced / consumed by the *_co instructions, which hipcc does
 // not use on its own for 64-bit compare-and-fix sequences.
 GLD u64 gl_pack(u32 lo, u32 hi) { return ((u64)hi << 32) | lo; }
+// x + d (mod 2^64) for a 32-bit d held in one VGPR: v_mad_u64_u32 with the inline multiplier 1 takes the 32-bit
+// operand as it is — the 64-bit add forms need it widened into an aligned register pair (a zero and often a move)
+GLD u64 gl_add32(u64 x, u32 d) {
+  u64 r, c;
+  asm("v_mad_u64_u32 %0, %1, %2, 1, %3" : "=v"(r), "=s"(c) : "v"(d), "v"(x));
+  return r;
+}
+
+// x - p = x + EPS (mod 2^64): one compare, one select of the 32-bit addend, one 64-bit add
+GLD u64 gl_canon(u64 x) {
+  u32 d0;
+  asm("v_cndmask_b32_e64 %0, 0, -1, %1" : "=v"(d0) : "s"(__builtin_amdgcn_uicmpl(x, 0xFFFFFFFF00000001ULL, 35 /* ICMP_UGE */)));
+  return gl_add32(x, d0);
+}
 
 // a, b canonical  ->  (a + b) mod p, canonical.   S = a+b in [0, 2p-2];  S >= p  <=>  a carry out of
 // (a+b) or of (a+b)+EPS;  in that case the answer is (S + EPS) mod 2^64.
 GLD u64 gl_add(u64 a, u64 b) {
-  u32 s0, s1, t0, t1;
-  u64 c0, c1, c2, c3;
+  u32 s0, s1, d0;
+  u64 c0, c1;
   asm("v_add_co_u32_e64 %0, %1, %2, %3" : "=v"(s0), "=s"(c0) : "v"((u32)a), "v"((u32)b));
   asm("v_addc_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(s1), "=s"(c1) : "v"((u32)(a >> 32)), "v"((u32)(b >> 32)), "s"(c0));
-  asm("v_add_co_u32_e64 %0, %1, %2, -1" : "=v"(t0), "=s"(c2) : "v"(s0));
-  asm("v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(t1), "=s"(c3) : "v"(s1), "s"(c2));
-  const u64 sel = c1 | c3;
-  u32 r0, r1;
-  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r0) : "v"(s0), "v"(t0), "s"(sel));
-  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r1) : "v"(s1), "v"(t1), "s"(sel));
-  return gl_pack(r0, r1);
+  const u64 s = gl_pack(s0, s1);
+  // S >= p  <=>  carry out, or no carry and s >= p; either way the answer is s + EPS (mod 2^64): 5 VALU
+  const u64 m = c1 | __builtin_amdgcn_uicmpl(s, (u64)GL_P, 35 /* ICMP_UGE */);
+  asm("v_cndmask_b32_e64 %0, 0, -1, %1" : "=v"(d0) : "s"(m));
+  return gl_add32(s, d0);
 }
+// a, b canonical -> (a - b) mod p, canonical: on a borrow the wrapped difference plus p (= minus EPS mod 2^64) is the
+// answer; the borrow of the subtraction itself selects it (5 VALU; hipcc's form re-compares the operands: 6)
 GLD u64 gl_sub(u64 a, u64 b) {
-  u64 d = a - b;
-  return a < b ? d + GL_P : d;  // wrapped d + p == a - b + p (mod 2^64)
+  u32 d0, d1, m, r0, r1;
+  u64 b0, bw, b2, b3;
+  asm("v_sub_co_u32_e64 %0, %1, %2, %3" : "=v"(d0), "=s"(b0) : "v"((u32)a), "v"((u32)b));
+  asm("v_subb_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(d1), "=s"(bw) : "v"((u32)(a >> 32)), "v"((u32)(b >> 32)), "s"(b0));
+  asm("v_cndmask_b32_e64 %0, 0, -1, %1" : "=v"(m) : "s"(bw));
+  asm("v_sub_co_u32_e64 %0, %1, %2, %3" : "=v"(r0), "=s"(b2) : "v"(d0), "v"(m));
+  asm("v_subbrev_co_u32_e64 %0, %1, 0, %2, %3" : "=v"(r1), "=s"(b3) : "v"(d1), "s"(b2));
+  return gl_pack(r0, r1);
 }
 GLD u64 gl_neg(u64 a) { return a ? GL_P - a : 0; }
 GLD u64 gl_dbl(u64 a) { return gl_add(a, a); }
@@ -59,7 +78,28 @@ GLD void gl_mul128(u64 a, u64 b, u64& lo, u64& hi) {
 //   (T, cT) = hl*EPS + lo  in one v_mad_u64_u32 with carry-out;  u = T - hh with borrow bw;
 //   result = u + (cT - bw)*EPS  (mod 2^64): the four (cT, bw) cases are exact — when both are set the wrapped
 //   u already equals T + 2^64 - hh, a valid representative because 2^64 = EPS (mod p).
-GLD u64 gl_reduce128_nc(u64 lo, u64 hi) {
+// CANON: the canonical value costs ONE more instruction, not a separate conditional subtraction: with a carry
+// (cT) the corrected value is already < p (T_wrapped < (2^32-1)^2, so T_wrapped - hh + EPS < p when there is no
+// borrow, and T_wrapped + EPS - hh < EPS when there is); with a borrow alone it is in (p - 2^32, p); only the
+// no-carry-no-borrow case can leave u >= p, and subtracting p is adding EPS (mod 2^64) — the same addend as the
+// carry case, so the compare just widens that lane mask.
+template <bool CANON>
+GLD u64 gl_fix_reduce(u32 u0, u32 u1, u64 cT, u64 bw) {
+  const u64 u = gl_pack(u0, u1);
+  u64 m1 = cT & ~bw;
+  const u64 m2 = bw & ~cT;  // +EPS  /  -EPS (= + 0xFFFFFFFF00000001)
+  if (CANON) m1 = cT | (__builtin_amdgcn_uicmpl(u, (u64)GL_P, 35 /* ICMP_UGE */) & ~bw);
+  u32 d0, d1;
+  asm("v_cndmask_b32_e64 %0, 0, -1, %1" : "=v"(d0) : "s"(m1));
+  asm("v_cndmask_b32_e64 %0, %1, 1, %2" : "=v"(d0) : "v"(d0), "s"(m2));
+  asm("v_cndmask_b32_e64 %0, 0, -1, %1" : "=v"(d1) : "s"(m2));
+  const u64 r = gl_add32(u, d0);
+  u32 r1;  // the high dword of the addend only touches the high dword of the sum: a plain 32-bit add
+  asm("v_add_u32_e32 %0, %1, %2" : "=v"(r1) : "v"((u32)(r >> 32)), "v"(d1));
+  return gl_pack((u32)r, r1);
+}
+template <bool CANON>
+GLD u64 gl_reduce128_t(u64 lo, u64 hi) {
   const u32 hh = (u32)(hi >> 32), hl = (u32)hi;
   u64 T, cT, b0, bw;
   const u32 eps = 0xFFFFFFFFu;
@@ -67,22 +107,18 @@ GLD u64 gl_reduce128_nc(u64 lo, u64 hi) {
   u32 u0, u1;
   asm("v_sub_co_u32_e64 %0, %1, %2, %3" : "=v"(u0), "=s"(b0) : "v"((u32)T), "v"(hh));
   asm("v_subbrev_co_u32_e64 %0, %1, 0, %2, %3" : "=v"(u1), "=s"(bw) : "v"((u32)(T >> 32)), "s"(b0));
-  const u64 m1 = cT & ~bw, m2 = bw & ~cT;  // +EPS  /  -EPS (= + 0xFFFFFFFF00000001)
-  u32 d0, d1;
-  asm("v_cndmask_b32_e64 %0, 0, -1, %1" : "=v"(d0) : "s"(m1));
-  asm("v_cndmask_b32_e64 %0, %1, 1, %2" : "=v"(d0) : "v"(d0), "s"(m2));
-  asm("v_cndmask_b32_e64 %0, 0, -1, %1" : "=v"(d1) : "s"(m2));
-  return gl_pack(u0, u1) + gl_pack(d0, d1);
+  return gl_fix_reduce<CANON>(u0, u1, cT, bw);
 }
+GLD u64 gl_reduce128_nc(u64 lo, u64 hi) { return gl_reduce128_t<false>(lo, hi); }
 // x = hi*2^64 + lo  ->  x mod p (canonical)
-GLD u64 gl_reduce128(u64 lo, u64 hi) { return gl_canon(gl_reduce128_nc(lo, hi)); }
+GLD u64 gl_reduce128(u64 lo, u64 hi) { return gl_reduce128_t<true>(lo, hi); }
 // Fused multiply(-add)-reduce, 16 (18) VALU instructions, no register-pair shuffling:
 //   a*b (+c) = p00 + (p10 + cM*2^64)*2^32 + p11*2^64   with p10 = a1*b0 + a0*b1 (carry-out cM),
 //   lo64 = p00 + (p10 mod 2^32)*2^32,  hi64 = p11 + (p10 >> 32) + carries = hh*2^32 + hl,
 //   result = lo64 + hl*EPS - (hh + cM)       (2^64 = EPS, 2^96 = -1 mod p; cM rides in as the borrow-in
 //   of the final subtraction), fixed up exactly as in gl_reduce128_nc.
-template <bool WITH_ADDEND>
-GLD u64 gl_mulmad_nc(u64 a, u64 b, u64 c) {
+template <bool WITH_ADDEND, bool CANON>
+GLD u64 gl_mulmad_t(u64 a, u64 b, u64 c) {
   const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
   u64 p00, c0 = 0;
   if (WITH_ADDEND)
@@ -110,20 +146,15 @@ GLD u64 gl_mulmad_nc(u64 a, u64 b, u64 c) {
   u32 u0, u1;
   asm("v_subb_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(u0), "=s"(bb) : "v"((u32)T), "v"(hh), "s"(cM));
   asm("v_subbrev_co_u32_e64 %0, %1, 0, %2, %3" : "=v"(u1), "=s"(bw) : "v"((u32)(T >> 32)), "s"(bb));
-  const u64 m1 = cT & ~bw, m2 = bw & ~cT;
-  u32 d0, d1;
-  asm("v_cndmask_b32_e64 %0, 0, -1, %1" : "=v"(d0) : "s"(m1));
-  asm("v_cndmask_b32_e64 %0, %1, 1, %2" : "=v"(d0) : "v"(d0), "s"(m2));
-  asm("v_cndmask_b32_e64 %0, 0, -1, %1" : "=v"(d1) : "s"(m2));
-  return gl_pack(u0, u1) + gl_pack(d0, d1);
+  return gl_fix_reduce<CANON>(u0, u1, cT, bw);
 }
-GLD u64 gl_mul_nc(u64 a, u64 b) { return gl_mulmad_nc<false>(a, b, 0); }
-GLD u64 gl_mul(u64 a, u64 b) { return gl_canon(gl_mul_nc(a, b)); }
+GLD u64 gl_mul_nc(u64 a, u64 b) { return gl_mulmad_t<false, false>(a, b, 0); }
+GLD u64 gl_mul(u64 a, u64 b) { return gl_mulmad_t<false, true>(a, b, 0); }
 GLD u64 gl_sqr(u64 a) { return gl_mul(a, a); }
 // a*b + c (any u64 representatives) -> some representative
-GLD u64 gl_mad_nc(u64 a, u64 b, u64 c) { return gl_mulmad_nc<true>(a, b, c); }
+GLD u64 gl_mad_nc(u64 a, u64 b, u64 c) { return gl_mulmad_t<true, false>(a, b, c); }
 // a*b + c, canonical result
-GLD u64 gl_mad(u64 a, u64 b, u64 c) { return gl_canon(gl_mad_nc(a, b, c)); }
+GLD u64 gl_mad(u64 a, u64 b, u64 c) { return gl_mulmad_t<true, true>(a, b, c); }
 GLD u64 gl_pow(u64 b, u64 e) {
   u64 r = 1;
   while (e) {

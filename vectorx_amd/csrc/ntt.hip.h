@@ -51,6 +51,10 @@ GLD u64 root_pow24(const u64* __restrict__ lo, const u64* __restrict__ hi, u32 e
   // w_{2^24}^e
   return gl_mul(lo[e & 4095u], hi[(e >> 12) & 4095u]);
 }
+// the same root as SOME u64 representative: for values that only feed multiplications
+GLD u64 root_pow24_nc(const u64* __restrict__ lo, const u64* __restrict__ hi, u32 e) {
+  return gl_mul_nc(lo[e & 4095u], hi[(e >> 12) & 4095u]);
+}
 
 // LDS padding: one extra 8-byte word every 32 words keeps power-of-two strides conflict-free.
 GLD u32 lds_pad(u32 i) { return i + (i >> 5) + (i >> 9); }  // second level spreads the bit-reversed first-pass load (stride 2^9+)

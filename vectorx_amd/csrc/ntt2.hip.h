@@ -41,9 +41,12 @@ GLD u64 gl_mul_2exp(u64 x) {
     u64 T, cT;
     const u32 eps = 0xFFFFFFFFu;
     asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(T), "=s"(cT) : "v"(hi), "v"(eps), "v"(lo));
+    // carry: wrapped T < hi*EPS < 2^63, so T + EPS is the canonical value;  no carry: T < 2^64 may exceed p, and
+    // T - p = T + EPS (mod 2^64): one lane mask, one addend
+    const u64 m = cT | __builtin_amdgcn_uicmpl(T, (u64)GL_P, 35 /* ICMP_UGE */);
     u32 d0;
-    asm("v_cndmask_b32_e64 %0, 0, -1, %1" : "=v"(d0) : "s"(cT));
-    return gl_canon(T + (u64)d0);  // wrapped T < hi*EPS < 2^64 - 2^32: adding EPS cannot overflow
+    asm("v_cndmask_b32_e64 %0, 0, -1, %1" : "=v"(d0) : "s"(m));
+    return gl_add32(T, d0);
   } else if constexpr (S < 64) {
     return gl_reduce128(x << S, x >> (64 - S));
   } else {
@@ -261,8 +264,9 @@ __global__ __launch_bounds__(NTT2_THREADS) void ntt2_pass_kernel(Ntt2Params p) {
       for (int h = 0; h < 8; ++h) {
         const ulonglong2 v = src[h];                 // positions 2h, 2h+1 = rev4(q), rev4(q + 8) with q = rev3(h)
         const int q = (int)rev_c<3>((u32)h);
-        x[q] = gl_canon(v.x);
-        x[q + 8] = gl_canon(v.y);
+        // with a prescale the multiply that follows takes any u64 representative
+        x[q] = PRE ? v.x : gl_canon(v.x);
+        x[q + 8] = PRE ? v.y : gl_canon(v.y);
       }
       if constexpr (PRE) {
         // shift^j for j = ((base_low | q << LO) << b_lo) | l  =  shift^j0 * (shift^(n/16))^q: one composed table
@@ -270,10 +274,10 @@ __global__ __launch_bounds__(NTT2_THREADS) void ntt2_pass_kernel(Ntt2Params p) {
         const u64* pre = p.pre + (size_t)bz * (((size_t)1 << (p.log_n - p.pre_bits)) + ((size_t)1 << p.pre_bits));
         const u64* __restrict__ beta = p.pre_beta + (size_t)bz * 16;
         const size_t j0 = ((size_t)base_low << p.b_lo) | l;
-        const u64 c0 = gl_mul(pre[j0 >> p.pre_bits], pre[((size_t)1 << (p.log_n - p.pre_bits)) + (j0 & (((size_t)1 << p.pre_bits) - 1))]);
+        const u64 c0 = gl_mul_nc(pre[j0 >> p.pre_bits], pre[((size_t)1 << (p.log_n - p.pre_bits)) + (j0 & (((size_t)1 << p.pre_bits) - 1))]);
         x[0] = gl_mul(x[0], c0);
 #pragma unroll
-        for (int q = 1; q < 16; ++q) x[q] = gl_mul(x[q], gl_mul(c0, beta[q]));
+        for (int q = 1; q < 16; ++q) x[q] = gl_mul(x[q], gl_mul_nc(c0, beta[q]));
       }
     } else {
 #pragma unroll
@@ -291,11 +295,13 @@ __global__ __launch_bounds__(NTT2_THREADS) void ntt2_pass_kernel(Ntt2Params p) {
         j = base + (((size_t)t << R_LOG) | m);
         gi = IN_BITREV ? (size_t)bitrev32((u32)j, p.log_n) : j;
       }
-      u64 v = gl_canon(in[gi]);
+      u64 v = in[gi];
       if constexpr (PRE) {
         const u64* pre = p.pre + (size_t)bz * (((size_t)1 << (p.log_n - p.pre_bits)) + ((size_t)1 << p.pre_bits));
-        const u64 s = gl_mul(pre[j >> p.pre_bits], pre[((size_t)1 << (p.log_n - p.pre_bits)) + (j & (((size_t)1 << p.pre_bits) - 1))]);
+        const u64 s = gl_mul_nc(pre[j >> p.pre_bits], pre[((size_t)1 << (p.log_n - p.pre_bits)) + (j & (((size_t)1 << p.pre_bits) - 1))]);
         v = gl_mul(v, s);
+      } else {
+        v = gl_canon(v);
       }
       x[q] = v;
     }
@@ -325,7 +331,7 @@ __global__ __launch_bounds__(NTT2_THREADS) void ntt2_pass_kernel(Ntt2Params p) {
     auto root_at = [&](u64 ex) {
       u32 e = (u32)((ex & (((u64)1 << span_log) - 1)) << (ROOT_TABLE_LOG - span_log));
       if (INV) e = ((1u << ROOT_TABLE_LOG) - e) & ((1u << ROOT_TABLE_LOG) - 1);
-      return root_pow24(p.root_lo, p.root_hi, e);
+      return root_pow24_nc(p.root_lo, p.root_hi, e);  // only ever a factor of the products below
     };
     u64 step[1 << EL];
 #pragma unroll
@@ -340,12 +346,12 @@ __global__ __launch_bounds__(NTT2_THREADS) void ntt2_pass_kernel(Ntt2Params p) {
       for (int q = 0; q < (1 << EL); ++q) x[q] = tile[tile_idx<R_LOG, true>(m0 | (u32)q, t)];
       dft_regs<EL, INV>(x);
       u64 tw0 = root_at(l * (u64)bitrev32(m0, R_LOG));
-      if (p.post_scale != 1) tw0 = gl_mul(tw0, p.post_scale);
+      if (p.post_scale != 1) tw0 = gl_mul_nc(tw0, p.post_scale);
 #pragma unroll
       for (int q = 0; q < (1 << EL); ++q) {
         const u32 m = m0 | (u32)q;
         const u32 k = rev_c<EL>((u32)q);
-        const u64 tw = k ? gl_mul(tw0, step[k]) : tw0;
+        const u64 tw = k ? gl_mul_nc(tw0, step[k]) : tw0;
         out[base + ((size_t)m << p.b_lo) + t] = gl_mul(x[q], tw);
       }
     }
