@@ -160,8 +160,8 @@ size_t vx_merkle_digest_count(size_t n_leaves, int cap_height);
  * Every other gate is handed over as a constraint program (VX_GATE_PROGRAM below), which vx_circuit_create compiles
  * to native code; the recursive verifier's whole gate set has been exercised that way.  The lookup
  * argument (LookupGate / LookupTableGate, tables in the description's tail) is supported.  Limits: 64 gates per circuit,
- * degree_bits + rate_bits <= 24, quotient_degree_factor = 2^rate_bits (standard_recursion_config; every circuit with a
- * PoseidonGate has 8). */
+ * degree_bits + rate_bits <= 24, 1 <= quotient_degree_factor <= 2^rate_bits (CircuitConfig::max_quotient_degree_factor: 8 in
+ * standard_recursion_config, which is what plonky2x builds with; every gate's degree must be <= quotient_degree_factor + 1). */
 #define VX_GATE_NOOP 0
 #define VX_GATE_CONSTANT 1
 #define VX_GATE_PUBLIC_INPUT 2
@@ -175,7 +175,7 @@ typedef struct vx_circuit_desc {
   int32_t degree_bits;
   int32_t num_wires, num_routed_wires, num_challenges;  /* 135, 80, 2 */
   int32_t rate_bits, cap_height, pow_bits, num_query_rounds; /* 3, 4, 16, 28 */
-  int32_t quotient_degree_factor;                       /* 8 */
+  int32_t quotient_degree_factor;                       /* 8 (any value in [1, 2^rate_bits]) */
   int32_t num_gates;
   const int32_t* gate_types;       /* [num_gates], sorted by (degree, id) as CircuitBuilder::build does */
   const int32_t* gate_params;      /* ArithmeticGate: num_ops; ConstantGate: num_consts; else 0 */

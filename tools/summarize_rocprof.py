@@ -21,7 +21,7 @@ def main():
     rows = list(csv.DictReader(open(stats)))
     bench = json.loads(open(bench_json).read().strip().splitlines()[-1])
     L = [f"# {title}", "",
-         f"Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps {bench['steps']} --warmup {bench['warmup']} --no-cpu-baseline`",
+         f"Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps {bench['steps']} --warmup {bench['warmup']} --no-cpu-baseline --no-host-witness-leg`",
          f"(workload: {bench['config']['workload'][:160]}…)", "",
          f"bench.py line of the same run: value = {bench['value']:.4f} {bench['unit']}, ms_per_step = {bench['ms_per_step']:.2f}", "",
          "## Per-kernel totals (all dispatches of the run: circuit build + warmup + timed steps)", "",

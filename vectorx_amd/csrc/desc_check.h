@@ -39,7 +39,9 @@ static inline std::string desc_check(const vx_circuit_desc* d, bool need_preproc
   if (d->num_challenges < 1 || d->num_challenges > VX_MAX_CHALLENGES) return bad("num_challenges unsupported", d->num_challenges);
   if (d->num_gates < 1 || d->num_gates > VX_MAX_GATES) return bad("num_gates unsupported", d->num_gates);
   if (!d->gate_types || !d->gate_params || !d->selector_indices || !d->group_starts || !d->group_ends) return "circuit: NULL gate arrays";
-  if (d->quotient_degree_factor != (1 << d->rate_bits)) return bad("quotient_degree_factor must equal the blow-up (standard_recursion_config: 8)", d->quotient_degree_factor);
+  // CircuitConfig::max_quotient_degree_factor (8 in standard_recursion_config); prover.rs asserts log2_ceil(qdf) <= rate_bits
+  if (d->quotient_degree_factor < 1 || d->quotient_degree_factor > (1 << d->rate_bits))
+    return bad("quotient_degree_factor outside [1, 2^rate_bits]", d->quotient_degree_factor);
   if (d->num_wires < 1 || d->num_wires > 4096 || d->num_routed_wires < 1 || d->num_routed_wires > d->num_wires) return bad("bad wire counts", d->num_wires);
   const int chunks = (d->num_routed_wires + d->quotient_degree_factor - 1) / d->quotient_degree_factor;
   if (chunks > PERM_MAX_CHUNKS) return bad("too many partial-product chunks", chunks);
@@ -82,6 +84,14 @@ static inline std::string desc_check(const vx_circuit_desc* d, bool need_preproc
     if (t == VX_GATE_CONSTANT && (prm < 0 || prm > gate_consts || prm > d->num_wires)) return bad("ConstantGate num_consts exceeds the constants / wires", prm);
     if (t == VX_GATE_ARITHMETIC && (prm < 1 || 4 * (long long)prm > d->num_wires || gate_consts < 2)) return bad("ArithmeticGate ops exceed the wires, or fewer than 2 gate constants", prm);
     if (t == VX_GATE_POSEIDON && d->num_wires < 135) return bad("PoseidonGate needs 135 wires", d->num_wires);
+    {
+      // filtered constraint degree = Gate::degree() + (gates sharing the selector - 1) + (1 for the UNUSED factor when there
+      // are several selectors) must be <= quotient_degree_factor + 1 (gates/selectors.rs), or the quotient does not fit
+      // its quotient_degree_factor chunks
+      const int deg = t == VX_GATE_POSEIDON ? 7 : t == VX_GATE_ARITHMETIC ? 3 : (t == VX_GATE_CONSTANT || t == VX_GATE_PUBLIC_INPUT) ? 1 : t == VX_GATE_PROGRAM ? prm : 0;
+      const int filtered = deg + (d->group_ends[g] - d->group_starts[g] - 1) + (d->num_selectors > 1 ? 1 : 0);
+      if (filtered > d->quotient_degree_factor + 1) return bad("filtered constraint degree of a gate exceeds quotient_degree_factor + 1", g);
+    }
     if (t == VX_GATE_PUBLIC_INPUT && d->num_wires < 4) return bad("PublicInputGate needs 4 wires", d->num_wires);
     if (t == VX_GATE_PROGRAM) {
       ++nprog;

@@ -36,7 +36,7 @@ struct PermParams {
   u64* cp;
 };
 
-#define PERM_MAX_CHUNKS 16
+#define PERM_MAX_CHUNKS 40  /* ceil(80 routed wires / quotient_degree_factor 2) */
 __global__ __launch_bounds__(256) void perm_chunk_products_kernel(PermParams p) {
   size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= p.n) return;
@@ -357,6 +357,10 @@ struct ChunkParams {
   int nch, zc;  // u is laid out [rate/zc rank blocks][nch][zc][n] (zc = cosets per rank; rate when not sharded)
   u64 w_rate_inv_pows[VX_MAX_RATE];  // w_rate^(-k)
   u64 chunk_scale[VX_MAX_RATE];      // 7^(-nc) / 2^rb
+  // trim_to_len(quotient_degree_factor * n): only chunks [0, keep) of a challenge are written, t is [nch][keep][n];
+  // a nonzero coefficient in a dropped chunk (the vanishing polynomial is not divisible by Z_H) sets *tail_nonzero
+  int keep;
+  unsigned* tail_nonzero;
 };
 __global__ __launch_bounds__(256) void quotient_chunks_kernel(ChunkParams p) {
   const size_t n = (size_t)1 << p.log_n;
@@ -372,11 +376,16 @@ __global__ __launch_bounds__(256) void quotient_chunks_kernel(ChunkParams p) {
     int r = (int)bitrev32((u32)z, p.rb);
     U[r] = gl_mul(p.u[(((size_t)(z / p.zc) * p.nch + ch) * p.zc + (z % p.zc)) * n + pos], sc);
   }
+  bool tail = false;
   for (int c = 0; c < rate; ++c) {
     u64 acc = 0;
     for (int r = 0; r < rate; ++r) acc = gl_mad(U[r], p.w_rate_inv_pows[(r * c) & (rate - 1)], acc);
-    p.t[((size_t)ch * rate + c) * n + pos] = gl_mul(acc, p.chunk_scale[c]);
+    if (c < p.keep)
+      p.t[((size_t)ch * p.keep + c) * n + pos] = gl_mul(acc, p.chunk_scale[c]);
+    else
+      tail |= acc != 0;
   }
+  if (tail) atomicOr(p.tail_nonzero, 1u);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -967,6 +967,9 @@ static int prove_impl(vx_ctx* c, vx_circuit* k, const u64* wires_in, bool wires_
                   16.0 * Nl * nch));
     VXCHK(shard_allgather(c, sh, qu, (size_t)nch * Nl * 8, "quotient coset coefficients"));
     VXCHK(batch_alloc(c, lg, (size_t)nch * qdf, rb, k->cap_height, &quot_b, sh.rank, sh.lg));
+    unsigned* tail_flag = (unsigned*)S.get(1);
+    if (!tail_flag) return vx_fail(VX_E_NOMEM, "vx_prove: out of device memory");
+    HIPCHK(hipMemsetAsync(tail_flag, 0, 8, c->stream));
     {
       std::vector<u64> inv_shifts(rate);
       u64 wN = root_of_unity(LG);
@@ -984,6 +987,8 @@ static int prove_impl(vx_ctx* c, vx_circuit* k, const u64* wires_in, bool wires_
       cp.bits = bits;
       cp.nch = nch;
       cp.zc = zc;
+      cp.keep = qdf;  // quotient_poly.trim_to_len(quotient_degree_factor * n), then chunks(n)
+      cp.tail_nonzero = tail_flag;
       u64 wr_inv = inv(root_of_unity(rb)), pw = 1;
       for (int i = 0; i < rate; ++i) {
         cp.w_rate_inv_pows[i] = pw;
@@ -998,6 +1003,13 @@ static int prove_impl(vx_ctx* c, vx_circuit* k, const u64* wires_in, bool wires_
       ProfScope ps(c, "quotient_chunks", 16.0 * N * nch);
       hipLaunchKernelGGL(quotient_chunks_kernel, dim3((unsigned)((n + 255) / 256), nch), dim3(256), 0, c->stream, cp);
       HIPCHK(hipGetLastError());
+    }
+    if (qdf < rate) {
+      // plonky2: trim_to_len(..).expect("Quotient has failed, the vanishing polynomial is not divisible by Z_H")
+      unsigned flag = 0;
+      HIPCHK(hipMemcpyAsync(&flag, tail_flag, 4, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(hipStreamSynchronize(c->stream));
+      if (flag) return vx_fail(VX_E_PROOF, "vx_prove: the quotient has degree >= quotient_degree_factor * n (witness does not satisfy the circuit?)");
     }
     VXCHK(batch_lde_and_tree(c, quot_b));
   }

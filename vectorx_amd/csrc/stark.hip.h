@@ -235,8 +235,9 @@ static int stark_prove_impl(vx_ctx* c, const vx_stark_desc* d, const u64* trace_
     const u64 ninv = inv((u64)n % P);
     VXCHK(run_ntt(c, qv, qu, rows, rows, n, n, lg, nch, nz, true, true, nullptr, 0, ninv, "quotient_intt", 16.0 * rows * nch));
     VXCHK(batch_alloc(c, lg, (size_t)nch * sh.qdf, rb, d->cap_height, &quot_b));
-    u64* chunks = S.get((size_t)nch * nz * n);  // 2^qb chunks per challenge; only the first qdf are kept (the rest are zero)
-    if (!chunks) return vx_fail(VX_E_NOMEM, "stark: out of device memory (quotient chunks)");
+    unsigned* tail_flag = (unsigned*)S.get(1);
+    if (!tail_flag) return vx_fail(VX_E_NOMEM, "stark: out of device memory");
+    HIPCHK(hipMemsetAsync(tail_flag, 0, 8, c->stream));
     {
       std::vector<u64> inv_shifts(nz);
       const u64 wq = root_of_unity(lg + qb);
@@ -247,9 +248,11 @@ static int stark_prove_impl(vx_ctx* c, const vx_stark_desc* d, const u64* trace_
       ChunkParams cp;
       memset(&cp, 0, sizeof cp);
       cp.u = qu;
-      cp.t = chunks;
+      cp.t = quot_b->coeffs;
       cp.inv_tab = tab;
       cp.log_n = lg, cp.rb = qb, cp.bits = bits, cp.nch = nch, cp.zc = nz;
+      cp.keep = sh.qdf;  // trim_to_len(degree * quotient_degree_factor): chunks [0, qdf) of the 2^qb the transform yields
+      cp.tail_nonzero = tail_flag;
       u64 wr_inv = qb ? inv(root_of_unity(qb)) : 1, pw = 1;
       for (int i = 0; i < nz; ++i) {
         cp.w_rate_inv_pows[i] = pw;
@@ -265,18 +268,12 @@ static int stark_prove_impl(vx_ctx* c, const vx_stark_desc* d, const u64* trace_
       hipLaunchKernelGGL(quotient_chunks_kernel, dim3((unsigned)((n + 255) / 256), nch), dim3(256), 0, c->stream, cp);
       HIPCHK(hipGetLastError());
     }
-    // trim_to_len(degree * quotient_degree_factor): keep chunks [0, qdf) of every challenge
-    for (int cI = 0; cI < nch; ++cI)
-      HIPCHK(hipMemcpyAsync(quot_b->coeffs + (size_t)cI * sh.qdf * n, chunks + (size_t)cI * nz * n, (size_t)sh.qdf * n * 8, hipMemcpyDeviceToDevice, c->stream));
     if (sh.qdf < nz) {
       // the dropped chunks must be zero (deg quotient < qdf * n), else the trace does not satisfy the AIR
-      std::vector<u64> tail((size_t)(nz - sh.qdf) * n);
-      for (int cI = 0; cI < nch; ++cI) {
-        HIPCHK(hipMemcpyAsync(tail.data(), chunks + ((size_t)cI * nz + sh.qdf) * n, tail.size() * 8, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
-        for (u64 v : tail)
-          if (v) return vx_fail(VX_E_PROOF, "stark: quotient has degree >= quotient_degree_factor * n (trace does not satisfy the AIR?)");
-      }
+      unsigned flag = 0;
+      HIPCHK(hipMemcpyAsync(&flag, tail_flag, 4, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(hipStreamSynchronize(c->stream));
+      if (flag) return vx_fail(VX_E_PROOF, "stark: quotient has degree >= quotient_degree_factor * n (trace does not satisfy the AIR?)");
     }
     VXCHK(batch_lde_and_tree(c, quot_b));
   }

@@ -70,6 +70,8 @@ def _load():
         L.vxs_build2.argtypes = [ctypes.c_int, ctypes.c_uint64, ctypes.c_int, ctypes.c_uint64]
         L.vxs_build3.restype = ctypes.c_void_p
         L.vxs_build3.argtypes = [ctypes.c_int, ctypes.c_uint64, ctypes.c_int, ctypes.c_uint64, ctypes.c_int]
+        L.vxs_build4.restype = ctypes.c_void_p
+        L.vxs_build4.argtypes = [ctypes.c_int, ctypes.c_uint64, ctypes.c_int, ctypes.c_uint64, ctypes.c_int, ctypes.c_int]
         L.vxs_row_counts_ext.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         L.vxs_recursion_rows.restype = ctypes.c_uint64
         L.vxs_recursion_rows.argtypes = [ctypes.c_void_p]
@@ -91,10 +93,12 @@ class SynthCircuit:
     """A synthetic standard_recursion_config circuit with a satisfying witness."""
 
     def __init__(self, degree_bits: int, seed: int = 0, poseidon_percent: int = 50, witness_seed: int | None = None,
-                 flags: int = 0):
-        """`seed` fixes the circuit; `witness_seed` (default = seed) only the witness values; `flags`: FLAG_*."""
+                 flags: int = 0, quotient_degree_factor: int = 8):
+        """`seed` fixes the circuit; `witness_seed` (default = seed) only the witness values; `flags`: FLAG_*;
+        `quotient_degree_factor` (CircuitConfig::max_quotient_degree_factor, 3..8): below 7 the circuit has no PoseidonGate."""
         L = _load()
-        self._h = L.vxs_build3(degree_bits, seed, poseidon_percent, seed if witness_seed is None else witness_seed, flags)
+        self._h = L.vxs_build4(degree_bits, seed, poseidon_percent, seed if witness_seed is None else witness_seed, flags,
+                               quotient_degree_factor)
         if not self._h:
             raise ValueError("vxs_build rejected the parameters")
         self.degree_bits = degree_bits

@@ -64,6 +64,7 @@ struct GateInfo {
 
 struct Synth {
   int degree_bits;
+  int quotient_degree_factor = 8;
   size_t n;
   std::vector<int32_t> gate_types, gate_params, selector_indices, group_starts, group_ends, program_offsets;
   std::vector<u64> programs;
@@ -467,7 +468,10 @@ extern "C" {
 
 typedef struct vxs_circuit vxs_circuit;
 
-vxs_circuit* vxs_build3(int degree_bits, uint64_t seed, int poseidon_percent, uint64_t witness_seed, int flags);
+vxs_circuit* vxs_build4(int degree_bits, uint64_t seed, int poseidon_percent, uint64_t witness_seed, int flags, int quotient_degree_factor);
+vxs_circuit* vxs_build3(int degree_bits, uint64_t seed, int poseidon_percent, uint64_t witness_seed, int flags) {
+  return vxs_build4(degree_bits, seed, poseidon_percent, witness_seed, flags, 8);
+}
 vxs_circuit* vxs_build2(int degree_bits, uint64_t seed, int poseidon_percent, uint64_t witness_seed) {
   return vxs_build3(degree_bits, seed, poseidon_percent, witness_seed, 0);
 }
@@ -475,14 +479,23 @@ vxs_circuit* vxs_build(int degree_bits, uint64_t seed, int poseidon_percent) {
   return vxs_build3(degree_bits, seed, poseidon_percent, seed, 0);
 }
 
-vxs_circuit* vxs_build3(int degree_bits, uint64_t seed, int poseidon_percent, uint64_t witness_seed, int flags) {
-  if (degree_bits < 3 || degree_bits > 24 || poseidon_percent < 0 || poseidon_percent > 100) return nullptr;
+// quotient_degree_factor (CircuitConfig::max_quotient_degree_factor; 8 in standard_recursion_config) sets the selector
+// grouping (max_degree = qdf + 1: a gate of degree d shares a selector with its group, so d + 1 <= qdf + 1 once there is
+// more than one group) and the partial-product chunking.  A gate family that does not fit is refused, except the
+// PoseidonGate (degree 7): below 7 the circuit is built without it (row 2, which hashes the public inputs in a real
+// circuit, becomes a NoopGate row that merely carries the hash).
+vxs_circuit* vxs_build4(int degree_bits, uint64_t seed, int poseidon_percent, uint64_t witness_seed, int flags, int qdf) {
+  if (degree_bits < 3 || degree_bits > 24 || poseidon_percent < 0 || poseidon_percent > 100 || qdf < 3 || qdf > 8) return nullptr;
+  const bool has_poseidon = qdf >= 7;
+  if (!has_poseidon) poseidon_percent = 0;
+  if (((flags & VXS_FLAG_RECURSION_GATES) && qdf < 8) || ((flags & VXS_FLAG_MORE_PROGRAM_GATES) && qdf < 5)) return nullptr;
   const bool with_prog = flags & VXS_FLAG_PROGRAM_GATES, arith_prog = flags & VXS_FLAG_ARITH_AS_PROGRAM;
   const bool more_prog = flags & VXS_FLAG_MORE_PROGRAM_GATES, rec_prog = flags & VXS_FLAG_RECURSION_GATES;
   const bool with_lookup = flags & VXS_FLAG_LOOKUP;
   if ((with_prog && degree_bits < 4) || (more_prog && degree_bits < 5) || (rec_prog && degree_bits < 5) || (with_lookup && degree_bits < 5)) return nullptr;
   Synth* S = new Synth();
   S->degree_bits = degree_bits;
+  S->quotient_degree_factor = qdf;
   const size_t n = S->n = (size_t)1 << degree_bits;
   const int NW = 135, NR = 80;
   SplitMix rng{seed};
@@ -496,6 +509,7 @@ vxs_circuit* vxs_build3(int degree_bits, uint64_t seed, int poseidon_percent, ui
       {K_ARITH, arith_prog ? VX_GATE_PROGRAM : VX_GATE_ARITHMETIC, arith_prog ? 3 : 20, 3, "ArithmeticGate { num_ops: 20 }"},
       {K_POSEIDON, VX_GATE_POSEIDON, 0, 7, "PoseidonGate(PhantomData<plonky2_field::goldilocks_field::GoldilocksField>)<WIDTH=12>"},
   };
+  if (!has_poseidon) gates.pop_back();
   if (with_prog) {
     gates.push_back({K_ARITHEXT, VX_GATE_PROGRAM, 3, 3, "ArithmeticExtensionGate { num_ops: 10 }"});
     gates.push_back({K_BASESUM, VX_GATE_PROGRAM, 2, 2, "BaseSumGate { num_limbs: 63 } + Base: 2"});
@@ -522,8 +536,8 @@ vxs_circuit* vxs_build3(int degree_bits, uint64_t seed, int poseidon_percent, ui
   int idx_of[K_COUNT];
   for (int k = 0; k < K_COUNT; ++k) idx_of[k] = -1;
   for (int g = 0; g < ng; ++g) idx_of[gates[g].key] = g;
-  // gates/selectors.rs::selector_polynomials, max_degree = 9
-  const int max_degree = 9;
+  // gates/selectors.rs::selector_polynomials, max_degree = quotient_degree_factor + 1 (9 in the standard configuration)
+  const int max_degree = qdf + 1;
   std::vector<std::pair<int, int>> groups;
   if (gates.back().degree + ng - 1 <= max_degree) {
     groups.push_back({0, ng});
@@ -532,6 +546,7 @@ vxs_circuit* vxs_build3(int degree_bits, uint64_t seed, int poseidon_percent, ui
     while (start < ng) {
       int size = 0;
       while (start + size < ng && size + gates[start + size].degree < max_degree) ++size;
+      if (size == 0) { delete S; return nullptr; }  // a gate whose degree does not fit max_degree (checked above; plonky2 would not build it either)
       groups.push_back({start, start + size});
       start += size;
     }
@@ -599,7 +614,7 @@ vxs_circuit* vxs_build3(int degree_bits, uint64_t seed, int poseidon_percent, ui
   S->n_randacc = n_ra;
   size_t n_pos = rest * (size_t)poseidon_percent / 100;
   size_t n_arith = rest - n_pos;
-  S->n_poseidon = n_pos + 1;
+  S->n_poseidon = has_poseidon ? n_pos + 1 : 0;
   S->n_arith = n_arith;
   S->n_noop = n_noop;
   S->n_arithext = n_ext;
@@ -628,7 +643,7 @@ vxs_circuit* vxs_build3(int degree_bits, uint64_t seed, int poseidon_percent, ui
   w[0 * n + 1] = 0;
   w[1 * n + 1] = 1;
   // row 2: in-circuit hash of the public inputs
-  set_gate(2, K_POSEIDON);
+  set_gate(2, has_poseidon ? K_POSEIDON : K_NOOP);
   u64 in[12] = {0}, out[12];
   for (int i = 0; i < 4; ++i) in[i] = S->public_inputs[i];
   fill_poseidon_row(w, n, 2, in, out);
@@ -914,7 +929,7 @@ vxs_circuit* vxs_build3(int degree_bits, uint64_t seed, int poseidon_percent, ui
   d.cap_height = std::min(4, degree_bits + 3);
   d.pow_bits = 16;
   d.num_query_rounds = 28;
-  d.quotient_degree_factor = 8;
+  d.quotient_degree_factor = S->quotient_degree_factor;
   d.num_gates = ng;
   d.gate_types = S->gate_types.data();
   d.gate_params = S->gate_params.data();
