@@ -405,3 +405,38 @@ def test_proof_size_bound_covers_a_long_final_polynomial(ctx, oracle):
         assert gp == oracle_lib.OracleCircuit(oracle, sc.desc_ptr).prove(sc.witness())
         gc.verify(gp)
         gc.free()
+
+
+@pytest.mark.parametrize("degree_bits,flags,qdf", [(5, 0, 3), (6, 1, 4), (8, 16, 5), (9, 2 | 1, 6), (10, 16 | 1, 7), (12, 0, 4), (14, 16, 6),
+                                                   (7, 16 | 3, 7)])
+def test_quotient_degree_factor_below_the_blowup(ctx, oracle, degree_bits, flags, qdf):
+    """CircuitConfig::max_quotient_degree_factor < 8 (VERDICT r1 item 6): partial products in chunks of qdf wires, selector
+    groups for max_degree qdf + 1, lookup polynomials of degree qdf - 1, and qdf quotient chunks per challenge — the quotient is
+    still evaluated on the whole 8n domain and the chunk transform keeps the first qdf chunks (trim_to_len), failing like
+    plonky2 does when a dropped one is non-zero.  Byte-identical to the oracle; both verifiers accept."""
+    sc = SynthCircuit(degree_bits, seed=8000 + degree_bits, poseidon_percent=50, flags=flags, quotient_degree_factor=qdf)
+    sc.desc.pow_bits = 6
+    oc = oracle_lib.OracleCircuit(oracle, sc.desc_ptr)
+    gc = vx.Circuit(ctx, sc.desc_ptr)
+    assert (gc.digest() == oc.digest()).all() and (gc.constants_sigmas_cap() == oc.cap()).all()
+    w = sc.witness()
+    gp, op = gc.prove(w), oc.prove(w)
+    assert len(gp) == len(op)
+    assert gp == op
+    assert oc.verify(gp) == ""
+    gc.verify(gp)
+    assert len(gp) <= vx.lib().vx_proof_size_bound(gc._h)
+    # an unsatisfied witness is reported at prove time by both (the quotient does not fit qdf * n coefficients)
+    wb = w.copy()
+    wb[3, 9] = (int(wb[3, 9]) + 1) % P
+    with pytest.raises(vx.VxError) as e:
+        gc.prove(wb)
+    assert e.value.code == vx.VX_E_PROOF
+    with pytest.raises(RuntimeError):
+        oc.prove(wb)
+    # the proof of the next witness on the same handle is unaffected by the failed call
+    assert gc.prove(w) == gp
+    g2 = vx.Circuit.load(ctx, vx.circuit_serialize(sc.desc_ptr, gc.constants_sigmas_cap(), True))
+    assert g2.prove(w) == gp
+    g2.free()
+    gc.free()

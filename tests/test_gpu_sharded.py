@@ -256,3 +256,18 @@ def test_sharded_proof_with_lookup_argument(oracle, degree_bits, world, flags):
             assert p == expect
     finally:
         _free(ctxs, circuits)
+
+
+@pytest.mark.parametrize("degree_bits,world,flags,qdf", [(7, 2, 1, 4), (9, 8, 16, 5), (10, 4, 16 | 1, 7), (8, 4, 0, 3)])
+def test_sharded_proof_with_a_quotient_degree_factor_below_the_blowup(oracle, degree_bits, world, flags, qdf):
+    """every rank evaluates its cosets of the full 8n domain; the chunk transform trims to qdf chunks per challenge"""
+    sc = SynthCircuit(degree_bits, seed=2900 + degree_bits, poseidon_percent=40, flags=flags, quotient_degree_factor=qdf)
+    sc.desc.pow_bits = 6
+    w = sc.witness()
+    expect = oracle_lib.OracleCircuit(oracle, sc.desc_ptr).prove(w)
+    ctxs, circuits = _rank_circuits(sc, world)
+    try:
+        for p in sharded.prove_sharded_threads(circuits, w):
+            assert p == expect
+    finally:
+        _free(ctxs, circuits)
