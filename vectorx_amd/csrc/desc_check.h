@@ -63,6 +63,14 @@ static inline std::string desc_check(const vx_circuit_desc* d, bool need_preproc
     if (!d->lut_lens || !d->lut_inputs || !d->lut_outputs || !d->lookup_rows) return "circuit: NULL lookup table data";
     if (d->num_selectors + nls > d->num_constants) return bad("lookup selectors exceed num_constants", nls);
     if (d->num_routed_wires < 6 || d->quotient_degree_factor < 2) return "circuit: lookups need >= 6 routed wires and quotient_degree_factor >= 2";
+    {
+      // slot groups of the partial Sum / LDC polynomials (lookup_degree = quotient_degree_factor - 1 looking slots, the table
+      // slots spread evenly over the same number of polynomials) must fit the kernel's group buffers
+      const int lu_deg = d->quotient_degree_factor - 1, nsl = (d->num_routed_wires / 2 + lu_deg - 1) / lu_deg;
+      const int lut_deg = (d->num_routed_wires / 3 + nsl - 1) / nsl;
+      if (lu_deg > VX_LOOKUP_GROUP_MAX || lut_deg > VX_LOOKUP_GROUP_MAX) return bad("lookup slot group too large", lu_deg > lut_deg ? lu_deg : lut_deg);
+      if ((long long)d->num_challenges * (4 + d->num_luts + 2 * nsl) + 160 > VX_ALPHA_POWS) return bad("too many lookup constraint terms", nsl);
+    }
     const long long nrows = (long long)1 << d->degree_bits;
     for (int t = 0; t < d->num_luts; ++t) {
       if (d->lut_lens[t] < 1 || d->lut_lens[t] > (1 << 20)) return bad("bad lookup table length", d->lut_lens[t]);

@@ -629,9 +629,9 @@ __global__ __launch_bounds__(256) void lookup_terms_kernel(LookupParams p) {
         f[s2 - t0] = gl_sub(dalpha, gl_mad(da, LW(3 * s2 + 1), LW(3 * s2)));
         w[s2 - t0] = LW(3 * s2 + 2);
       }
-      lookup_group(f, w, t1 - t0, lut_prod, lut_sum);
+      lookup_group(f, w, max(t1 - t0, 0), lut_prod, lut_sum);   // a polynomial past the last table slot has an empty group: product 1, sum 0
       for (int s2 = u0; s2 < u1; ++s2) f[s2 - u0] = gl_sub(dalpha, gl_mad(da, LW(2 * s2 + 1), LW(2 * s2)));
-      lookup_group(f, nullptr, u1 - u0, lu_prod, lu_sum);
+      lookup_group(f, nullptr, max(u1 - u0, 0), lu_prod, lu_sum);
       const u64 prev = poly == 0 ? ZN(nsl) : Z(poly);
       const u64 d = gl_sub(Z(poly + 1), prev);
       push(gl_mul(sel[0], gl_sub(gl_mul(lut_prod, d), lut_sum)));   // Sum transition
