@@ -6,7 +6,7 @@ import pytest
 
 import oracle_lib
 import vectorx_amd as vx
-from stark_airs import cubic, fibonacci
+from stark_airs import cubic, fibonacci, mulchain
 
 pytestmark = pytest.mark.gpu
 P = oracle_lib.P
@@ -17,7 +17,8 @@ P = oracle_lib.P
                                                   (fibonacci, 9, dict(rate_bits=3, num_challenges=1, cap_height=2)),
                                                   (cubic, 5, dict(rate_bits=1)), (cubic, 9, dict(rate_bits=1)), (cubic, 11, dict(rate_bits=2)),
                                                   (cubic, 7, dict(rate_bits=3, num_query_rounds=10, fri_arities=[2, 3])),
-                                                  (fibonacci, 16, {})])
+                                                  (fibonacci, 16, {}), (mulchain, 6, dict(groups=1)), (mulchain, 10, dict(groups=5)),
+                                                  (mulchain, 13, dict(groups=8, rate_bits=2, num_query_rounds=40))])
 def test_stark_proof_bytes_identical_to_oracle(ctx, oracle, make, degree_bits, cfg):
     cfg = dict(pow_bits=8, **cfg)
     stark, trace, pis = make(degree_bits, **cfg)
@@ -57,3 +58,26 @@ def test_stark_violated_air_is_refused_or_rejected(ctx):
         return
     with pytest.raises(vx.VxError):
         stark.verify(pis, proof)
+
+
+def test_air_programs_are_compiled_to_native_code_and_match_the_interpreter(ctx, oracle):
+    """vx_stark_prove compiles the AIR program with hiprtc (jit.hip.h, the lowering gate programs use); VX_NO_JIT=1 keeps the
+    on-GPU interpreter.  Both give the oracle's proof, byte for byte; the profile names which one ran."""
+    import os
+    for make, lg in [(cubic, 10), (fibonacci, 11)]:
+        stark, trace, pis = make(lg, pow_bits=6)
+        expect = oracle_lib.stark_prove(oracle, stark, trace, pis)
+        ctx.prof_enable(True)
+        ctx.prof_reset()
+        assert stark.prove(ctx, trace, pis) == expect
+        stages = ctx.prof()
+        assert "air_quotient_eval_jit" in stages and "air_quotient_eval" not in stages, sorted(stages)
+        os.environ["VX_NO_JIT"] = "1"
+        try:
+            ctx.prof_reset()
+            assert stark.prove(ctx, trace, pis) == expect
+            stages = ctx.prof()
+            assert "air_quotient_eval" in stages and "air_quotient_eval_jit" not in stages, sorted(stages)
+        finally:
+            del os.environ["VX_NO_JIT"]
+            ctx.prof_enable(False)

@@ -7,14 +7,15 @@ import pytest
 
 import oracle_lib
 import vectorx_amd as vx
-from stark_airs import cubic, fibonacci
+from stark_airs import cubic, fibonacci, mulchain, mulmod
 
 P = oracle_lib.P
 
 
 @pytest.mark.parametrize("make,degree_bits,cfg", [(fibonacci, 3, {}), (fibonacci, 6, {}), (fibonacci, 9, dict(rate_bits=2, num_query_rounds=20)),
                                                   (cubic, 5, dict(rate_bits=1)), (cubic, 7, dict(rate_bits=3, num_query_rounds=10, fri_arities=[2, 3])),
-                                                  (fibonacci, 8, dict(num_challenges=1, cap_height=2, pow_bits=5))])
+                                                  (fibonacci, 8, dict(num_challenges=1, cap_height=2, pow_bits=5)),
+                                                  (mulchain, 6, dict(groups=3)), (mulchain, 8, dict(groups=2, rate_bits=2, num_query_rounds=30))])
 def test_oracle_stark_proofs_are_accepted_by_the_product_verifier(oracle, make, degree_bits, cfg):
     cfg = dict(pow_bits=6, **cfg) if "pow_bits" not in cfg else cfg
     stark, trace, pis = make(degree_bits, **cfg)
@@ -60,3 +61,12 @@ def test_stark_description_checks(oracle):
         assert e.value.code == vx.VX_E_INVALID, field
         setattr(stark.desc, field, old)
     stark.verify(pis, proof)
+
+
+def test_vectorised_mulmod_of_the_trace_generators():
+    import random
+    random.seed(3)
+    xs = [random.randrange(P) for _ in range(3000)] + [0, 1, P - 1, P - 2, 2**32, 2**32 - 1, 2**63, P - 2**32]
+    ys = [random.randrange(P) for _ in range(3000)] + [P - 1, P - 1, P - 1, P - 2, 2**32, 2**32 - 1, 2**63, P - 2**32]
+    r = mulmod(np.array(xs, dtype=np.uint64), np.array(ys, dtype=np.uint64))
+    assert all(int(r[i]) == xs[i] * ys[i] % P for i in range(len(xs)))

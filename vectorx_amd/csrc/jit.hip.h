@@ -81,17 +81,12 @@ static JitApi& jit_api() {
   return api;
 }
 
-// HIP source of one gate's block (the words up to and including VX_OP_END; already validated by circuit_create).
-static void jit_gate_block(std::ostringstream& s, const uint64_t* prog, int nch, int slot) {
-  s << "  {  // program gate, slot " << slot << "\n"
-       "    const JitGateRt G = p.g[" << slot << "];\n"
-       "    const u64 s = CS[(size_t)G.selector_index * N + i];\n"
-       "    u64 filter = 1;\n"
-       "    for (int q = G.group_start; q < G.group_end; ++q)\n"
-       "      if (q != G.gate_index) filter = gl_mul(filter, gl_sub((u64)q, s));\n"
-       "    if (nsel > 1) filter = gl_mul(filter, gl_sub(0xFFFFFFFFULL, s));\n"
-       "    u64 a0 = 0, a1 = 0;\n"
-       "    u64 R[64];\n";
+// Straight-line HIP source of one constraint program (the words up to VX_OP_END; already validated by the caller).
+//   air == false: a gate program — LDW / LDC / LDP read the row's wires, the gate constants and the public-input hash;
+//                 PUSH adds R[a] * alpha^k (k = position of the constraint) to a0 / a1.
+//   air == true:  an AIR program (stark.hip.h) — LDW / LDN read the local / next trace row, LDP a public input; PUSH
+//                 multiplies by the kind's factor (VX_AIR_*) and folds Horner-style, acc = acc * alpha + t.
+static void jit_emit_program(std::ostringstream& s, const uint64_t* prog, int nch, bool air) {
   // ---- decode, then two straight-line optimisations before emitting ----------------------------------------
   //  (1) multiply-add fusion: a MUL whose result is read exactly once, by an ADD, becomes one gl_mad at the ADD
   //      (the F_p^2 products the emitters produce are chains of exactly this shape);
@@ -103,6 +98,7 @@ static void jit_gate_block(std::ostringstream& s, const uint64_t* prog, int nch,
     const uint64_t ins = prog[pc];
     Ins I{(int)(ins & 0xFF), (int)((ins >> 8) & 63), (int)((ins >> 16) & 0xFFFF), (int)((ins >> 32) & 0xFFFF), 0, false, -1, -1};
     if (I.op == VX_OP_END) break;
+    if (I.op == VX_OP_PUSH) I.b = (int)((ins >> 32) & 0xFFFF);  // AIR: the constraint kind
     if (I.op == VX_OP_LDI) I.imm = vxh::canon(prog[++pc]);
     if (I.op == VX_OP_ADD || I.op == VX_OP_SUB || I.op == VX_OP_MUL) I.a &= 63, I.b &= 63;
     if (I.op == VX_OP_PUSH) I.a &= 63;
@@ -155,6 +151,7 @@ static void jit_gate_block(std::ostringstream& s, const uint64_t* prog, int nch,
     if (I.skip) continue;
     switch (I.op) {
       case VX_OP_LDW: s << "  R[" << I.dst << "] = gl_canon(W[(size_t)" << I.a << " * SW + il]);\n"; canon_reg[I.dst] = true; break;
+      case VX_OP_LDN: s << "  R[" << I.dst << "] = gl_canon(W[(size_t)" << I.a << " * SW + il_next]);\n"; canon_reg[I.dst] = true; break;
       case VX_OP_LDC: s << "  R[" << I.dst << "] = CS[(size_t)(cbase + " << I.a << ") * N + i];\n"; canon_reg[I.dst] = true; break;
       case VX_OP_LDI: s << "  R[" << I.dst << "] = " << I.imm << "ULL;\n"; canon_reg[I.dst] = true; break;
       case VX_OP_ADD:
@@ -176,14 +173,41 @@ static void jit_gate_block(std::ostringstream& s, const uint64_t* prog, int nch,
         break;
       case VX_OP_MUL: s << "  R[" << I.dst << "] = gl_mul_nc(R[" << I.a << "], R[" << I.b << "]);\n"; canon_reg[I.dst] = false; break;
       case VX_OP_PUSH:
-        s << "  a0 = gl_mad(R[" << I.a << "], AP[" << k << "], a0);\n";
-        if (nch > 1) s << "  a1 = gl_mad(R[" << I.a << "], AP[" << (VX_ALPHA_POWS + k) << "], a1);\n";
+        if (air) {
+          const char* factor = I.b == VX_AIR_TRANSITION ? "z_last" : I.b == VX_AIR_FIRST_ROW ? "l_first" : I.b == VX_AIR_LAST_ROW ? "l_last" : nullptr;
+          if (factor) s << "  { const u64 t = gl_mul_nc(R[" << I.a << "], " << factor << ");\n";
+          else s << "  { const u64 t = R[" << I.a << "];\n";
+          s << "    a0 = gl_mad(a0, p.alphas[0], t);\n";
+          if (nch > 1) s << "    a1 = gl_mad(a1, p.alphas[1], t);\n";
+          s << "  }\n";
+        } else {
+          s << "  a0 = gl_mad(R[" << I.a << "], AP[" << k << "], a0);\n";
+          if (nch > 1) s << "  a1 = gl_mad(R[" << I.a << "], AP[" << (VX_ALPHA_POWS + k) << "], a1);\n";
+        }
         ++k;
         break;
-      case VX_OP_LDP: s << "  R[" << I.dst << "] = p.pih[" << (I.a & 3) << "];\n"; canon_reg[I.dst] = true; break;
+      case VX_OP_LDP:
+        if (air) s << "  R[" << I.dst << "] = p.pi[" << I.a << "];\n";
+        else s << "  R[" << I.dst << "] = p.pih[" << (I.a & 3) << "];\n";
+        canon_reg[I.dst] = true;
+        break;
       default: break;
     }
   }
+}
+
+// HIP source of one gate's block inside vx_program_gates
+static void jit_gate_block(std::ostringstream& s, const uint64_t* prog, int nch, int slot) {
+  s << "  {  // program gate, slot " << slot << "\n"
+       "    const JitGateRt G = p.g[" << slot << "];\n"
+       "    const u64 s = CS[(size_t)G.selector_index * N + i];\n"
+       "    u64 filter = 1;\n"
+       "    for (int q = G.group_start; q < G.group_end; ++q)\n"
+       "      if (q != G.gate_index) filter = gl_mul(filter, gl_sub((u64)q, s));\n"
+       "    if (nsel > 1) filter = gl_mul(filter, gl_sub(0xFFFFFFFFULL, s));\n"
+       "    u64 a0 = 0, a1 = 0;\n"
+       "    u64 R[64];\n";
+  jit_emit_program(s, prog, nch, false);
   s << "    t0 = gl_mad(filter, a0, t0);\n";
   if (nch > 1) s << "    t1 = gl_mad(filter, a1, t1);\n";
   s << "  }\n";
@@ -233,6 +257,54 @@ extern "C" __global__ __launch_bounds__(256, VX_JIT_BLOCKS_PER_CU) void vx_progr
   return s.str();
 }
 
+// HIP source of the kernel that evaluates ONE AIR program on the quotient domain of a STARK (stark.hip.h
+// air_quotient_kernel is the interpreter with the same prologue; the argument block is AirParams, mirrored textually).
+static std::string jit_air_source(const uint64_t* prog, int nch) {
+  std::ostringstream s;
+  s << "typedef unsigned long long uint64_t;\ntypedef unsigned int uint32_t;\n#define VX_JIT_BLOCKS_PER_CU 4\n"
+    << JIT_PRELUDE << R"VXJIT(
+struct AirParams {
+  const u64* trace;
+  const u64* program;
+  size_t stride;
+  size_t rows;
+  int log_n, rate_bits, qbits, ncols, nch, npi;
+  const u64 *root_lo, *root_hi;
+  u64 alphas[2];
+  u64 pi[64];
+  u64 zh[16], zh_inv[16];
+  u64 last, n_inv;
+  u64* out;
+};
+extern "C" __global__ __launch_bounds__(256, VX_JIT_BLOCKS_PER_CU) void vx_air_quotient(AirParams p) {
+  const size_t il = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (il >= p.rows) return;
+  const int LG = p.log_n + p.rate_bits;
+  const size_t n = (size_t)1 << p.log_n;
+  const u32 z = (u32)(il >> p.log_n);
+  const u32 r = (u32)(il & (n - 1));
+  const u32 j = __brev((u32)il) >> (32 - LG);
+  const u32 e = j << (24 - LG);  // w_{2^24}^e from the two 4096-entry root tables (ntt.hip.h root_pow24)
+  const u64 x = gl_mul7(gl_mul(p.root_lo[e & 4095u], p.root_hi[(e >> 12) & 4095u]));
+  const u32 rn = __brev(((__brev(r) >> (32 - p.log_n)) + 1) & (u32)(n - 1)) >> (32 - p.log_n);
+  const size_t il_next = ((size_t)z << p.log_n) | rn;
+  const u64 z_last = gl_sub(x, p.last), xm1 = gl_sub(x, 1);
+  const u64 inv_both = gl_inv(gl_mul(z_last, xm1));
+  const u64 zh_n = gl_mul(p.zh[z], p.n_inv);
+  const u64 l_first = gl_mul(zh_n, gl_mul(inv_both, z_last));
+  const u64 l_last = gl_mul(gl_mul(zh_n, p.last), gl_mul(inv_both, xm1));
+  const u64* __restrict__ W = p.trace;
+  const size_t SW = p.stride;
+  u64 a0 = 0, a1 = 0;
+  u64 R[64];
+)VXJIT";
+  jit_emit_program(s, prog, nch, true);
+  s << "  p.out[il] = gl_mul(a0, p.zh_inv[z]);\n";
+  if (nch > 1) s << "  p.out[p.rows + il] = gl_mul(a1, p.zh_inv[z]);\n";
+  s << "}\n";
+  return s.str();
+}
+
 struct JitCache {
   std::mutex mu;
   std::map<std::string, std::vector<char>> code;                     // source -> code object
@@ -277,7 +349,15 @@ static bool jit_cache_dir_ok(const char* dir) {
 }
 
 // Returns the kernel for this gate set on `device`, or nullptr (with *why set) when it cannot be compiled / loaded.
+static hipFunction_t jit_get_kernel(const std::string& src, const char* kernel_name, int device, std::string* why);
 static hipFunction_t jit_get(const std::vector<const uint64_t*>& progs, int nch, int device, std::string* why) {
+  return jit_get_kernel(jit_source(progs, nch), "vx_program_gates", device, why);
+}
+// the compiled evaluator of one AIR program (stark.hip.h), or nullptr -> interpreter
+static hipFunction_t jit_air_get(const uint64_t* prog, int nch, int device, std::string* why) {
+  return jit_get_kernel(jit_air_source(prog, nch), "vx_air_quotient", device, why);
+}
+static hipFunction_t jit_get_kernel(const std::string& src, const char* kernel_name, int device, std::string* why) {
   if (getenv("VX_NO_JIT")) {
     *why = "VX_NO_JIT is set";
     return nullptr;
@@ -287,7 +367,6 @@ static hipFunction_t jit_get(const std::vector<const uint64_t*>& progs, int nch,
     *why = "libhiprtc.so not available";
     return nullptr;
   }
-  const std::string src = jit_source(progs, nch);
   JitCache& C = jit_cache();
   std::lock_guard<std::mutex> lk(C.mu);
   auto fit = C.functions.find({src, device});
@@ -359,7 +438,7 @@ static hipFunction_t jit_get(const std::vector<const uint64_t*>& progs, int nch,
     }
   }
   hipFunction_t fn;
-  if (hipModuleGetFunction(&fn, mod, "vx_program_gates") != hipSuccess) {
+  if (hipModuleGetFunction(&fn, mod, kernel_name) != hipSuccess) {
     (void)hipGetLastError();
     *why = "hipModuleGetFunction failed";
     return nullptr;

@@ -11,8 +11,8 @@
 //   * the transcript of plonky2's `starky` prover (starky/src/prover.rs::prove_with_commitment, v0.2.0 — restated from
 //     memory like everything upstream; Curta's own prover has the same shape with its own challenge schedule);
 //   * the matching host verifier (starky/src/verifier.rs).
-// Scope of the spike: no permutation / lookup (CTL) arguments, one process / one GPU, interpreter only (a build would
-// compile AIR programs with jit.hip.h exactly like gate programs), byte format = this library's own framing of
+// Scope of the spike: no permutation / lookup (CTL) arguments, one process / one GPU; AIR programs are compiled with
+// jit.hip.h exactly like gate programs (the interpreter below is the fallback and the cross-check); byte format = this library's own framing of
 // StarkProofWithPublicInputs (starky v0.2.0 has no to_bytes): trace_cap | quotient_cap | local | next | quotient
 // openings | FriProof (write_fri_proof) | public inputs.
 #pragma once
@@ -226,9 +226,18 @@ static int stark_prove_impl(vx_ctx* c, const vx_stark_desc* d, const u64* trace_
     ap.n_inv = inv((u64)n % P);
     ap.out = qv;
     {
-      ProfScope ps(c, "air_quotient_eval", 8.0 * (double)rows * 2.0 * ncols);
-      hipLaunchKernelGGL(air_quotient_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, c->stream, ap);
-      HIPCHK(hipGetLastError());
+      // the AIR program compiled to native code (jit.hip.h: same lowering as gate programs — fused multiply-adds, lazy
+      // canonicalisation, registers promoted to VGPRs); the interpreter is the fallback when hiprtc is not there
+      std::string why;
+      hipFunction_t fn = jit_air_get(d->program, nch, c->device, &why);
+      ProfScope ps(c, fn ? "air_quotient_eval_jit" : "air_quotient_eval", 8.0 * (double)rows * 2.0 * ncols);
+      if (fn) {
+        void* args[] = {&ap};
+        HIPCHK(hipModuleLaunchKernel(fn, (unsigned)((rows + 255) / 256), 1, 1, 256, 1, 1, 0, c->stream, args, nullptr));
+      } else {
+        hipLaunchKernelGGL(air_quotient_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, c->stream, ap);
+        HIPCHK(hipGetLastError());
+      }
     }
     // coset_ifft(7) on the size-(n * 2^qb) domain = per-coset inverse NTTs + the cross-coset inverse DFT, which yields the
     // quotient_degree_factor chunks of n coefficients directly (same kernels as the plonk quotient, with 2^qb cosets)
