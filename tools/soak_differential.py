@@ -34,7 +34,16 @@ while time.time() < t_end:
     lo = 5 if flags & 28 else (4 if flags & 1 else 3)
     db = int(rng.integers(max(lo, db_min), db_max + 1))
     pct = int(rng.integers(0, 101))
-    sc = SynthCircuit(db, seed=int(rng.integers(1, 1 << 30)), poseidon_percent=pct, witness_seed=int(rng.integers(1, 1 << 30)), flags=flags)
+    # quotient_degree_factor below the blow-up (CircuitConfig::max_quotient_degree_factor): the gate families that fit
+    qdf = 8
+    if rng.random() < 0.25:
+        qdf = int(rng.integers(3, 8))
+        if qdf < 8:
+            flags &= ~8                  # CosetInterpolationGate has degree 8
+        if qdf < 5:
+            flags &= ~4                  # RandomAccess (degree 5) / Exponentiation (4) family
+    sc = SynthCircuit(db, seed=int(rng.integers(1, 1 << 30)), poseidon_percent=pct, witness_seed=int(rng.integers(1, 1 << 30)), flags=flags,
+                      quotient_degree_factor=qdf)
     sc.desc.pow_bits = int(rng.choice([0, 3, 8, 12]))
     if rng.random() < 0.3:
         sc.desc.num_challenges = 1
@@ -58,7 +67,7 @@ while time.time() < t_end:
         sc.set_fri_reduction_arity_bits(ar)
         overrides += "A"
     if rng.random() < 0.25:
-        sc.set_num_partial_products(9)
+        sc.set_num_partial_products((80 + qdf - 1) // qdf - 1)
         overrides += "P"
     world = int(rng.choice([1, 1, 2, 4, 8]))
     if world > (1 << sc.desc.cap_height):
@@ -80,14 +89,14 @@ while time.time() < t_end:
         ok = False
     except vx.VxError:
         pass
-    key = f"flags{flags}/world{world}" + (f"/{overrides}" if overrides else "")
+    key = f"flags{flags}/world{world}" + (f"/qdf{qdf}" if qdf != 8 else "") + (f"/{overrides}" if overrides else "")
     by_kind[key] = by_kind.get(key, 0) + 1
     if ok:
         n_ok += 1
     else:
         n_bad += 1
         print(json.dumps({"FAIL": {"degree_bits": db, "flags": flags, "pct": pct, "world": world, "pow_bits": sc.desc.pow_bits,
-                                   "nch": sc.desc.num_challenges, "cap_height": sc.desc.cap_height, "queries": sc.desc.num_query_rounds, "overrides": overrides}}), flush=True)
+                                   "nch": sc.desc.num_challenges, "cap_height": sc.desc.cap_height, "queries": sc.desc.num_query_rounds, "overrides": overrides, "qdf": qdf}}), flush=True)
     for c in cs:
         c.free()
     oc.free()

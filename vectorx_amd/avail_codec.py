@@ -1,0 +1,136 @@
+"""Byte formats on either side of the proving path (host logic, no GPU): what the reference packs into a proof request and
+what the circuits commit to in their public outputs.  Each function restates one helper of the reference and is pinned to
+the vectors the reference's own tests hold (tests/golden/reference_vectors.json, tests/test_reference_vectors.py).
+
+* SCALE compact integers (the block number inside an encoded Avail header): `decode_compact_int` gadget,
+  /root/reference/circuits/builder/decoder.rs:33-103, test table :238-249.
+* GRANDPA precommit message `1 | block_hash[32] | block_number u32 LE | round u64 LE | authority_set_id u64 LE` (53 bytes):
+  /root/reference/circuits/input/mod.rs:262-289, in-circuit decoder /root/reference/circuits/builder/decoder.rs:106-140,
+  test vector :388-395.
+* authority set commitment = SHA-256 chained over the compressed Ed25519 keys: /root/reference/circuits/input/mod.rs:250-260
+  (in-circuit: circuits/builder/justification.rs:140-161).
+* header-range commitments = SHA-256 binary tree over UNHASHED 32-byte leaves (state roots / data roots), zero-padded to the
+  tree size: /root/reference/circuits/input/mod.rs:464-489, 493-528.
+* function I/O packing: header_range input abi.encodePacked(uint32, bytes32, uint64, bytes32, uint32) = 80 bytes
+  (/root/reference/bin/vectorx.rs:106-112), output abi.encode(bytes32, bytes32, bytes32) = 96 bytes
+  (/root/reference/circuits/header_range.rs:56-58); rotate input abi.encodePacked(uint64, bytes32) = 40 bytes, output
+  bytes32 (/root/reference/circuits/rotate.rs:87-88, 108).
+"""
+from __future__ import annotations
+
+import hashlib
+import struct
+
+MAX_COMPACT_UINT_BYTES = 5
+ENCODED_PRECOMMIT_LENGTH = 53
+
+
+def encode_compact_u32(value: int) -> bytes:
+    """parity-scale-codec `Compact<u32>::encode`: the two low bits of the first byte select the width."""
+    if not 0 <= value < 1 << 32:
+        raise ValueError("compact u32 out of range")
+    if value < 1 << 6:
+        return bytes([value << 2])
+    if value < 1 << 14:
+        return struct.pack("<H", (value << 2) | 1)
+    if value < 1 << 30:
+        return struct.pack("<I", (value << 2) | 2)
+    return bytes([3]) + struct.pack("<I", value)     # big-integer mode: (4 - 4) << 2 | 3, then 4 bytes LE
+
+
+def decode_compact_u32(data: bytes) -> tuple[int, int, int]:
+    """(value, compress_mode, encoded length) of a compact integer at the start of `data` (<= 5 bytes are looked at); modes
+    0 / 1 / 2 = 1 / 2 / 4 bytes with the value shifted left by two, mode 3 = one length byte followed by 4 value bytes —
+    the only big-integer length a u32 block number can have, which is what the gadget supports."""
+    if not data:
+        raise ValueError("empty compact integer")
+    mode = data[0] & 3
+    if mode == 0:
+        return data[0] >> 2, 0, 1
+    if mode == 1:
+        if len(data) < 2:
+            raise ValueError("truncated compact integer")
+        return struct.unpack("<H", data[:2])[0] >> 2, 1, 2
+    if mode == 2:
+        if len(data) < 4:
+            raise ValueError("truncated compact integer")
+        return struct.unpack("<I", data[:4])[0] >> 2, 2, 4
+    if data[0] >> 2 != 0 or len(data) < 5:
+        raise ValueError("compact integer wider than a u32")
+    return struct.unpack("<I", data[1:5])[0], 3, 5
+
+
+def decode_precommit(precommit: bytes) -> dict:
+    if len(precommit) != ENCODED_PRECOMMIT_LENGTH or precommit[0] != 1:
+        raise ValueError("not an encoded precommit message")
+    block_number, = struct.unpack("<I", precommit[33:37])
+    rnd, set_id = struct.unpack("<QQ", precommit[37:53])
+    return {"block_hash": precommit[1:33], "block_number": block_number, "round": rnd, "authority_set_id": set_id}
+
+
+def encode_precommit(block_hash: bytes, block_number: int, rnd: int, authority_set_id: int) -> bytes:
+    if len(block_hash) != 32:
+        raise ValueError("block hash must be 32 bytes")
+    return bytes([1]) + block_hash + struct.pack("<IQQ", block_number, rnd, authority_set_id)
+
+
+def authority_set_commitment(pubkeys) -> bytes:
+    """H(H(...H(pk_0) || pk_1 ...) || pk_{k-1}) with H = SHA-256; the empty set hashes to the empty string."""
+    h = b""
+    for pk in pubkeys:
+        if len(pk) != 32:
+            raise ValueError("compressed Ed25519 keys are 32 bytes")
+        h = hashlib.sha256(h + pk).digest()
+    return h
+
+
+def simple_merkle_root(leaves) -> bytes:
+    """Binary SHA-256 tree whose leaves are NOT hashed; the leaf list is zero-padded to a power of two."""
+    nodes = [bytes(l) for l in leaves]
+    if not nodes:
+        return b""
+    if any(len(l) != 32 for l in nodes):
+        raise ValueError("leaves are 32-byte roots")
+    while len(nodes) & (len(nodes) - 1):
+        nodes.append(bytes(32))
+    while len(nodes) > 1:
+        nodes = [hashlib.sha256(nodes[2 * i] + nodes[2 * i + 1]).digest() for i in range(len(nodes) // 2)]
+    return nodes[0]
+
+
+def header_range_commitments(state_roots, data_roots, tree_size: int) -> tuple[bytes, bytes]:
+    """(state_root_commitment, data_root_commitment) of the headers (trusted, target]: both lists padded with zero leaves to
+    `tree_size` (256 or 512: the N of header_range_N)."""
+    if tree_size & (tree_size - 1) or not 0 < len(state_roots) <= tree_size or len(state_roots) != len(data_roots):
+        raise ValueError("range does not fit the commitment tree")
+    pad = [bytes(32)] * (tree_size - len(state_roots))
+    return simple_merkle_root(list(state_roots) + pad), simple_merkle_root(list(data_roots) + pad)
+
+
+def pack_header_range_input(trusted_block: int, trusted_header: bytes, authority_set_id: int, authority_set_hash: bytes,
+                            target_block: int) -> bytes:
+    if len(trusted_header) != 32 or len(authority_set_hash) != 32:
+        raise ValueError("hashes are 32 bytes")
+    return struct.pack(">I", trusted_block) + trusted_header + struct.pack(">Q", authority_set_id) + authority_set_hash + \
+        struct.pack(">I", target_block)
+
+
+def unpack_header_range_input(raw: bytes) -> dict:
+    if len(raw) != 80:
+        raise ValueError("header_range input is 80 bytes")
+    return {"trusted_block": struct.unpack(">I", raw[0:4])[0], "trusted_header": raw[4:36],
+            "authority_set_id": struct.unpack(">Q", raw[36:44])[0], "authority_set_hash": raw[44:76],
+            "target_block": struct.unpack(">I", raw[76:80])[0]}
+
+
+def pack_header_range_output(target_header: bytes, state_root_commitment: bytes, data_root_commitment: bytes) -> bytes:
+    out = target_header + state_root_commitment + data_root_commitment
+    if len(out) != 96:
+        raise ValueError("header_range output is three bytes32 values")
+    return out
+
+
+def pack_rotate_input(authority_set_id: int, authority_set_hash: bytes) -> bytes:
+    if len(authority_set_hash) != 32:
+        raise ValueError("hashes are 32 bytes")
+    return struct.pack(">Q", authority_set_id) + authority_set_hash
