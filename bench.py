@@ -135,18 +135,19 @@ def main():
             achieved = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9
             # HBM bytes per launch: PMC counters cannot be read from inside this process, so the measured
             # traffic-per-algorithmic-byte ratio of this kernel (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
-            # passes, gfx950 correction applied — profiles/r01_pmc_traffic.md) scales the launch's algorithmic bytes.
-            traffic = None
+            # passes, gfx950 correction applied — profiles/r02_pmc_traffic.md via tools/summarize_pmc.py) scales the launch's algorithmic bytes.
+            traffic, traffic_source = None, None
             try:
                 pmc = json.loads((ROOT / "profiles" / "pmc_traffic_lde.json").read_text())
                 traffic = per_launch_bytes * float(pmc["traffic_bytes_per_alg_byte"])
+                traffic_source = pmc["source"] + ": ratio x algorithmic bytes"
             except Exception:
                 pass
             roof = {
-                "kernel": "ntt_pass_kernel, coset-LDE launches (each = 8 coset NTTs per column, 2 passes; wires 135 / Z+pp 20 / quotient 16 columns)",
+                "kernel": "ntt2_pass_kernel, coset-LDE launches (each = 8 coset NTTs per column, 2 passes; wires 135 / Z+pp 20 / quotient 16 columns)",
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                "traffic_source": "profiles/r01_pmc_traffic.md (PMC FETCH_SIZE+WRITE_SIZE ratio x algorithmic bytes)",
+                "traffic_source": traffic_source,
                 "alg_bytes_per_launch": per_launch_bytes, "ms_per_launch": round(per_launch_ms, 4),
                 "launches": lde["calls"],
             }
