@@ -43,7 +43,6 @@ struct NttPassParams {
   const u64* pre;                        // optional prescale tables [z][ 2^(log_n-pre_bits) + 2^pre_bits ]
   int pre_bits;
   u64 post_scale;                        // every output *= post_scale (1 = skip)
-  const u64* twt;                        // ntt2 strided passes: inter-pass twiddle table of this shape (post_scale folded in) or null
 };
 
 GLD u32 bitrev32(u32 x, int bits) { return bits ? (__brev(x) >> (32 - bits)) : 0; }

@@ -17,7 +17,6 @@
 
 #define NTT2_THREADS 512
 #define NTT2_TILE_LOG 13
-#define NTT2_TWT_MAX_LOG 22  /* inter-pass twiddle tables up to 2^22 entries (32 MB); longer spans compose their twiddles */
 
 // 2^S mod p for 0 <= S < 192 (2^96 = -1)
 __host__ __device__ constexpr u64 gl_pow2_const(int S) {
@@ -162,26 +161,7 @@ struct Ntt2Params {
   // coefficient tile (one per coset of an LDE) are dispatched back to back on the SAME XCD — workgroups go to XCDs
   // round-robin, so block id = ((tile / 8) * nz + z) * 8 + tile % 8 — and 7 of the 8 reads hit that XCD's L2.
   int nz_fold;
-  // strided passes: the inter-pass twiddles w_{2^span}^(+-l * rev(m)) * post_scale of the whole span, [(m << b_lo) | l] — the
-  // layout of the pass's own output — or null (then they are composed from the root tables, one extra multiply per element)
-  const u64* twt;
 };
-// Fills such a table (2^(b_lo + r_log) entries; built once per context and transform shape, vx_runtime.hip.h).
-__global__ __launch_bounds__(256) void ntt2_twiddle_table_kernel(u64* __restrict__ out, const u64* __restrict__ root_lo,
-                                                                 const u64* __restrict__ root_hi, int b_lo, int r_log, int inverse,
-                                                                 u64 post_scale) {
-  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-  const int span_log = b_lo + r_log;
-  if (idx >> span_log) return;
-  const u64 l = idx & (((u64)1 << b_lo) - 1);
-  const u32 m = (u32)(idx >> b_lo);
-  const u64 ex = l * (u64)bitrev32(m, r_log);
-  u32 e = (u32)((ex & (((u64)1 << span_log) - 1)) << (ROOT_TABLE_LOG - span_log));
-  if (inverse) e = ((1u << ROOT_TABLE_LOG) - e) & ((1u << ROOT_TABLE_LOG) - 1);
-  u64 v = root_pow24(root_lo, root_hi, e);
-  if (post_scale != 1) v = gl_mul(v, post_scale);
-  out[idx] = v;
-}
 
 // LDS index of tile element (m, t): strided tiles are [m][t], contiguous tiles are [t][m]
 template <int R_LOG, bool STRIDED>
@@ -348,24 +328,6 @@ __global__ __launch_bounds__(NTT2_THREADS) void ntt2_pass_kernel(Ntt2Params p) {
     // composition (two gathers) instead of 2^EL of them
     const u32 t = threadIdx.x & ((1u << T_LOG) - 1);
     const u64 l = (base & (((size_t)1 << p.b_lo) - 1)) + t;
-    if (p.twt) {
-      // twiddles from the per-shape table: the same address arithmetic as the store, one multiply per element
-      const u64* __restrict__ twt = p.twt + l;
-#pragma unroll
-      for (u32 g0 = 0; g0 < n_groups; g0 += NTT2_THREADS) {
-        const u32 g = g0 + threadIdx.x;
-        const u32 m0 = (g >> T_LOG) << EL;
-        u64 x[1 << EL], tw[1 << EL];
-#pragma unroll
-        for (int q = 0; q < (1 << EL); ++q) tw[q] = twt[(size_t)(m0 | (u32)q) << p.b_lo];
-#pragma unroll
-        for (int q = 0; q < (1 << EL); ++q) x[q] = tile[tile_idx<R_LOG, true>(m0 | (u32)q, t)];
-        dft_regs<EL, INV>(x);
-#pragma unroll
-        for (int q = 0; q < (1 << EL); ++q) out[base + ((size_t)(m0 | (u32)q) << p.b_lo) + t] = gl_mul(x[q], tw[q]);
-      }
-      return;
-    }
     auto root_at = [&](u64 ex) {
       u32 e = (u32)((ex & (((u64)1 << span_log) - 1)) << (ROOT_TABLE_LOG - span_log));
       if (INV) e = ((1u << ROOT_TABLE_LOG) - e) & ((1u << ROOT_TABLE_LOG) - 1);

@@ -266,7 +266,6 @@ static hipError_t launch_ntt2_pass(const NttPass& ps, const NttPassParams& p, di
   q.pre_beta = p.pre ? p.pre + (size_t)grid.z * (((size_t)1 << (p.log_n - p.pre_bits)) + ((size_t)1 << p.pre_bits)) : nullptr;
   q.pre_bits = p.pre_bits;
   q.post_scale = p.post_scale;
-  q.twt = p.twt;
   q.nz_fold = 0;
   if (p.pre && grid.z > 1 && p.in_z_stride == 0 && grid.x % 8 == 0 && !getenv("VX_NTT_NO_ZFOLD")) {  // coset LDE from shared coefficients
     q.nz_fold = (int)grid.z;
@@ -367,26 +366,6 @@ static int run_ntt(vx_ctx* c, const u64* in, u64* out, size_t in_col_stride, siz
     // the scale commutes with the passes: in a multi-pass transform it rides on the FIRST (strided) pass, where it is
     // folded into the inter-pass twiddle for free, instead of costing a multiply per element in the last pass
     p.post_scale = (plan.size() > 1 ? first : last) ? post_scale : 1;
-    p.twt = nullptr;
-    if (ps_.b_lo > 0 && ntt2_eligible(ps_, true) && ps_.b_lo + ps_.r_log <= NTT2_TWT_MAX_LOG && !getenv("VX_NTT_NO_TWT")) {
-      // inter-pass twiddles of this (span, stages, direction, scale) from a table built once per context: 8 bytes of
-      // L2-friendly reads per element (the 8 cosets of a tile share them) instead of a multiply
-      const std::string key = "twt:" + std::to_string(ps_.b_lo) + ":" + std::to_string(ps_.r_log) + ":" + std::to_string((int)inverse) + ":" + std::to_string(p.post_scale);
-      auto it = c->scale_cache.find(key);
-      if (it == c->scale_cache.end()) {
-        const size_t len = (size_t)1 << (ps_.b_lo + ps_.r_log);
-        u64* d = nullptr;
-        if (hipMalloc(&d, len * 8) == hipSuccess) {
-          hipLaunchKernelGGL(ntt2_twiddle_table_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, c->stream, d, c->root_lo, c->root_hi,
-                             ps_.b_lo, ps_.r_log, (int)inverse, p.post_scale);
-          if (hipGetLastError() == hipSuccess) it = c->scale_cache.emplace(key, d).first;
-          else hipFree(d);
-        } else {
-          (void)hipGetLastError();  // no room for the table: compose the twiddles in the kernel
-        }
-      }
-      if (it != c->scale_cache.end()) p.twt = it->second;
-    }
     size_t tile = (size_t)1 << (ps_.r_log + ps_.t_log);
     size_t lds = (tile + (tile >> 5) + (tile >> 9) + 1 + ((size_t)1 << (ps_.r_log - 1 > 0 ? ps_.r_log - 1 : 0))) * 8 + 16;
     dim3 grid((unsigned)((size_t)1 << (log_n - ps_.r_log - ps_.t_log)), (unsigned)ncols, (unsigned)nz);
