@@ -272,7 +272,8 @@ def test_malformed_constraint_programs_are_refused(ctx):
     vx.Circuit(ctx, sc.desc_ptr).free()
 
 
-@pytest.mark.parametrize("degree_bits,arities", [(7, [2, 1, 3]), (10, [4, 3]), (12, [1, 2, 3, 4]), (9, [])])
+@pytest.mark.parametrize("degree_bits,arities", [(7, [2, 1, 3]), (10, [4, 3]), (12, [1, 2, 3, 4]), (9, []),
+                                                 (14, [1])])   # one arity-2 reduction: a 2^16-value final layer (the host transform was quadratic once)
 def test_caller_supplied_digest_and_fri_arities(ctx, oracle, degree_bits, arities):
     """vx_circuit_desc carries what the Rust side holds (VerifierOnlyCircuitData::circuit_digest, FriParams::
     reduction_arity_bits, CommonCircuitData::num_partial_products): the GPU prover must follow the caller's values —

@@ -4,6 +4,7 @@ oracle; proofs must be byte-identical, `vx_verify` must accept them and reject a
 
     python tools/soak_differential.py [seconds] [seed] [min_degree_bits] [max_degree_bits] > gpurun_out/soak.jsonl
 """
+import faulthandler
 import json
 import sys
 import time
@@ -72,6 +73,11 @@ while time.time() < t_end:
     world = int(rng.choice([1, 1, 2, 4, 8]))
     if world > (1 << sc.desc.cap_height):
         world = 1 << sc.desc.cap_height
+    # progress on stderr + a watchdog: a case that stalls dumps every thread's Python stack and ends the run (rc != 0)
+    print(json.dumps({"case": n_ok + n_bad, "degree_bits": db, "flags": flags, "pct": pct, "qdf": qdf, "world": world, "overrides": overrides,
+                      "pow_bits": int(sc.desc.pow_bits), "nch": int(sc.desc.num_challenges), "cap_height": int(sc.desc.cap_height),
+                      "queries": int(sc.desc.num_query_rounds)}), file=sys.stderr, flush=True)
+    faulthandler.dump_traceback_later(300 if db_max > 13 else 120, exit=True)
     w = sc.witness()
     oc = oracle_lib.OracleCircuit(oracle, sc.desc_ptr)
     want = oc.prove(w)
@@ -97,6 +103,7 @@ while time.time() < t_end:
         n_bad += 1
         print(json.dumps({"FAIL": {"degree_bits": db, "flags": flags, "pct": pct, "world": world, "pow_bits": sc.desc.pow_bits,
                                    "nch": sc.desc.num_challenges, "cap_height": sc.desc.cap_height, "queries": sc.desc.num_query_rounds, "overrides": overrides, "qdf": qdf}}), flush=True)
+    faulthandler.cancel_dump_traceback_later()
     for c in cs:
         c.free()
     oc.free()

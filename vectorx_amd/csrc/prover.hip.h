@@ -233,7 +233,10 @@ struct Shard {
 static int shard_allgather(vx_ctx* c, const Shard& sh, void* dev, size_t bytes_per_rank, const char* what) {
   if (sh.world == 1) return VX_OK;
   HIPCHK(hipStreamSynchronize(c->stream));
+  static const bool trace = getenv("VX_TRACE_EXCHANGES") != nullptr;  // one line per exchange: which rank waits for what
+  if (trace) fprintf(stderr, "[vx rank %d/%d] all-gather: %s, %zu bytes per rank\n", sh.rank, sh.world, what, bytes_per_rank);
   int rc = sh.fn(sh.user, dev, bytes_per_rank);
+  if (trace) fprintf(stderr, "[vx rank %d/%d] all-gather done: %s (rc %d)\n", sh.rank, sh.world, what, rc);
   if (rc) return vx_fail(VX_E_COMM, "prove: all-gather of %s failed on rank %d (callback returned %d)", what, sh.rank, rc);
   return VX_OK;
 }
@@ -434,24 +437,33 @@ static int fri_prove_openings(vx_ctx* c, const FriProverParams& fpp, const std::
     std::vector<u64> hv(2 * Mf);
     HIPCHK(hipMemcpyAsync(hv.data(), fvals[R], hv.size() * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    for (u64& v : hv) v = canon(v);
     std::vector<Ext>& coeffs = out.final_poly;
     coeffs.assign(Mf, Ext{0, 0});
     {
-      // coefficient j = shift^-j / Mf * sum_k v_k w^(-jk), v_k at natural index k = rev(position)
-      u64 w_inv = inv(root_of_unity(lMf)), s_inv = inv(shift), m_inv = inv((u64)Mf % P);
-      std::vector<u64> wp(Mf);
+      // coefficient j = shift^-j / Mf * sum_k v_k w^(-jk), v_k at natural index k = rev(position): the array IS the
+      // bit-reversed input of a decimation-in-time inverse transform, which leaves the coefficients in natural order.
+      // O(Mf log Mf) on the host: Mf is 2^8 with the standard arities but anything up to the whole LDE with a
+      // caller-supplied list (a quadratic loop here once took minutes for a single arity-2 reduction at n = 2^17).
+      const u64 w_inv = inv(root_of_unity(lMf)), s_inv = inv(shift), m_inv = inv((u64)Mf % P);
+      std::vector<u64> wp(std::max<size_t>(Mf / 2, 1));
       wp[0] = 1;
-      for (size_t i = 1; i < Mf; ++i) wp[i] = mul(wp[i - 1], w_inv);
+      for (size_t i = 1; i < wp.size(); ++i) wp[i] = mul(wp[i - 1], w_inv);
+      for (size_t len = 2; len <= Mf; len <<= 1) {
+        const size_t half = len >> 1, stride = Mf / len;
+        for (size_t i = 0; i < Mf; i += len)
+          for (size_t j = 0; j < half; ++j) {
+            const u64 w = wp[j * stride];
+            for (int e = 0; e < 2; ++e) {
+              const u64 u = hv[2 * (i + j) + e], v = mul(hv[2 * (i + j + half) + e], w);
+              hv[2 * (i + j) + e] = add(u, v);
+              hv[2 * (i + j + half) + e] = sub(u, v);
+            }
+          }
+      }
       u64 sj = m_inv;
       for (size_t j = 0; j < Mf; ++j) {
-        u64 a = 0, b = 0;
-        for (size_t pos = 0; pos < Mf; ++pos) {
-          size_t kk = reverse_bits(pos, lMf);
-          u64 w = wp[(j * kk) & (Mf - 1)];
-          a = add(a, mul(hv[2 * pos], w));
-          b = add(b, mul(hv[2 * pos + 1], w));
-        }
-        coeffs[j] = Ext{mul(a, sj), mul(b, sj)};
+        coeffs[j] = Ext{mul(hv[2 * j], sj), mul(hv[2 * j + 1], sj)};
         sj = mul(sj, s_inv);
       }
     }
