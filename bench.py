@@ -175,6 +175,11 @@ def main():
                 alu.update({"valu_insts_per_perm": ipp, "clock_ghz_measured_in_kernel": round(ghz, 3),
                             "achieved_wave_inst_per_s": achieved, "ceiling_wave_inst_per_s": ceiling,
                             "frac": round(achieved / ceiling, 4),
+                            # the in-kernel sample (s_memtime over s_memrealtime) reads ~4-5 % below the clock the GRBM counter
+                            # gives for the same kernel, which is why frac exceeds 1; the rate this run would have at the PMC
+                            # run's clock is given for comparison (same kernel, separate run: profiles/r02_pmc_sq.md)
+                            "frac_at_pmc_run_clock": (round(achieved / (ceil_info["simds"] * float(ceil_info["pmc_run"]["clock_ghz"]) * 1e9 / 4.0), 4)
+                                                      if (ceil_info.get("pmc_run") or {}).get("clock_ghz") else None),
                             "ceiling_model": "1024 SIMDs x measured clock / 4 cycles per wavefront-instruction (quad-cycle VALU issue)",
                             "ubench_cycles_per_inst": ceil_info["cycles"],
                             "source": "profiles/r02_alu_ceiling.json (tools/alu_ceiling.py), profiles/r02_ubench_int.md, profiles/r02_pmc_sq.md"})

@@ -12,7 +12,7 @@ with
     2 x 4 full rounds, 5 blocks of four partial rounds + one block of two), cross-checked against the PMC count SQ_INSTS_VALU.
 
     hipcc -O3 -std=c++17 --offload-arch=gfx950 -S --cuda-device-only -o /tmp/vxprover.s vectorx_amd/csrc/vxprover.hip
-    python3 tools/alu_ceiling.py /tmp/vxprover.s profiles/r02_ubench_int.md [SQ_INSTS_VALU per permutation] > profiles/r02_alu_ceiling.json
+    python3 tools/alu_ceiling.py /tmp/vxprover.s profiles/r02_ubench_int.md [SQ_INSTS_VALU per permutation] [PMC clock GHz] [PMC cycles per VALU instruction] > profiles/r02_alu_ceiling.json
 
 bench.py reads profiles/r02_alu_ceiling.json and reports, from the run's own hash_leaves time,
     achieved  = permutations/s x valu_insts_per_perm / 64      (wavefront-instructions per second)
@@ -102,6 +102,7 @@ def main():
     asm = open(sys.argv[1]).read()
     md = open(sys.argv[2]).read()
     pmc_valu_per_perm = float(sys.argv[3]) if len(sys.argv) > 3 else None
+    pmc_clock_ghz = float(sys.argv[4]) if len(sys.argv) > 4 else None   # GRBM_GUI_ACTIVE / 8 XCDs / duration of the kernel in the PMC run
     hist, loops = weighted_histogram(kernel_text(asm, KERNEL))
     valu = {k: v for k, v in hist.items() if k.startswith("v_")}
     n_valu = sum(valu.values())
@@ -123,6 +124,7 @@ def main():
         "ncols": NCOLS, "perms_per_row": PERMS, "loops": loops,
         "valu_insts_per_row_static": n_valu, "valu_insts_per_perm_static": round(per_perm, 1),
         "valu_insts_per_perm_pmc": pmc_valu_per_perm,
+        "pmc_run": {"clock_ghz": pmc_clock_ghz, "cycles_per_valu_inst": float(sys.argv[5]) if len(sys.argv) > 5 else None, "source": "profiles/r02_pmc_sq.md (commit workload)"},
         "s_nop_per_perm": round(hist.get("s_nop", 0) / PERMS, 1),
         "salu_per_perm": round(sum(v for k, v in hist.items() if k.startswith("s_") and k != "s_nop") / PERMS, 1),
         "class_counts_per_perm": {"slow (4.4-cycle class: v_mad_u64_u32, carry adds/subs, v_cndmask_e64, 64-bit ops)": round((n_valu - n_fast) / PERMS, 1),
