@@ -18,7 +18,8 @@ Derivation.  Partial round r (r = 0..21):  s <- M * S(s + c_r),  S = x^7 on lane
      M_{r-1} = N'_r M.   The dense part that is left over is N'_0 (the "initial matrix"), applied once.
  Result:  x = N'_0 (s + c'_0);  for r in 0..21: x0 = x0^7 + k_r;  x = N''_r x.
 
-Writes vectorx_amd/csrc/poseidon_fast_constants.h.   --check verifies the committed header.
+Writes oracle/poseidon_fast_constants.h (the oracle's permutation; the product's kernels use integer-power blocks built at
+compile time in poseidon.hip.h and no longer read these tables).   --check verifies the committed header.
 """
 import random
 import sys
@@ -173,8 +174,7 @@ def main():
         if t < 3:
             assert a[0] == kat_out0[t]
     root = Path(__file__).resolve().parent.parent
-    # the product and the oracle share no code: each gets its own generated copy
-    paths = [root / "vectorx_amd" / "csrc" / "poseidon_fast_constants.h", root / "oracle" / "poseidon_fast_constants.h"]
+    paths = [root / "oracle" / "poseidon_fast_constants.h"]
     text = header_text(first, k, init, w_hats, vs)
     if "--check" in sys.argv:
         ok = all(p.exists() and p.read_text() == text for p in paths)
