@@ -318,9 +318,28 @@ typedef struct vx_stark_desc {
   uint32_t override_flags;                /* VX_DESC_HAS_FRI_ARITIES or 0 (then ConstantArityBits(4, 5)) */
   int32_t num_fri_reduction_arity_bits;
   const int32_t* fri_reduction_arity_bits;
+  /* A SECOND COMMITMENT ROUND (0 / 0 = none): after the trace cap the prover draws num_aux_challenges challenges and
+   * commits num_aux_columns more columns that may depend on them — where starky commits its permutation Z polynomials and
+   * Curta its lookup / bus accumulators.  The AIR program addresses them as columns num_columns .. num_columns +
+   * num_aux_columns - 1 (VX_OP_LDW / VX_OP_LDN) and reads the challenges with VX_OP_LDCH.  The columns themselves are
+   * witness data (running sums / products over rows): the CALLER computes them between vx_stark_begin and vx_stark_finish.
+   * (As in starky, first- and last-row constraints are multiplied by a Lagrange selector of degree n - 1: keep them at degree
+   * <= constraint_degree - 2 + 1, i.e. linear for constraint_degree 3, or the quotient no longer fits its chunks.) */
+  int32_t num_aux_columns, num_aux_challenges;
 } vx_stark_desc;
+#define VX_OP_LDCH 10 /* AIR programs only: r[dst] = aux challenge a */
 int vx_stark_prove(vx_ctx* ctx, const vx_stark_desc* desc, const uint64_t* trace /* [num_columns][2^degree_bits] */, int trace_on_device,
-                   const uint64_t* public_inputs, const uint64_t* pow_witness_hint, uint8_t* out_buf, size_t* out_len);
+                   const uint64_t* public_inputs, const uint64_t* pow_witness_hint, uint8_t* out_buf, size_t* out_len); /* num_aux_columns = 0 */
+/* The two-round form: vx_stark_begin commits the trace and returns the aux challenges; vx_stark_finish takes the aux
+ * columns [num_aux_columns][2^degree_bits] (host or device) and completes the proof:
+ *   trace_cap | aux_cap | quotient_cap | trace(zeta) | trace(g zeta) | aux(zeta) | aux(g zeta) | quotient(zeta) | FriProof | public inputs.
+ * With num_aux_columns = 0 the pair is equivalent to vx_stark_prove.  A session is used for one proof and then freed. */
+typedef struct vx_stark_session vx_stark_session;
+int vx_stark_begin(vx_ctx* ctx, const vx_stark_desc* desc, const uint64_t* trace, int trace_on_device, const uint64_t* public_inputs,
+                   uint64_t* aux_challenges_out /* [num_aux_challenges] */, vx_stark_session** out);
+int vx_stark_finish(vx_stark_session* session, const uint64_t* aux_columns, int aux_on_device, const uint64_t* pow_witness_hint,
+                    uint8_t* out_buf, size_t* out_len);
+void vx_stark_session_free(vx_stark_session* session);
 int vx_stark_verify(const vx_stark_desc* desc, const uint64_t* public_inputs, const uint8_t* proof, size_t proof_len);
 
 /* ---- ONE proof sharded across the GPUs of a node (BASELINE.json configs[3]) -------------------

@@ -343,14 +343,24 @@ struct vxo_stark_desc {
   uint32_t override_flags;
   int32_t num_fri_reduction_arity_bits;
   const int32_t* fri_reduction_arity_bits;
+  int32_t num_aux_columns, num_aux_challenges;
 };
+// aux_fn(challenges[num_aux_challenges], aux_out[num_aux_columns][n], user): the caller's second-round column generator
+typedef void (*vxo_stark_aux_fn)(const u64* challenges, u64* aux_out, void* user);
+long long vxo_stark_prove2(const vxo_stark_desc* d, const u64* trace, const u64* pis, const u64* pow_hint, vxo_stark_aux_fn aux_fn, void* user,
+                           uint8_t* out, size_t cap, char* err, size_t err_cap);
 long long vxo_stark_prove(const vxo_stark_desc* d, const u64* trace, const u64* pis, const u64* pow_hint, uint8_t* out, size_t cap,
                           char* err, size_t err_cap) {
+  return vxo_stark_prove2(d, trace, pis, pow_hint, nullptr, nullptr, out, cap, err, err_cap);
+}
+long long vxo_stark_prove2(const vxo_stark_desc* d, const u64* trace, const u64* pis, const u64* pow_hint, vxo_stark_aux_fn aux_fn, void* user,
+                           uint8_t* out, size_t cap, char* err, size_t err_cap) {
   try {
     StarkDesc s;
     s.degree_bits = d->degree_bits, s.num_columns = d->num_columns, s.num_public_inputs = d->num_public_inputs;
     s.rate_bits = d->rate_bits, s.cap_height = d->cap_height, s.pow_bits = d->pow_bits, s.num_query_rounds = d->num_query_rounds;
     s.num_challenges = d->num_challenges, s.constraint_degree = d->constraint_degree;
+    s.num_aux_columns = d->num_aux_columns, s.num_aux_challenges = d->num_aux_challenges;
     s.program.assign(d->program, d->program + d->program_len);
     if (d->override_flags & 2) s.arity_bits.assign(d->fri_reduction_arity_bits, d->fri_reduction_arity_bits + d->num_fri_reduction_arity_bits);
     else s.default_arities();
@@ -363,7 +373,16 @@ long long vxo_stark_prove(const vxo_stark_desc* d, const u64* trace, const u64* 
     std::vector<u64> pi(pis, pis + d->num_public_inputs);
     ProveOptions opt;
     if (pow_hint) opt.has_pow_hint = true, opt.pow_hint = *pow_hint;
-    std::vector<uint8_t> bytes = serialize_stark_proof(stark_prove(s, tr, pi, opt));
+    StarkAuxFn fn;
+    if (aux_fn)
+      fn = [&](const std::vector<u64>& ch) {
+        std::vector<u64> flat((size_t)s.num_aux_columns * n);
+        aux_fn(ch.data(), flat.data(), user);
+        std::vector<std::vector<u64>> cols(s.num_aux_columns);
+        for (int c = 0; c < s.num_aux_columns; ++c) cols[c].assign(flat.begin() + (size_t)c * n, flat.begin() + (size_t)(c + 1) * n);
+        return cols;
+      };
+    std::vector<uint8_t> bytes = serialize_stark_proof(stark_prove(s, tr, pi, opt, fn));
     if (bytes.size() > cap) {
       snprintf(err, err_cap, "output buffer too small: need %zu bytes", bytes.size());
       return -1;

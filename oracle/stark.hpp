@@ -7,18 +7,23 @@
 // schedule).  Written in the straightforward textbook order (natural-order coset, Lagrange selectors by formula,
 // coefficient-domain FRI fold), independent of the GPU code's layout tricks.
 #pragma once
+#include <functional>
 #include "plonk.hpp"
 
 namespace vxo {
 
 static const int AIR_OP_END = 0, AIR_OP_LDW = 1, AIR_OP_LDI = 3, AIR_OP_ADD = 4, AIR_OP_SUB = 5, AIR_OP_MUL = 6, AIR_OP_PUSH = 7,
-                 AIR_OP_LDP = 8, AIR_OP_LDN = 9;
+                 AIR_OP_LDP = 8, AIR_OP_LDN = 9, AIR_OP_LDCH = 10;
 static const int AIR_ALL = 0, AIR_TRANSITION = 1, AIR_FIRST = 2, AIR_LAST = 3;
 
 struct StarkDesc {
   int degree_bits = 0, num_columns = 0, num_public_inputs = 0;
   int rate_bits = 1, cap_height = 4, pow_bits = 16, num_query_rounds = 84, num_challenges = 2;  // StarkConfig::standard_fast_config
   int constraint_degree = 2;
+  // second commitment round (the shape of Curta's lookup / bus accumulators and of starky's permutation Z columns): after
+  // the trace cap `num_aux_challenges` challenges are drawn, the prover commits `num_aux_columns` more columns that may
+  // depend on them, and the AIR program sees both (columns num_columns.. = aux columns, AIR_OP_LDCH = a challenge)
+  int num_aux_columns = 0, num_aux_challenges = 0;
   std::vector<u64> program;
   std::vector<int> arity_bits;
   int quotient_degree_factor() const { return constraint_degree > 1 ? constraint_degree - 1 : 1; }  // Stark::quotient_degree_factor
@@ -29,15 +34,16 @@ struct StarkDesc {
   }
 };
 struct StarkProof {
-  std::vector<Hash> trace_cap, quotient_cap;
-  std::vector<Ext> local_values, next_values, quotient_polys;
+  std::vector<Hash> trace_cap, aux_cap, quotient_cap;
+  std::vector<Ext> local_values, next_values, aux_local_values, aux_next_values, quotient_polys;
   FriProof fri;
   std::vector<u64> public_inputs;
 };
 
 // ConstraintConsumer + Stark::eval_packed_generic / eval_ext: the AIR as a straight-line program over (local, next, pis)
 template <class T>
-static void eval_air(const StarkDesc& d, const T* local, const T* next, const u64* pis, T z_last, T l_first, T l_last, const u64* alphas, T* acc) {
+static void eval_air(const StarkDesc& d, const T* local, const T* next, const u64* pis, const u64* aux_challenges, T z_last, T l_first, T l_last,
+                     const u64* alphas, T* acc) {
   T R[64];
   for (int c = 0; c < d.num_challenges; ++c) acc[c] = T();
   for (size_t pc = 0; pc < d.program.size(); ++pc) {
@@ -48,6 +54,7 @@ static void eval_air(const StarkDesc& d, const T* local, const T* next, const u6
     else if (op == AIR_OP_LDN) R[dst] = next[a];
     else if (op == AIR_OP_LDI) R[dst] = T(canon(d.program[++pc]));
     else if (op == AIR_OP_LDP) R[dst] = T(canon(pis[a]));
+    else if (op == AIR_OP_LDCH) R[dst] = T(aux_challenges[a]);
     else if (op == AIR_OP_ADD) R[dst] = R[a & 63] + R[b & 63];
     else if (op == AIR_OP_SUB) R[dst] = R[a & 63] - R[b & 63];
     else if (op == AIR_OP_MUL) R[dst] = R[a & 63] * R[b & 63];
@@ -177,20 +184,38 @@ static void fri_prove_two_points(const std::vector<const PolynomialBatch*>& orac
   }
 }
 
-// starky/src/prover.rs::prove_with_commitment (no permutation arguments)
-static StarkProof stark_prove(const StarkDesc& d, const std::vector<std::vector<u64>>& trace, const std::vector<u64>& pis, const ProveOptions& opt = ProveOptions()) {
+// starky/src/prover.rs::prove_with_commitment; with num_aux_columns > 0 a second commitment round sits between the trace
+// cap and the alphas (where starky commits its permutation Z polynomials and Curta its accumulators): `aux_fn` maps the
+// drawn challenges to the aux columns.
+typedef std::function<std::vector<std::vector<u64>>(const std::vector<u64>&)> StarkAuxFn;
+static StarkProof stark_prove(const StarkDesc& d, const std::vector<std::vector<u64>>& trace, const std::vector<u64>& pis, const ProveOptions& opt = ProveOptions(),
+                              const StarkAuxFn& aux_fn = StarkAuxFn()) {
   const int lg = d.degree_bits, rb = d.rate_bits, nch = d.num_challenges;
   const size_t n = (size_t)1 << lg;
   StarkProof proof;
   proof.public_inputs = pis;
   for (auto& v : proof.public_inputs) v = canon(v);
-  PolynomialBatch trace_b, quot_b;
+  PolynomialBatch trace_b, aux_b, quot_b;
   {
     std::vector<std::vector<u64>> cols = trace;
     trace_b.from_values(std::move(cols), rb, d.cap_height);
   }
   Challenger ch;
   ch.observe_cap(trace_b.tree.cap());
+  const int naux = d.num_aux_columns, ntot = d.num_columns + naux;
+  std::vector<u64> aux_challenges(d.num_aux_challenges);
+  if (naux > 0) {
+    for (auto& v : aux_challenges) v = ch.get_challenge();
+    if (!aux_fn) throw std::runtime_error("this AIR has a second commitment round: no aux column generator given");
+    std::vector<std::vector<u64>> cols = aux_fn(aux_challenges);
+    if ((int)cols.size() != naux) throw std::runtime_error("aux column generator returned the wrong number of columns");
+    for (auto& col : cols) {
+      if (col.size() != n) throw std::runtime_error("aux column has the wrong length");
+      for (auto& v : col) v = canon(v);
+    }
+    aux_b.from_values(std::move(cols), rb, d.cap_height);
+    ch.observe_cap(aux_b.tree.cap());
+  }
   std::vector<u64> alphas(nch);
   for (int i = 0; i < nch; ++i) alphas[i] = ch.get_challenge();
   // ---- compute_quotient_polys ----
@@ -204,17 +229,23 @@ static StarkProof stark_prove(const StarkDesc& d, const std::vector<std::vector<
   {
     const u64 w = root_of_unity(lg + qbits);
     u64 x = MULTIPLICATIVE_GENERATOR;
-    std::vector<Fp> local(d.num_columns), next(d.num_columns), acc(nch);
+    std::vector<Fp> local(ntot), next(ntot), acc(nch);
     for (size_t i = 0; i < size; ++i, x = mul(x, w)) {
       const size_t i_next = (i + next_step) % size;
       const u64* lv = trace_b.get_lde_values(i, step);
       const u64* nv = trace_b.get_lde_values(i_next, step);
       for (int c = 0; c < d.num_columns; ++c) local[c] = Fp(lv[c]), next[c] = Fp(nv[c]);
+      if (naux > 0) {
+        const u64* la = aux_b.get_lde_values(i, step);
+        const u64* na = aux_b.get_lde_values(i_next, step);
+        for (int c = 0; c < naux; ++c) local[d.num_columns + c] = Fp(la[c]), next[d.num_columns + c] = Fp(na[c]);
+      }
       // Z_H(x), the Lagrange selectors of the first / last row of H evaluated on the coset, z_last = x - g^-1
       const u64 zh = sub(pow(x, (u64)n), 1);
       const u64 l_first = mul(mul(zh, n_inv), inv(sub(x, 1)));
       const u64 l_last = mul(mul(mul(zh, n_inv), last), inv(sub(x, last)));
-      eval_air<Fp>(d, local.data(), next.data(), proof.public_inputs.data(), Fp(sub(x, last)), Fp(l_first), Fp(l_last), alphas.data(), acc.data());
+      eval_air<Fp>(d, local.data(), next.data(), proof.public_inputs.data(), aux_challenges.data(), Fp(sub(x, last)), Fp(l_first), Fp(l_last),
+                   alphas.data(), acc.data());
       const u64 zi = inv(zh);
       for (int c = 0; c < nch; ++c) qvals[c][i] = mul(acc[c].v, zi);
     }
@@ -244,24 +275,40 @@ static StarkProof stark_prove(const StarkDesc& d, const std::vector<std::vector<
   };
   proof.local_values = eval_batch(trace_b, zeta);
   proof.next_values = eval_batch(trace_b, gzeta);
+  if (naux > 0) {
+    proof.aux_local_values = eval_batch(aux_b, zeta);
+    proof.aux_next_values = eval_batch(aux_b, gzeta);
+  }
   proof.quotient_polys = eval_batch(quot_b, zeta);
-  for (auto* v : {&proof.local_values, &proof.quotient_polys})
+  // zeta batch = [trace, aux, quotient] in FRI-oracle order, zeta_next batch = [trace, aux]
+  for (auto* v : {&proof.local_values, &proof.aux_local_values, &proof.quotient_polys})
     for (Ext e : *v) ch.observe_ext(e);
-  for (Ext e : proof.next_values) ch.observe_ext(e);
+  for (auto* v : {&proof.next_values, &proof.aux_next_values})
+    for (Ext e : *v) ch.observe_ext(e);
   proof.trace_cap = trace_b.tree.cap();
+  if (naux > 0) proof.aux_cap = aux_b.tree.cap();
   proof.quotient_cap = quot_b.tree.cap();
   std::vector<const std::vector<u64>*> batch1;
   for (size_t k = 0; k < trace_b.ncols; ++k) batch1.push_back(&trace_b.coeffs[k]);
-  fri_prove_two_points({&trace_b, &quot_b}, batch1, zeta, gzeta, lg, rb, d.cap_height, d.pow_bits, d.num_query_rounds, d.arity_bits, ch, opt, proof.fri);
+  std::vector<const PolynomialBatch*> oracles = {&trace_b};
+  if (naux > 0) {
+    for (size_t k = 0; k < aux_b.ncols; ++k) batch1.push_back(&aux_b.coeffs[k]);
+    oracles.push_back(&aux_b);
+  }
+  oracles.push_back(&quot_b);
+  fri_prove_two_points(oracles, batch1, zeta, gzeta, lg, rb, d.cap_height, d.pow_bits, d.num_query_rounds, d.arity_bits, ch, opt, proof.fri);
   return proof;
 }
 
 static std::vector<uint8_t> serialize_stark_proof(const StarkProof& p) {
   ByteWriter w;
   w.cap(p.trace_cap);
+  if (!p.aux_cap.empty()) w.cap(p.aux_cap);
   w.cap(p.quotient_cap);
   w.extvec(p.local_values);
   w.extvec(p.next_values);
+  w.extvec(p.aux_local_values);
+  w.extvec(p.aux_next_values);
   w.extvec(p.quotient_polys);
   for (const auto& c : p.fri.commit_phase_caps) w.cap(c);
   for (const FriQueryRound& q : p.fri.query_rounds) {

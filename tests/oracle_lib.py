@@ -199,17 +199,34 @@ _cached = None
 
 
 def stark_prove(oracle, stark, trace, public_inputs, pow_hint=None) -> bytes:
-    """oracle/stark.hpp::stark_prove on a `vectorx_amd.Stark` description (same vx_stark_desc layout)."""
+    """oracle/stark.hpp::stark_prove on a `vectorx_amd.Stark` description (same vx_stark_desc layout); a description with a
+    second commitment round hands its `aux_fn` to the oracle as a callback."""
     L = oracle.L
-    L.vxo_stark_prove.restype = ctypes.c_longlong
-    L.vxo_stark_prove.argtypes = [_vp, _vp, _vp, _vp, _vp, _sz, ctypes.c_char_p, _sz]
+    AUXFN = ctypes.CFUNCTYPE(None, _vp, _vp, _vp)
+    L.vxo_stark_prove2.restype = ctypes.c_longlong
+    L.vxo_stark_prove2.argtypes = [_vp, _vp, _vp, _vp, AUXFN, _vp, _vp, _sz, ctypes.c_char_p, _sz]
     t = np.ascontiguousarray(trace, dtype=np.uint64)
     pi = np.ascontiguousarray(public_inputs, dtype=np.uint64)
     hint = np.array([pow_hint], dtype=np.uint64) if pow_hint is not None else None
     buf = np.empty(1 << 24, dtype=np.uint8)
     err = ctypes.create_string_buffer(512)
-    r = L.vxo_stark_prove(ctypes.cast(stark.desc_ptr, _vp), t.ctypes.data, pi.ctypes.data, hint.ctypes.data if hint is not None else None,
-                          buf.ctypes.data, buf.size, err, 512)
+    naux, nchal, n = stark.desc.num_aux_columns, stark.desc.num_aux_challenges, 1 << stark.desc.degree_bits
+    failure = []
+
+    def cb(chal_p, out_p, _user):
+        try:
+            chal = np.ctypeslib.as_array(ctypes.cast(chal_p, ctypes.POINTER(ctypes.c_uint64)), shape=(max(nchal, 1),))[:nchal].copy()
+            aux = np.ascontiguousarray(stark.aux_fn(t, chal), dtype=np.uint64)
+            assert aux.shape == (naux, n), aux.shape
+            ctypes.memmove(out_p, aux.ctypes.data, aux.nbytes)
+        except BaseException as e:      # must not propagate through the C frames
+            failure.append(e)
+
+    fn = AUXFN(cb) if naux else ctypes.cast(None, AUXFN)
+    r = L.vxo_stark_prove2(ctypes.cast(stark.desc_ptr, _vp), t.ctypes.data, pi.ctypes.data, hint.ctypes.data if hint is not None else None,
+                           fn, None, buf.ctypes.data, buf.size, err, 512)
+    if failure:
+        raise failure[0]
     if r < 0:
         raise RuntimeError(err.value.decode())
     return buf[:r].tobytes()

@@ -108,3 +108,83 @@ def mulchain(degree_bits, groups=2, seed=5, **cfg):
         t[4 * g], t[4 * g + 1], t[4 * g + 2], t[4 * g + 3] = a, b, c, mulmod(mulmod(a, b), c)
     stark = vx.Stark(degree_bits, ncols, 2, prog, constraint_degree=3, **cfg)
     return stark, t, np.array([int(t[0, 0]), int(t[2, n - 1])], dtype=np.uint64)
+
+
+def invmod(a):
+    """element-wise inverse mod p (Fermat) on a uint64 array"""
+    a = np.asarray(a, dtype=np.uint64)
+    r = np.ones_like(a)
+    base = a.copy()
+    e = P - 2
+    while e:
+        if e & 1:
+            r = mulmod(r, base)
+        base = mulmod(base, base)
+        e >>= 1
+    return r
+
+
+def addmod(a, b):
+    a = np.asarray(a, dtype=np.uint64)
+    b = np.asarray(b, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        s = a + b
+        s = np.where((s < a) | (s >= np.uint64(P)), s - np.uint64(P), s)
+    return s
+
+
+def submod(a, b):
+    a = np.asarray(a, dtype=np.uint64)
+    b = np.asarray(b, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        return np.where(a >= b, a - b, a - b + np.uint64(P))
+
+
+def logup(degree_bits, table_bits=4, seed=11, **cfg):
+    """A TWO-ROUND AIR: a log-derivative lookup (the argument behind Curta's lookup tables / bus, and the role starky's
+    permutation Z columns play).  Trace columns [v, t, m]: every v is an entry of the table column t (a table of
+    2^table_bits values repeated down the column), m = how often the row's t is looked up; after the trace commitment ONE
+    challenge gamma is drawn and the prover commits the running sum
+         acc_0 = 0,   acc_{i+1} = acc_i + 1/(gamma - v_i) - m_i/(gamma - t_i)   over the rows 0 .. n-2 (the last row is inert:
+       first- and last-row constraints are multiplied by a Lagrange selector of degree n - 1, so they must stay linear):
+       transition  (acc' - acc)(gamma - v)(gamma - t) - (gamma - t) + m (gamma - v) = 0           (degree 3)
+       first row   acc = 0             last row   acc = 0
+    Public inputs: [v_0] (first row: v = pi[0]) so that the proof is tied to a statement."""
+    n = 1 << degree_bits
+    T = 1 << table_bits
+    rng = np.random.default_rng(seed)
+    table = rng.integers(1, 1 << 40, size=T, dtype=np.uint64)
+    t = np.tile(table, n // T) if n >= T else table[:n].copy()
+    picks = rng.integers(0, min(T, n), size=n)
+    v = table[picks]
+    # multiplicities: the count of each table entry is placed on the FIRST occurrence of that entry in column t
+    m = np.zeros(n, dtype=np.uint64)
+    m[:min(T, n)] = np.bincount(picks[:n - 1], minlength=min(T, n)).astype(np.uint64)   # the last row's v is not looked up
+    trace = np.stack([v, t, m]).astype(np.uint64)
+    V, Tt, M, ACC = 0, 1, 2, 3
+    prog = [I(vx.VX_OP_LDCH, 10, 0),
+            I(vx.VX_OP_LDW, 0, V), I(vx.VX_OP_LDW, 1, Tt), I(vx.VX_OP_LDW, 2, M), I(vx.VX_OP_LDW, 3, ACC), I(vx.VX_OP_LDN, 4, ACC),
+            I(vx.VX_OP_SUB, 5, 10, 0),                    # gamma - v
+            I(vx.VX_OP_SUB, 6, 10, 1),                    # gamma - t
+            I(vx.VX_OP_MUL, 7, 5, 6),                     # (gamma - v)(gamma - t)
+            I(vx.VX_OP_MUL, 8, 2, 5),                     # m (gamma - v)
+            I(vx.VX_OP_SUB, 9, 4, 3), I(vx.VX_OP_MUL, 9, 9, 7), I(vx.VX_OP_SUB, 9, 9, 6), I(vx.VX_OP_ADD, 9, 9, 8),
+            I(vx.VX_OP_PUSH, 0, 9, vx.VX_AIR_TRANSITION),
+            I(vx.VX_OP_PUSH, 0, 3, vx.VX_AIR_FIRST_ROW),
+            I(vx.VX_OP_PUSH, 0, 3, vx.VX_AIR_LAST_ROW),
+            I(vx.VX_OP_LDP, 12, 0), I(vx.VX_OP_SUB, 12, 0, 12), I(vx.VX_OP_PUSH, 0, 12, vx.VX_AIR_FIRST_ROW),
+            I(vx.VX_OP_END)]
+
+    def aux_fn(tr, chal):
+        g = np.full(n, chal[0], dtype=np.uint64)
+        term = submod(invmod(submod(g, tr[0] % np.uint64(P))), mulmod(tr[2] % np.uint64(P), invmod(submod(g, tr[1] % np.uint64(P)))))
+        acc = np.zeros(n, dtype=np.uint64)
+        run = 0
+        tl = [int(x) for x in term]
+        for i in range(1, n):                     # exclusive prefix sum mod p
+            run = (run + tl[i - 1]) % P
+            acc[i] = run
+        return acc.reshape(1, n)
+
+    stark = vx.Stark(degree_bits, 3, 1, prog, constraint_degree=3, num_aux_columns=1, num_aux_challenges=1, aux_fn=aux_fn, **cfg)
+    return stark, trace, np.array([int(v[0])], dtype=np.uint64)

@@ -6,7 +6,7 @@ import pytest
 
 import oracle_lib
 import vectorx_amd as vx
-from stark_airs import cubic, fibonacci, mulchain
+from stark_airs import cubic, fibonacci, logup, mulchain
 
 pytestmark = pytest.mark.gpu
 P = oracle_lib.P
@@ -18,7 +18,8 @@ P = oracle_lib.P
                                                   (cubic, 5, dict(rate_bits=1)), (cubic, 9, dict(rate_bits=1)), (cubic, 11, dict(rate_bits=2)),
                                                   (cubic, 7, dict(rate_bits=3, num_query_rounds=10, fri_arities=[2, 3])),
                                                   (fibonacci, 16, {}), (mulchain, 6, dict(groups=1)), (mulchain, 10, dict(groups=5)),
-                                                  (mulchain, 13, dict(groups=8, rate_bits=2, num_query_rounds=40))])
+                                                  (mulchain, 13, dict(groups=8, rate_bits=2, num_query_rounds=40)),
+                                                  (logup, 5, {}), (logup, 9, dict(table_bits=6)), (logup, 12, dict(rate_bits=2, num_query_rounds=40))])
 def test_stark_proof_bytes_identical_to_oracle(ctx, oracle, make, degree_bits, cfg):
     cfg = dict(pow_bits=8, **cfg)
     stark, trace, pis = make(degree_bits, **cfg)
@@ -64,7 +65,7 @@ def test_air_programs_are_compiled_to_native_code_and_match_the_interpreter(ctx,
     """vx_stark_prove compiles the AIR program with hiprtc (jit.hip.h, the lowering gate programs use); VX_NO_JIT=1 keeps the
     on-GPU interpreter.  Both give the oracle's proof, byte for byte; the profile names which one ran."""
     import os
-    for make, lg in [(cubic, 10), (fibonacci, 11)]:
+    for make, lg in [(cubic, 10), (fibonacci, 11), (logup, 10)]:
         stark, trace, pis = make(lg, pow_bits=6)
         expect = oracle_lib.stark_prove(oracle, stark, trace, pis)
         ctx.prof_enable(True)
@@ -81,3 +82,32 @@ def test_air_programs_are_compiled_to_native_code_and_match_the_interpreter(ctx,
         finally:
             del os.environ["VX_NO_JIT"]
             ctx.prof_enable(False)
+
+
+def test_two_round_session_api(ctx, oracle):
+    """vx_stark_begin / vx_stark_finish directly: device-resident aux columns, a too-small output buffer leaves the session
+    usable, a second finish is refused, vx_stark_prove refuses an AIR with a second round."""
+    import ctypes
+    stark, trace, pis = logup(8, pow_bits=4)
+    expect = oracle_lib.stark_prove(oracle, stark, trace, pis)
+    L = vx.lib()
+    vp = ctypes.c_void_p
+    chal = np.zeros(1, dtype=np.uint64)
+    sess = vp()
+    t = np.ascontiguousarray(trace, dtype=np.uint64)
+    assert L.vx_stark_begin(ctx._h, ctypes.cast(stark.desc_ptr, vp), t.ctypes.data, 0, pis.ctypes.data, chal.ctypes.data, ctypes.byref(sess)) == 0
+    aux = np.ascontiguousarray(stark.aux_fn(t, chal), dtype=np.uint64)
+    d_aux = ctx.alloc(aux.nbytes)
+    ctx.upload(d_aux, aux)
+    small = np.empty(16, dtype=np.uint8)
+    n = ctypes.c_size_t(small.size)
+    assert L.vx_stark_finish(sess, vp(d_aux), 1, None, small.ctypes.data, ctypes.byref(n)) == vx.VX_E_INVALID and n.value == len(expect)
+    out = np.empty(n.value, dtype=np.uint8)
+    assert L.vx_stark_finish(sess, vp(d_aux), 1, None, out.ctypes.data, ctypes.byref(n)) == 0
+    assert out[:n.value].tobytes() == expect
+    assert L.vx_stark_finish(sess, vp(d_aux), 1, None, out.ctypes.data, ctypes.byref(n)) == vx.VX_E_INVALID
+    L.vx_stark_session_free(sess)
+    ctx.free(d_aux)
+    big = np.empty(1 << 20, dtype=np.uint8)
+    n = ctypes.c_size_t(big.size)
+    assert L.vx_stark_prove(ctx._h, ctypes.cast(stark.desc_ptr, vp), t.ctypes.data, 0, pis.ctypes.data, None, big.ctypes.data, ctypes.byref(n)) == vx.VX_E_INVALID

@@ -7,7 +7,7 @@ import pytest
 
 import oracle_lib
 import vectorx_amd as vx
-from stark_airs import cubic, fibonacci, mulchain, mulmod
+from stark_airs import cubic, fibonacci, logup, mulchain, mulmod
 
 P = oracle_lib.P
 
@@ -15,7 +15,8 @@ P = oracle_lib.P
 @pytest.mark.parametrize("make,degree_bits,cfg", [(fibonacci, 3, {}), (fibonacci, 6, {}), (fibonacci, 9, dict(rate_bits=2, num_query_rounds=20)),
                                                   (cubic, 5, dict(rate_bits=1)), (cubic, 7, dict(rate_bits=3, num_query_rounds=10, fri_arities=[2, 3])),
                                                   (fibonacci, 8, dict(num_challenges=1, cap_height=2, pow_bits=5)),
-                                                  (mulchain, 6, dict(groups=3)), (mulchain, 8, dict(groups=2, rate_bits=2, num_query_rounds=30))])
+                                                  (mulchain, 6, dict(groups=3)), (mulchain, 8, dict(groups=2, rate_bits=2, num_query_rounds=30)),
+                                                  (logup, 6, {}), (logup, 8, dict(rate_bits=2, num_query_rounds=30, table_bits=5))])
 def test_oracle_stark_proofs_are_accepted_by_the_product_verifier(oracle, make, degree_bits, cfg):
     cfg = dict(pow_bits=6, **cfg) if "pow_bits" not in cfg else cfg
     stark, trace, pis = make(degree_bits, **cfg)
@@ -70,3 +71,46 @@ def test_vectorised_mulmod_of_the_trace_generators():
     ys = [random.randrange(P) for _ in range(3000)] + [P - 1, P - 1, P - 1, P - 2, 2**32, 2**32 - 1, 2**63, P - 2**32]
     r = mulmod(np.array(xs, dtype=np.uint64), np.array(ys, dtype=np.uint64))
     assert all(int(r[i]) == xs[i] * ys[i] % P for i in range(len(xs)))
+
+
+def test_two_round_air_lookup_soundness(oracle):
+    """The second commitment round (aux columns that depend on challenges drawn after the trace cap): a log-derivative lookup.
+    A wrong multiplicity or a value outside the table either cannot be proven or yields a proof the verifier rejects; the
+    description checks know the new fields."""
+    stark, trace, pis = logup(7, pow_bits=4)
+    proof = oracle_lib.stark_prove(oracle, stark, trace, pis)
+    stark.verify(pis, proof)
+    for col, row, val in [(2, 0, None), (0, 3, 12345), (1, 5, 777)]:
+        t = trace.copy()
+        t[col, row] = (int(t[col, row]) + 1) % P if val is None else val
+        try:
+            bad = oracle_lib.stark_prove(oracle, stark, t, pis)
+        except RuntimeError:
+            continue
+        with pytest.raises(vx.VxError):
+            stark.verify(pis, bad)
+    # aux columns that do not follow the recurrence
+    good_fn = stark.aux_fn
+    stark.aux_fn = lambda tr, ch: (good_fn(tr, ch) + np.uint64(1)) % np.uint64(P)
+    try:
+        try:
+            bad = oracle_lib.stark_prove(oracle, stark, trace, pis)
+        except RuntimeError:
+            bad = None
+        if bad is not None:
+            with pytest.raises(vx.VxError):
+                stark.verify(pis, bad)
+    finally:
+        stark.aux_fn = good_fn
+    # description checks
+    stark.desc.num_aux_challenges = 0            # the program reads challenge 0
+    with pytest.raises(vx.VxError) as e:
+        stark.verify(pis, proof)
+    assert e.value.code == vx.VX_E_INVALID
+    stark.desc.num_aux_challenges = 1
+    stark.desc.num_aux_columns = 0               # challenges without a second round, and the program reads column 3
+    with pytest.raises(vx.VxError) as e:
+        stark.verify(pis, proof)
+    assert e.value.code == vx.VX_E_INVALID
+    stark.desc.num_aux_columns = 1
+    stark.verify(pis, proof)

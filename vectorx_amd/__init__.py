@@ -105,6 +105,9 @@ _SIGNATURES = {
     "vx_verify_standalone": (_i, [_vp, _vp, _vp, _sz]),
     "vx_stark_prove": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, ctypes.POINTER(_sz)]),
     "vx_stark_verify": (_i, [_vp, _vp, _vp, _sz]),
+    "vx_stark_begin": (_i, [_vp, _vp, _vp, _i, _vp, _vp, ctypes.POINTER(_vp)]),
+    "vx_stark_finish": (_i, [_vp, _vp, _i, _vp, _vp, ctypes.POINTER(_sz)]),
+    "vx_stark_session_free": (None, [_vp]),
     "vx_circuit_program_gates": (_i, [_vp, ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.c_char_p, _sz]),
     "vx_prove_sharded": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, ctypes.POINTER(_sz)]),
     "vx_group_create": (_i, [_i, ctypes.POINTER(_vp)]),
@@ -403,10 +406,11 @@ class StarkDesc(ctypes.Structure):
                 ("rate_bits", ctypes.c_int32), ("cap_height", ctypes.c_int32), ("pow_bits", ctypes.c_int32),
                 ("num_query_rounds", ctypes.c_int32), ("num_challenges", ctypes.c_int32), ("constraint_degree", ctypes.c_int32),
                 ("program_len", ctypes.c_int32), ("program", ctypes.c_void_p), ("override_flags", ctypes.c_uint32),
-                ("num_fri_reduction_arity_bits", ctypes.c_int32), ("fri_reduction_arity_bits", ctypes.c_void_p)]
+                ("num_fri_reduction_arity_bits", ctypes.c_int32), ("fri_reduction_arity_bits", ctypes.c_void_p),
+                ("num_aux_columns", ctypes.c_int32), ("num_aux_challenges", ctypes.c_int32)]
 
 
-VX_OP_END, VX_OP_LDW, VX_OP_LDC, VX_OP_LDI, VX_OP_ADD, VX_OP_SUB, VX_OP_MUL, VX_OP_PUSH, VX_OP_LDP, VX_OP_LDN = range(10)
+VX_OP_END, VX_OP_LDW, VX_OP_LDC, VX_OP_LDI, VX_OP_ADD, VX_OP_SUB, VX_OP_MUL, VX_OP_PUSH, VX_OP_LDP, VX_OP_LDN, VX_OP_LDCH = range(11)
 VX_AIR_ALL_ROWS, VX_AIR_TRANSITION, VX_AIR_FIRST_ROW, VX_AIR_LAST_ROW = range(4)
 
 
@@ -420,10 +424,14 @@ class Stark:
     StarkConfig::standard_fast_config (rate_bits 1, cap_height 4, 16 PoW bits, 84 queries, 2 challenges)."""
 
     def __init__(self, degree_bits, num_columns, num_public_inputs, program, constraint_degree, rate_bits=1, cap_height=4, pow_bits=16,
-                 num_query_rounds=84, num_challenges=2, fri_arities=None):
+                 num_query_rounds=84, num_challenges=2, fri_arities=None, num_aux_columns=0, num_aux_challenges=0, aux_fn=None):
+        """`num_aux_columns` / `num_aux_challenges` / `aux_fn`: a second commitment round — `aux_fn(trace, challenges)` returns the
+        [num_aux_columns][n] columns the caller computes between `vx_stark_begin` and `vx_stark_finish`."""
         self._prog = (ctypes.c_uint64 * len(program))(*program)
         self.desc = StarkDesc(degree_bits, num_columns, num_public_inputs, rate_bits, cap_height, pow_bits, num_query_rounds, num_challenges,
-                              constraint_degree, len(program), ctypes.cast(self._prog, ctypes.c_void_p).value, 0, 0, None)
+                              constraint_degree, len(program), ctypes.cast(self._prog, ctypes.c_void_p).value, 0, 0, None,
+                              num_aux_columns, num_aux_challenges)
+        self.aux_fn = aux_fn
         if fri_arities is not None:
             self._ar = (ctypes.c_int32 * max(1, len(fri_arities)))(*fri_arities)
             self.desc.override_flags = 2
@@ -443,8 +451,21 @@ class Stark:
         hint = None
         if pow_witness is not None:
             hint = ctypes.c_uint64(pow_witness)
-        _chk(lib().vx_stark_prove(ctx._h, ctypes.cast(self.desc_ptr, _vp), t.ctypes.data, 0, pi.ctypes.data,
-                                  None if hint is None else ctypes.cast(ctypes.pointer(hint), _vp), out.ctypes.data, ctypes.byref(n)))
+        hint_p = None if hint is None else ctypes.cast(ctypes.pointer(hint), _vp)
+        if self.desc.num_aux_columns == 0:
+            _chk(lib().vx_stark_prove(ctx._h, ctypes.cast(self.desc_ptr, _vp), t.ctypes.data, 0, pi.ctypes.data, hint_p, out.ctypes.data, ctypes.byref(n)))
+            return out[:n.value].tobytes()
+        # two rounds: commit the trace, get the challenges, compute the aux columns, finish
+        chal = np.zeros(max(1, self.desc.num_aux_challenges), dtype=np.uint64)
+        sess = _vp()
+        _chk(lib().vx_stark_begin(ctx._h, ctypes.cast(self.desc_ptr, _vp), t.ctypes.data, 0, pi.ctypes.data, chal.ctypes.data, ctypes.byref(sess)))
+        try:
+            aux = _as_u64(self.aux_fn(t, chal[:self.desc.num_aux_challenges]))
+            if aux.shape != (self.desc.num_aux_columns, 1 << self.desc.degree_bits):
+                raise VxError(VX_E_INVALID, f"aux columns have shape {aux.shape}")
+            _chk(lib().vx_stark_finish(sess, aux.ctypes.data, 0, hint_p, out.ctypes.data, ctypes.byref(n)))
+        finally:
+            lib().vx_stark_session_free(sess)
         return out[:n.value].tobytes()
 
     def verify(self, public_inputs, proof: bytes):

@@ -86,7 +86,14 @@ static JitApi& jit_api() {
 //                 PUSH adds R[a] * alpha^k (k = position of the constraint) to a0 / a1.
 //   air == true:  an AIR program (stark.hip.h) — LDW / LDN read the local / next trace row, LDP a public input; PUSH
 //                 multiplies by the kind's factor (VX_AIR_*) and folds Horner-style, acc = acc * alpha + t.
-static void jit_emit_program(std::ostringstream& s, const uint64_t* prog, int nch, bool air) {
+static void jit_emit_program(std::ostringstream& s, const uint64_t* prog, int nch, bool air, int air_ncols = 0) {
+  // AIR: columns >= air_ncols are second-round (aux) columns, held in their own LDE with the same row stride
+  auto col = [&](int a) {
+    std::ostringstream e;
+    if (air && a >= air_ncols) e << "AUX[(size_t)" << (a - air_ncols) << " * SW + ";
+    else e << "W[(size_t)" << a << " * SW + ";
+    return e.str();
+  };
   // ---- decode, then two straight-line optimisations before emitting ----------------------------------------
   //  (1) multiply-add fusion: a MUL whose result is read exactly once, by an ADD, becomes one gl_mad at the ADD
   //      (the F_p^2 products the emitters produce are chains of exactly this shape);
@@ -150,8 +157,9 @@ static void jit_emit_program(std::ostringstream& s, const uint64_t* prog, int nc
   for (const Ins& I : code) {
     if (I.skip) continue;
     switch (I.op) {
-      case VX_OP_LDW: s << "  R[" << I.dst << "] = gl_canon(W[(size_t)" << I.a << " * SW + il]);\n"; canon_reg[I.dst] = true; break;
-      case VX_OP_LDN: s << "  R[" << I.dst << "] = gl_canon(W[(size_t)" << I.a << " * SW + il_next]);\n"; canon_reg[I.dst] = true; break;
+      case VX_OP_LDW: s << "  R[" << I.dst << "] = gl_canon(" << col(I.a) << "il]);\n"; canon_reg[I.dst] = true; break;
+      case VX_OP_LDN: s << "  R[" << I.dst << "] = gl_canon(" << col(I.a) << "il_next]);\n"; canon_reg[I.dst] = true; break;
+      case VX_OP_LDCH: s << "  R[" << I.dst << "] = p.chal[" << I.a << "];\n"; canon_reg[I.dst] = true; break;
       case VX_OP_LDC: s << "  R[" << I.dst << "] = CS[(size_t)(cbase + " << I.a << ") * N + i];\n"; canon_reg[I.dst] = true; break;
       case VX_OP_LDI: s << "  R[" << I.dst << "] = " << I.imm << "ULL;\n"; canon_reg[I.dst] = true; break;
       case VX_OP_ADD:
@@ -259,12 +267,13 @@ extern "C" __global__ __launch_bounds__(256, VX_JIT_BLOCKS_PER_CU) void vx_progr
 
 // HIP source of the kernel that evaluates ONE AIR program on the quotient domain of a STARK (stark.hip.h
 // air_quotient_kernel is the interpreter with the same prologue; the argument block is AirParams, mirrored textually).
-static std::string jit_air_source(const uint64_t* prog, int nch) {
+static std::string jit_air_source(const uint64_t* prog, int nch, int ncols) {
   std::ostringstream s;
   s << "typedef unsigned long long uint64_t;\ntypedef unsigned int uint32_t;\n#define VX_JIT_BLOCKS_PER_CU 4\n"
     << JIT_PRELUDE << R"VXJIT(
 struct AirParams {
   const u64* trace;
+  const u64* aux;
   const u64* program;
   size_t stride;
   size_t rows;
@@ -272,6 +281,7 @@ struct AirParams {
   const u64 *root_lo, *root_hi;
   u64 alphas[2];
   u64 pi[64];
+  u64 chal[16];
   u64 zh[16], zh_inv[16];
   u64 last, n_inv;
   u64* out;
@@ -294,12 +304,13 @@ extern "C" __global__ __launch_bounds__(256, VX_JIT_BLOCKS_PER_CU) void vx_air_q
   const u64 l_first = gl_mul(zh_n, gl_mul(inv_both, z_last));
   const u64 l_last = gl_mul(gl_mul(zh_n, p.last), gl_mul(inv_both, xm1));
   const u64* __restrict__ W = p.trace;
+  const u64* __restrict__ AUX = p.aux;
   const size_t SW = p.stride;
   u64 a0 = 0, a1 = 0;
   u64 R[64];
 )VXJIT";
-  jit_emit_program(s, prog, nch, true);
-  s << "  p.out[il] = gl_mul(a0, p.zh_inv[z]);\n";
+  jit_emit_program(s, prog, nch, true, ncols);
+  s << "  (void)AUX;\n  p.out[il] = gl_mul(a0, p.zh_inv[z]);\n";
   if (nch > 1) s << "  p.out[p.rows + il] = gl_mul(a1, p.zh_inv[z]);\n";
   s << "}\n";
   return s.str();
@@ -354,8 +365,8 @@ static hipFunction_t jit_get(const std::vector<const uint64_t*>& progs, int nch,
   return jit_get_kernel(jit_source(progs, nch), "vx_program_gates", device, why);
 }
 // the compiled evaluator of one AIR program (stark.hip.h), or nullptr -> interpreter
-static hipFunction_t jit_air_get(const uint64_t* prog, int nch, int device, std::string* why) {
-  return jit_get_kernel(jit_air_source(prog, nch), "vx_air_quotient", device, why);
+static hipFunction_t jit_air_get(const uint64_t* prog, int nch, int ncols, int device, std::string* why) {
+  return jit_get_kernel(jit_air_source(prog, nch, ncols), "vx_air_quotient", device, why);
 }
 static hipFunction_t jit_get_kernel(const std::string& src, const char* kernel_name, int device, std::string* why) {
   if (getenv("VX_NO_JIT")) {

@@ -20,8 +20,10 @@
 #include "verifier.h"
 
 #define VX_AIR_MAX_PI 64
-struct AirParams {
+#define VX_AIR_MAX_CHALLENGES 16
+struct AirParams {  // mirrored textually in jit.hip.h::jit_air_source
   const u64* trace;  // trace LDE, column stride = stride (rows of the whole LDE), rows in Merkle-leaf (bit-reversed) order
+  const u64* aux;    // second-round columns' LDE (same stride) or null; program columns >= ncols address it
   const u64* program;
   size_t stride;
   size_t rows;  // n << qbits: the first 2^qbits cosets of the LDE = the size-(n * 2^qbits) coset 7 * H'
@@ -29,6 +31,7 @@ struct AirParams {
   const u64 *root_lo, *root_hi;
   u64 alphas[VX_MAX_CHALLENGES];
   u64 pi[VX_AIR_MAX_PI];
+  u64 chal[VX_AIR_MAX_CHALLENGES];  // the aux challenges (VX_OP_LDCH)
   u64 zh[VX_MAX_RATE], zh_inv[VX_MAX_RATE];  // Z_H on coset block z, and its inverse
   u64 last, n_inv;                            // g^-1 (the last element of H), 1/n
   u64* out;                                   // [nch][rows]
@@ -59,8 +62,9 @@ __global__ __launch_bounds__(256) void air_quotient_kernel(AirParams p) {
     const int op = (int)(ins & 0xFF), dst = (int)((ins >> 8) & 63), a = (int)((ins >> 16) & 0xFFFF), b = (int)((ins >> 32) & 0xFFFF);
     if (op == VX_OP_END) break;
     switch (op) {
-      case VX_OP_LDW: R[dst] = gl_canon(p.trace[(size_t)a * p.stride + i]); break;
-      case VX_OP_LDN: R[dst] = gl_canon(p.trace[(size_t)a * p.stride + i_next]); break;
+      case VX_OP_LDW: R[dst] = gl_canon(a < p.ncols ? p.trace[(size_t)a * p.stride + i] : p.aux[(size_t)(a - p.ncols) * p.stride + i]); break;
+      case VX_OP_LDN: R[dst] = gl_canon(a < p.ncols ? p.trace[(size_t)a * p.stride + i_next] : p.aux[(size_t)(a - p.ncols) * p.stride + i_next]); break;
+      case VX_OP_LDCH: R[dst] = p.chal[a]; break;
       case VX_OP_LDI: R[dst] = gl_canon(prog[++pc]); break;
       case VX_OP_LDP: R[dst] = p.pi[a]; break;
       case VX_OP_ADD: R[dst] = gl_add(R[a & 63], R[b & 63]); break;
@@ -97,6 +101,9 @@ static std::string stark_check(const vx_stark_desc* d, StarkShape* out) {
   if (d->degree_bits < 1 || d->rate_bits < 1 || d->degree_bits + d->rate_bits > ROOT_TABLE_LOG || (1 << d->rate_bits) > VX_MAX_RATE)
     return bad("degree_bits / rate_bits unsupported", d->degree_bits);
   if (d->num_columns < 1 || d->num_columns > 4096) return bad("bad column count", d->num_columns);
+  if (d->num_aux_columns < 0 || d->num_aux_columns > 4096) return bad("bad aux column count", d->num_aux_columns);
+  if (d->num_aux_challenges < 0 || d->num_aux_challenges > VX_AIR_MAX_CHALLENGES) return bad("too many aux challenges", d->num_aux_challenges);
+  if (d->num_aux_columns == 0 && d->num_aux_challenges != 0) return bad("aux challenges without a second commitment round", d->num_aux_challenges);
   if (d->num_public_inputs < 0 || d->num_public_inputs > VX_AIR_MAX_PI) return bad("too many public inputs", d->num_public_inputs);
   if (d->num_challenges < 1 || d->num_challenges > VX_MAX_CHALLENGES) return bad("num_challenges unsupported", d->num_challenges);
   if (d->cap_height < 0 || d->cap_height > d->degree_bits + d->rate_bits) return bad("cap_height out of range", d->cap_height);
@@ -115,10 +122,11 @@ static std::string stark_check(const vx_stark_desc* d, StarkShape* out) {
     const int op = (int)(ins & 0xFF), dst = (int)((ins >> 8) & 0xFF), a = (int)((ins >> 16) & 0xFFFF), b = (int)((ins >> 32) & 0xFFFF);
     auto is_def = [&](int r) { return r < VX_PROGRAM_REGS && ((defined >> r) & 1); };
     if (op == VX_OP_END) { ended = true; continue; }
-    if (op < VX_OP_END || op > VX_OP_LDN || op == VX_OP_LDC) return bad("bad opcode in an AIR program", op);
+    if (op < VX_OP_END || op > VX_OP_LDCH || op == VX_OP_LDC) return bad("bad opcode in an AIR program", op);
     if (op != VX_OP_PUSH && dst >= VX_PROGRAM_REGS) return bad("AIR program writes a register out of range", dst);
     if (op == VX_OP_LDI) { if (++pc >= d->program_len) return "stark: truncated AIR program"; }
-    else if (op == VX_OP_LDW || op == VX_OP_LDN) { if (a >= d->num_columns) return bad("AIR program reads a column out of range", a); }
+    else if (op == VX_OP_LDW || op == VX_OP_LDN) { if (a >= d->num_columns + d->num_aux_columns) return bad("AIR program reads a column out of range", a); }
+    else if (op == VX_OP_LDCH) { if (a >= d->num_aux_challenges) return bad("AIR program reads an aux challenge out of range", a); }
     else if (op == VX_OP_LDP) { if (a >= d->num_public_inputs) return bad("AIR program reads a public input out of range", a); }
     else if (op == VX_OP_ADD || op == VX_OP_SUB || op == VX_OP_MUL) { if (!is_def(a) || !is_def(b)) return "stark: AIR program reads a register before writing it"; }
     else if (op == VX_OP_PUSH) {
@@ -153,30 +161,45 @@ static std::string stark_check(const vx_stark_desc* d, StarkShape* out) {
   return std::string();
 }
 
-static int stark_prove_impl(vx_ctx* c, const vx_stark_desc* d, const u64* trace_in, bool on_device, const u64* pis, const u64* pow_hint,
-                            std::vector<uint8_t>& proof_out) {
-  using namespace vxh;
+// One proof in two steps (include/vxprover.h vx_stark_begin / vx_stark_finish): the trace commitment and the transcript up
+// to the aux challenges live here between the calls.  The description is deep-copied (the caller's may go away).
+struct vx_stark_session {
+  vx_ctx* c = nullptr;
+  vx_stark_desc d;
+  std::vector<uint64_t> program;
+  std::vector<int32_t> arities;
   StarkShape sh;
+  std::vector<vxh::u64> public_inputs, trace_cap, aux_challenges;
+  vx_batch* trace_b = nullptr;
+  vxh::Challenger ch;
+  bool finished = false;
+  ~vx_stark_session() {
+    if (c && trace_b) {
+      hipSetDevice(c->device);
+      batch_release(c, trace_b);
+    }
+  }
+};
+
+static int stark_begin_impl(vx_ctx* c, const vx_stark_desc* d_in, const u64* trace_in, bool on_device, const u64* pis, vx_stark_session& s) {
+  using namespace vxh;
   {
-    const std::string why = stark_check(d, &sh);
+    const std::string why = stark_check(d_in, &s.sh);
     if (!why.empty()) return vx_fail(VX_E_INVALID, "%s", why.c_str());
   }
-  const int lg = d->degree_bits, rb = d->rate_bits, LG = lg + rb, nch = d->num_challenges, ncols = d->num_columns;
-  const size_t n = (size_t)1 << lg, N = (size_t)1 << LG;
+  s.c = c;
+  s.d = *d_in;
+  s.program.assign(d_in->program, d_in->program + d_in->program_len);
+  s.d.program = s.program.data();
+  if (d_in->override_flags & VX_DESC_HAS_FRI_ARITIES) s.arities.assign(d_in->fri_reduction_arity_bits, d_in->fri_reduction_arity_bits + d_in->num_fri_reduction_arity_bits);
+  s.d.fri_reduction_arity_bits = s.arities.empty() ? nullptr : s.arities.data();
+  const vx_stark_desc* d = &s.d;
+  const int lg = d->degree_bits, rb = d->rate_bits, ncols = d->num_columns;
+  const size_t n = (size_t)1 << lg;
   const size_t cap_words = (size_t)4 << d->cap_height;
   Scratch S(c);
-  vx_batch *trace_b = nullptr, *quot_b = nullptr;
-  struct Cleanup {
-    vx_ctx* c;
-    vx_batch **a, **b;
-    ~Cleanup() {
-      batch_release(c, *a);
-      batch_release(c, *b);
-    }
-  } cleanup{c, &trace_b, &quot_b};
-  std::vector<u64> public_inputs(pis, pis + d->num_public_inputs);
-  for (auto& v : public_inputs) v = canon(v);
-
+  s.public_inputs.assign(pis, pis + d->num_public_inputs);
+  for (auto& v : s.public_inputs) v = canon(v);
   // ---- trace commitment: PolynomialBatch::from_values(trace_poly_values, rate_bits, false, cap_height) ----
   const u64* d_trace = trace_in;
   if (!on_device) {
@@ -185,13 +208,56 @@ static int stark_prove_impl(vx_ctx* c, const vx_stark_desc* d, const u64* trace_
     HIPCHK(hipMemcpyAsync(w, trace_in, (size_t)ncols * n * 8, hipMemcpyHostToDevice, c->stream));
     d_trace = w;
   }
-  VXCHK(batch_alloc(c, lg, ncols, rb, d->cap_height, &trace_b));
-  VXCHK(batch_commit_device(c, trace_b, d_trace, n, false));
-  std::vector<u64> trace_cap, quot_cap;
+  VXCHK(batch_alloc(c, lg, ncols, rb, d->cap_height, &s.trace_b));
+  VXCHK(batch_commit_device(c, s.trace_b, d_trace, n, false));
   const Shard one;
-  VXCHK(gather_cap(c, one, S, trace_b->tree + trace_b->cap_off * 4, trace_b->local_cap_words(), trace_cap));
-  Challenger ch;
-  ch.observe_elements(trace_cap.data(), cap_words);
+  VXCHK(gather_cap(c, one, S, s.trace_b->tree + s.trace_b->cap_off * 4, s.trace_b->local_cap_words(), s.trace_cap));
+  s.ch.observe_elements(s.trace_cap.data(), cap_words);
+  // second commitment round: its challenges are drawn here, between the trace cap and the aux cap
+  s.aux_challenges.resize(d->num_aux_columns > 0 ? d->num_aux_challenges : 0);
+  for (auto& v : s.aux_challenges) v = s.ch.get_challenge();
+  return VX_OK;
+}
+
+static int stark_finish_impl(vx_stark_session& s, const u64* aux_in, bool aux_on_device, const u64* pow_hint, std::vector<uint8_t>& proof_out) {
+  using namespace vxh;
+  vx_ctx* c = s.c;
+  const vx_stark_desc* d = &s.d;
+  const StarkShape& sh = s.sh;
+  const int lg = d->degree_bits, rb = d->rate_bits, LG = lg + rb, nch = d->num_challenges, ncols = d->num_columns, naux = d->num_aux_columns;
+  const size_t n = (size_t)1 << lg, N = (size_t)1 << LG;
+  const size_t cap_words = (size_t)4 << d->cap_height;
+  if (naux > 0 && !aux_in) return vx_fail(VX_E_INVALID, "vx_stark_finish: this AIR has %d aux columns and none were given", naux);
+  Scratch S(c);
+  vx_batch* trace_b = s.trace_b;
+  vx_batch *aux_b = nullptr, *quot_b = nullptr;
+  struct Cleanup {
+    vx_ctx* c;
+    vx_batch **a, **b;
+    ~Cleanup() {
+      batch_release(c, *a);
+      batch_release(c, *b);
+    }
+  } cleanup{c, &aux_b, &quot_b};
+  const std::vector<u64>& public_inputs = s.public_inputs;
+  const std::vector<u64>& trace_cap = s.trace_cap;
+  Challenger ch = s.ch;  // a copy: a failed call (e.g. an output buffer that is too small) leaves the session where vx_stark_begin left it
+  const Shard one;
+  std::vector<u64> aux_cap, quot_cap;
+  if (naux > 0) {
+    // ---- the caller's second-round columns: PolynomialBatch::from_values like the trace ----
+    const u64* d_aux = aux_in;
+    if (!aux_on_device) {
+      u64* w = S.get((size_t)naux * n);
+      if (!w) return vx_fail(VX_E_NOMEM, "stark: out of device memory (aux columns)");
+      HIPCHK(hipMemcpyAsync(w, aux_in, (size_t)naux * n * 8, hipMemcpyHostToDevice, c->stream));
+      d_aux = w;
+    }
+    VXCHK(batch_alloc(c, lg, naux, rb, d->cap_height, &aux_b));
+    VXCHK(batch_commit_device(c, aux_b, d_aux, n, false));
+    VXCHK(gather_cap(c, one, S, aux_b->tree + aux_b->cap_off * 4, aux_b->local_cap_words(), aux_cap));
+    ch.observe_elements(aux_cap.data(), cap_words);
+  }
   u64 alphas[VX_MAX_CHALLENGES] = {0, 0};
   for (int i = 0; i < nch; ++i) alphas[i] = ch.get_challenge();
 
@@ -207,6 +273,7 @@ static int stark_prove_impl(vx_ctx* c, const vx_stark_desc* d, const u64* trace_
     AirParams ap;
     memset(&ap, 0, sizeof ap);
     ap.trace = trace_b->lde;
+    ap.aux = aux_b ? aux_b->lde : nullptr;
     ap.program = d_prog;
     ap.stride = N;
     ap.rows = rows;
@@ -214,6 +281,7 @@ static int stark_prove_impl(vx_ctx* c, const vx_stark_desc* d, const u64* trace_
     ap.root_lo = c->root_lo, ap.root_hi = c->root_hi;
     for (int i = 0; i < VX_MAX_CHALLENGES; ++i) ap.alphas[i] = alphas[i];
     for (int i = 0; i < d->num_public_inputs; ++i) ap.pi[i] = public_inputs[i];
+    for (size_t i = 0; i < s.aux_challenges.size(); ++i) ap.chal[i] = s.aux_challenges[i];
     {
       // Z_H(x) on LDE block z: x^n = 7^n * w_{2^rb}^(rev_rb(z))
       const u64 shift_n = pow(7, n), g_rate = root_of_unity(rb);
@@ -229,7 +297,7 @@ static int stark_prove_impl(vx_ctx* c, const vx_stark_desc* d, const u64* trace_
       // the AIR program compiled to native code (jit.hip.h: same lowering as gate programs — fused multiply-adds, lazy
       // canonicalisation, registers promoted to VGPRs); the interpreter is the fallback when hiprtc is not there
       std::string why;
-      hipFunction_t fn = jit_air_get(d->program, nch, c->device, &why);
+      hipFunction_t fn = jit_air_get(d->program, nch, ncols, c->device, &why);
       ProfScope ps(c, fn ? "air_quotient_eval_jit" : "air_quotient_eval", 8.0 * (double)rows * 2.0 * ncols);
       if (fn) {
         void* args[] = {&ap};
@@ -296,43 +364,65 @@ static int stark_prove_impl(vx_ctx* c, const vx_stark_desc* d, const u64* trace_
   }
   const u64 g = root_of_unity(lg);
   const Ext gzeta{mul(zeta.a, g), mul(zeta.b, g)};
-  // ---- StarkOpeningSet: local_values, next_values, quotient_polys ----
-  std::vector<u64> ev_trace(2 * (size_t)ncols), ev_next(2 * (size_t)ncols), ev_quot(2 * quot_b->ncols);
+  // ---- StarkOpeningSet: local_values, next_values [, aux local / next], quotient_polys ----
+  std::vector<u64> ev_trace(2 * (size_t)ncols), ev_next(2 * (size_t)ncols), ev_aux(2 * (size_t)naux), ev_aux_next(2 * (size_t)naux), ev_quot(2 * quot_b->ncols);
   {
     u64* ztab = S.get(2 * n);
     if (!ztab) return vx_fail(VX_E_NOMEM, "stark: out of device memory (openings)");
     VXCHK(build_zeta_table(c, zeta, lg, ztab));
     VXCHK(batch_eval_ext(c, trace_b->coeffs, n, lg, ncols, ztab, ev_trace.data()));
+    if (naux) VXCHK(batch_eval_ext(c, aux_b->coeffs, n, lg, naux, ztab, ev_aux.data()));
     VXCHK(batch_eval_ext(c, quot_b->coeffs, n, lg, quot_b->ncols, ztab, ev_quot.data()));
     VXCHK(build_zeta_table(c, gzeta, lg, ztab));
     VXCHK(batch_eval_ext(c, trace_b->coeffs, n, lg, ncols, ztab, ev_next.data()));
+    if (naux) VXCHK(batch_eval_ext(c, aux_b->coeffs, n, lg, naux, ztab, ev_aux_next.data()));
   }
-  // to_fri_openings: zeta batch = [local_values, quotient_polys], zeta_next batch = [next_values]
+  // to_fri_openings: zeta batch = [local_values, aux local, quotient_polys] (FRI-oracle order), zeta_next batch = [next_values, aux next]
   std::vector<Ext> batch0, batch1;
   for (int i = 0; i < ncols; ++i) batch0.push_back(Ext{ev_trace[2 * i], ev_trace[2 * i + 1]});
+  for (int i = 0; i < naux; ++i) batch0.push_back(Ext{ev_aux[2 * i], ev_aux[2 * i + 1]});
   for (size_t i = 0; i < quot_b->ncols; ++i) batch0.push_back(Ext{ev_quot[2 * i], ev_quot[2 * i + 1]});
   for (int i = 0; i < ncols; ++i) batch1.push_back(Ext{ev_next[2 * i], ev_next[2 * i + 1]});
+  for (int i = 0; i < naux; ++i) batch1.push_back(Ext{ev_aux_next[2 * i], ev_aux_next[2 * i + 1]});
   for (Ext e : batch0) ch.observe_ext(e);
   for (Ext e : batch1) ch.observe_ext(e);
   // ---- opening proof: the same FRI prover as vx_prove ----
   FriProverParams fp;
   fp.degree_bits = lg, fp.rate_bits = rb, fp.cap_height = d->cap_height, fp.pow_bits = d->pow_bits, fp.num_queries = d->num_query_rounds;
   fp.arity_bits = sh.arity_bits;
-  std::vector<vx_batch*> oracles = {trace_b, quot_b};
-  std::vector<FriRange> batch0_ranges = {FriRange{0, 0, (size_t)ncols}, FriRange{1, 0, quot_b->ncols}};
-  std::vector<FriRange> batch1_ranges = {FriRange{0, 0, (size_t)ncols}};
+  std::vector<vx_batch*> oracles = {trace_b};
+  std::vector<FriRange> batch0_ranges = {FriRange{0, 0, (size_t)ncols}}, batch1_ranges = {FriRange{0, 0, (size_t)ncols}};
+  if (naux) {
+    oracles.push_back(aux_b);
+    batch0_ranges.push_back(FriRange{1, 0, (size_t)naux});
+    batch1_ranges.push_back(FriRange{1, 0, (size_t)naux});
+  }
+  oracles.push_back(quot_b);
+  batch0_ranges.push_back(FriRange{(int)oracles.size() - 1, 0, quot_b->ncols});
   FriParts fri;
   VXCHK(fri_prove_openings(c, fp, oracles, batch0_ranges, batch1_ranges, zeta, gzeta, batch0, batch1, ch, pow_hint, one, S, fri));
   ByteSink w;
   w.words(trace_cap.data(), cap_words);
+  if (naux) w.words(aux_cap.data(), cap_words);
   w.words(quot_cap.data(), cap_words);
   w.words(ev_trace.data(), ev_trace.size());
   w.words(ev_next.data(), ev_next.size());
+  w.words(ev_aux.data(), ev_aux.size());
+  w.words(ev_aux_next.data(), ev_aux_next.size());
   w.words(ev_quot.data(), ev_quot.size());
   write_fri_proof(w, fp, oracles, fri, one);
   w.words(public_inputs.data(), public_inputs.size());
   proof_out.swap(w.b);
   return VX_OK;
+}
+
+// vx_stark_prove: both steps in one call (an AIR without a second commitment round)
+static int stark_prove_impl(vx_ctx* c, const vx_stark_desc* d, const u64* trace_in, bool on_device, const u64* pis, const u64* pow_hint,
+                            std::vector<uint8_t>& proof_out) {
+  if (d->num_aux_columns != 0) return vx_fail(VX_E_INVALID, "vx_stark_prove: this AIR has a second commitment round: use vx_stark_begin / vx_stark_finish");
+  vx_stark_session s;
+  VXCHK(stark_begin_impl(c, d, trace_in, on_device, pis, s));
+  return stark_finish_impl(s, nullptr, false, pow_hint, proof_out);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -344,8 +434,8 @@ using vxv::Reader;
 using vxh::u64;
 
 // The AIR program over extension-field openings (local = trace(zeta), next = trace(g zeta))
-static inline void eval_air_ext(const vx_stark_desc* d, const E* local, const E* next, const u64* pis, E z_last, E l_first, E l_last,
-                                const u64* alphas, int nch, E* acc) {
+static inline void eval_air_ext(const vx_stark_desc* d, const E* local, const E* next, const u64* pis, const u64* aux_challenges, E z_last, E l_first,
+                                E l_last, const u64* alphas, int nch, E* acc) {
   E R[VX_PROGRAM_REGS];
   for (int c = 0; c < nch; ++c) acc[c] = E();
   for (int pc = 0; pc < d->program_len; ++pc) {
@@ -357,6 +447,7 @@ static inline void eval_air_ext(const vx_stark_desc* d, const E* local, const E*
       case VX_OP_LDN: R[dst] = next[a]; break;
       case VX_OP_LDI: R[dst] = E(vxh::canon(d->program[++pc])); break;
       case VX_OP_LDP: R[dst] = E(vxh::canon(pis[a])); break;
+      case VX_OP_LDCH: R[dst] = E(aux_challenges[a]); break;
       case VX_OP_ADD: R[dst] = R[a & 63] + R[b & 63]; break;
       case VX_OP_SUB: R[dst] = R[a & 63] - R[b & 63]; break;
       case VX_OP_MUL: R[dst] = R[a & 63] * R[b & 63]; break;
@@ -377,25 +468,30 @@ static std::string verify(const vx_stark_desc* d, const StarkShape& sh, const u6
   const int lg = d->degree_bits, rb = d->rate_bits, LG = lg + rb, nch = d->num_challenges, ncols = d->num_columns;
   const size_t n = (size_t)1 << lg, N = (size_t)1 << LG, cap_len = (size_t)1 << d->cap_height, R = sh.arity_bits.size();
   const size_t nquot = (size_t)nch * sh.qdf;
+  const int naux = d->num_aux_columns, noracles = naux ? 3 : 2;   // FRI oracles: trace [, aux], quotient
   Reader r{bytes, len};
-  std::vector<u64> trace_cap, quot_cap;
+  std::vector<u64> trace_cap, aux_cap, quot_cap;
   r.words(trace_cap, 4 * cap_len);
+  if (naux) r.words(aux_cap, 4 * cap_len);
   r.words(quot_cap, 4 * cap_len);
-  std::vector<E> o_local, o_next, o_quot;
+  std::vector<E> o_local, o_next, o_aux, o_aux_next, o_quot;
   r.exts(o_local, ncols);
   r.exts(o_next, ncols);
+  r.exts(o_aux, naux);
+  r.exts(o_aux_next, naux);
   r.exts(o_quot, nquot);
   std::vector<std::vector<u64>> commit_caps(R);
   for (auto& cp : commit_caps) r.words(cp, 4 * cap_len);
-  const size_t widths[2] = {(size_t)ncols, nquot};
+  size_t widths[3] = {(size_t)ncols, nquot, 0};
+  if (naux) widths[1] = (size_t)naux, widths[2] = nquot;
   struct Query {
-    std::vector<u64> leaf[2], path[2];
+    std::vector<u64> leaf[3], path[3];
     std::vector<std::vector<E>> step_evals;
     std::vector<std::vector<u64>> step_path;
   };
   std::vector<Query> queries(d->num_query_rounds);
   for (auto& q : queries) {
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < noracles; ++t) {
       r.words(q.leaf[t], widths[t]);
       r.words(q.path[t], 4 * (size_t)r.u8());
     }
@@ -421,13 +517,19 @@ static std::string verify(const vx_stark_desc* d, const StarkShape& sh, const u6
   // ---- challenges (starky get_challenges): trace cap -> alphas -> quotient cap -> zeta -> openings -> FRI ----
   vxh::Challenger ch;
   ch.observe_elements(trace_cap.data(), trace_cap.size());
+  std::vector<u64> aux_challenges(naux ? d->num_aux_challenges : 0);
+  if (naux) {
+    for (auto& v : aux_challenges) v = ch.get_challenge();
+    ch.observe_elements(aux_cap.data(), aux_cap.size());
+  }
   std::vector<u64> alphas(nch);
   for (auto& v : alphas) v = ch.get_challenge();
   ch.observe_elements(quot_cap.data(), quot_cap.size());
   const E zeta = ch.get_extension_challenge();
-  for (auto* v : {&o_local, &o_quot})
+  for (auto* v : {&o_local, &o_aux, &o_quot})
     for (E e : *v) ch.observe_ext(e.x());
-  for (E e : o_next) ch.observe_ext(e.x());
+  for (auto* v : {&o_next, &o_aux_next})
+    for (E e : *v) ch.observe_ext(e.x());
   const E fri_alpha = ch.get_extension_challenge();
   std::vector<E> fri_betas;
   for (auto& cp : commit_caps) {
@@ -450,7 +552,10 @@ static std::string verify(const vx_stark_desc* d, const StarkShape& sh, const u6
     const E l_first = vxv::scale(z_h, n_inv) * vxv::inv(zeta - E(1));
     const E l_last = vxv::scale(vxv::scale(z_h, n_inv), last) * vxv::inv(z_last);
     E acc[VX_MAX_CHALLENGES];
-    eval_air_ext(d, o_local.data(), o_next.data(), pis.data(), z_last, l_first, l_last, alphas.data(), nch, acc);
+    std::vector<E> all_local(o_local), all_next(o_next);   // program columns: trace, then aux
+    all_local.insert(all_local.end(), o_aux.begin(), o_aux.end());
+    all_next.insert(all_next.end(), o_aux_next.begin(), o_aux_next.end());
+    eval_air_ext(d, all_local.data(), all_next.data(), pis.data(), aux_challenges.data(), z_last, l_first, l_last, alphas.data(), nch, acc);
     for (int k = 0; k < nch; ++k) {
       E q;
       for (int j = sh.qdf; j-- > 0;) q = q * zeta_n + o_quot[(size_t)k * sh.qdf + j];
@@ -462,17 +567,19 @@ static std::string verify(const vx_stark_desc* d, const StarkShape& sh, const u6
   const E points[2] = {zeta, vxv::scale(zeta, vxh::root_of_unity(lg))};
   E reduced[2];
   {
-    std::vector<E> b0(o_local);
+    std::vector<E> b0(o_local), b1(o_next);
+    b0.insert(b0.end(), o_aux.begin(), o_aux.end());
     b0.insert(b0.end(), o_quot.begin(), o_quot.end());
+    b1.insert(b1.end(), o_aux_next.begin(), o_aux_next.end());
     for (size_t i = b0.size(); i-- > 0;) reduced[0] = reduced[0] * fri_alpha + b0[i];
-    for (size_t i = o_next.size(); i-- > 0;) reduced[1] = reduced[1] * fri_alpha + o_next[i];
+    for (size_t i = b1.size(); i-- > 0;) reduced[1] = reduced[1] * fri_alpha + b1[i];
   }
-  const u64* caps[2] = {trace_cap.data(), quot_cap.data()};
+  const u64* caps[3] = {trace_cap.data(), naux ? aux_cap.data() : quot_cap.data(), quot_cap.data()};
   const u64 wN = vxh::root_of_unity(LG);
   for (int qi = 0; qi < d->num_query_rounds; ++qi) {
     const Query& q = queries[qi];
     size_t xi = x_indices[qi];
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < noracles; ++t) {
       if (q.path[t].size() != 4 * (size_t)(LG - d->cap_height)) return "initial Merkle proof has the wrong length";
       if (!vxv::merkle_ok(q.leaf[t].data(), widths[t], xi, caps[t], cap_len, q.path[t])) return "initial Merkle proof fails (oracle " + std::to_string(t) + ")";
     }
@@ -481,9 +588,9 @@ static std::string verify(const vx_stark_desc* d, const StarkShape& sh, const u6
     for (int b = 0; b < 2; ++b) {
       std::vector<u64> ev;
       if (b == 0)
-        for (int t = 0; t < 2; ++t) ev.insert(ev.end(), q.leaf[t].begin(), q.leaf[t].end());
+        for (int t = 0; t < noracles; ++t) ev.insert(ev.end(), q.leaf[t].begin(), q.leaf[t].end());
       else
-        ev = q.leaf[0];
+        for (int t = 0; t < noracles - 1; ++t) ev.insert(ev.end(), q.leaf[t].begin(), q.leaf[t].end());   // trace [, aux] at g * zeta
       E red;
       for (size_t i = ev.size(); i-- > 0;) red = red * fri_alpha + E(ev[i]);
       sum = sum * E(vxh::epow(fri_alpha.x(), ev.size())) + (red - reduced[b]) * vxv::inv(E(sx) - points[b]);

@@ -780,6 +780,59 @@ int vx_stark_prove(vx_ctx* c, const vx_stark_desc* d, const uint64_t* trace, int
   *out_len = proof.size();
   return VX_OK;
 }
+int vx_stark_begin(vx_ctx* c, const vx_stark_desc* d, const uint64_t* trace, int trace_on_device, const uint64_t* public_inputs,
+                   uint64_t* aux_challenges_out, vx_stark_session** out) {
+  if (!c || !d || !trace || !out || (d->num_public_inputs > 0 && !public_inputs)) return vx_fail(VX_E_INVALID, "vx_stark_begin: NULL argument");
+  *out = nullptr;
+  HIPCHK(hipSetDevice(c->device));
+  int rc;
+  vx_stark_session* s = nullptr;
+  try {
+    s = new vx_stark_session();
+    rc = stark_begin_impl(c, d, trace, trace_on_device != 0, public_inputs, *s);
+    if (rc == VX_OK && !s->aux_challenges.empty() && !aux_challenges_out) rc = vx_fail(VX_E_INVALID, "vx_stark_begin: NULL aux_challenges_out");
+  } catch (const std::bad_alloc&) {
+    rc = vx_fail(VX_E_NOMEM, "vx_stark_begin: out of host memory");
+  } catch (const std::exception& e) {
+    rc = vx_fail(VX_E_INVALID, "vx_stark_begin: %s", e.what());
+  }
+  if (rc != VX_OK) {
+    hipStreamSynchronize(c->stream);
+    delete s;
+    return rc;
+  }
+  for (size_t i = 0; i < s->aux_challenges.size(); ++i) aux_challenges_out[i] = s->aux_challenges[i];
+  *out = s;
+  return VX_OK;
+}
+int vx_stark_finish(vx_stark_session* s, const uint64_t* aux_columns, int aux_on_device, const uint64_t* pow_witness_hint, uint8_t* out_buf,
+                    size_t* out_len) {
+  if (!s || !out_buf || !out_len) return vx_fail(VX_E_INVALID, "vx_stark_finish: NULL argument");
+  if (s->finished) return vx_fail(VX_E_INVALID, "vx_stark_finish: the session has already produced its proof");
+  HIPCHK(hipSetDevice(s->c->device));
+  std::vector<uint8_t> proof;
+  int rc;
+  try {
+    rc = stark_finish_impl(*s, aux_columns, aux_on_device != 0, pow_witness_hint, proof);
+  } catch (const std::bad_alloc&) {
+    rc = vx_fail(VX_E_NOMEM, "vx_stark_finish: out of host memory");
+  } catch (const std::exception& e) {
+    rc = vx_fail(VX_E_INVALID, "vx_stark_finish: %s", e.what());
+  }
+  if (rc != VX_OK) {
+    hipStreamSynchronize(s->c->stream);
+    return rc;
+  }
+  if (proof.size() > *out_len) {
+    *out_len = proof.size();
+    return vx_fail(VX_E_INVALID, "vx_stark_finish: output buffer too small, need %zu bytes", proof.size());
+  }
+  memcpy(out_buf, proof.data(), proof.size());
+  *out_len = proof.size();
+  s->finished = true;
+  return VX_OK;
+}
+void vx_stark_session_free(vx_stark_session* s) { delete s; }
 int vx_stark_verify(const vx_stark_desc* d, const uint64_t* public_inputs, const uint8_t* proof, size_t proof_len) {
   if (!d || !proof || (d->num_public_inputs > 0 && !public_inputs)) return vx_fail(VX_E_INVALID, "vx_stark_verify: NULL argument");
   try {
