@@ -323,8 +323,8 @@ typedef struct vx_stark_desc {
    * Curta its lookup / bus accumulators.  The AIR program addresses them as columns num_columns .. num_columns +
    * num_aux_columns - 1 (VX_OP_LDW / VX_OP_LDN) and reads the challenges with VX_OP_LDCH.  The columns themselves are
    * witness data (running sums / products over rows): the CALLER computes them between vx_stark_begin and vx_stark_finish.
-   * (As in starky, first- and last-row constraints are multiplied by a Lagrange selector of degree n - 1: keep them at degree
-   * <= constraint_degree - 2 + 1, i.e. linear for constraint_degree 3, or the quotient no longer fits its chunks.) */
+   * (As in starky, first- and last-row constraints are multiplied by a Lagrange selector of degree n - 1: their own degree
+   * must stay <= constraint_degree - 1, or the quotient no longer fits its quotient_degree_factor chunks.) */
   int32_t num_aux_columns, num_aux_challenges;
 } vx_stark_desc;
 #define VX_OP_LDCH 10 /* AIR programs only: r[dst] = aux challenge a */

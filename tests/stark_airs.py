@@ -146,7 +146,8 @@ def logup(degree_bits, table_bits=4, seed=11, **cfg):
     2^table_bits values repeated down the column), m = how often the row's t is looked up; after the trace commitment ONE
     challenge gamma is drawn and the prover commits the running sum
          acc_0 = 0,   acc_{i+1} = acc_i + 1/(gamma - v_i) - m_i/(gamma - t_i)   over the rows 0 .. n-2 (the last row is inert:
-       first- and last-row constraints are multiplied by a Lagrange selector of degree n - 1, so they must stay linear):
+       first- and last-row constraints are multiplied by a Lagrange selector of degree n - 1, so their own degree must stay
+       below the constraint degree — closing the sum in the last row with the degree-3 term would not fit):
        transition  (acc' - acc)(gamma - v)(gamma - t) - (gamma - t) + m (gamma - v) = 0           (degree 3)
        first row   acc = 0             last row   acc = 0
     Public inputs: [v_0] (first row: v = pi[0]) so that the proof is tied to a statement."""
