@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""One-off soak of the STARK path: random AIRs / sizes / configurations proven on the GPU (compiled and interpreted AIR
+programs alternating) and by the oracle; proofs must be byte-identical, vx_stark_verify must accept them and reject a bit flip.
+
+    python tools/soak_stark.py [seconds] [seed] [max_degree_bits] > gpurun_out/soak_stark.jsonl
+"""
+import faulthandler
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+import oracle_lib  # noqa: E402  (checker only)
+import vectorx_amd as vx  # noqa: E402
+from stark_airs import cubic, fibonacci, logup, mulchain  # noqa: E402
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2024)
+db_max = int(sys.argv[3]) if len(sys.argv) > 3 else 13
+oracle = oracle_lib.load()
+ctx = vx.Context(0)
+t_end = time.time() + budget
+n_ok, n_bad, by_kind = 0, 0, {}
+while time.time() < t_end:
+    kind = str(rng.choice(["fibonacci", "cubic", "mulchain", "logup"]))
+    lg = int(rng.integers(5 if kind == "logup" else 3, db_max + 1))
+    rate_bits = int(rng.choice([1, 1, 2, 3]))
+    cfg = dict(rate_bits=rate_bits, pow_bits=int(rng.choice([0, 4, 8])), num_query_rounds=int(rng.choice([5, 20, 84])),
+               num_challenges=int(rng.choice([1, 2])), cap_height=int(rng.integers(0, min(4, lg + rate_bits) + 1)))
+    if rng.random() < 0.3:
+        ar, left = [], lg
+        while left > 0 and len(ar) < 5 and rng.random() < 0.8:
+            a = int(rng.integers(1, min(4, left) + 1))
+            if lg + rate_bits - sum(ar) - a < cfg["cap_height"]:
+                break
+            ar.append(a)
+            left -= a
+        cfg["fri_arities"] = ar
+    if kind == "fibonacci":
+        stark, trace, pis = fibonacci(lg, x0=int(rng.integers(0, 1 << 40)), x1=int(rng.integers(1, 1 << 40)), **cfg)
+    elif kind == "cubic":
+        stark, trace, pis = cubic(lg, seed=int(rng.integers(1, 1 << 40)), **cfg)
+    elif kind == "mulchain":
+        stark, trace, pis = mulchain(lg, groups=int(rng.integers(1, 7)), seed=int(rng.integers(1, 1 << 20)), **cfg)
+    else:
+        stark, trace, pis = logup(lg, table_bits=int(rng.integers(2, min(lg - 1, 6) + 1)), seed=int(rng.integers(1, 1 << 20)), **cfg)
+    jit = bool(rng.random() < 0.7)
+    print(json.dumps({"case": n_ok + n_bad, "kind": kind, "degree_bits": lg, "jit": jit, **{k: v for k, v in cfg.items()}}), file=sys.stderr, flush=True)
+    faulthandler.dump_traceback_later(180, exit=True)
+    if not jit:
+        os.environ["VX_NO_JIT"] = "1"
+    try:
+        got = stark.prove(ctx, trace, pis)
+    finally:
+        os.environ.pop("VX_NO_JIT", None)
+    want = oracle_lib.stark_prove(oracle, stark, trace, pis)
+    ok = got == want
+    try:
+        stark.verify(pis, got)
+    except vx.VxError:
+        ok = False
+    bad = bytearray(got)
+    bad[int(rng.integers(0, len(bad)))] ^= 1 << int(rng.integers(0, 8))
+    try:
+        stark.verify(pis, bytes(bad))
+        ok = False
+    except vx.VxError:
+        pass
+    faulthandler.cancel_dump_traceback_later()
+    key = f"{kind}/rate{rate_bits}" + ("" if jit else "/interpreted") + ("/A" if "fri_arities" in cfg else "")
+    by_kind[key] = by_kind.get(key, 0) + 1
+    if ok:
+        n_ok += 1
+    else:
+        n_bad += 1
+        print(json.dumps({"FAIL": {"kind": kind, "degree_bits": lg, "jit": jit, **cfg}}), flush=True)
+print(json.dumps({"stark_cases": n_ok + n_bad, "identical_and_verified": n_ok, "failures": n_bad, "seconds": budget, "max_degree_bits": db_max,
+                  "by_kind": by_kind}), flush=True)
