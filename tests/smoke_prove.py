@@ -1,5 +1,6 @@
 """One small whole proof on cuda:0 checked against the oracle — called by __graft_entry__.smoke().  Also one proof of a
-circuit with constraint-program gates + a lookup table, and one STARK (Fibonacci AIR), each byte-compared with the oracle."""
+circuit with constraint-program gates + a lookup table, and two STARKs (Fibonacci AIR; a two-round lookup AIR), each byte-compared
+with the oracle."""
 
 
 def run(ctx, oracle):
@@ -31,9 +32,14 @@ def run(ctx, oracle):
     import sys
     from pathlib import Path
     sys.path.insert(0, str(Path(__file__).resolve().parent))
-    from stark_airs import fibonacci
+    from stark_airs import fibonacci, logup
     stark, trace, pis = fibonacci(8, pow_bits=8)
     sp = stark.prove(ctx, trace, pis)
     assert sp == oracle_lib.stark_prove(oracle, stark, trace, pis), "GPU STARK proof differs from the oracle's"
     stark.verify(pis, sp)
     print(f"smoke ok: vx_stark_prove (Fibonacci AIR, n=2^8, {len(sp)} bytes) byte-identical to the oracle and verifies")
+    stark, trace, pis = logup(7, pow_bits=6)               # second commitment round: vx_stark_begin / vx_stark_finish
+    sp = stark.prove(ctx, trace, pis)
+    assert sp == oracle_lib.stark_prove(oracle, stark, trace, pis), "GPU two-round STARK proof differs from the oracle's"
+    stark.verify(pis, sp)
+    print(f"smoke ok: vx_stark_begin / vx_stark_finish (log-derivative lookup AIR, n=2^7, {len(sp)} bytes) byte-identical to the oracle")
