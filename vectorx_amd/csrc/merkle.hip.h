@@ -34,7 +34,7 @@ __global__ __launch_bounds__(HASH_THREADS, 4) void hash_leaves_colmajor_kernel(
     for (int c = 0; c < ncols; c += 8) {
 #pragma unroll
       for (int i = 0; i < 8; ++i)
-        if (c + i < ncols) s[i] = gl_canon(cols[(size_t)(c + i) * col_stride + row]);
+        if (c + i < ncols) s[i] = cols[(size_t)(c + i) * col_stride + row];   // any u64 representative: the permutation works on those
       poseidon_permute_nc(s);
     }
   }
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(HASH_THREADS, 4) void hash_leaves_rowmajor_kernel(
     for (int c = 0; c < width; c += 8) {
 #pragma unroll
       for (int i = 0; i < 8; ++i)
-        if (c + i < width) s[i] = gl_canon(src[c + i]);
+        if (c + i < width) s[i] = src[c + i];
       poseidon_permute_nc(s);
     }
   }
