@@ -333,7 +333,9 @@ int vx_stark_prove(vx_ctx* ctx, const vx_stark_desc* desc, const uint64_t* trace
 /* The two-round form: vx_stark_begin commits the trace and returns the aux challenges; vx_stark_finish takes the aux
  * columns [num_aux_columns][2^degree_bits] (host or device) and completes the proof:
  *   trace_cap | aux_cap | quotient_cap | trace(zeta) | trace(g zeta) | aux(zeta) | aux(g zeta) | quotient(zeta) | FriProof | public inputs.
- * With num_aux_columns = 0 the pair is equivalent to vx_stark_prove.  A session is used for one proof and then freed. */
+ * With num_aux_columns = 0 the pair is equivalent to vx_stark_prove.  A session is used for one proof and then freed —
+ * BEFORE its context is destroyed (it holds the trace commitment in that context's memory); a vx_stark_finish that fails
+ * (e.g. output buffer too small: *out_len then holds the size needed) leaves the session usable. */
 typedef struct vx_stark_session vx_stark_session;
 int vx_stark_begin(vx_ctx* ctx, const vx_stark_desc* desc, const uint64_t* trace, int trace_on_device, const uint64_t* public_inputs,
                    uint64_t* aux_challenges_out /* [num_aux_challenges] */, vx_stark_session** out);
