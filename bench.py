@@ -14,6 +14,9 @@ CPU restatement of plonky2 v0.2.0, timed on this box's host cores on a bounded s
 """
 import argparse
 import json
+import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -73,13 +76,60 @@ def cpu_baseline_commit(args):
     }
 
 
+def _pci_bus_id(torch, idx) -> int:
+    p = torch.cuda.get_device_properties(idx)
+    return int(getattr(p, "pci_bus_id", -1))
+
+
+def launch_ranks(args) -> int:
+    """`python bench.py --gpus N` run plainly (no launcher): start the N ranks as CHILD processes through
+    torch.distributed.run — before this process has made a single GPU call, and never by exec — relay rank 0's JSON
+    line and return the launcher's exit code.  Fewer than N visible devices is an error, not a smaller run."""
+    import torch
+    ndev = torch.cuda.device_count()      # does not initialise the GPU on this image
+    if ndev < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} asked for but only {ndev} GPU(s) are visible — refusing to run a smaller job "
+              f"under that label", file=sys.stderr)
+        return 3
+    with socket.socket() as s:            # a free rendezvous port on the loopback
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["VX_BENCH_CHILD"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in r.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if r.returncode == 0 and line is None:
+        print("bench.py: the ranks exited 0 but rank 0 printed no result line", file=sys.stderr)
+        return 4
+    if line is not None and r.returncode == 0:
+        print(line, flush=True)
+    return r.returncode
+
+
 def main():
     args = parse()
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            sys.exit(launch_ranks(args))
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ['WORLD_SIZE']} ranks")
     import torch
     import vectorx_amd as vx
     from vectorx_amd import dist_harness as H
 
     rank, world, local_rank = H.env_rank()
+    if local_rank >= torch.cuda.device_count():
+        sys.exit(f"bench.py: rank {rank} has LOCAL_RANK={local_rank} but only {torch.cuda.device_count()} GPU(s) are visible")
     dist = H.init("nccl", local_rank)
     ctx = vx.Context(local_rank)  # no CPU fallback: raises if the HIP library / GPU is missing
     n = 1 << args.log_n
@@ -113,9 +163,19 @@ def main():
     def before_timed():
         ctx.prof_enable(True)
         ctx.prof_reset()
+        if args.workload == "prove" and "allgather" in bench_prove._LEG:   # sharded mode: count the timed steps' exchanges only
+            bench_prove._LEG["allgather"].calls = bench_prove._LEG["allgather"].bytes = 0
 
     dt = H.run_timed(step, args.steps, args.warmup, sync, dist, device=f"cuda:{local_rank}", before_timed=before_timed)
     prof = ctx.prof()
+    # which device every rank ran on — gathered over RCCL, so the line proves N distinct GPUs took part
+    rank_devices, rccl_ranks = [{"rank": 0, "local_rank": local_rank, "pci_bus_id": _pci_bus_id(torch, local_rank)}], 1
+    if dist is not None:
+        rccl_ranks = dist.get_world_size()
+        mine = torch.tensor([rank, local_rank, _pci_bus_id(torch, local_rank)], dtype=torch.int64, device=f"cuda:{local_rank}")
+        slots = [torch.empty_like(mine) for _ in range(rccl_ranks)]
+        dist.all_gather(slots, mine)
+        rank_devices = [{"rank": int(t[0]), "local_rank": int(t[1]), "pci_bus_id": int(t[2])} for t in (x.cpu() for x in slots)]
     hash_clock_ghz = ctx.clock_ghz() if args.workload == "prove" else None   # before anything else runs: the timed region's own samples
     ctx.prof_enable(False)
 
@@ -197,12 +257,17 @@ def main():
                                        f"coefficients, first FRI layer, openings; NO row-chunk all-to-all NTT in this mode — that "
                                        f"formulation exists for the commitment only: sharded.commit_sharded)" if sharded_mode else
                                        f"proof-level x{world} (one witness per GPU, no collective)")},
+            "rccl_ranks": rccl_ranks, "rank_devices": rank_devices,
             "roofline": roof,
             "alu_bound_dominant_kernel": alu,
             "stage_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in prof.items()},
             "stage_alg_GBps": {k: round(v["alg_bytes"] / (v["ms"] * 1e-3) / 1e9, 1) for k, v in prof.items()
                                if v["alg_bytes"] and v["ms"]},
         }
+        if sharded_mode:
+            ag = bench_prove._LEG["allgather"]
+            out["exchange"] = {"allgather_calls_per_proof": ag.calls / args.steps, "inbound_bytes_per_rank_per_proof": ag.bytes / args.steps,
+                               "backend": dist.get_backend(), "what": "in-place all-gathers vx_prove_sharded asked its host for (RCCL over xGMI)"}
         if host_leg is not None:
             out["value_from_host_witness"] = host_leg
         if not args.no_cpu_baseline and world == 1:

@@ -24,6 +24,7 @@ def make_step(ctx, args, rank, dist=None, device=None):
     if sharded_mode:
         from vectorx_amd.sharded import TorchAllGather
         ag = TorchAllGather(ctx, dist, device)
+        _LEG["allgather"] = ag
         world = dist.get_world_size()
 
         def step():

@@ -490,10 +490,10 @@ static std::vector<uint8_t> serialize_proof(const Proof& p) {
   w.extvec(o.wires);
   w.extvec(o.plonk_zs);
   w.extvec(o.plonk_zs_next);
+  w.extvec(o.lookup_zs);  // util/serialization write_opening_set: lookup openings before the partial products
+  w.extvec(o.lookup_zs_next);
   w.extvec(o.partial_products);
   w.extvec(o.quotient_polys);
-  w.extvec(o.lookup_zs);
-  w.extvec(o.lookup_zs_next);
   for (const auto& c : p.fri.commit_phase_caps) w.cap(c);
   for (const FriQueryRound& q : p.fri.query_rounds) {
     for (size_t t = 0; t < q.initial.evals.size(); ++t) {
@@ -1143,10 +1143,10 @@ static bool deserialize_proof(const Circuit& c, const uint8_t* bytes, size_t len
   o.wires = r.extvec(c.num_wires);
   o.plonk_zs = r.extvec(nch);
   o.plonk_zs_next = r.extvec(nch);
-  o.partial_products = r.extvec((size_t)nch * c.num_partial_products());
-  o.quotient_polys = r.extvec(c.num_quotient());
   o.lookup_zs = r.extvec((size_t)nch * c.num_lookup_polys());
   o.lookup_zs_next = r.extvec((size_t)nch * c.num_lookup_polys());
+  o.partial_products = r.extvec((size_t)nch * c.num_partial_products());
+  o.quotient_polys = r.extvec(c.num_quotient());
   p.fri.commit_phase_caps.clear();
   for (size_t i = 0; i < c.reduction_arity_bits.size(); ++i) p.fri.commit_phase_caps.push_back(r.cap(c.cap_height));
   const size_t widths[4] = {(size_t)c.num_preprocessed(), (size_t)c.num_wires, (size_t)c.num_zs_pp_lookup(), (size_t)c.num_quotient()};

@@ -201,6 +201,29 @@ static StarkProof stark_prove(const StarkDesc& d, const std::vector<std::vector<
     trace_b.from_values(std::move(cols), rb, d.cap_height);
   }
   Challenger ch;
+  {
+    // the statement first (shape + FRI configuration, Poseidon digest of the program as 32-bit limbs, public inputs): the
+    // library's own transcript prefix — old starky observes nothing before the trace cap (weak Fiat-Shamir)
+    std::vector<u64> st = {(u64)d.degree_bits, (u64)d.rate_bits, (u64)d.cap_height, (u64)d.pow_bits, (u64)d.num_query_rounds, (u64)d.num_challenges,
+                           (u64)d.constraint_degree, (u64)d.num_columns, (u64)d.num_aux_columns, (u64)d.num_aux_challenges, (u64)d.num_public_inputs,
+                           (u64)d.arity_bits.size()};
+    for (int a : d.arity_bits) st.push_back((u64)a);
+    std::vector<u64> limbs;
+    for (size_t pc = 0; pc < d.program.size(); ++pc) {
+      const u64 w = d.program[pc];
+      limbs.push_back(w & 0xFFFFFFFFu), limbs.push_back(w >> 32);
+      if ((w & 0xFF) == (u64)AIR_OP_END) break;
+      if ((w & 0xFF) == (u64)AIR_OP_LDI && pc + 1 < d.program.size()) {
+        const u64 imm = d.program[++pc];
+        limbs.push_back(imm & 0xFFFFFFFFu), limbs.push_back(imm >> 32);
+      }
+    }
+    const Hash ph = hash_no_pad(limbs.data(), limbs.size());
+    for (int i = 0; i < 4; ++i) st.push_back(ph.e[i]);
+    if ((int)proof.public_inputs.size() != d.num_public_inputs) throw std::runtime_error("wrong number of public inputs");
+    st.insert(st.end(), proof.public_inputs.begin(), proof.public_inputs.end());
+    ch.observe_elements(st.data(), st.size());
+  }
   ch.observe_cap(trace_b.tree.cap());
   const int naux = d.num_aux_columns, ntot = d.num_columns + naux;
   std::vector<u64> aux_challenges(d.num_aux_challenges);

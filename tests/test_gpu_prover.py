@@ -102,7 +102,7 @@ def test_prove_argument_errors(ctx):
     old = d.quotient_degree_factor
     d.quotient_degree_factor = 4
     with pytest.raises(vx.VxError):
-        vx.Circuit(ctx, sc.desc_ptr)                  # unsupported configuration is refused, not mis-proved
+        vx.Circuit(ctx, sc.desc_ptr)                  # factor 4 is supported, but this circuit holds a PoseidonGate (filtered degree 9 > 4 + 1): refused, not mis-proved
     d.quotient_degree_factor = old
     gc.free()
 

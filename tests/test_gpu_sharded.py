@@ -244,6 +244,44 @@ def test_bench_two_gpus_under_torchrun(mode):
     assert line["scaling"] == ("strong" if mode == "sharded" else "weak")
 
 
+def _plain_bench(*extra):
+    """`python bench.py --gpus N ...` run PLAINLY — no launcher in front: bench.py starts its own ranks as child processes"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    return subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "2", "--warmup", "1", "--log-n", "16", "--no-cpu-baseline", *extra],
+                          capture_output=True, text=True, timeout=900, cwd=str(ROOT), env=env)
+
+
+@pytest.mark.parametrize("mode", ["throughput", "sharded"])
+def test_bench_gpus_2_run_plainly_launches_two_ranks(mode):
+    """the driver's command form is `python3 bench.py --gpus N ...`: it must BE an N-rank run (VERDICT r2 #1)"""
+    _need_devices(2)
+    r = _plain_bench("--gpus", "2", "--mode", mode)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["value"] > 0
+    assert len({d["local_rank"] for d in line["rank_devices"]}) == 2
+    if mode == "sharded":
+        assert line["exchange"]["allgather_calls_per_proof"] >= 8 and line["exchange"]["inbound_bytes_per_rank_per_proof"] > 0
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """asking for more GPUs than the box has must fail loudly — never a smaller run that prints a result line"""
+    n = vx.lib().vx_device_count()
+    r = _plain_bench("--gpus", str(n + 1))
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert "refusing" in r.stderr
+
+
+def test_bench_single_gpu_line_names_its_device():
+    r = _plain_bench("--gpus", "1", "--no-host-witness-leg")
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["rccl_ranks"] == 1 and len(line["rank_devices"]) == 1
+
+
 @pytest.mark.parametrize("degree_bits,world,flags", [(7, 2, 16), (9, 4, 16 | 1), (11, 8, 16)])
 def test_sharded_proof_with_lookup_argument(oracle, degree_bits, world, flags):
     sc = SynthCircuit(degree_bits, seed=1900 + degree_bits, poseidon_percent=40, flags=flags)

@@ -192,9 +192,9 @@ def test_lookup_argument_oracle_prover_and_product_verifier_agree(oracle, degree
         bad_w[col, row] = (int(bad_w[col, row]) + 1) % P
         bad = oc.prove(bad_w)
         assert oc.verify(bad) != "" and _verdict(sc, cap, bad) != "", (col, row)
-    # tampering with the lookup openings (they follow the quotient openings) is caught by both verifiers
+    # tampering with the lookup openings (write_opening_set puts them right after plonk_zs_next) is caught by both verifiers
     d = sc.desc
-    off_lookup = 3 * (32 << d.cap_height) + 16 * (d.num_constants + 80 + 135 + 2 + 2 + 18 + 16)
+    off_lookup = 3 * (32 << d.cap_height) + 16 * (d.num_constants + 80 + 135 + 2 + 2)
     for off in (off_lookup + 3, off_lookup + 16 * 14 + 9):
         bad = bytearray(proof)
         bad[off] ^= 1
@@ -205,3 +205,20 @@ def test_lookup_argument_oracle_prover_and_product_verifier_agree(oracle, degree
     assert _verdict(sc, cap, proof) != ""
     outs[0] ^= 1
     assert _verdict(sc, cap, proof) == ""
+
+
+def test_more_lookup_tables_than_the_prover_holds_are_refused(oracle):
+    """the prover's lookup path is sized for VX_MAX_LUTS = 8 tables; a description with more must be
+    answered VX_E_INVALID by the one validator instead of overrunning LookupParams in vx_prove."""
+    from vectorx_amd.synth import FLAG_LOOKUP
+    sc = SynthCircuit(6, seed=77, poseidon_percent=40, flags=FLAG_LOOKUP)
+    sc.desc.pow_bits = 5
+    oc = oracle_lib.OracleCircuit(oracle, sc.desc_ptr)
+    cap, proof = oc.cap(), oc.prove(sc.witness())
+    vx.verify_standalone(sc.desc_ptr, cap, proof)
+    sc.desc.num_luts, sc.desc.num_lookup_selectors = 9, 13
+    with pytest.raises(vx.VxError) as e:
+        vx.verify_standalone(sc.desc_ptr, cap, proof)
+    assert e.value.code == vx.VX_E_INVALID and "num_luts" in str(e.value)
+    sc.desc.num_luts, sc.desc.num_lookup_selectors = 1, 5
+    vx.verify_standalone(sc.desc_ptr, cap, proof)

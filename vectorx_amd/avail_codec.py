@@ -134,3 +134,9 @@ def pack_rotate_input(authority_set_id: int, authority_set_hash: bytes) -> bytes
     if len(authority_set_hash) != 32:
         raise ValueError("hashes are 32 bytes")
     return struct.pack(">Q", authority_set_id) + authority_set_hash
+
+
+def unpack_rotate_input(raw: bytes) -> dict:
+    if len(raw) != 40:
+        raise ValueError("rotate input is 40 bytes")
+    return {"authority_set_id": struct.unpack(">Q", raw[0:8])[0], "authority_set_hash": raw[8:40]}

@@ -56,7 +56,7 @@ static inline std::string desc_check(const vx_circuit_desc* d, bool need_preproc
     if ((uint64_t)d->pi_rows[i] >= ((uint64_t)1 << d->degree_bits) || (int64_t)d->pi_cols[i] >= d->num_wires) return bad("public input target out of range", i);
   if (d->programs_len < 0 || (d->programs_len && !d->programs)) return bad("bad programs_len", d->programs_len);
   // lookup argument: sizes first, the gate constants start after BOTH kinds of selectors
-  if (d->num_luts < 0 || d->num_luts > 64) return bad("num_luts unsupported", d->num_luts);
+  if (d->num_luts < 0 || d->num_luts > VX_MAX_LUTS) return bad("num_luts unsupported (the prover's lookup path holds at most VX_MAX_LUTS tables)", d->num_luts);
   const int nls = d->num_luts > 0 ? d->num_lookup_selectors : 0;
   if (d->num_luts > 0) {
     if (d->num_lookup_selectors != 4 + d->num_luts) return bad("num_lookup_selectors must be 4 + num_luts (TransSre, TransLdc, InitSre, LastLdc + one per table)", d->num_lookup_selectors);

@@ -24,6 +24,19 @@
 #include <string>
 #include <vector>
 
+#define VX_AIR_MAX_PI 64          /* public inputs of an AIR (AirParams::pi, stark.hip.h) */
+#define VX_AIR_MAX_CHALLENGES 16  /* second-round challenges of an AIR (AirParams::chal) */
+// The generated sources mirror JitGateParams / AirParams textually: every array bound and the root-table shift are
+// emitted from the SAME macros the host structs use (jit_limits_defines), so moving a limit cannot shift the
+// kernel-argument layout of one side only.
+static std::string jit_limits_defines() {
+  std::ostringstream s;
+  s << "#define VX_MAX_CHALLENGES " << VX_MAX_CHALLENGES << "\n#define VX_MAX_RATE " << VX_MAX_RATE << "\n#define VX_MAX_PROGRAM_GATES " << VX_MAX_PROGRAM_GATES
+    << "\n#define VX_AIR_MAX_PI " << VX_AIR_MAX_PI << "\n#define VX_AIR_MAX_CHALLENGES " << VX_AIR_MAX_CHALLENGES << "\n#define VX_PROGRAM_REGS " << VX_PROGRAM_REGS
+    << "\n#define ROOT_TABLE_LOG " << ROOT_TABLE_LOG << "\n";
+  return s.str();
+}
+
 struct JitGateRt {
   int gate_index, selector_index, group_start, group_end;
 };
@@ -145,7 +158,7 @@ static void jit_emit_program(std::ostringstream& s, const uint64_t* prog, int nc
     A.a = other;  // the addend
     code[i].skip = true;
   }
-  bool canon_reg[64];
+  bool canon_reg[VX_PROGRAM_REGS];
   for (bool& c : canon_reg) c = true;
   auto need_canon = [&](int r) {
     if (!canon_reg[r]) {
@@ -214,7 +227,7 @@ static void jit_gate_block(std::ostringstream& s, const uint64_t* prog, int nch,
        "      if (q != G.gate_index) filter = gl_mul(filter, gl_sub((u64)q, s));\n"
        "    if (nsel > 1) filter = gl_mul(filter, gl_sub(0xFFFFFFFFULL, s));\n"
        "    u64 a0 = 0, a1 = 0;\n"
-       "    u64 R[64];\n";
+       "    u64 R[VX_PROGRAM_REGS];\n";
   jit_emit_program(s, prog, nch, false);
   s << "    t0 = gl_mad(filter, a0, t0);\n";
   if (nch > 1) s << "    t1 = gl_mad(filter, a1, t1);\n";
@@ -229,7 +242,7 @@ static std::string jit_source(const std::vector<const uint64_t*>& progs, int nch
   // VGPRs, like the native quotient kernel) gives 6.7 ms.
   const char* bpc = getenv("VX_JIT_BLOCKS_PER_CU");
   s << "typedef unsigned long long uint64_t;\ntypedef unsigned int uint32_t;\n#define VX_JIT_BLOCKS_PER_CU " << (bpc ? atoi(bpc) : 4) << "\n"
-    << JIT_PRELUDE << R"VXJIT(
+    << jit_limits_defines() << JIT_PRELUDE << R"VXJIT(
 struct JitGateRt {
   int gate_index, selector_index, group_start, group_end;
 };
@@ -242,8 +255,8 @@ struct JitGateParams {
   int base_idx, ngates;
   int const_base, pad_;
   u64 pih[4];
-  u64 zh_inv[16];
-  JitGateRt g[64];
+  u64 zh_inv[VX_MAX_RATE];
+  JitGateRt g[VX_MAX_PROGRAM_GATES];
 };
 extern "C" __global__ __launch_bounds__(256, VX_JIT_BLOCKS_PER_CU) void vx_program_gates(JitGateParams p) {
   const size_t il = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -270,7 +283,7 @@ extern "C" __global__ __launch_bounds__(256, VX_JIT_BLOCKS_PER_CU) void vx_progr
 static std::string jit_air_source(const uint64_t* prog, int nch, int ncols) {
   std::ostringstream s;
   s << "typedef unsigned long long uint64_t;\ntypedef unsigned int uint32_t;\n#define VX_JIT_BLOCKS_PER_CU 4\n"
-    << JIT_PRELUDE << R"VXJIT(
+    << jit_limits_defines() << JIT_PRELUDE << R"VXJIT(
 struct AirParams {
   const u64* trace;
   const u64* aux;
@@ -279,10 +292,10 @@ struct AirParams {
   size_t rows;
   int log_n, rate_bits, qbits, ncols, nch, npi;
   const u64 *root_lo, *root_hi;
-  u64 alphas[2];
-  u64 pi[64];
-  u64 chal[16];
-  u64 zh[16], zh_inv[16];
+  u64 alphas[VX_MAX_CHALLENGES];
+  u64 pi[VX_AIR_MAX_PI];
+  u64 chal[VX_AIR_MAX_CHALLENGES];
+  u64 zh[VX_MAX_RATE], zh_inv[VX_MAX_RATE];
   u64 last, n_inv;
   u64* out;
 };
@@ -294,7 +307,7 @@ extern "C" __global__ __launch_bounds__(256, VX_JIT_BLOCKS_PER_CU) void vx_air_q
   const u32 z = (u32)(il >> p.log_n);
   const u32 r = (u32)(il & (n - 1));
   const u32 j = __brev((u32)il) >> (32 - LG);
-  const u32 e = j << (24 - LG);  // w_{2^24}^e from the two 4096-entry root tables (ntt.hip.h root_pow24)
+  const u32 e = j << (ROOT_TABLE_LOG - LG);  // w_{2^24}^e from the two 4096-entry root tables (ntt.hip.h root_pow24)
   const u64 x = gl_mul7(gl_mul(p.root_lo[e & 4095u], p.root_hi[(e >> 12) & 4095u]));
   const u32 rn = __brev(((__brev(r) >> (32 - p.log_n)) + 1) & (u32)(n - 1)) >> (32 - p.log_n);
   const size_t il_next = ((size_t)z << p.log_n) | rn;
@@ -307,7 +320,7 @@ extern "C" __global__ __launch_bounds__(256, VX_JIT_BLOCKS_PER_CU) void vx_air_q
   const u64* __restrict__ AUX = p.aux;
   const size_t SW = p.stride;
   u64 a0 = 0, a1 = 0;
-  u64 R[64];
+  u64 R[VX_PROGRAM_REGS];
 )VXJIT";
   jit_emit_program(s, prog, nch, true, ncols);
   s << "  (void)AUX;\n  p.out[il] = gl_mul(a0, p.zh_inv[z]);\n";

@@ -16,6 +16,7 @@
 #define VX_MAX_GATES 64          /* gates per circuit (kernel-argument table: 20 B each); plonky2x registers ~40 gate types in total */
 #define VX_MAX_CHALLENGES 2
 #define VX_MAX_RATE 16
+#define VX_MAX_LUTS 8            /* lookup tables per circuit: sizes LookupParams::lut_poly and the lookup kernel's selector array; desc_check refuses more */
 
 struct GateDev {
   int type, param, selector_index, group_start, group_end;
@@ -554,7 +555,6 @@ __global__ void gather_open_kernel(const u64* __restrict__ data, size_t stride, 
 // multiplicity).  Products of (alpha - combo) over a slot group and its leave-one-out sums are formed with prefix /
 // suffix products (groups have at most quotient_degree_factor - 1 = 7 members).
 // ------------------------------------------------------------------------------------------------
-#define VX_MAX_LUTS 8
 #define VX_LOOKUP_GROUP_MAX 16
 struct LookupParams {
   const u64 *cs, *wires, *zs;  // as in QuotientParams (cs: global rows, stride N; wires / zs / out: local rows, stride_w)

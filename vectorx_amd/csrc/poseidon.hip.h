@@ -12,7 +12,7 @@
 //    half per term into plain 64-bit accumulators — no carries) and folds once per output (5 instructions);
 //  * round constants are never added on their own: they are the initial values of the accumulators of the linear
 //    layer in front of them;
-//  * the 22 partial rounds run in blocks of 3 through integer powers of the MDS matrix (below) — upstream's "fast"
+//  * the 22 partial rounds run in blocks of 4 (schedule 4·5 + 2) through integer powers of the MDS matrix (below) — upstream's "fast"
 //    sparse form needs full-size constants, i.e. six multiply-adds per term instead of two.
 // The 12-lane state lives in VGPRs; constants sit in constant memory and, because the loops are unrolled, are fetched
 // with scalar loads shared by the whole wavefront.

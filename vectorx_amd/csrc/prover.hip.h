@@ -1088,16 +1088,18 @@ static int prove_impl(vx_ctx* c, vx_circuit* k, const u64* wires_in, bool wires_
     w.words(wires_cap.data(), cap_words);
     w.words(zs_cap.data(), cap_words);
     w.words(quot_cap.data(), cap_words);
-    // OpeningSet: constants, plonk_sigmas, wires, plonk_zs, plonk_zs_next, partial_products, quotient_polys
+    // write_opening_set (util/serialization): constants, plonk_sigmas, wires, plonk_zs, plonk_zs_next, lookup_zs,
+    // lookup_zs_next, partial_products, quotient_polys — the serializer's order, NOT the struct's field order (the two
+    // lookup vectors are empty for a circuit without tables, so lookup-free proofs are the same bytes either way)
     w.words(ev[0].data(), 2 * (size_t)k->num_constants);
     w.words(ev[0].data() + 2 * (size_t)k->num_constants, 2 * (size_t)k->nr);
     w.words(ev[1].data(), ev[1].size());
     w.words(ev[2].data(), 2 * (size_t)nch);
     w.words(zs_next.data(), 2 * (size_t)nch);
-    w.words(ev[2].data() + 2 * (size_t)nch, 2 * (zs_pp - (size_t)nch));
-    w.words(ev[3].data(), ev[3].size());
     w.words(ev[2].data() + 2 * zs_pp, 2 * (size_t)nlook);   // lookup_zs
     w.words(lzs_next.data(), lzs_next.size());               // lookup_zs_next
+    w.words(ev[2].data() + 2 * (size_t)nch, 2 * (zs_pp - (size_t)nch));
+    w.words(ev[3].data(), ev[3].size());
     write_fri_proof(w, fp, fri_oracles, fri, sh);
     w.words(public_inputs.data(), public_inputs.size());
     proof_out.swap(w.b);

@@ -19,8 +19,6 @@
 #include "prover.hip.h"
 #include "verifier.h"
 
-#define VX_AIR_MAX_PI 64
-#define VX_AIR_MAX_CHALLENGES 16
 struct AirParams {  // mirrored textually in jit.hip.h::jit_air_source
   const u64* trace;  // trace LDE, column stride = stride (rows of the whole LDE), rows in Merkle-leaf (bit-reversed) order
   const u64* aux;    // second-round columns' LDE (same stride) or null; program columns >= ncols address it
@@ -161,6 +159,29 @@ static std::string stark_check(const vx_stark_desc* d, StarkShape* out) {
   return std::string();
 }
 
+// The STATEMENT enters the transcript first (old starky observes nothing before the trace cap, so a prover who
+// picks the statement could choose public inputs after seeing the alphas): shape and FRI configuration, a Poseidon digest
+// of the AIR program (each 64-bit word as two 32-bit limbs — always canonical), then the canonical public inputs.  The
+// byte format is this library's own, so nothing upstream constrains this prefix; the prover, vxsv::verify and the test checker
+// build the same list.
+static std::vector<vxh::u64> stark_statement(const vx_stark_desc* d, const StarkShape& sh, const vxh::u64* canonical_pis) {
+  std::vector<vxh::u64> st = {(vxh::u64)d->degree_bits, (vxh::u64)d->rate_bits, (vxh::u64)d->cap_height, (vxh::u64)d->pow_bits, (vxh::u64)d->num_query_rounds,
+                              (vxh::u64)d->num_challenges, (vxh::u64)d->constraint_degree, (vxh::u64)d->num_columns, (vxh::u64)d->num_aux_columns,
+                              (vxh::u64)d->num_aux_challenges, (vxh::u64)d->num_public_inputs, (vxh::u64)sh.arity_bits.size()};
+  for (int a : sh.arity_bits) st.push_back((vxh::u64)a);
+  std::vector<vxh::u64> limbs;
+  limbs.reserve(2 * (size_t)d->program_len);
+  for (int pc = 0; pc < d->program_len; ++pc) {
+    limbs.push_back(d->program[pc] & 0xFFFFFFFFu), limbs.push_back(d->program[pc] >> 32);
+    if ((d->program[pc] & 0xFF) == VX_OP_END) break;   // words after END are not part of the AIR
+    if ((d->program[pc] & 0xFF) == VX_OP_LDI && pc + 1 < d->program_len) ++pc, limbs.push_back(d->program[pc] & 0xFFFFFFFFu), limbs.push_back(d->program[pc] >> 32);
+  }
+  const vxh::Hash4 ph = vxh::hash_no_pad(limbs.data(), limbs.size());
+  st.insert(st.end(), ph.e, ph.e + 4);
+  st.insert(st.end(), canonical_pis, canonical_pis + d->num_public_inputs);
+  return st;
+}
+
 // One proof in two steps (include/vxprover.h vx_stark_begin / vx_stark_finish): the trace commitment and the transcript up
 // to the aux challenges live here between the calls.  The description is deep-copied (the caller's may go away).
 struct vx_stark_session {
@@ -212,6 +233,10 @@ static int stark_begin_impl(vx_ctx* c, const vx_stark_desc* d_in, const u64* tra
   VXCHK(batch_commit_device(c, s.trace_b, d_trace, n, false));
   const Shard one;
   VXCHK(gather_cap(c, one, S, s.trace_b->tree + s.trace_b->cap_off * 4, s.trace_b->local_cap_words(), s.trace_cap));
+  {
+    const std::vector<u64> st = stark_statement(d, s.sh, s.public_inputs.data());
+    s.ch.observe_elements(st.data(), st.size());
+  }
   s.ch.observe_elements(s.trace_cap.data(), cap_words);
   // second commitment round: its challenges are drawn here, between the trace cap and the aux cap
   s.aux_challenges.resize(d->num_aux_columns > 0 ? d->num_aux_challenges : 0);
@@ -514,8 +539,13 @@ static std::string verify(const vx_stark_desc* d, const StarkShape& sh, const u6
   for (int i = 0; i < d->num_public_inputs; ++i)
     if (pis[i] != vxh::canon(pis_expected[i])) return "public inputs differ from the expected ones";
 
-  // ---- challenges (starky get_challenges): trace cap -> alphas -> quotient cap -> zeta -> openings -> FRI ----
+  // ---- challenges: statement (shape, program digest, public inputs) -> trace cap -> [aux challenges -> aux cap] -> alphas
+  //      -> quotient cap -> zeta -> openings -> FRI  (starky get_challenges, with the statement in front) ----
   vxh::Challenger ch;
+  {
+    const std::vector<u64> st = stark_statement(d, sh, pis.data());
+    ch.observe_elements(st.data(), st.size());
+  }
   ch.observe_elements(trace_cap.data(), trace_cap.size());
   std::vector<u64> aux_challenges(naux ? d->num_aux_challenges : 0);
   if (naux) {

@@ -267,10 +267,10 @@ static std::string verify(const CircuitV& c, const uint8_t* bytes, size_t len) {
   r.exts(o_wires, c.num_wires);
   r.exts(o_zs, nch);
   r.exts(o_zs_next, nch);
+  r.exts(o_lzs, (size_t)nch * nlp);       // read_opening_set: the lookup openings sit between plonk_zs_next and the partial products
+  r.exts(o_lzs_next, (size_t)nch * nlp);
   r.exts(o_pp, (size_t)nch * npp);
   r.exts(o_quot, (size_t)nch * qdf);
-  r.exts(o_lzs, (size_t)nch * nlp);
-  r.exts(o_lzs_next, (size_t)nch * nlp);
   std::vector<std::vector<u64>> commit_caps(R);
   for (auto& cp : commit_caps) r.words(cp, 4 * cap_len);
   struct Query {

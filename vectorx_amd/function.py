@@ -43,6 +43,7 @@ from pathlib import Path
 
 import numpy as np
 
+from . import avail_codec as codec
 from . import mapreduce as mr
 
 P = mr.P
@@ -94,15 +95,27 @@ def parse_request(text: str, function: str) -> bytes:
     if len(raw) != want:
         raise RequestError(f"{function}: input is {len(raw)} bytes, the circuit reads {want} "
                            f"({'uint32|bytes32|uint64|bytes32|uint32' if want == 80 else 'uint64|bytes32'}, packed)")
+    check_request_semantics(function, raw)
     return raw
 
 
 def decode_header_range_input(raw: bytes) -> dict:
     """abi.encodePacked(uint32, bytes32, uint64, bytes32, uint32): big-endian integers (bin/vectorx.rs:106-112)."""
-    assert len(raw) == 80
-    return {"trusted_block": int.from_bytes(raw[0:4], "big"), "trusted_header": raw[4:36].hex(),
-            "authority_set_id": int.from_bytes(raw[36:44], "big"), "authority_set_hash": raw[44:76].hex(),
-            "target_block": int.from_bytes(raw[76:80], "big")}
+    d = codec.unpack_header_range_input(raw)
+    return {**d, "trusted_header": d["trusted_header"].hex(), "authority_set_hash": d["authority_set_hash"].hex()}
+
+
+def check_request_semantics(function: str, raw: bytes) -> None:
+    """What the circuit itself would refuse: header_range_N proves the headers (trusted, target] with
+    0 < target - trusted <= N (/root/reference/circuits/builder/subchain_verification.rs:29-36: "the range [trusted_block + 1, target_block] inclusive" over at most MAX_NUM_HEADERS headers; the map stage walks
+    trusted+1 .. trusted+N and the reduce stage requires the target block among them)."""
+    if function.startswith("header_range"):
+        d = codec.unpack_header_range_input(raw)
+        span, limit = d["target_block"] - d["trusted_block"], int(function.rsplit("_", 1)[1])
+        if not 0 < span <= limit:
+            raise RequestError(f"{function}: target_block - trusted_block = {span}, the circuit covers 1..{limit} headers")
+    else:
+        codec.unpack_rotate_input(raw)
 
 
 def format_result(proof: bytes, output: bytes) -> str:
