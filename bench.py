@@ -45,6 +45,11 @@ def parse():
     ap.add_argument("--cpu-sample-log-n", type=int, default=None,
                     help="rows (log2) of the bounded CPU-baseline sample (default 18 for prove: ~20 s on 16 cores; 17 for commit)")
     ap.add_argument("--poseidon-percent", type=int, default=50, help="share of PoseidonGate rows in the synthetic circuit")
+    ap.add_argument("--no-dag-leg", action="store_true",
+                    help="skip the extra (untimed-by-the-contract) leg that proves one whole header_range_512 DAG: 64 map + 63 reduce + 1 outer proofs")
+    ap.add_argument("--circuit-flags", type=int, default=0,
+                    help="vectorx_amd.synth FLAG_* bits of the synthetic circuit (1|4|8: constraint-program gates, 16: a lookup table); the "
+                         "default 0 is the headline gate mix — other values are for profiling the prove-only kernels")
     ap.add_argument("--no-host-witness-leg", action="store_true",
                     help="skip the extra (untimed-by-the-contract) leg that proves from a pinned HOST witness (PCIe-inclusive rate)")
     return ap.parse_args()
@@ -186,6 +191,10 @@ def main():
         import bench_prove
         host_leg = bench_prove.host_witness_leg(ctx, args, sync)
 
+    dag_leg = None
+    if args.workload == "prove" and world == 1 and not args.no_dag_leg and args.log_n >= 20 and not args.circuit_flags:
+        dag_leg = bench_prove.dag_leg(ctx, local_rank)
+
     if rank == 0:
         lde = prof.get("lde", {"ms": 0.0, "calls": 0, "alg_bytes": 0.0})
         roof = None
@@ -270,6 +279,8 @@ def main():
                                "backend": dist.get_backend(), "what": "in-place all-gathers vx_prove_sharded asked its host for (RCCL over xGMI)"}
         if host_leg is not None:
             out["value_from_host_witness"] = host_leg
+        if dag_leg is not None:
+            out["dag_header_range_512"] = dag_leg
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline_commit(args) if args.workload == "commit" else bench_prove.cpu_baseline(args)
         print(json.dumps(out), flush=True)

@@ -11,7 +11,8 @@ def make_step(ctx, args, rank, dist=None, device=None):
 
     sharded_mode = getattr(args, "mode", "throughput") == "sharded" and dist is not None
     # throughput mode: every rank proves its OWN witness; sharded mode: all ranks work on the SAME proof
-    sc = SynthCircuit(args.log_n, seed=0x5EED0000 + (0 if sharded_mode else rank), poseidon_percent=args.poseidon_percent)
+    sc = SynthCircuit(args.log_n, seed=0x5EED0000 + (0 if sharded_mode else rank), poseidon_percent=args.poseidon_percent,
+                      flags=getattr(args, "circuit_flags", 0))
     counts = sc.row_counts()
     circuit = vx.Circuit(ctx, sc.desc_ptr)   # constants_sigmas commitment stays resident (per-circuit, not per-proof)
     w = sc.witness()
@@ -73,6 +74,44 @@ def host_witness_leg(ctx, args, sync):
     return {"value": args.steps / dt, "unit": "proofs/sec", "ms_per_step": dt / args.steps * 1e3, "steps": args.steps,
             "what": "same circuit and witness, witness in page-locked HOST memory when each step starts (2.27 GB over PCIe per proof at "
                     "n = 2^21, hidden behind the first transforms); proofs byte-identical to the HBM-resident run"}
+
+
+def dag_leg(ctx, local_rank, in_flight=3):
+    """The REAL unit of work of the metric, outside the contract's timed region: one header_range_512 = 64 map + 63 reduce
+    + 1 outer plonky2 proofs (/root/reference/circuits/builder/subchain_verification.rs:72-78, header_range.rs:71-88)
+    scheduled layer by layer on this GPU with `in_flight` proofs in flight (vectorx_amd/mapreduce.py).  Stand-in circuit
+    sizes 2^18 / 2^16 / 2^19 rows (the real degrees need the Rust builder); witnesses resident in HBM before the clock starts."""
+    import vectorx_amd as vx
+    from vectorx_amd import mapreduce as mr
+    t_setup = time.perf_counter()
+    lanes = [vx.Context(local_rank) for _ in range(in_flight - 1)]
+    spec = mr.DagSpec(64, 18, 16, 19)
+    provers = []
+
+    def make(kind, log_n, jobs):
+        p = mr.GpuProver(ctx, kind, log_n, jobs, spec.poseidon_percent, extra_lanes=lanes)
+        provers.append(p)
+        return p
+
+    def sync():
+        ctx.sync()
+        for l in lanes:
+            l.sync()
+
+    try:
+        res = mr.run_dag(spec, make, None, sync, in_flight=in_flight)
+    finally:
+        for p in provers:
+            p.free()
+        for l in lanes:
+            l.close()
+    secs = res["seconds"]
+    return {"header_range_512_per_sec": 1.0 / secs, "dag_seconds": secs, "plonky2_proofs": res["proofs"],
+            "plonky2_proofs_per_sec": res["proofs"] / secs, "in_flight_per_gpu": in_flight,
+            "per_layer_ms": [(l["kind"], l["jobs"], round(l["ms"], 1)) for l in res["per_layer"]],
+            "setup_seconds_untimed": round(time.perf_counter() - t_setup - secs, 2), "root": res["root"].hex(),
+            "what": "64 map (2^18 rows) + 63 reduce (2^16) + 1 outer (2^19) proofs, layer barriers, synthetic stand-in circuits; "
+                    "witnesses HBM-resident; NOT the contract's timed region"}
 
 
 def usable_cores():

@@ -282,6 +282,21 @@ def test_bench_single_gpu_line_names_its_device():
     assert line["n_gpus"] == 1 and line["rccl_ranks"] == 1 and len(line["rank_devices"]) == 1
 
 
+@pytest.mark.parametrize("degree_bits,world,flags", [(6, 2, 32), (9, 4, 32 | 7), (11, 8, 32 | 16)])
+def test_sharded_proof_with_u32_gates(oracle, degree_bits, world, flags):
+    """the U32 / comparison program gates (VERDICT r2 #4) under the coset split: every rank evaluates them on its own cosets"""
+    sc = SynthCircuit(degree_bits, seed=3300 + degree_bits, poseidon_percent=40, flags=flags)
+    sc.desc.pow_bits = 6
+    w = sc.witness()
+    expect = oracle_lib.OracleCircuit(oracle, sc.desc_ptr).prove(w)
+    ctxs, circuits = _rank_circuits(sc, world)
+    try:
+        for p in sharded.prove_sharded_threads(circuits, w):
+            assert p == expect
+    finally:
+        _free(ctxs, circuits)
+
+
 @pytest.mark.parametrize("degree_bits,world,flags", [(7, 2, 16), (9, 4, 16 | 1), (11, 8, 16)])
 def test_sharded_proof_with_lookup_argument(oracle, degree_bits, world, flags):
     sc = SynthCircuit(degree_bits, seed=1900 + degree_bits, poseidon_percent=40, flags=flags)

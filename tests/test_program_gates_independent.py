@@ -159,6 +159,86 @@ def poseidon_mds(w, c):
     return out
 
 
+# ---- plonky2-u32 gates (gates/{arithmetic_u32, add_many_u32, subtraction_u32, range_check_u32, comparison}.rs) ----
+def _limb4(l):
+    return l * (l - 1) * (l - 2) * (l - 3) % P
+
+
+def _horner(limbs, base):
+    acc = 0
+    for l in reversed(limbs):
+        acc = (acc * base + l) % P
+    return acc
+
+
+def u32_arithmetic(w, c, num_ops=3):
+    out = []
+    for i in range(num_ops):
+        m0, m1, ad, lo, hi, inverse = (w[6 * i + k] for k in range(6))
+        out.append((inverse * (0xFFFFFFFF - hi) - 1) * lo % P)               # high == u32::MAX  =>  low == 0 (canonical 64-bit split)
+        out.append((hi * (1 << 32) + lo - (m0 * m1 + ad)) % P)
+        limbs = [w[6 * num_ops + 32 * i + j] for j in range(32)]
+        out += [_limb4(l) for l in reversed(limbs)]
+        out.append((_horner(limbs[:16], 4) - lo) % P)
+        out.append((_horner(limbs[16:], 4) - hi) % P)
+    return out
+
+
+def u32_add_many(w, c, num_addends=3, num_ops=5):
+    per, out = num_addends + 3, []
+    for i in range(num_ops):
+        total = sum(w[per * i + j] for j in range(num_addends + 1))           # addends + carry-in
+        res, carry = w[per * i + num_addends + 1], w[per * i + num_addends + 2]
+        out.append((carry * (1 << 32) + res - total) % P)
+        limbs = [w[per * num_ops + 18 * i + j] for j in range(18)]
+        out += [_limb4(l) for l in reversed(limbs)]
+        out.append((_horner(limbs[:16], 4) - res) % P)
+        out.append((_horner(limbs[16:], 4) - carry) % P)
+    return out
+
+
+def u32_subtraction(w, c, num_ops=6):
+    out = []
+    for i in range(num_ops):
+        x, y, bin_, res, bout = (w[5 * i + k] for k in range(5))
+        out.append((res - (x - y - bin_ + (1 << 32) * bout)) % P)
+        limbs = [w[5 * num_ops + 16 * i + j] for j in range(16)]
+        out += [_limb4(l) for l in reversed(limbs)]
+        out.append((_horner(limbs, 4) - res) % P)
+        out.append(bout * (1 - bout) % P)
+    return out
+
+
+def u32_range_check(w, c, n=7):
+    out = []
+    for i in range(n):
+        aux = [w[n + 16 * i + j] for j in range(16)]
+        out.append((_horner(aux, 4) - w[i]) % P)
+        out += [_limb4(a) for a in aux]
+    return out
+
+
+def comparison(w, c, nc=16):
+    first = [w[4 + k] for k in range(nc)]
+    second = [w[4 + nc + k] for k in range(nc)]
+    out = [(_horner(first, 4) - w[0]) % P, (_horner(second, 4) - w[1]) % P]
+    so_far = 0
+    for k in range(nc):
+        out += [_limb4(first[k]), _limb4(second[k])]
+        diff = (second[k] - first[k]) % P
+        dummy, eq, inter = w[4 + 2 * nc + k], w[4 + 3 * nc + k], w[4 + 4 * nc + k]
+        out.append((diff * dummy - (1 - eq)) % P)
+        out.append(eq * diff % P)
+        out.append((inter - eq * so_far) % P)
+        so_far = (inter + (1 - eq) * diff) % P
+    out.append((w[3] - so_far) % P)
+    bits = [w[4 + 5 * nc + b] for b in range(3)]
+    out += [b * (1 - b) % P for b in bits]
+    out.append((4 + w[3] - _horner(bits, 2)) % P)
+    out.append((w[2] - bits[2]) % P)
+    return out
+
+
 def _desc_arrays(sc):
     d = sc.desc
     words = list((ctypes.c_uint64 * d.programs_len).from_address(d.programs))
@@ -167,7 +247,7 @@ def _desc_arrays(sc):
     return d, words, offs, sels
 
 
-@pytest.mark.parametrize("flags", [15, 2])
+@pytest.mark.parametrize("flags", [15, 2, 32, 32 | 15])
 def test_every_program_equals_its_gates_defining_relation(flags):
     sc = SynthCircuit(7, seed=77, poseidon_percent=40, flags=flags)
     d, words, offs, sels = _desc_arrays(sc)
@@ -186,6 +266,9 @@ def test_every_program_equals_its_gates_defining_relation(flags):
     if flags & 8:
         refs += [("mulext", mul_extension), ("reducing", lambda ww, cc: reducing(ww, cc, 43, False)),
                  ("reducingext", lambda ww, cc: reducing(ww, cc, 32, True)), ("mds", poseidon_mds)]
+    if flags & 32:
+        refs += [("u32arith", u32_arithmetic), ("u32addmany", u32_add_many), ("u32sub", u32_subtraction), ("u32range", u32_range_check),
+                 ("comparison", comparison)]
     # gate index of a row = the value of its selector polynomial; program gates have program_offsets >= 0
     def gate_of_row(r):
         for g in range(d.num_gates):
@@ -239,3 +322,37 @@ def test_every_program_equals_its_gates_defining_relation(flags):
             assert all(v == 0 for v in run_program(words, offs[g], wires, consts)), (g, r)
     assert matched - {"coset"} == {name for name, _ in refs}, matched
     assert ("coset" in matched) == bool(flags & 8)
+
+
+def test_u32_block_means_what_the_reference_circuit_means():
+    """The witness rows of the U32 block are not just constraint-satisfying: they compute what verify_voting_threshold
+    (/root/reference/circuits/builder/justification.rs:164-186) computes — num_signed = sum of the signed bits, the two scaled
+    products, and is_valid = [num_active * 2 <= num_signed * 3] — checked here on plain Python integers."""
+    sc = SynthCircuit(8, seed=5, poseidon_percent=40, flags=32)
+    d, words, offs, sels = _desc_arrays(sc)
+    n = 1 << 8
+    w = sc.witness()
+    cs = [list((ctypes.c_uint64 * n).from_address(d.constants_sigmas + 8 * n * k)) for k in range(d.num_constants)]
+    u32 = sc.row_counts()["u32_each"]
+    rows = {}
+    for r in range(n):
+        for g in range(d.num_gates):
+            if cs[sels[g]][r] == g and offs[g] >= 0:
+                rows.setdefault(g, []).append(r)
+    by_len = {len(v): v for v in rows.values()}
+    arith = by_len[u32 + 1]                       # the chained adds + the threshold row
+    signed, total = 0, 0
+    for r in arith[:-1]:
+        for op in range(3):
+            m0, m1, ad, lo, hi = (int(w[6 * op + k, r]) for k in range(5))
+            assert (m0, m1, hi) == (signed, 1, 0) and ad in (0, 1) and lo == signed + ad
+            signed, total = lo, total + 1
+    t = arith[-1]
+    assert [int(w[k, t]) for k in (0, 1, 3)] == [signed, 3, (3 * signed) & 0xFFFFFFFF]
+    assert [int(w[6 + k, t]) for k in (0, 1, 3)] == [total, 2, (2 * total) & 0xFFFFFFFF]
+    m0, m1, ad, lo, hi = (int(w[12 + k, t]) for k in range(5))
+    assert hi * (1 << 32) + lo == m0 * m1 + ad and hi > 0
+    cmp_rows = [v for v in rows.values() if len(v) == u32 and int(w[0, v[0]]) == 2 * total and int(w[1, v[0]]) == 3 * signed]
+    assert len(cmp_rows) == 1 and int(w[2, cmp_rows[0][0]]) == int(2 * total <= 3 * signed) == 1
+    for r in cmp_rows[0]:                          # every ComparisonGate row decides a <= b correctly
+        assert int(w[2, r]) == int(int(w[0, r]) <= int(w[1, r]))

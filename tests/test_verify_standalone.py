@@ -222,3 +222,37 @@ def test_more_lookup_tables_than_the_prover_holds_are_refused(oracle):
     assert e.value.code == vx.VX_E_INVALID and "num_luts" in str(e.value)
     sc.desc.num_luts, sc.desc.num_lookup_selectors = 1, 5
     vx.verify_standalone(sc.desc_ptr, cap, proof)
+
+
+@pytest.mark.parametrize("degree_bits,flags,qdf", [(5, 32, 8), (7, 32 | 15, 8), (8, 32 | 16, 8), (6, 32, 5)])
+def test_u32_and_comparison_gates_oracle_prover_and_product_verifier_agree(oracle, degree_bits, flags, qdf):
+    """plonky2-u32's U32Arithmetic / U32AddMany / U32Subtraction / U32RangeCheck / Comparison gates as constraint programs
+    (what plonky2x's U32Variable ops instantiate: /root/reference/circuits/builder/justification.rs:164-186): both restated
+    verifiers accept the honest proof and reject a wrong sum, a wrong borrow, an out-of-range limb and a flipped comparison."""
+    sc = SynthCircuit(degree_bits, seed=3100 + degree_bits, poseidon_percent=40, flags=flags, quotient_degree_factor=qdf)
+    sc.desc.pow_bits = 4
+    oc = oracle_lib.OracleCircuit(oracle, sc.desc_ptr)
+    cap, w = oc.cap(), sc.witness()
+    proof = oc.prove(w)
+    assert oc.verify(proof) == "" and _verdict(sc, cap, proof) == ""
+    import ctypes
+    d = sc.desc
+    n = sc.n
+    sels = list((ctypes.c_int32 * d.num_gates).from_address(d.selector_indices))
+    offs = list((ctypes.c_int32 * d.num_gates).from_address(d.program_offsets))
+    cs = [np.frombuffer((ctypes.c_uint64 * n).from_address(d.constants_sigmas + 8 * n * k), dtype=np.uint64) for k in range(d.num_selectors)]
+    u32_rows = [r for r in range(n) if any(offs[g] >= 0 and int(cs[sels[g]][r]) == g for g in range(d.num_gates))]
+    assert u32_rows
+    hits = 0
+    for r in u32_rows[:: max(1, len(u32_rows) // 6)]:
+        for col in (3, 4, 30, 2):                          # a result wire, a carry / high wire, a limb, an input / result_bool
+            bad_w = w.copy()
+            bad_w[col, r] = (int(bad_w[col, r]) + 1) % P
+            try:
+                bad = oc.prove(bad_w)
+            except RuntimeError:
+                hits += 1                                   # the quotient does not exist: unprovable
+                continue
+            assert oc.verify(bad) != "" and _verdict(sc, cap, bad) != "", (r, col)
+            hits += 1
+    assert hits >= 8

@@ -45,6 +45,7 @@ FLAG_PROGRAM_GATES = 1      # add ArithmeticExtensionGate + BaseSumGate rows, ev
 FLAG_ARITH_AS_PROGRAM = 2   # hand the ArithmeticGate to the prover as a constraint program instead of the native gate
 FLAG_MORE_PROGRAM_GATES = 4  # + ExponentiationGate (degree 4) and RandomAccessGate (degree 5) as programs: 3 selector groups
 FLAG_LOOKUP = 16             # + one lookup table (LookupTableGate rows) and LookupGate rows looking values up in it
+FLAG_U32_GATES = 32          # + plonky2-u32's U32Arithmetic / U32AddMany / U32Subtraction / U32RangeCheck / Comparison gates as programs (a voting-threshold block)
 FLAG_RECURSION_GATES = 8     # + MulExtension, Reducing, ReducingExtension, PoseidonMds, CosetInterpolation{4 bits, degree 8} as programs
 
 
@@ -75,6 +76,8 @@ def _load():
         L.vxs_row_counts_ext.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         L.vxs_recursion_rows.restype = ctypes.c_uint64
         L.vxs_recursion_rows.argtypes = [ctypes.c_void_p]
+        L.vxs_u32_rows.restype = ctypes.c_uint64
+        L.vxs_u32_rows.argtypes = [ctypes.c_void_p]
         L.vxs_patch_public_inputs.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         L.vxs_free.argtypes = [ctypes.c_void_p]
         L.vxs_desc.restype = ctypes.POINTER(CircuitDesc)
@@ -137,6 +140,9 @@ class SynthCircuit:
         if int(ext[5]) or int(ext[6]):
             d["exponentiation"], d["random_access"] = int(ext[5]), int(ext[6])
         rec = int(_load().vxs_recursion_rows(self._h))
+        u32 = int(_load().vxs_u32_rows(self._h))
+        if u32:
+            d["u32_each"] = u32         # rows of EACH of U32AddMany / U32Subtraction / U32RangeCheck / Comparison; U32Arithmetic has one more
         if rec:
             d["recursion_each"] = rec   # rows of EACH of MulExtension / Reducing / ReducingExtension / PoseidonMds / CosetInterpolation
         return d

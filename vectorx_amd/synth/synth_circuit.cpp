@@ -38,6 +38,11 @@ using namespace vxh;
 #define VXS_FLAG_RECURSION_GATES 8    /* + the rest of the recursive verifier's gate set as programs: MulExtensionGate, ReducingGate,
                                          ReducingExtensionGate, PoseidonMdsGate, CosetInterpolationGate{4 bits, degree 8} */
 
+#define VXS_FLAG_U32_GATES 32         /* + plonky2-u32's gates as programs (what plonky2x's U32Variable add / mul / sub / gt and its range checks
+                                         instantiate — /root/reference/circuits/builder/justification.rs:164-186, decoder.rs:39-92):
+                                         U32ArithmeticGate{3 ops}, U32AddManyGate{3 addends, 5 ops}, U32SubtractionGate{6 ops},
+                                         U32RangeCheckGate{7 limbs}, ComparisonGate{32 bits, 16 chunks}; laid out as a voting-threshold block */
+
 namespace {
 struct SplitMix {
   u64 s;
@@ -56,7 +61,7 @@ struct SplitMix {
 };
 
 enum Key { K_NOOP, K_CONST, K_PI, K_ARITH, K_POSEIDON, K_ARITHEXT, K_BASESUM, K_EXP, K_RANDACC, K_MULEXT, K_REDUCING, K_REDUCINGEXT,
-           K_POSEIDONMDS, K_COSETINTERP, K_LOOKUP, K_LOOKUPTABLE, K_COUNT };
+           K_POSEIDONMDS, K_COSETINTERP, K_LOOKUP, K_LOOKUPTABLE, K_U32ARITH, K_U32ADDMANY, K_U32SUB, K_U32RANGE, K_COMPARISON, K_COUNT };
 struct GateInfo {
   int key, type, param, degree;
   std::string id;
@@ -74,7 +79,7 @@ struct Synth {
   std::vector<u64> witness;  // [135][n]
   std::vector<u64> public_inputs;
   size_t n_poseidon = 0, n_arith = 0, n_noop = 0, n_arithext = 0, n_basesum = 0, n_exp = 0, n_randacc = 0, n_recursion = 0;
-  size_t n_lookup = 0, n_lookup_table = 0;
+  size_t n_lookup = 0, n_lookup_table = 0, n_u32 = 0;
   std::vector<int32_t> lut_lens, lookup_rows;
   std::vector<uint16_t> lut_inputs, lut_outputs;
   vx_circuit_desc desc;
@@ -462,6 +467,219 @@ Prog program_coset_interpolation() {
   p.ins(VX_OP_END, 0);
   return p;
 }
+
+// ---- plonky2-u32 gates (the crate behind plonky2x's U32Variable; un-vendored, restated from its gates/*.rs) --------------
+// Shared pieces: a 2-bit limb range check  prod_{x<4} (limb - x)  (degree 4) and Horner recombination in base 4.
+// Register conventions of these emitters: r51, r52, r53 = 1, 2, 3; r60 = 2^32; r61 = 4; r59 = 2^32 - 1.
+void emit_u32_consts(Prog& p) {
+  p.ldi(51, 1);
+  p.ldi(52, 2);
+  p.ldi(53, 3);
+  p.ldi(59, 0xFFFFFFFFULL);
+  p.ldi(60, (u64)1 << 32);
+  p.ldi(61, 4);
+}
+// pushes limb (limb - 1)(limb - 2)(limb - 3) for the value in register `limb`; t, t+1 scratch
+void emit_limb4_check(Prog& p, int limb, int t) {
+  p.ins(VX_OP_SUB, t, limb, 51);
+  p.ins(VX_OP_MUL, t, t, limb);
+  p.ins(VX_OP_SUB, t + 1, limb, 52);
+  p.ins(VX_OP_MUL, t, t, t + 1);
+  p.ins(VX_OP_SUB, t + 1, limb, 53);
+  p.ins(VX_OP_MUL, t, t, t + 1);
+  p.ins(VX_OP_PUSH, 0, t);
+}
+// gates/arithmetic_u32.rs  U32ArithmeticGate: per op [m0, m1, addend, out_low, out_high, inverse] routed, 32 two-bit limbs after
+// the routed block; constraints: canonicity (inverse (2^32-1 - high) - 1) low, high 2^32 + low - (m0 m1 + addend), the limb
+// range checks from the top limb down, low / high recombination.
+Prog program_u32_arithmetic(int num_ops) {
+  Prog p;
+  emit_u32_consts(p);
+  for (int i = 0; i < num_ops; ++i) {
+    for (int k = 0; k < 6; ++k) p.ins(VX_OP_LDW, k, 6 * i + k);
+    p.ins(VX_OP_MUL, 6, 0, 1);
+    p.ins(VX_OP_ADD, 6, 6, 2);          // computed_output
+    p.ins(VX_OP_SUB, 7, 59, 4);         // u32::MAX - high
+    p.ins(VX_OP_MUL, 7, 5, 7);
+    p.ins(VX_OP_SUB, 7, 7, 51);         // hi_not_max
+    p.ins(VX_OP_MUL, 7, 7, 3);
+    p.ins(VX_OP_PUSH, 0, 7);            // hi_not_max_or_lo_zero
+    p.ins(VX_OP_MUL, 8, 4, 60);
+    p.ins(VX_OP_ADD, 8, 8, 3);
+    p.ins(VX_OP_SUB, 8, 8, 6);
+    p.ins(VX_OP_PUSH, 0, 8);            // combined_output - computed_output
+    p.ldi(9, 0);
+    p.ldi(10, 0);
+    for (int j = 31; j >= 0; --j) {
+      p.ins(VX_OP_LDW, 11, 6 * num_ops + 32 * i + j);
+      emit_limb4_check(p, 11, 12);
+      const int acc = j < 16 ? 9 : 10;
+      p.ins(VX_OP_MUL, acc, acc, 61);
+      p.ins(VX_OP_ADD, acc, acc, 11);
+    }
+    p.ins(VX_OP_SUB, 9, 9, 3);
+    p.ins(VX_OP_PUSH, 0, 9);
+    p.ins(VX_OP_SUB, 10, 10, 4);
+    p.ins(VX_OP_PUSH, 0, 10);
+  }
+  p.ins(VX_OP_END, 0);
+  return p;
+}
+// gates/add_many_u32.rs  U32AddManyGate: per op [addends.., carry, out_result, out_carry] routed; 16 result + 2 carry limbs
+Prog program_u32_add_many(int num_addends, int num_ops) {
+  Prog p;
+  emit_u32_consts(p);
+  const int per = num_addends + 3;
+  for (int i = 0; i < num_ops; ++i) {
+    p.ins(VX_OP_LDW, 0, per * i);
+    for (int j = 1; j <= num_addends; ++j) {   // the addends, then the carry-in
+      p.ins(VX_OP_LDW, 1, per * i + j);
+      p.ins(VX_OP_ADD, 0, 0, 1);
+    }
+    p.ins(VX_OP_LDW, 2, per * i + num_addends + 1);   // output_result
+    p.ins(VX_OP_LDW, 3, per * i + num_addends + 2);   // output_carry
+    p.ins(VX_OP_MUL, 4, 3, 60);
+    p.ins(VX_OP_ADD, 4, 4, 2);
+    p.ins(VX_OP_SUB, 4, 4, 0);
+    p.ins(VX_OP_PUSH, 0, 4);
+    p.ldi(5, 0);
+    p.ldi(6, 0);
+    for (int j = 17; j >= 0; --j) {
+      p.ins(VX_OP_LDW, 7, per * num_ops + 18 * i + j);
+      emit_limb4_check(p, 7, 8);
+      const int acc = j < 16 ? 5 : 6;
+      p.ins(VX_OP_MUL, acc, acc, 61);
+      p.ins(VX_OP_ADD, acc, acc, 7);
+    }
+    p.ins(VX_OP_SUB, 5, 5, 2);
+    p.ins(VX_OP_PUSH, 0, 5);
+    p.ins(VX_OP_SUB, 6, 6, 3);
+    p.ins(VX_OP_PUSH, 0, 6);
+  }
+  p.ins(VX_OP_END, 0);
+  return p;
+}
+// gates/subtraction_u32.rs  U32SubtractionGate: per op [x, y, borrow, out_result, out_borrow] routed; 16 limbs of the result
+Prog program_u32_subtraction(int num_ops) {
+  Prog p;
+  emit_u32_consts(p);
+  for (int i = 0; i < num_ops; ++i) {
+    for (int k = 0; k < 5; ++k) p.ins(VX_OP_LDW, k, 5 * i + k);
+    p.ins(VX_OP_SUB, 5, 0, 1);
+    p.ins(VX_OP_SUB, 5, 5, 2);          // result_initial = x - y - borrow
+    p.ins(VX_OP_MUL, 6, 4, 60);
+    p.ins(VX_OP_ADD, 6, 5, 6);
+    p.ins(VX_OP_SUB, 6, 3, 6);
+    p.ins(VX_OP_PUSH, 0, 6);            // out_result - (result_initial + 2^32 out_borrow)
+    p.ldi(7, 0);
+    for (int j = 15; j >= 0; --j) {
+      p.ins(VX_OP_LDW, 8, 5 * num_ops + 16 * i + j);
+      emit_limb4_check(p, 8, 9);
+      p.ins(VX_OP_MUL, 7, 7, 61);
+      p.ins(VX_OP_ADD, 7, 7, 8);
+    }
+    p.ins(VX_OP_SUB, 7, 7, 3);
+    p.ins(VX_OP_PUSH, 0, 7);
+    p.ins(VX_OP_SUB, 9, 51, 4);
+    p.ins(VX_OP_MUL, 9, 4, 9);
+    p.ins(VX_OP_PUSH, 0, 9);            // out_borrow (1 - out_borrow)
+  }
+  p.ins(VX_OP_END, 0);
+  return p;
+}
+// gates/range_check_u32.rs  U32RangeCheckGate: input limbs 0..n, 16 two-bit aux limbs each
+Prog program_u32_range_check(int num_input_limbs) {
+  Prog p;
+  emit_u32_consts(p);
+  for (int i = 0; i < num_input_limbs; ++i) {
+    p.ins(VX_OP_LDW, 0, i);
+    p.ldi(1, 0);
+    for (int j = 15; j >= 0; --j) {     // reduce_with_powers(aux_limbs, 4)
+      p.ins(VX_OP_LDW, 2, num_input_limbs + 16 * i + j);
+      p.ins(VX_OP_MUL, 1, 1, 61);
+      p.ins(VX_OP_ADD, 1, 1, 2);
+    }
+    p.ins(VX_OP_SUB, 1, 1, 0);
+    p.ins(VX_OP_PUSH, 0, 1);
+    for (int j = 0; j < 16; ++j) {
+      p.ins(VX_OP_LDW, 2, num_input_limbs + 16 * i + j);
+      emit_limb4_check(p, 2, 3);
+    }
+  }
+  p.ins(VX_OP_END, 0);
+  return p;
+}
+// gates/comparison.rs  ComparisonGate{num_bits, num_chunks} (chunk_bits = 2): result_bool = [first_input <= second_input]
+//   wires: first 0 | second 1 | result_bool 2 | most_significant_diff 3 | first chunks 4.. | second chunks | equality dummies |
+//          chunks_equal | intermediate values | the chunk_bits + 1 bits of 2^chunk_bits + most_significant_diff
+struct ComparisonLayout {
+  int nc;
+  int first(int c) const { return 4 + c; }
+  int second(int c) const { return 4 + nc + c; }
+  int eq_dummy(int c) const { return 4 + 2 * nc + c; }
+  int chunks_equal(int c) const { return 4 + 3 * nc + c; }
+  int intermediate(int c) const { return 4 + 4 * nc + c; }
+  int msd_bit(int b) const { return 4 + 5 * nc + b; }
+};
+Prog program_comparison(int num_chunks) {
+  Prog p;
+  emit_u32_consts(p);
+  const ComparisonLayout L{num_chunks};
+  for (int side = 0; side < 2; ++side) {   // the chunks recombine to the inputs
+    p.ldi(1, 0);
+    for (int c = num_chunks - 1; c >= 0; --c) {
+      p.ins(VX_OP_LDW, 2, side ? L.second(c) : L.first(c));
+      p.ins(VX_OP_MUL, 1, 1, 61);
+      p.ins(VX_OP_ADD, 1, 1, 2);
+    }
+    p.ins(VX_OP_LDW, 0, side);
+    p.ins(VX_OP_SUB, 1, 1, 0);
+    p.ins(VX_OP_PUSH, 0, 1);
+  }
+  p.ldi(10, 0);                            // most_significant_diff_so_far
+  for (int c = 0; c < num_chunks; ++c) {
+    p.ins(VX_OP_LDW, 2, L.first(c));
+    p.ins(VX_OP_LDW, 3, L.second(c));
+    emit_limb4_check(p, 2, 4);
+    emit_limb4_check(p, 3, 4);
+    p.ins(VX_OP_SUB, 6, 3, 2);             // difference
+    p.ins(VX_OP_LDW, 7, L.eq_dummy(c));
+    p.ins(VX_OP_LDW, 8, L.chunks_equal(c));
+    p.ins(VX_OP_SUB, 9, 51, 8);            // 1 - chunks_equal
+    p.ins(VX_OP_MUL, 4, 6, 7);
+    p.ins(VX_OP_SUB, 4, 4, 9);
+    p.ins(VX_OP_PUSH, 0, 4);               // difference * dummy - (1 - chunks_equal)
+    p.ins(VX_OP_MUL, 4, 8, 6);
+    p.ins(VX_OP_PUSH, 0, 4);               // chunks_equal * difference
+    p.ins(VX_OP_LDW, 11, L.intermediate(c));
+    p.ins(VX_OP_MUL, 4, 8, 10);
+    p.ins(VX_OP_SUB, 4, 11, 4);
+    p.ins(VX_OP_PUSH, 0, 4);               // intermediate - chunks_equal * so_far
+    p.ins(VX_OP_MUL, 4, 9, 6);
+    p.ins(VX_OP_ADD, 10, 11, 4);           // so_far = intermediate + (1 - chunks_equal) * difference
+  }
+  p.ins(VX_OP_LDW, 12, 3);
+  p.ins(VX_OP_SUB, 4, 12, 10);
+  p.ins(VX_OP_PUSH, 0, 4);                 // most_significant_diff - so_far
+  for (int b = 0; b < 3; ++b) {
+    p.ins(VX_OP_LDW, 13 + b, L.msd_bit(b));
+    p.ins(VX_OP_SUB, 4, 51, 13 + b);
+    p.ins(VX_OP_MUL, 4, 13 + b, 4);
+    p.ins(VX_OP_PUSH, 0, 4);               // bit (1 - bit)
+  }
+  p.ins(VX_OP_ADD, 4, 15, 15);             // bits_combined = ((b2 * 2) + b1) * 2 + b0
+  p.ins(VX_OP_ADD, 4, 4, 14);
+  p.ins(VX_OP_ADD, 4, 4, 4);
+  p.ins(VX_OP_ADD, 4, 4, 13);
+  p.ins(VX_OP_ADD, 5, 61, 12);             // 2^chunk_bits + most_significant_diff
+  p.ins(VX_OP_SUB, 4, 5, 4);
+  p.ins(VX_OP_PUSH, 0, 4);
+  p.ins(VX_OP_LDW, 5, 2);
+  p.ins(VX_OP_SUB, 4, 5, 15);
+  p.ins(VX_OP_PUSH, 0, 4);                 // result_bool - top bit
+  p.ins(VX_OP_END, 0);
+  return p;
+}
 }  // namespace
 
 extern "C" {
@@ -491,7 +709,8 @@ vxs_circuit* vxs_build4(int degree_bits, uint64_t seed, int poseidon_percent, ui
   if (((flags & VXS_FLAG_RECURSION_GATES) && qdf < 8) || ((flags & VXS_FLAG_MORE_PROGRAM_GATES) && qdf < 5)) return nullptr;
   const bool with_prog = flags & VXS_FLAG_PROGRAM_GATES, arith_prog = flags & VXS_FLAG_ARITH_AS_PROGRAM;
   const bool more_prog = flags & VXS_FLAG_MORE_PROGRAM_GATES, rec_prog = flags & VXS_FLAG_RECURSION_GATES;
-  const bool with_lookup = flags & VXS_FLAG_LOOKUP;
+  const bool with_lookup = flags & VXS_FLAG_LOOKUP, u32_prog = flags & VXS_FLAG_U32_GATES;
+  if (u32_prog && (qdf < 5 || degree_bits < 5)) return nullptr;
   if ((with_prog && degree_bits < 4) || (more_prog && degree_bits < 5) || (rec_prog && degree_bits < 5) || (with_lookup && degree_bits < 5)) return nullptr;
   Synth* S = new Synth();
   S->degree_bits = degree_bits;
@@ -524,6 +743,14 @@ vxs_circuit* vxs_build4(int degree_bits, uint64_t seed, int poseidon_percent, ui
     gates.push_back({K_REDUCINGEXT, VX_GATE_PROGRAM, 2, 2, "ReducingExtensionGate { num_coeffs: 32 }"});
     gates.push_back({K_POSEIDONMDS, VX_GATE_PROGRAM, 1, 1, "PoseidonMdsGate(PhantomData<plonky2_field::goldilocks_field::GoldilocksField>)<WIDTH=12>"});
     gates.push_back({K_COSETINTERP, VX_GATE_PROGRAM, 8, 8, "CosetInterpolationGate { subgroup_bits: 4, degree: 8, barycentric_weights: [..], _phantom: PhantomData<plonky2_field::goldilocks_field::GoldilocksField> }<D=2>"});
+  }
+  if (u32_prog) {
+    const char* ph = ", _phantom: PhantomData<plonky2_field::goldilocks_field::GoldilocksField> }<D=2>";
+    gates.push_back({K_U32ARITH, VX_GATE_PROGRAM, 4, 4, std::string("U32ArithmeticGate { num_ops: 3") + ph});
+    gates.push_back({K_U32ADDMANY, VX_GATE_PROGRAM, 4, 4, std::string("U32AddManyGate { num_addends: 3, num_ops: 5") + ph});
+    gates.push_back({K_U32SUB, VX_GATE_PROGRAM, 4, 4, std::string("U32SubtractionGate { num_ops: 6") + ph});
+    gates.push_back({K_U32RANGE, VX_GATE_PROGRAM, 4, 4, std::string("U32RangeCheckGate { num_input_limbs: 7") + ph});
+    gates.push_back({K_COMPARISON, VX_GATE_PROGRAM, 4, 4, std::string("ComparisonGate { num_bits: 32, num_chunks: 16") + ph});
   }
   if (with_lookup) {
     gates.push_back({K_LOOKUP, VX_GATE_LOOKUP, 40, 0, "LookupGate {num_slots: 40, lut_hash: [..]}"});
@@ -587,6 +814,13 @@ vxs_circuit* vxs_build4(int degree_bits, uint64_t seed, int poseidon_percent, ui
     attach(K_POSEIDONMDS, program_poseidon_mds());
     attach(K_COSETINTERP, program_coset_interpolation());
   }
+  if (u32_prog) {
+    attach(K_U32ARITH, program_u32_arithmetic(3));
+    attach(K_U32ADDMANY, program_u32_add_many(3, 5));
+    attach(K_U32SUB, program_u32_subtraction(6));
+    attach(K_U32RANGE, program_u32_range_check(7));
+    attach(K_COMPARISON, program_comparison(16));
+  }
 
   // ---- row budget ----
   const size_t body = n - 3;
@@ -599,17 +833,23 @@ vxs_circuit* vxs_build4(int degree_bits, uint64_t seed, int poseidon_percent, ui
   // all-zero NoopGate row that must follow the table (circuit_builder.rs::add_all_lookups)
   const size_t lut_len = with_lookup ? std::min<size_t>(200, 26 * std::max<size_t>(1, body / 32)) : 0;
   const size_t n_lut = with_lookup ? (lut_len + 25) / 26 : 0, n_lu = with_lookup ? std::max<size_t>(1, body / 32) : 0;
-  const size_t lookup_total = with_lookup ? n_lu + n_lut + 1 : 0;
-  while (n_noop + n_ext + n_bs + n_exp + n_ra + 5 * n_rec + lookup_total > body && n_ext + n_exp + (n_rec > 1) > 0) {
+  // the U32 "voting threshold" block: n_u32 chained U32ArithmeticGate rows + 1 threshold row, and n_u32 rows of each of the
+  // other four gates
+  size_t n_u32 = u32_prog ? std::max<size_t>(1, body / 64) : 0;
+  const size_t lookup_total = (with_lookup ? n_lu + n_lut + 1 : 0);
+  auto u32_total = [&]() { return n_u32 ? 5 * n_u32 + 1 : (size_t)0; };
+  while (n_noop + n_ext + n_bs + n_exp + n_ra + 5 * n_rec + lookup_total + u32_total() > body && n_ext + n_exp + (n_rec > 1) + (n_u32 > 1) > 0) {
     if (n_ext) --n_ext, --n_bs;
     if (n_exp) --n_exp, --n_ra;
     if (n_rec > 1) --n_rec;
+    if (n_u32 > 1) --n_u32;
   }
-  if (n_noop + n_ext + n_bs + n_exp + n_ra + 5 * n_rec + lookup_total > body) { delete S; return nullptr; }
+  if (n_noop + n_ext + n_bs + n_exp + n_ra + 5 * n_rec + lookup_total + u32_total() > body) { delete S; return nullptr; }
+  S->n_u32 = n_u32;
   S->n_recursion = n_rec;
   S->n_lookup = n_lu;
   S->n_lookup_table = n_lut;
-  size_t rest = body - n_noop - n_ext - n_bs - n_exp - n_ra - 5 * n_rec - lookup_total;
+  size_t rest = body - n_noop - n_ext - n_bs - n_exp - n_ra - 5 * n_rec - lookup_total - u32_total();
   S->n_exp = n_exp;
   S->n_randacc = n_ra;
   size_t n_pos = rest * (size_t)poseidon_percent / 100;
@@ -840,6 +1080,112 @@ vxs_circuit* vxs_build4(int degree_bits, uint64_t seed, int poseidon_percent, ui
       }
     }
   }
+  if (u32_prog) {
+    // ---- the voting-threshold block (circuits/builder/justification.rs:164-186): num_signed = sum of the validators'
+    // "signed" bits through chained U32 additions (U32ArithmeticGate m0 * 1 + bit), then num_signed * 3 and
+    // num_active * 2 (two more ops of that gate) and a ComparisonGate on the two products ----
+    auto W = [&](int col, size_t r) -> u64& { return w[(size_t)col * n + r]; };
+    auto u32r = [&]() { return wrng.next() >> 32; };
+    auto put_limbs = [&](int base, int count, u64 v, size_t r) {
+      for (int j = 0; j < count; ++j) W(base + j, r) = (v >> (2 * j)) & 3;
+    };
+    const u64 U32MAX = 0xFFFFFFFFULL;
+    auto fill_arith_op = [&](size_t r, int op, u64 m0, u64 m1, u64 ad) {
+      const u64 full = m0 * m1 + ad;   // < 2^64: (2^32-1)^2 + 2^32 - 1
+      const u64 lo = full & U32MAX, hi = full >> 32;
+      W(6 * op, r) = m0, W(6 * op + 1, r) = m1, W(6 * op + 2, r) = ad, W(6 * op + 3, r) = lo, W(6 * op + 4, r) = hi;
+      W(6 * op + 5, r) = hi == U32MAX ? 0 : inv(U32MAX - hi);
+      put_limbs(18 + 32 * op, 32, full, r);
+      return lo;
+    };
+    u64 num_signed = 0, num_active = 0;
+    size_t prev_row = 0;
+    int prev_op = -1;
+    for (size_t e = 0; e < n_u32; ++e, ++row) {
+      set_gate(row, K_U32ARITH);
+      for (int op = 0; op < 3; ++op) {
+        const u64 bit = (wrng.next() & 7) != 0;   // 7 of 8 validators signed
+        const u64 prev = num_signed;
+        num_signed = fill_arith_op(row, op, prev, 1, bit);
+        ++num_active;
+        dsu.unite(cell(6 * op + 1, row), cell(1, 1));                       // multiplicand 1 = the constant one
+        if (prev_op < 0) dsu.unite(cell(6 * op, row), cell(0, 1));          // num_signed starts from the constant zero
+        else dsu.unite(cell(6 * op, row), cell(6 * prev_op + 3, prev_row)); // ... and continues from the previous low half
+        prev_row = row, prev_op = op;
+      }
+    }
+    const size_t thr_row = row++;
+    set_gate(thr_row, K_U32ARITH);
+    const u64 scaled_signed = fill_arith_op(thr_row, 0, num_signed, 3, 0);
+    dsu.unite(cell(0, thr_row), cell(6 * prev_op + 3, prev_row));
+    const u64 scaled_threshold = fill_arith_op(thr_row, 1, num_active, 2, 0);
+    fill_arith_op(thr_row, 2, u32r(), u32r(), u32r());                      // a full-size product: both halves in use
+    auto fill_comparison = [&](size_t r, u64 a, u64 b) {
+      const ComparisonLayout L{16};
+      W(0, r) = a, W(1, r) = b;
+      u64 so_far = 0;
+      for (int c = 0; c < 16; ++c) {
+        const u64 fc = (a >> (2 * c)) & 3, sc = (b >> (2 * c)) & 3;
+        W(L.first(c), r) = fc, W(L.second(c), r) = sc;
+        const u64 diff = sub(sc, fc);
+        const u64 eq = fc == sc;
+        W(L.eq_dummy(c), r) = eq ? 1 : inv(diff);
+        W(L.chunks_equal(c), r) = eq;
+        const u64 inter = eq ? so_far : 0;
+        W(L.intermediate(c), r) = inter;
+        so_far = add(inter, eq ? 0 : diff);
+      }
+      W(3, r) = so_far;                                  // most_significant_diff in {-3..3}
+      const u64 shifted = add(4, so_far);                // 2^chunk_bits + diff in [1, 7]
+      for (int b2 = 0; b2 < 3; ++b2) W(L.msd_bit(b2), r) = (shifted >> b2) & 1;
+      W(2, r) = (shifted >> 2) & 1;                      // = [a <= b]
+    };
+    for (size_t e = 0; e < n_u32; ++e, ++row) {
+      set_gate(row, K_COMPARISON);
+      if (e == 0) {
+        fill_comparison(row, scaled_threshold, scaled_signed);
+        dsu.unite(cell(0, row), cell(6 * 1 + 3, thr_row));
+        dsu.unite(cell(1, row), cell(6 * 0 + 3, thr_row));
+        if (scaled_threshold <= scaled_signed) dsu.unite(cell(2, row), cell(1, 1));   // is_valid_num_signed == true
+      } else {
+        const u64 a = u32r();
+        fill_comparison(row, a, (e & 3) == 3 ? a : u32r());
+      }
+    }
+    for (size_t e = 0; e < n_u32; ++e, ++row) {          // U32AddManyGate{3 addends, 5 ops}
+      set_gate(row, K_U32ADDMANY);
+      for (int op = 0; op < 5; ++op) {
+        const u64 a0 = u32r(), a1 = u32r(), a2 = u32r(), cin = wrng.next() & 3;
+        const u64 sum = a0 + a1 + a2 + cin;
+        W(6 * op, row) = a0, W(6 * op + 1, row) = a1, W(6 * op + 2, row) = a2, W(6 * op + 3, row) = cin;
+        W(6 * op + 4, row) = sum & U32MAX, W(6 * op + 5, row) = sum >> 32;
+        put_limbs(30 + 18 * op, 16, sum & U32MAX, row);
+        put_limbs(30 + 18 * op + 16, 2, sum >> 32, row);
+      }
+    }
+    for (size_t e = 0; e < n_u32; ++e, ++row) {          // U32SubtractionGate{6 ops}: a 192-bit subtraction, borrow chained
+      set_gate(row, K_U32SUB);
+      u64 borrow = 0;
+      for (int op = 0; op < 6; ++op) {
+        const u64 x = u32r(), y = u32r();
+        const bool under = x < y + borrow;
+        const u64 res = (x - y - borrow) & U32MAX;
+        W(5 * op, row) = x, W(5 * op + 1, row) = y, W(5 * op + 2, row) = borrow, W(5 * op + 3, row) = res, W(5 * op + 4, row) = under;
+        put_limbs(30 + 16 * op, 16, res, row);
+        if (op > 0) dsu.unite(cell(5 * op + 2, row), cell(5 * (op - 1) + 4, row));
+        else dsu.unite(cell(2, row), cell(0, 1));
+        borrow = under;
+      }
+    }
+    for (size_t e = 0; e < n_u32; ++e, ++row) {          // U32RangeCheckGate{7 limbs}
+      set_gate(row, K_U32RANGE);
+      for (int i = 0; i < 7; ++i) {
+        const u64 v = u32r();
+        W(i, row) = v;
+        put_limbs(7 + 16 * i, 16, v, row);
+      }
+    }
+  }
   if (with_lookup) {
     // rows [last_lu_row, last_lut_row) = LookupGate, [last_lut_row, first_lut_row] = LookupTableGate, first_lut_row + 1 = Noop (zeros)
     const size_t last_lu_row = row, last_lut_row = row + n_lu, first_lut_row = last_lut_row + n_lut - 1;
@@ -990,6 +1336,7 @@ void vxs_row_counts(vxs_circuit* c, uint64_t out[3]) {
   out[2] = S->n_noop;
 }
 uint64_t vxs_recursion_rows(vxs_circuit* c) { return reinterpret_cast<Synth*>(c)->n_recursion; }
+uint64_t vxs_u32_rows(vxs_circuit* c) { return reinterpret_cast<Synth*>(c)->n_u32; }
 void vxs_row_counts_ext(vxs_circuit* c, uint64_t out[7]) {
   Synth* S = reinterpret_cast<Synth*>(c);
   out[0] = S->n_poseidon;
