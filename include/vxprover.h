@@ -326,6 +326,11 @@ typedef struct vx_stark_desc {
    * (As in starky, first- and last-row constraints are multiplied by a Lagrange selector of degree n - 1: their own degree
    * must stay <= constraint_degree - 1, or the quotient no longer fits its quotient_degree_factor chunks.) */
   int32_t num_aux_columns, num_aux_challenges;
+  /* Values the prover announces AFTER the second commitment (0 = none): closing sums of lookup / bus accumulators — what
+   * starky's cross-table lookups call ctl_zs_last.  They are observed into the transcript after the aux cap, travel at the end
+   * of the proof, and the AIR program reads them with VX_OP_LDP at indices num_public_inputs .. num_public_inputs +
+   * num_aux_public_inputs - 1 (typically in a last-row constraint  acc = closing sum). */
+  int32_t num_aux_public_inputs;
 } vx_stark_desc;
 #define VX_OP_LDCH 10 /* AIR programs only: r[dst] = aux challenge a */
 int vx_stark_prove(vx_ctx* ctx, const vx_stark_desc* desc, const uint64_t* trace /* [num_columns][2^degree_bits] */, int trace_on_device,
@@ -343,6 +348,24 @@ int vx_stark_finish(vx_stark_session* session, const uint64_t* aux_columns, int 
                     uint8_t* out_buf, size_t* out_len);
 void vx_stark_session_free(vx_stark_session* session);
 int vx_stark_verify(const vx_stark_desc* desc, const uint64_t* public_inputs, const uint8_t* proof, size_t proof_len);
+/* ---- several tables on ONE bus (the shape of Curta's chips: every chip is its own trace, lookups and the bus run across them).
+ * One session per table; the challenges of the cross-table argument must be the same in every table and may only be drawn when
+ * EVERY trace is committed:
+ *   vx_stark_begin (each table)  ->  vx_stark_session_trace_cap (each)  ->  vx_stark_joint_challenges over all caps  ->
+ *   vx_stark_set_aux_challenges (each: replaces the session's own challenges and binds the shared ones into its transcript)  ->
+ *   the caller computes each table's second-round columns and closing sums  ->  vx_stark_finish2 (each).
+ * Verification: vx_stark_proof_trace_cap (each proof) -> vx_stark_joint_challenges -> vx_stark_verify_shared (each; returns
+ * the table's closing sums) -> the caller checks that the closing sums of the bus cancel (send minus receive = 0).
+ * `aux_public_inputs` = [num_aux_public_inputs] values (see vx_stark_desc).  vx_stark_finish == vx_stark_finish2 with NULL. */
+int vx_stark_session_trace_cap(vx_stark_session* session, uint64_t* cap_out /* [2^cap_height][4] */);
+int vx_stark_set_aux_challenges(vx_stark_session* session, const uint64_t* shared_challenges /* [num_aux_challenges] */);
+int vx_stark_finish2(vx_stark_session* session, const uint64_t* aux_columns, int aux_on_device, const uint64_t* aux_public_inputs,
+                     const uint64_t* pow_witness_hint, uint8_t* out_buf, size_t* out_len);
+int vx_stark_joint_challenges(const uint64_t* const* trace_caps, const int32_t* cap_heights, int num_tables, int num_challenges,
+                              uint64_t* challenges_out);   /* host: Challenger over [num_tables, cap_0, cap_1, ..] */
+int vx_stark_proof_trace_cap(const vx_stark_desc* desc, const uint8_t* proof, size_t proof_len, uint64_t* cap_out);
+int vx_stark_verify_shared(const vx_stark_desc* desc, const uint64_t* public_inputs, const uint8_t* proof, size_t proof_len,
+                           const uint64_t* shared_challenges /* NULL: the proof's own */, uint64_t* aux_public_inputs_out /* may be NULL */);
 
 /* ---- ONE proof sharded across the GPUs of a node (BASELINE.json configs[3]) -------------------
  * `world` in {1, 2, 4, 8} ranks (one vx_ctx + one copy of the circuit each; world <= 2^rate_bits and
@@ -374,6 +397,10 @@ int vx_group_join(vx_group* g, int rank, vx_ctx* ctx, void** member_out); /* mem
 int vx_group_peer_staged(vx_group* g); /* 1 if some pair of member devices has no peer access (copies are host-staged) */
 int vx_group_allgather(void* member, void* dev_buf, size_t bytes_per_rank);
 void vx_group_abort(vx_group* g); /* wake every rank waiting in vx_group_allgather with VX_E_COMM (a rank has failed) */
+/* A rank that DIED cannot abort: a barrier inside vx_group_allgather gives up after this long (default 120 000 ms), aborts the
+ * group and returns VX_E_COMM on every waiting rank.  A host whose rank fails with any other error between two exchanges
+ * (vx_prove_sharded returned non-zero) calls vx_group_abort itself — the peers then return at once instead of timing out. */
+int vx_group_set_timeout_ms(vx_group* g, long long milliseconds);
 
 #ifdef __cplusplus
 }

@@ -344,9 +344,53 @@ struct vxo_stark_desc {
   int32_t num_fri_reduction_arity_bits;
   const int32_t* fri_reduction_arity_bits;
   int32_t num_aux_columns, num_aux_challenges;
+  int32_t num_aux_public_inputs;
 };
-// aux_fn(challenges[num_aux_challenges], aux_out[num_aux_columns][n], user): the caller's second-round column generator
+// aux_fn(challenges[num_aux_challenges], aux_out[num_aux_columns][n] followed by [num_aux_public_inputs] closing sums, user):
+// the caller's second-round column generator
 typedef void (*vxo_stark_aux_fn)(const u64* challenges, u64* aux_out, void* user);
+static StarkDesc vxo_to_desc(const vxo_stark_desc* d) {
+  StarkDesc s;
+  s.degree_bits = d->degree_bits, s.num_columns = d->num_columns, s.num_public_inputs = d->num_public_inputs;
+  s.rate_bits = d->rate_bits, s.cap_height = d->cap_height, s.pow_bits = d->pow_bits, s.num_query_rounds = d->num_query_rounds;
+  s.num_challenges = d->num_challenges, s.constraint_degree = d->constraint_degree;
+  s.num_aux_columns = d->num_aux_columns, s.num_aux_challenges = d->num_aux_challenges, s.num_aux_public_inputs = d->num_aux_public_inputs;
+  s.program.assign(d->program, d->program + d->program_len);
+  if (d->override_flags & 2) s.arity_bits.assign(d->fri_reduction_arity_bits, d->fri_reduction_arity_bits + d->num_fri_reduction_arity_bits);
+  else s.default_arities();
+  return s;
+}
+static std::vector<std::vector<u64>> vxo_to_trace(const vxo_stark_desc* d, const u64* trace) {
+  const size_t n = (size_t)1 << d->degree_bits;
+  std::vector<std::vector<u64>> tr(d->num_columns);
+  for (int c = 0; c < d->num_columns; ++c) {
+    tr[c].assign(trace + (size_t)c * n, trace + (size_t)(c + 1) * n);
+    for (auto& x : tr[c]) x = canon(x);
+  }
+  return tr;
+}
+long long vxo_stark_prove3(const vxo_stark_desc* d, const u64* trace, const u64* pis, const u64* pow_hint, vxo_stark_aux_fn aux_fn, void* user,
+                           const u64* shared_challenges, uint8_t* out, size_t cap, char* err, size_t err_cap);
+// trace cap of one table (cap_out [2^cap_height][4]) and the joint challenges over several tables' caps
+int vxo_stark_trace_cap(const vxo_stark_desc* d, const u64* trace, u64* cap_out) {
+  try {
+    const std::vector<Hash> cap = stark_trace_cap(vxo_to_desc(d), vxo_to_trace(d, trace));
+    for (size_t i = 0; i < cap.size(); ++i) memcpy(cap_out + 4 * i, cap[i].e, 32);
+    return 0;
+  } catch (const std::exception&) {
+    return -1;
+  }
+}
+int vxo_stark_joint_challenges(const u64* const* caps, const int32_t* cap_heights, int ntables, int n, u64* out) {
+  std::vector<std::vector<Hash>> cs(ntables);
+  for (int t = 0; t < ntables; ++t) {
+    cs[t].resize((size_t)1 << cap_heights[t]);
+    for (size_t i = 0; i < cs[t].size(); ++i) memcpy(cs[t][i].e, caps[t] + 4 * i, 32);
+  }
+  const std::vector<u64> ch = stark_joint_challenges(cs, n);
+  memcpy(out, ch.data(), ch.size() * 8);
+  return 0;
+}
 long long vxo_stark_prove2(const vxo_stark_desc* d, const u64* trace, const u64* pis, const u64* pow_hint, vxo_stark_aux_fn aux_fn, void* user,
                            uint8_t* out, size_t cap, char* err, size_t err_cap);
 long long vxo_stark_prove(const vxo_stark_desc* d, const u64* trace, const u64* pis, const u64* pow_hint, uint8_t* out, size_t cap,
@@ -355,34 +399,30 @@ long long vxo_stark_prove(const vxo_stark_desc* d, const u64* trace, const u64* 
 }
 long long vxo_stark_prove2(const vxo_stark_desc* d, const u64* trace, const u64* pis, const u64* pow_hint, vxo_stark_aux_fn aux_fn, void* user,
                            uint8_t* out, size_t cap, char* err, size_t err_cap) {
+  return vxo_stark_prove3(d, trace, pis, pow_hint, aux_fn, user, nullptr, out, cap, err, err_cap);
+}
+long long vxo_stark_prove3(const vxo_stark_desc* d, const u64* trace, const u64* pis, const u64* pow_hint, vxo_stark_aux_fn aux_fn, void* user,
+                           const u64* shared_challenges, uint8_t* out, size_t cap, char* err, size_t err_cap) {
   try {
-    StarkDesc s;
-    s.degree_bits = d->degree_bits, s.num_columns = d->num_columns, s.num_public_inputs = d->num_public_inputs;
-    s.rate_bits = d->rate_bits, s.cap_height = d->cap_height, s.pow_bits = d->pow_bits, s.num_query_rounds = d->num_query_rounds;
-    s.num_challenges = d->num_challenges, s.constraint_degree = d->constraint_degree;
-    s.num_aux_columns = d->num_aux_columns, s.num_aux_challenges = d->num_aux_challenges;
-    s.program.assign(d->program, d->program + d->program_len);
-    if (d->override_flags & 2) s.arity_bits.assign(d->fri_reduction_arity_bits, d->fri_reduction_arity_bits + d->num_fri_reduction_arity_bits);
-    else s.default_arities();
+    const StarkDesc s = vxo_to_desc(d);
     const size_t n = (size_t)1 << d->degree_bits;
-    std::vector<std::vector<u64>> tr(d->num_columns);
-    for (int c = 0; c < d->num_columns; ++c) {
-      tr[c].assign(trace + (size_t)c * n, trace + (size_t)(c + 1) * n);
-      for (auto& x : tr[c]) x = canon(x);
-    }
+    const std::vector<std::vector<u64>> tr = vxo_to_trace(d, trace);
     std::vector<u64> pi(pis, pis + d->num_public_inputs);
     ProveOptions opt;
     if (pow_hint) opt.has_pow_hint = true, opt.pow_hint = *pow_hint;
     StarkAuxFn fn;
     if (aux_fn)
-      fn = [&](const std::vector<u64>& ch) {
-        std::vector<u64> flat((size_t)s.num_aux_columns * n);
+      fn = [&](const std::vector<u64>& ch, std::vector<u64>& aux_pis) {
+        std::vector<u64> flat((size_t)s.num_aux_columns * n + (size_t)s.num_aux_public_inputs);
         aux_fn(ch.data(), flat.data(), user);
         std::vector<std::vector<u64>> cols(s.num_aux_columns);
         for (int c = 0; c < s.num_aux_columns; ++c) cols[c].assign(flat.begin() + (size_t)c * n, flat.begin() + (size_t)(c + 1) * n);
+        aux_pis.assign(flat.begin() + (size_t)s.num_aux_columns * n, flat.end());
         return cols;
       };
-    std::vector<uint8_t> bytes = serialize_stark_proof(stark_prove(s, tr, pi, opt, fn));
+    std::vector<u64> shared;
+    if (shared_challenges) shared.assign(shared_challenges, shared_challenges + s.num_aux_challenges);
+    std::vector<uint8_t> bytes = serialize_stark_proof(stark_prove(s, tr, pi, opt, fn, shared_challenges ? &shared : nullptr));
     if (bytes.size() > cap) {
       snprintf(err, err_cap, "output buffer too small: need %zu bytes", bytes.size());
       return -1;

@@ -24,6 +24,9 @@ struct StarkDesc {
   // the trace cap `num_aux_challenges` challenges are drawn, the prover commits `num_aux_columns` more columns that may
   // depend on them, and the AIR program sees both (columns num_columns.. = aux columns, AIR_OP_LDCH = a challenge)
   int num_aux_columns = 0, num_aux_challenges = 0;
+  // values announced after the second commitment (closing sums of bus / lookup accumulators; starky's ctl_zs_last): observed
+  // after the aux cap, read by the program as public inputs num_public_inputs..
+  int num_aux_public_inputs = 0;
   std::vector<u64> program;
   std::vector<int> arity_bits;
   int quotient_degree_factor() const { return constraint_degree > 1 ? constraint_degree - 1 : 1; }  // Stark::quotient_degree_factor
@@ -37,7 +40,7 @@ struct StarkProof {
   std::vector<Hash> trace_cap, aux_cap, quotient_cap;
   std::vector<Ext> local_values, next_values, aux_local_values, aux_next_values, quotient_polys;
   FriProof fri;
-  std::vector<u64> public_inputs;
+  std::vector<u64> public_inputs, aux_public_inputs;
 };
 
 // ConstraintConsumer + Stark::eval_packed_generic / eval_ext: the AIR as a straight-line program over (local, next, pis)
@@ -187,9 +190,12 @@ static void fri_prove_two_points(const std::vector<const PolynomialBatch*>& orac
 // starky/src/prover.rs::prove_with_commitment; with num_aux_columns > 0 a second commitment round sits between the trace
 // cap and the alphas (where starky commits its permutation Z polynomials and Curta its accumulators): `aux_fn` maps the
 // drawn challenges to the aux columns.
-typedef std::function<std::vector<std::vector<u64>>(const std::vector<u64>&)> StarkAuxFn;
+// aux_fn(challenges, aux_public_inputs_out) -> aux columns
+typedef std::function<std::vector<std::vector<u64>>(const std::vector<u64>&, std::vector<u64>&)> StarkAuxFn;
+// `shared_challenges` (cross-table arguments: several tables on one bus): challenges the caller drew over EVERY table's trace
+// cap (stark_joint_challenges below); they replace the table's own and are observed into its transcript.
 static StarkProof stark_prove(const StarkDesc& d, const std::vector<std::vector<u64>>& trace, const std::vector<u64>& pis, const ProveOptions& opt = ProveOptions(),
-                              const StarkAuxFn& aux_fn = StarkAuxFn()) {
+                              const StarkAuxFn& aux_fn = StarkAuxFn(), const std::vector<u64>* shared_challenges = nullptr) {
   const int lg = d.degree_bits, rb = d.rate_bits, nch = d.num_challenges;
   const size_t n = (size_t)1 << lg;
   StarkProof proof;
@@ -206,7 +212,7 @@ static StarkProof stark_prove(const StarkDesc& d, const std::vector<std::vector<
     // library's own transcript prefix — old starky observes nothing before the trace cap (weak Fiat-Shamir)
     std::vector<u64> st = {(u64)d.degree_bits, (u64)d.rate_bits, (u64)d.cap_height, (u64)d.pow_bits, (u64)d.num_query_rounds, (u64)d.num_challenges,
                            (u64)d.constraint_degree, (u64)d.num_columns, (u64)d.num_aux_columns, (u64)d.num_aux_challenges, (u64)d.num_public_inputs,
-                           (u64)d.arity_bits.size()};
+                           (u64)d.num_aux_public_inputs, (u64)d.arity_bits.size()};
     for (int a : d.arity_bits) st.push_back((u64)a);
     std::vector<u64> limbs;
     for (size_t pc = 0; pc < d.program.size(); ++pc) {
@@ -229,8 +235,15 @@ static StarkProof stark_prove(const StarkDesc& d, const std::vector<std::vector<
   std::vector<u64> aux_challenges(d.num_aux_challenges);
   if (naux > 0) {
     for (auto& v : aux_challenges) v = ch.get_challenge();
+    if (shared_challenges) {
+      if (shared_challenges->size() != aux_challenges.size()) throw std::runtime_error("wrong number of shared challenges");
+      for (size_t i = 0; i < aux_challenges.size(); ++i) aux_challenges[i] = canon((*shared_challenges)[i]);
+      ch.observe_elements(aux_challenges.data(), aux_challenges.size());
+    }
     if (!aux_fn) throw std::runtime_error("this AIR has a second commitment round: no aux column generator given");
-    std::vector<std::vector<u64>> cols = aux_fn(aux_challenges);
+    std::vector<std::vector<u64>> cols = aux_fn(aux_challenges, proof.aux_public_inputs);
+    if ((int)proof.aux_public_inputs.size() != d.num_aux_public_inputs) throw std::runtime_error("aux column generator returned the wrong number of aux public inputs");
+    for (auto& v : proof.aux_public_inputs) v = canon(v);
     if ((int)cols.size() != naux) throw std::runtime_error("aux column generator returned the wrong number of columns");
     for (auto& col : cols) {
       if (col.size() != n) throw std::runtime_error("aux column has the wrong length");
@@ -238,7 +251,10 @@ static StarkProof stark_prove(const StarkDesc& d, const std::vector<std::vector<
     }
     aux_b.from_values(std::move(cols), rb, d.cap_height);
     ch.observe_cap(aux_b.tree.cap());
+    if (!proof.aux_public_inputs.empty()) ch.observe_elements(proof.aux_public_inputs.data(), proof.aux_public_inputs.size());
   }
+  std::vector<u64> all_pis(proof.public_inputs);   // the program's LDP index space: public inputs, then aux public inputs
+  all_pis.insert(all_pis.end(), proof.aux_public_inputs.begin(), proof.aux_public_inputs.end());
   std::vector<u64> alphas(nch);
   for (int i = 0; i < nch; ++i) alphas[i] = ch.get_challenge();
   // ---- compute_quotient_polys ----
@@ -267,7 +283,7 @@ static StarkProof stark_prove(const StarkDesc& d, const std::vector<std::vector<
       const u64 zh = sub(pow(x, (u64)n), 1);
       const u64 l_first = mul(mul(zh, n_inv), inv(sub(x, 1)));
       const u64 l_last = mul(mul(mul(zh, n_inv), last), inv(sub(x, last)));
-      eval_air<Fp>(d, local.data(), next.data(), proof.public_inputs.data(), aux_challenges.data(), Fp(sub(x, last)), Fp(l_first), Fp(l_last),
+      eval_air<Fp>(d, local.data(), next.data(), all_pis.data(), aux_challenges.data(), Fp(sub(x, last)), Fp(l_first), Fp(l_last),
                    alphas.data(), acc.data());
       const u64 zi = inv(zh);
       for (int c = 0; c < nch; ++c) qvals[c][i] = mul(acc[c].v, zi);
@@ -347,7 +363,25 @@ static std::vector<uint8_t> serialize_stark_proof(const StarkProof& p) {
   w.extvec(p.fri.final_poly);
   w.f(p.fri.pow_witness);
   for (u64 v : p.public_inputs) w.f(v);
+  for (u64 v : p.aux_public_inputs) w.f(v);
   return w.b;
+}
+
+// Challenges of a cross-table argument: one transcript over [number of tables, every table's trace cap in table order].
+static std::vector<u64> stark_joint_challenges(const std::vector<std::vector<Hash>>& caps, int n) {
+  Challenger ch;
+  ch.observe_element((u64)caps.size());
+  for (const auto& cap : caps) ch.observe_cap(cap);
+  std::vector<u64> out(n);
+  for (auto& v : out) v = ch.get_challenge();
+  return out;
+}
+// The trace commitment alone (what a multi-table host needs before it can draw the joint challenges).
+static std::vector<Hash> stark_trace_cap(const StarkDesc& d, const std::vector<std::vector<u64>>& trace) {
+  PolynomialBatch b;
+  std::vector<std::vector<u64>> cols = trace;
+  b.from_values(std::move(cols), d.rate_bits, d.cap_height);
+  return b.tree.cap();
 }
 
 }  // namespace vxo

@@ -198,17 +198,19 @@ class OracleCircuit:
 _cached = None
 
 
-def stark_prove(oracle, stark, trace, public_inputs, pow_hint=None) -> bytes:
+def stark_prove(oracle, stark, trace, public_inputs, pow_hint=None, shared_challenges=None) -> bytes:
     """oracle/stark.hpp::stark_prove on a `vectorx_amd.Stark` description (same vx_stark_desc layout); a description with a
-    second commitment round hands its `aux_fn` to the oracle as a callback."""
+    second commitment round hands its `aux_fn` to the oracle as a callback (columns, then the aux public inputs).
+    `shared_challenges`: the joint challenges of a cross-table argument (stark_joint_challenges)."""
     L = oracle.L
     AUXFN = ctypes.CFUNCTYPE(None, _vp, _vp, _vp)
-    L.vxo_stark_prove2.restype = ctypes.c_longlong
-    L.vxo_stark_prove2.argtypes = [_vp, _vp, _vp, _vp, AUXFN, _vp, _vp, _sz, ctypes.c_char_p, _sz]
+    L.vxo_stark_prove3.restype = ctypes.c_longlong
+    L.vxo_stark_prove3.argtypes = [_vp, _vp, _vp, _vp, AUXFN, _vp, _vp, _vp, _sz, ctypes.c_char_p, _sz]
     t = np.ascontiguousarray(trace, dtype=np.uint64)
     pi = np.ascontiguousarray(public_inputs, dtype=np.uint64)
     hint = np.array([pow_hint], dtype=np.uint64) if pow_hint is not None else None
-    buf = np.empty(1 << 24, dtype=np.uint8)
+    sh = np.ascontiguousarray(shared_challenges, dtype=np.uint64) if shared_challenges is not None else None
+    buf = np.empty(1 << 25, dtype=np.uint8)
     err = ctypes.create_string_buffer(512)
     naux, nchal, n = stark.desc.num_aux_columns, stark.desc.num_aux_challenges, 1 << stark.desc.degree_bits
     failure = []
@@ -216,20 +218,46 @@ def stark_prove(oracle, stark, trace, public_inputs, pow_hint=None) -> bytes:
     def cb(chal_p, out_p, _user):
         try:
             chal = np.ctypeslib.as_array(ctypes.cast(chal_p, ctypes.POINTER(ctypes.c_uint64)), shape=(max(nchal, 1),))[:nchal].copy()
-            aux = np.ascontiguousarray(stark.aux_fn(t, chal), dtype=np.uint64)
-            assert aux.shape == (naux, n), aux.shape
+            aux, api = stark.run_aux(t, chal)
             ctypes.memmove(out_p, aux.ctypes.data, aux.nbytes)
+            if api.size:
+                ctypes.memmove(out_p + aux.nbytes, api.ctypes.data, api.nbytes)
         except BaseException as e:      # must not propagate through the C frames
             failure.append(e)
 
     fn = AUXFN(cb) if naux else ctypes.cast(None, AUXFN)
-    r = L.vxo_stark_prove2(ctypes.cast(stark.desc_ptr, _vp), t.ctypes.data, pi.ctypes.data, hint.ctypes.data if hint is not None else None,
-                           fn, None, buf.ctypes.data, buf.size, err, 512)
+    r = L.vxo_stark_prove3(ctypes.cast(stark.desc_ptr, _vp), t.ctypes.data, pi.ctypes.data, hint.ctypes.data if hint is not None else None,
+                           fn, None, sh.ctypes.data if sh is not None else None, buf.ctypes.data, buf.size, err, 512)
     if failure:
         raise failure[0]
     if r < 0:
         raise RuntimeError(err.value.decode())
     return buf[:r].tobytes()
+
+
+def stark_trace_cap(oracle, stark, trace) -> np.ndarray:
+    cap = np.zeros((1 << stark.desc.cap_height, 4), dtype=np.uint64)
+    t = np.ascontiguousarray(trace, dtype=np.uint64)
+    oracle.L.vxo_stark_trace_cap.argtypes = [_vp, _vp, _vp]
+    assert oracle.L.vxo_stark_trace_cap(ctypes.cast(stark.desc_ptr, _vp), t.ctypes.data, cap.ctypes.data) == 0
+    return cap
+
+
+def stark_joint_challenges(oracle, caps, cap_heights, n) -> np.ndarray:
+    keep = [np.ascontiguousarray(c, dtype=np.uint64) for c in caps]
+    arr = (ctypes.c_void_p * len(keep))(*[k.ctypes.data for k in keep])
+    hs = (ctypes.c_int32 * len(keep))(*cap_heights)
+    out = np.zeros(n, dtype=np.uint64)
+    oracle.L.vxo_stark_joint_challenges.argtypes = [_vp, _vp, ctypes.c_int, ctypes.c_int, _vp]
+    assert oracle.L.vxo_stark_joint_challenges(ctypes.cast(arr, _vp), ctypes.cast(hs, _vp), len(keep), n, out.ctypes.data) == 0
+    return out
+
+
+def stark_prove_tables(oracle, tables):
+    """the oracle's side of vectorx_amd/stark_bus.py::prove_tables: [(stark, trace, pis)] -> (proofs, shared challenges)"""
+    caps = [stark_trace_cap(oracle, st, tr) for st, tr, _ in tables]
+    shared = stark_joint_challenges(oracle, caps, [st.desc.cap_height for st, _, _ in tables], tables[0][0].desc.num_aux_challenges)
+    return [stark_prove(oracle, st, tr, pi, shared_challenges=shared) for st, tr, pi in tables], shared
 
 
 def load() -> Oracle:

@@ -107,6 +107,67 @@ def test_unsatisfied_witness_behaves_like_the_unsharded_prover(oracle):
         _free(ctxs, circuits)
 
 
+def test_a_rank_that_dies_mid_proof_does_not_hang_its_peers():
+    """rank 2 of 4 stops taking part after its third exchange WITHOUT aborting the group (a crashed host
+    thread cannot).  The peers must come back with VX_E_COMM — through the barrier timeout — not wait forever; and a rank
+    that fails with an error between exchanges aborts the group so that the peers return at once."""
+    import threading
+    import time
+    sc = SynthCircuit(8, seed=77, poseidon_percent=40)
+    sc.desc.pow_bits = 4
+    w = sc.witness()
+    world = 4
+    L = vx.lib()
+    for mode in ("dies", "aborts"):
+        ctxs, circuits = _rank_circuits(sc, world)
+        g = ctypes.c_void_p()
+        assert L.vx_group_create(world, ctypes.byref(g)) == 0
+        assert L.vx_group_set_timeout_ms(g, 3000) == 0
+        members = []
+        for r in range(world):
+            m = ctypes.c_void_p()
+            assert L.vx_group_join(g, r, ctxs[r]._h, ctypes.byref(m)) == 0
+            members.append(m)
+        calls = {"n": 0}
+
+        def flaky(dptr, nbytes):                       # rank 2's exchange: three good ones, then the rank is gone
+            calls["n"] += 1
+            if calls["n"] > 3:
+                if mode == "aborts":
+                    L.vx_group_abort(g)
+                raise RuntimeError("rank 2 died")
+            rc = L.vx_group_allgather(members[2], ctypes.c_void_p(dptr), nbytes)
+            if rc != 0:
+                raise vx.VxError(rc, "exchange failed")
+
+        out = [None] * world
+
+        def run(r):
+            try:
+                if r == 2:
+                    circuits[r].prove_sharded(w, r, world, flaky)
+                else:
+                    circuits[r].prove_sharded(w, r, world, L.vx_group_allgather, members[r])
+                out[r] = "proof"
+            except BaseException as e:
+                out[r] = e
+
+        t0 = time.time()
+        threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=60)
+        took = time.time() - t0
+        assert not any(t.is_alive() for t in threads), "a rank is still waiting for the dead one"
+        assert isinstance(out[2], RuntimeError)
+        for r in (0, 1, 3):
+            assert isinstance(out[r], vx.VxError) and out[r].code == vx.VX_E_COMM, (mode, r, out[r])
+        assert took < (20 if mode == "dies" else 10), took
+        L.vx_group_destroy(g)
+        _free(ctxs, circuits)
+
+
 def test_sharded_argument_checks(ctx):
     sc = SynthCircuit(5, seed=1, poseidon_percent=50)
     c = vx.Circuit(ctx, sc.desc_ptr)

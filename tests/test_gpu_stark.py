@@ -111,3 +111,84 @@ def test_two_round_session_api(ctx, oracle):
     big = np.empty(1 << 20, dtype=np.uint8)
     n = ctypes.c_size_t(big.size)
     assert L.vx_stark_prove(ctx._h, ctypes.cast(stark.desc_ptr, vp), t.ctypes.data, 0, pis.ctypes.data, None, big.ctypes.data, ctypes.byref(n)) == vx.VX_E_INVALID
+
+
+# ---- chip density: the SHA-256 AIR of vectorx_amd/sha256_air.py — 1024 + 3 columns, 2072 constraints of degree <= 3,
+#      a 16 k-word program, a log-derivative range check in the second commitment round — own AIR, not Curta's ----------------------
+SHA_MESSAGES = [b"abc", b"", b"The quick brown fox jumps over the lazy dog" * 3, bytes(range(200)), b"vectorx" * 100]
+
+
+@pytest.mark.parametrize("degree_bits,cfg", [(7, {}), (9, dict(rate_bits=2, num_query_rounds=30)), (11, dict(num_query_rounds=40))])
+def test_sha256_air_proof_bytes_identical_to_oracle(ctx, oracle, degree_bits, cfg):
+    import hashlib
+    from vectorx_amd import sha256_air as sha
+    cfg = dict(dict(pow_bits=8, num_query_rounds=20), **cfg)
+    stark = sha.make_stark(degree_bits, **cfg)
+    trace, pis, digests = sha.generate_trace(degree_bits, SHA_MESSAGES)
+    assert digests == [hashlib.sha256(m).digest() for m in SHA_MESSAGES[:len(digests)]] and digests
+    ctx.prof_enable(True)
+    ctx.prof_reset()
+    gp = stark.prove(ctx, trace, pis)
+    stages = ctx.prof()
+    ctx.prof_enable(False)
+    assert "air_quotient_eval_jit" in stages, sorted(stages)           # the 16 k-word program compiles (VX_PROGRAM_REGS / length limits do not bind)
+    op = oracle_lib.stark_prove(oracle, stark, trace, pis)
+    assert gp == op
+    stark.verify(pis, gp)
+    wrong = pis.copy()
+    wrong[7] = (int(wrong[7]) + 1) % P
+    with pytest.raises(vx.VxError):
+        stark.verify(wrong, gp)
+    bad = trace.copy()                                                   # a single flipped state bit: refused or rejected
+    bad[sha.Cols.S + 40, 77] ^= np.uint64(1)
+    try:
+        bp = stark.prove(ctx, bad, pis)
+    except vx.VxError:
+        bp = None
+    if bp is not None:
+        with pytest.raises(vx.VxError):
+            stark.verify(pis, bp)
+
+
+def test_sha256_air_interpreted_equals_compiled(ctx, oracle):
+    import os
+    from vectorx_amd import sha256_air as sha
+    stark = sha.make_stark(7, pow_bits=6, num_query_rounds=12)
+    trace, pis, _ = sha.generate_trace(7, SHA_MESSAGES)
+    expect = stark.prove(ctx, trace, pis)
+    os.environ["VX_NO_JIT"] = "1"
+    try:
+        ctx.prof_enable(True)
+        ctx.prof_reset()
+        assert stark.prove(ctx, trace, pis) == expect
+        assert "air_quotient_eval" in ctx.prof()
+    finally:
+        del os.environ["VX_NO_JIT"]
+        ctx.prof_enable(False)
+
+
+def test_two_tables_on_one_bus_bytes_identical_to_oracle(ctx, oracle):
+    """vx_stark_begin x 2 -> joint challenges over both trace caps -> vx_stark_set_aux_challenges -> vx_stark_finish2 with the
+    closing sums (vectorx_amd/stark_bus.py): both proofs byte-identical to the oracle's, the bus balances, a proof moved into
+    another bus (other joint challenges) is refused."""
+    import hashlib
+    from vectorx_amd import sha256_air as sha
+    from vectorx_amd import stark_bus
+    cfg = dict(num_query_rounds=16, pow_bits=6)
+    sha_stark = sha.make_stark(9, bus=True, **cfg)
+    t, pis, digests = sha.generate_trace(9, SHA_MESSAGES)
+    assert len(digests) >= 3
+    sink_stark, sink_t, sink_pis = sha.make_sink(5, digests, **cfg)
+    tables = [(sha_stark, t, pis), (sink_stark, sink_t, sink_pis)]
+    proofs, shared = stark_bus.prove_tables(ctx, tables)
+    expect, shared_o = oracle_lib.stark_prove_tables(oracle, tables)
+    assert (shared == shared_o).all()
+    assert proofs[0] == expect[0] and proofs[1] == expect[1]
+    sums = stark_bus.verify_bus([(sha_stark, pis), (sink_stark, sink_pis)], proofs)
+    assert (int(sums[0][0]) + int(sums[1][0])) % P == 0 and int(sums[0][0]) != 0
+    other_sink, other_t, other_pis = sha.make_sink(5, digests[:-1] + [hashlib.sha256(b"x").digest()], **cfg)
+    proofs2, _ = stark_bus.prove_tables(ctx, [(sha_stark, t, pis), (other_sink, other_t, other_pis)])
+    with pytest.raises(vx.VxError):
+        stark_bus.verify_bus([(sha_stark, pis), (other_sink, other_pis)], proofs2)          # valid proofs, unbalanced bus
+    with pytest.raises(vx.VxError):
+        stark_bus.verify_tables([(sha_stark, pis), (sink_stark, sink_pis)], [proofs2[0], proofs[1]])   # a proof from another bus

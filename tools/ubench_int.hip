@@ -195,6 +195,94 @@ __device__ __forceinline__ u64 gl_mul_nc_v2(u64 a, u64 b) {
 }
 // (A "v3" with the schoolbook (x >> 32) addends expressed as register pairs overlapping the previous product's high half
 // — 11 instructions — does not assemble: gfx950 requires 64-bit VGPR tuples to be even-aligned.)
+
+// ---- round 3 experiment: THREE independent multiply-reduces interleaved instruction by instruction in ONE asm
+// block.  Stream A keeps its adjacent carries in VCC (as gl_mul_nc_v2); streams B and C carry through their own SGPR pairs
+// (VOP3 forms), which is legal here because an SGPR written by a VALU instruction may be read by a VALU instruction only two
+// issue slots later (gfx940+ hazard) — and in the interleaved order the consumer of a B carry sits exactly two slots after
+// its producer (one A and one C instruction in between).  Fixed temporaries: A v[100:105], B v[106:111], C v[112:117] (+ one
+// output-side pair each: v[118:123]); SGPRs s[40:63].
+#define MUL3_LINE_A(x) x "\n"
+__device__ __forceinline__ void gl_mul_nc_x3(u64 a0, u64 b0, u64 a1, u64 b1, u64 a2, u64 b2, u64& r0, u64& r1, u64& r2) {
+  asm(// p00
+      "v_mad_u64_u32 v[100:101], vcc, %[a0l], %[b0l], 0\n"
+      "v_mad_u64_u32 v[106:107], s[48:49], %[a1l], %[b1l], 0\n"
+      "v_mad_u64_u32 v[112:113], s[56:57], %[a2l], %[b2l], 0\n"
+      // p01
+      "v_mad_u64_u32 v[102:103], vcc, %[a0l], %[b0h], 0\n"
+      "v_mad_u64_u32 v[108:109], s[48:49], %[a1l], %[b1h], 0\n"
+      "v_mad_u64_u32 v[114:115], s[56:57], %[a2l], %[b2h], 0\n"
+      // p11
+      "v_mad_u64_u32 v[104:105], vcc, %[a0h], %[b0h], 0\n"
+      "v_mad_u64_u32 v[110:111], s[48:49], %[a1h], %[b1h], 0\n"
+      "v_mad_u64_u32 v[116:117], s[56:57], %[a2h], %[b2h], 0\n"
+      // p10 = a1 b0 + p01, carry cM
+      "v_mad_u64_u32 v[102:103], s[40:41], %[a0h], %[b0l], v[102:103]\n"
+      "v_mad_u64_u32 v[108:109], s[50:51], %[a1h], %[b1l], v[108:109]\n"
+      "v_mad_u64_u32 v[114:115], s[58:59], %[a2h], %[b2l], v[114:115]\n"
+      // lo64.hi = p00.hi + p10.lo
+      "v_add_co_u32_e64 v101, s[42:43], v101, v102\n"
+      "v_add_co_u32_e64 v107, s[52:53], v107, v108\n"
+      "v_add_co_u32_e64 v113, s[60:61], v113, v114\n"
+      // hl
+      "v_addc_co_u32_e64 v104, s[42:43], v104, v103, s[42:43]\n"
+      "v_addc_co_u32_e64 v110, s[52:53], v110, v109, s[52:53]\n"
+      "v_addc_co_u32_e64 v116, s[60:61], v116, v115, s[60:61]\n"
+      // hh
+      "v_addc_co_u32_e64 v105, s[42:43], 0, v105, s[42:43]\n"
+      "v_addc_co_u32_e64 v111, s[52:53], 0, v111, s[52:53]\n"
+      "v_addc_co_u32_e64 v117, s[60:61], 0, v117, s[60:61]\n"
+      // T = hl * EPS + lo64, carry cT
+      "v_mad_u64_u32 v[100:101], s[44:45], v104, -1, v[100:101]\n"
+      "v_mad_u64_u32 v[106:107], s[54:55], v110, -1, v[106:107]\n"
+      "v_mad_u64_u32 v[112:113], s[62:63], v116, -1, v[112:113]\n"
+      // u = T - hh - cM
+      "v_subb_co_u32_e64 v100, s[40:41], v100, v105, s[40:41]\n"
+      "v_subb_co_u32_e64 v106, s[50:51], v106, v111, s[50:51]\n"
+      "v_subb_co_u32_e64 v112, s[58:59], v112, v117, s[58:59]\n"
+      "v_subbrev_co_u32_e64 v101, s[40:41], 0, v101, s[40:41]\n"
+      "v_subbrev_co_u32_e64 v107, s[50:51], 0, v107, s[50:51]\n"
+      "v_subbrev_co_u32_e64 v113, s[58:59], 0, v113, s[58:59]\n"
+      // masks: m1 = cT & ~bw (+EPS), m2 = bw & ~cT (-EPS)
+      "s_andn2_b64 s[42:43], s[44:45], s[40:41]\n"
+      "s_andn2_b64 s[40:41], s[40:41], s[44:45]\n"
+      "s_andn2_b64 s[52:53], s[54:55], s[50:51]\n"
+      "s_andn2_b64 s[50:51], s[50:51], s[54:55]\n"
+      "s_andn2_b64 s[60:61], s[62:63], s[58:59]\n"
+      "s_andn2_b64 s[58:59], s[58:59], s[62:63]\n"
+      "v_cndmask_b32_e64 v118, 0, -1, s[42:43]\n"
+      "v_cndmask_b32_e64 v120, 0, -1, s[52:53]\n"
+      "v_cndmask_b32_e64 v122, 0, -1, s[60:61]\n"
+      "v_cndmask_b32_e64 v119, 0, -1, s[40:41]\n"
+      "v_cndmask_b32_e64 v121, 0, -1, s[50:51]\n"
+      "v_cndmask_b32_e64 v123, 0, -1, s[58:59]\n"
+      "v_cndmask_b32_e64 v118, v118, 1, s[40:41]\n"
+      "v_cndmask_b32_e64 v120, v120, 1, s[50:51]\n"
+      "v_cndmask_b32_e64 v122, v122, 1, s[58:59]\n"
+      "v_lshl_add_u64 %[r0], v[100:101], 0, v[118:119]\n"
+      "v_lshl_add_u64 %[r1], v[106:107], 0, v[120:121]\n"
+      "v_lshl_add_u64 %[r2], v[112:113], 0, v[122:123]\n"
+      : [r0] "=&v"(r0), [r1] "=&v"(r1), [r2] "=v"(r2)
+      : [a0l] "v"((u32)a0), [a0h] "v"((u32)(a0 >> 32)), [b0l] "v"((u32)b0), [b0h] "v"((u32)(b0 >> 32)), [a1l] "v"((u32)a1), [a1h] "v"((u32)(a1 >> 32)),
+        [b1l] "v"((u32)b1), [b1h] "v"((u32)(b1 >> 32)), [a2l] "v"((u32)a2), [a2h] "v"((u32)(a2 >> 32)), [b2l] "v"((u32)b2), [b2h] "v"((u32)(b2 >> 32))
+      : "vcc", "scc", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116",
+        "v117", "v118", "v119", "v120", "v121", "v122", "v123", "s40", "s41", "s42", "s43", "s44", "s45", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55",
+        "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63");
+}
+GLD void poseidon_sbox_x3(u64& x, u64& y, u64& z) {
+  u64 x2, y2, z2, x4, y4, z4, x3, y3, z3;
+  gl_mul_nc_x3(x, x, y, y, z, z, x2, y2, z2);
+  gl_mul_nc_x3(x2, x2, y2, y2, z2, z2, x4, y4, z4);
+  gl_mul_nc_x3(x, x2, y, y2, z, z2, x3, y3, z3);
+  gl_mul_nc_x3(x3, x4, y3, y4, z3, z4, x, y, z);
+}
+__global__ void k_check_mul3(const u64* a, const u64* b, u64* out, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (3 * i + 2 >= n) return;
+  u64 r0, r1, r2;
+  gl_mul_nc_x3(a[3 * i], b[3 * i], a[3 * i + 1], b[3 * i + 1], a[3 * i + 2], b[3 * i + 2], r0, r1, r2);
+  out[3 * i] = gl_canon(r0), out[3 * i + 1] = gl_canon(r1), out[3 * i + 2] = gl_canon(r2);
+}
 GLD u64 poseidon_sbox_nc_v2(u64 x) {
   const u64 x2 = gl_mul_nc_v2(x, x), x4 = gl_mul_nc_v2(x2, x2), x3 = gl_mul_nc_v2(x, x2);
   return gl_mul_nc_v2(x3, x4);
@@ -207,7 +295,7 @@ __global__ void k_check_mul(const u64* a, const u64* b, u64* out_ref, u64* out_v
 }
 
 // ---- real sequences from the product headers ------------------------------------------------------------------
-enum Seq { SEQ_MUL, SEQ_SBOX, SEQ_MDS, SEQ_PERM, SEQ_ADD_NC, SEQ_MUL_V2, SEQ_SBOX_V2, SEQ_MUL_V3, SEQ_SBOX_V3, SEQ_MDS_RC, SEQ_BLOCK3, NUM_SEQS };
+enum Seq { SEQ_MUL, SEQ_SBOX, SEQ_MDS, SEQ_PERM, SEQ_ADD_NC, SEQ_MUL_V2, SEQ_SBOX_V2, SEQ_MUL_V3, SEQ_SBOX_V3, SEQ_MDS_RC, SEQ_BLOCK3, SEQ_MUL_X3, SEQ_SBOX_X3, SEQ_SBOX_FX, NUM_SEQS };
 template <int SEQ>
 __global__ __launch_bounds__(256, 4) void k_seq(WaveStamp* stamps, uint64_t* sink, int iters, uint64_t seed) {
   u64 s[12];
@@ -230,6 +318,18 @@ __global__ __launch_bounds__(256, 4) void k_seq(WaveStamp* stamps, uint64_t* sin
     if (SEQ == SEQ_SBOX_V2) {
 #pragma unroll
       for (int i = 0; i < 12; ++i) s[i] = poseidon_sbox_nc_v2(s[i]);
+    }
+    if (SEQ == SEQ_MUL_X3) {
+#pragma unroll
+      for (int i = 0; i < 12; i += 3) gl_mul_nc_x3(s[i], s[(i + 5) % 12], s[i + 1], s[(i + 6) % 12], s[i + 2], s[(i + 7) % 12], s[i], s[i + 1], s[i + 2]);
+    }
+    if (SEQ == SEQ_SBOX_X3) {
+#pragma unroll
+      for (int i = 0; i < 12; i += 3) poseidon_sbox_x3(s[i], s[i + 1], s[i + 2]);
+    }
+    if (SEQ == SEQ_SBOX_FX) {
+#pragma unroll
+      for (int i = 0; i < 12; ++i) s[i] = poseidon_sbox_fx(s[i]);
     }
     if (SEQ == SEQ_MDS_RC) poseidon_mds_rc_nc(s, it & 15);
     if (SEQ == SEQ_BLOCK3) poseidon_partial_block_nc<POSEIDON_BLOCK_B>(s, POSEIDON_BLK.kappa[it & 3], POSEIDON_BLK.K[it & 3]);
@@ -337,6 +437,35 @@ void run_seq(const char* name, double units_per_iter, int iters, const char* uni
   fflush(stdout);
 }
 
+static int check_mul_x3() {
+  const size_t n = 3 << 18;
+  std::vector<u64> a(n), b(n), r(n);
+  u64 x = 0x13198A2E03707344ull;
+  auto next = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+  const u64 edge[] = {0, 1, GL_P - 1, GL_P, GL_P + 1, ~0ull, 0xFFFFFFFFull, 0x100000000ull, 0xFFFFFFFF00000000ull, 0x8000000000000000ull, GL_EPS - 1, 0xFFFFFFFEFFFFFFFFull};
+  const int ne = sizeof(edge) / sizeof(edge[0]);
+  for (size_t i = 0; i < n; ++i) {
+    a[i] = next();
+    b[i] = next();
+    if (i < (size_t)ne * ne) { a[i] = edge[i / ne]; b[i] = edge[i % ne]; }
+  }
+  u64 *da, *db, *d0;
+  hipMalloc(&da, n * 8); hipMalloc(&db, n * 8); hipMalloc(&d0, n * 8);
+  hipMemcpy(da, a.data(), n * 8, hipMemcpyHostToDevice);
+  hipMemcpy(db, b.data(), n * 8, hipMemcpyHostToDevice);
+  hipLaunchKernelGGL(k_check_mul3, dim3((n / 3 + 255) / 256), dim3(256), 0, 0, da, db, d0, n);
+  hipMemcpy(r.data(), d0, n * 8, hipMemcpyDeviceToHost);
+  size_t bad = 0;
+  for (size_t i = 0; i < n; ++i) {
+    const unsigned __int128 P = (unsigned __int128)a[i] * b[i];
+    if (r[i] != (u64)(P % GL_P)) ++bad;
+  }
+  printf("gl_mul_nc_x3 (three multiplies interleaved in one asm block: stream A on VCC, B and C on their own SGPR carry pairs, consumer two issue slots "
+         "after its producer) vs 128-bit host arithmetic on %zu operand pairs incl. %d edge pairs: %zu mismatches\n\n", n, ne * ne, bad);
+  hipFree(da); hipFree(db); hipFree(d0);
+  return bad != 0;
+}
+
 static int check_mul_v2() {
   const size_t n = 1 << 20;
   std::vector<u64> a(n), b(n), r0(n), r1(n);
@@ -413,6 +542,7 @@ int main() {
   run_op<28>("v_mad_u64_u32 ; v_add_u32_e32 alternating (per VALU)", 64);
   run_op<29>("v_mad_u64_u32 ; v_add_u32 ; v_and_b32 (per VALU)", 96);
   if (check_mul_v2()) printf("**gl_mul_nc_v2 IS WRONG**\n");
+  if (check_mul_x3()) printf("**gl_mul_nc_x3 IS WRONG**\n");
   printf("## real sequences (vectorx_amd/csrc as hipcc compiles them, hazard nops included): shader cycles per unit per SIMD\n\n");
   printf("| sequence (unit) | W=1 | W=2 | W=3 | W=4 | GHz | lane-units/s (W=4) | cycles/unit/SIMD from wall time |\n|---|---|---|---|---|---|---|---|\n");
   run_seq<SEQ_ADD_NC>("gl_add_nc_c (per add, wave-wide)", 12, 2048, "adds");
@@ -422,6 +552,9 @@ int main() {
   run_seq<SEQ_MDS_RC>("poseidon_mds_rc_nc, constants folded (per 12x12 layer)", 1, 1024, "layers");
   run_seq<SEQ_BLOCK3>("poseidon_partial_block_nc<4> (per block of 4 partial rounds)", 1, 512, "blocks");
   run_seq<SEQ_SBOX_V2>("x^7 on gl_mul_nc_v2 (per S-box)", 12, 512, "sboxes");
+  run_seq<SEQ_SBOX_FX>("x^7 on gl_mul_nc_fx = the product's S-box (per S-box)", 12, 512, "sboxes");
+  run_seq<SEQ_MUL_X3>("gl_mul_nc_x3 = 3 multiplies interleaved in one asm block (per multiply)", 12, 1024, "muls");
+  run_seq<SEQ_SBOX_X3>("x^7 on gl_mul_nc_x3, three lanes at a time (per S-box)", 12, 512, "sboxes");
   run_seq<SEQ_MDS>("poseidon_mds_nc (per 12x12 layer)", 1, 1024, "layers");
   run_seq<SEQ_PERM>("poseidon_permute_nc (per permutation)", 1, 64, "perms");
   return 0;

@@ -108,6 +108,12 @@ _SIGNATURES = {
     "vx_stark_begin": (_i, [_vp, _vp, _vp, _i, _vp, _vp, ctypes.POINTER(_vp)]),
     "vx_stark_finish": (_i, [_vp, _vp, _i, _vp, _vp, ctypes.POINTER(_sz)]),
     "vx_stark_session_free": (None, [_vp]),
+    "vx_stark_session_trace_cap": (_i, [_vp, _vp]),
+    "vx_stark_set_aux_challenges": (_i, [_vp, _vp]),
+    "vx_stark_finish2": (_i, [_vp, _vp, _i, _vp, _vp, _vp, ctypes.POINTER(_sz)]),
+    "vx_stark_joint_challenges": (_i, [_vp, _vp, _i, _i, _vp]),
+    "vx_stark_proof_trace_cap": (_i, [_vp, _vp, _sz, _vp]),
+    "vx_stark_verify_shared": (_i, [_vp, _vp, _vp, _sz, _vp, _vp]),
     "vx_circuit_program_gates": (_i, [_vp, ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.c_char_p, _sz]),
     "vx_prove_sharded": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, ctypes.POINTER(_sz)]),
     "vx_group_create": (_i, [_i, ctypes.POINTER(_vp)]),
@@ -116,6 +122,7 @@ _SIGNATURES = {
     "vx_group_peer_staged": (_i, [_vp]),
     "vx_group_allgather": (_i, [_vp, _vp, _sz]),
     "vx_group_abort": (None, [_vp]),
+    "vx_group_set_timeout_ms": (_i, [_vp, ctypes.c_longlong]),
 }
 # vx_allgather_fn: int (*)(void* user, void* dev_buf, size_t bytes_per_rank)
 ALLGATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t)
@@ -407,7 +414,7 @@ class StarkDesc(ctypes.Structure):
                 ("num_query_rounds", ctypes.c_int32), ("num_challenges", ctypes.c_int32), ("constraint_degree", ctypes.c_int32),
                 ("program_len", ctypes.c_int32), ("program", ctypes.c_void_p), ("override_flags", ctypes.c_uint32),
                 ("num_fri_reduction_arity_bits", ctypes.c_int32), ("fri_reduction_arity_bits", ctypes.c_void_p),
-                ("num_aux_columns", ctypes.c_int32), ("num_aux_challenges", ctypes.c_int32)]
+                ("num_aux_columns", ctypes.c_int32), ("num_aux_challenges", ctypes.c_int32), ("num_aux_public_inputs", ctypes.c_int32)]
 
 
 VX_OP_END, VX_OP_LDW, VX_OP_LDC, VX_OP_LDI, VX_OP_ADD, VX_OP_SUB, VX_OP_MUL, VX_OP_PUSH, VX_OP_LDP, VX_OP_LDN, VX_OP_LDCH = range(11)
@@ -424,13 +431,15 @@ class Stark:
     StarkConfig::standard_fast_config (rate_bits 1, cap_height 4, 16 PoW bits, 84 queries, 2 challenges)."""
 
     def __init__(self, degree_bits, num_columns, num_public_inputs, program, constraint_degree, rate_bits=1, cap_height=4, pow_bits=16,
-                 num_query_rounds=84, num_challenges=2, fri_arities=None, num_aux_columns=0, num_aux_challenges=0, aux_fn=None):
+                 num_query_rounds=84, num_challenges=2, fri_arities=None, num_aux_columns=0, num_aux_challenges=0, aux_fn=None,
+                 num_aux_public_inputs=0):
         """`num_aux_columns` / `num_aux_challenges` / `aux_fn`: a second commitment round — `aux_fn(trace, challenges)` returns the
-        [num_aux_columns][n] columns the caller computes between `vx_stark_begin` and `vx_stark_finish`."""
+        [num_aux_columns][n] columns the caller computes between `vx_stark_begin` and `vx_stark_finish`; with
+        `num_aux_public_inputs` > 0 (closing sums of a bus / lookup accumulator) it returns `(columns, aux_public_inputs)`."""
         self._prog = (ctypes.c_uint64 * len(program))(*program)
         self.desc = StarkDesc(degree_bits, num_columns, num_public_inputs, rate_bits, cap_height, pow_bits, num_query_rounds, num_challenges,
                               constraint_degree, len(program), ctypes.cast(self._prog, ctypes.c_void_p).value, 0, 0, None,
-                              num_aux_columns, num_aux_challenges)
+                              num_aux_columns, num_aux_challenges, num_aux_public_inputs)
         self.aux_fn = aux_fn
         if fri_arities is not None:
             self._ar = (ctypes.c_int32 * max(1, len(fri_arities)))(*fri_arities)
@@ -439,40 +448,91 @@ class Stark:
             self.desc.fri_reduction_arity_bits = ctypes.cast(self._ar, ctypes.c_void_p).value
         self.desc_ptr = ctypes.pointer(self.desc)
 
-    def prove(self, ctx, trace, public_inputs, pow_witness=None) -> bytes:
-        """`vx_stark_prove`: trace [num_columns][2^degree_bits] (host) -> proof bytes"""
+    def run_aux(self, trace, challenges):
+        """-> (aux columns [num_aux_columns][n] uint64, aux public inputs [num_aux_public_inputs] uint64)"""
+        r = self.aux_fn(trace, challenges)
+        cols, api = r if isinstance(r, tuple) else (r, np.zeros(0, dtype=np.uint64))
+        cols, api = _as_u64(cols), np.ascontiguousarray(api, dtype=np.uint64).reshape(-1)
+        if cols.shape != (self.desc.num_aux_columns, 1 << self.desc.degree_bits) or api.size != self.desc.num_aux_public_inputs:
+            raise VxError(VX_E_INVALID, f"aux columns have shape {cols.shape}, {api.size} aux public inputs")
+        return cols, api
+
+    # ---- two-round / multi-table building blocks (the pieces `prove` and vectorx_amd.stark_bus are made of) ----
+    def begin(self, ctx, trace, public_inputs):
+        """`vx_stark_begin` -> (session handle, the table's own aux challenges, trace as contiguous uint64)"""
         t = _as_u64(trace)
         if t.shape != (self.desc.num_columns, 1 << self.desc.degree_bits):
             raise VxError(VX_E_INVALID, f"trace has shape {t.shape}")
         pi = _as_u64(public_inputs)
-        cap = 1 << 24
-        out = np.empty(cap, dtype=np.uint8)
-        n = _sz(cap)
-        hint = None
-        if pow_witness is not None:
-            hint = ctypes.c_uint64(pow_witness)
-        hint_p = None if hint is None else ctypes.cast(ctypes.pointer(hint), _vp)
-        if self.desc.num_aux_columns == 0:
-            _chk(lib().vx_stark_prove(ctx._h, ctypes.cast(self.desc_ptr, _vp), t.ctypes.data, 0, pi.ctypes.data, hint_p, out.ctypes.data, ctypes.byref(n)))
-            return out[:n.value].tobytes()
-        # two rounds: commit the trace, get the challenges, compute the aux columns, finish
         chal = np.zeros(max(1, self.desc.num_aux_challenges), dtype=np.uint64)
         sess = _vp()
         _chk(lib().vx_stark_begin(ctx._h, ctypes.cast(self.desc_ptr, _vp), t.ctypes.data, 0, pi.ctypes.data, chal.ctypes.data, ctypes.byref(sess)))
-        try:
-            aux = _as_u64(self.aux_fn(t, chal[:self.desc.num_aux_challenges]))
-            if aux.shape != (self.desc.num_aux_columns, 1 << self.desc.degree_bits):
-                raise VxError(VX_E_INVALID, f"aux columns have shape {aux.shape}")
-            _chk(lib().vx_stark_finish(sess, aux.ctypes.data, 0, hint_p, out.ctypes.data, ctypes.byref(n)))
-        finally:
-            lib().vx_stark_session_free(sess)
+        return sess, chal[:self.desc.num_aux_challenges].copy(), t
+
+    def session_trace_cap(self, sess) -> np.ndarray:
+        cap = np.zeros((1 << self.desc.cap_height, 4), dtype=np.uint64)
+        _chk(lib().vx_stark_session_trace_cap(sess, cap.ctypes.data))
+        return cap
+
+    def finish(self, sess, aux, aux_public_inputs=None, pow_witness=None) -> bytes:
+        cap = 1 << 25
+        out = np.empty(cap, dtype=np.uint8)
+        n = _sz(cap)
+        hint = ctypes.c_uint64(pow_witness) if pow_witness is not None else None
+        hint_p = None if hint is None else ctypes.cast(ctypes.pointer(hint), _vp)
+        api = None if aux_public_inputs is None or len(aux_public_inputs) == 0 else np.ascontiguousarray(aux_public_inputs, dtype=np.uint64)
+        _chk(lib().vx_stark_finish2(sess, aux.ctypes.data, 0, None if api is None else api.ctypes.data, hint_p, out.ctypes.data, ctypes.byref(n)))
         return out[:n.value].tobytes()
 
-    def verify(self, public_inputs, proof: bytes):
-        """`vx_stark_verify` (host): raises VxError(VX_E_PROOF, reason) when the proof is not valid."""
+    def prove(self, ctx, trace, public_inputs, pow_witness=None) -> bytes:
+        """`vx_stark_prove`: trace [num_columns][2^degree_bits] (host) -> proof bytes"""
+        if self.desc.num_aux_columns == 0:
+            t = _as_u64(trace)
+            if t.shape != (self.desc.num_columns, 1 << self.desc.degree_bits):
+                raise VxError(VX_E_INVALID, f"trace has shape {t.shape}")
+            pi = _as_u64(public_inputs)
+            cap = 1 << 24
+            out = np.empty(cap, dtype=np.uint8)
+            n = _sz(cap)
+            hint = ctypes.c_uint64(pow_witness) if pow_witness is not None else None
+            hint_p = None if hint is None else ctypes.cast(ctypes.pointer(hint), _vp)
+            _chk(lib().vx_stark_prove(ctx._h, ctypes.cast(self.desc_ptr, _vp), t.ctypes.data, 0, pi.ctypes.data, hint_p, out.ctypes.data, ctypes.byref(n)))
+            return out[:n.value].tobytes()
+        # two rounds: commit the trace, get the challenges, compute the aux columns (and closing sums), finish
+        sess, chal, t = self.begin(ctx, trace, public_inputs)
+        try:
+            aux, api = self.run_aux(t, chal)
+            return self.finish(sess, aux, api, pow_witness)
+        finally:
+            lib().vx_stark_session_free(sess)
+
+    def verify(self, public_inputs, proof: bytes, shared_challenges=None):
+        """`vx_stark_verify` (host): raises VxError(VX_E_PROOF, reason) when the proof is not valid; returns the proof's aux
+        public inputs (closing sums).  `shared_challenges`: the joint challenges of a cross-table argument."""
         pi = _as_u64(public_inputs)
         buf = np.frombuffer(proof, dtype=np.uint8)
-        _chk(lib().vx_stark_verify(ctypes.cast(self.desc_ptr, _vp), pi.ctypes.data, buf.ctypes.data if buf.size else None, buf.size))
+        api = np.zeros(max(1, self.desc.num_aux_public_inputs), dtype=np.uint64)
+        sh = None if shared_challenges is None else np.ascontiguousarray(shared_challenges, dtype=np.uint64)
+        _chk(lib().vx_stark_verify_shared(ctypes.cast(self.desc_ptr, _vp), pi.ctypes.data, buf.ctypes.data if buf.size else None, buf.size,
+                                          None if sh is None else sh.ctypes.data, api.ctypes.data))
+        return api[:self.desc.num_aux_public_inputs].copy()
+
+    def proof_trace_cap(self, proof: bytes) -> np.ndarray:
+        cap = np.zeros((1 << self.desc.cap_height, 4), dtype=np.uint64)
+        buf = np.frombuffer(proof, dtype=np.uint8)
+        _chk(lib().vx_stark_proof_trace_cap(ctypes.cast(self.desc_ptr, _vp), buf.ctypes.data, buf.size, cap.ctypes.data))
+        return cap
+
+
+def stark_joint_challenges(caps, cap_heights, n: int) -> np.ndarray:
+    """`vx_stark_joint_challenges`: the challenges of a cross-table argument, from every table's trace cap (table order matters)."""
+    arr = (ctypes.c_void_p * len(caps))(*[np.ascontiguousarray(c, dtype=np.uint64).ctypes.data for c in caps])
+    keep = [np.ascontiguousarray(c, dtype=np.uint64) for c in caps]
+    arr = (ctypes.c_void_p * len(caps))(*[k.ctypes.data for k in keep])
+    hs = (ctypes.c_int32 * len(caps))(*cap_heights)
+    out = np.zeros(n, dtype=np.uint64)
+    _chk(lib().vx_stark_joint_challenges(ctypes.cast(arr, _vp), ctypes.cast(hs, _vp), len(caps), n, out.ctypes.data))
+    return out
 
 
 def circuit_serialize(desc_ptr, constants_sigmas_cap=None, with_preprocessed=True) -> bytes:

@@ -189,7 +189,19 @@ GLD void acc_push(AlphaAcc& a, const QuotientParams& p, u64 term) {
 #ifndef VX_QUOTIENT_BLOCKS
 #define VX_QUOTIENT_BLOCKS 5
 #endif
-__global__ __launch_bounds__(256, VX_QUOTIENT_BLOCKS) void quotient_kernel(QuotientParams p) {
+#ifndef VX_QUOTIENT_PERM_BLOCKS
+#define VX_QUOTIENT_PERM_BLOCKS 8
+#endif
+// Two launches per quotient (round 3): the vanishing polynomial is a sum, and its two halves want different machines.
+//   PART 0  L_0 (Z - 1) and the partial-product checks: 640 multiplications per row on 80 wires + 80 sigmas + 20 Z columns —
+//           a long stream of loads with a small live state (two running products), so it runs at 8 blocks per CU and hides
+//           its memory latency behind other waves;  writes  out = A / Z_H.
+//   PART 1  the gate constraints (the PoseidonGate's ~19 k instructions on a 12-lane state): register-bound, 5 blocks per CU;
+//           adds  G / Z_H  to out.
+// Fused (rounds 1-2) the kernel sat at 96 VGPRs with 81 spilled values and the VALU busy 82 % of the time
+// (profiles/r03_pmc_sq_prove.md: 4.88 cycles per instruction against 3.98 for the hash kernel).
+template <int PART>
+__global__ __launch_bounds__(256, PART == 0 ? VX_QUOTIENT_PERM_BLOCKS : VX_QUOTIENT_BLOCKS) void quotient_kernel(QuotientParams p) {
   const size_t il = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (il >= p.rows) return;
   const size_t N = p.N, SW = p.stride_w, i = il + p.row_base;
@@ -197,19 +209,19 @@ __global__ __launch_bounds__(256, VX_QUOTIENT_BLOCKS) void quotient_kernel(Quoti
   const u32 nmask = (1u << log_n) - 1;
   const u32 z = (u32)(i >> log_n);
   const u32 r = bitrev32(z, rb);
+#define CS(c) (p.cs[(size_t)(c) * N + i])
+#define WIRE(c) (p.wires[(size_t)(c) * SW + il])
+#define ZS(c) (p.zs[(size_t)(c) * SW + il])
+  const u64 zi = p.zh_inv[r];
+  if constexpr (PART == 0) {
   const u32 k = bitrev32((u32)i & nmask, log_n);
   const u32 j = (k << rb) | r;  // natural LDE index
   const size_t il_next = (((size_t)z << log_n) | bitrev32((k + 1) & nmask, log_n)) - p.row_base;  // same coset: local
   const u64 x = gl_mul7(root_pow24(p.root_lo, p.root_hi, j << (ROOT_TABLE_LOG - log_n - rb)));
-#define CS(c) (p.cs[(size_t)(c) * N + i])
-#define WIRE(c) (p.wires[(size_t)(c) * SW + il])
-#define ZS(c) (p.zs[(size_t)(c) * SW + il])
-
   AlphaAcc A;
 #pragma unroll
   for (int c = 0; c < VX_MAX_CHALLENGES; ++c) A.acc[c] = dot3{0, 0, 0};
   A.idx = 0;
-  u64 gates_sum[VX_MAX_CHALLENGES] = {0, 0};  // sum_g filter_g * (the gate's alpha-weighted constraints)
 
   // (1) L_0(x) (Z(x) - 1) per challenge;  eval_l_0 = Z_H(x) / (n (x - 1))
   const u64 l0 = gl_mul(p.zh[r], gl_inv(gl_mul(p.n_field, gl_sub(x, 1))));
@@ -233,8 +245,11 @@ __global__ __launch_bounds__(256, VX_QUOTIENT_BLOCKS) void quotient_kernel(Quoti
       prev = next;
     }
   }
+  for (int ch = 0; ch < p.nch; ++ch) p.out[(size_t)ch * SW + il] = gl_mul(gl_canon(dot3_reduce_nc(A.acc[ch])), zi);
+  } else {
+  u64 gates_sum[VX_MAX_CHALLENGES] = {0, 0};  // sum_g filter_g * (the gate's alpha-weighted constraints)
   // (3) gate constraints: sum_g filter_g * sum_i c_{g,i} alpha^(i + offset)
-  const int base_idx = A.idx + p.extra_terms;
+  const int base_idx = p.nch * (2 + p.npp) + p.extra_terms;   // after the L_0 terms, the partial-product checks and the lookup terms
   for (int g = 0; g < p.num_gates; ++g) {
     const GateDev gd = p.gates[g];
     if (gd.type == 0 || gd.type >= 5) continue;  // NoopGate / lookup gates: no constraints; program gates: program_gates_kernel
@@ -335,8 +350,11 @@ __global__ __launch_bounds__(256, VX_QUOTIENT_BLOCKS) void quotient_kernel(Quoti
 #pragma unroll
     for (int c = 0; c < VX_MAX_CHALLENGES; ++c) gates_sum[c] = gl_mad(filter, dot3_reduce_nc(G.acc[c]), gates_sum[c]);
   }
-  const u64 zi = p.zh_inv[r];
-  for (int ch = 0; ch < p.nch; ++ch) p.out[(size_t)ch * SW + il] = gl_mul(gl_add(gl_canon(dot3_reduce_nc(A.acc[ch])), gates_sum[ch]), zi);
+  for (int ch = 0; ch < p.nch; ++ch) {
+    u64* o = p.out + (size_t)ch * SW + il;
+    *o = gl_add(*o, gl_mul(gates_sum[ch], zi));
+  }
+  }
 #undef CS
 #undef WIRE
 #undef ZS

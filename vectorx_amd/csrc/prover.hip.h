@@ -5,6 +5,7 @@
 // Everything heavy is a kernel launch on the context's stream; the host keeps only the Fiat-Shamir
 // transcript (a few hundred field elements per proof) and the proof assembly.
 #pragma once
+#include <chrono>
 #include "batch.hip.h"
 #include "challenger.h"
 #include "plonk_kernels.hip.h"
@@ -235,7 +236,12 @@ static int shard_allgather(vx_ctx* c, const Shard& sh, void* dev, size_t bytes_p
   HIPCHK(hipStreamSynchronize(c->stream));
   static const bool trace = getenv("VX_TRACE_EXCHANGES") != nullptr;  // one line per exchange: which rank waits for what
   if (trace) fprintf(stderr, "[vx rank %d/%d] all-gather: %s, %zu bytes per rank\n", sh.rank, sh.world, what, bytes_per_rank);
+  const auto t0 = std::chrono::steady_clock::now();
   int rc = sh.fn(sh.user, dev, bytes_per_rank);
+  // host wall time of the exchange INCLUDING the wait for the slowest rank — its own stage ("exchange_host_wait"), so that
+  // the HIP-event stages around it are compute only (query_gather looked 60x slower sharded)
+  c->prof_add_host("exchange_host_wait", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(),
+                   (double)bytes_per_rank * (sh.world - 1));
   if (trace) fprintf(stderr, "[vx rank %d/%d] all-gather done: %s (rc %d)\n", sh.rank, sh.world, what, rc);
   if (rc) return vx_fail(VX_E_COMM, "prove: all-gather of %s failed on rank %d (callback returned %d)", what, sh.rank, rc);
   return VX_OK;
@@ -547,44 +553,62 @@ static int fri_prove_openings(vx_ctx* c, const FriProverParams& fpp, const std::
         }
       }
       HIPCHK(hipMemcpyAsync(d_idx, idx_host.data(), idx_host.size() * 8, hipMemcpyHostToDevice, c->stream));
-      std::vector<u64*> pending_dev;
-      std::vector<std::vector<u64>*> pending_host;
+      // Every sharded tree (the oracles' and the first FRI layer's) is opened by the rank that owns the leaf; ALL those rows
+      // travel in ONE all-gather: slot s of `d_sh` = [oracle 0 rows | oracle 1 rows | .. | FRI layer 0 rows] of rank s
+      // (round 2 did one exchange per tree: 5 barriers where 1 does).  Unsharded trees are gathered into `d_un`.
+      struct Piece { size_t rowlen, off; bool sharded; std::vector<u64>* host; };
+      std::vector<Piece> pieces;
+      size_t per_rank = 0, unsharded = 0;
       for (size_t o = 0; o < oracles.size(); ++o) {
         const bool sharded = oracles[o]->shard_lg > 0;
-        const size_t rowlen = oracles[o]->ncols + 4 * (size_t)depth0, slots = sharded ? sh.world : 1;
-        u64* d_out = S.get(rowlen * nq * slots);
-        if (!d_out) return vx_fail(VX_E_NOMEM, "prove: out of device memory (queries)");
-        const size_t rows_o = oracles[o]->rows();
-        hipLaunchKernelGGL(gather_open_kernel, dim3(nq), dim3(128), 0, c->stream, oracles[o]->lde, rows_o, (int)oracles[o]->ncols, 1,
-                           oracles[o]->tree, rows_o, depth0, sharded ? d_idx + (R + 1) * nq : d_idx,
-                           d_out + (sharded ? rowlen * nq * sh.rank : 0));
-        if (sharded) VXCHK(shard_allgather(c, sh, d_out, rowlen * nq * 8, "query openings"));
-        init_out[o].resize(rowlen * nq * slots);
-        pending_dev.push_back(d_out);
-        pending_host.push_back(&init_out[o]);
+        const size_t rowlen = oracles[o]->ncols + 4 * (size_t)depth0;
+        pieces.push_back(Piece{rowlen, sharded ? per_rank : unsharded, sharded, &init_out[o]});
+        (sharded ? per_rank : unsharded) += rowlen * nq;
       }
+      std::vector<int> depth_r(R);
       for (size_t r = 0; r < R; ++r) {
         const int ab = fpp.arity_bits[r];
         const bool sharded = r == 0 && sh.world > 1;
-        const size_t leaves_all = flen[r] >> ab, leaves = sharded ? leaves_all >> sh.lg : leaves_all, slots = sharded ? sh.world : 1;
+        const size_t leaves_all = flen[r] >> ab;
         int depth = 0;
         while (((size_t)1 << (depth + fpp.cap_height)) < leaves_all) ++depth;
-        const int width = 2 << ab;
-        size_t rowlen = width + 4 * (size_t)depth;
-        u64* d_out = S.get(rowlen * nq * slots);
-        if (!d_out) return vx_fail(VX_E_NOMEM, "prove: out of device memory (queries)");
-        hipLaunchKernelGGL(gather_open_kernel, dim3(nq), dim3(128), 0, c->stream, fvals[r] + (sharded ? 2 * row_base : 0), 0, width, 0,
-                           ftrees[r], leaves, depth, sharded ? d_idx + (R + 2) * nq : d_idx + (r + 1) * nq,
-                           d_out + (sharded ? rowlen * nq * sh.rank : 0));
-        if (sharded) VXCHK(shard_allgather(c, sh, d_out, rowlen * nq * 8, "FRI query openings"));
-        step_out[r].resize(rowlen * nq * slots);
-        pending_dev.push_back(d_out);
-        pending_host.push_back(&step_out[r]);
+        depth_r[r] = depth;
+        const size_t rowlen = ((size_t)2 << ab) + 4 * (size_t)depth;
+        pieces.push_back(Piece{rowlen, sharded ? per_rank : unsharded, sharded, &step_out[r]});
+        (sharded ? per_rank : unsharded) += rowlen * nq;
       }
-      for (size_t i = 0; i < pending_dev.size(); ++i)
-        HIPCHK(hipMemcpyAsync(pending_host[i]->data(), pending_dev[i], pending_host[i]->size() * 8, hipMemcpyDeviceToHost, c->stream));
+      u64* d_sh = per_rank ? S.get(per_rank * sh.world) : nullptr;
+      u64* d_un = unsharded ? S.get(unsharded) : nullptr;
+      if ((per_rank && !d_sh) || (unsharded && !d_un)) return vx_fail(VX_E_NOMEM, "prove: out of device memory (queries)");
+      u64* my_slot = d_sh ? d_sh + per_rank * sh.rank : nullptr;
+      for (size_t o = 0; o < oracles.size(); ++o) {
+        const Piece& pc = pieces[o];
+        const size_t rows_o = oracles[o]->rows();
+        hipLaunchKernelGGL(gather_open_kernel, dim3(nq), dim3(128), 0, c->stream, oracles[o]->lde, rows_o, (int)oracles[o]->ncols, 1,
+                           oracles[o]->tree, rows_o, depth0, pc.sharded ? d_idx + (R + 1) * nq : d_idx, (pc.sharded ? my_slot : d_un) + pc.off);
+      }
+      for (size_t r = 0; r < R; ++r) {
+        const Piece& pc = pieces[oracles.size() + r];
+        const int ab = fpp.arity_bits[r];
+        const size_t leaves_all = flen[r] >> ab, leaves = pc.sharded ? leaves_all >> sh.lg : leaves_all;
+        hipLaunchKernelGGL(gather_open_kernel, dim3(nq), dim3(128), 0, c->stream, fvals[r] + (pc.sharded ? 2 * row_base : 0), 0, 2 << ab, 0,
+                           ftrees[r], leaves, depth_r[r], pc.sharded ? d_idx + (R + 2) * nq : d_idx + (r + 1) * nq,
+                           (pc.sharded ? my_slot : d_un) + pc.off);
+      }
       HIPCHK(hipGetLastError());
+      ps.end();   // the kernels; the exchange below is its own (host-clock) stage
+      if (per_rank && sh.world > 1) VXCHK(shard_allgather(c, sh, d_sh, per_rank * 8, "query openings (all sharded trees)"));
+      ProfScope ps2(c, "query_gather");
+      std::vector<u64> h_sh(per_rank * (per_rank ? sh.world : 0)), h_un(unsharded);
+      if (per_rank) HIPCHK(hipMemcpyAsync(h_sh.data(), d_sh, h_sh.size() * 8, hipMemcpyDeviceToHost, c->stream));
+      if (unsharded) HIPCHK(hipMemcpyAsync(h_un.data(), d_un, h_un.size() * 8, hipMemcpyDeviceToHost, c->stream));
       HIPCHK(hipStreamSynchronize(c->stream));
+      for (const Piece& pc : pieces) {   // the layout write_fri_proof reads: [slot][query][row] per tree
+        const size_t len = pc.rowlen * nq, slots = pc.sharded ? (size_t)sh.world : 1;
+        pc.host->resize(len * slots);
+        for (size_t sl = 0; sl < slots; ++sl)
+          memcpy(pc.host->data() + len * sl, pc.sharded ? h_sh.data() + per_rank * sl + pc.off : h_un.data() + pc.off, len * 8);
+      }
     }
     out.flen = flen;
     out.depth0 = depth0;
@@ -876,7 +900,8 @@ static int prove_impl(vx_ctx* c, vx_circuit* k, const u64* wires_in, bool wires_
       qp.out = qv;
       size_t bytes_read = 8ull * Nl * ((size_t)k->num_constants + k->nr + k->num_wires + (size_t)nch * (2 + npp));
       ProfScope ps(c, "quotient_eval", (double)bytes_read);
-      hipLaunchKernelGGL(quotient_kernel, dim3((unsigned)((Nl + 255) / 256)), dim3(256), 0, c->stream, qp);
+      hipLaunchKernelGGL(quotient_kernel<0>, dim3((unsigned)((Nl + 255) / 256)), dim3(256), 0, c->stream, qp);   // out = (L_0 + permutation terms) / Z_H
+      hipLaunchKernelGGL(quotient_kernel<1>, dim3((unsigned)((Nl + 255) / 256)), dim3(256), 0, c->stream, qp);   // out += gate terms / Z_H
       HIPCHK(hipGetLastError());
       if (k->num_luts > 0) {  // the lookup argument's terms sit between the partial-product checks and the gate constraints
         LookupParams lp;

@@ -103,6 +103,8 @@ static std::string stark_check(const vx_stark_desc* d, StarkShape* out) {
   if (d->num_aux_challenges < 0 || d->num_aux_challenges > VX_AIR_MAX_CHALLENGES) return bad("too many aux challenges", d->num_aux_challenges);
   if (d->num_aux_columns == 0 && d->num_aux_challenges != 0) return bad("aux challenges without a second commitment round", d->num_aux_challenges);
   if (d->num_public_inputs < 0 || d->num_public_inputs > VX_AIR_MAX_PI) return bad("too many public inputs", d->num_public_inputs);
+  if (d->num_aux_public_inputs < 0 || d->num_public_inputs + d->num_aux_public_inputs > VX_AIR_MAX_PI) return bad("too many aux public inputs", d->num_aux_public_inputs);
+  if (d->num_aux_public_inputs > 0 && d->num_aux_columns == 0) return bad("aux public inputs without a second commitment round", d->num_aux_public_inputs);
   if (d->num_challenges < 1 || d->num_challenges > VX_MAX_CHALLENGES) return bad("num_challenges unsupported", d->num_challenges);
   if (d->cap_height < 0 || d->cap_height > d->degree_bits + d->rate_bits) return bad("cap_height out of range", d->cap_height);
   if (d->num_query_rounds < 1 || d->num_query_rounds > 4096) return bad("num_query_rounds out of range", d->num_query_rounds);
@@ -125,7 +127,7 @@ static std::string stark_check(const vx_stark_desc* d, StarkShape* out) {
     if (op == VX_OP_LDI) { if (++pc >= d->program_len) return "stark: truncated AIR program"; }
     else if (op == VX_OP_LDW || op == VX_OP_LDN) { if (a >= d->num_columns + d->num_aux_columns) return bad("AIR program reads a column out of range", a); }
     else if (op == VX_OP_LDCH) { if (a >= d->num_aux_challenges) return bad("AIR program reads an aux challenge out of range", a); }
-    else if (op == VX_OP_LDP) { if (a >= d->num_public_inputs) return bad("AIR program reads a public input out of range", a); }
+    else if (op == VX_OP_LDP) { if (a >= d->num_public_inputs + d->num_aux_public_inputs) return bad("AIR program reads a public input out of range", a); }
     else if (op == VX_OP_ADD || op == VX_OP_SUB || op == VX_OP_MUL) { if (!is_def(a) || !is_def(b)) return "stark: AIR program reads a register before writing it"; }
     else if (op == VX_OP_PUSH) {
       if (!is_def(a)) return "stark: AIR program pushes a register before writing it";
@@ -167,7 +169,8 @@ static std::string stark_check(const vx_stark_desc* d, StarkShape* out) {
 static std::vector<vxh::u64> stark_statement(const vx_stark_desc* d, const StarkShape& sh, const vxh::u64* canonical_pis) {
   std::vector<vxh::u64> st = {(vxh::u64)d->degree_bits, (vxh::u64)d->rate_bits, (vxh::u64)d->cap_height, (vxh::u64)d->pow_bits, (vxh::u64)d->num_query_rounds,
                               (vxh::u64)d->num_challenges, (vxh::u64)d->constraint_degree, (vxh::u64)d->num_columns, (vxh::u64)d->num_aux_columns,
-                              (vxh::u64)d->num_aux_challenges, (vxh::u64)d->num_public_inputs, (vxh::u64)sh.arity_bits.size()};
+                              (vxh::u64)d->num_aux_challenges, (vxh::u64)d->num_public_inputs, (vxh::u64)d->num_aux_public_inputs,
+                              (vxh::u64)sh.arity_bits.size()};
   for (int a : sh.arity_bits) st.push_back((vxh::u64)a);
   std::vector<vxh::u64> limbs;
   limbs.reserve(2 * (size_t)d->program_len);
@@ -191,6 +194,7 @@ struct vx_stark_session {
   std::vector<int32_t> arities;
   StarkShape sh;
   std::vector<vxh::u64> public_inputs, trace_cap, aux_challenges;
+  bool shared_challenges = false;   // vx_stark_set_aux_challenges: the challenges of a cross-table argument, drawn by the caller over ALL tables' caps
   vx_batch* trace_b = nullptr;
   vxh::Challenger ch;
   bool finished = false;
@@ -244,7 +248,8 @@ static int stark_begin_impl(vx_ctx* c, const vx_stark_desc* d_in, const u64* tra
   return VX_OK;
 }
 
-static int stark_finish_impl(vx_stark_session& s, const u64* aux_in, bool aux_on_device, const u64* pow_hint, std::vector<uint8_t>& proof_out) {
+static int stark_finish_impl(vx_stark_session& s, const u64* aux_in, bool aux_on_device, const u64* aux_pis_in, const u64* pow_hint,
+                             std::vector<uint8_t>& proof_out) {
   using namespace vxh;
   vx_ctx* c = s.c;
   const vx_stark_desc* d = &s.d;
@@ -253,6 +258,10 @@ static int stark_finish_impl(vx_stark_session& s, const u64* aux_in, bool aux_on
   const size_t n = (size_t)1 << lg, N = (size_t)1 << LG;
   const size_t cap_words = (size_t)4 << d->cap_height;
   if (naux > 0 && !aux_in) return vx_fail(VX_E_INVALID, "vx_stark_finish: this AIR has %d aux columns and none were given", naux);
+  const int napi = d->num_aux_public_inputs;
+  if (napi > 0 && !aux_pis_in) return vx_fail(VX_E_INVALID, "vx_stark_finish: this AIR has %d aux public inputs (closing sums): use vx_stark_finish2", napi);
+  std::vector<u64> aux_pis(aux_pis_in, aux_pis_in + (napi > 0 ? napi : 0));
+  for (auto& v : aux_pis) v = canon(v);
   Scratch S(c);
   vx_batch* trace_b = s.trace_b;
   vx_batch *aux_b = nullptr, *quot_b = nullptr;
@@ -282,6 +291,7 @@ static int stark_finish_impl(vx_stark_session& s, const u64* aux_in, bool aux_on
     VXCHK(batch_commit_device(c, aux_b, d_aux, n, false));
     VXCHK(gather_cap(c, one, S, aux_b->tree + aux_b->cap_off * 4, aux_b->local_cap_words(), aux_cap));
     ch.observe_elements(aux_cap.data(), cap_words);
+    if (napi > 0) ch.observe_elements(aux_pis.data(), aux_pis.size());   // the closing sums are bound before the alphas are drawn
   }
   u64 alphas[VX_MAX_CHALLENGES] = {0, 0};
   for (int i = 0; i < nch; ++i) alphas[i] = ch.get_challenge();
@@ -306,6 +316,7 @@ static int stark_finish_impl(vx_stark_session& s, const u64* aux_in, bool aux_on
     ap.root_lo = c->root_lo, ap.root_hi = c->root_hi;
     for (int i = 0; i < VX_MAX_CHALLENGES; ++i) ap.alphas[i] = alphas[i];
     for (int i = 0; i < d->num_public_inputs; ++i) ap.pi[i] = public_inputs[i];
+    for (int i = 0; i < napi; ++i) ap.pi[d->num_public_inputs + i] = aux_pis[i];
     for (size_t i = 0; i < s.aux_challenges.size(); ++i) ap.chal[i] = s.aux_challenges[i];
     {
       // Z_H(x) on LDE block z: x^n = 7^n * w_{2^rb}^(rev_rb(z))
@@ -437,6 +448,7 @@ static int stark_finish_impl(vx_stark_session& s, const u64* aux_in, bool aux_on
   w.words(ev_quot.data(), ev_quot.size());
   write_fri_proof(w, fp, oracles, fri, one);
   w.words(public_inputs.data(), public_inputs.size());
+  w.words(aux_pis.data(), aux_pis.size());
   proof_out.swap(w.b);
   return VX_OK;
 }
@@ -447,7 +459,7 @@ static int stark_prove_impl(vx_ctx* c, const vx_stark_desc* d, const u64* trace_
   if (d->num_aux_columns != 0) return vx_fail(VX_E_INVALID, "vx_stark_prove: this AIR has a second commitment round: use vx_stark_begin / vx_stark_finish");
   vx_stark_session s;
   VXCHK(stark_begin_impl(c, d, trace_in, on_device, pis, s));
-  return stark_finish_impl(s, nullptr, false, pow_hint, proof_out);
+  return stark_finish_impl(s, nullptr, false, nullptr, pow_hint, proof_out);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -489,7 +501,8 @@ static inline void eval_air_ext(const vx_stark_desc* d, const E* local, const E*
   }
 }
 
-static std::string verify(const vx_stark_desc* d, const StarkShape& sh, const u64* pis_expected, const uint8_t* bytes, size_t len) {
+static std::string verify(const vx_stark_desc* d, const StarkShape& sh, const u64* pis_expected, const uint8_t* bytes, size_t len,
+                          const u64* shared_challenges = nullptr, u64* aux_pis_out = nullptr) {
   const int lg = d->degree_bits, rb = d->rate_bits, LG = lg + rb, nch = d->num_challenges, ncols = d->num_columns;
   const size_t n = (size_t)1 << lg, N = (size_t)1 << LG, cap_len = (size_t)1 << d->cap_height, R = sh.arity_bits.size();
   const size_t nquot = (size_t)nch * sh.qdf;
@@ -535,9 +548,13 @@ static std::string verify(const vx_stark_desc* d, const StarkShape& sh, const u6
   const u64 pow_witness = r.f();
   std::vector<u64> pis;
   r.words(pis, d->num_public_inputs);
+  std::vector<u64> aux_pis;
+  r.words(aux_pis, d->num_aux_public_inputs);
   if (!r.ok || r.pos != len) return "malformed proof (length or non-canonical field element)";
   for (int i = 0; i < d->num_public_inputs; ++i)
     if (pis[i] != vxh::canon(pis_expected[i])) return "public inputs differ from the expected ones";
+  if (aux_pis_out)
+    for (int i = 0; i < d->num_aux_public_inputs; ++i) aux_pis_out[i] = aux_pis[i];
 
   // ---- challenges: statement (shape, program digest, public inputs) -> trace cap -> [aux challenges -> aux cap] -> alphas
   //      -> quotient cap -> zeta -> openings -> FRI  (starky get_challenges, with the statement in front) ----
@@ -550,7 +567,14 @@ static std::string verify(const vx_stark_desc* d, const StarkShape& sh, const u6
   std::vector<u64> aux_challenges(naux ? d->num_aux_challenges : 0);
   if (naux) {
     for (auto& v : aux_challenges) v = ch.get_challenge();
+    if (shared_challenges) {   // a cross-table argument: the caller's challenges (drawn over every table's cap) replace the table's own
+      for (size_t i = 0; i < aux_challenges.size(); ++i) aux_challenges[i] = vxh::canon(shared_challenges[i]);
+      ch.observe_elements(aux_challenges.data(), aux_challenges.size());
+    }
     ch.observe_elements(aux_cap.data(), aux_cap.size());
+    if (!aux_pis.empty()) ch.observe_elements(aux_pis.data(), aux_pis.size());
+  } else if (shared_challenges) {
+    return "shared challenges given for an AIR without a second commitment round";
   }
   std::vector<u64> alphas(nch);
   for (auto& v : alphas) v = ch.get_challenge();
@@ -585,7 +609,9 @@ static std::string verify(const vx_stark_desc* d, const StarkShape& sh, const u6
     std::vector<E> all_local(o_local), all_next(o_next);   // program columns: trace, then aux
     all_local.insert(all_local.end(), o_aux.begin(), o_aux.end());
     all_next.insert(all_next.end(), o_aux_next.begin(), o_aux_next.end());
-    eval_air_ext(d, all_local.data(), all_next.data(), pis.data(), aux_challenges.data(), z_last, l_first, l_last, alphas.data(), nch, acc);
+    std::vector<u64> all_pis(pis);     // VX_OP_LDP index space: public inputs, then the aux public inputs
+    all_pis.insert(all_pis.end(), aux_pis.begin(), aux_pis.end());
+    eval_air_ext(d, all_local.data(), all_next.data(), all_pis.data(), aux_challenges.data(), z_last, l_first, l_last, alphas.data(), nch, acc);
     for (int k = 0; k < nch; ++k) {
       E q;
       for (int j = sh.qdf; j-- > 0;) q = q * zeta_n + o_quot[(size_t)k * sh.qdf + j];

@@ -114,6 +114,16 @@ struct vx_ctx {
     hipEventCreate(&e);
     return e;
   }
+  // a stage measured on the HOST clock (an exchange the host performs between two stream segments): kept apart from the
+  // HIP-event stages so that waiting for other ranks is never booked as compute
+  void prof_add_host(const char* name, double ms, double bytes) {
+    if (!prof_on) return;
+    if (!prof.count(name)) prof_order.push_back(name);
+    ProfEntry& e = prof[name];
+    e.ms += ms;
+    e.calls += 1;
+    e.alg_bytes += bytes;
+  }
   void fold() {
     for (auto& p : pending) {
       hipEventSynchronize(p.b);
@@ -144,12 +154,15 @@ struct ProfScope {
       hipEventRecord(a, c->stream);
     }
   }
-  ~ProfScope() {
-    if (c->prof_on) {
+  bool ended = false;
+  void end() {   // close the bracket early (something that is not this stage follows inside the C++ scope)
+    if (c->prof_on && !ended) {
       hipEventRecord(b, c->stream);
       c->pending.push_back({name, a, b, bytes});
     }
+    ended = true;
   }
+  ~ProfScope() { end(); }
 };
 
 // ------------------------------------------------------------------------------------------------

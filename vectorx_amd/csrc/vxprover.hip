@@ -3,6 +3,7 @@
 // point returns VX_E_NO_DEVICE.
 #include "vx_runtime.hip.h"
 #include "batch.hip.h"
+#include <chrono>
 #include <condition_variable>
 #include <mutex>
 #include "plonk_kernels.hip.h"
@@ -807,13 +808,52 @@ int vx_stark_begin(vx_ctx* c, const vx_stark_desc* d, const uint64_t* trace, int
 }
 int vx_stark_finish(vx_stark_session* s, const uint64_t* aux_columns, int aux_on_device, const uint64_t* pow_witness_hint, uint8_t* out_buf,
                     size_t* out_len) {
+  return vx_stark_finish2(s, aux_columns, aux_on_device, nullptr, pow_witness_hint, out_buf, out_len);
+}
+int vx_stark_session_trace_cap(vx_stark_session* s, uint64_t* cap_out) {
+  if (!s || !cap_out) return vx_fail(VX_E_INVALID, "vx_stark_session_trace_cap: NULL argument");
+  memcpy(cap_out, s->trace_cap.data(), s->trace_cap.size() * 8);
+  return VX_OK;
+}
+int vx_stark_set_aux_challenges(vx_stark_session* s, const uint64_t* shared) {
+  if (!s || !shared) return vx_fail(VX_E_INVALID, "vx_stark_set_aux_challenges: NULL argument");
+  if (s->finished || s->shared_challenges) return vx_fail(VX_E_INVALID, "vx_stark_set_aux_challenges: the session's challenges are already fixed");
+  if (s->aux_challenges.empty()) return vx_fail(VX_E_INVALID, "vx_stark_set_aux_challenges: this AIR has no second-round challenges");
+  for (size_t i = 0; i < s->aux_challenges.size(); ++i) s->aux_challenges[i] = vxh::canon(shared[i]);
+  s->ch.observe_elements(s->aux_challenges.data(), s->aux_challenges.size());   // the shared challenges are part of THIS proof's transcript
+  s->shared_challenges = true;
+  return VX_OK;
+}
+int vx_stark_joint_challenges(const uint64_t* const* trace_caps, const int32_t* cap_heights, int num_tables, int num_challenges, uint64_t* out) {
+  if (!trace_caps || !cap_heights || !out || num_tables < 1 || num_tables > 64 || num_challenges < 1 || num_challenges > VX_AIR_MAX_CHALLENGES)
+    return vx_fail(VX_E_INVALID, "vx_stark_joint_challenges: bad argument");
+  vxh::Challenger ch;
+  ch.observe_element((uint64_t)num_tables);
+  for (int t = 0; t < num_tables; ++t) {
+    if (!trace_caps[t] || cap_heights[t] < 0 || cap_heights[t] > 24) return vx_fail(VX_E_INVALID, "vx_stark_joint_challenges: bad cap %d", t);
+    std::vector<vxh::u64> cap(trace_caps[t], trace_caps[t] + ((size_t)4 << cap_heights[t]));
+    for (auto& v : cap) v = vxh::canon(v);
+    ch.observe_elements(cap.data(), cap.size());
+  }
+  for (int i = 0; i < num_challenges; ++i) out[i] = ch.get_challenge();
+  return VX_OK;
+}
+int vx_stark_proof_trace_cap(const vx_stark_desc* d, const uint8_t* proof, size_t proof_len, uint64_t* cap_out) {
+  if (!d || !proof || !cap_out || d->cap_height < 0 || d->cap_height > 24) return vx_fail(VX_E_INVALID, "vx_stark_proof_trace_cap: bad argument");
+  const size_t bytes = (size_t)32 << d->cap_height;
+  if (proof_len < bytes) return vx_fail(VX_E_PROOF, "vx_stark_proof_trace_cap: proof shorter than its trace cap");
+  memcpy(cap_out, proof, bytes);
+  return VX_OK;
+}
+int vx_stark_finish2(vx_stark_session* s, const uint64_t* aux_columns, int aux_on_device, const uint64_t* aux_public_inputs,
+                     const uint64_t* pow_witness_hint, uint8_t* out_buf, size_t* out_len) {
   if (!s || !out_buf || !out_len) return vx_fail(VX_E_INVALID, "vx_stark_finish: NULL argument");
   if (s->finished) return vx_fail(VX_E_INVALID, "vx_stark_finish: the session has already produced its proof");
   HIPCHK(hipSetDevice(s->c->device));
   std::vector<uint8_t> proof;
   int rc;
   try {
-    rc = stark_finish_impl(*s, aux_columns, aux_on_device != 0, pow_witness_hint, proof);
+    rc = stark_finish_impl(*s, aux_columns, aux_on_device != 0, aux_public_inputs, pow_witness_hint, proof);
   } catch (const std::bad_alloc&) {
     rc = vx_fail(VX_E_NOMEM, "vx_stark_finish: out of host memory");
   } catch (const std::exception& e) {
@@ -834,12 +874,16 @@ int vx_stark_finish(vx_stark_session* s, const uint64_t* aux_columns, int aux_on
 }
 void vx_stark_session_free(vx_stark_session* s) { delete s; }
 int vx_stark_verify(const vx_stark_desc* d, const uint64_t* public_inputs, const uint8_t* proof, size_t proof_len) {
+  return vx_stark_verify_shared(d, public_inputs, proof, proof_len, nullptr, nullptr);
+}
+int vx_stark_verify_shared(const vx_stark_desc* d, const uint64_t* public_inputs, const uint8_t* proof, size_t proof_len,
+                           const uint64_t* shared_challenges, uint64_t* aux_public_inputs_out) {
   if (!d || !proof || (d->num_public_inputs > 0 && !public_inputs)) return vx_fail(VX_E_INVALID, "vx_stark_verify: NULL argument");
   try {
     StarkShape sh;
     std::string why = stark_check(d, &sh);
     if (!why.empty()) return vx_fail(VX_E_INVALID, "vx_stark_verify: %s", why.c_str());
-    why = vxsv::verify(d, sh, public_inputs, proof, proof_len);
+    why = vxsv::verify(d, sh, public_inputs, proof, proof_len, shared_challenges, aux_public_inputs_out);
     if (!why.empty()) return vx_fail(VX_E_PROOF, "vx_stark_verify: %s", why.c_str());
     return VX_OK;
   } catch (const std::bad_alloc&) {
@@ -905,7 +949,10 @@ struct vx_group {
   std::vector<vx_group_member> members;
   std::vector<void*> bufs;
   std::vector<size_t> sizes;
-  // returns false when the group was aborted
+  // returns false when the group was aborted — or when a member did not arrive within `timeout_ms` (a rank that died
+  // cannot call vx_group_abort: its peers must not wait for it forever).  A timeout aborts the group for everybody.
+  long long timeout_ms = 120000;
+  bool timed_out = false;
   bool barrier() {
     std::unique_lock<std::mutex> lk(mu);
     if (aborted) return false;
@@ -916,7 +963,12 @@ struct vx_group {
       cv.notify_all();
       return true;
     }
-    cv.wait(lk, [&] { return generation != gen || aborted; });
+    if (!cv.wait_for(lk, std::chrono::milliseconds(timeout_ms), [&] { return generation != gen || aborted; })) {
+      aborted = true;
+      timed_out = true;
+      cv.notify_all();
+      return false;
+    }
     return !aborted;
   }
 };
@@ -933,6 +985,12 @@ int vx_group_create(int world, vx_group** out) {
   return VX_OK;
 }
 void vx_group_destroy(vx_group* g) { delete g; }
+int vx_group_set_timeout_ms(vx_group* g, long long ms) {
+  if (!g || ms < 1) return vx_fail(VX_E_INVALID, "vx_group_set_timeout_ms: bad argument");
+  std::lock_guard<std::mutex> lk(g->mu);
+  g->timeout_ms = ms;
+  return VX_OK;
+}
 void vx_group_abort(vx_group* g) {
   if (!g) return;
   std::lock_guard<std::mutex> lk(g->mu);
@@ -978,9 +1036,16 @@ int vx_group_allgather(void* member, void* dev_buf, size_t bytes_per_rank) {
     g->bufs[m->rank] = dev_buf;
     g->sizes[m->rank] = bytes_per_rank;
   }
-  if (!g->barrier()) return vx_fail(VX_E_COMM, "vx_group_allgather: group aborted");
-  // every rank's buffer is published and its producer stream is idle: pull the other ranks' slots
-  HIPCHK(hipSetDevice(m->ctx->device));
+  if (!g->barrier()) return vx_fail(VX_E_COMM, g->timed_out ? "vx_group_allgather: a rank did not arrive (timeout): group aborted" : "vx_group_allgather: group aborted");
+  // every rank's buffer is published and its producer stream is idle: pull the other ranks' slots.  EVERY early return
+  // below aborts the group first — the peers are blocked in a barrier that this rank will never reach.
+  {
+    hipError_t e = hipSetDevice(m->ctx->device);
+    if (e != hipSuccess) {
+      vx_group_abort(g);
+      return vx_fail(VX_E_HIP, "vx_group_allgather: hipSetDevice(%d): %s", m->ctx->device, hipGetErrorString(e));
+    }
+  }
   for (int s = 0; s < g->world; ++s) {
     if (s == m->rank) continue;
     if (g->sizes[s] != bytes_per_rank) {
@@ -1001,7 +1066,7 @@ int vx_group_allgather(void* member, void* dev_buf, size_t bytes_per_rank) {
     return vx_fail(VX_E_HIP, "vx_group_allgather: %s", hipGetErrorString(e));
   }
   // nobody may overwrite its slot before all ranks have read it
-  if (!g->barrier()) return vx_fail(VX_E_COMM, "vx_group_allgather: group aborted");
+  if (!g->barrier()) return vx_fail(VX_E_COMM, g->timed_out ? "vx_group_allgather: a rank did not arrive (timeout): group aborted" : "vx_group_allgather: group aborted");
   return VX_OK;
 }
 
