@@ -348,6 +348,12 @@ int vx_stark_finish(vx_stark_session* session, const uint64_t* aux_columns, int 
                     uint8_t* out_buf, size_t* out_len);
 void vx_stark_session_free(vx_stark_session* session);
 int vx_stark_verify(const vx_stark_desc* desc, const uint64_t* public_inputs, const uint8_t* proof, size_t proof_len);
+/* Compile an AIR program ahead of time: every chunk of the program (jit.hip.h cuts long programs into kernels of ~1200
+ * instructions) is compiled with hiprtc into the process cache and, when VX_JIT_CACHE_DIR names a private directory, onto disk
+ * — needs NO GPU, so a `build` step can run where the circuits are compiled and the proving host only loads code objects.
+ * Returns the number of chunks compiled now (>= 0; chunks found in a cache are not counted), negative VX_E_* when hiprtc is
+ * missing or a chunk fails to compile.  *num_chunks_out (may be NULL) = chunks the program has. */
+int vx_stark_precompile(const vx_stark_desc* desc, int* num_chunks_out);
 /* ---- several tables on ONE bus (the shape of Curta's chips: every chip is its own trace, lookups and the bus run across them).
  * One session per table; the challenges of the cross-table argument must be the same in every table and may only be drawn when
  * EVERY trace is committed:

@@ -8,6 +8,13 @@ sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
 
 
+import os
+
+_JIT_CACHE = ROOT / ".jit_cache"   # filled by __graft_entry__.build() (vx_stark_precompile): compiled AIR chunks, loaded instead of recompiled
+if "VX_JIT_CACHE_DIR" not in os.environ and _JIT_CACHE.is_dir():
+    os.environ["VX_JIT_CACHE_DIR"] = str(_JIT_CACHE)
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

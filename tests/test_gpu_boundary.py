@@ -111,6 +111,24 @@ def test_mapreduce_dag_on_one_gpu_matches_the_oracle_dag(ctx, oracle):
     assert g2["root"] == o["root"] and g2["my_proofs"] == o["my_proofs"]
     for p in gp2:
         p.free()
+    # the bench's DAG leg: a few base witnesses per circuit kind, each job's public inputs patched into the lane's own copy:
+    # every proof verifies, the root does not depend on how many jobs are in flight
+    roots = []
+    for in_flight, use_lanes in ((3, lanes), (1, [])):
+        gp3 = []
+
+        def make_few(kind, log_n, jobs, use_lanes=use_lanes):
+            p = mr.GpuProver(ctx, kind, log_n, jobs, extra_lanes=use_lanes, distinct_witnesses=2)
+            gp3.append(p)
+            return p
+        g3 = mr.run_dag(spec, make_few, None, ctx.sync, in_flight=in_flight)
+        roots.append(g3["root"])
+        for (li, j), proof in g3["my_proofs"].items():
+            kind = spec.layers()[li][0]
+            next(p for p in gp3 if p.kind == kind).circuit.verify(proof)
+        for p in gp3:
+            p.free()
+    assert roots[0] == roots[1] and roots[0] != o["root"]
     for l in lanes:
         l.close()
 

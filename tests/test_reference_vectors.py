@@ -68,3 +68,34 @@ def test_commitments_follow_their_definitions():
     assert d == H(H(H(c, b), H(a, z)), H(H(z, z), H(z, z)))
     with pytest.raises(ValueError):
         ac.header_range_commitments([a] * 9, [a] * 9, 8)
+
+
+def test_synthetic_epoch_end_header_passes_the_circuits_checks_and_tampering_does_not():
+    """BASELINE.json configs[0] plumbing: a synthetic epoch-end header with an FRNK scheduled-change log and 300
+    dummy keys, checked the way /root/reference/circuits/builder/rotate.rs:81-93, 95-166, 223-283 checks it."""
+    import hashlib
+    from vectorx_amd import avail_codec as ac
+    header, start, pubkeys = ac.synthetic_epoch_end_header(b"seed")
+    assert len(pubkeys) == 300 and len(header) <= ac.MAX_HEADER_SIZE == 35840
+    assert header[start + 1] == 4 and header[start + 2:start + 6] == b"FRNK"
+    out = ac.rotate_output(header, start, pubkeys)
+    h = b""
+    for pk in pubkeys:
+        h = hashlib.sha256(h + pk).digest()
+    assert out == h
+    body = start + 6
+    _, mode, ln = ac.decode_compact_u32(header[body:body + 5])          # message length: 1 + 2 + 300 * 40 + 4 = 12007 < 2^14 -> two-byte mode
+    assert mode == 1 and ln == 2 and header[body + ln] == 1
+    count, _, cl = ac.decode_compact_u32(header[body + ln + 1:body + ln + 6])
+    assert count == 300 and cl == 2
+    first = body + ln + 1 + cl
+    for off, what in [(start + 1, "consensus"), (start + 3, "consensus"), (body + ln, "scheduled"), (first + 5, "public key"),
+                      (first + 32, "weight"), (first + 40 * 299 + 39, "weight"), (first + 40 * 300 + 2, "delay")]:
+        bad = bytearray(header)
+        bad[off] ^= 1
+        with pytest.raises(ValueError, match=what):
+            ac.rotate_output(bytes(bad), start, pubkeys)
+    with pytest.raises(ValueError):
+        ac.verify_epoch_end_header(header, start, 299, pubkeys[:299])      # the witness' count must equal the encoded one
+    small, s2, pk2 = ac.synthetic_epoch_end_header(b"x", num_authorities=5)
+    assert ac.rotate_output(small, s2, pk2) == ac.authority_set_commitment(pk2)

@@ -108,6 +108,7 @@ _SIGNATURES = {
     "vx_stark_begin": (_i, [_vp, _vp, _vp, _i, _vp, _vp, ctypes.POINTER(_vp)]),
     "vx_stark_finish": (_i, [_vp, _vp, _i, _vp, _vp, ctypes.POINTER(_sz)]),
     "vx_stark_session_free": (None, [_vp]),
+    "vx_stark_precompile": (_i, [_vp, ctypes.POINTER(_i)]),
     "vx_stark_session_trace_cap": (_i, [_vp, _vp]),
     "vx_stark_set_aux_challenges": (_i, [_vp, _vp]),
     "vx_stark_finish2": (_i, [_vp, _vp, _i, _vp, _vp, _vp, ctypes.POINTER(_sz)]),
@@ -447,6 +448,14 @@ class Stark:
             self.desc.num_fri_reduction_arity_bits = len(fri_arities)
             self.desc.fri_reduction_arity_bits = ctypes.cast(self._ar, ctypes.c_void_p).value
         self.desc_ptr = ctypes.pointer(self.desc)
+
+    def precompile(self) -> tuple:
+        """`vx_stark_precompile`: compile every chunk of the AIR program with hiprtc (no GPU needed) -> (compiled now, chunks)"""
+        n = _i(0)
+        rc = lib().vx_stark_precompile(ctypes.cast(self.desc_ptr, _vp), ctypes.byref(n))
+        if rc < 0:
+            _chk(rc)
+        return rc, n.value
 
     def run_aux(self, trace, challenges):
         """-> (aux columns [num_aux_columns][n] uint64, aux public inputs [num_aux_public_inputs] uint64)"""

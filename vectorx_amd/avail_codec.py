@@ -140,3 +140,76 @@ def unpack_rotate_input(raw: bytes) -> dict:
     if len(raw) != 40:
         raise ValueError("rotate input is 40 bytes")
     return {"authority_set_id": struct.unpack(">Q", raw[0:8])[0], "authority_set_hash": raw[8:40]}
+
+
+# ---- the epoch-end header a `rotate` proof is about (BASELINE.json configs[0]: plumbing, host side) -----------------------------
+# /root/reference/circuits/builder/rotate.rs:81-93 (consensus log: flag 0x04 + engine id "FRNK"), :95-135 (compact message length,
+# scheduled-change flag 0x01), :137-166 (compact authority count), :223-283 (pubkey[32] | weight u64 LE = 1 per validator, then a
+# u32 delay = 0); sizes /root/reference/circuits/consts.rs:9-52.
+MAX_HEADER_SIZE = 280 * 128           # consts.rs:9-16: 280 BLAKE2b chunks
+MAX_AUTHORITY_SET_SIZE = 300          # consts.rs:52
+CONSENSUS_ENGINE_ID = bytes([70, 82, 78, 75])     # "FRNK"
+PUBKEY_LENGTH, WEIGHT_LENGTH, DELAY_LENGTH = 32, 8, 4
+
+
+def encode_scheduled_change_log(pubkeys, delay: int = 0) -> bytes:
+    """DigestItem::Consensus(FRNK, ConsensusLog::ScheduledChange{next_authorities, delay}) as the circuit reads it, starting
+    at the byte BEFORE the consensus flag (the circuit skips it: `start_position` points there)."""
+    body = bytes([1]) + encode_compact_u32(len(pubkeys))          # scheduled-change flag, authority count
+    for pk in pubkeys:
+        if len(pk) != PUBKEY_LENGTH:
+            raise ValueError("compressed Ed25519 keys are 32 bytes")
+        body += pk + struct.pack("<Q", 1)                         # every Avail validator has weight 1
+    body += struct.pack("<I", delay)
+    return bytes([0]) + bytes([4]) + CONSENSUS_ENGINE_ID + encode_compact_u32(len(body)) + body
+
+
+def synthetic_epoch_end_header(seed: bytes, num_authorities: int = MAX_AUTHORITY_SET_SIZE, block_number: int = 4321) -> tuple:
+    """-> (header bytes, start_position, pubkeys): a SCALE-shaped header (parent hash | compact number | state root |
+    extrinsics root | digest) whose digest holds one authority-set change log with `num_authorities` dummy keys derived from
+    `seed` — the input a `rotate` witness generator fetches from the chain (circuits/rotate.rs:95-99), synthesised."""
+    if not 0 < num_authorities <= MAX_AUTHORITY_SET_SIZE:
+        raise ValueError("authority set size outside (0, 300]")
+    h = lambda tag: hashlib.sha256(seed + tag).digest()           # noqa: E731
+    pubkeys = [h(b"pk" + struct.pack("<I", i)) for i in range(num_authorities)]
+    head = h(b"parent") + encode_compact_u32(block_number) + h(b"state") + h(b"extrinsics") + encode_compact_u32(2)
+    pre_runtime = bytes([6]) + b"BABE" + encode_compact_u32(8) + h(b"slot")[:8]      # an unrelated log in front
+    log = encode_scheduled_change_log(pubkeys)
+    header = head + pre_runtime + log[1:]                          # log[0] is the skipped byte = the last byte in front of the flag
+    start = len(head) + len(pre_runtime) - 1
+    if len(header) > MAX_HEADER_SIZE:
+        raise ValueError("header longer than MAX_HEADER_SIZE")
+    return header, start, pubkeys
+
+
+def verify_epoch_end_header(header: bytes, start_position: int, num_authorities: int, pubkeys) -> None:
+    """The checks `verify_epoch_end_header` makes in-circuit (builder/rotate.rs:168-283), on the host; raises ValueError."""
+    if num_authorities == 0 or num_authorities > MAX_AUTHORITY_SET_SIZE or len(header) > MAX_HEADER_SIZE:
+        raise ValueError("bad authority count / header size")
+    p = header[start_position:]
+    if p[1] != 4 or p[2:6] != CONSENSUS_ENGINE_ID:
+        raise ValueError("start_position is not a GRANDPA consensus log")
+    _, _, ln = decode_compact_u32(p[6:11])                          # message length: skipped, not checked (rotate.rs:114)
+    cur = 6 + ln
+    if p[cur] != 1:
+        raise ValueError("not a scheduled-change message")
+    cur += 1
+    count, _, ln = decode_compact_u32(p[cur:cur + 5])
+    if count != num_authorities:
+        raise ValueError("encoded authority count differs from the witness")
+    cur += ln
+    for i in range(num_authorities):
+        v = p[cur + i * 40:cur + (i + 1) * 40]
+        if v[:32] != pubkeys[i]:
+            raise ValueError(f"validator {i}: public key differs")
+        if v[32:40] != struct.pack("<Q", 1):
+            raise ValueError(f"validator {i}: weight is not 1")
+    end = cur + num_authorities * 40
+    if p[end:end + 4] != bytes(4):
+        raise ValueError("delay is not 0")
+
+
+def rotate_output(header: bytes, start_position: int, pubkeys) -> bytes:
+    """new_authority_set_hash: what the rotate circuit writes (circuits/rotate.rs:101-108) once the header checks pass"""
+    verify_epoch_end_header(header, start_position, len(pubkeys), pubkeys)
+    return authority_set_commitment(pubkeys)

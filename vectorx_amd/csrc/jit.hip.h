@@ -20,7 +20,9 @@
 #include <hip/hiprtc.h>
 #include <map>
 #include <mutex>
+#include <atomic>
 #include <sstream>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -99,24 +101,12 @@ static JitApi& jit_api() {
 //                 PUSH adds R[a] * alpha^k (k = position of the constraint) to a0 / a1.
 //   air == true:  an AIR program (stark.hip.h) — LDW / LDN read the local / next trace row, LDP a public input; PUSH
 //                 multiplies by the kind's factor (VX_AIR_*) and folds Horner-style, acc = acc * alpha + t.
-static void jit_emit_program(std::ostringstream& s, const uint64_t* prog, int nch, bool air, int air_ncols = 0) {
-  // AIR: columns >= air_ncols are second-round (aux) columns, held in their own LDE with the same row stride
-  auto col = [&](int a) {
-    std::ostringstream e;
-    if (air && a >= air_ncols) e << "AUX[(size_t)" << (a - air_ncols) << " * SW + ";
-    else e << "W[(size_t)" << a << " * SW + ";
-    return e.str();
-  };
-  // ---- decode, then two straight-line optimisations before emitting ----------------------------------------
-  //  (1) multiply-add fusion: a MUL whose result is read exactly once, by an ADD, becomes one gl_mad at the ADD
-  //      (the F_p^2 products the emitters produce are chains of exactly this shape);
-  //  (2) lazy canonicalisation: products stay arbitrary u64 representatives (gl_mul_nc / gl_mad_nc accept and return
-  //      them, PUSH accepts them); a register is canonicalised only when an ADD / SUB is about to read it.
-  struct Ins { int op, dst, a, b; uint64_t imm; bool skip; int fa, fb; };  // fa/fb: multiplicands folded into an ADD
-  std::vector<Ins> code;
+struct JitIns { int op, dst, a, b; uint64_t imm; bool skip; int fa, fb; };  // fa/fb: multiplicands folded into an ADD
+static std::vector<JitIns> jit_decode(const uint64_t* prog) {
+  std::vector<JitIns> code;
   for (int pc = 0;; ++pc) {
     const uint64_t ins = prog[pc];
-    Ins I{(int)(ins & 0xFF), (int)((ins >> 8) & 63), (int)((ins >> 16) & 0xFFFF), (int)((ins >> 32) & 0xFFFF), 0, false, -1, -1};
+    JitIns I{(int)(ins & 0xFF), (int)((ins >> 8) & 63), (int)((ins >> 16) & 0xFFFF), (int)((ins >> 32) & 0xFFFF), 0, false, -1, -1};
     if (I.op == VX_OP_END) break;
     if (I.op == VX_OP_PUSH) I.b = (int)((ins >> 32) & 0xFFFF);  // AIR: the constraint kind
     if (I.op == VX_OP_LDI) I.imm = vxh::canon(prog[++pc]);
@@ -124,6 +114,27 @@ static void jit_emit_program(std::ostringstream& s, const uint64_t* prog, int nc
     if (I.op == VX_OP_PUSH) I.a &= 63;
     code.push_back(I);
   }
+  return code;
+}
+static void jit_emit_code(std::ostringstream& s, std::vector<JitIns> code, int nch, bool air, int air_ncols);
+static void jit_emit_program(std::ostringstream& s, const uint64_t* prog, int nch, bool air, int air_ncols = 0) {
+  jit_emit_code(s, jit_decode(prog), nch, air, air_ncols);
+}
+// `code`: a self-contained straight-line sequence (every register is written before it is read)
+static void jit_emit_code(std::ostringstream& s, std::vector<JitIns> code, int nch, bool air, int air_ncols) {
+  typedef JitIns Ins;
+  // AIR: columns >= air_ncols are second-round (aux) columns, held in their own LDE with the same row stride
+  auto col = [&](int a) {
+    std::ostringstream e;
+    if (air && a >= air_ncols) e << "AUX[(size_t)" << (a - air_ncols) << " * SW + ";
+    else e << "W[(size_t)" << a << " * SW + ";
+    return e.str();
+  };
+  // ---- two straight-line optimisations before emitting ----------------------------------------
+  //  (1) multiply-add fusion: a MUL whose result is read exactly once, by an ADD, becomes one gl_mad at the ADD
+  //      (the F_p^2 products the emitters produce are chains of exactly this shape);
+  //  (2) lazy canonicalisation: products stay arbitrary u64 representatives (gl_mul_nc / gl_mad_nc accept and return
+  //      them, PUSH accepts them); a register is canonicalised only when an ADD / SUB is about to read it.
   auto reads = [](const Ins& I, int r) {
     if (I.op == VX_OP_ADD || I.op == VX_OP_SUB || I.op == VX_OP_MUL) return (I.a == r) + (I.b == r);
     if (I.op == VX_OP_PUSH) return (int)(I.a == r);
@@ -278,9 +289,26 @@ extern "C" __global__ __launch_bounds__(256, VX_JIT_BLOCKS_PER_CU) void vx_progr
   return s.str();
 }
 
-// HIP source of the kernel that evaluates ONE AIR program on the quotient domain of a STARK (stark.hip.h
-// air_quotient_kernel is the interpreter with the same prologue; the argument block is AirParams, mirrored textually).
-static std::string jit_air_source(const uint64_t* prog, int nch, int ncols) {
+// ---- AIR programs are compiled in CHUNKS (round 3) --------------------------------------------------------------------------
+// One kernel for a chip-sized AIR (16 k instructions, 2 k constraints: vectorx_amd/sha256_air.py) took hiprtc SEVEN MINUTES —
+// the back end's scheduling and register allocation are superlinear in the size of a basic block.  The program is cut at
+// constraint boundaries into chunks of <= VX_JIT_AIR_CHUNK instructions, one kernel each:
+//   * a chunk starts with the PROLOGUE that re-creates the registers it reads but does not write — the backward slice of the
+//     earlier code (row-type selectors, constants, a running sum ...), replayed in program order;
+//   * the Horner accumulation  acc = acc alpha + c_i  is local to the chunk and its result enters the total multiplied by
+//     alpha^(K - b) (K constraints in all, b = the first constraint AFTER the chunk) — the host supplies that power — so the
+//     kernels simply ADD into the quotient buffer, in any order;
+//   * the per-row factors of the constraint kinds (z_last, L_first, L_last: one field inversion per row) are computed once
+//     by air_row_factors_kernel (stark.hip.h) and read by every chunk.
+#ifndef VX_JIT_AIR_CHUNK
+#define VX_JIT_AIR_CHUNK 1200
+#endif
+struct JitAirChunk {
+  std::string src;
+  int push_begin = 0, push_end = 0;   // constraints [push_begin, push_end) of the program
+  int prologue = 0, body = 0;         // instruction counts (diagnostics)
+};
+static std::string jit_air_chunk_source(const std::vector<JitIns>& code, int nch, int ncols) {
   std::ostringstream s;
   s << "typedef unsigned long long uint64_t;\ntypedef unsigned int uint32_t;\n#define VX_JIT_BLOCKS_PER_CU 4\n"
     << jit_limits_defines() << JIT_PRELUDE << R"VXJIT(
@@ -298,35 +326,96 @@ struct AirParams {
   u64 zh[VX_MAX_RATE], zh_inv[VX_MAX_RATE];
   u64 last, n_inv;
   u64* out;
+  u64* rowfac;
+  u64 tail_pow[VX_MAX_CHALLENGES];
 };
 extern "C" __global__ __launch_bounds__(256, VX_JIT_BLOCKS_PER_CU) void vx_air_quotient(AirParams p) {
   const size_t il = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (il >= p.rows) return;
-  const int LG = p.log_n + p.rate_bits;
   const size_t n = (size_t)1 << p.log_n;
   const u32 z = (u32)(il >> p.log_n);
   const u32 r = (u32)(il & (n - 1));
-  const u32 j = __brev((u32)il) >> (32 - LG);
-  const u32 e = j << (ROOT_TABLE_LOG - LG);  // w_{2^24}^e from the two 4096-entry root tables (ntt.hip.h root_pow24)
-  const u64 x = gl_mul7(gl_mul(p.root_lo[e & 4095u], p.root_hi[(e >> 12) & 4095u]));
   const u32 rn = __brev(((__brev(r) >> (32 - p.log_n)) + 1) & (u32)(n - 1)) >> (32 - p.log_n);
   const size_t il_next = ((size_t)z << p.log_n) | rn;
-  const u64 z_last = gl_sub(x, p.last), xm1 = gl_sub(x, 1);
-  const u64 inv_both = gl_inv(gl_mul(z_last, xm1));
-  const u64 zh_n = gl_mul(p.zh[z], p.n_inv);
-  const u64 l_first = gl_mul(zh_n, gl_mul(inv_both, z_last));
-  const u64 l_last = gl_mul(gl_mul(zh_n, p.last), gl_mul(inv_both, xm1));
+  const u64 z_last = p.rowfac[il], l_first = p.rowfac[p.rows + il], l_last = p.rowfac[2 * p.rows + il];
   const u64* __restrict__ W = p.trace;
   const u64* __restrict__ AUX = p.aux;
   const size_t SW = p.stride;
   u64 a0 = 0, a1 = 0;
   u64 R[VX_PROGRAM_REGS];
 )VXJIT";
-  jit_emit_program(s, prog, nch, true, ncols);
-  s << "  (void)AUX;\n  p.out[il] = gl_mul(a0, p.zh_inv[z]);\n";
-  if (nch > 1) s << "  p.out[p.rows + il] = gl_mul(a1, p.zh_inv[z]);\n";
+  jit_emit_code(s, code, nch, true, ncols);
+  s << "  (void)AUX; (void)z_last; (void)l_first; (void)l_last;\n"
+       "  { u64* o = p.out + il; *o = gl_add(*o, gl_mul(gl_mul_nc(a0, p.tail_pow[0]), p.zh_inv[z])); }\n";
+  if (nch > 1) s << "  { u64* o = p.out + p.rows + il; *o = gl_add(*o, gl_mul(gl_mul_nc(a1, p.tail_pow[1]), p.zh_inv[z])); }\n";
   s << "}\n";
   return s.str();
+}
+static std::vector<JitAirChunk> jit_air_chunks(const uint64_t* prog, int nch, int ncols) {
+  const std::vector<JitIns> code = jit_decode(prog);
+  const char* env = getenv("VX_JIT_AIR_CHUNK");
+  const size_t limit = env && atoi(env) > 0 ? (size_t)atoi(env) : (size_t)VX_JIT_AIR_CHUNK;
+  auto srcs = [](const JitIns& I, int out[2]) {
+    int k = 0;
+    if (I.op == VX_OP_ADD || I.op == VX_OP_SUB || I.op == VX_OP_MUL) out[k++] = I.a, out[k++] = I.b;
+    else if (I.op == VX_OP_PUSH) out[k++] = I.a;
+    return k;
+  };
+  std::vector<JitAirChunk> chunks;
+  size_t begin = 0;
+  int pushes = 0;
+  while (begin < code.size()) {
+    // the chunk ends after the first PUSH at or beyond `limit` instructions (or at the end of the program)
+    size_t end = begin;
+    int np = 0;
+    while (end < code.size()) {
+      const bool push = code[end].op == VX_OP_PUSH;
+      ++end;
+      if (push) {
+        ++np;
+        if (end - begin >= limit) break;
+      }
+    }
+    if (end < code.size()) {  // never leave a tail without constraints for a chunk of its own
+      bool more = false;
+      for (size_t i = end; i < code.size(); ++i) more = more || code[i].op == VX_OP_PUSH;
+      if (!more) end = code.size();
+    }
+    // registers the body reads before writing them
+    bool written[VX_PROGRAM_REGS] = {false}, need[VX_PROGRAM_REGS] = {false};
+    for (size_t i = begin; i < end; ++i) {
+      int sr[2];
+      const int k = srcs(code[i], sr);
+      for (int q = 0; q < k; ++q)
+        if (!written[sr[q]]) need[sr[q]] = true;
+      if (code[i].op != VX_OP_PUSH) written[code[i].dst] = true;
+    }
+    // backward slice over the earlier code: the nearest earlier definition of every needed register, recursively
+    std::vector<char> take(begin, 0);
+    for (size_t i = begin; i-- > 0;) {
+      const JitIns& I = code[i];
+      if (I.op == VX_OP_PUSH || !need[I.dst]) continue;
+      take[i] = 1;
+      need[I.dst] = false;
+      int sr[2];
+      const int k = srcs(I, sr);
+      for (int q = 0; q < k; ++q) need[sr[q]] = true;
+    }
+    std::vector<JitIns> sub;
+    for (size_t i = 0; i < begin; ++i)
+      if (take[i]) sub.push_back(code[i]);
+    JitAirChunk c;
+    c.prologue = (int)sub.size();
+    sub.insert(sub.end(), code.begin() + begin, code.begin() + end);
+    c.body = (int)(end - begin);
+    c.push_begin = pushes;
+    c.push_end = pushes + np;
+    c.src = jit_air_chunk_source(sub, nch, ncols);
+    chunks.push_back(std::move(c));
+    pushes += np;
+    begin = end;
+  }
+  return chunks;
 }
 
 struct JitCache {
@@ -346,7 +435,8 @@ static std::vector<char> jit_compile(JitApi& api, const std::string& src, std::s
     *why = "hiprtcCreateProgram failed";
     return {};
   }
-  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
+  const char* ol = getenv("VX_JIT_OPT");   // experiments only: the optimisation level handed to hiprtc
+  const char* opts[] = {"--offload-arch=gfx950", ol ? ol : "-O3", "-std=c++17"};
   hiprtcResult rc = api.compile(pr, 3, opts);
   if (rc != HIPRTC_SUCCESS) {
     size_t ls = 0;
@@ -366,6 +456,17 @@ static std::vector<char> jit_compile(JitApi& api, const std::string& src, std::s
 }
 // The on-disk cache is only used when the directory is the caller's own and closed to others (mode 0700, owner = euid):
 // a code object read from it is executed on the GPU, so a directory other users can write to would let them inject code.
+static std::string jit_cache_file(JitApi& api, const char* dir, const std::string& src) {
+  // key: FNV-1a over the source (which embeds the prelude, so a library update misses) + the hiprtc version and the
+  // offload arch the blob was built with/for, so a ROCm upgrade never reuses a stale code object
+  uint64_t h = 1469598103934665603ULL;
+  for (unsigned char ch : src) h = (h ^ ch) * 1099511628211ULL;
+  int rtc_major = 0, rtc_minor = 0;
+  if (api.version) api.version(&rtc_major, &rtc_minor);
+  char name[128];
+  snprintf(name, sizeof name, "/vxjit-gfx950-rtc%d.%d-%016llx-%zu.hsaco", rtc_major, rtc_minor, (unsigned long long)h, src.size());
+  return std::string(dir) + name;
+}
 static bool jit_cache_dir_ok(const char* dir) {
   struct stat st;
   if (stat(dir, &st) != 0 || !S_ISDIR(st.st_mode)) return false;
@@ -377,9 +478,40 @@ static hipFunction_t jit_get_kernel(const std::string& src, const char* kernel_n
 static hipFunction_t jit_get(const std::vector<const uint64_t*>& progs, int nch, int device, std::string* why) {
   return jit_get_kernel(jit_source(progs, nch), "vx_program_gates", device, why);
 }
-// the compiled evaluator of one AIR program (stark.hip.h), or nullptr -> interpreter
-static hipFunction_t jit_air_get(const uint64_t* prog, int nch, int ncols, int device, std::string* why) {
-  return jit_get_kernel(jit_air_source(prog, nch, ncols), "vx_air_quotient", device, why);
+// compile (or find in the caches) every chunk WITHOUT loading it: needs no GPU — the `build` step of a host that proves later
+static int jit_air_precompile(const uint64_t* prog, int nch, int ncols, int* nchunks, std::string* why);
+// the compiled evaluator of one AIR program (stark.hip.h): one kernel per chunk; empty -> interpreter
+struct JitAirKernel {
+  hipFunction_t fn;
+  int push_begin, push_end;
+};
+static std::vector<JitAirKernel> jit_air_get(const uint64_t* prog, int nch, int ncols, int device, std::string* why) {
+  std::vector<JitAirKernel> out;
+  if (getenv("VX_NO_JIT")) {
+    *why = "VX_NO_JIT is set";
+    return out;
+  }
+  // per (program, nch, ncols, device): the loaded kernels — generating a megabyte of source per proof just to look it up again
+  // cost more than the kernels take to run
+  static std::mutex mu;
+  static std::map<std::vector<uint64_t>, std::vector<JitAirKernel>> loaded;
+  std::vector<uint64_t> key = {(uint64_t)nch, (uint64_t)ncols, (uint64_t)device};
+  for (int pc = 0;; ++pc) {
+    key.push_back(prog[pc]);
+    if ((prog[pc] & 0xFF) == VX_OP_END) break;
+    if ((prog[pc] & 0xFF) == VX_OP_LDI) key.push_back(prog[++pc]);
+  }
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = loaded.find(key);
+  if (it != loaded.end()) return it->second;
+  if (jit_air_precompile(prog, nch, ncols, nullptr, why) < 0) return out;   // all missing chunks
+  for (const JitAirChunk& c : jit_air_chunks(prog, nch, ncols)) {
+    hipFunction_t fn = jit_get_kernel(c.src, "vx_air_quotient", device, why);
+    if (!fn) return {};
+    out.push_back(JitAirKernel{fn, c.push_begin, c.push_end});
+  }
+  loaded.emplace(std::move(key), out);
+  return out;
 }
 static hipFunction_t jit_get_kernel(const std::string& src, const char* kernel_name, int device, std::string* why) {
   if (getenv("VX_NO_JIT")) {
@@ -401,15 +533,7 @@ static hipFunction_t jit_get_kernel(const std::string& src, const char* kernel_n
   bool from_disk = false;
   if (const char* dir = getenv("VX_JIT_CACHE_DIR")) {
     if (jit_cache_dir_ok(dir)) {
-      // key: FNV-1a over the source (which embeds the prelude, so a library update misses) + the hiprtc version and the
-      // offload arch the blob was built with/for, so a ROCm upgrade never reuses a stale code object
-      uint64_t h = 1469598103934665603ULL;
-      for (unsigned char ch : src) h = (h ^ ch) * 1099511628211ULL;
-      int rtc_major = 0, rtc_minor = 0;
-      if (api.version) api.version(&rtc_major, &rtc_minor);
-      char name[128];
-      snprintf(name, sizeof name, "/vxjit-gfx950-rtc%d.%d-%016llx-%zu.hsaco", rtc_major, rtc_minor, (unsigned long long)h, src.size());
-      cache_file = std::string(dir) + name;
+      cache_file = jit_cache_file(api, dir, src);
       if (cit == C.code.end()) {
         if (FILE* f = fopen(cache_file.c_str(), "rb")) {
           std::vector<char> code;
@@ -469,4 +593,71 @@ static hipFunction_t jit_get_kernel(const std::string& src, const char* kernel_n
   }
   C.functions[{src, device}] = fn;
   return fn;
+}
+
+static int jit_air_precompile(const uint64_t* prog, int nch, int ncols, int* nchunks, std::string* why) {
+  JitApi& api = jit_api();
+  if (!api.ok) {
+    *why = "libhiprtc.so not available";
+    return -1;
+  }
+  const std::vector<JitAirChunk> chunks = jit_air_chunks(prog, nch, ncols);
+  if (nchunks) *nchunks = (int)chunks.size();
+  JitCache& C = jit_cache();
+  const char* dir = getenv("VX_JIT_CACHE_DIR");
+  const bool disk = dir && jit_cache_dir_ok(dir);
+  // which chunks are in neither cache
+  std::vector<size_t> todo;
+  for (size_t i = 0; i < chunks.size(); ++i) {
+    std::lock_guard<std::mutex> lk(C.mu);
+    if (C.code.count(chunks[i].src)) continue;
+    if (disk) {
+      if (FILE* f = fopen(jit_cache_file(api, dir, chunks[i].src).c_str(), "rb")) {
+        std::vector<char> code;
+        char buf[65536];
+        size_t n;
+        while ((n = fread(buf, 1, sizeof buf, f)) > 0) code.insert(code.end(), buf, buf + n);
+        fclose(f);
+        if (code.size() > 64) {
+          C.code.emplace(chunks[i].src, std::move(code));
+          continue;
+        }
+      }
+    }
+    todo.push_back(i);
+  }
+  // the chunks are independent translation units: compile them on a few host threads (VX_JIT_THREADS, default 1: hiprtc 7.x serialises compilations behind one lock — measured 48 s with 1, 4 and 8 threads)
+  const char* te = getenv("VX_JIT_THREADS");
+  const size_t nthreads = std::max<size_t>(1, std::min<size_t>(todo.size(), te && atoi(te) > 0 ? (size_t)atoi(te) : 1));
+  std::vector<std::vector<char>> objs(todo.size());
+  std::vector<std::string> errs(todo.size());
+  std::atomic<size_t> next{0};
+  auto worker = [&]() {
+    for (;;) {
+      const size_t k = next.fetch_add(1);
+      if (k >= todo.size()) return;
+      objs[k] = jit_compile(api, chunks[todo[k]].src, &errs[k]);
+    }
+  };
+  std::vector<std::thread> pool;
+  for (size_t t = 1; t < nthreads; ++t) pool.emplace_back(worker);
+  worker();
+  for (auto& t : pool) t.join();
+  for (size_t k = 0; k < todo.size(); ++k) {
+    if (objs[k].empty()) {
+      *why = errs[k];
+      return -1;
+    }
+    if (disk) {
+      const std::string cache_file = jit_cache_file(api, dir, chunks[todo[k]].src), tmp = cache_file + ".tmp" + std::to_string((long)getpid());
+      if (FILE* f = fopen(tmp.c_str(), "wb")) {
+        const bool ok = fwrite(objs[k].data(), 1, objs[k].size(), f) == objs[k].size();
+        fclose(f);
+        if (!ok || rename(tmp.c_str(), cache_file.c_str()) != 0) remove(tmp.c_str());
+      }
+    }
+    std::lock_guard<std::mutex> lk(C.mu);
+    C.code.emplace(chunks[todo[k]].src, std::move(objs[k]));
+  }
+  return (int)todo.size();
 }

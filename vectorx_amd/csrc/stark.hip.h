@@ -16,6 +16,8 @@
 // StarkProofWithPublicInputs (starky v0.2.0 has no to_bytes): trace_cap | quotient_cap | local | next | quotient
 // openings | FriProof (write_fri_proof) | public inputs.
 #pragma once
+#include <map>
+#include <mutex>
 #include "prover.hip.h"
 #include "verifier.h"
 
@@ -33,7 +35,25 @@ struct AirParams {  // mirrored textually in jit.hip.h::jit_air_source
   u64 zh[VX_MAX_RATE], zh_inv[VX_MAX_RATE];  // Z_H on coset block z, and its inverse
   u64 last, n_inv;                            // g^-1 (the last element of H), 1/n
   u64* out;                                   // [nch][rows]
+  u64* rowfac;                                // [3][rows]: z_last, L_first, L_last per row (compiled chunks read them)
+  u64 tail_pow[VX_MAX_CHALLENGES];            // compiled chunks: alpha^(constraints after the chunk), see jit.hip.h
 };
+// z_last = x - g^-1, L_first, L_last on every row of the quotient domain: one field inversion per row, computed ONCE for all
+// the chunk kernels of a compiled AIR program (the interpreter below computes them inline).
+__global__ __launch_bounds__(256) void air_row_factors_kernel(AirParams p) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= p.rows) return;
+  const int LG = p.log_n + p.rate_bits;
+  const u32 z = (u32)(i >> p.log_n);
+  const u32 j = bitrev32((u32)i, LG);
+  const u64 x = gl_mul7(root_pow24(p.root_lo, p.root_hi, j << (ROOT_TABLE_LOG - LG)));
+  const u64 z_last = gl_sub(x, p.last), xm1 = gl_sub(x, 1);
+  const u64 inv_both = gl_inv(gl_mul(z_last, xm1));
+  const u64 zh_n = gl_mul(p.zh[z], p.n_inv);
+  p.rowfac[i] = z_last;
+  p.rowfac[p.rows + i] = gl_mul(zh_n, gl_mul(inv_both, z_last));
+  p.rowfac[2 * p.rows + i] = gl_mul(gl_mul(zh_n, p.last), gl_mul(inv_both, xm1));
+}
 // One thread per row of the quotient domain.  Registers of the program live in per-thread private memory (interpreter).
 __global__ __launch_bounds__(256) void air_quotient_kernel(AirParams p) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -172,14 +192,29 @@ static std::vector<vxh::u64> stark_statement(const vx_stark_desc* d, const Stark
                               (vxh::u64)d->num_aux_challenges, (vxh::u64)d->num_public_inputs, (vxh::u64)d->num_aux_public_inputs,
                               (vxh::u64)sh.arity_bits.size()};
   for (int a : sh.arity_bits) st.push_back((vxh::u64)a);
-  std::vector<vxh::u64> limbs;
-  limbs.reserve(2 * (size_t)d->program_len);
+  // Poseidon digest of the program: ~4 k host permutations for a chip-sized AIR, so it is computed once per distinct program
+  // and process (the words up to END are the key)
+  static std::mutex mu;
+  static std::map<std::vector<uint64_t>, vxh::Hash4> digests;
+  std::vector<uint64_t> key;
+  key.reserve((size_t)d->program_len);
   for (int pc = 0; pc < d->program_len; ++pc) {
-    limbs.push_back(d->program[pc] & 0xFFFFFFFFu), limbs.push_back(d->program[pc] >> 32);
+    key.push_back(d->program[pc]);
     if ((d->program[pc] & 0xFF) == VX_OP_END) break;   // words after END are not part of the AIR
-    if ((d->program[pc] & 0xFF) == VX_OP_LDI && pc + 1 < d->program_len) ++pc, limbs.push_back(d->program[pc] & 0xFFFFFFFFu), limbs.push_back(d->program[pc] >> 32);
+    if ((d->program[pc] & 0xFF) == VX_OP_LDI && pc + 1 < d->program_len) key.push_back(d->program[++pc]);
   }
-  const vxh::Hash4 ph = vxh::hash_no_pad(limbs.data(), limbs.size());
+  vxh::Hash4 ph;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = digests.find(key);
+    if (it == digests.end()) {
+      std::vector<vxh::u64> limbs;
+      limbs.reserve(2 * key.size());
+      for (uint64_t w : key) limbs.push_back(w & 0xFFFFFFFFu), limbs.push_back(w >> 32);
+      it = digests.emplace(key, vxh::hash_no_pad(limbs.data(), limbs.size())).first;
+    }
+    ph = it->second;
+  }
   st.insert(st.end(), ph.e, ph.e + 4);
   st.insert(st.end(), canonical_pis, canonical_pis + d->num_public_inputs);
   return st;
@@ -333,11 +368,19 @@ static int stark_finish_impl(vx_stark_session& s, const u64* aux_in, bool aux_on
       // the AIR program compiled to native code (jit.hip.h: same lowering as gate programs — fused multiply-adds, lazy
       // canonicalisation, registers promoted to VGPRs); the interpreter is the fallback when hiprtc is not there
       std::string why;
-      hipFunction_t fn = jit_air_get(d->program, nch, ncols, c->device, &why);
-      ProfScope ps(c, fn ? "air_quotient_eval_jit" : "air_quotient_eval", 8.0 * (double)rows * 2.0 * ncols);
-      if (fn) {
-        void* args[] = {&ap};
-        HIPCHK(hipModuleLaunchKernel(fn, (unsigned)((rows + 255) / 256), 1, 1, 256, 1, 1, 0, c->stream, args, nullptr));
+      const std::vector<JitAirKernel> chunks = jit_air_get(d->program, nch, ncols, c->device, &why);
+      ProfScope ps(c, !chunks.empty() ? "air_quotient_eval_jit" : "air_quotient_eval", 8.0 * (double)rows * 2.0 * ncols);
+      if (!chunks.empty()) {
+        u64* rowfac = S.get(3 * rows);
+        if (!rowfac) return vx_fail(VX_E_NOMEM, "stark: out of device memory (row factors)");
+        ap.rowfac = rowfac;
+        hipLaunchKernelGGL(air_row_factors_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, c->stream, ap);
+        HIPCHK(hipMemsetAsync(qv, 0, (size_t)nch * rows * 8, c->stream));
+        for (const JitAirKernel& ck : chunks) {   // every chunk ADDS its part: acc_chunk * alpha^(constraints after the chunk) / Z_H
+          for (int i = 0; i < VX_MAX_CHALLENGES; ++i) ap.tail_pow[i] = pow(alphas[i], (u64)(sh.num_constraints - ck.push_end));
+          void* args[] = {&ap};
+          HIPCHK(hipModuleLaunchKernel(ck.fn, (unsigned)((rows + 255) / 256), 1, 1, 256, 1, 1, 0, c->stream, args, nullptr));
+        }
       } else {
         hipLaunchKernelGGL(air_quotient_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, c->stream, ap);
         HIPCHK(hipGetLastError());

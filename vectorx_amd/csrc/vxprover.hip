@@ -810,6 +810,20 @@ int vx_stark_finish(vx_stark_session* s, const uint64_t* aux_columns, int aux_on
                     size_t* out_len) {
   return vx_stark_finish2(s, aux_columns, aux_on_device, nullptr, pow_witness_hint, out_buf, out_len);
 }
+int vx_stark_precompile(const vx_stark_desc* d, int* num_chunks_out) {
+  if (!d) return vx_fail(VX_E_INVALID, "vx_stark_precompile: NULL argument");
+  try {
+    StarkShape sh;
+    const std::string bad = stark_check(d, &sh);
+    if (!bad.empty()) return vx_fail(VX_E_INVALID, "vx_stark_precompile: %s", bad.c_str());
+    std::string why;
+    const int rc = jit_air_precompile(d->program, d->num_challenges, d->num_columns, num_chunks_out, &why);
+    if (rc < 0) return vx_fail(VX_E_INVALID, "vx_stark_precompile: %s", why.c_str());
+    return rc;
+  } catch (const std::exception& e) {
+    return vx_fail(VX_E_INVALID, "vx_stark_precompile: %s", e.what());
+  }
+}
 int vx_stark_session_trace_cap(vx_stark_session* s, uint64_t* cap_out) {
   if (!s || !cap_out) return vx_fail(VX_E_INVALID, "vx_stark_session_trace_cap: NULL argument");
   memcpy(cap_out, s->trace_cap.data(), s->trace_cap.size() * 8);

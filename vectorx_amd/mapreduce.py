@@ -150,14 +150,17 @@ class GpuProver:
     """One circuit kind on one GPU: circuit loaded once (constants_sigmas resident), one device-resident witness per
     job; `prove` patches the two witness rows that depend on the public inputs and calls vx_prove."""
 
-    def __init__(self, ctx, kind, log_n, jobs, poseidon_percent=50, extra_lanes=()):
+    def __init__(self, ctx, kind, log_n, jobs, poseidon_percent=50, extra_lanes=(), distinct_witnesses=None):
         """extra_lanes: more contexts on the SAME GPU; lane k proves on its own stream with its own copy of the circuit
-        (run_dag(in_flight=...)); witnesses are device-global and shared."""
+        (run_dag(in_flight=...)).  distinct_witnesses = None: every job has its own generated witness (device-global, shared by
+        the lanes).  distinct_witnesses = k: only k base witnesses are generated per circuit kind and job j proves base witness
+        j mod k with ITS public inputs patched in — every lane then holds its own copies (two jobs in flight must never patch
+        the same buffer).  Same proving work per job, a fraction of the (untimed, CPU) witness generation: the bench's DAG leg."""
         import threading
 
         import vectorx_amd as vx
         from vectorx_amd.synth import SynthCircuit
-        self.ctx, self.n = ctx, 1 << log_n
+        self.ctx, self.n, self.kind = ctx, 1 << log_n, kind
         self.lanes = [ctx] + list(extra_lanes)
         self._lock = threading.Lock()
         circuit_seed = {"map": 101, "reduce": 202, "outer": 303}[kind]
@@ -165,17 +168,32 @@ class GpuProver:
         self.circuits = [vx.Circuit(c, self.sc.desc_ptr) for c in self.lanes]
         self.circuit = self.circuits[0]
         self.wit = {}
-        for (li, j) in jobs:
-            sj = SynthCircuit(log_n, seed=circuit_seed, poseidon_percent=poseidon_percent, witness_seed=1000 * li + j + 1)
-            w = sj.witness()
-            d = ctx.alloc(w.nbytes)
-            ctx.upload(d, w)
-            self.wit[(li, j)] = d
-            sj.free()
+        self.distinct = distinct_witnesses
+        self.lane_wit = []
+        if distinct_witnesses is None:
+            for (li, j) in jobs:
+                sj = SynthCircuit(log_n, seed=circuit_seed, poseidon_percent=poseidon_percent, witness_seed=1000 * li + j + 1)
+                w = sj.witness()
+                d = ctx.alloc(w.nbytes)
+                ctx.upload(d, w)
+                self.wit[(li, j)] = d
+                sj.free()
+        else:
+            k = max(1, min(distinct_witnesses, len(jobs)))
+            self.distinct = k
+            self.lane_wit = [[] for _ in self.lanes]
+            for b in range(k):
+                sj = SynthCircuit(log_n, seed=circuit_seed, poseidon_percent=poseidon_percent, witness_seed=7000 + b)
+                w = sj.witness()
+                for li_, c in enumerate(self.lanes):
+                    d = ctx.alloc(w.nbytes)
+                    ctx.upload(d, w)
+                    self.lane_wit[li_].append(d)
+                sj.free()
         self.sc.release_host_buffers(witness=True, preprocessed=True)
 
     def prove(self, key, public_inputs, lane=0):
-        d = self.wit[key]
+        d = self.wit[key] if self.distinct is None else self.lane_wit[lane][key[1] % self.distinct]
         with self._lock:                      # the generator keeps the current public inputs: one caller at a time
             r0, r2 = self.sc.patch_public_inputs(public_inputs)
         ctx = self.lanes[lane]
@@ -186,6 +204,9 @@ class GpuProver:
     def free(self):
         for d in self.wit.values():
             self.ctx.free(d)
+        for lane in self.lane_wit:
+            for d in lane:
+                self.ctx.free(d)
         for c in self.circuits:
             c.free()
         self.sc.free()
