@@ -232,26 +232,31 @@ def main():
                    "ms_per_proof": round(ms, 2), "gperms_per_s": round(perms / (ms * 1e-3) / 1e9, 3)}
             try:
                 # per-permutation VALU instruction count: PMC-measured (SQ_INSTS_VALU), reproduced by the loop-weighted static
-                # histogram of the gfx950 assembly (tools/alu_ceiling.py -> profiles/r02_alu_ceiling.json)
-                ceil_info = json.loads((ROOT / "profiles" / "r02_alu_ceiling.json").read_text())
+                # histogram of the gfx950 assembly (tools/alu_ceiling.py -> profiles/r03_alu_ceiling.json)
+                ceil_info = json.loads((ROOT / "profiles" / "r03_alu_ceiling.json").read_text())
                 ipp = float(ceil_info["valu_insts_per_perm_pmc"] or ceil_info["valu_insts_per_perm_static"])
-                ghz = hash_clock_ghz           # sampled INSIDE the timed hash_leaves launches (s_memtime / s_memrealtime per sampled wave)
                 achieved = perms / (ms * 1e-3) * ipp / 64.0
-                # ceiling: one VALU instruction per wavefront per SIMD per QUAD-cycle — the unit the SQ's own counters use
-                # (SQ_ACTIVE_INST_VALU == SQ_INSTS_VALU for this kernel); single-opcode loops of its instruction classes
-                # measure 4.4 cycles (profiles/r02_ubench_int.md), mixed streams 3.8-4.1: 4.0 is the issue model.
-                ceiling = ceil_info["simds"] * ghz * 1e9 / 4.0
-                alu.update({"valu_insts_per_perm": ipp, "clock_ghz_measured_in_kernel": round(ghz, 3),
-                            "achieved_wave_inst_per_s": achieved, "ceiling_wave_inst_per_s": ceiling,
+                # THE CEILING IS A BOUND: the fastest rate ANY measured instruction stream containing this kernel's
+                # instruction classes reached (profiles/r03_ubench_int.md: `best_mixed_stream_cycles` per wavefront-instruction per
+                # SIMD) at the device's MAXIMUM engine clock — one clock source, an upper limit of whatever the kernel ran at —
+                # so frac <= 1 by construction.
+                max_ghz = torch.cuda.get_device_properties(local_rank).clock_rate / 1e6
+                c_best = float(ceil_info["best_mixed_stream_cycles"])
+                ceiling = ceil_info["simds"] * max_ghz * 1e9 / c_best
+                ghz = hash_clock_ghz           # sampled INSIDE the timed hash_leaves launches (s_memtime / s_memrealtime per sampled wave)
+                quad = ceil_info["simds"] * ghz * 1e9 / 4.0
+                alu.update({"valu_insts_per_perm": ipp, "achieved_wave_inst_per_s": achieved, "ceiling_wave_inst_per_s": ceiling,
                             "frac": round(achieved / ceiling, 4),
-                            # the in-kernel sample (s_memtime over s_memrealtime) reads ~4-5 % below the clock the GRBM counter
-                            # gives for the same kernel, which is why frac exceeds 1; the rate this run would have at the PMC
-                            # run's clock is given for comparison (same kernel, separate run: profiles/r02_pmc_sq.md)
+                            "ceiling_model": f"1024 SIMDs x device max clock {max_ghz:.2f} GHz / {c_best} cycles per wavefront-instruction (the best "
+                                             "mixed slow-class stream tools/ubench_int.hip measured): a bound, not a fit",
+                            # the round-2 figure, kept: one VALU instruction per wavefront per SIMD per QUAD-cycle at the clock sampled in
+                            # the kernel (SQ_ACTIVE_INST_VALU == SQ_INSTS_VALU for this kernel); reads 1.03-1.09 because the in-kernel
+                            # sample is ~4 % below the GRBM clock and a few fast-class instructions pair up
+                            "frac_quad_issue_model": round(achieved / quad, 4), "clock_ghz_measured_in_kernel": round(ghz, 3),
                             "frac_at_pmc_run_clock": (round(achieved / (ceil_info["simds"] * float(ceil_info["pmc_run"]["clock_ghz"]) * 1e9 / 4.0), 4)
                                                       if (ceil_info.get("pmc_run") or {}).get("clock_ghz") else None),
-                            "ceiling_model": "1024 SIMDs x measured clock / 4 cycles per wavefront-instruction (quad-cycle VALU issue)",
                             "ubench_cycles_per_inst": ceil_info["cycles"],
-                            "source": "profiles/r02_alu_ceiling.json (tools/alu_ceiling.py), profiles/r02_ubench_int.md, profiles/r02_pmc_sq.md"})
+                            "source": "profiles/r03_alu_ceiling.json (tools/alu_ceiling.py), profiles/r03_ubench_int.md, profiles/r03_pmc_sq_prove.md"})
             except Exception as e:  # the bench line must not die on a missing evidence file
                 alu["ceiling_error"] = repr(e)
         sharded_mode = args.mode == "sharded" and world > 1 and args.workload == "prove"
