@@ -348,6 +348,8 @@ int vx_stark_finish(vx_stark_session* session, const uint64_t* aux_columns, int 
                     uint8_t* out_buf, size_t* out_len);
 void vx_stark_session_free(vx_stark_session* session);
 int vx_stark_verify(const vx_stark_desc* desc, const uint64_t* public_inputs, const uint8_t* proof, size_t proof_len);
+/* The same for the constraint-program gates of a circuit (one kernel per program gate): returns the number compiled now. */
+int vx_circuit_precompile(const vx_circuit_desc* desc, int* num_program_gates_out);
 /* Compile an AIR program ahead of time: every chunk of the program (jit.hip.h cuts long programs into kernels of ~1200
  * instructions) is compiled with hiprtc into the process cache and, when VX_JIT_CACHE_DIR names a private directory, onto disk
  * — needs NO GPU, so a `build` step can run where the circuits are compiled and the proving host only loads code objects.

@@ -114,3 +114,30 @@ def test_two_round_air_lookup_soundness(oracle):
     assert e.value.code == vx.VX_E_INVALID
     stark.desc.num_aux_columns = 1
     stark.verify(pis, proof)
+
+
+def test_programs_can_be_compiled_ahead_of_time_without_a_gpu():
+    """vx_stark_precompile / vx_circuit_precompile: hiprtc needs no device, so the `build` step of a host can leave code objects
+    (VX_JIT_CACHE_DIR) for the proving machine.  Long AIR programs are cut into chunks (csrc/jit.hip.h)."""
+    import os
+    from vectorx_amd.synth import SynthCircuit
+    stark, _, _ = cubic(6)
+    first, chunks = stark.precompile()
+    assert chunks == 1 and first in (0, 1)
+    assert stark.precompile() == (0, 1)                       # now in the process cache
+    os.environ["VX_JIT_AIR_CHUNK"] = "4"                      # a tiny chunk limit: the 3-constraint program splits, every chunk compiles
+    try:
+        stark2, _, _ = mulchain(5, groups=2)
+        done, chunks = stark2.precompile()
+        assert chunks >= 3 and 0 <= done <= chunks
+    finally:
+        del os.environ["VX_JIT_AIR_CHUNK"]
+    sc = SynthCircuit(5, seed=2, poseidon_percent=40, flags=1)
+    done, total = vx.circuit_precompile(sc.desc_ptr)
+    assert total == 2 and 0 <= done <= 2
+    assert vx.circuit_precompile(sc.desc_ptr) == (0, 2)
+    plain = SynthCircuit(5, seed=2, poseidon_percent=40)
+    assert vx.circuit_precompile(plain.desc_ptr) == (0, 0)
+    sc.desc.num_gates = 0
+    with pytest.raises(vx.VxError):
+        vx.circuit_precompile(sc.desc_ptr)

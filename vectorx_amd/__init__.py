@@ -109,6 +109,7 @@ _SIGNATURES = {
     "vx_stark_finish": (_i, [_vp, _vp, _i, _vp, _vp, ctypes.POINTER(_sz)]),
     "vx_stark_session_free": (None, [_vp]),
     "vx_stark_precompile": (_i, [_vp, ctypes.POINTER(_i)]),
+    "vx_circuit_precompile": (_i, [_vp, ctypes.POINTER(_i)]),
     "vx_stark_session_trace_cap": (_i, [_vp, _vp]),
     "vx_stark_set_aux_challenges": (_i, [_vp, _vp]),
     "vx_stark_finish2": (_i, [_vp, _vp, _i, _vp, _vp, _vp, ctypes.POINTER(_sz)]),
@@ -542,6 +543,16 @@ def stark_joint_challenges(caps, cap_heights, n: int) -> np.ndarray:
     out = np.zeros(n, dtype=np.uint64)
     _chk(lib().vx_stark_joint_challenges(ctypes.cast(arr, _vp), ctypes.cast(hs, _vp), len(caps), n, out.ctypes.data))
     return out
+
+
+def circuit_precompile(desc_ptr) -> tuple:
+    """`vx_circuit_precompile`: compile the constraint-program gates of a circuit with hiprtc ahead of time (no GPU needed; with
+    VX_JIT_CACHE_DIR the code objects persist) -> (compiled now, program gates)"""
+    n = _i(0)
+    rc = lib().vx_circuit_precompile(ctypes.cast(desc_ptr, _vp), ctypes.byref(n))
+    if rc < 0:
+        _chk(rc)
+    return rc, n.value
 
 
 def circuit_serialize(desc_ptr, constants_sigmas_cap=None, with_preprocessed=True) -> bytes:

@@ -42,9 +42,10 @@ static std::string jit_limits_defines() {
 struct JitGateRt {
   int gate_index, selector_index, group_start, group_end;
 };
-struct JitGateParams {  // mirrored textually in jit_source()
+struct JitGateParams {  // mirrored textually in jit_gate_source()
   const u64 *cs, *wires;
   const u64* alpha_pows;
+  const Limbs3x2* alpha_limbs;   // the same powers pre-split for carry-free accumulation (poseidon.hip.h dot3)
   u64* out;
   size_t N, rows, row_base, stride_w;
   int log_n, rate_bits, num_selectors, nch;
@@ -52,7 +53,7 @@ struct JitGateParams {  // mirrored textually in jit_source()
   int const_base, pad_;  // first gate constant among the preprocessed columns: num_selectors + num_lookup_selectors
   u64 pih[4];
   u64 zh_inv[VX_MAX_RATE];
-  JitGateRt g[VX_MAX_PROGRAM_GATES];
+  JitGateRt g;                   // the gate this launch evaluates (one kernel per program gate)
 };
 
 static const char* JIT_PRELUDE =
@@ -213,8 +214,10 @@ static void jit_emit_code(std::ostringstream& s, std::vector<JitIns> code, int n
           if (nch > 1) s << "    a1 = gl_mad(a1, p.alphas[1], t);\n";
           s << "  }\n";
         } else {
-          s << "  a0 = gl_mad(R[" << I.a << "], AP[" << k << "], a0);\n";
-          if (nch > 1) s << "  a1 = gl_mad(R[" << I.a << "], AP[" << (VX_ALPHA_POWS + k) << "], a1);\n";
+          // carry-free accumulation against the pre-split alpha powers (12 multiply-adds for both challenges instead of two
+          // 18-instruction fused multiply-add-reduces): the native quotient kernel's acc_push
+          s << "  dot3_mac(A0, R[" << I.a << "], AL[" << k << "]);\n";
+          if (nch > 1) s << "  dot3_mac(A1, R[" << I.a << "], AL[" << (VX_ALPHA_POWS + k) << "]);\n";
         }
         ++k;
         break;
@@ -228,38 +231,42 @@ static void jit_emit_code(std::ostringstream& s, std::vector<JitIns> code, int n
   }
 }
 
-// HIP source of one gate's block inside vx_program_gates
-static void jit_gate_block(std::ostringstream& s, const uint64_t* prog, int nch, int slot) {
-  s << "  {  // program gate, slot " << slot << "\n"
-       "    const JitGateRt G = p.g[" << slot << "];\n"
-       "    const u64 s = CS[(size_t)G.selector_index * N + i];\n"
-       "    u64 filter = 1;\n"
-       "    for (int q = G.group_start; q < G.group_end; ++q)\n"
-       "      if (q != G.gate_index) filter = gl_mul(filter, gl_sub((u64)q, s));\n"
-       "    if (nsel > 1) filter = gl_mul(filter, gl_sub(0xFFFFFFFFULL, s));\n"
-       "    u64 a0 = 0, a1 = 0;\n"
-       "    u64 R[VX_PROGRAM_REGS];\n";
-  jit_emit_program(s, prog, nch, false);
-  s << "    t0 = gl_mad(filter, a0, t0);\n";
-  if (nch > 1) s << "    t1 = gl_mad(filter, a1, t1);\n";
-  s << "  }\n";
+// HIP source of the kernel of ONE program gate (round 3: one kernel per gate — the fused kernel of rounds 1-2 kept values
+// of several gates live at once and spilled 1 kB per lane; a gate on its own gets the whole register file, compiles in a
+// fraction of the time, and is cached per PROGRAM, so circuits that share gates share code objects).
+static const char* JIT_DOT3 = R"VXJIT(
+struct Limbs3x2 { u32 lo[3]; u32 hi[3]; };
+struct dot3 { u64 s0, s1, s2; };
+GLD void dot3_mac(dot3& D, u64 a, const Limbs3x2& b) {
+  const u32 a0 = (u32)a, a1 = (u32)(a >> 32);
+  D.s0 += (u64)a0 * b.lo[0];
+  D.s1 += (u64)a0 * b.lo[1];
+  D.s2 += (u64)a0 * b.lo[2];
+  D.s0 += (u64)a1 * b.hi[0];
+  D.s1 += (u64)a1 * b.hi[1];
+  D.s2 += (u64)a1 * b.hi[2];
 }
-
-// HIP source of the kernel that evaluates all program gates of a circuit.
-static std::string jit_source(const std::vector<const uint64_t*>& progs, int nch) {
+GLD u64 dot3_reduce_nc(const dot3& D) {
+  typedef unsigned __int128 u128;
+  const u128 V = (u128)D.s0 + ((u128)D.s1 << 22) + ((u128)D.s2 << 44);
+  return gl_reduce128_nc((u64)V, (u64)(V >> 64));
+}
+)VXJIT";
+static std::string jit_gate_source(const uint64_t* prog, int nch) {
   std::ostringstream s;
-  // Occupancy bound: without one the compiler keeps every wire it has loaded live across the gate blocks, takes >256
-  // VGPRs and runs one wave per SIMD (measured: 15.9 ms for 1947 program words at n = 2^20); 4 blocks per CU (<= 128
-  // VGPRs, like the native quotient kernel) gives 6.7 ms.
+  // Occupancy bound: without one the compiler keeps every wire it has loaded live, takes >256 VGPRs and runs one wave per SIMD
+  // (measured in round 1: 15.9 ms instead of 6.7); 4 blocks per CU = <= 128 VGPRs, like the native gate kernel.
   const char* bpc = getenv("VX_JIT_BLOCKS_PER_CU");
   s << "typedef unsigned long long uint64_t;\ntypedef unsigned int uint32_t;\n#define VX_JIT_BLOCKS_PER_CU " << (bpc ? atoi(bpc) : 4) << "\n"
-    << jit_limits_defines() << JIT_PRELUDE << R"VXJIT(
+    << "#define VX_ALPHA_POWS " << VX_ALPHA_POWS << "\n"
+    << jit_limits_defines() << JIT_PRELUDE << JIT_DOT3 << R"VXJIT(
 struct JitGateRt {
   int gate_index, selector_index, group_start, group_end;
 };
 struct JitGateParams {
   const u64 *cs, *wires;
   const u64* alpha_pows;
+  const Limbs3x2* alpha_limbs;
   u64* out;
   size_t N, rows, row_base, stride_w;
   int log_n, rate_bits, num_selectors, nch;
@@ -267,9 +274,9 @@ struct JitGateParams {
   int const_base, pad_;
   u64 pih[4];
   u64 zh_inv[VX_MAX_RATE];
-  JitGateRt g[VX_MAX_PROGRAM_GATES];
+  JitGateRt g;
 };
-extern "C" __global__ __launch_bounds__(256, VX_JIT_BLOCKS_PER_CU) void vx_program_gates(JitGateParams p) {
+extern "C" __global__ __launch_bounds__(256, VX_JIT_BLOCKS_PER_CU) void vx_program_gate(JitGateParams p) {
   const size_t il = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (il >= p.rows) return;
   const size_t N = p.N, SW = p.stride_w, i = il + p.row_base;
@@ -277,15 +284,22 @@ extern "C" __global__ __launch_bounds__(256, VX_JIT_BLOCKS_PER_CU) void vx_progr
   const u32 r = p.rate_bits ? (__brev(z) >> (32 - p.rate_bits)) : 0u;
   const u64* __restrict__ CS = p.cs;
   const u64* __restrict__ W = p.wires;
-  const u64* __restrict__ AP = p.alpha_pows + p.base_idx;
+  const Limbs3x2* __restrict__ AL = p.alpha_limbs + p.base_idx;
   const int nsel = p.num_selectors, cbase = p.const_base;
-  u64 t0 = 0, t1 = 0;
+  const JitGateRt G = p.g;
+  const u64 s = CS[(size_t)G.selector_index * N + i];
+  u64 filter = 1;
+  for (int q = G.group_start; q < G.group_end; ++q)
+    if (q != G.gate_index) filter = gl_mul(filter, gl_sub((u64)q, s));
+  if (nsel > 1) filter = gl_mul(filter, gl_sub(0xFFFFFFFFULL, s));
+  dot3 A0 = {0, 0, 0}, A1 = {0, 0, 0};
+  u64 R[VX_PROGRAM_REGS];
 )VXJIT";
-  for (size_t q = 0; q < progs.size(); ++q) jit_gate_block(s, progs[q], nch, (int)q);
-  s << "  const u64 zi = p.zh_inv[r];\n"
-       "  { u64* o = p.out + il; *o = gl_add(*o, gl_mul(t0, zi)); }\n";
-  if (nch > 1) s << "  { u64* o = p.out + SW + il; *o = gl_add(*o, gl_mul(t1, zi)); }\n";
-  s << "}\n";
+  jit_emit_program(s, prog, nch, false);
+  s << "  const u64 zi = gl_mul(p.zh_inv[r], filter);\n"
+       "  { u64* o = p.out + il; *o = gl_add(*o, gl_mul(dot3_reduce_nc(A0), zi)); }\n";
+  if (nch > 1) s << "  { u64* o = p.out + SW + il; *o = gl_add(*o, gl_mul(dot3_reduce_nc(A1), zi)); }\n";
+  s << "  (void)A1; (void)cbase;\n}\n";
   return s.str();
 }
 
@@ -475,8 +489,8 @@ static bool jit_cache_dir_ok(const char* dir) {
 
 // Returns the kernel for this gate set on `device`, or nullptr (with *why set) when it cannot be compiled / loaded.
 static hipFunction_t jit_get_kernel(const std::string& src, const char* kernel_name, int device, std::string* why);
-static hipFunction_t jit_get(const std::vector<const uint64_t*>& progs, int nch, int device, std::string* why) {
-  return jit_get_kernel(jit_source(progs, nch), "vx_program_gates", device, why);
+static hipFunction_t jit_get_gate(const uint64_t* prog, int nch, int device, std::string* why) {
+  return jit_get_kernel(jit_gate_source(prog, nch), "vx_program_gate", device, why);
 }
 // compile (or find in the caches) every chunk WITHOUT loading it: needs no GPU — the `build` step of a host that proves later
 static int jit_air_precompile(const uint64_t* prog, int nch, int ncols, int* nchunks, std::string* why);
@@ -595,38 +609,37 @@ static hipFunction_t jit_get_kernel(const std::string& src, const char* kernel_n
   return fn;
 }
 
-static int jit_air_precompile(const uint64_t* prog, int nch, int ncols, int* nchunks, std::string* why) {
+// compile every source that is in neither cache (process map, VX_JIT_CACHE_DIR): no device needed.  Returns how many were compiled.
+static int jit_precompile_sources(const std::vector<const std::string*>& srcs, std::string* why) {
   JitApi& api = jit_api();
   if (!api.ok) {
     *why = "libhiprtc.so not available";
     return -1;
   }
-  const std::vector<JitAirChunk> chunks = jit_air_chunks(prog, nch, ncols);
-  if (nchunks) *nchunks = (int)chunks.size();
   JitCache& C = jit_cache();
   const char* dir = getenv("VX_JIT_CACHE_DIR");
   const bool disk = dir && jit_cache_dir_ok(dir);
-  // which chunks are in neither cache
   std::vector<size_t> todo;
-  for (size_t i = 0; i < chunks.size(); ++i) {
+  for (size_t i = 0; i < srcs.size(); ++i) {
     std::lock_guard<std::mutex> lk(C.mu);
-    if (C.code.count(chunks[i].src)) continue;
+    if (C.code.count(*srcs[i])) continue;
     if (disk) {
-      if (FILE* f = fopen(jit_cache_file(api, dir, chunks[i].src).c_str(), "rb")) {
+      if (FILE* f = fopen(jit_cache_file(api, dir, *srcs[i]).c_str(), "rb")) {
         std::vector<char> code;
         char buf[65536];
         size_t n;
         while ((n = fread(buf, 1, sizeof buf, f)) > 0) code.insert(code.end(), buf, buf + n);
         fclose(f);
         if (code.size() > 64) {
-          C.code.emplace(chunks[i].src, std::move(code));
+          C.code.emplace(*srcs[i], std::move(code));
           continue;
         }
       }
     }
     todo.push_back(i);
   }
-  // the chunks are independent translation units: compile them on a few host threads (VX_JIT_THREADS, default 1: hiprtc 7.x serialises compilations behind one lock — measured 48 s with 1, 4 and 8 threads)
+  // independent translation units: a few host threads (VX_JIT_THREADS, default 1: hiprtc 7.x serialises compilations behind
+  // one lock — measured 48 s with 1, 4 and 8 threads for the 13 chunks of the SHA-256 AIR)
   const char* te = getenv("VX_JIT_THREADS");
   const size_t nthreads = std::max<size_t>(1, std::min<size_t>(todo.size(), te && atoi(te) > 0 ? (size_t)atoi(te) : 1));
   std::vector<std::vector<char>> objs(todo.size());
@@ -636,7 +649,7 @@ static int jit_air_precompile(const uint64_t* prog, int nch, int ncols, int* nch
     for (;;) {
       const size_t k = next.fetch_add(1);
       if (k >= todo.size()) return;
-      objs[k] = jit_compile(api, chunks[todo[k]].src, &errs[k]);
+      objs[k] = jit_compile(api, *srcs[todo[k]], &errs[k]);
     }
   };
   std::vector<std::thread> pool;
@@ -649,7 +662,7 @@ static int jit_air_precompile(const uint64_t* prog, int nch, int ncols, int* nch
       return -1;
     }
     if (disk) {
-      const std::string cache_file = jit_cache_file(api, dir, chunks[todo[k]].src), tmp = cache_file + ".tmp" + std::to_string((long)getpid());
+      const std::string cache_file = jit_cache_file(api, dir, *srcs[todo[k]]), tmp = cache_file + ".tmp" + std::to_string((long)getpid());
       if (FILE* f = fopen(tmp.c_str(), "wb")) {
         const bool ok = fwrite(objs[k].data(), 1, objs[k].size(), f) == objs[k].size();
         fclose(f);
@@ -657,7 +670,22 @@ static int jit_air_precompile(const uint64_t* prog, int nch, int ncols, int* nch
       }
     }
     std::lock_guard<std::mutex> lk(C.mu);
-    C.code.emplace(chunks[todo[k]].src, std::move(objs[k]));
+    C.code.emplace(*srcs[todo[k]], std::move(objs[k]));
   }
   return (int)todo.size();
+}
+static int jit_air_precompile(const uint64_t* prog, int nch, int ncols, int* nchunks, std::string* why) {
+  const std::vector<JitAirChunk> chunks = jit_air_chunks(prog, nch, ncols);
+  if (nchunks) *nchunks = (int)chunks.size();
+  std::vector<const std::string*> srcs;
+  for (const JitAirChunk& c : chunks) srcs.push_back(&c.src);
+  return jit_precompile_sources(srcs, why);
+}
+// the gate programs of a circuit description (vx_circuit_precompile): one source per program gate
+static int jit_gates_precompile(const std::vector<const uint64_t*>& progs, int nch, std::string* why) {
+  std::vector<std::string> keep;
+  for (const uint64_t* pr : progs) keep.push_back(jit_gate_source(pr, nch));
+  std::vector<const std::string*> srcs;
+  for (const std::string& k : keep) srcs.push_back(&k);
+  return jit_precompile_sources(srcs, why);
 }

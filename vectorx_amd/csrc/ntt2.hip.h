@@ -161,7 +161,6 @@ struct Ntt2Params {
   // coefficient tile (one per coset of an LDE) are dispatched back to back on the SAME XCD — workgroups go to XCDs
   // round-robin, so block id = ((tile / 8) * nz + z) * 8 + tile % 8 — and 7 of the 8 reads hit that XCD's L2.
   int nz_fold;
-  u32 gx, gy, gz;   // the logical grid (one item per tile x column x coset); the launch itself has <= persist blocks
 };
 
 // LDS index of tile element (m, t): strided tiles are [m][t], contiguous tiles are [t][m]
@@ -202,139 +201,12 @@ GLD void ntt2_round_lds(u64* __restrict__ tile, const u64* __restrict__ W) {
   }
 }
 
-// Kernel: tiles of 2^13 elements, PERSISTENT blocks (round 3): the launch has at most p.persist blocks (two per CU) and block g
-// works through the items g, g + gridDim.x, ... of the original (x fastest, then y, then z) grid — the order the hardware would
-// have dispatched them in, so the XCD of an item (id mod 8) and the z-fold below are unchanged — and issues the global loads of
-// its NEXT tile's first round before the current tile's last round: the 16 operands (+ the two prescale table entries) are in
-// flight while the last round runs out of LDS, instead of being waited for at the top of a fresh block.
+// Kernel: one tile of 2^13 elements per block.
 //   STRIDED: stages [b_lo, b_lo+R_LOG) over T = 2^(13-R_LOG) adjacent low indices; else 2^(13-R_LOG) contiguous
 //            chunks of 2^R_LOG (final pass, b_lo == 0).
 //   IN_BITREV (first pass only): input stored in bit-reversed order.   PRE: prescale tables present.
-struct Ntt2Item {
-  u32 bz;
-  size_t base;
-  const u64* in;
-  u64* out;
-};
-template <int R_LOG, bool STRIDED>
-GLD Ntt2Item ntt2_item(const Ntt2Params& p, u32 w) {
-  constexpr int T_LOG = NTT2_TILE_LOG - R_LOG;
-  const u32 bx = w % p.gx, rest0 = w / p.gx, by = rest0 % p.gy;
-  Ntt2Item it;
-  it.bz = rest0 / p.gy;
-  size_t tile_id = bx;
-  if (p.nz_fold > 0) {
-    const u32 rest = bx >> 3;
-    it.bz = rest % (u32)p.nz_fold;
-    tile_id = (size_t)(rest / (u32)p.nz_fold) * 8 + (bx & 7);
-  }
-  if constexpr (STRIDED) {
-    const int span_log = p.b_lo + R_LOG;
-    const size_t tiles_per_span = (size_t)1 << (p.b_lo - T_LOG);
-    const size_t H = tile_id / tiles_per_span;
-    const size_t l0 = (tile_id % tiles_per_span) << T_LOG;
-    it.base = (H << span_log) | l0;
-  } else {
-    it.base = tile_id << NTT2_TILE_LOG;
-  }
-  it.in = p.in + (size_t)by * p.in_col_stride + (size_t)it.bz * p.in_z_stride;
-  it.out = p.out + (size_t)by * p.out_col_stride + (size_t)it.bz * p.out_z_stride;
-  return it;
-}
-// first-round operands of this thread: the raw global loads only (issued early), arithmetic in ntt2_r1_finish
-template <int R_LOG, bool STRIDED, bool IN_BITREV, bool PRE>
-GLD void ntt2_r1_load(const Ntt2Params& p, const Ntt2Item& it, u64 (&x)[16], u64& pre_a, u64& pre_b) {
-  constexpr int T_LOG = NTT2_TILE_LOG - R_LOG;
-  constexpr int LO = R_LOG - 4;
-  const u32 g = threadIdx.x;
-  u32 t, base_low;
-  if constexpr (STRIDED) {
-    t = g & ((1u << T_LOG) - 1);
-    base_low = g >> T_LOG;
-  } else {
-    base_low = g & ((1u << LO) - 1);
-    t = g >> LO;
-  }
-  if constexpr (STRIDED && IN_BITREV) {
-    const size_t l = (it.base & (((size_t)1 << p.b_lo) - 1)) + t;
-    const size_t g0 = ((size_t)bitrev32((u32)l, p.b_lo) << R_LOG) | bitrev32(base_low, R_LOG);
-    const ulonglong2* __restrict__ src = reinterpret_cast<const ulonglong2*>(it.in + g0);
-#pragma unroll
-    for (int h = 0; h < 8; ++h) {
-      const ulonglong2 v = src[h];                 // positions 2h, 2h+1 = rev4(q), rev4(q + 8) with q = rev3(h)
-      const int q = (int)rev_c<3>((u32)h);
-      x[q] = v.x;
-      x[q + 8] = v.y;
-    }
-    if constexpr (PRE) {
-      const u64* pre = p.pre + (size_t)it.bz * (((size_t)1 << (p.log_n - p.pre_bits)) + ((size_t)1 << p.pre_bits));
-      const size_t j0 = ((size_t)base_low << p.b_lo) | l;
-      pre_a = pre[j0 >> p.pre_bits];
-      pre_b = pre[((size_t)1 << (p.log_n - p.pre_bits)) + (j0 & (((size_t)1 << p.pre_bits) - 1))];
-    }
-  } else {
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const u32 m = base_low | ((u32)q << LO);
-      size_t gi;
-      if constexpr (STRIDED) {
-        const size_t l = (it.base & (((size_t)1 << p.b_lo) - 1)) + t;
-        if constexpr (IN_BITREV)
-          gi = ((size_t)bitrev32((u32)l, p.b_lo) << R_LOG) | bitrev32(m, R_LOG);
-        else
-          gi = it.base + ((size_t)m << p.b_lo) + t;
-      } else {
-        const size_t j = it.base + (((size_t)t << R_LOG) | m);
-        gi = IN_BITREV ? (size_t)bitrev32((u32)j, p.log_n) : j;
-      }
-      x[q] = it.in[gi];
-    }
-  }
-}
-template <int R_LOG, bool STRIDED, bool IN_BITREV, bool PRE>
-GLD void ntt2_r1_finish(const Ntt2Params& p, const Ntt2Item& it, u64 (&x)[16], u64 pre_a, u64 pre_b) {
-  constexpr int T_LOG = NTT2_TILE_LOG - R_LOG;
-  constexpr int LO = R_LOG - 4;
-  if constexpr (STRIDED && IN_BITREV && PRE) {
-    // shift^j for j = ((base_low | q << LO) << b_lo) | l  =  shift^j0 * (shift^(n/16))^q: one composed table
-    // product per thread, then the 16 per-coset factors, which are wave-uniform (scalar loads); with a prescale the
-    // multiply takes any u64 representative, so the loaded words are not canonicalised
-    const u64* __restrict__ beta = p.pre_beta + (size_t)it.bz * 16;
-    const u64 c0 = gl_mul_nc(pre_a, pre_b);
-    x[0] = gl_mul(x[0], c0);
-#pragma unroll
-    for (int q = 1; q < 16; ++q) x[q] = gl_mul(x[q], gl_mul_nc(c0, beta[q]));
-  } else if constexpr (PRE) {
-    const u32 g = threadIdx.x;
-    u32 t, base_low;
-    if constexpr (STRIDED) {
-      t = g & ((1u << T_LOG) - 1);
-      base_low = g >> T_LOG;
-    } else {
-      base_low = g & ((1u << LO) - 1);
-      t = g >> LO;
-    }
-    const u64* pre = p.pre + (size_t)it.bz * (((size_t)1 << (p.log_n - p.pre_bits)) + ((size_t)1 << p.pre_bits));
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const u32 m = base_low | ((u32)q << LO);
-      size_t j;  // natural index inside the transform
-      if constexpr (STRIDED) {
-        const size_t l = (it.base & (((size_t)1 << p.b_lo) - 1)) + t;
-        j = ((size_t)m << p.b_lo) | l;
-      } else {
-        j = it.base + (((size_t)t << R_LOG) | m);
-      }
-      const u64 sc = gl_mul_nc(pre[j >> p.pre_bits], pre[((size_t)1 << (p.log_n - p.pre_bits)) + (j & (((size_t)1 << p.pre_bits) - 1))]);
-      x[q] = gl_mul(x[q], sc);
-    }
-  } else {
-#pragma unroll
-    for (int q = 0; q < 16; ++q) x[q] = gl_canon(x[q]);
-  }
-}
 template <int R_LOG, int E1, int E2, int E3, bool STRIDED, bool IN_BITREV, bool PRE, bool INV>
-__global__ __launch_bounds__(NTT2_THREADS, 4) void ntt2_pass_kernel(Ntt2Params p) {   // 4 waves per SIMD = two 512-thread blocks per CU: <= 128 VGPRs
+__global__ __launch_bounds__(NTT2_THREADS) void ntt2_pass_kernel(Ntt2Params p) {
   static_assert(E1 == 4 && E1 + E2 + E3 == R_LOG, "round plan");
   extern __shared__ __attribute__((aligned(16))) u64 smem[];
   constexpr int T_LOG = NTT2_TILE_LOG - R_LOG;
@@ -348,15 +220,25 @@ __global__ __launch_bounds__(NTT2_THREADS, 4) void ntt2_pass_kernel(Ntt2Params p
     if (INV) e = ((1u << ROOT_TABLE_LOG) - e) & ((1u << ROOT_TABLE_LOG) - 1);
     W[j] = root_pow24(p.root_lo, p.root_hi, e);
   }
-  const u32 total = p.gx * p.gy * p.gz;
-  u32 w = blockIdx.x;
-  u64 xr[16], pre_a = 0, pre_b = 0;
-  Ntt2Item nxt = ntt2_item<R_LOG, STRIDED>(p, w < total ? w : 0);
-  if (w < total) ntt2_r1_load<R_LOG, STRIDED, IN_BITREV, PRE>(p, nxt, xr, pre_a, pre_b);
-  for (; w < total; w += gridDim.x) {
-  const Ntt2Item it = nxt;
-  const size_t base = it.base;
-  u64* __restrict__ out = it.out;
+
+  u32 bz = blockIdx.z;
+  size_t tile_id = blockIdx.x;
+  if (p.nz_fold > 0) {
+    const u32 rest = blockIdx.x >> 3;
+    bz = rest % (u32)p.nz_fold;
+    tile_id = (size_t)(rest / (u32)p.nz_fold) * 8 + (blockIdx.x & 7);
+  }
+  size_t base;
+  if constexpr (STRIDED) {
+    const size_t tiles_per_span = (size_t)1 << (p.b_lo - T_LOG);
+    const size_t H = tile_id / tiles_per_span;
+    const size_t l0 = (tile_id % tiles_per_span) << T_LOG;
+    base = (H << span_log) | l0;
+  } else {
+    base = tile_id << NTT2_TILE_LOG;
+  }
+  const u64* __restrict__ in = p.in + (size_t)blockIdx.y * p.in_col_stride + (size_t)bz * p.in_z_stride;
+  u64* __restrict__ out = p.out + (size_t)blockIdx.y * p.out_col_stride + (size_t)bz * p.out_z_stride;
 
   // ---------------- round 1: stage bits [R_LOG-4, R_LOG), fed from global memory ----------------
   {
@@ -371,11 +253,61 @@ __global__ __launch_bounds__(NTT2_THREADS, 4) void ntt2_pass_kernel(Ntt2Params p
       t = g >> LO;
     }
     u64 x[16];
+    if constexpr (STRIDED && IN_BITREV) {
+      // bit-reversed input: the 16 operands of this thread's radix-16 DFT (q = the top 4 bits of m) are the 16
+      // CONSECUTIVE words at rev(base_low) * 16 of chunk t, in the order rev4(q): eight 16-byte loads instead of
+      // sixteen 8-byte ones (x[q] and x[q + 8] are neighbours)
+      const size_t l = (base & (((size_t)1 << p.b_lo) - 1)) + t;
+      const size_t g0 = ((size_t)bitrev32((u32)l, p.b_lo) << R_LOG) | bitrev32(base_low, R_LOG);
+      const ulonglong2* __restrict__ src = reinterpret_cast<const ulonglong2*>(in + g0);
 #pragma unroll
-    for (int q = 0; q < 16; ++q) x[q] = xr[q];
-    ntt2_r1_finish<R_LOG, STRIDED, IN_BITREV, PRE>(p, it, x, pre_a, pre_b);
+      for (int h = 0; h < 8; ++h) {
+        const ulonglong2 v = src[h];                 // positions 2h, 2h+1 = rev4(q), rev4(q + 8) with q = rev3(h)
+        const int q = (int)rev_c<3>((u32)h);
+        // with a prescale the multiply that follows takes any u64 representative
+        x[q] = PRE ? v.x : gl_canon(v.x);
+        x[q + 8] = PRE ? v.y : gl_canon(v.y);
+      }
+      if constexpr (PRE) {
+        // shift^j for j = ((base_low | q << LO) << b_lo) | l  =  shift^j0 * (shift^(n/16))^q: one composed table
+        // product per thread, then the 16 per-coset factors, which are wave-uniform (scalar loads)
+        const u64* pre = p.pre + (size_t)bz * (((size_t)1 << (p.log_n - p.pre_bits)) + ((size_t)1 << p.pre_bits));
+        const u64* __restrict__ beta = p.pre_beta + (size_t)bz * 16;
+        const size_t j0 = ((size_t)base_low << p.b_lo) | l;
+        const u64 c0 = gl_mul_nc(pre[j0 >> p.pre_bits], pre[((size_t)1 << (p.log_n - p.pre_bits)) + (j0 & (((size_t)1 << p.pre_bits) - 1))]);
+        x[0] = gl_mul(x[0], c0);
+#pragma unroll
+        for (int q = 1; q < 16; ++q) x[q] = gl_mul(x[q], gl_mul_nc(c0, beta[q]));
+      }
+    } else {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const u32 m = base_low | ((u32)q << LO);
+      size_t gi, j;  // gi: where to read;  j: natural index inside the transform (for the prescale)
+      if constexpr (STRIDED) {
+        const size_t l = (base & (((size_t)1 << p.b_lo) - 1)) + t;
+        j = ((size_t)m << p.b_lo) | l;
+        if constexpr (IN_BITREV)
+          gi = ((size_t)bitrev32((u32)l, p.b_lo) << R_LOG) | bitrev32(m, R_LOG);
+        else
+          gi = base + ((size_t)m << p.b_lo) + t;
+      } else {
+        j = base + (((size_t)t << R_LOG) | m);
+        gi = IN_BITREV ? (size_t)bitrev32((u32)j, p.log_n) : j;
+      }
+      u64 v = in[gi];
+      if constexpr (PRE) {
+        const u64* pre = p.pre + (size_t)bz * (((size_t)1 << (p.log_n - p.pre_bits)) + ((size_t)1 << p.pre_bits));
+        const u64 s = gl_mul_nc(pre[j >> p.pre_bits], pre[((size_t)1 << (p.log_n - p.pre_bits)) + (j & (((size_t)1 << p.pre_bits) - 1))]);
+        v = gl_mul(v, s);
+      } else {
+        v = gl_canon(v);
+      }
+      x[q] = v;
+    }
+    }
     dft_regs<4, INV>(x);
-    __syncthreads();  // W table complete (first tile); the previous tile's last round has finished reading `tile`
+    __syncthreads();  // W table complete
     round_twiddles<R_LOG, LO, 4>(x, W, base_low);
 #pragma unroll
     for (int q = 0; q < 16; ++q) tile[tile_idx<R_LOG, STRIDED>(base_low | ((u32)q << LO), t)] = x[q];
@@ -385,11 +317,6 @@ __global__ __launch_bounds__(NTT2_THREADS, 4) void ntt2_pass_kernel(Ntt2Params p
   if constexpr (E3 > 0) {
     ntt2_round_lds<R_LOG, E3, E2, STRIDED, INV>(tile, W);
     __syncthreads();
-  }
-  // the next tile's first-round operands: in flight during this tile's last round
-  if (w + gridDim.x < total) {
-    nxt = ntt2_item<R_LOG, STRIDED>(p, w + gridDim.x);
-    ntt2_r1_load<R_LOG, STRIDED, IN_BITREV, PRE>(p, nxt, xr, pre_a, pre_b);
   }
   // ---------------- last round: stage bits [0, EL) ----------------
   constexpr int EL = E3 > 0 ? E3 : E2;
@@ -437,5 +364,4 @@ __global__ __launch_bounds__(NTT2_THREADS, 4) void ntt2_pass_kernel(Ntt2Params p
       *reinterpret_cast<ulonglong2*>(out + base + idx) = make_ulonglong2(v0, v1);
     }
   }
-  }  // persistent loop
 }

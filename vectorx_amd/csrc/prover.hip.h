@@ -21,7 +21,7 @@ struct vx_circuit {
   std::vector<int> arity_bits;
   std::vector<int> prog_off;   // per gate: word offset into `programs`, -1 for native gates
   u64* programs = nullptr;     // device copy of the constraint programs
-  hipFunction_t jit_fn = nullptr;     // all programs compiled into one native kernel (jit.hip.h), or nullptr -> interpreter
+  std::vector<hipFunction_t> jit_fns;  // one native kernel per program gate (jit.hip.h), in jit_gates order; empty -> interpreter
   std::vector<int> jit_gates;         // gate index of each block of that kernel, in order
   std::vector<uint64_t> programs_host;  // host copy of the programs (vx_verify evaluates gates at zeta on the host)
   std::vector<u64> cs_cap_host;         // constants_sigmas cap (verifier data)
@@ -142,10 +142,14 @@ static int circuit_create(vx_ctx* c, const vx_circuit_desc* d, vx_circuit** out)
         progs.push_back(prog);
         k->jit_gates.push_back(g);
       }
-      if (why.empty()) k->jit_fn = jit_get(progs, d->num_challenges, c->device, &why);
-      if (!k->jit_fn) {
+      for (size_t q = 0; q < progs.size() && why.empty(); ++q) {
+        hipFunction_t fn = jit_get_gate(progs[q], d->num_challenges, c->device, &why);
+        if (fn) k->jit_fns.push_back(fn);
+      }
+      if (!why.empty() || k->jit_fns.size() != progs.size()) {   // all or nothing: the interpreter takes every program gate
         k->jit_note = why;
         k->jit_gates.clear();
+        k->jit_fns.clear();
       }
     }
   }
@@ -945,6 +949,7 @@ static int prove_impl(vx_ctx* c, vx_circuit* k, const u64* wires_in, bool wires_
           jp.cs = k->cs->lde;
           jp.wires = wires_b->lde;
           jp.alpha_pows = qp.alpha_pows;
+          jp.alpha_limbs = qp.alpha_limbs;
           jp.out = qv;
           jp.N = N;
           jp.rows = Nl;
@@ -958,15 +963,15 @@ static int prove_impl(vx_ctx* c, vx_circuit* k, const u64* wires_in, bool wires_
           jp.base_idx = (int)nterms_before;
           for (int i = 0; i < 4; ++i) jp.pih[i] = pih.e[i];
           for (int r = 0; r < rate; ++r) jp.zh_inv[r] = qp.zh_inv[r];
-          if (k->jit_fn) {
-            jp.ngates = (int)k->jit_gates.size();
-            for (int q = 0; q < jp.ngates; ++q) {
-              const int g = k->jit_gates[q];
-              jp.g[q] = JitGateRt{g, k->gates[g].selector_index, k->gates[g].group_start, k->gates[g].group_end};
-            }
+          if (!k->jit_fns.empty()) {
+            jp.ngates = 1;
             ProfScope psj(c, "quotient_program_gates_jit");
-            void* args[] = {&jp};
-            HIPCHK(hipModuleLaunchKernel(k->jit_fn, (unsigned)((Nl + 255) / 256), 1, 1, 256, 1, 1, 0, c->stream, args, nullptr));
+            for (size_t q = 0; q < k->jit_fns.size(); ++q) {   // one launch per program gate, each adds its share
+              const int g = k->jit_gates[q];
+              jp.g = JitGateRt{g, k->gates[g].selector_index, k->gates[g].group_start, k->gates[g].group_end};
+              void* args[] = {&jp};
+              HIPCHK(hipModuleLaunchKernel(k->jit_fns[q], (unsigned)((Nl + 255) / 256), 1, 1, 256, 1, 1, 0, c->stream, args, nullptr));
+            }
           }
         }
         ProgramParams pg;
@@ -984,7 +989,7 @@ static int prove_impl(vx_ctx* c, vx_circuit* k, const u64* wires_in, bool wires_
         pg.const_base = k->const_base();
         pg.nch = nch;
         for (size_t g = 0; g < k->gates.size(); ++g)
-          if (k->prog_off[g] >= 0 && !k->jit_fn)  // not compiled: interpreter
+          if (k->prog_off[g] >= 0 && k->jit_fns.empty())  // not compiled: interpreter
             pg.gates[pg.num_gates++] = ProgramGateDev{(int)g, k->gates[g].selector_index, k->gates[g].group_start, k->gates[g].group_end, k->prog_off[g]};
         for (int i = 0; i < VX_MAX_CHALLENGES; ++i) pg.alphas[i] = alphas[i], pg.base_pw[i] = pow(alphas[i], nterms_before);
         for (int i = 0; i < 4; ++i) pg.pih[i] = pih.e[i];

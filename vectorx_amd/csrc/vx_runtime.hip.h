@@ -234,23 +234,8 @@ static bool ntt2_eligible(const NttPass& ps, bool strided) {
   return strided ? (ps.r_log >= 8 && ps.r_log <= 10 && ps.b_lo >= ps.t_log) : (ps.r_log == 11);
 }
 template <int R, int E2, int E3, bool STRIDED, bool IN_BITREV, bool PRE, bool INV>
-static hipError_t launch_ntt2_k(const Ntt2Params& q_in, dim3 grid, hipStream_t s) {
+static hipError_t launch_ntt2_k(const Ntt2Params& q, dim3 grid, hipStream_t s) {
   auto kern = ntt2_pass_kernel<R, 4, E2, E3, STRIDED, IN_BITREV, PRE, INV>;
-  // persistent blocks: the logical grid travels in the parameters, the launch has at most two blocks per CU (what the
-  // 74 KB tile allows) — a multiple of 8, so that item id mod 8 stays the XCD the item runs on
-  Ntt2Params q = q_in;
-  q.gx = grid.x, q.gy = grid.y, q.gz = grid.z;
-  static const unsigned persist = [] {
-    if (getenv("VX_NTT_NO_PERSIST")) return 0u;
-    int dev = 0, cus = 256;
-    hipGetDevice(&dev);
-    hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    const char* e = getenv("VX_NTT_BLOCKS_PER_CU");
-    return (unsigned)(cus * (e && atoi(e) > 0 ? atoi(e) : 2)) / 8u * 8u;
-  }();
-  const unsigned long long items = (unsigned long long)grid.x * grid.y * grid.z;
-  if (items >= (1ull << 32)) return hipErrorInvalidValue;
-  grid = dim3((unsigned)(persist && items > persist ? persist : items), 1, 1);
   static bool attr_set[16] = {};
   int dev = 0;
   hipGetDevice(&dev);

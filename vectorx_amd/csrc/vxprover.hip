@@ -635,7 +635,7 @@ int vx_circuit_program_gates(vx_circuit* k, int* total_out, int* compiled_out, c
   for (size_t g = 0; g < k->prog_off.size(); ++g)
     if (k->prog_off[g] >= 0) {
       ++total;
-      compiled += k->jit_fn != nullptr;
+      compiled += !k->jit_fns.empty();
     }
   if (total_out) *total_out = total;
   if (compiled_out) *compiled_out = compiled;
@@ -809,6 +809,24 @@ int vx_stark_begin(vx_ctx* c, const vx_stark_desc* d, const uint64_t* trace, int
 int vx_stark_finish(vx_stark_session* s, const uint64_t* aux_columns, int aux_on_device, const uint64_t* pow_witness_hint, uint8_t* out_buf,
                     size_t* out_len) {
   return vx_stark_finish2(s, aux_columns, aux_on_device, nullptr, pow_witness_hint, out_buf, out_len);
+}
+int vx_circuit_precompile(const vx_circuit_desc* d, int* num_program_gates_out) {
+  if (!d) return vx_fail(VX_E_INVALID, "vx_circuit_precompile: NULL argument");
+  try {
+    const std::string bad = desc_check(d, false, nullptr);
+    if (!bad.empty()) return vx_fail(VX_E_INVALID, "vx_circuit_precompile: %s", bad.c_str());
+    std::vector<const uint64_t*> progs;
+    for (int g = 0; g < d->num_gates; ++g)
+      if (d->gate_types[g] == VX_GATE_PROGRAM) progs.push_back(d->programs + d->program_offsets[g]);
+    if (num_program_gates_out) *num_program_gates_out = (int)progs.size();
+    if (progs.empty()) return 0;
+    std::string why;
+    const int rc = jit_gates_precompile(progs, d->num_challenges, &why);
+    if (rc < 0) return vx_fail(VX_E_INVALID, "vx_circuit_precompile: %s", why.c_str());
+    return rc;
+  } catch (const std::exception& e) {
+    return vx_fail(VX_E_INVALID, "vx_circuit_precompile: %s", e.what());
+  }
 }
 int vx_stark_precompile(const vx_stark_desc* d, int* num_chunks_out) {
   if (!d) return vx_fail(VX_E_INVALID, "vx_stark_precompile: NULL argument");
