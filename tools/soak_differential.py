@@ -31,8 +31,8 @@ lanes = [vx.Context(0) for _ in range(7)]
 t_end = time.time() + budget
 n_ok, n_bad, by_kind = 0, 0, {}
 while time.time() < t_end:
-    flags = int(rng.choice([0, 0, 1, 2, 3, 4, 5, 7, 8, 15, 16, 16, 17, 19, 21, 31]))   # 16 = lookup table + LookupGate rows
-    lo = 5 if flags & 28 else (4 if flags & 1 else 3)
+    flags = int(rng.choice([0, 0, 1, 2, 3, 4, 5, 7, 8, 15, 16, 16, 17, 19, 21, 31, 32, 32, 33, 39, 48, 63]))   # 16 = lookup table, 32 = U32 / comparison gates
+    lo = 5 if flags & 60 else (4 if flags & 1 else 3)
     db = int(rng.integers(max(lo, db_min), db_max + 1))
     pct = int(rng.integers(0, 101))
     # quotient_degree_factor below the blow-up (CircuitConfig::max_quotient_degree_factor): the gate families that fit
@@ -42,7 +42,7 @@ while time.time() < t_end:
         if qdf < 8:
             flags &= ~8                  # CosetInterpolationGate has degree 8
         if qdf < 5:
-            flags &= ~4                  # RandomAccess (degree 5) / Exponentiation (4) family
+            flags &= ~(4 | 32)           # RandomAccess (degree 5) / Exponentiation (4) family; the U32 gates (degree 4) need qdf >= 5
     sc = SynthCircuit(db, seed=int(rng.integers(1, 1 << 30)), poseidon_percent=pct, witness_seed=int(rng.integers(1, 1 << 30)), flags=flags,
                       quotient_degree_factor=qdf)
     sc.desc.pow_bits = int(rng.choice([0, 3, 8, 12]))

@@ -53,7 +53,7 @@ struct JitGateParams {  // mirrored textually in jit_gate_source()
   int const_base, pad_;  // first gate constant among the preprocessed columns: num_selectors + num_lookup_selectors
   u64 pih[4];
   u64 zh_inv[VX_MAX_RATE];
-  JitGateRt g;                   // the gate this launch evaluates (one kernel per program gate)
+  JitGateRt g[8];                // the gates this launch evaluates (VX_JIT_GROUP_MAX; a group of program gates per kernel)
 };
 
 static const char* JIT_PRELUDE =
@@ -252,13 +252,14 @@ GLD u64 dot3_reduce_nc(const dot3& D) {
   return gl_reduce128_nc((u64)V, (u64)(V >> 64));
 }
 )VXJIT";
-static std::string jit_gate_source(const uint64_t* prog, int nch) {
+#define VX_JIT_GROUP_MAX 8   /* program gates per generated kernel (JitGateParams::g) */
+static std::string jit_gate_source(const std::vector<const uint64_t*>& progs, int nch) {
   std::ostringstream s;
   // Occupancy bound: without one the compiler keeps every wire it has loaded live, takes >256 VGPRs and runs one wave per SIMD
   // (measured in round 1: 15.9 ms instead of 6.7); 4 blocks per CU = <= 128 VGPRs, like the native gate kernel.
   const char* bpc = getenv("VX_JIT_BLOCKS_PER_CU");
   s << "typedef unsigned long long uint64_t;\ntypedef unsigned int uint32_t;\n#define VX_JIT_BLOCKS_PER_CU " << (bpc ? atoi(bpc) : 4) << "\n"
-    << "#define VX_ALPHA_POWS " << VX_ALPHA_POWS << "\n"
+    << "#define VX_ALPHA_POWS " << VX_ALPHA_POWS << "\n#define VX_JIT_GROUP_MAX " << VX_JIT_GROUP_MAX << "\n"
     << jit_limits_defines() << JIT_PRELUDE << JIT_DOT3 << R"VXJIT(
 struct JitGateRt {
   int gate_index, selector_index, group_start, group_end;
@@ -274,7 +275,7 @@ struct JitGateParams {
   int const_base, pad_;
   u64 pih[4];
   u64 zh_inv[VX_MAX_RATE];
-  JitGateRt g;
+  JitGateRt g[VX_JIT_GROUP_MAX];
 };
 extern "C" __global__ __launch_bounds__(256, VX_JIT_BLOCKS_PER_CU) void vx_program_gate(JitGateParams p) {
   const size_t il = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -286,21 +287,54 @@ extern "C" __global__ __launch_bounds__(256, VX_JIT_BLOCKS_PER_CU) void vx_progr
   const u64* __restrict__ W = p.wires;
   const Limbs3x2* __restrict__ AL = p.alpha_limbs + p.base_idx;
   const int nsel = p.num_selectors, cbase = p.const_base;
-  const JitGateRt G = p.g;
-  const u64 s = CS[(size_t)G.selector_index * N + i];
-  u64 filter = 1;
-  for (int q = G.group_start; q < G.group_end; ++q)
-    if (q != G.gate_index) filter = gl_mul(filter, gl_sub((u64)q, s));
-  if (nsel > 1) filter = gl_mul(filter, gl_sub(0xFFFFFFFFULL, s));
-  dot3 A0 = {0, 0, 0}, A1 = {0, 0, 0};
-  u64 R[VX_PROGRAM_REGS];
+  u64 t0 = 0, t1 = 0;
 )VXJIT";
-  jit_emit_program(s, prog, nch, false);
-  s << "  const u64 zi = gl_mul(p.zh_inv[r], filter);\n"
-       "  { u64* o = p.out + il; *o = gl_add(*o, gl_mul(dot3_reduce_nc(A0), zi)); }\n";
-  if (nch > 1) s << "  { u64* o = p.out + SW + il; *o = gl_add(*o, gl_mul(dot3_reduce_nc(A1), zi)); }\n";
-  s << "  (void)A1; (void)cbase;\n}\n";
+  for (size_t q = 0; q < progs.size(); ++q) {
+    s << "  {  // program gate, slot " << q << "\n"
+         "    const JitGateRt G = p.g[" << q << "];\n"
+         "    const u64 s = CS[(size_t)G.selector_index * N + i];\n"
+         "    u64 filter = 1;\n"
+         "    for (int q = G.group_start; q < G.group_end; ++q)\n"
+         "      if (q != G.gate_index) filter = gl_mul(filter, gl_sub((u64)q, s));\n"
+         "    if (nsel > 1) filter = gl_mul(filter, gl_sub(0xFFFFFFFFULL, s));\n"
+         "    dot3 A0 = {0, 0, 0}, A1 = {0, 0, 0};\n"
+         "    u64 R[VX_PROGRAM_REGS];\n";
+    jit_emit_program(s, progs[q], nch, false);
+    s << "    t0 = gl_mad(filter, dot3_reduce_nc(A0), t0);\n";
+    if (nch > 1) s << "    t1 = gl_mad(filter, dot3_reduce_nc(A1), t1);\n";
+    s << "    (void)A1;\n  }\n";
+  }
+  s << "  const u64 zi = p.zh_inv[r];\n"
+       "  { u64* o = p.out + il; *o = gl_add(*o, gl_mul(t0, zi)); }\n";
+  if (nch > 1) s << "  { u64* o = p.out + SW + il; *o = gl_add(*o, gl_mul(t1, zi)); }\n";
+  s << "  (void)t1; (void)cbase;\n}\n";
   return s.str();
+}
+// How the program gates of a circuit are packed into kernels.  Measured at n = 2^20 with 9 program gates (flags 29, two runs
+// each, gpurun_out r03g): ONE GATE PER KERNEL 13.4 ms  <  groups of <= 1500 instructions 16.1 - 16.6  <  everything in one kernel
+// 18.2  <  groups of <= 3000 20.4 - 20.8 (and the all-in-one kernel of rounds 1-2 without the carry-free accumulation: 14.1 with
+// 1 kB of scratch per lane).  Sharing the wire loads between gates does not pay for the registers it costs, so the default is one
+// gate per kernel — which also makes the code-object cache per PROGRAM; VX_JIT_GATE_GROUP_INS > 1 packs consecutive gates up to
+// that many instructions (at most VX_JIT_GROUP_MAX gates) for experiments.
+static std::vector<std::vector<size_t>> jit_gate_groups(const std::vector<const uint64_t*>& progs) {
+  const char* env = getenv("VX_JIT_GATE_GROUP_INS");
+  const size_t budget = env && atoi(env) > 0 ? (size_t)atoi(env) : 1;
+  std::vector<std::vector<size_t>> groups;
+  size_t cur = 0;
+  for (size_t q = 0; q < progs.size(); ++q) {
+    size_t len = 0;
+    for (int pc = 0; (progs[q][pc] & 0xFF) != VX_OP_END; ++pc) {
+      ++len;
+      if ((progs[q][pc] & 0xFF) == VX_OP_LDI) ++pc;
+    }
+    if (groups.empty() || cur + len > budget || groups.back().size() >= VX_JIT_GROUP_MAX) {
+      groups.emplace_back();
+      cur = 0;
+    }
+    groups.back().push_back(q);
+    cur += len;
+  }
+  return groups;
 }
 
 // ---- AIR programs are compiled in CHUNKS (round 3) --------------------------------------------------------------------------
@@ -489,8 +523,8 @@ static bool jit_cache_dir_ok(const char* dir) {
 
 // Returns the kernel for this gate set on `device`, or nullptr (with *why set) when it cannot be compiled / loaded.
 static hipFunction_t jit_get_kernel(const std::string& src, const char* kernel_name, int device, std::string* why);
-static hipFunction_t jit_get_gate(const uint64_t* prog, int nch, int device, std::string* why) {
-  return jit_get_kernel(jit_gate_source(prog, nch), "vx_program_gate", device, why);
+static hipFunction_t jit_get_gates(const std::vector<const uint64_t*>& progs, int nch, int device, std::string* why) {
+  return jit_get_kernel(jit_gate_source(progs, nch), "vx_program_gate", device, why);
 }
 // compile (or find in the caches) every chunk WITHOUT loading it: needs no GPU — the `build` step of a host that proves later
 static int jit_air_precompile(const uint64_t* prog, int nch, int ncols, int* nchunks, std::string* why);
@@ -684,7 +718,11 @@ static int jit_air_precompile(const uint64_t* prog, int nch, int ncols, int* nch
 // the gate programs of a circuit description (vx_circuit_precompile): one source per program gate
 static int jit_gates_precompile(const std::vector<const uint64_t*>& progs, int nch, std::string* why) {
   std::vector<std::string> keep;
-  for (const uint64_t* pr : progs) keep.push_back(jit_gate_source(pr, nch));
+  for (const std::vector<size_t>& grp : jit_gate_groups(progs)) {
+    std::vector<const uint64_t*> sub;
+    for (size_t q : grp) sub.push_back(progs[q]);
+    keep.push_back(jit_gate_source(sub, nch));
+  }
   std::vector<const std::string*> srcs;
   for (const std::string& k : keep) srcs.push_back(&k);
   return jit_precompile_sources(srcs, why);

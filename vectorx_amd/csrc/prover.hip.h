@@ -21,7 +21,8 @@ struct vx_circuit {
   std::vector<int> arity_bits;
   std::vector<int> prog_off;   // per gate: word offset into `programs`, -1 for native gates
   u64* programs = nullptr;     // device copy of the constraint programs
-  std::vector<hipFunction_t> jit_fns;  // one native kernel per program gate (jit.hip.h), in jit_gates order; empty -> interpreter
+  std::vector<hipFunction_t> jit_fns;  // native kernels (jit.hip.h), one per GROUP of program gates; empty -> interpreter
+  std::vector<std::vector<size_t>> jit_groups;  // jit_fns[i] evaluates the gates jit_gates[jit_groups[i][..]]
   std::vector<int> jit_gates;         // gate index of each block of that kernel, in order
   std::vector<uint64_t> programs_host;  // host copy of the programs (vx_verify evaluates gates at zeta on the host)
   std::vector<u64> cs_cap_host;         // constants_sigmas cap (verifier data)
@@ -142,14 +143,18 @@ static int circuit_create(vx_ctx* c, const vx_circuit_desc* d, vx_circuit** out)
         progs.push_back(prog);
         k->jit_gates.push_back(g);
       }
-      for (size_t q = 0; q < progs.size() && why.empty(); ++q) {
-        hipFunction_t fn = jit_get_gate(progs[q], d->num_challenges, c->device, &why);
+      if (why.empty()) k->jit_groups = jit_gate_groups(progs);
+      for (size_t gi = 0; gi < k->jit_groups.size() && why.empty(); ++gi) {
+        std::vector<const uint64_t*> sub;
+        for (size_t q : k->jit_groups[gi]) sub.push_back(progs[q]);
+        hipFunction_t fn = jit_get_gates(sub, d->num_challenges, c->device, &why);
         if (fn) k->jit_fns.push_back(fn);
       }
-      if (!why.empty() || k->jit_fns.size() != progs.size()) {   // all or nothing: the interpreter takes every program gate
+      if (!why.empty() || k->jit_fns.size() != k->jit_groups.size() || k->jit_fns.empty()) {   // all or nothing: the interpreter takes every program gate
         k->jit_note = why;
         k->jit_gates.clear();
         k->jit_fns.clear();
+        k->jit_groups.clear();
       }
     }
   }
@@ -658,8 +663,28 @@ static void write_fri_proof(ByteSink& w, const FriProverParams& fp, const std::v
 // Horner chain down the table rows, the partial Sums / LDCs running sums) over at most a few thousand rows — so the rows
 // are gathered from the device-resident witness (80 routed columns x the row range), the recurrences run on the host,
 // and only the non-zero row range of the nch * nlp columns is written back.  dst: [nch * nlp][n] on the device.
+// Montgomery's trick: v[i] <- 1 / v[i] for `count` non-zero values with ONE field inversion (3 multiplications per element
+// instead of a ~70-multiplication exponentiation each: the looking rows of a 2^20-row circuit hold 2.6 M denominators, which took
+// 0.57 s per proof inverted one by one — round 3).  A zero denominator (probability 2^-64 per element) maps to zero.
+static inline void batch_inverse(vxh::u64* v, size_t count, std::vector<vxh::u64>& scratch) {
+  using namespace vxh;
+  scratch.resize(count);
+  u64 acc = 1;
+  for (size_t i = 0; i < count; ++i) {
+    scratch[i] = acc;
+    if (v[i]) acc = mul(acc, v[i]);
+  }
+  acc = inv(acc);
+  for (size_t i = count; i-- > 0;) {
+    if (!v[i]) continue;
+    const u64 t = mul(acc, scratch[i]);
+    acc = mul(acc, v[i]);
+    v[i] = t;
+  }
+}
 static int lookup_polys_to_device(vx_ctx* c, const vx_circuit* k, const u64* d_wires, const std::vector<u64>& deltas, u64* dst) {
   using namespace vxh;
+  std::vector<u64> inv_scratch;
   const size_t n = k->n();
   const int nch = k->nch, nlp = k->nlp(), nsl = nlp - 1;
   const int lu_slots = k->nr / 2, lut_slots = k->nr / 3, lu_deg = k->qdf - 1, lut_deg = (lut_slots + nsl - 1) / nsl;
@@ -681,9 +706,10 @@ static int lookup_polys_to_device(vx_ctx* c, const vx_circuit* k, const u64* d_w
         u64 re = PV(0, row + 1);
         for (int s2 = 0; s2 < lut_slots; ++s2) {
           const u64 inp = W(3 * s2, row), out = W(3 * s2 + 1, row);
-          den[s2] = inv(sub(dalpha, add(inp, mul(da, out))));
+          den[s2] = sub(dalpha, add(inp, mul(da, out)));
           re = add(mul(re, ddelta), add(inp, mul(db, out)));
         }
+        batch_inverse(den.data(), (size_t)lut_slots, inv_scratch);
         PV(0, row) = re;
         for (int slot = 0; slot < nsl; ++slot) {
           u64 acc = slot ? PV(slot, row) : PV(nsl, row + 1);
@@ -692,7 +718,8 @@ static int lookup_polys_to_device(vx_ctx* c, const vx_circuit* k, const u64* d_w
         }
       }
       for (size_t row = last_lut; row-- > last_lu;) {        // looking rows: the partial LDCs
-        for (int s2 = 0; s2 < lu_slots; ++s2) den[s2] = inv(sub(dalpha, add(W(2 * s2, row), mul(da, W(2 * s2 + 1, row)))));
+        for (int s2 = 0; s2 < lu_slots; ++s2) den[s2] = sub(dalpha, add(W(2 * s2, row), mul(da, W(2 * s2 + 1, row))));
+        batch_inverse(den.data(), (size_t)lu_slots, inv_scratch);
         for (int slot = 0; slot < nsl; ++slot) {
           const u64 prev = slot ? PV(slot, row) : PV(nsl, row + 1);
           u64 sum = 0;
@@ -938,7 +965,10 @@ static int prove_impl(vx_ctx* c, vx_circuit* k, const u64* wires_in, bool wires_
         }
         for (int r = 0; r < rate; ++r) lp.zh_inv[r] = qp.zh_inv[r];
         ProfScope psl(c, "quotient_lookup_terms");
-        hipLaunchKernelGGL(lookup_terms_kernel, dim3((unsigned)((Nl + 255) / 256)), dim3(256), 0, c->stream, lp);
+        if (lp.nlp == 7 && lp.lut_slots == 26 && lp.lu_slots == 40 && lp.lut_deg == 5 && lp.lu_deg == 7)   // standard_recursion_config
+          hipLaunchKernelGGL(lookup_terms_kernel<true>, dim3((unsigned)((Nl + 255) / 256)), dim3(256), 0, c->stream, lp);
+        else
+          hipLaunchKernelGGL(lookup_terms_kernel<false>, dim3((unsigned)((Nl + 255) / 256)), dim3(256), 0, c->stream, lp);
         HIPCHK(hipGetLastError());
       }
       if (k->programs) {  // gates supplied as constraint programs add their share to the same quotient values
@@ -964,13 +994,15 @@ static int prove_impl(vx_ctx* c, vx_circuit* k, const u64* wires_in, bool wires_
           for (int i = 0; i < 4; ++i) jp.pih[i] = pih.e[i];
           for (int r = 0; r < rate; ++r) jp.zh_inv[r] = qp.zh_inv[r];
           if (!k->jit_fns.empty()) {
-            jp.ngates = 1;
             ProfScope psj(c, "quotient_program_gates_jit");
-            for (size_t q = 0; q < k->jit_fns.size(); ++q) {   // one launch per program gate, each adds its share
-              const int g = k->jit_gates[q];
-              jp.g = JitGateRt{g, k->gates[g].selector_index, k->gates[g].group_start, k->gates[g].group_end};
+            for (size_t gi = 0; gi < k->jit_fns.size(); ++gi) {   // one launch per group of program gates, each adds its share
+              jp.ngates = (int)k->jit_groups[gi].size();
+              for (int q = 0; q < jp.ngates; ++q) {
+                const int g = k->jit_gates[k->jit_groups[gi][q]];
+                jp.g[q] = JitGateRt{g, k->gates[g].selector_index, k->gates[g].group_start, k->gates[g].group_end};
+              }
               void* args[] = {&jp};
-              HIPCHK(hipModuleLaunchKernel(k->jit_fns[q], (unsigned)((Nl + 255) / 256), 1, 1, 256, 1, 1, 0, c->stream, args, nullptr));
+              HIPCHK(hipModuleLaunchKernel(k->jit_fns[gi], (unsigned)((Nl + 255) / 256), 1, 1, 256, 1, 1, 0, c->stream, args, nullptr));
             }
           }
         }
