@@ -204,7 +204,7 @@ def main():
             achieved = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9
             # HBM bytes per launch: PMC counters cannot be read from inside this process, so the measured
             # traffic-per-algorithmic-byte ratio of this kernel (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
-            # passes, gfx950 correction applied — profiles/r02_pmc_traffic.md via tools/summarize_pmc.py) scales the launch's algorithmic bytes.
+            # passes, gfx950 correction applied — profiles/r03_pmc_traffic.md via tools/summarize_pmc.py) scales the launch's algorithmic bytes.
             traffic, traffic_source = None, None
             try:
                 pmc = json.loads((ROOT / "profiles" / "pmc_traffic_lde.json").read_text())
@@ -240,7 +240,9 @@ def main():
                 # instruction classes reached (profiles/r03_ubench_int.md: `best_mixed_stream_cycles` per wavefront-instruction per
                 # SIMD) at the device's MAXIMUM engine clock — one clock source, an upper limit of whatever the kernel ran at —
                 # so frac <= 1 by construction.
-                max_ghz = torch.cuda.get_device_properties(local_rank).clock_rate / 1e6
+                max_ghz = vx.lib().vx_device_max_clock_khz(local_rank) / 1e6
+                if not 1.0 < max_ghz < 4.0:
+                    raise RuntimeError(f"implausible device clock {max_ghz} GHz")
                 c_best = float(ceil_info["best_mixed_stream_cycles"])
                 ceiling = ceil_info["simds"] * max_ghz * 1e9 / c_best
                 ghz = hash_clock_ghz           # sampled INSIDE the timed hash_leaves launches (s_memtime / s_memrealtime per sampled wave)

@@ -51,6 +51,7 @@ typedef struct vx_circuit vx_circuit; /* device-resident prover key: CommonCircu
 const char* vx_last_error(void);
 const char* vx_version(void);
 int vx_device_count(void);
+int vx_device_max_clock_khz(int device); /* hipDeviceAttributeClockRate: the engine clock ceiling (bench.py prices the ALU bound at it); < 0 on error */
 int vx_ctx_create(int device, vx_ctx** out);
 void vx_ctx_destroy(vx_ctx* ctx);
 int vx_ctx_sync(vx_ctx* ctx);

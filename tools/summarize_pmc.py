@@ -83,7 +83,7 @@ def sq(path, out):
 def traffic(fetch_path, write_path, out, out_json):
     order, fv, ft = load(fetch_path)
     _, wv, wt = load(write_path)
-    L = ["# Round 2 — HBM traffic of the commit path from PMC counters (rocprofv3 --pmc, separate passes)", "",
+    L = ["# HBM traffic of the commit path from PMC counters (rocprofv3 --pmc, separate passes)", "",
          "    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python3 bench.py --workload commit --steps 1 --warmup 0 --no-cpu-baseline",
          "    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -- python3 bench.py --workload commit --steps 1 --warmup 0 --no-cpu-baseline",
          "",

@@ -57,6 +57,7 @@ _SIGNATURES = {
     "vx_last_error": (ctypes.c_char_p, []),
     "vx_version": (ctypes.c_char_p, []),
     "vx_device_count": (_i, []),
+    "vx_device_max_clock_khz": (_i, [_i]),
     "vx_ctx_create": (_i, [_i, ctypes.POINTER(_vp)]),
     "vx_ctx_destroy": (None, [_vp]),
     "vx_ctx_sync": (_i, [_vp]),

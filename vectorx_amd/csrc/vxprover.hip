@@ -44,6 +44,14 @@ extern "C" {
 const char* vx_last_error(void) { return g_err; }
 const char* vx_version(void) { return "vxprover 0.1 (gfx950)"; }
 
+int vx_device_max_clock_khz(int device) {
+  int khz = 0;
+  if (hipDeviceGetAttribute(&khz, hipDeviceAttributeClockRate, device) != hipSuccess) {
+    (void)hipGetLastError();
+    return vx_fail(VX_E_HIP, "vx_device_max_clock_khz: hipDeviceGetAttribute failed");
+  }
+  return khz;
+}
 int vx_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
