@@ -165,10 +165,33 @@ struct QuotientParams {
   u64 pih[4];
   u64 zh[VX_MAX_RATE], zh_inv[VX_MAX_RATE];  // ZeroPolyOnCoset evals / inverses, indexed by coset r
   u64 n_field;                               // n mod p
+  const u64* __restrict__ l0;                // L_0 on the LDE rows (global row index), built once per circuit: l0_table_kernel
   const u64* __restrict__ alpha_pows;        // [VX_MAX_CHALLENGES][VX_ALPHA_POWS]: alpha_c^i
   const Limbs3x2* __restrict__ alpha_limbs;  // the same powers pre-split for carry-free accumulation (poseidon.hip.h dot3)
   u64* out;                                  // [nch][stride_w]
 };
+
+// L_0(x) = Z_H(x) / (n (x - 1)) on every row of the LDE domain — it depends on the circuit's size only, and its field inversion
+// (~70 multiplications) was 7 % of quotient_kernel<0>'s instructions on every row of every proof: one table per circuit instead
+// (8 bytes per LDE row, 0.6 % of the preprocessed commitment it sits next to).
+struct L0Params {
+  const u64 *root_lo, *root_hi;
+  size_t N;
+  int log_n, rate_bits;
+  u64 zh[VX_MAX_RATE];
+  u64 n_field;
+  u64* out;
+};
+__global__ __launch_bounds__(256) void l0_table_kernel(L0Params p) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= p.N) return;
+  const u32 nmask = (1u << p.log_n) - 1;
+  const u32 r = bitrev32((u32)(i >> p.log_n), p.rate_bits);
+  const u32 k = bitrev32((u32)i & nmask, p.log_n);
+  const u32 j = (k << p.rate_bits) | r;
+  const u64 x = gl_mul7(root_pow24(p.root_lo, p.root_hi, j << (ROOT_TABLE_LOG - p.log_n - p.rate_bits)));
+  p.out[i] = gl_mul(p.zh[r], gl_inv(gl_mul(p.n_field, gl_sub(x, 1))));
+}
 
 // reduce_with_powers: acc += term * alpha^idx per challenge.  The powers come from a table built on the host
 // (alpha_pows[c * VX_ALPHA_POWS + idx]); idx is wave-uniform, so the loads are scalar and the running-power
@@ -223,8 +246,8 @@ __global__ __launch_bounds__(256, PART == 0 ? VX_QUOTIENT_PERM_BLOCKS : VX_QUOTI
   for (int c = 0; c < VX_MAX_CHALLENGES; ++c) A.acc[c] = dot3{0, 0, 0};
   A.idx = 0;
 
-  // (1) L_0(x) (Z(x) - 1) per challenge;  eval_l_0 = Z_H(x) / (n (x - 1))
-  const u64 l0 = gl_mul(p.zh[r], gl_inv(gl_mul(p.n_field, gl_sub(x, 1))));
+  // (1) L_0(x) (Z(x) - 1) per challenge;  eval_l_0 = Z_H(x) / (n (x - 1)) from the circuit's table
+  const u64 l0 = p.l0[i];
   for (int ch = 0; ch < p.nch; ++ch) acc_push(A, p, gl_mul(l0, gl_sub(ZS(ch), 1)));
   // (2) partial-product checks per challenge
   for (int ch = 0; ch < p.nch; ++ch) {

@@ -30,6 +30,7 @@ struct vx_circuit {
   vx_batch* cs = nullptr;  // constants_sigmas commitment (resident across proofs)
   u64* sigmas = nullptr;   // [nr][n] sigma VALUES on H (natural order) for the permutation argument
   u64* k_is = nullptr;     // device copy
+  u64* l0_lde = nullptr;   // [N] L_0 on the LDE rows (plonk_kernels.hip.h l0_table_kernel)
   vxh::Hash4 digest;
   // lookup argument (host copies of CommonCircuitData::luts / ProverOnlyCircuitData::lookup_rows); num_luts = 0: none
   int num_luts = 0, num_lookup_selectors = 0;
@@ -68,6 +69,7 @@ static void circuit_free(vx_circuit* k) {
   }
   hipFree(k->sigmas);
   hipFree(k->k_is);
+  hipFree(k->l0_lde);
   hipFree(k->programs);
   delete k;
 }
@@ -174,6 +176,25 @@ static int circuit_create(vx_ctx* c, const vx_circuit_desc* d, vx_circuit** out)
   hipLaunchKernelGGL(canon_kernel, dim3((unsigned)((m * n + 255) / 256)), dim3(256), 0, c->stream, staging, m * n);
   HIPCHK(hipMemcpyAsync(k->sigmas, staging + (size_t)k->num_constants * n, (size_t)k->nr * n * 8, hipMemcpyDeviceToDevice, c->stream));
   rc = batch_commit_device(c, k->cs, staging, n, false);
+  {
+    // L_0 on the LDE domain (per circuit size; read by quotient_kernel<0> of every proof)
+    const int rb = k->rate_bits, rate = 1 << rb;
+    const size_t N = n << rb;
+    if (hipMalloc(&k->l0_lde, N * 8) != hipSuccess) return vx_fail(VX_E_NOMEM, "circuit: out of device memory (L_0 table)");
+    L0Params lp;
+    memset(&lp, 0, sizeof lp);
+    lp.root_lo = c->root_lo, lp.root_hi = c->root_hi;
+    lp.N = N, lp.log_n = k->degree_bits, lp.rate_bits = rb;
+    const u64 shift_n = vxh::pow(7, n), g_rate = vxh::root_of_unity(rb);
+    u64 pw = 1;
+    for (int r = 0; r < rate; ++r) {
+      lp.zh[r] = vxh::sub(vxh::mul(shift_n, pw), 1);
+      pw = vxh::mul(pw, g_rate);
+    }
+    lp.n_field = (u64)n % vxh::P;
+    lp.out = k->l0_lde;
+    hipLaunchKernelGGL(l0_table_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, lp);
+  }
   hipError_t e = hipStreamSynchronize(c->stream);
   if (rc == VX_OK && e != hipSuccess) rc = vx_fail(VX_E_HIP, "circuit: %s", hipGetErrorString(e));
   if (rc) return rc;
@@ -901,6 +922,7 @@ static int prove_impl(vx_ctx* c, vx_circuit* k, const u64* wires_in, bool wires_
         pw = mul(pw, g_rate);
       }
       qp.n_field = (u64)n % P;
+      qp.l0 = k->l0_lde;
       {
         // alpha powers for reduce_with_powers: L_0 terms, partial-product checks, then the widest gate (123 constraints)
         if ((size_t)nch * (1 + nchunks) + (size_t)lookup_terms + 160 > VX_ALPHA_POWS) return vx_fail(VX_E_INVALID, "prove: too many constraint terms");
