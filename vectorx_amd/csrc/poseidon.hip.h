@@ -431,6 +431,67 @@ GLD void poseidon_permute_nc(u64 (&s)[12]) {
   }
 }
 
+// The permutation of PoseidonHash::two_to_one — lanes 8..11 enter as ZERO and only lanes 0..3 leave — with the two things that
+// buys: in round 0 the four capacity lanes hold their round constants, so their S-box outputs are the compile-time constants
+// rc^7 (4 of 12 S-boxes gone), and the last dense layer only needs its first four rows (8 of 12 rows gone): 488 of the
+// 13,000 instructions, on the 5·10^7 node permutations of a proof.  s[8..11] are ignored on entry; s[4..11] are garbage on exit.
+constexpr u64 gl_pow7_const(u64 x) {
+  const u64 x2 = gl_mulmod_const(x, x), x4 = gl_mulmod_const(x2, x2), x3 = gl_mulmod_const(x2, x);
+  return gl_mulmod_const(x3, x4);
+}
+struct PoseidonCapSbox {
+  u64 v[4];
+};
+constexpr PoseidonCapSbox make_cap_sbox() {
+  PoseidonCapSbox r{};
+  for (int i = 0; i < 4; ++i) r.v[i] = gl_pow7_const(POSEIDON_RC_RAW[8 + i] % GL_P);
+  return r;
+}
+__constant__ PoseidonCapSbox POSEIDON_CAP_SBOX = make_cap_sbox();
+GLD void poseidon_mds_rows4_rc_nc(u64 (&s)[12], int round_next) {
+  u32 lo[12], hi[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) {
+    lo[i] = (u32)s[i];
+    hi[i] = (u32)(s[i] >> 32);
+  }
+  const u64(*__restrict__ rc)[2] = POSEIDON_RC_EXT.split + round_next * 12;
+  s[0] = poseidon_mds_row0_asm(lo, hi, rc[0][0], rc[0][1]);
+  s[1] = poseidon_mds_row1_asm(lo, hi, rc[1][0], rc[1][1]);
+  s[2] = poseidon_mds_row2_asm(lo, hi, rc[2][0], rc[2][1]);
+  s[3] = poseidon_mds_row3_asm(lo, hi, rc[3][0], rc[3][1]);
+}
+// (The same two savings inside the leaf sponge — first permutation of a leaf: capacity lanes zero, last one: four lanes out —
+// under wave-uniform flags measured NO gain on hash_leaves_colmajor_kernel, 125.65 / 125.98 ms against 125.70 / 125.95: the
+// branches cost what the 488 instructions per leaf save.  Not kept; profiles/r03_hash_experiments.md.)
+GLD void poseidon_two_to_one_permute_nc(u64 (&s)[12]) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s[i] = gl_add_nc_c(s[i], POSEIDON_RC_EXT.v[i]);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s[i] = poseidon_sbox_fx(s[i]);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) s[8 + i] = POSEIDON_CAP_SBOX.v[i];   // (0 + rc)^7
+  poseidon_mds_rc_nc(s, 1);
+#pragma unroll 1
+  for (int r = 1; r < 4; ++r) {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) s[i] = poseidon_sbox_fx(s[i]);
+    poseidon_mds_rc_nc(s, r + 1);
+  }
+#pragma unroll 1
+  for (int blk = 0; blk < POSEIDON_NBLOCKS - 1; ++blk) poseidon_partial_block_nc<POSEIDON_BLOCK_B>(s, POSEIDON_BLK.kappa[blk], POSEIDON_BLK.K[blk]);
+  poseidon_partial_block_nc<2>(s, POSEIDON_BLK.kappa[POSEIDON_NBLOCKS - 1], POSEIDON_BLK.K[POSEIDON_NBLOCKS - 1]);
+#pragma unroll 1
+  for (int r = 26; r < 29; ++r) {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) s[i] = poseidon_sbox_fx(s[i]);
+    poseidon_mds_rc_nc(s, r + 1);
+  }
+#pragma unroll
+  for (int i = 0; i < 12; ++i) s[i] = poseidon_sbox_fx(s[i]);
+  poseidon_mds_rows4_rc_nc(s, 30);
+}
+
 GLD void poseidon_permute(u64 (&s)[12]) {
   poseidon_permute_nc(s);
 #pragma unroll
