@@ -249,23 +249,55 @@ __global__ __launch_bounds__(256, PART == 0 ? VX_QUOTIENT_PERM_BLOCKS : VX_QUOTI
   // (1) L_0(x) (Z(x) - 1) per challenge;  eval_l_0 = Z_H(x) / (n (x - 1)) from the circuit's table
   const u64 l0 = p.l0[i];
   for (int ch = 0; ch < p.nch; ++ch) acc_push(A, p, gl_mul(l0, gl_sub(ZS(ch), 1)));
-  // (2) partial-product checks per challenge
-  for (int ch = 0; ch < p.nch; ++ch) {
-    const u64 beta = p.betas[ch], gamma = p.gammas[ch];
-    const u64 bx = gl_mul(beta, x);
-    u64 prev = ZS(ch);
+  // (2) partial-product checks.  Both challenges walk the wires TOGETHER: every wire and sigma value is loaded once and
+  // feeds the (beta, gamma) pairs of both — loading them per challenge (rounds 1-2) moved 43 GB through this kernel at
+  // n = 2^21, 5 TB/s of its 8.6 ms, which is what held its clock at 1.65 - 1.9 GHz.  The constraints keep their order in
+  // the alpha-power table (challenge-major), hence the explicit index.
+  {
     const int nchunks = p.npp + 1;
-    for (int kk = 0; kk < nchunks; ++kk) {
-      u64 np = 1, dp = 1;
-      const int j1 = min(p.nr, (kk + 1) * p.deg);
-      for (int jj = kk * p.deg; jj < j1; ++jj) {   // products kept as arbitrary u64 representatives until the end
-        u64 wg = gl_add(WIRE(jj), gamma);
-        np = gl_mul_nc(np, gl_mad_nc(p.k_is[jj], bx, wg));
-        dp = gl_mul_nc(dp, gl_mad_nc(beta, CS(p.num_constants + jj), wg));
+    auto push_at = [&](int idx, u64 term) {
+#pragma unroll
+      for (int c = 0; c < VX_MAX_CHALLENGES; ++c) dot3_mac(A.acc[c], term, p.alpha_limbs[c * VX_ALPHA_POWS + idx]);
+    };
+    if (p.nch == 2) {
+      const u64 beta0 = p.betas[0], gamma0 = p.gammas[0], beta1 = p.betas[1], gamma1 = p.gammas[1];
+      const u64 bx0 = gl_mul(beta0, x), bx1 = gl_mul(beta1, x);
+      u64 prev0 = ZS(0), prev1 = ZS(1);
+      for (int kk = 0; kk < nchunks; ++kk) {
+        u64 np0 = 1, dp0 = 1, np1 = 1, dp1 = 1;
+        const int j1 = min(p.nr, (kk + 1) * p.deg);
+        for (int jj = kk * p.deg; jj < j1; ++jj) {   // products kept as arbitrary u64 representatives until the end
+          const u64 w = WIRE(jj), sg = CS(p.num_constants + jj), kj = p.k_is[jj];
+          const u64 wg0 = gl_add(w, gamma0), wg1 = gl_add(w, gamma1);
+          np0 = gl_mul_nc(np0, gl_mad_nc(kj, bx0, wg0));
+          dp0 = gl_mul_nc(dp0, gl_mad_nc(beta0, sg, wg0));
+          np1 = gl_mul_nc(np1, gl_mad_nc(kj, bx1, wg1));
+          dp1 = gl_mul_nc(dp1, gl_mad_nc(beta1, sg, wg1));
+        }
+        const u64 next0 = kk < p.npp ? ZS(2 + kk) : p.zs[il_next];
+        const u64 next1 = kk < p.npp ? ZS(2 + p.npp + kk) : p.zs[SW + il_next];
+        push_at(2 + kk, gl_sub(gl_mul(prev0, np0), gl_mul(next0, dp0)));
+        push_at(2 + nchunks + kk, gl_sub(gl_mul(prev1, np1), gl_mul(next1, dp1)));
+        prev0 = next0, prev1 = next1;
       }
-      u64 next = kk < p.npp ? ZS(p.nch + ch * p.npp + kk) : p.zs[(size_t)ch * SW + il_next];
-      acc_push(A, p, gl_sub(gl_mul(prev, np), gl_mul(next, dp)));
-      prev = next;
+    } else {
+      for (int ch = 0; ch < p.nch; ++ch) {
+        const u64 beta = p.betas[ch], gamma = p.gammas[ch];
+        const u64 bx = gl_mul(beta, x);
+        u64 prev = ZS(ch);
+        for (int kk = 0; kk < nchunks; ++kk) {
+          u64 np = 1, dp = 1;
+          const int j1 = min(p.nr, (kk + 1) * p.deg);
+          for (int jj = kk * p.deg; jj < j1; ++jj) {
+            u64 wg = gl_add(WIRE(jj), gamma);
+            np = gl_mul_nc(np, gl_mad_nc(p.k_is[jj], bx, wg));
+            dp = gl_mul_nc(dp, gl_mad_nc(beta, CS(p.num_constants + jj), wg));
+          }
+          u64 next = kk < p.npp ? ZS(p.nch + ch * p.npp + kk) : p.zs[(size_t)ch * SW + il_next];
+          push_at(p.nch + ch * nchunks + kk, gl_sub(gl_mul(prev, np), gl_mul(next, dp)));
+          prev = next;
+        }
+      }
     }
   }
   for (int ch = 0; ch < p.nch; ++ch) p.out[(size_t)ch * SW + il] = gl_mul(gl_canon(dot3_reduce_nc(A.acc[ch])), zi);
