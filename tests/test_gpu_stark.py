@@ -167,6 +167,83 @@ def test_sha256_air_interpreted_equals_compiled(ctx, oracle):
         ctx.prof_enable(False)
 
 
+# ---- a second chip: the BLAKE2b AIR of vectorx_amd/blake2b_air.py — 1063 + 6 columns, 1561 constraints, message bytes looked up in a
+#      256-entry table (8 lookups per row, five helper columns) — the header-hash chip of circuits/builder/header.rs:18; own AIR ------
+BLAKE_MESSAGES = [b"abc", b"", bytes(range(200)), b"x" * 128, b"y" * 129, b"vectorx" * 100]
+
+
+@pytest.mark.parametrize("degree_bits,cfg", [(9, {}), (10, dict(rate_bits=2, num_query_rounds=30)), (12, dict(num_query_rounds=40))])
+def test_blake2b_air_proof_bytes_identical_to_oracle(ctx, oracle, degree_bits, cfg):
+    import hashlib
+    from vectorx_amd import blake2b_air as b2
+    cfg = dict(dict(pow_bits=8, num_query_rounds=20), **cfg)
+    stark = b2.make_stark(degree_bits, **cfg)
+    trace, pis, digests = b2.generate_trace(degree_bits, BLAKE_MESSAGES)
+    assert digests == [hashlib.blake2b(m, digest_size=32).digest() for m in BLAKE_MESSAGES[:len(digests)]] and len(digests) >= 3
+    ctx.prof_enable(True)
+    ctx.prof_reset()
+    gp = stark.prove(ctx, trace, pis)
+    stages = ctx.prof()
+    ctx.prof_enable(False)
+    assert "air_quotient_eval_jit" in stages, sorted(stages)
+    assert gp == oracle_lib.stark_prove(oracle, stark, trace, pis)
+    stark.verify(pis, gp)
+    wrong = pis.copy()
+    wrong[0] = (int(wrong[0]) + 1) % P
+    with pytest.raises(vx.VxError):
+        stark.verify(wrong, gp)
+    bad = trace.copy()                                                   # a single flipped bit of an intermediate of G: refused or rejected
+    bad[b2.Cols.BITS + 64 * b2.W_C1 + 17, 77] ^= np.uint64(1)
+    try:
+        bp = stark.prove(ctx, bad, pis)
+    except vx.VxError:
+        bp = None
+    if bp is not None:
+        with pytest.raises(vx.VxError):
+            stark.verify(pis, bp)
+
+
+def test_blake2b_air_interpreted_equals_compiled(ctx):
+    import os
+    from vectorx_amd import blake2b_air as b2
+    stark = b2.make_stark(9, pow_bits=6, num_query_rounds=12)
+    trace, pis, _ = b2.generate_trace(9, BLAKE_MESSAGES)
+    expect = stark.prove(ctx, trace, pis)
+    os.environ["VX_NO_JIT"] = "1"
+    try:
+        ctx.prof_enable(True)
+        ctx.prof_reset()
+        assert stark.prove(ctx, trace, pis) == expect
+        assert "air_quotient_eval" in ctx.prof()
+    finally:
+        del os.environ["VX_NO_JIT"]
+        ctx.prof_enable(False)
+
+
+def test_three_tables_on_one_bus_bytes_identical_to_oracle(ctx, oracle):
+    """SHA-256 and BLAKE2b tables SEND their digests, one sink RECEIVES them all: three sessions, joint challenges over the three
+    trace caps, three proofs byte-identical to the oracle's, closing sums cancel."""
+    from vectorx_amd import blake2b_air as b2
+    from vectorx_amd import sha256_air as sha
+    from vectorx_amd import stark_bus
+    cfg = dict(num_query_rounds=16, pow_bits=6)
+    sha_stark = sha.make_stark(9, bus=True, **cfg)
+    st, spis, sdig = sha.generate_trace(9, SHA_MESSAGES)
+    bl_stark = b2.make_stark(10, bus=True, **cfg)
+    bt, bpis, bdig = b2.generate_trace(10, BLAKE_MESSAGES)
+    rows = [np.frombuffer(d, dtype=">u4").astype(np.uint64) for d in sdig] + [np.array(b2.digest_limbs(d), dtype=np.uint64) for d in bdig]
+    sink_stark, sink_t, _ = sha.make_sink(5, [b"\0" * 32] * len(rows), **cfg)
+    for i, r in enumerate(rows):
+        sink_t[:8, i] = r
+    sink_pis = sink_t[:8, 0].copy()
+    tables = [(sha_stark, st, spis), (bl_stark, bt, bpis), (sink_stark, sink_t, sink_pis)]
+    proofs, shared = stark_bus.prove_tables(ctx, tables)
+    expect, shared_o = oracle_lib.stark_prove_tables(oracle, tables)
+    assert (shared == shared_o).all() and list(proofs) == list(expect)
+    sums = stark_bus.verify_bus([(s, p) for s, _, p in tables], proofs)
+    assert sum(int(s[0]) for s in sums) % P == 0 and all(int(s[0]) for s in sums)
+
+
 def test_two_tables_on_one_bus_bytes_identical_to_oracle(ctx, oracle):
     """vx_stark_begin x 2 -> joint challenges over both trace caps -> vx_stark_set_aux_challenges -> vx_stark_finish2 with the
     closing sums (vectorx_amd/stark_bus.py): both proofs byte-identical to the oracle's, the bus balances, a proof moved into

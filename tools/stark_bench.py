@@ -29,13 +29,15 @@ def main():
     ap.add_argument("--groups", type=int, default=16, help="blocks of 4 trace columns")
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--air", default="mulchain", choices=["mulchain", "sha256"],
+    ap.add_argument("--air", default="mulchain", choices=["mulchain", "sha256", "blake2b"],
                     help="sha256: vectorx_amd/sha256_air.py — 1024 + 3 columns, 2072 constraints, two commitment rounds (own AIR, not Curta's)")
     ap.add_argument("--check", action="store_true", help="verify the last proof with vx_stark_verify")
     args = ap.parse_args()
     import vectorx_amd as vx
     if args.air == "sha256":
         return sha256_bench(args, vx)
+    if args.air == "blake2b":
+        return sha256_bench(args, vx, "blake2b")
     from stark_airs import mulchain
     stark, trace, pis = mulchain(args.log_n, groups=args.groups)
     ctx = vx.Context(0)
@@ -80,15 +82,22 @@ def main():
     ctx.close()
 
 
-def sha256_bench(args, vx):
-    """the SHA-256 AIR: trace AND second-round columns resident in HBM (vx_stark_begin / vx_stark_finish with device pointers);
+def sha256_bench(args, vx, which="sha256"):
+    """the SHA-256 AIR (or, which="blake2b", the BLAKE2b AIR of vectorx_amd/blake2b_air.py): trace AND second-round columns resident in HBM (vx_stark_begin / vx_stark_finish with device pointers);
     the caller's aux-column computation (host arithmetic) happens once, outside the timed loop — witness generation stays on
     the caller's side of the boundary"""
-    from vectorx_amd import sha256_air as sha
+    if which == "blake2b":
+        from vectorx_amd import blake2b_air as sha
+        name, block_bytes, naux = "BLAKE2b-256", 128, 6
+        what = "message bytes range-checked by a log-derivative lookup into a 256-entry table"
+    else:
+        from vectorx_amd import sha256_air as sha
+        name, block_bytes, naux = "SHA-256", 64, 3
+        what = "log-derivative range check"
     t_gen = time.perf_counter()
     n = 1 << args.log_n
     nblocks = n // sha.PERIOD
-    msgs = [bytes([i & 255]) * (64 * 7 + 20) for i in range(max(1, nblocks // 8))]     # 8-block messages
+    msgs = [bytes([i & 255]) * (block_bytes * 7 + 20) for i in range(max(1, nblocks // 8))]     # 8-block messages
     stark = sha.make_stark(args.log_n)
     trace, pis, digests = sha.generate_trace(args.log_n, msgs)
     t_gen = time.perf_counter() - t_gen
@@ -100,7 +109,7 @@ def sha256_bench(args, vx):
     cap = 1 << 25
     out = np.empty(cap, dtype=np.uint8)
     chal = np.zeros(1, dtype=np.uint64)
-    d_aux = ctx.alloc(3 * n * 8)
+    d_aux = ctx.alloc(naux * n * 8)
     state = {"chal": None}
 
     def prove():
@@ -141,10 +150,10 @@ def sha256_bench(args, vx):
     hashing = stages.get("hash_leaves", 0.0) + stages.get("merkle_levels", 0.0)
     prog, npush = sha.build_program()
     print(json.dumps({
-        "metric": "vx_stark_begin + vx_stark_finish proofs/sec (SHA-256 AIR at chip density; own AIR, not Curta's)", "value": 1.0 / dt, "unit": "proofs/sec",
-        "ms_per_proof": dt * 1e3, "sha256_blocks_per_s": nblocks / dt,
-        "config": {"workload": f"SHA-256 AIR: {sha.Cols.N} + 3 columns x 2^{args.log_n} rows ({nblocks} compression blocks of 66 rows), {npush} constraints "
-                               f"of degree <= 3, program {len(prog)} words, log-derivative range check in a second commitment round, rate_bits 1, "
+        "metric": f"vx_stark_begin + vx_stark_finish proofs/sec ({name} AIR at chip density; own AIR, not Curta's)", "value": 1.0 / dt, "unit": "proofs/sec",
+        "ms_per_proof": dt * 1e3, f"{which}_blocks_per_s": nblocks / dt,
+        "config": {"workload": f"{name} AIR: {sha.Cols.N} + {naux} columns x 2^{args.log_n} rows ({nblocks} compression blocks of {sha.PERIOD} rows), {npush} constraints "
+                               f"of degree <= 3, program {len(prog)} words, {what} in a second commitment round, rate_bits 1, "
                                "cap_height 4, 84 queries, 16 PoW bits, trace + aux columns resident in HBM",
                    "trace_bytes": int(trace.nbytes), "proof_bytes": int(nb), "evaluator": "compiled" if "air_quotient_eval_jit" in stages else "interpreted"},
         "stage_ms_per_proof": stages, "evaluator_ms": ev, "hashing_ms": hashing, "evaluator_share": round(ev / (dt * 1e3), 4),

@@ -71,9 +71,10 @@ class _Emit:
     """straight-line program emitter with a trivial register discipline: r0..r47 scratch (bump-allocated per constraint),
     r48.. persistent"""
 
-    def __init__(self):
+    def __init__(self, scratch=48):
         self.w = []
         self.top = 0
+        self.scratch = scratch
 
     def ins(self, op, dst=0, a=0, b=0):
         self.w.append(vx_ins(op, dst, a, b))
@@ -81,7 +82,7 @@ class _Emit:
     def tmp(self):
         r = self.top
         self.top += 1
-        assert r < 48, "scratch registers exhausted"
+        assert r < self.scratch, "scratch registers exhausted"
         return r
 
     def release(self, mark):
@@ -692,14 +693,15 @@ def sink_aux(trace, chal):
     return np.stack([u, acc]), np.array([int(acc[n - 1])], dtype=np.uint64)
 
 
-def make_sink(degree_bits: int, digests, **cfg):
-    """-> (stark, trace [9][n], public inputs): row i receives digests[i] (32-byte strings); the last row stays empty (it is
-    inert in a running sum)."""
+def make_sink(degree_bits: int, digests, fmt=">8I", **cfg):
+    """-> (stark, trace [9][n], public inputs): row i receives digests[i] (32-byte strings, as the eight 32-bit values `fmt` unpacks:
+    big-endian words for the SHA-256 table, little-endian limbs for the BLAKE2b table); the last row stays empty (it is inert in a
+    running sum)."""
     n = 1 << degree_bits
     assert len(digests) < n
     t = np.zeros((9, n), dtype=np.uint64)
     for i, dg in enumerate(digests):
-        t[:8, i] = struct.unpack(">8I", dg)
+        t[:8, i] = struct.unpack(fmt, dg)
         t[8, i] = 1
     cfg.setdefault("rate_bits", 1)
     stark = Stark(degree_bits, 9, 8, sink_program(), constraint_degree=3, num_aux_columns=2, num_aux_challenges=3, aux_fn=sink_aux,
