@@ -244,6 +244,60 @@ def test_three_tables_on_one_bus_bytes_identical_to_oracle(ctx, oracle):
     assert sum(int(s[0]) for s in sums) % P == 0 and all(int(s[0]) for s in sums)
 
 
+# ---- a third chip: Ed25519 scalar multiplication as non-native field arithmetic (vectorx_amd/ed25519_air.py — 617 + 96 columns, one
+#      multiply-add mod 2^255 - 19 per row over byte limbs, 188 byte lookups per row through 94 helper columns); own AIR ----------------
+@pytest.mark.parametrize("degree_bits,scalar,cfg", [
+    (10, 0xC0FFEE11, {}), (11, 0x0123456789ABCDEF, dict(rate_bits=2, num_query_rounds=30)),
+    (13, ((int.from_bytes(__import__("hashlib").sha512(bytes.fromhex("9d61b19deffd5a60ba844af492ec2cc44449c5697b326919703bac031cae7f60")).digest()[:32],
+                          "little") & ((1 << 254) - 8)) | (1 << 254)), dict(num_query_rounds=40))])
+def test_ed25519_air_proof_bytes_identical_to_oracle(ctx, oracle, degree_bits, scalar, cfg):
+    from vectorx_amd import ed25519_air as ed
+    cfg = dict(dict(pow_bits=8, num_query_rounds=20), **cfg)
+    stark = ed.make_stark(degree_bits, **cfg)
+    trace, pis, pt = ed.generate_trace(degree_bits, scalar)
+    assert pt == ed.affine_scalar_mult(scalar)
+    if degree_bits == 13:                                               # RFC 8032 section 7.1 test 1: the public key of that secret key
+        assert ed.compress(pt).hex() == "d75a980182b10ab7d54bfed3c964073a0ee172f3daa62325af021a68f707511a"
+    ctx.prof_enable(True)
+    ctx.prof_reset()
+    gp = stark.prove(ctx, trace, pis)
+    stages = ctx.prof()
+    ctx.prof_enable(False)
+    assert "air_quotient_eval_jit" in stages, sorted(stages)
+    assert gp == oracle_lib.stark_prove(oracle, stark, trace, pis)
+    stark.verify(pis, gp)
+    wrong = pis.copy()
+    wrong[24] = (int(wrong[24]) + 1) % P                                # another y
+    with pytest.raises(vx.VxError):
+        stark.verify(wrong, gp)
+    bad = trace.copy()                                                   # one quotient byte off: refused or rejected
+    bad[ed.Cols.Q + 3, 32 * 5 + 10] = (int(bad[ed.Cols.Q + 3, 32 * 5 + 10]) + 1) % 256
+    try:
+        bp = stark.prove(ctx, bad, pis)
+    except vx.VxError:
+        bp = None
+    if bp is not None:
+        with pytest.raises(vx.VxError):
+            stark.verify(pis, bp)
+
+
+def test_ed25519_air_interpreted_equals_compiled(ctx):
+    import os
+    from vectorx_amd import ed25519_air as ed
+    stark = ed.make_stark(10, pow_bits=6, num_query_rounds=12)
+    trace, pis, _ = ed.generate_trace(10, 0x9E3779B9)
+    expect = stark.prove(ctx, trace, pis)
+    os.environ["VX_NO_JIT"] = "1"
+    try:
+        ctx.prof_enable(True)
+        ctx.prof_reset()
+        assert stark.prove(ctx, trace, pis) == expect
+        assert "air_quotient_eval" in ctx.prof()
+    finally:
+        del os.environ["VX_NO_JIT"]
+        ctx.prof_enable(False)
+
+
 def test_two_tables_on_one_bus_bytes_identical_to_oracle(ctx, oracle):
     """vx_stark_begin x 2 -> joint challenges over both trace caps -> vx_stark_set_aux_challenges -> vx_stark_finish2 with the
     closing sums (vectorx_amd/stark_bus.py): both proofs byte-identical to the oracle's, the bus balances, a proof moved into

@@ -16,7 +16,8 @@ rocprofv3 --pmc $PMC --kernel-trace --output-format csv -d "$OUT/pmc_sq_prove_fl
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -- python3 bench.py --workload commit --steps 1 --warmup 0 --no-cpu-baseline > "$OUT/pmc_fetch.json" 2> "$OUT/pmc_fetch.err"
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write" -- python3 bench.py --workload commit --steps 1 --warmup 0 --no-cpu-baseline > "$OUT/pmc_write.json" 2> "$OUT/pmc_write.err"
 python3 tools/dag_bench.py --in-flight 3 > "$OUT/dag_512.json" 2> "$OUT/dag_512.err"
-for lg in 13 15; do python3 tools/stark_bench.py --air sha256 --log-n $lg --steps 3 --warmup 1 --check >> "$OUT/stark_bench.jsonl" 2>> "$OUT/stark_bench.err"; done
+python3 tools/stark_bench.py --air ed25519 --log-n 13 --steps 3 --warmup 1 --check >> "$OUT/stark_bench.jsonl" 2>> "$OUT/stark_bench.err"
+for air in sha256 blake2b; do for lg in 13 15; do python3 tools/stark_bench.py --air $air --log-n $lg --steps 3 --warmup 1 --check >> "$OUT/stark_bench.jsonl" 2>> "$OUT/stark_bench.err"; done; done
 python3 tools/stark_bench.py --log-n 18 --groups 16 --steps 5 --warmup 2 --check >> "$OUT/stark_bench.jsonl" 2>> "$OUT/stark_bench.err"
 python3 tools/sharded_prove_bench.py 21 1,2,4,8 dev > "$OUT/sharded_prove_bench_21.jsonl" 2> "$OUT/sharded_prove_bench_21.err"
 timeout 400 python3 tools/soak_stark.py 240 31337 12 > "$OUT/soak_stark.jsonl" 2> "$OUT/soak_stark.err"

@@ -19,7 +19,7 @@ sys.path.insert(0, str(ROOT / "tests"))
 import oracle_lib  # noqa: E402  (checker only)
 import vectorx_amd as vx  # noqa: E402
 from stark_airs import cubic, fibonacci, logup, mulchain  # noqa: E402
-from vectorx_amd import blake2b_air, sha256_air  # noqa: E402
+from vectorx_amd import blake2b_air, ed25519_air, sha256_air  # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2024)
@@ -29,7 +29,7 @@ ctx = vx.Context(0)
 t_end = time.time() + budget
 n_ok, n_bad, by_kind = 0, 0, {}
 while time.time() < t_end:
-    kind = str(rng.choice(["fibonacci", "cubic", "mulchain", "logup", "logup", "sha256", "blake2b"]))
+    kind = str(rng.choice(["fibonacci", "cubic", "mulchain", "logup", "logup", "sha256", "blake2b", "ed25519"]))
     lg = int(rng.integers(5 if kind == "logup" else 3, db_max + 1))
     if kind == "sha256":
         lg = int(rng.integers(7, min(db_max, 10) + 1))
@@ -38,7 +38,9 @@ while time.time() < t_end:
     rate_bits = int(rng.choice([1, 1, 2, 3]))
     cfg = dict(rate_bits=rate_bits, pow_bits=int(rng.choice([0, 4, 8])), num_query_rounds=int(rng.choice([5, 20, 84])),
                num_challenges=int(rng.choice([1, 2])), cap_height=int(rng.integers(0, min(4, lg + rate_bits) + 1)))
-    if kind in ("sha256", "blake2b"):      # one compiled program shape (2 challenges); the rest of the configuration varies
+    if kind == "ed25519":
+        lg = int(rng.integers(10, 12))
+    if kind in ("sha256", "blake2b", "ed25519"):      # one compiled program shape (2 challenges); the rest of the configuration varies
         cfg["num_challenges"] = 2
         cfg["rate_bits"] = rate_bits = int(rng.choice([1, 2]))
     if rng.random() < 0.3:
@@ -60,6 +62,9 @@ while time.time() < t_end:
         msgs = [bytes(rng.integers(0, 256, size=int(rng.integers(0, 200)), dtype=np.uint8)) for _ in range(6)]
         stark = sha256_air.make_stark(lg, **cfg)
         trace, pis, _ = sha256_air.generate_trace(lg, msgs)
+    elif kind == "ed25519":
+        stark = ed25519_air.make_stark(lg, **cfg)
+        trace, pis, _ = ed25519_air.generate_trace(lg, int(rng.integers(0, 1 << 32)) | (int(rng.integers(0, 1 << 32)) << 32 if lg == 11 else 0))
     elif kind == "blake2b":
         msgs = [bytes(rng.integers(0, 256, size=int(rng.integers(0, 300)), dtype=np.uint8)) for _ in range(6)]
         stark = blake2b_air.make_stark(lg, **cfg)

@@ -29,7 +29,7 @@ def main():
     ap.add_argument("--groups", type=int, default=16, help="blocks of 4 trace columns")
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--air", default="mulchain", choices=["mulchain", "sha256", "blake2b"],
+    ap.add_argument("--air", default="mulchain", choices=["mulchain", "sha256", "blake2b", "ed25519"],
                     help="sha256: vectorx_amd/sha256_air.py — 1024 + 3 columns, 2072 constraints, two commitment rounds (own AIR, not Curta's)")
     ap.add_argument("--check", action="store_true", help="verify the last proof with vx_stark_verify")
     args = ap.parse_args()
@@ -38,6 +38,8 @@ def main():
         return sha256_bench(args, vx)
     if args.air == "blake2b":
         return sha256_bench(args, vx, "blake2b")
+    if args.air == "ed25519":
+        return sha256_bench(args, vx, "ed25519")
     from stark_airs import mulchain
     stark, trace, pis = mulchain(args.log_n, groups=args.groups)
     ctx = vx.Context(0)
@@ -86,7 +88,11 @@ def sha256_bench(args, vx, which="sha256"):
     """the SHA-256 AIR (or, which="blake2b", the BLAKE2b AIR of vectorx_amd/blake2b_air.py): trace AND second-round columns resident in HBM (vx_stark_begin / vx_stark_finish with device pointers);
     the caller's aux-column computation (host arithmetic) happens once, outside the timed loop — witness generation stays on
     the caller's side of the boundary"""
-    if which == "blake2b":
+    if which == "ed25519":
+        from vectorx_amd import ed25519_air as sha
+        name, block_bytes, naux = "Ed25519 scalar-multiplication", 0, sha.Cols.NAUX
+        what = "188 bytes of result, quotient and carries per row looked up in a 256-entry table (log-derivative)"
+    elif which == "blake2b":
         from vectorx_amd import blake2b_air as sha
         name, block_bytes, naux = "BLAKE2b-256", 128, 6
         what = "message bytes range-checked by a log-derivative lookup into a 256-entry table"
@@ -99,7 +105,10 @@ def sha256_bench(args, vx, which="sha256"):
     nblocks = n // sha.PERIOD
     msgs = [bytes([i & 255]) * (block_bytes * 7 + 20) for i in range(max(1, nblocks // 8))]     # 8-block messages
     stark = sha.make_stark(args.log_n)
-    trace, pis, digests = sha.generate_trace(args.log_n, msgs)
+    if which == "ed25519":
+        trace, pis, _ = sha.generate_trace(args.log_n, int.from_bytes(bytes(range(7, 7 + n // 256)), "little"))
+    else:
+        trace, pis, digests = sha.generate_trace(args.log_n, msgs)
     t_gen = time.perf_counter() - t_gen
     ctx = vx.Context(0)
     L = vx.lib()
@@ -152,7 +161,7 @@ def sha256_bench(args, vx, which="sha256"):
     print(json.dumps({
         "metric": f"vx_stark_begin + vx_stark_finish proofs/sec ({name} AIR at chip density; own AIR, not Curta's)", "value": 1.0 / dt, "unit": "proofs/sec",
         "ms_per_proof": dt * 1e3, f"{which}_blocks_per_s": nblocks / dt,
-        "config": {"workload": f"{name} AIR: {sha.Cols.N} + {naux} columns x 2^{args.log_n} rows ({nblocks} compression blocks of {sha.PERIOD} rows), {npush} constraints "
+        "config": {"workload": f"{name} AIR: {sha.Cols.N} + {naux} columns x 2^{args.log_n} rows ({nblocks} {'double-and-add steps' if which == 'ed25519' else 'compression blocks'} of {sha.PERIOD} rows), {npush} constraints "
                                f"of degree <= 3, program {len(prog)} words, {what} in a second commitment round, rate_bits 1, "
                                "cap_height 4, 84 queries, 16 PoW bits, trace + aux columns resident in HBM",
                    "trace_bytes": int(trace.nbytes), "proof_bytes": int(nb), "evaluator": "compiled" if "air_quotient_eval_jit" in stages else "interpreted"},
