@@ -86,12 +86,12 @@ def dag_leg(ctx, local_rank, in_flight=3):
     t_setup = time.perf_counter()
     lanes = [vx.Context(local_rank) for _ in range(in_flight - 1)]
     spec = mr.DagSpec(64, 18, 16, 19)
-    provers = []
+    provers = {}
 
-    def make(kind, log_n, jobs):
-        p = mr.GpuProver(ctx, kind, log_n, jobs, spec.poseidon_percent, extra_lanes=lanes, distinct_witnesses=4)
-        provers.append(p)
-        return p
+    def make(kind, log_n, jobs):        # one prover per circuit kind, kept across the two passes
+        if kind not in provers:
+            provers[kind] = mr.GpuProver(ctx, kind, log_n, jobs, spec.poseidon_percent, extra_lanes=lanes, distinct_witnesses=4)
+        return provers[kind]
 
     def sync():
         ctx.sync()
@@ -99,17 +99,19 @@ def dag_leg(ctx, local_rank, in_flight=3):
             l.sync()
 
     try:
-        res = mr.run_dag(spec, make, None, sync, in_flight=in_flight)
+        runs = [mr.run_dag(spec, make, None, sync, in_flight=in_flight) for _ in range(2)]
+        assert runs[0]["root"] == runs[1]["root"]
+        res = min(runs, key=lambda r: r["seconds"])      # the first pass also pays each circuit's first-use allocations
     finally:
-        for p in provers:
+        for p in provers.values():
             p.free()
         for l in lanes:
             l.close()
     secs = res["seconds"]
     return {"header_range_512_per_sec": 1.0 / secs, "dag_seconds": secs, "plonky2_proofs": res["proofs"],
-            "plonky2_proofs_per_sec": res["proofs"] / secs, "in_flight_per_gpu": in_flight,
+            "plonky2_proofs_per_sec": res["proofs"] / secs, "in_flight_per_gpu": in_flight, "dag_seconds_both_passes": [round(r["seconds"], 4) for r in runs],
             "per_layer_ms": [(l["kind"], l["jobs"], round(l["ms"], 1)) for l in res["per_layer"]],
-            "setup_seconds_untimed": round(time.perf_counter() - t_setup - secs, 2), "root": res["root"].hex(),
+            "setup_seconds_untimed": round(time.perf_counter() - t_setup - sum(r["seconds"] for r in runs), 2), "root": res["root"].hex(),
             "what": "64 map (2^18 rows) + 63 reduce (2^16) + 1 outer (2^19) proofs, layer barriers, synthetic stand-in circuits; "
                     "witnesses HBM-resident (4 base witnesses per circuit kind, each job's own public inputs patched in: the proving "
                     "work of 128 distinct proofs without 128 CPU witness generations); NOT the contract's timed region"}
