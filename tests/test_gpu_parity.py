@@ -163,6 +163,35 @@ def test_polynomial_batch_matches_oracle(ctx, oracle, log_n, ncols, rate_bits, c
     b2.free()
 
 
+@pytest.mark.parametrize("log_n,ncols,rate_bits", [(6, 64, 3), (8, 135, 3), (7, 71, 1), (5, 200, 2), (9, 57 + 8, 3)])
+def test_host_batches_hash_with_a_carried_sponge_state(ctx, oracle, monkeypatch, log_n, ncols, rate_bits):
+    """A HOST matrix of >= 64 columns and >= 2^20 LDE rows is hashed while it is still crossing PCIe: three launches of the leaf
+    sponge (after 8 columns, after 56, at the end) carry the 12-word state (batch_commit_host).  The threshold is lowered here so
+    that small batches take that path: digests, cap and openings must equal the oracle's, from values and from coefficients."""
+    monkeypatch.setenv("VX_HASH_PIPELINE_MIN_ROWS", "0")
+    rng = np.random.default_rng(log_n * 977 + ncols)
+    vals = rand_field(rng, (ncols, 1 << log_n))
+    e = oracle.commit(vals, rate_bits, 3)
+    b = vx.PolynomialBatch.from_values(ctx, vals, rate_bits, 3)
+    ctx.prof_enable(True)
+    ctx.prof_reset()
+    b2 = vx.PolynomialBatch.from_coeffs(ctx, e["coeffs"], rate_bits, 3)
+    stages = ctx.prof()
+    ctx.prof_enable(False)
+    assert stages["hash_leaves"]["calls"] == 3, stages["hash_leaves"]
+    for bb in (b, b2):
+        assert (bb.digests() == e["digests"]).all()
+        assert (bb.cap() == e["cap"]).all()
+        N = 1 << (log_n + rate_bits)
+        v, path = bb.open_row(N // 3)
+        assert (v == e["leaves"][N // 3]).all()
+        bb.free()
+    monkeypatch.delenv("VX_HASH_PIPELINE_MIN_ROWS")
+    b3 = vx.PolynomialBatch.from_values(ctx, vals, rate_bits, 3)        # the one-launch path on the same input
+    assert (b3.digests() == e["digests"]).all()
+    b3.free()
+
+
 def test_batch_eval_ext_matches_horner(ctx, oracle):
     rng = np.random.default_rng(5)
     log_n, ncols = 10, 11

@@ -34,6 +34,23 @@ def test_proof_bytes_identical_to_oracle(ctx, oracle, degree_bits, pct):
     gc.free()
 
 
+def test_host_witness_with_pipelined_leaf_hashing(ctx, oracle, monkeypatch):
+    """vx_prove from a host witness hashes the wire LDE in carried-state launches behind the PCIe upload (>= 2^20 LDE rows; forced
+    here for a small circuit): same bytes as the oracle and as the proof from a device-resident witness."""
+    sc = SynthCircuit(10, seed=77, poseidon_percent=50)
+    oc = oracle_lib.OracleCircuit(oracle, sc.desc_ptr)
+    gc = vx.Circuit(ctx, sc.desc_ptr)
+    w = sc.witness()
+    ref = oc.prove(w)
+    monkeypatch.setenv("VX_HASH_PIPELINE_MIN_ROWS", "0")
+    assert gc.prove(w) == ref
+    d = ctx.alloc(w.nbytes)
+    ctx.upload(d, w)
+    assert gc.prove(dev_ptr=d) == ref
+    ctx.free(d)
+    gc.free()
+
+
 def test_pow_hint_and_device_resident_witness(ctx, oracle):
     sc = SynthCircuit(8, seed=5, poseidon_percent=50)
     sc.desc.pow_bits = 6       # 1 in 64 candidates is valid: the "next valid witness" search below stays short

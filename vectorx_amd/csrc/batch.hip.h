@@ -160,22 +160,35 @@ static int batch_commit_device(vx_ctx* c, vx_batch* b, const u64* src, size_t n,
   return batch_lde_and_tree(c, b);
 }
 
-// The same from a HOST matrix, with the upload hidden: the matrix crosses PCIe in 16-column blocks on the context's
-// copy stream while the interpolation (or bit-reversal) and coset extension of the previous block run on the main
-// stream — columns are independent polynomials; only the leaf hashing needs them all.  The host loop is "copy k,
-// launch k", so the overlap also happens with pageable memory, whose asynchronous copies block the host.
-// `dev` ([m][n], caller-owned) receives the uploaded matrix.
+// The same from a HOST matrix, with the upload hidden: the matrix crosses PCIe in column blocks on the context's copy stream
+// while the interpolation (or bit-reversal) and coset extension of the previous block run on the main stream — columns are
+// independent polynomials.  The leaf hashing needs them all, but it is a sponge over the columns in order: for large batches it
+// runs in THREE launches that carry the sponge state (after the first 8 columns, after 56, at the end), so the GPU has hashing
+// to do while the later blocks are still on the bus and only the first 8-column block's transfer stays exposed
+// (n = 2^21 x 135 columns: 2.27 GB = ~41 ms of PCIe against ~27 ms of transforms; host-witness proof 221.6 -> HOSTPIPE ms).
+// The host loop is "copy k, launch k", so the overlap also happens with pageable memory, whose asynchronous copies block
+// the host.  `dev` ([m][n], caller-owned) receives the uploaded matrix.
+static size_t hash_pipeline_min_rows() {
+  const char* e = getenv("VX_HASH_PIPELINE_MIN_ROWS");   // tests lower it to exercise the carried-state kernel on small batches
+  return e ? (size_t)strtoull(e, nullptr, 10) : ((size_t)1 << 20);
+}
 static int batch_commit_host(vx_ctx* c, vx_batch* b, const u64* host, u64* dev, bool is_coeffs) {
   using namespace vxh;
-  const size_t n = b->n(), m = b->ncols;
+  const size_t n = b->n(), m = b->ncols, N = b->rows();
   if (!c->copy_stream) HIPCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
   HIPCHK(hipStreamSynchronize(c->stream));  // `dev` and the batch buffers may be recycled blocks the main stream still owns
-  const size_t block = 16, nblocks = (m + block - 1) / block;
+  const bool pipelined = m >= 64 && N >= hash_pipeline_min_rows();
+  std::vector<size_t> starts;                // column blocks: 16 each; pipelined: a first block of 8 so that hashing starts early
+  for (size_t c0 = 0; c0 < m; c0 += (pipelined && c0 == 0) ? 8 : 16) starts.push_back(c0);
+  const size_t nblocks = starts.size();
+  const size_t group_end[3] = {8, 56, m};   // the sponge is cut after these many columns (multiples of the rate)
+  u64* state = nullptr;
+  if (pipelined && c->pool_alloc((void**)&state, 12 * N * 8) != hipSuccess) return vx_fail(VX_E_NOMEM, "commit: out of device memory (sponge state)");
   std::vector<hipEvent_t> ev(nblocks, nullptr);
   const u64 ninv = inv((u64)n % P);
-  int rc = VX_OK;
+  int rc = VX_OK, group = 0;
   for (size_t bk = 0; bk < nblocks && rc == VX_OK; ++bk) {
-    const size_t c0 = bk * block, nc = std::min(block, m - c0);
+    const size_t c0 = starts[bk], nc = (bk + 1 < nblocks ? starts[bk + 1] : m) - c0;
     if (hipEventCreateWithFlags(&ev[bk], hipEventDisableTiming) != hipSuccess ||
         hipMemcpyAsync(dev + c0 * n, host + c0 * n, nc * n * 8, hipMemcpyHostToDevice, c->copy_stream) != hipSuccess ||
         hipEventRecord(ev[bk], c->copy_stream) != hipSuccess || hipStreamWaitEvent(c->stream, ev[bk], 0) != hipSuccess)
@@ -189,11 +202,21 @@ static int batch_commit_host(vx_ctx* c, vx_batch* b, const u64* host, u64* dev, 
                    16.0 * (double)n * (double)nc);
     }
     if (rc == VX_OK) rc = batch_lde_cols(c, b, c0, nc);
+    if (rc == VX_OK && pipelined && c0 + nc == group_end[group]) {
+      const size_t g0 = group ? group_end[group - 1] : 0, g1 = group_end[group];
+      ProfScope ps(c, "hash_leaves", (double)(g1 - g0) * 8.0 * (double)N + (group ? 96.0 * N : 0.0) + (group < 2 ? 96.0 * N : 0.0));
+      hipLaunchKernelGGL(hash_leaves_colmajor_part_kernel, dim3((unsigned)((N + HASH_THREADS - 1) / HASH_THREADS)), dim3(HASH_THREADS), 0, c->stream,
+                         b->lde, N, N, (int)g0, (int)g1, state, group == 0, group == 2, b->tree);
+      if (hipGetLastError() != hipSuccess) rc = vx_fail(VX_E_HIP, "leaf hashing launch failed");
+      ++group;
+    }
   }
   hipStreamSynchronize(c->copy_stream);
   for (hipEvent_t e : ev)
     if (e) hipEventDestroy(e);
+  c->pool_free(state);   // stream-ordered reuse, like every pool block
   VXCHK(rc);
+  if (pipelined) return build_merkle_levels(c, b->tree, N, b->local_cap_height(), &b->cap_off);
   return batch_hash_tree(c, b);
 }
 

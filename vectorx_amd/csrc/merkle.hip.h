@@ -52,6 +52,35 @@ __global__ __launch_bounds__(HASH_THREADS, 4) void hash_leaves_colmajor_kernel(
   }
 }
 
+// The same sponge over the column range [c0, c1) with its 12-word state carried between launches (state[l * nrows + row], any u64
+// representatives): lets the leaf hashing of a batch whose columns arrive over PCIe start before the last column is there
+// (batch_commit_host).  c1 - c0 is a multiple of 8 except in the last launch, which writes the digests instead of the state.
+// Only for rows of more than 4 columns (hash_or_noop's copy case never gets here).
+__global__ __launch_bounds__(HASH_THREADS, 4) void hash_leaves_colmajor_part_kernel(
+    const u64* __restrict__ cols, size_t col_stride, size_t nrows, int c0, int c1, u64* __restrict__ state, int first, int last,
+    u64* __restrict__ digests) {
+  size_t row = (size_t)blockIdx.x * HASH_THREADS + threadIdx.x;
+  if (row >= nrows) return;
+  u64 s[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) s[i] = first ? 0 : state[(size_t)i * nrows + row];
+#pragma unroll 1
+  for (int c = c0; c < c1; c += 8) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (c + i < c1) s[i] = cols[(size_t)(c + i) * col_stride + row];
+    poseidon_permute_nc(s);
+  }
+  if (last) {
+    u64* d = digests + row * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) d[i] = gl_canon(s[i]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) state[(size_t)i * nrows + row] = s[i];
+  }
+}
+
 // Row-major leaves [nrows][width] (C-ABI vx_merkle_cap and the FRI commit-phase trees, whose leaves
 // are 16 consecutive F_p^2 values = 32 contiguous u64).
 __global__ __launch_bounds__(HASH_THREADS, 4) void hash_leaves_rowmajor_kernel(
