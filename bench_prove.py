@@ -73,7 +73,7 @@ def host_witness_leg(ctx, args, sync):
     ctx.host_free(host)
     return {"value": args.steps / dt, "unit": "proofs/sec", "ms_per_step": dt / args.steps * 1e3, "steps": args.steps,
             "what": "same circuit and witness, witness in page-locked HOST memory when each step starts (2.27 GB over PCIe per proof at "
-                    "n = 2^21, hidden behind the first transforms); proofs byte-identical to the HBM-resident run"}
+                    "n = 2^21, hidden behind the first transforms and the leaf hashing, which runs in carried-state launches); proofs byte-identical to the HBM-resident run"}
 
 
 def dag_leg(ctx, local_rank, in_flight=3):

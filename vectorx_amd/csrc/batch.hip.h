@@ -165,7 +165,7 @@ static int batch_commit_device(vx_ctx* c, vx_batch* b, const u64* src, size_t n,
 // independent polynomials.  The leaf hashing needs them all, but it is a sponge over the columns in order: for large batches it
 // runs in THREE launches that carry the sponge state (after the first 8 columns, after 56, at the end), so the GPU has hashing
 // to do while the later blocks are still on the bus and only the first 8-column block's transfer stays exposed
-// (n = 2^21 x 135 columns: 2.27 GB = ~41 ms of PCIe against ~27 ms of transforms; host-witness proof 221.6 -> HOSTPIPE ms).
+// (n = 2^21 x 135 columns: 2.27 GB = ~41 ms of PCIe against ~27 ms of transforms; host-witness proof 222.2 -> 211.9 ms on a box whose HBM-resident proof takes 208).
 // The host loop is "copy k, launch k", so the overlap also happens with pageable memory, whose asynchronous copies block
 // the host.  `dev` ([m][n], caller-owned) receives the uploaded matrix.
 static size_t hash_pipeline_min_rows() {
