@@ -203,6 +203,24 @@ def test_blake2b_air_proof_bytes_identical_to_oracle(ctx, oracle, degree_bits, c
             stark.verify(pis, bp)
 
 
+def test_host_trace_commits_behind_its_upload_with_carried_state_hashing(ctx, oracle, monkeypatch):
+    """vx_stark_begin with a HOST trace: column blocks cross PCIe behind the transforms, and for big traces the leaf sponge runs in
+    carried-state launches (threshold lowered here): same bytes as the oracle and as the device-resident trace."""
+    from vectorx_amd import blake2b_air as b2
+    stark = b2.make_stark(9, pow_bits=6, num_query_rounds=12)
+    trace, pis, _ = b2.generate_trace(9, BLAKE_MESSAGES)
+    expect = oracle_lib.stark_prove(oracle, stark, trace, pis)
+    monkeypatch.setenv("VX_HASH_PIPELINE_MIN_ROWS", "0")
+    ctx.prof_enable(True)
+    ctx.prof_reset()
+    assert stark.prove(ctx, trace, pis) == expect
+    calls = ctx.prof()["hash_leaves"]["calls"]
+    ctx.prof_enable(False)
+    assert calls == 3 + 1 + 1, calls            # trace in three launches, then the aux and the quotient batches in one each
+    monkeypatch.setenv("VX_NO_UPLOAD_OVERLAP", "1")
+    assert stark.prove(ctx, trace, pis) == expect
+
+
 def test_blake2b_air_interpreted_equals_compiled(ctx):
     import os
     from vectorx_amd import blake2b_air as b2

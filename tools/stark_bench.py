@@ -32,6 +32,8 @@ def main():
     ap.add_argument("--air", default="mulchain", choices=["mulchain", "sha256", "blake2b", "ed25519"],
                     help="sha256: vectorx_amd/sha256_air.py — 1024 + 3 columns, 2072 constraints, two commitment rounds (own AIR, not Curta's)")
     ap.add_argument("--check", action="store_true", help="verify the last proof with vx_stark_verify")
+    ap.add_argument("--host-trace", action="store_true", help="chip AIRs: the trace starts in page-locked HOST memory on every proof (PCIe-inclusive rate; "
+                    "the upload hides behind the transforms and the carried-state leaf hashing)")
     args = ap.parse_args()
     import vectorx_amd as vx
     if args.air == "sha256":
@@ -115,6 +117,10 @@ def sha256_bench(args, vx, which="sha256"):
     vp = ctypes.c_void_p
     d_trace = ctx.alloc(trace.nbytes)
     ctx.upload(d_trace, trace)
+    h_trace = None
+    if args.host_trace:
+        h_trace = ctx.host_alloc(trace.shape)
+        h_trace[:] = trace
     cap = 1 << 25
     out = np.empty(cap, dtype=np.uint8)
     chal = np.zeros(1, dtype=np.uint64)
@@ -123,7 +129,10 @@ def sha256_bench(args, vx, which="sha256"):
 
     def prove():
         sess = vp()
-        rc = L.vx_stark_begin(ctx._h, ctypes.cast(stark.desc_ptr, vp), vp(d_trace), 1, pis.ctypes.data, chal.ctypes.data, ctypes.byref(sess))
+        if h_trace is not None:
+            rc = L.vx_stark_begin(ctx._h, ctypes.cast(stark.desc_ptr, vp), vp(h_trace.ctypes.data), 0, pis.ctypes.data, chal.ctypes.data, ctypes.byref(sess))
+        else:
+            rc = L.vx_stark_begin(ctx._h, ctypes.cast(stark.desc_ptr, vp), vp(d_trace), 1, pis.ctypes.data, chal.ctypes.data, ctypes.byref(sess))
         if rc != 0:
             raise RuntimeError(L.vx_last_error().decode())
         try:
@@ -163,7 +172,8 @@ def sha256_bench(args, vx, which="sha256"):
         "ms_per_proof": dt * 1e3, f"{which}_blocks_per_s": nblocks / dt,
         "config": {"workload": f"{name} AIR: {sha.Cols.N} + {naux} columns x 2^{args.log_n} rows ({nblocks} {'double-and-add steps' if which == 'ed25519' else 'compression blocks'} of {sha.PERIOD} rows), {npush} constraints "
                                f"of degree <= 3, program {len(prog)} words, {what} in a second commitment round, rate_bits 1, "
-                               "cap_height 4, 84 queries, 16 PoW bits, trace + aux columns resident in HBM",
+                               "cap_height 4, 84 queries, 16 PoW bits, " + ("trace in page-locked HOST memory at the start of every proof, aux columns resident in HBM"
+                                                                         if args.host_trace else "trace + aux columns resident in HBM"),
                    "trace_bytes": int(trace.nbytes), "proof_bytes": int(nb), "evaluator": "compiled" if "air_quotient_eval_jit" in stages else "interpreted"},
         "stage_ms_per_proof": stages, "evaluator_ms": ev, "hashing_ms": hashing, "evaluator_share": round(ev / (dt * 1e3), 4),
         "hashing_share": round(hashing / (dt * 1e3), 4), "first_proof_seconds_incl_jit": round(t_first, 2), "trace_generation_seconds_host": round(t_gen, 2),

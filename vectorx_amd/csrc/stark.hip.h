@@ -261,15 +261,19 @@ static int stark_begin_impl(vx_ctx* c, const vx_stark_desc* d_in, const u64* tra
   s.public_inputs.assign(pis, pis + d->num_public_inputs);
   for (auto& v : s.public_inputs) v = canon(v);
   // ---- trace commitment: PolynomialBatch::from_values(trace_poly_values, rate_bits, false, cap_height) ----
-  const u64* d_trace = trace_in;
-  if (!on_device) {
+  VXCHK(batch_alloc(c, lg, ncols, rb, d->cap_height, &s.trace_b));
+  if (!on_device) {   // a host trace crosses PCIe behind its own transforms and leaf hashing, like a host witness in vx_prove
     u64* w = S.get((size_t)ncols * n);
     if (!w) return vx_fail(VX_E_NOMEM, "stark: out of device memory (trace)");
-    HIPCHK(hipMemcpyAsync(w, trace_in, (size_t)ncols * n * 8, hipMemcpyHostToDevice, c->stream));
-    d_trace = w;
+    if (!getenv("VX_NO_UPLOAD_OVERLAP")) {
+      VXCHK(batch_commit_host(c, s.trace_b, trace_in, w, false));
+    } else {
+      HIPCHK(hipMemcpyAsync(w, trace_in, (size_t)ncols * n * 8, hipMemcpyHostToDevice, c->stream));
+      VXCHK(batch_commit_device(c, s.trace_b, w, n, false));
+    }
+  } else {
+    VXCHK(batch_commit_device(c, s.trace_b, trace_in, n, false));
   }
-  VXCHK(batch_alloc(c, lg, ncols, rb, d->cap_height, &s.trace_b));
-  VXCHK(batch_commit_device(c, s.trace_b, d_trace, n, false));
   const Shard one;
   VXCHK(gather_cap(c, one, S, s.trace_b->tree + s.trace_b->cap_off * 4, s.trace_b->local_cap_words(), s.trace_cap));
   {
