@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--poseidon-percent", type=int, default=50, help="share of PoseidonGate rows in the synthetic circuit")
     ap.add_argument("--no-dag-leg", action="store_true",
                     help="skip the extra (untimed-by-the-contract) leg that proves one whole header_range_512 DAG: 64 map + 63 reduce + 1 outer proofs")
+    ap.add_argument("--no-chip-leg", action="store_true",
+                    help="skip the extra leg that proves the three chip-sized STARK tables (SHA-256, BLAKE2b, Ed25519 scalar multiplication; SURVEY §8 f-3)")
     ap.add_argument("--circuit-flags", type=int, default=0,
                     help="vectorx_amd.synth FLAG_* bits of the synthetic circuit (1|4|8: constraint-program gates, 16: a lookup table); the "
                          "default 0 is the headline gate mix — other values are for profiling the prove-only kernels")
@@ -195,6 +197,10 @@ def main():
     if args.workload == "prove" and world == 1 and not args.no_dag_leg and args.log_n >= 20 and not args.circuit_flags:
         dag_leg = bench_prove.dag_leg(ctx, local_rank)
 
+    chip_leg = None
+    if args.workload == "prove" and world == 1 and not args.no_chip_leg and args.log_n >= 20 and not args.circuit_flags:
+        chip_leg = bench_prove.chip_leg(ctx)
+
     if rank == 0:
         lde = prof.get("lde", {"ms": 0.0, "calls": 0, "alg_bytes": 0.0})
         roof = None
@@ -288,6 +294,8 @@ def main():
             out["value_from_host_witness"] = host_leg
         if dag_leg is not None:
             out["dag_header_range_512"] = dag_leg
+        if chip_leg is not None:
+            out["chip_starks"] = chip_leg
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline_commit(args) if args.workload == "commit" else bench_prove.cpu_baseline(args)
         print(json.dumps(out), flush=True)

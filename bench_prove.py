@@ -117,6 +117,28 @@ def dag_leg(ctx, local_rank, in_flight=3):
                     "work of 128 distinct proofs without 128 CPU witness generations); NOT the contract's timed region"}
 
 
+def chip_leg(ctx, log_n=13):
+    """SURVEY §8 f-3 outside the contract's timed region: the STARK path (`vx_stark_begin` / `vx_stark_finish`) on the three chip-sized
+    AIRs of this repository's own design — SHA-256, BLAKE2b-256, Ed25519 scalar multiplication (the chips Curta proves under every
+    VectorX map / outer proof: /root/reference/circuits/builder/header.rs:18, justification.rs:140-156, 237) — 2^13 rows each, trace
+    and second-round columns resident in HBM.  Compiled constraint programs come from .jit_cache/ when __graft_entry__.build() filled it."""
+    import os
+    from pathlib import Path
+
+    from vectorx_amd import stark_chips
+    cache = Path(__file__).resolve().parent / ".jit_cache"
+    if "VX_JIT_CACHE_DIR" not in os.environ and cache.is_dir():
+        os.environ["VX_JIT_CACHE_DIR"] = str(cache)
+    out = {"what": "own AIRs, not Curta's; 2^%d rows each; rate_bits 1, 84 queries, 16 PoW bits; NOT the contract's timed region" % log_n}
+    for which in stark_chips.CHIPS:
+        r = stark_chips.bench_chip(ctx, which, log_n, steps=3, warmup=1)
+        out[which] = {"ms_per_proof": round(r["ms_per_proof"], 3), "columns": r["config"]["workload"].split(":")[1].split(" x ")[0].strip(),
+                      "evaluator_ms": r["evaluator_ms"], "hashing_ms": round(r["hashing_ms"], 3), "proof_bytes": r["config"]["proof_bytes"],
+                      "evaluator": r["config"]["evaluator"], "first_proof_seconds_incl_jit": r["first_proof_seconds_incl_jit"],
+                      "trace_generation_seconds_host": r["trace_generation_seconds_host"]}
+    return out
+
+
 def usable_cores():
     """host cores this process may actually use: the scheduler affinity, capped by the cgroup CPU quota
     (the GPU box reports 256 logical CPUs but the container is limited by cpu.max)."""

@@ -1,0 +1,115 @@
+"""Timing harness for the chip-sized AIRs (sha256_air / blake2b_air / ed25519_air): one function that proves a table repeatedly through
+`vx_stark_begin` / `vx_stark_finish` and returns the record `tools/stark_bench.py` prints and `bench.py`'s extra leg embeds.
+Caller-side code (trace generation and second-round columns are host arithmetic, done once outside the timed loop); no oracle."""
+from __future__ import annotations
+
+import ctypes
+import time
+
+import numpy as np
+
+CHIPS = ("sha256", "blake2b", "ed25519")
+
+
+def bench_chip(ctx, which: str, log_n: int, steps: int = 3, warmup: int = 1, host_trace: bool = False, check: bool = False) -> dict:
+    """`ctx`: an open vectorx_amd.Context.  Trace (unless host_trace) AND second-round columns resident in HBM; the aux columns are
+    computed once per distinct challenge (same trace => same challenge)."""
+    import vectorx_amd as vx
+    if which == "ed25519":
+        from . import ed25519_air as air
+        name, block_bytes, naux = "Ed25519 scalar-multiplication", 0, air.Cols.NAUX
+        what = "188 bytes of result, quotient and carries per row looked up in a 256-entry table (log-derivative)"
+    elif which == "blake2b":
+        from . import blake2b_air as air
+        name, block_bytes, naux = "BLAKE2b-256", 128, 6
+        what = "message bytes range-checked by a log-derivative lookup into a 256-entry table"
+    elif which == "sha256":
+        from . import sha256_air as air
+        name, block_bytes, naux = "SHA-256", 64, 3
+        what = "log-derivative range check"
+    else:
+        raise ValueError(which)
+    t_gen = time.perf_counter()
+    n = 1 << log_n
+    nblocks = n // air.PERIOD
+    stark = air.make_stark(log_n)
+    if which == "ed25519":
+        trace, pis, _ = air.generate_trace(log_n, int.from_bytes(bytes(range(7, 7 + n // 256)), "little"))
+    else:
+        msgs = [bytes([i & 255]) * (block_bytes * 7 + 20) for i in range(max(1, nblocks // 8))]     # 8-block messages
+        trace, pis, _ = air.generate_trace(log_n, msgs)
+    t_gen = time.perf_counter() - t_gen
+    L = vx.lib()
+    vp = ctypes.c_void_p
+    d_trace = ctx.alloc(trace.nbytes)
+    ctx.upload(d_trace, trace)
+    h_trace = None
+    if host_trace:
+        h_trace = ctx.host_alloc(trace.shape)
+        h_trace[:] = trace
+    cap = 1 << 25
+    out = np.empty(cap, dtype=np.uint8)
+    chal = np.zeros(1, dtype=np.uint64)
+    d_aux = ctx.alloc(naux * n * 8)
+    state = {"chal": None}
+
+    def prove():
+        sess = vp()
+        if h_trace is not None:
+            rc = L.vx_stark_begin(ctx._h, ctypes.cast(stark.desc_ptr, vp), vp(h_trace.ctypes.data), 0, pis.ctypes.data, chal.ctypes.data, ctypes.byref(sess))
+        else:
+            rc = L.vx_stark_begin(ctx._h, ctypes.cast(stark.desc_ptr, vp), vp(d_trace), 1, pis.ctypes.data, chal.ctypes.data, ctypes.byref(sess))
+        if rc != 0:
+            raise RuntimeError(L.vx_last_error().decode())
+        try:
+            if state["chal"] != int(chal[0]):
+                aux = np.ascontiguousarray(air.aux_columns(trace, chal), dtype=np.uint64)
+                ctx.upload(d_aux, aux)
+                state["chal"] = int(chal[0])
+            nb = ctypes.c_size_t(cap)
+            rc = L.vx_stark_finish(sess, vp(d_aux), 1, None, out.ctypes.data, ctypes.byref(nb))
+            if rc != 0:
+                raise RuntimeError(L.vx_last_error().decode())
+            return nb.value
+        finally:
+            L.vx_stark_session_free(sess)
+
+    try:
+        t_first = time.perf_counter()
+        prove()                                              # includes loading (or compiling) the program's kernels
+        t_first = time.perf_counter() - t_first
+        for _ in range(warmup):
+            prove()
+        ctx.prof_enable(True)
+        ctx.prof_reset()
+        ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            nb = prove()
+        ctx.sync()
+        dt = (time.perf_counter() - t0) / steps
+        stages = {k: round(v["ms"] / steps, 3) for k, v in ctx.prof().items()}
+        ctx.prof_enable(False)
+        if check:
+            stark.verify(pis, out[:nb].tobytes())
+    finally:
+        ctx.free(d_trace)
+        ctx.free(d_aux)
+        if h_trace is not None:
+            ctx.host_free(h_trace)
+    ev = stages.get("air_quotient_eval_jit", stages.get("air_quotient_eval", 0.0))
+    hashing = stages.get("hash_leaves", 0.0) + stages.get("merkle_levels", 0.0)
+    prog, npush = air.build_program()
+    unit = "double-and-add steps" if which == "ed25519" else "compression blocks"
+    return {
+        "metric": f"vx_stark_begin + vx_stark_finish proofs/sec ({name} AIR at chip density; own AIR, not Curta's)", "value": 1.0 / dt, "unit": "proofs/sec",
+        "ms_per_proof": dt * 1e3, f"{which}_blocks_per_s": nblocks / dt,
+        "config": {"workload": f"{name} AIR: {air.Cols.N} + {naux} columns x 2^{log_n} rows ({nblocks} {unit} of {air.PERIOD} rows), {npush} constraints "
+                               f"of degree <= 3, program {len(prog)} words, {what} in a second commitment round, rate_bits 1, "
+                               "cap_height 4, 84 queries, 16 PoW bits, " + ("trace in page-locked HOST memory at the start of every proof, aux columns resident in HBM"
+                                                                         if host_trace else "trace + aux columns resident in HBM"),
+                   "trace_bytes": int(trace.nbytes), "proof_bytes": int(nb), "evaluator": "compiled" if "air_quotient_eval_jit" in stages else "interpreted"},
+        "stage_ms_per_proof": stages, "evaluator_ms": ev, "hashing_ms": hashing, "evaluator_share": round(ev / (dt * 1e3), 4),
+        "hashing_share": round(hashing / (dt * 1e3), 4), "first_proof_seconds_incl_jit": round(t_first, 2), "trace_generation_seconds_host": round(t_gen, 2),
+        "steps": steps, "warmup": warmup, "n_gpus": 1, "data": "synthetic", "dtype": "u64 (Goldilocks field, integer modular arithmetic)",
+        "trace_cells_per_s": air.Cols.N * n / dt}
