@@ -195,11 +195,17 @@ def main():
 
     dag_leg = None
     if args.workload == "prove" and world == 1 and not args.no_dag_leg and args.log_n >= 20 and not args.circuit_flags:
-        dag_leg = bench_prove.dag_leg(ctx, local_rank)
+        try:
+            dag_leg = bench_prove.dag_leg(ctx, local_rank)
+        except Exception as e:   # noqa: BLE001 — an extra leg must never cost the contract's line
+            dag_leg = {"error": repr(e)}
 
     chip_leg = None
     if args.workload == "prove" and world == 1 and not args.no_chip_leg and args.log_n >= 20 and not args.circuit_flags:
-        chip_leg = bench_prove.chip_leg(ctx)
+        try:
+            chip_leg = bench_prove.chip_leg(ctx)
+        except Exception as e:   # noqa: BLE001
+            chip_leg = {"error": repr(e)}
 
     if rank == 0:
         lde = prof.get("lde", {"ms": 0.0, "calls": 0, "alg_bytes": 0.0})
