@@ -216,7 +216,7 @@ def test_host_trace_commits_behind_its_upload_with_carried_state_hashing(ctx, or
     assert stark.prove(ctx, trace, pis) == expect
     calls = ctx.prof()["hash_leaves"]["calls"]
     ctx.prof_enable(False)
-    assert calls == 3 + 1 + 1, calls            # trace in three launches, then the aux and the quotient batches in one each
+    assert calls == 12 + 1 + 1, calls           # the 1063-column trace in twelve pieces, then the aux and the quotient batches in one each
     monkeypatch.setenv("VX_NO_UPLOAD_OVERLAP", "1")
     assert stark.prove(ctx, trace, pis) == expect
 

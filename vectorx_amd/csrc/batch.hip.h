@@ -163,8 +163,9 @@ static int batch_commit_device(vx_ctx* c, vx_batch* b, const u64* src, size_t n,
 // The same from a HOST matrix, with the upload hidden: the matrix crosses PCIe in column blocks on the context's copy stream
 // while the interpolation (or bit-reversal) and coset extension of the previous block run on the main stream — columns are
 // independent polynomials.  The leaf hashing needs them all, but it is a sponge over the columns in order: for large batches it
-// runs in THREE launches that carry the sponge state (after the first 8 columns, after 56, at the end), so the GPU has hashing
-// to do while the later blocks are still on the bus and only the first 8-column block's transfer stays exposed
+// runs in several launches that carry the sponge state (after the first 8 columns, after 56, at the end; wide traces: a dozen
+// pieces), so the GPU has hashing to do while the later blocks are still on the bus and only the first 8-column block's transfer
+// stays exposed
 // (n = 2^21 x 135 columns: 2.27 GB = ~41 ms of PCIe against ~27 ms of transforms; host-witness proof 222.2 -> 211.9 ms on a box whose HBM-resident proof takes 208).
 // The host loop is "copy k, launch k", so the overlap also happens with pageable memory, whose asynchronous copies block
 // the host.  `dev` ([m][n], caller-owned) receives the uploaded matrix.
@@ -181,7 +182,14 @@ static int batch_commit_host(vx_ctx* c, vx_batch* b, const u64* host, u64* dev, 
   std::vector<size_t> starts;                // column blocks: 16 each; pipelined: a first block of 8 so that hashing starts early
   for (size_t c0 = 0; c0 < m; c0 += (pipelined && c0 == 0) ? 8 : 16) starts.push_back(c0);
   const size_t nblocks = starts.size();
-  const size_t group_end[3] = {8, 56, m};   // the sponge is cut after these many columns (multiples of the rate)
+  // the sponge is cut after these many columns (multiples of the rate, on block boundaries): 8, 56, m for the prover's batches
+  // (<= 160 columns); a wide STARK trace in a dozen pieces so that only the last one is left when its upload ends
+  std::vector<size_t> group_end;
+  if (pipelined) {
+    const size_t step = m <= 160 ? 48 : 16 * ((m - 8 + 16 * 12 - 1) / (16 * 12));
+    for (size_t e = 8; e < m && (m > 160 || group_end.size() < 2); e += step) group_end.push_back(e);
+    group_end.push_back(m);
+  }
   u64* state = nullptr;
   if (pipelined && c->pool_alloc((void**)&state, 12 * N * 8) != hipSuccess) return vx_fail(VX_E_NOMEM, "commit: out of device memory (sponge state)");
   std::vector<hipEvent_t> ev(nblocks, nullptr);
@@ -202,11 +210,12 @@ static int batch_commit_host(vx_ctx* c, vx_batch* b, const u64* host, u64* dev, 
                    16.0 * (double)n * (double)nc);
     }
     if (rc == VX_OK) rc = batch_lde_cols(c, b, c0, nc);
-    if (rc == VX_OK && pipelined && c0 + nc == group_end[group]) {
+    if (rc == VX_OK && pipelined && c0 + nc == group_end[group]) {   // (group < group_end.size(): the last entry is m)
       const size_t g0 = group ? group_end[group - 1] : 0, g1 = group_end[group];
-      ProfScope ps(c, "hash_leaves", (double)(g1 - g0) * 8.0 * (double)N + (group ? 96.0 * N : 0.0) + (group < 2 ? 96.0 * N : 0.0));
+      const bool first = group == 0, last = group + 1 == (int)group_end.size();
+      ProfScope ps(c, "hash_leaves", (double)(g1 - g0) * 8.0 * (double)N + (first ? 0.0 : 96.0 * N) + (last ? 0.0 : 96.0 * N));
       hipLaunchKernelGGL(hash_leaves_colmajor_part_kernel, dim3((unsigned)((N + HASH_THREADS - 1) / HASH_THREADS)), dim3(HASH_THREADS), 0, c->stream,
-                         b->lde, N, N, (int)g0, (int)g1, state, group == 0, group == 2, b->tree);
+                         b->lde, N, N, (int)g0, (int)g1, state, first ? 1 : 0, last ? 1 : 0, b->tree);
       if (hipGetLastError() != hipSuccess) rc = vx_fail(VX_E_HIP, "leaf hashing launch failed");
       ++group;
     }
