@@ -165,10 +165,10 @@ def test_polynomial_batch_matches_oracle(ctx, oracle, log_n, ncols, rate_bits, c
 
 @pytest.mark.parametrize("log_n,ncols,rate_bits", [(6, 64, 3), (8, 135, 3), (7, 71, 1), (5, 200, 2), (9, 57 + 8, 3), (4, 1063, 1), (4, 161, 1)])
 def test_host_batches_hash_with_a_carried_sponge_state(ctx, oracle, monkeypatch, log_n, ncols, rate_bits):
-    """A HOST matrix of >= 64 columns and >= 2^20 LDE rows is hashed while it is still crossing PCIe: several launches of the leaf
+    """A HOST matrix of >= 64 columns and >= 64 MB is hashed while it is still crossing PCIe: several launches of the leaf
     sponge (after 8 columns, after 56, at the end; wide traces in a dozen pieces) carry the 12-word state (batch_commit_host).  The threshold is lowered here so
     that small batches take that path: digests, cap and openings must equal the oracle's, from values and from coefficients."""
-    monkeypatch.setenv("VX_HASH_PIPELINE_MIN_ROWS", "0")
+    monkeypatch.setenv("VX_HASH_PIPELINE_MIN_BYTES", "0")
     rng = np.random.default_rng(log_n * 977 + ncols)
     vals = rand_field(rng, (ncols, 1 << log_n))
     e = oracle.commit(vals, rate_bits, 3)
@@ -188,7 +188,7 @@ def test_host_batches_hash_with_a_carried_sponge_state(ctx, oracle, monkeypatch,
         v, path = bb.open_row(N // 3)
         assert (v == e["leaves"][N // 3]).all()
         bb.free()
-    monkeypatch.delenv("VX_HASH_PIPELINE_MIN_ROWS")
+    monkeypatch.delenv("VX_HASH_PIPELINE_MIN_BYTES")
     b3 = vx.PolynomialBatch.from_values(ctx, vals, rate_bits, 3)        # the one-launch path on the same input
     assert (b3.digests() == e["digests"]).all()
     b3.free()

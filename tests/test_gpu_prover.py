@@ -35,14 +35,14 @@ def test_proof_bytes_identical_to_oracle(ctx, oracle, degree_bits, pct):
 
 
 def test_host_witness_with_pipelined_leaf_hashing(ctx, oracle, monkeypatch):
-    """vx_prove from a host witness hashes the wire LDE in carried-state launches behind the PCIe upload (>= 2^20 LDE rows; forced
+    """vx_prove from a host witness hashes the wire LDE in carried-state launches behind the PCIe upload (witness >= 64 MB; forced
     here for a small circuit): same bytes as the oracle and as the proof from a device-resident witness."""
     sc = SynthCircuit(10, seed=77, poseidon_percent=50)
     oc = oracle_lib.OracleCircuit(oracle, sc.desc_ptr)
     gc = vx.Circuit(ctx, sc.desc_ptr)
     w = sc.witness()
     ref = oc.prove(w)
-    monkeypatch.setenv("VX_HASH_PIPELINE_MIN_ROWS", "0")
+    monkeypatch.setenv("VX_HASH_PIPELINE_MIN_BYTES", "0")
     assert gc.prove(w) == ref
     d = ctx.alloc(w.nbytes)
     ctx.upload(d, w)

@@ -210,7 +210,7 @@ def test_host_trace_commits_behind_its_upload_with_carried_state_hashing(ctx, or
     stark = b2.make_stark(9, pow_bits=6, num_query_rounds=12)
     trace, pis, _ = b2.generate_trace(9, BLAKE_MESSAGES)
     expect = oracle_lib.stark_prove(oracle, stark, trace, pis)
-    monkeypatch.setenv("VX_HASH_PIPELINE_MIN_ROWS", "0")
+    monkeypatch.setenv("VX_HASH_PIPELINE_MIN_BYTES", "0")
     ctx.prof_enable(True)
     ctx.prof_reset()
     assert stark.prove(ctx, trace, pis) == expect

@@ -50,7 +50,8 @@ def test_product_and_oracle_verifiers_agree_on_tampering(oracle):
     for bad in (proof[:-1], proof + b"\0", b"", proof[:777]):
         assert _verdict(sc, cap, bad) != ""
     # wrong verifier data: another circuit's cap / a modified cap
-    other = oracle_lib.OracleCircuit(oracle, SynthCircuit(6, seed=9, poseidon_percent=20, flags=5).desc_ptr)
+    other_sc = SynthCircuit(6, seed=9, poseidon_percent=20, flags=5)          # (kept alive: the description borrows its buffers)
+    other = oracle_lib.OracleCircuit(oracle, other_sc.desc_ptr)
     assert _verdict(sc, other.cap(), proof) != ""
     cap2 = cap.copy()
     cap2[3, 1] = (int(cap2[3, 1]) + 1) % P

@@ -169,16 +169,16 @@ static int batch_commit_device(vx_ctx* c, vx_batch* b, const u64* src, size_t n,
 // (n = 2^21 x 135 columns: 2.27 GB = ~41 ms of PCIe against ~27 ms of transforms; host-witness proof 222.2 -> 211.9 ms on a box whose HBM-resident proof takes 208).
 // The host loop is "copy k, launch k", so the overlap also happens with pageable memory, whose asynchronous copies block
 // the host.  `dev` ([m][n], caller-owned) receives the uploaded matrix.
-static size_t hash_pipeline_min_rows() {
-  const char* e = getenv("VX_HASH_PIPELINE_MIN_ROWS");   // tests lower it to exercise the carried-state kernel on small batches
-  return e ? (size_t)strtoull(e, nullptr, 10) : ((size_t)1 << 20);
+static size_t hash_pipeline_min_bytes() {
+  const char* e = getenv("VX_HASH_PIPELINE_MIN_BYTES");   // tests lower it to exercise the carried-state kernel on small batches
+  return e ? (size_t)strtoull(e, nullptr, 10) : ((size_t)64 << 20);   // below ~64 MB the transfer is too short to matter
 }
 static int batch_commit_host(vx_ctx* c, vx_batch* b, const u64* host, u64* dev, bool is_coeffs) {
   using namespace vxh;
   const size_t n = b->n(), m = b->ncols, N = b->rows();
   if (!c->copy_stream) HIPCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
   HIPCHK(hipStreamSynchronize(c->stream));  // `dev` and the batch buffers may be recycled blocks the main stream still owns
-  const bool pipelined = m >= 64 && N >= hash_pipeline_min_rows();
+  const bool pipelined = m >= 64 && n * m * 8 >= hash_pipeline_min_bytes();
   std::vector<size_t> starts;                // column blocks: 16 each; pipelined: a first block of 8 so that hashing starts early
   for (size_t c0 = 0; c0 < m; c0 += (pipelined && c0 == 0) ? 8 : 16) starts.push_back(c0);
   const size_t nblocks = starts.size();
