@@ -50,7 +50,7 @@ def test_poseidon_iterated_chains(ctx, oracle):
         assert (g == o).all(), it
 
 
-@pytest.mark.parametrize("log_n", [1, 2, 3, 4, 5, 7, 8, 10, 11, 12, 13, 14, 16, 18])
+@pytest.mark.parametrize("log_n", [1, 2, 3, 4, 5, 7, 8, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19])
 @pytest.mark.parametrize("kind", [0, 1, 2, 3])
 def test_ntt_matches_oracle(ctx, oracle, log_n, kind):
     rng = np.random.default_rng(100 * log_n + kind)
