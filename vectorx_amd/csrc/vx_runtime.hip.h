@@ -177,10 +177,10 @@ static std::vector<NttPass> plan_ntt(int log_n) {
     v.push_back({log_n, 0, 0});
     return v;
   }
-  // 16 <= log_n <= 18 (the map / reduce proofs of a header_range DAG, 2^16 and 2^18 rows): 8 strided stages + a contiguous pass of
+  // 13 <= log_n <= 18 (the map / reduce proofs of a header_range DAG, 2^16 and 2^18 rows; chip-sized STARK traces): 8 strided stages + a contiguous pass of
   // log_n - 8, so that BOTH passes run the second-generation kernel on full 8192-element tiles; with an 11-stage final pass the
   // strided one would have 5..7 stages and fall back to the generic kernel, which made the NTTs 39 % of the GPU time of a DAG
-  const int r_final = (log_n >= 16 && log_n <= 18 && !getenv("VX_NTT_V1")) ? log_n - 8 : 11;
+  const int r_final = (log_n >= 13 && log_n <= 18 && !getenv("VX_NTT_V1")) ? log_n - 8 : 11;
   int rem = log_n - r_final;
   int k = (rem + 9) / 10;  // strided passes of <= 10 stages
   int b = log_n;
@@ -234,7 +234,7 @@ static hipError_t launch_ntt_pass(int r_log, const NttPassParams& p, dim3 grid, 
 static bool ntt2_eligible(const NttPass& ps, bool strided) {
   static const bool disabled = getenv("VX_NTT_V1") != nullptr;  // A/B switch: force the generic kernel
   if (disabled || ps.r_log + ps.t_log != NTT2_TILE_LOG) return false;
-  return strided ? (ps.r_log >= 8 && ps.r_log <= 10 && ps.b_lo >= ps.t_log) : (ps.r_log >= 8 && ps.r_log <= 11);
+  return strided ? (ps.r_log >= 8 && ps.r_log <= 10 && ps.b_lo >= ps.t_log) : (ps.r_log >= 5 && ps.r_log <= 11);
 }
 template <int R, int E2, int E3, bool STRIDED, bool IN_BITREV, bool PRE, bool INV>
 static hipError_t launch_ntt2_k(const Ntt2Params& q, dim3 grid, hipStream_t s) {
@@ -296,6 +296,9 @@ static hipError_t launch_ntt2_pass(const NttPass& ps, const NttPassParams& p, di
     }
   }
   switch (ps.r_log) {   // final contiguous pass
+    case 5: return launch_ntt2_r<5, 1, 0, false>(p, q, grid, s);
+    case 6: return launch_ntt2_r<6, 2, 0, false>(p, q, grid, s);
+    case 7: return launch_ntt2_r<7, 3, 0, false>(p, q, grid, s);
     case 8: return launch_ntt2_r<8, 4, 0, false>(p, q, grid, s);
     case 9: return launch_ntt2_r<9, 3, 2, false>(p, q, grid, s);
     case 10: return launch_ntt2_r<10, 4, 2, false>(p, q, grid, s);
