@@ -79,6 +79,49 @@ def test_mapreduce_dag_is_partition_independent():
     assert sum(two["per_rank"]) == 8 and min(two["per_rank"]) >= 3, two["per_rank"]   # round-robin per layer: 5 + 3
 
 
+def test_dependency_driven_schedule_gives_the_same_dag():
+    """barriers=False (one process): a job starts when ITS children are done, lanes pull from one ready queue.  Same proofs and root
+    as the layered schedule, every job proven exactly once, no parent before its children — checked with a recording fake prover
+    whose "proof" is a hash of the job and its public inputs, so any wrong or early input would change the root."""
+    import hashlib
+    import threading
+    import time as _time
+
+    from vectorx_amd import mapreduce as mr
+
+    class FakeProver:
+        log = []
+        lock = threading.Lock()
+
+        def __init__(self, kind, log_n, jobs):
+            self.kind, self.jobs = kind, set(jobs)
+
+        def prove(self, key, pi, lane=0):
+            assert key in self.jobs
+            _time.sleep(0.001 * ((key[0] * 7 + key[1] * 3) % 5))          # jobs finish out of order
+            with FakeProver.lock:
+                FakeProver.log.append(key)
+            return hashlib.sha256(self.kind.encode() + repr(key).encode() + bytes(memoryview(pi))).digest() * 3
+
+    spec = mr.DagSpec(num_map=16, map_log_n=4, reduce_log_n=3, outer_log_n=4)
+    make = lambda kind, log_n, jobs: FakeProver(kind, log_n, jobs)                 # noqa: E731
+    layered = mr.run_dag(spec, make, None, in_flight=3, input_seed=b"x")
+    FakeProver.log.clear()
+    free = mr.run_dag(spec, make, None, in_flight=3, input_seed=b"x", barriers=False)
+    assert free["root"] == layered["root"] and free["my_proofs"] == layered["my_proofs"] and free["proofs"] == 32
+    order = {k: i for i, k in enumerate(FakeProver.log)}
+    assert len(order) == 32 == len(FakeProver.log)
+    layers = spec.layers()
+    for (li, j), at in order.items():
+        if li == 0:
+            continue
+        kids = [0] if len(layers[li - 1][1]) == 1 else [2 * j, 2 * j + 1]
+        assert all(order[(li - 1, c)] < at for c in kids), (li, j)
+    assert any(order[(1, j)] < max(order[(0, m)] for m in range(16)) for j in range(8))   # a reduce proof ran before the last map proof
+    assert mr.run_dag(spec, make, None, in_flight=1, input_seed=b"x", barriers=False)["root"] == layered["root"]
+    assert mr.run_dag(spec, make, None, in_flight=3, input_seed=b"y", barriers=False)["root"] != layered["root"]
+
+
 def test_dag_spec_header_range_512():
     from vectorx_amd.mapreduce import DagSpec
     s = DagSpec()

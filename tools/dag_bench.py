@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--reduce-log-n", type=int, default=16)
     ap.add_argument("--outer-log-n", type=int, default=19)
     ap.add_argument("--in-flight", type=int, default=1, help="jobs of a layer kept in flight per GPU (contexts / host threads)")
+    ap.add_argument("--no-barriers", action="store_true", help="single process only: dependency-driven schedule (a job starts when its own children are done)")
     args = ap.parse_args()
     import torch
     import vectorx_amd as vx
@@ -49,7 +50,7 @@ def main():
             l.sync()
         torch.cuda.synchronize()
 
-    res = mr.run_dag(spec, make, dist, sync, in_flight=args.in_flight)
+    res = mr.run_dag(spec, make, dist, sync, in_flight=args.in_flight, barriers=not args.no_barriers)
     secs = res["seconds"]
     if dist is not None:
         t = torch.tensor([secs], dtype=torch.float64, device=f"cuda:{local_rank}")

@@ -66,12 +66,89 @@ def child_inputs(layer_idx: int, job: int, prev_digests: dict, input_seed: bytes
     return digest_to_field(hashlib.sha256(prev_digests[2 * job] + prev_digests[2 * job + 1]).digest())
 
 
-def run_dag(spec: DagSpec, make_prover, dist=None, sync=lambda: None, in_flight: int = 1, input_seed: bytes = b""):
+def _run_dag_dependency_driven(layers, provers, in_flight, input_seed, sync):
+    """One process, no layer barriers: a job starts as soon as ITS children are proven (a reduce job needs its two children, the
+    outer proof the root reduce proof), `in_flight` lanes pull from one ready queue — the upper reduce layers, too narrow to fill
+    the lanes on their own, run while map proofs are still being produced.  Same proofs, same digests, same root as the layered
+    schedule (public inputs depend on the children only); per-layer times are first-start to last-end and overlap."""
+    import queue
+    import threading
+    n_layers = len(layers)
+    digests = [dict() for _ in range(n_layers)]
+    proofs = {}
+    span = [[None, None] for _ in range(n_layers)]
+    ready = queue.Queue()
+    lock = threading.Lock()
+    errors = []
+    total = sum(len(j) for _, j in layers)
+    done = [0]
+
+    def children(li, j):
+        if li == 0:
+            return []
+        return [0] if len(layers[li - 1][1]) == 1 else [2 * j, 2 * j + 1]
+
+    def parent(li, j):
+        if li + 1 >= n_layers:
+            return None
+        return (li + 1, 0 if len(layers[li][1]) == 1 else j // 2)
+
+    for j in layers[0][1]:
+        ready.put((0, j))
+
+    def lane_main(lane):
+        while True:
+            item = ready.get()
+            if item is None:
+                return
+            li, j = item
+            try:
+                kind = layers[li][0]
+                with lock:
+                    prev = dict(digests[li - 1]) if li else {}
+                    if span[li][0] is None:
+                        span[li][0] = time.perf_counter()
+                proof = provers[kind].prove((li, j), child_inputs(li, j, prev, input_seed), lane)
+                dg = hashlib.sha256(proof).digest()
+                with lock:
+                    digests[li][j] = dg
+                    proofs[(li, j)] = proof
+                    span[li][1] = time.perf_counter()
+                    done[0] += 1
+                    finished = done[0] == total
+                    par = parent(li, j)
+                    if par is not None and all(c in digests[li] for c in children(*par)):
+                        ready.put(par)
+                if finished:
+                    for _ in range(in_flight):
+                        ready.put(None)
+            except BaseException as e:   # surfaces after the join
+                errors.append(e)
+                for _ in range(in_flight):
+                    ready.put(None)
+                return
+
+    t0 = time.perf_counter()
+    threads = [threading.Thread(target=lane_main, args=(lane,)) for lane in range(in_flight)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        raise errors[0]
+    sync()
+    seconds = time.perf_counter() - t0
+    per_layer = [{"kind": layers[li][0], "jobs": len(layers[li][1]), "ms": (span[li][1] - span[li][0]) * 1e3} for li in range(n_layers)]
+    return {"root": digests[-1][0], "seconds": seconds, "proofs": total, "per_layer": per_layer, "my_proofs": proofs}
+
+
+def run_dag(spec: DagSpec, make_prover, dist=None, sync=lambda: None, in_flight: int = 1, input_seed: bytes = b"", barriers: bool = True):
     """make_prover(kind, log_n, job_ids) -> object with .prove(job, public_inputs[, lane]) -> proof bytes, prepared
     (circuit loaded, per-job witnesses resident) BEFORE the timed region; witness generation is outside the hot path
     (U9).  in_flight > 1: this rank keeps that many jobs of a layer in flight on its GPU (host threads, one prover
     lane = one context/stream each) — the map/reduce proofs are small enough (2^16..2^18 rows) that a single proof
     leaves the chip partly idle in its latency-bound stages.
+    barriers=False (one process only): no layer barriers — a job starts when its own children are done (_run_dag_dependency_driven).
     Returns dict(root=<digest of the outer proof>, seconds=<timed DAG wall time>, proofs=<count>, per_layer=[...])."""
     world = dist.get_world_size() if dist is not None else 1
     rank = dist.get_rank() if dist is not None else 0
@@ -88,6 +165,10 @@ def run_dag(spec: DagSpec, make_prover, dist=None, sync=lambda: None, in_flight:
     sync()
     if dist is not None:
         dist.barrier()
+    if not barriers:
+        if dist is not None and world > 1:
+            raise ValueError("the dependency-driven schedule is single-process; ranks exchange digests at layer barriers")
+        return _run_dag_dependency_driven(layers, provers, max(1, in_flight), input_seed, sync)
     # ---- timed: layer by layer ----
     t0 = time.perf_counter()
     prev = {}
