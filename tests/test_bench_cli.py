@@ -26,3 +26,15 @@ def test_world_size_must_match_gpus_flag():
     r = _run(["--gpus", "4", "--log-n", "10"], WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
     assert r.returncode != 0
     assert "WORLD_SIZE=2" in r.stderr and not r.stdout.strip()
+
+
+def test_extra_legs_import_without_a_gpu_and_the_chip_harness_knows_its_tables():
+    """The bench's extra legs (host witness, DAG, chip STARKs) live in bench_prove.py / vectorx_amd/stark_chips.py: importable on a
+    CPU-only machine (a syntax error there would cost the driver's whole bench line), and the harness names the three chip tables."""
+    sys.path.insert(0, str(ROOT))
+    import bench_prove
+    from vectorx_amd import stark_chips
+    assert callable(bench_prove.dag_leg) and callable(bench_prove.chip_leg) and callable(bench_prove.host_witness_leg)
+    assert stark_chips.CHIPS == ("sha256", "blake2b", "ed25519")
+    r = _run(["--help"])
+    assert r.returncode == 0 and "--no-chip-leg" in r.stdout and "--no-dag-leg" in r.stdout
