@@ -137,7 +137,7 @@ def chip_leg(ctx, log_n=13):
     out = {"what": "own AIRs, not Curta's; 2^%d rows each; rate_bits 1, 84 queries, 16 PoW bits; NOT the contract's timed region" % log_n}
     for which in stark_chips.CHIPS:
         r = stark_chips.bench_chip(ctx, which, log_n, steps=3, warmup=1)
-        out[which] = {"ms_per_proof": round(r["ms_per_proof"], 3), "columns": r["config"]["workload"].split(":")[1].split(" x ")[0].strip(),
+        out[which] = {"ms_per_proof": round(r["ms_per_proof"], 3), "columns": r["config"]["columns"],
                       "evaluator_ms": r["evaluator_ms"], "hashing_ms": round(r["hashing_ms"], 3), "proof_bytes": r["config"]["proof_bytes"],
                       "evaluator": r["config"]["evaluator"], "first_proof_seconds_incl_jit": r["first_proof_seconds_incl_jit"],
                       "trace_generation_seconds_host": r["trace_generation_seconds_host"]}

@@ -108,7 +108,7 @@ def bench_chip(ctx, which: str, log_n: int, steps: int = 3, warmup: int = 1, hos
                                f"of degree <= 3, program {len(prog)} words, {what} in a second commitment round, rate_bits 1, "
                                "cap_height 4, 84 queries, 16 PoW bits, " + ("trace in page-locked HOST memory at the start of every proof, aux columns resident in HBM"
                                                                          if host_trace else "trace + aux columns resident in HBM"),
-                   "trace_bytes": int(trace.nbytes), "proof_bytes": int(nb), "evaluator": "compiled" if "air_quotient_eval_jit" in stages else "interpreted"},
+                   "columns": f"{air.Cols.N} + {naux}", "trace_bytes": int(trace.nbytes), "proof_bytes": int(nb), "evaluator": "compiled" if "air_quotient_eval_jit" in stages else "interpreted"},
         "stage_ms_per_proof": stages, "evaluator_ms": ev, "hashing_ms": hashing, "evaluator_share": round(ev / (dt * 1e3), 4),
         "hashing_share": round(hashing / (dt * 1e3), 4), "first_proof_seconds_incl_jit": round(t_first, 2), "trace_generation_seconds_host": round(t_gen, 2),
         "steps": steps, "warmup": warmup, "n_gpus": 1, "data": "synthetic", "dtype": "u64 (Goldilocks field, integer modular arithmetic)",
