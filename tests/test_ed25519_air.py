@@ -79,12 +79,27 @@ def test_every_constraint_vanishes_on_the_trace_and_not_on_a_broken_one(ed10):
     assert [(i, kd) for i, kd, _ in got] == [(npush - 1, vx.VX_AIR_LAST_ROW)], got
 
 
-def test_rfc8032_public_key_with_all_256_scalar_bits():
-    sk = bytes.fromhex("9d61b19deffd5a60ba844af492ec2cc44449c5697b326919703bac031cae7f60")
+RFC8032_KEYS = [   # RFC 8032 section 7.1, tests 1 - 3: secret key -> public key
+    ("9d61b19deffd5a60ba844af492ec2cc44449c5697b326919703bac031cae7f60", "d75a980182b10ab7d54bfed3c964073a0ee172f3daa62325af021a68f707511a"),
+    ("4ccd089b28ff96da9db6c346ec114e0f5b8a319f35aba624da8cf6ed4fb8a6fb", "3d4017c3e843895a92b70aa74d1b7ebc9c982ccf2ec4968cc0cd55f12af4660c"),
+    ("c5aa8df43f9f837bedb7442f31dcb7b166d38535076f094b85ce3a2e0b4458f7", "fc51cd8e6218a1a38da47ed00230f0580816ed13ba3303ac5deb911548908025"),
+]
+
+
+def test_rfc8032_keys_on_the_reference_implementation():
+    for sk_hex, pk_hex in RFC8032_KEYS:
+        h = hashlib.sha512(bytes.fromhex(sk_hex)).digest()
+        s = (int.from_bytes(h[:32], "little") & ((1 << 254) - 8)) | (1 << 254)
+        assert ed.compress(ed.affine_scalar_mult(s)).hex() == pk_hex
+
+
+@pytest.mark.parametrize("sk_hex,pk_hex", RFC8032_KEYS[:2])
+def test_rfc8032_public_key_with_all_256_scalar_bits(sk_hex, pk_hex):
+    sk = bytes.fromhex(sk_hex)
     h = hashlib.sha512(sk).digest()
     s = (int.from_bytes(h[:32], "little") & ((1 << 254) - 8)) | (1 << 254)
     t, pis, pt = ed.generate_trace(13, s)
-    assert ed.compress(pt).hex() == "d75a980182b10ab7d54bfed3c964073a0ee172f3daa62325af021a68f707511a"
+    assert ed.compress(pt).hex() == pk_hex
     assert [int(x) for x in pis[:8]] == [(s >> (32 * (7 - j))) & 0xFFFFFFFF for j in range(8)]       # consumed most significant first
     prog, npush = ed.build_program()
     cons = eval_program(prog, t, ed.aux_columns(t, CHAL), CHAL, pis)
