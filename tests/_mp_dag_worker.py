@@ -25,7 +25,7 @@ class OracleProver:
             self.wit[(li, j)] = sj.witness().copy()
             sj.free()
 
-    def prove(self, key, pi):
+    def prove(self, key, pi, lane=0):
         w = self.wit[key]
         r0, r2 = self.sc.patch_public_inputs(pi)
         w[:, 0] = r0
