@@ -120,3 +120,42 @@ def test_oracle_proves_and_the_product_verifier_accepts(oracle):
     bad[len(bad) // 2] ^= 1
     with pytest.raises(vx.VxError):
         stark.verify(pis, bytes(bad))
+
+
+def test_rfc8032_signature_verifies_through_two_scalar_multiplication_tables():
+    """EdDSA verification [S]B = R + [h]A (RFC 8032 section 5.1.7) with BOTH scalar multiplications taken from the table's traces:
+    [S]B from the base-point program, [h]A from a program with A's cached form baked in (`build_program(base=A)`); h = SHA-512(R || A || M)
+    mod L and the final point addition / comparison are plain host arithmetic (own stand-in: Curta's gadget also proves the hash and
+    the group equation).  Test vector 2 of section 7.1 (one-byte message); every constraint of both traces vanishes."""
+    sk = bytes.fromhex("4ccd089b28ff96da9db6c346ec114e0f5b8a319f35aba624da8cf6ed4fb8a6fb")
+    pk = bytes.fromhex("3d4017c3e843895a92b70aa74d1b7ebc9c982ccf2ec4968cc0cd55f12af4660c")
+    msg = bytes.fromhex("72")
+    sig = bytes.fromhex("92a009a9f0d4cab8720e820b5f642540a2b27b5416503f8fb3762223ebdb69da085ac1e43e15996e458f3613d0f11d8c387b2eaeb4302aeeb00d291612bb0c00")
+    q, d = ed.Q25519, ed.D_ED
+    L = (1 << 252) + 27742317777372353535851937790883648493
+
+    def decompress(b):
+        y = int.from_bytes(b, "little") & ((1 << 255) - 1)
+        sign = b[31] >> 7
+        x2 = (y * y - 1) * pow(d * y * y + 1, q - 2, q) % q
+        x = pow(x2, (q + 3) // 8, q)
+        if (x * x - x2) % q:
+            x = x * pow(2, (q - 1) // 4, q) % q
+        assert (x * x - x2) % q == 0
+        return (q - x if (x & 1) != sign else x, y)
+
+    A, R = decompress(pk), decompress(sig[:32])
+    S = int.from_bytes(sig[32:], "little")
+    h = int.from_bytes(hashlib.sha512(sig[:32] + pk + msg).digest(), "little") % L
+    assert S < L
+    t1, pis1, SB = ed.generate_trace(13, S)
+    t2, pis2, hA = ed.generate_trace(13, h, base=A)
+    assert SB == ed.affine_scalar_mult(S) and hA == ed.affine_scalar_mult(h, A)
+    assert ed.affine_add(R, hA) == SB                                          # the signature is valid
+    assert ed.affine_add(R, ed.affine_scalar_mult(h + 1, A)) != SB
+    prog_b, _ = ed.build_program()
+    prog_a, n_a = ed.build_program(base=A)
+    assert prog_a != prog_b and len(prog_a) == len(prog_b)                     # same shape, other constants
+    assert violations(eval_program(prog_b, t1, ed.aux_columns(t1, CHAL), CHAL, pis1), t1.shape[1]) == []
+    assert violations(eval_program(prog_a, t2, ed.aux_columns(t2, CHAL), CHAL, pis2), t2.shape[1]) == []
+    assert violations(eval_program(prog_b, t2, ed.aux_columns(t2, CHAL), CHAL, pis2), t2.shape[1])      # [h]A is not a trace of the B program

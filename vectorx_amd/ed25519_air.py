@@ -17,6 +17,9 @@ check Z * ZI = 1 and leave the affine coordinates; the scalar's bits (MSB first,
 with the public inputs at word boundaries.  Public inputs: the scalar's 32-bit words in the order they are consumed (most
 significant first; a trace of n rows consumes n / 1024 of the 8 slots), then x and y of [k]B as 16 limbs of 16 bits each.
 A trace of 2^degree_bits rows runs 2^degree_bits / 32 steps = that many scalar bits (2^13 rows: all 256).
+`build_program(base=A)` bakes another point's cached form into the program instead of B's (the program digest is part of the
+transcript, so that program IS the statement "[k] * A"): with one table of each kind an RFC 8032 signature verifies —
+[S]B = R + [h]A — the hash and the final addition staying on the host (tests/test_ed25519_air.py).
 Plain host code: it emits a constraint program (include/vxprover.h VX_OP_*), generates the trace and the second-round columns,
 and is checked against an independent affine implementation of the curve and the RFC 8032 test vector; no GPU, no oracle.
 """
@@ -39,7 +42,13 @@ W_OFFSET = 1 << 15
 
 # Y-slot constants; C0..C2 = the cached base point (y - x, y + x, 2 d x y) when the step's bit is 1, the identity's (1, 1, 0) otherwise
 CONSTS = {"ONE": 1, "MINUS1": Q25519 - 1, "MINUS2": Q25519 - 2, "TWO": 2}
-CACHED = {"C0": ((BY - BX) % Q25519, 1), "C1": ((BY + BX) % Q25519, 1), "C2": ((2 * D_ED * BX * BY) % Q25519, 0)}
+def cached_point(pt):
+    """the cached form (y - x, y + x, 2 d x y) of an affine point, each paired with the identity's value for a zero scalar bit"""
+    x, y = pt
+    return {"C0": ((y - x) % Q25519, 1), "C1": ((y + x) % Q25519, 1), "C2": ((2 * D_ED * x * y) % Q25519, 0)}
+
+
+CACHED = cached_point((BX, BY))
 
 R = lambda i: ("r", i)       # noqa: E731
 K = lambda name: ("c", name)  # noqa: E731
@@ -118,9 +127,12 @@ def _sel_rows(pred):
     return [t for t, op in enumerate(OPS) if op != FREE and pred(op)]
 
 
-def build_program():
-    """-> (program words, number of constraints); one program for every trace length (1024 rows per scalar word)"""
+def build_program(base=None):
+    """-> (program words, number of constraints); one program for every trace length (1024 rows per scalar word).
+    `base`: an affine point other than the curve's base point — its cached form is baked into the program as constants, i.e. the
+    program (whose digest the transcript observes) is the statement "[k] * THIS point"."""
     C = Cols
+    CACHED = cached_point(base) if base is not None else globals()["CACHED"]
     e = _Emit(scratch=24)
     ONE, ZERO, GAMMA, S31, BND, BITr, NOTFREE, C256 = 63, 62, 61, 60, 59, 58, 57, 56
     PH = list(range(24, 56))       # phase registers: selector sums, recomputed at the start of each phase
@@ -429,10 +441,10 @@ def build_program():
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-def _const_value(name, bit):
+def _const_value(name, bit, cached=None):
     if name in CONSTS:
         return CONSTS[name]
-    on, off = CACHED[name]
+    on, off = (cached or CACHED)[name]
     return on if bit else off
 
 
@@ -457,9 +469,10 @@ def mul_add_witness(x, y, ev, z):
     return qb, wb
 
 
-def generate_trace(degree_bits: int, scalar: int) -> tuple:
-    """-> (trace [N][n] uint64, public inputs [40], (x, y) of [scalar]B).  The scalar has n / 32 bits."""
+def generate_trace(degree_bits: int, scalar: int, base=None) -> tuple:
+    """-> (trace [N][n] uint64, public inputs [40], (x, y) of [scalar]B — or of [scalar]base).  The scalar has n / 32 bits."""
     C = Cols
+    cached = cached_point(base) if base is not None else None
     n = 1 << degree_bits
     nbits = n // PERIOD
     assert 0 <= scalar < (1 << nbits) and 10 <= degree_bits <= 13
@@ -489,7 +502,7 @@ def generate_trace(degree_bits: int, scalar: int) -> tuple:
             else:
                 xs, ys, es, dst = op
                 x = reg[xs[1]]
-                y = reg[ys[1]] if ys[0] == "r" else _const_value(ys[1], bit)
+                y = reg[ys[1]] if ys[0] == "r" else _const_value(ys[1], bit, cached)
                 ev = reg[es[1]] if es is not None else 0
                 z = (x * y + ev) % Q25519
                 qb, wb = mul_add_witness(x, y, ev, z)
@@ -534,9 +547,9 @@ def aux_columns(trace, chal):
     return np.stack([np.array(c, dtype=np.uint64) for c in h + [ht, acc]])
 
 
-def make_stark(degree_bits: int, **cfg) -> Stark:
+def make_stark(degree_bits: int, base=None, **cfg) -> Stark:
     assert 10 <= degree_bits <= 13, "one scalar word = 32 steps = 1024 rows; 2^13 rows = 256 bits"
-    prog, _ = build_program()
+    prog, _ = build_program(base)
     cfg.setdefault("rate_bits", 1)
     return Stark(degree_bits, Cols.N, 40, prog, constraint_degree=3, num_aux_columns=Cols.NAUX, num_aux_challenges=1, aux_fn=aux_columns, **cfg)
 
