@@ -316,6 +316,28 @@ def test_ed25519_air_interpreted_equals_compiled(ctx):
         ctx.prof_enable(False)
 
 
+def test_sha512_air_proof_bytes_identical_to_oracle_and_to_the_golden(ctx, oracle):
+    """the fourth chip (vectorx_amd/sha512_air.py: 1995 + 5 columns, 4037 constraints, a 31.7 k-word program in 27 chunks): GPU proof ==
+    oracle proof == the digest frozen in tests/golden/chip_goldens.json (same inputs and configuration as the generator)"""
+    import hashlib
+    import json
+    from pathlib import Path
+
+    from vectorx_amd import sha512_air as s5
+    stark = s5.make_stark(8, num_query_rounds=12, pow_bits=4)
+    trace, pis, digests = s5.generate_trace(8, [b"abc", b"", bytes(range(200))])
+    assert digests[0] == hashlib.sha512(b"abc").digest()
+    gp = stark.prove(ctx, trace, pis)
+    assert gp == oracle_lib.stark_prove(oracle, stark, trace, pis)
+    gold = json.loads((Path(__file__).resolve().parent / "golden" / "chip_goldens.json").read_text())["sha512"]
+    assert hashlib.sha256(gp).hexdigest() == gold["oracle_proof_sha256"] and len(gp) == gold["oracle_proof_bytes"]
+    stark.verify(pis, gp)
+    wrong = pis.copy()
+    wrong[0] = (int(wrong[0]) + 1) % P
+    with pytest.raises(vx.VxError):
+        stark.verify(wrong, gp)
+
+
 def test_two_tables_on_one_bus_bytes_identical_to_oracle(ctx, oracle):
     """vx_stark_begin x 2 -> joint challenges over both trace caps -> vx_stark_set_aux_challenges -> vx_stark_finish2 with the
     closing sums (vectorx_amd/stark_bus.py): both proofs byte-identical to the oracle's, the bus balances, a proof moved into
