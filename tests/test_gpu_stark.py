@@ -317,7 +317,7 @@ def test_ed25519_air_interpreted_equals_compiled(ctx):
 
 
 def test_sha512_air_proof_bytes_identical_to_oracle_and_to_the_golden(ctx, oracle):
-    """the fourth chip (vectorx_amd/sha512_air.py: 1995 + 5 columns, 4037 constraints, a 31.7 k-word program in 27 chunks): GPU proof ==
+    """the fourth chip (vectorx_amd/sha512_air.py: 1995 + 5 columns, 4037 constraints, a 31.7 k-word program in 25 chunks): GPU proof ==
     oracle proof == the digest frozen in tests/golden/chip_goldens.json (same inputs and configuration as the generator)"""
     import hashlib
     import json
