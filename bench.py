@@ -54,6 +54,18 @@ def parse():
                          "default 0 is the headline gate mix — other values are for profiling the prove-only kernels")
     ap.add_argument("--no-host-witness-leg", action="store_true",
                     help="skip the extra (untimed-by-the-contract) leg that proves from a pinned HOST witness (PCIe-inclusive rate)")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend of the N > 1 run: nccl (= RCCL over xGMI, the default and the only one a result may be "
+                         "quoted from) or gloo (host-staged exchanges; for --ranks-on-one-device)")
+    ap.add_argument("--ranks-on-one-device", action="store_true",
+                    help="EMULATION for single-GPU boxes: the N ranks are N processes that all use device 0 (RCCL refuses duplicate devices, "
+                         "so this forces --dist-backend gloo).  Exercises the N > 1 code path; the line is labelled and is not a measurement")
+    ap.add_argument("--no-multi-rank-legs", action="store_true",
+                    help="N > 1 only: skip the two extra legs after the timed region (one proof sharded over all ranks = BASELINE configs[3]; "
+                         "one header_range_512 DAG over all ranks)")
+    ap.add_argument("--sharded-leg-steps", type=int, default=3)
+    ap.add_argument("--dag-spec", default="64,18,16,19",
+                    help="num_map,map_log_n,reduce_log_n,outer_log_n of the multi-rank DAG leg (tests pass tiny sizes)")
     return ap.parse_args()
 
 
@@ -94,7 +106,7 @@ def launch_ranks(args) -> int:
     line and return the launcher's exit code.  Fewer than N visible devices is an error, not a smaller run."""
     import torch
     ndev = torch.cuda.device_count()      # does not initialise the GPU on this image
-    if ndev < args.gpus:
+    if ndev < (1 if args.ranks_on_one_device else args.gpus):
         print(f"bench.py: --gpus {args.gpus} asked for but only {ndev} GPU(s) are visible — refusing to run a smaller job "
               f"under that label", file=sys.stderr)
         return 3
@@ -135,9 +147,13 @@ def main():
     from vectorx_amd import dist_harness as H
 
     rank, world, local_rank = H.env_rank()
+    if args.ranks_on_one_device:
+        args.dist_backend = "gloo"        # RCCL refuses two ranks on one device
+        local_rank = 0                    # every rank is a process on device 0: an emulation, labelled as such in the line
     if local_rank >= torch.cuda.device_count():
         sys.exit(f"bench.py: rank {rank} has LOCAL_RANK={local_rank} but only {torch.cuda.device_count()} GPU(s) are visible")
-    dist = H.init("nccl", local_rank)
+    dist = H.init(args.dist_backend, local_rank)
+    on_host = dist is not None and dist.get_backend() != "nccl"     # gloo: collectives on host tensors
     ctx = vx.Context(local_rank)  # no CPU fallback: raises if the HIP library / GPU is missing
     n = 1 << args.log_n
     if args.cpu_sample_log_n is None:
@@ -173,13 +189,13 @@ def main():
         if args.workload == "prove" and "allgather" in bench_prove._LEG:   # sharded mode: count the timed steps' exchanges only
             bench_prove._LEG["allgather"].calls = bench_prove._LEG["allgather"].bytes = 0
 
-    dt = H.run_timed(step, args.steps, args.warmup, sync, dist, device=f"cuda:{local_rank}", before_timed=before_timed)
+    dt = H.run_timed(step, args.steps, args.warmup, sync, dist, device=None if on_host else f"cuda:{local_rank}", before_timed=before_timed)
     prof = ctx.prof()
     # which device every rank ran on — gathered over RCCL, so the line proves N distinct GPUs took part
     rank_devices, rccl_ranks = [{"rank": 0, "local_rank": local_rank, "pci_bus_id": _pci_bus_id(torch, local_rank)}], 1
     if dist is not None:
         rccl_ranks = dist.get_world_size()
-        mine = torch.tensor([rank, local_rank, _pci_bus_id(torch, local_rank)], dtype=torch.int64, device=f"cuda:{local_rank}")
+        mine = torch.tensor([rank, local_rank, _pci_bus_id(torch, local_rank)], dtype=torch.int64, device="cpu" if on_host else f"cuda:{local_rank}")
         slots = [torch.empty_like(mine) for _ in range(rccl_ranks)]
         dist.all_gather(slots, mine)
         rank_devices = [{"rank": int(t[0]), "local_rank": int(t[1]), "pci_bus_id": int(t[2])} for t in (x.cpu() for x in slots)]
@@ -206,6 +222,16 @@ def main():
             chip_leg = bench_prove.chip_leg(ctx)
         except Exception as e:   # noqa: BLE001
             chip_leg = {"error": repr(e)}
+
+    # N > 1: two more legs after the timed region so that ONE `bench.py --gpus N` yields the weak-scaling point
+    # (`value`), the strong-scaling point (one 2^21 proof over all N ranks = BASELINE configs[3]) and the real unit of work (one
+    # header_range_512 DAG over all N ranks: /root/reference/circuits/builder/subchain_verification.rs:72-78).  Collective:
+    # every rank takes part; an error on any rank is reported by rank 0 instead of costing the contract's line.
+    sharded_leg = dag_n_leg = None
+    if args.workload == "prove" and world > 1 and not args.no_multi_rank_legs and not args.circuit_flags:
+        dev = None if on_host else torch.device("cuda", local_rank)
+        sharded_leg = bench_prove.guarded_collective_leg(dist, lambda: bench_prove.sharded_one_proof_leg(ctx, args, rank, world, dist, dev, sync))
+        dag_n_leg = bench_prove.guarded_collective_leg(dist, lambda: bench_prove.dag_leg_ranks(ctx, args, local_rank, dist, dev))
 
     if rank == 0:
         lde = prof.get("lde", {"ms": 0.0, "calls": 0, "alg_bytes": 0.0})
@@ -285,7 +311,7 @@ def main():
                                        f"coefficients, first FRI layer, openings; NO row-chunk all-to-all NTT in this mode — that "
                                        f"formulation exists for the commitment only: sharded.commit_sharded)" if sharded_mode else
                                        f"proof-level x{world} (one witness per GPU, no collective)")},
-            "rccl_ranks": rccl_ranks, "rank_devices": rank_devices,
+            "rccl_ranks": rccl_ranks, "rank_devices": rank_devices, "dist_backend": dist.get_backend() if dist is not None else None,
             "roofline": roof,
             "alu_bound_dominant_kernel": alu,
             "stage_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in prof.items()},
@@ -300,6 +326,13 @@ def main():
             out["value_from_host_witness"] = host_leg
         if dag_leg is not None:
             out["dag_header_range_512"] = dag_leg
+        if sharded_leg is not None:
+            out["sharded_one_proof"] = sharded_leg
+        if dag_n_leg is not None:
+            out["dag_header_range_512"] = dag_n_leg
+        if args.ranks_on_one_device:
+            out["emulated_ranks_on_one_device"] = ("EVERY RANK IS A PROCESS ON DEVICE 0 over gloo: exercises the N > 1 code path on a single-GPU box; "
+                                                   "no figure in this line is a multi-GPU measurement")
         if chip_leg is not None:
             out["chip_starks"] = chip_leg
         if not args.no_cpu_baseline and world == 1:

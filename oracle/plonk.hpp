@@ -163,10 +163,18 @@ struct Circuit {
     for (const Gate& g : gates) num_gate_constraints = std::max(num_gate_constraints, g.num_constraints());
     compute_fri_params();
     constants_sigmas.from_values(std::move(constants_sigmas_values), rate_bits, cap_height);
-    // circuit_digest = hash_no_pad(cap.flatten() || domain_separator(empty) || [degree_bits])
+    // circuit_digest = hash_no_pad(cap.flatten() || hash_pad(domain_separator).elements || [degree_bits])   (circuit_builder.rs::build,
+    // recalled; round 4: the separator enters as its PADDED hash).  plonky2x leaves the separator empty; hashing.rs::hash_pad pushes a 1,
+    // zeros until one slot short of a multiple of the rate (8), and a closing 1.
+    std::vector<u64> sep;                    // the (empty) domain separator
+    sep.push_back(1);
+    while ((sep.size() + 1) % 8 != 0) sep.push_back(0);
+    sep.push_back(1);
+    const Hash sep_digest = hash_no_pad(sep.data(), sep.size());
     std::vector<u64> pre;
     for (const Hash& h : constants_sigmas.tree.cap())
       for (int i = 0; i < 4; ++i) pre.push_back(h.e[i]);
+    for (int i = 0; i < 4; ++i) pre.push_back(sep_digest.e[i]);
     pre.push_back((u64)degree_bits);
     circuit_digest = has_digest_override ? digest_override : hash_no_pad(pre.data(), pre.size());
   }

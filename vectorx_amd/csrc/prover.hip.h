@@ -45,16 +45,22 @@ struct vx_circuit {
 
 // VerifierOnlyCircuitData::circuit_digest.  The caller's value when it passes one (VX_DESC_HAS_CIRCUIT_DIGEST) — the Rust
 // side holds it, and then no recalled convention of this library is involved; otherwise THE one place the rule is
-// restated (plonk/circuit_builder.rs, recalled): hash_no_pad(constants_sigmas_cap || domain_separator || [degree_bits])
-// with plonky2x's default EMPTY domain separator.  Open question kept here on purpose: whether v0.2.0 hashes the raw
-// (empty) separator, as below, or a padded form — a real circuit answers it by passing its digest.
+// restated (plonk/circuit_builder.rs::build, recalled — two independent reviews recalled the same form, round 4):
+//   hash_no_pad(constants_sigmas_cap.flatten() || hash_pad(domain_separator).elements || [degree_bits])
+// with plonky2x's default EMPTY domain separator; hash_pad = pad10*1 to a multiple of the rate, so
+// hash_pad([]) = hash_no_pad([1,0,0,0,0,0,0,1]).  `cap_and_degree` = the cap's elements followed by degree_bits.
 static vxh::Hash4 circuit_digest_of(const vx_circuit_desc* d, const u64* cap_and_degree, size_t len) {
   if (d->override_flags & VX_DESC_HAS_CIRCUIT_DIGEST) {
     vxh::Hash4 h;
     for (int i = 0; i < 4; ++i) h.e[i] = vxh::canon(d->circuit_digest[i]);
     return h;
   }
-  return vxh::hash_no_pad(cap_and_degree, len);
+  const u64 padded_empty_separator[8] = {1, 0, 0, 0, 0, 0, 0, 1};
+  const vxh::Hash4 sep = vxh::hash_no_pad(padded_empty_separator, 8);
+  std::vector<u64> parts(cap_and_degree, cap_and_degree + (len - 1));
+  for (int i = 0; i < 4; ++i) parts.push_back(sep.e[i]);
+  parts.push_back(cap_and_degree[len - 1]);
+  return vxh::hash_no_pad(parts.data(), parts.size());
 }
 
 static void circuit_free(vx_circuit* k) {
