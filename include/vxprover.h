@@ -375,6 +375,14 @@ int vx_stark_joint_challenges(const uint64_t* const* trace_caps, const int32_t* 
 int vx_stark_proof_trace_cap(const vx_stark_desc* desc, const uint8_t* proof, size_t proof_len, uint64_t* cap_out);
 int vx_stark_verify_shared(const vx_stark_desc* desc, const uint64_t* public_inputs, const uint8_t* proof, size_t proof_len,
                            const uint64_t* shared_challenges /* NULL: the proof's own */, uint64_t* aux_public_inputs_out /* may be NULL */);
+/* The whole verifier side of a bus in ONE call: the trace caps out of the proofs -> the joint challenges -> every proof verified with
+ * them -> every closing sum (index i of each table's num_aux_public_inputs values; all tables declare the same number of shared
+ * challenges and of closing sums) must cancel over the tables mod p.  VX_E_PROOF when a proof is invalid OR the bus does not balance.
+ * `closing_sums_out` (may be NULL) = [num_tables][num_aux_public_inputs].
+ * vx_stark_verify (no argument for closing sums) accepts a table with num_aux_public_inputs > 0 only when every sum is ZERO —
+ * the meaning a table verified on its own can have; a caller that does its own accounting uses vx_stark_verify_shared. */
+int vx_stark_verify_bus(const vx_stark_desc* const* descs, const uint64_t* const* public_inputs, const uint8_t* const* proofs,
+                        const size_t* proof_lens, int num_tables, uint64_t* closing_sums_out);
 
 /* ---- ONE proof sharded across the GPUs of a node (BASELINE.json configs[3]) -------------------
  * `world` in {1, 2, 4, 8} ranks (one vx_ctx + one copy of the circuit each; world <= 2^rate_bits and

@@ -256,17 +256,12 @@ void* vxo_circuit_create_verifier(const vxo_circuit_desc* d, const u64* cap) {
   load_overrides(d, c);
   c->compute_fri_params();
   std::vector<Hash> capv((size_t)1 << d->cap_height);
-  std::vector<u64> pre;
   for (size_t i = 0; i < capv.size(); ++i)
-    for (int k = 0; k < 4; ++k) {
-      capv[i].e[k] = canon(cap[4 * i + k]);
-      pre.push_back(capv[i].e[k]);
-    }
-  pre.push_back((u64)d->degree_bits);
+    for (int k = 0; k < 4; ++k) capv[i].e[k] = canon(cap[4 * i + k]);
   c->constants_sigmas.tree.layers.clear();
   c->constants_sigmas.tree.layers.push_back(capv);
   c->constants_sigmas.tree.cap_height = d->cap_height;
-  c->circuit_digest = c->has_digest_override ? c->digest_override : hash_no_pad(pre.data(), pre.size());
+  c->circuit_digest = c->has_digest_override ? c->digest_override : Circuit::digest_of_cap(capv, d->degree_bits);
   return c;
 }
 void vxo_circuit_free(void* c) { delete (Circuit*)c; }

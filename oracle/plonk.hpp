@@ -157,26 +157,29 @@ struct Circuit {
       db -= arity_bits;
     }
   }
-  // circuit_builder.rs::build: constants_sigmas_commitment + circuit_digest
-  void finalize(std::vector<std::vector<u64>>&& constants_sigmas_values) {
-    num_gate_constraints = 0;
-    for (const Gate& g : gates) num_gate_constraints = std::max(num_gate_constraints, g.num_constraints());
-    compute_fri_params();
-    constants_sigmas.from_values(std::move(constants_sigmas_values), rate_bits, cap_height);
-    // circuit_digest = hash_no_pad(cap.flatten() || hash_pad(domain_separator).elements || [degree_bits])   (circuit_builder.rs::build,
-    // recalled; round 4: the separator enters as its PADDED hash).  plonky2x leaves the separator empty; hashing.rs::hash_pad pushes a 1,
-    // zeros until one slot short of a multiple of the rate (8), and a closing 1.
+  // circuit_digest = hash_no_pad(cap.flatten() || hash_pad(domain_separator).elements || [degree_bits])   (circuit_builder.rs::build,
+  // recalled; round 4: the separator enters as its PADDED hash).  plonky2x leaves the separator empty; hashing.rs::hash_pad pushes a 1,
+  // zeros until one slot short of a multiple of the rate (8), and a closing 1.  THE one place of the rule in the oracle.
+  static Hash digest_of_cap(const std::vector<Hash>& cap, int degree_bits) {
     std::vector<u64> sep;                    // the (empty) domain separator
     sep.push_back(1);
     while ((sep.size() + 1) % 8 != 0) sep.push_back(0);
     sep.push_back(1);
     const Hash sep_digest = hash_no_pad(sep.data(), sep.size());
     std::vector<u64> pre;
-    for (const Hash& h : constants_sigmas.tree.cap())
+    for (const Hash& h : cap)
       for (int i = 0; i < 4; ++i) pre.push_back(h.e[i]);
     for (int i = 0; i < 4; ++i) pre.push_back(sep_digest.e[i]);
     pre.push_back((u64)degree_bits);
-    circuit_digest = has_digest_override ? digest_override : hash_no_pad(pre.data(), pre.size());
+    return hash_no_pad(pre.data(), pre.size());
+  }
+  // circuit_builder.rs::build: constants_sigmas_commitment + circuit_digest
+  void finalize(std::vector<std::vector<u64>>&& constants_sigmas_values) {
+    num_gate_constraints = 0;
+    for (const Gate& g : gates) num_gate_constraints = std::max(num_gate_constraints, g.num_constraints());
+    compute_fri_params();
+    constants_sigmas.from_values(std::move(constants_sigmas_values), rate_bits, cap_height);
+    circuit_digest = has_digest_override ? digest_override : digest_of_cap(constants_sigmas.tree.cap(), degree_bits);
   }
 };
 

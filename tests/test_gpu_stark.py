@@ -92,11 +92,11 @@ def test_two_round_session_api(ctx, oracle):
     expect = oracle_lib.stark_prove(oracle, stark, trace, pis)
     L = vx.lib()
     vp = ctypes.c_void_p
-    chal = np.zeros(1, dtype=np.uint64)
+    chal = np.zeros(stark.desc.num_aux_challenges, dtype=np.uint64)      # one per challenge set (Stark repeats the second round)
     sess = vp()
     t = np.ascontiguousarray(trace, dtype=np.uint64)
     assert L.vx_stark_begin(ctx._h, ctypes.cast(stark.desc_ptr, vp), t.ctypes.data, 0, pis.ctypes.data, chal.ctypes.data, ctypes.byref(sess)) == 0
-    aux = np.ascontiguousarray(stark.aux_fn(t, chal), dtype=np.uint64)
+    aux = stark.run_aux(t, chal)[0]
     d_aux = ctx.alloc(aux.nbytes)
     ctx.upload(d_aux, aux)
     small = np.empty(16, dtype=np.uint8)

@@ -61,6 +61,18 @@ def test_prove_verify_round_trip(small):
     assert np.frombuffer(proof[-32:], dtype="<u8").tolist() == sc.public_inputs().tolist()
 
 
+def test_verifier_only_circuit_has_the_same_digest_and_verdict(small, oracle):
+    """VerifierOnlyCircuitData built from the cap alone: circuit_digest follows the one rule (Circuit::digest_of_cap —
+    hash_no_pad(cap || hash_pad(empty separator) || [degree_bits])), recomputed here with the oracle's sponge as an independent spelling"""
+    sc, oc, proof = small
+    ov = oracle_lib.OracleCircuit(oracle, sc.desc_ptr, verifier_cap=oc.cap())
+    assert (ov.digest() == oc.digest()).all()
+    assert ov.verify(proof) == ""
+    sep = oracle.hash_no_pad(np.array([1, 0, 0, 0, 0, 0, 0, 1], dtype=np.uint64))
+    pre = np.concatenate([oc.cap().reshape(-1), sep, np.array([sc.degree_bits], dtype=np.uint64)])
+    assert (oracle.hash_no_pad(pre) == oc.digest()).all()
+
+
 def test_proof_is_deterministic_and_accepts_a_pow_hint(small):
     sc, oc, proof = small
     assert oc.prove(sc.witness()) == proof

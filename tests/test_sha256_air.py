@@ -145,7 +145,9 @@ def test_two_tables_on_one_bus(oracle):
         sha_stark.verify(pis, proofs[0])
     # the product's challenge derivation equals the oracle's
     caps = [sha_stark.proof_trace_cap(proofs[0]), sink_stark.proof_trace_cap(proofs[1])]
-    assert (vx.stark_joint_challenges(caps, [4, 4], 3) == shared).all()
+    assert sha_stark.desc.num_aux_challenges == 6                     # [gamma_range, beta, gamma_bus] x 2 challenge sets
+    assert (vx.stark_joint_challenges(caps, [4, 4], 6) == shared).all()
+    assert len(sums[0]) == 2 and (int(sums[0][1]) + int(sums[1][1])) % P == 0 and int(sums[0][1]) != int(sums[0][0])
     # a sink that receives a digest nobody sent: both proofs are valid on their own, the bus does not balance
     wrong = [digests[0], hashlib.sha256(b"not sent").digest()]
     sink2, sink2_t, sink2_pis = sha.make_sink(4, wrong, **cfg)

@@ -107,12 +107,12 @@ def test_two_round_air_lookup_soundness(oracle):
     with pytest.raises(vx.VxError) as e:
         stark.verify(pis, proof)
     assert e.value.code == vx.VX_E_INVALID
-    stark.desc.num_aux_challenges = 1
+    stark.desc.num_aux_challenges = 2            # one per challenge set
     stark.desc.num_aux_columns = 0               # challenges without a second round, and the program reads column 3
     with pytest.raises(vx.VxError) as e:
         stark.verify(pis, proof)
     assert e.value.code == vx.VX_E_INVALID
-    stark.desc.num_aux_columns = 1
+    stark.desc.num_aux_columns = 2
     stark.verify(pis, proof)
 
 
@@ -141,3 +141,82 @@ def test_programs_can_be_compiled_ahead_of_time_without_a_gpu():
     sc.desc.num_gates = 0
     with pytest.raises(vx.VxError):
         vx.circuit_precompile(sc.desc_ptr)
+
+
+def test_second_round_is_repeated_per_challenge_set(oracle):
+    """one base-field challenge gives a lookup / bus ~2^-43 soundness; `Stark` repeats the second round once per challenge
+    set (replicate_aux_program).  The repeated program reads set 1's challenge, column and closing sum; the first-round constraint
+    is not repeated; corrupting ONLY set 1's accumulator is fatal."""
+    stark, trace, pis = logup(6, pow_bits=4)
+    assert stark.aux_reps == 2 and stark.desc.num_aux_columns == 2 and stark.desc.num_aux_challenges == 2
+    words = [int(stark._prog[i]) for i in range(stark.desc.program_len)]
+    ops = []
+    i = 0
+    while i < len(words):
+        w = words[i]
+        ops.append((w & 0xFF, (w >> 16) & 0xFFFF))
+        i += 2 if (w & 0xFF) == vx.VX_OP_LDI else 1
+    assert [a for op, a in ops if op == vx.VX_OP_LDCH] == [0, 1]
+    assert sorted(a for op, a in ops if op in (vx.VX_OP_LDW, vx.VX_OP_LDN) and a >= 3) == [3, 3, 4, 4]
+    assert sum(1 for op, _ in ops if op == vx.VX_OP_PUSH) == 4 + 3          # 3 second-round constraints repeated, v = pi[0] not
+    assert sum(1 for op, _ in ops if op == vx.VX_OP_LDP) == 1
+    single = vx.Stark(6, 3, 1, [int(w) for w in vx.replicate_aux_program(words, 3, 1, 1, 1, 0, 1)], constraint_degree=3,
+                      num_aux_columns=2, num_aux_challenges=2, aux_reps=1)
+    assert single.desc.program_len == len(words)                           # reps = 1 is the identity
+    proof = oracle_lib.stark_prove(oracle, stark, trace, pis)
+    stark.verify(pis, proof)
+    good_fn, calls = stark.aux_fn, [0]
+
+    def second_set_only(tr, ch):
+        calls[0] += 1
+        a = good_fn(tr, ch)
+        return (a + np.uint64(1)) % np.uint64(P) if calls[0] % 2 == 0 else a
+    stark.aux_fn = second_set_only
+    try:
+        try:
+            bad = oracle_lib.stark_prove(oracle, stark, trace, pis)
+        except RuntimeError:
+            bad = None
+        if bad is not None:
+            with pytest.raises(vx.VxError):
+                stark.verify(pis, bad)
+    finally:
+        stark.aux_fn = good_fn
+
+
+def test_c_entry_points_look_at_the_closing_sums(oracle):
+    """vx_stark_verify used to return VX_OK for a table with closing sums while dropping them.  Now a table verified on
+    its own must close at zero, and vx_stark_verify_bus does the whole verifier side of a bus — joint challenges, every proof, the
+    balance — behind the C ABI."""
+    import ctypes
+    import hashlib
+
+    from vectorx_amd import sha256_air as sha
+    from vectorx_amd import stark_bus
+    cfg = dict(num_query_rounds=12, pow_bits=4)
+    sha_stark = sha.make_stark(8, bus=True, **cfg)
+    t, pis, digests = sha.generate_trace(8, [b"abc", b""])
+    sink_stark, sink_t, sink_pis = sha.make_sink(4, digests, **cfg)
+    proofs, _ = oracle_lib.stark_prove_tables(oracle, [(sha_stark, t, pis), (sink_stark, sink_t, sink_pis)])
+    sums = vx.stark_verify_bus([(sha_stark, pis), (sink_stark, sink_pis)], proofs)
+    assert sums.shape == (2, 2) and all((int(sums[0][i]) + int(sums[1][i])) % P == 0 and int(sums[0][i]) != 0 for i in range(2))
+    # a sender alone: every proof of it is valid, its closing sums are not zero -> the plain entry point refuses it
+    own = oracle_lib.stark_prove(oracle, sha_stark, t, pis)          # the table's OWN challenges (no bus session)
+    assert any(int(s) for s in sha_stark.verify(pis, own))           # valid through vx_stark_verify_shared, which hands the sums back
+    lone, _ = oracle_lib.stark_prove_tables(oracle, [(sha_stark, t, pis)])
+    buf = np.frombuffer(own, dtype=np.uint8)
+    L = vx.lib()
+    rc = L.vx_stark_verify(ctypes.cast(sha_stark.desc_ptr, ctypes.c_void_p), np.ascontiguousarray(pis, dtype=np.uint64).ctypes.data, buf.ctypes.data, buf.size)
+    assert rc == vx.VX_E_PROOF and b"closing sum" in L.vx_last_error()
+    with pytest.raises(vx.VxError, match="cancel"):
+        vx.stark_verify_bus([(sha_stark, pis)], lone)
+    # valid proofs, unbalanced bus
+    wrong = [digests[0], hashlib.sha256(b"not sent").digest()]
+    sink2, sink2_t, sink2_pis = sha.make_sink(4, wrong, **cfg)
+    proofs2, _ = oracle_lib.stark_prove_tables(oracle, [(sha_stark, t, pis), (sink2, sink2_t, sink2_pis)])
+    with pytest.raises(vx.VxError, match="cancel"):
+        vx.stark_verify_bus([(sha_stark, pis), (sink2, sink2_pis)], proofs2)
+    assert not stark_bus.bus_balanced(stark_bus.verify_tables([(sha_stark, pis), (sink2, sink2_pis)], proofs2))
+    # table order is part of the statement
+    with pytest.raises(vx.VxError):
+        vx.stark_verify_bus([(sink_stark, sink_pis), (sha_stark, pis)], proofs[::-1])

@@ -117,6 +117,7 @@ _SIGNATURES = {
     "vx_stark_joint_challenges": (_i, [_vp, _vp, _i, _i, _vp]),
     "vx_stark_proof_trace_cap": (_i, [_vp, _vp, _sz, _vp]),
     "vx_stark_verify_shared": (_i, [_vp, _vp, _vp, _sz, _vp, _vp]),
+    "vx_stark_verify_bus": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
     "vx_circuit_program_gates": (_i, [_vp, ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.c_char_p, _sz]),
     "vx_prove_sharded": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, ctypes.POINTER(_sz)]),
     "vx_group_create": (_i, [_i, ctypes.POINTER(_vp)]),
@@ -429,20 +430,99 @@ def vx_ins(op, dst=0, a=0, b=0) -> int:
     return op | (dst << 8) | (a << 16) | (b << 32)
 
 
+def replicate_aux_program(program, num_columns, num_public_inputs, num_aux_columns, num_aux_challenges, num_aux_public_inputs, reps):
+    """The second-round argument of an AIR program, repeated once per challenge set (what starky does with its lookups for each of
+    `num_challenges`): a log-derivative lookup or a bus over ONE base-field challenge is sound to about (lookups + table size) / 2^64
+    — ~2^-43 at 2^13 .. 2^18 rows — far below what the FRI configuration targets; with `reps` independent challenge sets, each with
+    its own helper / accumulator columns and closing sums, the error is that to the power `reps`.
+
+    `program` is written for ONE set.  Set 0 is the program as it stands; for set r >= 1 the backward slice of every constraint that
+    depends on a challenge, a second-round column or a closing sum is emitted again (same instructions, same registers, same order —
+    an instruction outside the slice never feeds one inside it) with challenge index + r * num_aux_challenges, second-round
+    column + r * num_aux_columns, closing sum + r * num_aux_public_inputs.  Constraints of the first round are not repeated."""
+    ins = []          # (op, dst, a, b, imm)
+    i, words = 0, [int(w) for w in program]
+    while i < len(words):
+        w = words[i]
+        op, dst, a, b = w & 0xFF, (w >> 8) & 0xFF, (w >> 16) & 0xFFFF, (w >> 32) & 0xFFFFFFFF
+        if op == VX_OP_END:
+            break
+        imm = None
+        if op == VX_OP_LDI:
+            i += 1
+            imm = words[i]
+        ins.append((op, dst, a, b, imm))
+        i += 1
+    if reps <= 1:
+        return list(words)
+    last_def = {}                 # register -> index of the instruction that wrote it last
+    srcs, taint = [], []
+    for k, (op, dst, a, b, imm) in enumerate(ins):
+        if op in (VX_OP_ADD, VX_OP_SUB, VX_OP_MUL):
+            s = [last_def[a], last_def[b]]
+        elif op == VX_OP_PUSH:
+            s = [last_def[a]]
+        else:
+            s = []
+        own = (op == VX_OP_LDCH) or (op in (VX_OP_LDW, VX_OP_LDN) and a >= num_columns) or (op == VX_OP_LDP and a >= num_public_inputs)
+        srcs.append(s)
+        taint.append(own or any(taint[j] for j in s))
+        if op != VX_OP_PUSH:
+            last_def[dst] = k
+    need = [False] * len(ins)
+    stack = [k for k, t in enumerate(ins) if t[0] == VX_OP_PUSH and taint[k]]
+    while stack:
+        k = stack.pop()
+        if need[k]:
+            continue
+        need[k] = True
+        stack.extend(srcs[k])
+    out = []
+
+    def emit(op, dst, a, b, imm):
+        out.append(vx_ins(op, dst, a, b))
+        if imm is not None:
+            out.append(imm)
+
+    for t in ins:
+        emit(*t)
+    for r in range(1, reps):
+        for k, (op, dst, a, b, imm) in enumerate(ins):
+            if not need[k]:
+                continue
+            if op == VX_OP_LDCH:
+                a += r * num_aux_challenges
+            elif op in (VX_OP_LDW, VX_OP_LDN) and a >= num_columns:
+                a += r * num_aux_columns
+            elif op == VX_OP_LDP and a >= num_public_inputs:
+                a += r * num_aux_public_inputs
+            emit(op, dst, a, b, imm)
+    out.append(vx_ins(VX_OP_END))
+    return out
+
+
 class Stark:
     """An AIR as a constraint program + its STARK configuration (`vx_stark_desc`).  Defaults = starky's
     StarkConfig::standard_fast_config (rate_bits 1, cap_height 4, 16 PoW bits, 84 queries, 2 challenges)."""
 
     def __init__(self, degree_bits, num_columns, num_public_inputs, program, constraint_degree, rate_bits=1, cap_height=4, pow_bits=16,
                  num_query_rounds=84, num_challenges=2, fri_arities=None, num_aux_columns=0, num_aux_challenges=0, aux_fn=None,
-                 num_aux_public_inputs=0):
+                 num_aux_public_inputs=0, aux_reps=None):
         """`num_aux_columns` / `num_aux_challenges` / `aux_fn`: a second commitment round — `aux_fn(trace, challenges)` returns the
         [num_aux_columns][n] columns the caller computes between `vx_stark_begin` and `vx_stark_finish`; with
-        `num_aux_public_inputs` > 0 (closing sums of a bus / lookup accumulator) it returns `(columns, aux_public_inputs)`."""
+        `num_aux_public_inputs` > 0 (closing sums of a bus / lookup accumulator) it returns `(columns, aux_public_inputs)`.
+        These counts, the program and `aux_fn` describe ONE challenge set; the second round is repeated `aux_reps` times
+        (default: `num_challenges`, as starky repeats its lookups) by `replicate_aux_program`, so the description the library sees has
+        `aux_reps` times the columns, challenges and closing sums (set-major: everything of set 0, then set 1, ...)."""
+        self.aux_reps = (num_challenges if aux_reps is None else aux_reps) if num_aux_columns > 0 else 1
+        self.per_set = (num_aux_columns, num_aux_challenges, num_aux_public_inputs)
+        if self.aux_reps > 1:
+            program = replicate_aux_program(program, num_columns, num_public_inputs, num_aux_columns, num_aux_challenges,
+                                            num_aux_public_inputs, self.aux_reps)
         self._prog = (ctypes.c_uint64 * len(program))(*program)
         self.desc = StarkDesc(degree_bits, num_columns, num_public_inputs, rate_bits, cap_height, pow_bits, num_query_rounds, num_challenges,
                               constraint_degree, len(program), ctypes.cast(self._prog, ctypes.c_void_p).value, 0, 0, None,
-                              num_aux_columns, num_aux_challenges, num_aux_public_inputs)
+                              num_aux_columns * self.aux_reps, num_aux_challenges * self.aux_reps, num_aux_public_inputs * self.aux_reps)
         self.aux_fn = aux_fn
         if fri_arities is not None:
             self._ar = (ctypes.c_int32 * max(1, len(fri_arities)))(*fri_arities)
@@ -461,9 +541,14 @@ class Stark:
 
     def run_aux(self, trace, challenges):
         """-> (aux columns [num_aux_columns][n] uint64, aux public inputs [num_aux_public_inputs] uint64)"""
-        r = self.aux_fn(trace, challenges)
-        cols, api = r if isinstance(r, tuple) else (r, np.zeros(0, dtype=np.uint64))
-        cols, api = _as_u64(cols), np.ascontiguousarray(api, dtype=np.uint64).reshape(-1)
+        nch = self.per_set[1]
+        cols, api = [], []
+        for r in range(self.aux_reps):           # one run of the table's aux_fn per challenge set
+            res = self.aux_fn(trace, challenges[r * nch:(r + 1) * nch])
+            c, a = res if isinstance(res, tuple) else (res, np.zeros(0, dtype=np.uint64))
+            cols.append(_as_u64(c))
+            api.append(np.ascontiguousarray(a, dtype=np.uint64).reshape(-1))
+        cols, api = np.ascontiguousarray(np.concatenate(cols, axis=0)), np.concatenate(api)
         if cols.shape != (self.desc.num_aux_columns, 1 << self.desc.degree_bits) or api.size != self.desc.num_aux_public_inputs:
             raise VxError(VX_E_INVALID, f"aux columns have shape {cols.shape}, {api.size} aux public inputs")
         return cols, api
@@ -533,6 +618,22 @@ class Stark:
         buf = np.frombuffer(proof, dtype=np.uint8)
         _chk(lib().vx_stark_proof_trace_cap(ctypes.cast(self.desc_ptr, _vp), buf.ctypes.data, buf.size, cap.ctypes.data))
         return cap
+
+
+def stark_verify_bus(tables, proofs) -> np.ndarray:
+    """`vx_stark_verify_bus`: tables = [(Stark, public_inputs)] in bus order -> closing sums [num_tables][num_aux_public_inputs];
+    raises VxError(VX_E_PROOF, reason) when a proof is invalid or a closing sum does not cancel over the tables."""
+    k = len(tables)
+    pis = [_as_u64(pi) for _, pi in tables]
+    bufs = [np.frombuffer(p, dtype=np.uint8) for p in proofs]
+    descs = (ctypes.c_void_p * k)(*[ctypes.cast(st.desc_ptr, _vp).value for st, _ in tables])
+    pi_p = (ctypes.c_void_p * k)(*[a.ctypes.data for a in pis])
+    pr_p = (ctypes.c_void_p * k)(*[b.ctypes.data for b in bufs])
+    lens = (ctypes.c_size_t * k)(*[b.size for b in bufs])
+    ns = tables[0][0].desc.num_aux_public_inputs
+    out = np.zeros((k, max(1, ns)), dtype=np.uint64)
+    _chk(lib().vx_stark_verify_bus(ctypes.cast(descs, _vp), ctypes.cast(pi_p, _vp), ctypes.cast(pr_p, _vp), ctypes.cast(lens, _vp), k, out.ctypes.data))
+    return out[:, :ns]
 
 
 def stark_joint_challenges(caps, cap_heights, n: int) -> np.ndarray:

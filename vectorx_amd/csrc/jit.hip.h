@@ -39,6 +39,7 @@ static std::string jit_limits_defines() {
   return s.str();
 }
 
+#define VX_JIT_GROUP_MAX 8   /* program gates per generated kernel (JitGateParams::g); emitted into the generated source by jit_limits_defines */
 struct JitGateRt {
   int gate_index, selector_index, group_start, group_end;
 };
@@ -53,8 +54,9 @@ struct JitGateParams {  // mirrored textually in jit_gate_source()
   int const_base, pad_;  // first gate constant among the preprocessed columns: num_selectors + num_lookup_selectors
   u64 pih[4];
   u64 zh_inv[VX_MAX_RATE];
-  JitGateRt g[8];                // the gates this launch evaluates (VX_JIT_GROUP_MAX; a group of program gates per kernel)
+  JitGateRt g[VX_JIT_GROUP_MAX];  // the gates this launch evaluates (a group of program gates per kernel)
 };
+static_assert(sizeof(JitGateParams::g) / sizeof(JitGateRt) == VX_JIT_GROUP_MAX, "host JitGateParams and the generated source share VX_JIT_GROUP_MAX");
 
 static const char* JIT_PRELUDE =
 #include "jit_prelude.inc"
@@ -252,7 +254,6 @@ GLD u64 dot3_reduce_nc(const dot3& D) {
   return gl_reduce128_nc((u64)V, (u64)(V >> 64));
 }
 )VXJIT";
-#define VX_JIT_GROUP_MAX 8   /* program gates per generated kernel (JitGateParams::g) */
 static std::string jit_gate_source(const std::vector<const uint64_t*>& progs, int nch) {
   std::ostringstream s;
   // Occupancy bound: without one the compiler keeps every wire it has loaded live, takes >256 VGPRs and runs one wave per SIMD
@@ -261,6 +262,7 @@ static std::string jit_gate_source(const std::vector<const uint64_t*>& progs, in
   s << "typedef unsigned long long uint64_t;\ntypedef unsigned int uint32_t;\n#define VX_JIT_BLOCKS_PER_CU " << (bpc ? atoi(bpc) : 4) << "\n"
     << "#define VX_ALPHA_POWS " << VX_ALPHA_POWS << "\n#define VX_JIT_GROUP_MAX " << VX_JIT_GROUP_MAX << "\n"
     << jit_limits_defines() << JIT_PRELUDE << JIT_DOT3 << R"VXJIT(
+#define VX_JIT_GROUP_MAX 8   /* program gates per generated kernel (JitGateParams::g); emitted into the generated source by jit_limits_defines */
 struct JitGateRt {
   int gate_index, selector_index, group_start, group_end;
 };
@@ -539,26 +541,54 @@ static std::vector<JitAirKernel> jit_air_get(const uint64_t* prog, int nch, int 
     *why = "VX_NO_JIT is set";
     return out;
   }
+  if (!jit_api().ok) {            // before a megabyte of chunk sources is generated for nothing
+    *why = "libhiprtc.so not available";
+    return out;
+  }
   // per (program, nch, ncols, device): the loaded kernels — generating a megabyte of source per proof just to look it up again
-  // cost more than the kernels take to run
+  // cost more than the kernels take to run.  One entry per key, compiled ONCE under the entry's own lock (the map's lock is held for
+  // the lookup only: another lane proving another table is not blocked for the minutes a compilation can take), and a FAILED
+  // compilation / load is remembered too — the program then stays on the interpreter without retrying on every proof.
+  struct Entry {
+    std::mutex m;
+    bool done = false;
+    std::vector<JitAirKernel> kernels;
+    std::string why;
+  };
   static std::mutex mu;
-  static std::map<std::vector<uint64_t>, std::vector<JitAirKernel>> loaded;
+  static std::map<std::vector<uint64_t>, std::shared_ptr<Entry>> loaded;
   std::vector<uint64_t> key = {(uint64_t)nch, (uint64_t)ncols, (uint64_t)device};
   for (int pc = 0;; ++pc) {
     key.push_back(prog[pc]);
     if ((prog[pc] & 0xFF) == VX_OP_END) break;
     if ((prog[pc] & 0xFF) == VX_OP_LDI) key.push_back(prog[++pc]);
   }
-  std::lock_guard<std::mutex> lk(mu);
-  auto it = loaded.find(key);
-  if (it != loaded.end()) return it->second;
-  if (jit_air_precompile(prog, nch, ncols, nullptr, why) < 0) return out;   // all missing chunks
+  std::shared_ptr<Entry> e;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    std::shared_ptr<Entry>& slot = loaded[key];
+    if (!slot) slot = std::make_shared<Entry>();
+    e = slot;
+  }
+  std::lock_guard<std::mutex> lk(e->m);
+  if (e->done) {
+    if (e->kernels.empty()) *why = e->why;
+    return e->kernels;
+  }
+  e->done = true;
+  if (jit_air_precompile(prog, nch, ncols, nullptr, why) < 0) {   // all missing chunks
+    e->why = *why;
+    return out;
+  }
   for (const JitAirChunk& c : jit_air_chunks(prog, nch, ncols)) {
     hipFunction_t fn = jit_get_kernel(c.src, "vx_air_quotient", device, why);
-    if (!fn) return {};
+    if (!fn) {
+      e->why = *why;
+      return {};
+    }
     out.push_back(JitAirKernel{fn, c.push_begin, c.push_end});
   }
-  loaded.emplace(std::move(key), out);
+  e->kernels = out;
   return out;
 }
 static hipFunction_t jit_get_kernel(const std::string& src, const char* kernel_name, int device, std::string* why) {
@@ -709,6 +739,10 @@ static int jit_precompile_sources(const std::vector<const std::string*>& srcs, s
   return (int)todo.size();
 }
 static int jit_air_precompile(const uint64_t* prog, int nch, int ncols, int* nchunks, std::string* why) {
+  if (!jit_api().ok && !nchunks) {   // nothing could be compiled: do not generate the sources (vx_stark_precompile still reports the chunk count)
+    *why = "libhiprtc.so not available";
+    return -1;
+  }
   const std::vector<JitAirChunk> chunks = jit_air_chunks(prog, nch, ncols);
   if (nchunks) *nchunks = (int)chunks.size();
   std::vector<const std::string*> srcs;

@@ -914,7 +914,65 @@ int vx_stark_finish2(vx_stark_session* s, const uint64_t* aux_columns, int aux_o
 }
 void vx_stark_session_free(vx_stark_session* s) { delete s; }
 int vx_stark_verify(const vx_stark_desc* d, const uint64_t* public_inputs, const uint8_t* proof, size_t proof_len) {
-  return vx_stark_verify_shared(d, public_inputs, proof, proof_len, nullptr, nullptr);
+  // A table that announces closing sums is only proven once somebody has looked at them.  This entry point has no argument for
+  // them, so it takes the one meaning a lone table can have: every sum is zero (what it sent it received itself).  Tables whose
+  // sums cancel against OTHER tables go through vx_stark_verify_bus.
+  if (!d) return vx_fail(VX_E_INVALID, "vx_stark_verify: NULL argument");
+  const int ns = d->num_aux_public_inputs;
+  if (ns < 0 || ns > (1 << 16)) return vx_fail(VX_E_INVALID, "vx_stark_verify: bad num_aux_public_inputs");
+  std::vector<uint64_t> sums((size_t)std::max(ns, 1), 0);
+  const int rc = vx_stark_verify_shared(d, public_inputs, proof, proof_len, nullptr, sums.data());
+  if (rc != VX_OK) return rc;
+  for (int i = 0; i < ns; ++i)
+    if (vxh::canon(sums[i]) != 0)
+      return vx_fail(VX_E_PROOF, "vx_stark_verify: closing sum %d of a table verified on its own is not zero (tables on a shared bus: vx_stark_verify_bus)", i);
+  return VX_OK;
+}
+int vx_stark_verify_bus(const vx_stark_desc* const* descs, const uint64_t* const* public_inputs, const uint8_t* const* proofs,
+                        const size_t* proof_lens, int num_tables, uint64_t* closing_sums_out) {
+  if (!descs || !public_inputs || !proofs || !proof_lens || num_tables < 1 || num_tables > 4096)
+    return vx_fail(VX_E_INVALID, "vx_stark_verify_bus: bad argument");
+  try {
+    for (int t = 0; t < num_tables; ++t)
+      if (!descs[t] || !proofs[t]) return vx_fail(VX_E_INVALID, "vx_stark_verify_bus: table %d: NULL description or proof", t);
+    const int nch = descs[0]->num_aux_challenges, ns = descs[0]->num_aux_public_inputs;
+    if (nch < 1 || ns < 1) return vx_fail(VX_E_INVALID, "vx_stark_verify_bus: the tables of a bus draw shared challenges and announce closing sums");
+    for (int t = 1; t < num_tables; ++t)
+      if (descs[t]->num_aux_challenges != nch || descs[t]->num_aux_public_inputs != ns)
+        return vx_fail(VX_E_INVALID, "vx_stark_verify_bus: table %d declares %d shared challenges / %d closing sums, table 0 %d / %d", t,
+                       descs[t]->num_aux_challenges, descs[t]->num_aux_public_inputs, nch, ns);
+    // the joint challenges come from the trace caps INSIDE the proofs (table order is part of the statement)
+    std::vector<std::vector<uint64_t>> caps((size_t)num_tables);
+    std::vector<const uint64_t*> cap_ptrs((size_t)num_tables);
+    std::vector<int32_t> heights((size_t)num_tables);
+    for (int t = 0; t < num_tables; ++t) {
+      if (descs[t]->cap_height < 0 || descs[t]->cap_height > 24) return vx_fail(VX_E_INVALID, "vx_stark_verify_bus: table %d: bad cap_height", t);
+      caps[t].resize((size_t)4 << descs[t]->cap_height);
+      const int rc = vx_stark_proof_trace_cap(descs[t], proofs[t], proof_lens[t], caps[t].data());
+      if (rc != VX_OK) return rc;
+      cap_ptrs[t] = caps[t].data();
+      heights[t] = descs[t]->cap_height;
+    }
+    std::vector<uint64_t> shared((size_t)nch);
+    int rc = vx_stark_joint_challenges(cap_ptrs.data(), heights.data(), num_tables, nch, shared.data());
+    if (rc != VX_OK) return rc;
+    std::vector<uint64_t> sums((size_t)num_tables * ns);
+    for (int t = 0; t < num_tables; ++t) {
+      rc = vx_stark_verify_shared(descs[t], public_inputs[t], proofs[t], proof_lens[t], shared.data(), sums.data() + (size_t)t * ns);
+      if (rc != VX_OK) return rc;
+    }
+    if (closing_sums_out) memcpy(closing_sums_out, sums.data(), sums.size() * sizeof(uint64_t));
+    for (int i = 0; i < ns; ++i) {
+      uint64_t acc = 0;
+      for (int t = 0; t < num_tables; ++t) acc = vxh::add(acc, vxh::canon(sums[(size_t)t * ns + i]));
+      if (acc != 0) return vx_fail(VX_E_PROOF, "vx_stark_verify_bus: closing sum %d does not cancel over the %d tables (every proof is valid; the bus is unbalanced)", i, num_tables);
+    }
+    return VX_OK;
+  } catch (const std::bad_alloc&) {
+    return vx_fail(VX_E_NOMEM, "vx_stark_verify_bus: out of host memory");
+  } catch (const std::exception& e) {
+    return vx_fail(VX_E_PROOF, "vx_stark_verify_bus: exception: %s", e.what());
+  }
 }
 int vx_stark_verify_shared(const vx_stark_desc* d, const uint64_t* public_inputs, const uint8_t* proof, size_t proof_len,
                            const uint64_t* shared_challenges, uint64_t* aux_public_inputs_out) {

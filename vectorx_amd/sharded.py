@@ -167,7 +167,7 @@ def prove_sharded_processes(circuit, wires, dist, device=None, pow_witness=None)
     return circuit.prove_sharded(wires, dist.get_rank(), world, ag, pow_witness=pow_witness)
 
 
-def prove_sharded_threads(circuits, wires, pow_witness=None):
+def prove_sharded_threads(circuits, wires, pow_witness=None, timeout_ms=600_000):
     """One process, one host thread + one `vx_ctx` (GPU) per rank, exchanging through the library's own `vx_group`
     (peer copies over xGMI) — the shape a Rust host with 8 worker threads uses.  `circuits[r]` is rank r's copy of
     the circuit (its own context).  Returns the list of per-rank proofs (all identical)."""
@@ -180,6 +180,9 @@ def prove_sharded_threads(circuits, wires, pow_witness=None):
     L = lib()
     g = ctypes.c_void_p()
     _chk(L.vx_group_create(world, ctypes.byref(g)))
+    # ranks can reach their FIRST exchange far apart (one still uploading its share of the witness, or compiling the circuit's program
+    # gates on first use): the harness sets the barrier timeout explicitly instead of inheriting the library's 120 s default
+    _chk(L.vx_group_set_timeout_ms(g, int(timeout_ms)))
     out, errs = [None] * world, [None] * world
     try:
         members = []

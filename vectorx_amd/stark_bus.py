@@ -49,12 +49,17 @@ def verify_tables(tables, proofs):
     return [st.verify(pi, p, shared) for (st, pi), p in zip(tables, proofs)]
 
 
-def bus_balanced(closing_sums, index=0) -> bool:
-    return sum(int(c[index]) for c in closing_sums) % P == 0
+def bus_balanced(closing_sums) -> bool:
+    """every closing sum — one per bus and per challenge set — cancels over the tables (all tables announce the same number)"""
+    k = {len(c) for c in closing_sums}
+    if len(k) != 1:
+        return False
+    return all(sum(int(c[i]) for c in closing_sums) % P == 0 for i in range(k.pop()))
 
 
-def verify_bus(tables, proofs, index=0):
-    sums = verify_tables(tables, proofs)
-    if not bus_balanced(sums, index):
-        raise VxError(VX_E_PROOF, "the bus does not balance: the tables' closing sums do not cancel")
-    return sums
+def verify_bus(tables, proofs):
+    """`vx_stark_verify_bus` is the same check behind the C ABI (one call: joint challenges, every proof, the balance)"""
+    from . import stark_verify_bus
+    sums = stark_verify_bus(tables, proofs)
+    assert bus_balanced(list(sums))           # the Python restatement of the same rule, kept as a cross-check
+    return list(sums)

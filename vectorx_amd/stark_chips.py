@@ -49,7 +49,8 @@ def bench_chip(ctx, which: str, log_n: int, steps: int = 3, warmup: int = 1, hos
         h_trace[:] = trace
     cap = 1 << 25
     out = np.empty(cap, dtype=np.uint8)
-    chal = np.zeros(1, dtype=np.uint64)
+    chal = np.zeros(stark.desc.num_aux_challenges, dtype=np.uint64)     # one challenge per set (the second round is repeated per set)
+    naux = stark.desc.num_aux_columns
     d_aux = ctx.alloc(naux * n * 8)
     state = {"chal": None}
 
@@ -62,10 +63,10 @@ def bench_chip(ctx, which: str, log_n: int, steps: int = 3, warmup: int = 1, hos
         if rc != 0:
             raise RuntimeError(L.vx_last_error().decode())
         try:
-            if state["chal"] != int(chal[0]):
-                aux = np.ascontiguousarray(air.aux_columns(trace, chal), dtype=np.uint64)
+            if state["chal"] != tuple(int(c) for c in chal):
+                aux = stark.run_aux(trace, chal)[0]
                 ctx.upload(d_aux, aux)
-                state["chal"] = int(chal[0])
+                state["chal"] = tuple(int(c) for c in chal)
             nb = ctypes.c_size_t(cap)
             rc = L.vx_stark_finish(sess, vp(d_aux), 1, None, out.ctypes.data, ctypes.byref(nb))
             if rc != 0:
