@@ -1,0 +1,898 @@
+"""The EdDSA group equation  [S]B - [h]A = R,  MANY signatures per table — caller-side stand-in for the chip that dominates VectorX's
+outer proof: Curta's `curta_eddsa_verify_sigs_conditional` over the 300 GRANDPA signatures of a justification
+(/root/reference/circuits/builder/justification.rs:237-243; starkyx v1.0.0, /root/reference/Cargo.lock:7232-7249).  OWN AIR, NOT
+CURTA'S (the starkyx sources are not in the reference tree).  Round 3's table (ed25519_air.py) proved ONE scalar multiplication of a
+point baked into the program on 2^13 rows of 713 columns; this one differs in every axis that mattered for the cost of 300 signatures:
+
+* many INSTANCES per trace: an instance is a straight-line program of L = 16 + 42 * 256 + 4 = 10 772 rows (any number of them fills a
+  2^k-row trace; the tail is an unfinished instance that sends nothing), so one FRI proof covers ~97 signatures per 2^20 rows;
+* both scalar multiplications of a signature in ONE pass (Straus / Shamir): per scalar bit one doubling, one mixed addition of the
+  cached base point B or of the identity (bit of S), one mixed addition of the cached -A or of the identity (bit of h) — 42 rows
+  instead of 2 x 28 (+ the affine rows round 3 spent on every bit: 2 x 32);
+* A is a WITNESS of the instance (two free rows, an on-curve check, its cached form computed in the table), not a program constant;
+* limbs of 16 bits looked up in a 65 536-entry table instead of bytes: a field element is 16 columns, the coefficient relation
+      X(t) Y(t) + E(t) - Z(t) - Q(t) P(t) = (t - 2^16) W(t)
+  has 31 coefficients (16 x 16 products) instead of 63 (32 x 32), and a row looks up 92 limbs (Z, Q and two limbs per carry) instead
+  of 188 bytes.  `limb_bits=8` keeps the byte form for traces shorter than 2^16 rows (tests);
+* results leave on a BUS: the last row of an instance sends (A, S, h, x, y) with (x, y) the affine [S]B - [h]A, and whoever holds the
+  signatures — `make_sink`, in a real integration the plonky2 circuit that verifies the STARK — receives (A, S, h, R): the bus
+  balances iff every equation holds.  No per-instance public inputs.
+
+What stays OUTSIDE the table (stated precisely): decompressing A and R from their 32-byte encodings (recovering x from y
+and the sign bit — the table takes affine (x, y) and checks the curve equation for A; R only has to EQUAL a computed point, which is on
+the curve by construction), h = SHA-512(R || A || M) mod L (the SHA-512 table of sha512_air.py gives the digest; the reduction mod L is
+host arithmetic) and the range check S < L.  Non-canonical limbs (a value in [p, 2^256)) cannot make a false equation pass: every
+relation holds mod p, and the result must equal the sink's canonical R limb by limb.
+
+Plain host code: emits a constraint program (include/vxprover.h VX_OP_*), generates the trace (vectorised over the instances) and the
+second-round columns; checked against an independent affine implementation and RFC 8032 signatures (tests/test_eddsa_air.py)."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import (VX_AIR_ALL_ROWS, VX_AIR_FIRST_ROW, VX_AIR_LAST_ROW, VX_AIR_TRANSITION, VX_OP_ADD, VX_OP_END, VX_OP_LDCH, VX_OP_LDP, VX_OP_MUL,
+               VX_OP_SUB, Stark)
+from . import hostfield as hf
+from .ed25519_air import BX, BY, D_ED, Q25519, affine_add, affine_scalar_mult
+from .sha256_air import P, _Emit
+
+ELL = (1 << 252) + 27742317777372353535851937790883648493       # the order of the base point
+NREG = 14
+X1, Y1, Z1, T1, AC0, AC1, AC2, AX, AY = 0, 1, 2, 3, 9, 10, 11, 12, 13   # registers 4..8 are temporaries
+
+
+@dataclass(frozen=True)
+class Op:
+    x: int = 0                 # register in the X slot
+    y: tuple = ("c", 0)        # ("r", reg) | ("c", constant) | ("b1", on, off): constant picked by the bit of S
+    #                            | ("b2", reg, off): register when the bit of h is set, else the constant
+    e: int | None = None       # register added (None: nothing)
+    dst: int = 0
+    free: bool = False         # Z is a free (range-checked) witness, the relation is off
+    one: bool = False          # Z must be 1
+
+
+def _cached(x, y):
+    return ((y - x) % Q25519, (y + x) % Q25519, (2 * D_ED * x * y) % Q25519)
+
+
+CACHED_B = _cached(BX, BY)
+CACHED_ID = (1, 1, 0)
+M1, M2 = Q25519 - 1, Q25519 - 2
+
+
+def _double():
+    return [Op(X1, ("r", X1), None, 4), Op(Y1, ("r", Y1), None, 5), Op(Z1, ("r", Z1), None, 6), Op(X1, ("c", 1), Y1, 7), Op(7, ("r", 7), None, 7),
+            Op(4, ("c", 1), 5, 8), Op(8, ("c", M1), 7, 7), Op(4, ("c", M1), 5, 4), Op(6, ("c", M2), 4, 6), Op(8, ("c", M1), None, 8),
+            Op(7, ("r", 6), None, X1), Op(4, ("r", 8), None, Y1), Op(7, ("r", 8), None, T1), Op(6, ("r", 4), None, Z1)]
+
+
+def _madd(c):
+    """mixed addition of a cached point (c[0], c[1], c[2] = the three Y-slot sources)"""
+    return [Op(X1, ("c", M1), Y1, 4), Op(X1, ("c", 1), Y1, 5), Op(4, c[0], None, 4), Op(5, c[1], None, 5), Op(T1, c[2], None, 6), Op(Z1, ("c", 2), None, 7),
+            Op(4, ("c", M1), 5, 8), Op(4, ("c", 1), 5, 4), Op(6, ("c", M1), 7, 5), Op(6, ("c", 1), 7, 6),
+            Op(8, ("r", 5), None, X1), Op(6, ("r", 4), None, Y1), Op(8, ("r", 4), None, T1), Op(5, ("r", 6), None, Z1)]
+
+
+PROLOGUE = [
+    Op(free=True, dst=AX), Op(free=True, dst=AY),                                     # the public key, affine
+    Op(AX, ("r", AX), None, 4), Op(AY, ("r", AY), None, 5), Op(4, ("r", 5), None, 6),   # xx, yy, xx yy
+    Op(6, ("c", D_ED), None, 6), Op(4, ("c", M1), 5, 7),                               # d xx yy;  yy - xx
+    Op(6, ("c", M1), 7, 8, one=True),                                                  # yy - xx - d xx yy = 1: A is on the curve
+    Op(AX, ("c", 1), AY, AC0), Op(AX, ("c", M1), AY, AC1),                             # cached(-A) = (y + x, y - x, -2 d x y)
+    Op(AX, ("r", AY), None, 4), Op(4, ("c", (-2 * D_ED) % Q25519), None, AC2),
+    Op(AX, ("c", 0), None, X1), Op(AX, ("c", 0), None, T1), Op(8, ("c", 1), None, Y1), Op(8, ("c", 1), None, Z1),   # accumulator = identity
+]
+LOOP = _double() + _madd([("b1", CACHED_B[k], CACHED_ID[k]) for k in range(3)]) + _madd([("b2", AC0 + k, CACHED_ID[k]) for k in range(3)])
+EPILOGUE = [Op(free=True, dst=4), Op(Z1, ("r", 4), None, 5, one=True), Op(X1, ("r", 4), None, 6), Op(Y1, ("r", 4), None, 7)]
+OPS = PROLOGUE + LOOP + EPILOGUE
+NP_, NL_, NE_ = len(PROLOGUE), len(LOOP), len(EPILOGUE)
+T_P0, T_PLAST, T_L0, T_LLAST, T_E0, T_ELAST = 0, NP_ - 1, NP_, NP_ + NL_ - 1, NP_ + NL_, NP_ + NL_ + NE_ - 1
+NT = len(OPS)
+RESULT_X_REG = 6               # the affine x is in register 6 on the last row of an instance, y is that row's Z
+assert (NP_, NL_, NE_) == (16, 42, 4)
+
+
+class Layout:
+    """column map for a limb width and a scalar length (steps per instance; a multiple of 32)"""
+
+    def __init__(self, limb_bits=16, scalar_bits=256):
+        assert limb_bits in (8, 16) and scalar_bits % 32 == 0 and 32 <= scalar_bits <= 256
+        self.LB, self.NB = limb_bits, scalar_bits
+        self.NL = 256 // limb_bits
+        self.NW = scalar_bits // 32
+        self.NC = 2 * self.NL - 2                 # carries
+        self.L = NP_ + NL_ * scalar_bits + NE_    # rows per instance
+        self.RT = 0
+        self.REG = self.RT + NT
+        self.X = self.REG + self.NL * NREG
+        self.Y = self.X + self.NL
+        self.Z = self.Y + self.NL
+        self.Q = self.Z + self.NL
+        self.W = self.Q + self.NL                 # carry k: W + 2 k (low limb), W + 2 k + 1 (high limb) of w_k + 2^(2 LB - 1)
+        self.NLOOK = 2 * self.NL + 2 * self.NC    # looked-up limb columns: Z, Q, W (contiguous from Z)
+        self.BIT = self.W + 2 * self.NC           # BIT, BIT + 1: the step's bits of S and of h
+        self.KACC = self.BIT + 2                  # the bits of the current 32-bit word so far (S, h)
+        self.BND = self.KACC + 2                  # last row of the last step of a scalar word
+        self.FIN = self.BND + 1                   # last row of the last step of the instance
+        self.POS = self.FIN + 1                   # one-hot position of the step inside its word, 32
+        self.J = self.POS + 32                    # one-hot word being filled, NW
+        self.SW = self.J + self.NW                # the instance's scalar words, most significant first: S (NW), then h (NW)
+        self.ACT = self.SW + 2 * self.NW          # 1 when the instance's result goes out on the bus (filler instances: 0)
+        self.TBL = self.ACT + 1
+        self.MULT = self.TBL + 1
+        self.N = self.MULT + 1
+        self.NPAIR = self.NLOOK // 2
+        self.AUX_H = self.N                       # per challenge set: pair helpers, table helper, lookup sum, bus helper, bus sum
+        self.AUX_HT = self.N + self.NPAIR
+        self.AUX_ACC = self.AUX_HT + 1
+        self.AUX_U = self.AUX_ACC + 1
+        self.AUX_BUS = self.AUX_U + 1
+        self.NAUX = self.NPAIR + 4
+        self.W_OFFSET = 1 << (2 * limb_bits - 1)
+        self.NTUPLE = 4 * self.NL + 2 * self.NW   # A.x, A.y, S words, h words, x, y
+
+    def limbs(self, v):
+        return [(int(v) >> (self.LB * i)) & ((1 << self.LB) - 1) for i in range(self.NL)]
+
+    def min_degree_bits(self):
+        # the limb table needs 2^LB rows BEFORE the last row (the running sum stops there, so a multiplicity placed on the last row would
+        # not count: 2^LB rows exactly would lose the entry 2^LB - 1); at least one whole instance
+        return max(self.LB + 1, (self.L).bit_length())
+
+
+def build_program(lay: Layout):
+    """-> (program words for ONE challenge set, number of constraints)"""
+    C, NL, LB = lay, lay.NL, lay.LB
+    e = _Emit(scratch=24)
+    ONE, ZERO, GAMMA, ADV, BND, B1, B2, NOTFREE, CLB = 63, 62, 61, 60, 59, 58, 57, 56, 55
+    PH = list(range(24, 55))
+    e.ldi(ONE, 1)
+    e.ldi(ZERO, 0)
+    e.ldi(CLB, 1 << LB)
+    e.ins(VX_OP_LDCH, GAMMA, 0)
+    e.ldw(C.RT + T_LLAST, dst=ADV)
+    e.ldw(C.BND, dst=BND)
+    e.ldw(C.BIT, dst=B1)
+    e.ldw(C.BIT + 1, dst=B2)
+    npush = 0
+    tmp = e.tmp
+
+    def push(r, kind):
+        nonlocal npush
+        e.push(r, kind)
+        npush += 1
+
+    def sum_sel(rows, dst):
+        m0 = e.top
+        first = True
+        for r in rows:
+            x = e.ldw(C.RT + r)
+            e.op(VX_OP_ADD, x, ZERO if first else dst, dst)
+            first = False
+            e.release(m0)
+        if first:
+            e.op(VX_OP_ADD, ZERO, ZERO, dst)
+
+    free_rows = [t for t, op in enumerate(OPS) if op.free]
+    sum_sel(free_rows, NOTFREE)
+    e.op(VX_OP_SUB, ONE, NOTFREE, NOTFREE)
+
+    def reg(r, i, nxt=False):
+        return e.ldw(C.REG + NL * r + i, nxt=nxt)
+
+    # ---- X slot = the register the row type names (free rows: 0) ----
+    xregs = sorted({op.x for op in OPS if not op.free})
+    assert len(xregs) <= len(PH)
+    for k, r in enumerate(xregs):
+        sum_sel([t for t, op in enumerate(OPS) if not op.free and op.x == r], PH[k])
+    for i in range(NL):
+        m0 = e.top
+        t = tmp()
+        first = True
+        for k, r in enumerate(xregs):
+            m1 = e.top
+            v = reg(r, i)
+            e.op(VX_OP_MUL, v, PH[k], v)
+            e.op(VX_OP_ADD, v, ZERO if first else t, t)
+            first = False
+            e.release(m1)
+        push(e.op(VX_OP_SUB, e.ldw(C.X + i), t), VX_AIR_ALL_ROWS)
+        e.release(m0)
+    # ---- Y slot = a register, a constant, a constant picked by the bit of S, or a register / constant picked by the bit of h ----
+    yregs = sorted({op.y[1] for op in OPS if not op.free and op.y[0] == "r"})
+    consts = sorted({op.y[1] for op in OPS if not op.free and op.y[0] == "c"})
+    b1s = sorted({op.y[1:] for op in OPS if not op.free and op.y[0] == "b1"})
+    b2s = sorted({op.y[1:] for op in OPS if not op.free and op.y[0] == "b2"})
+    groups = [("r", r) for r in yregs] + [("c", c) for c in consts] + [("b1",) + b for b in b1s] + [("b2",) + b for b in b2s]
+    assert len(groups) <= len(PH)
+    for k, g in enumerate(groups):
+        sum_sel([t for t, op in enumerate(OPS) if not op.free and op.y == g], PH[k])
+    for i in range(NL):
+        m0 = e.top
+        t = tmp()
+        e.op(VX_OP_ADD, ZERO, ZERO, t)
+        for k, g in enumerate(groups):
+            m1 = e.top
+            if g[0] == "r":
+                v = reg(g[1], i)
+            elif g[0] == "c":
+                b = lay.limbs(g[1])[i]
+                if b == 0:
+                    continue
+                v = tmp()
+                e.ldi(v, b)
+            elif g[0] == "b1":
+                on, off = lay.limbs(g[1])[i], lay.limbs(g[2])[i]
+                if on == 0 and off == 0:
+                    continue
+                v = tmp()
+                e.ldi(v, (on - off) % P)
+                e.op(VX_OP_MUL, v, B1, v)
+                c2 = tmp()
+                e.ldi(c2, off)
+                e.op(VX_OP_ADD, v, c2, v)
+            else:
+                off = lay.limbs(g[2])[i]
+                c2 = tmp()
+                e.ldi(c2, off)
+                v = e.op(VX_OP_SUB, reg(g[1], i), c2)
+                e.op(VX_OP_MUL, v, B2, v)
+                e.op(VX_OP_ADD, v, c2, v)
+            e.op(VX_OP_MUL, v, PH[k], v)
+            e.op(VX_OP_ADD, t, v, t)
+            e.release(m1)
+        push(e.op(VX_OP_SUB, e.ldw(C.Y + i), t), VX_AIR_ALL_ROWS)
+        e.release(m0)
+    # ---- the multiply-add relation, coefficient by coefficient (off on the free rows) ----
+    eregs = sorted({op.e for op in OPS if not op.free and op.e is not None})
+    for k, r in enumerate(eregs):
+        sum_sel([t for t, op in enumerate(OPS) if not op.free and op.e == r], PH[k])
+    pl = lay.limbs(Q25519)
+    mask = (1 << LB) - 1
+    assert pl[0] == mask - 18 and pl[NL - 1] == mask >> 1 and all(b == mask for b in pl[1:NL - 1])
+    c_lo, c_hi, c_mid, coff = PH[16], PH[17], PH[18], PH[19]
+    e.ldi(c_lo, pl[0])
+    e.ldi(c_hi, pl[NL - 1])
+    e.ldi(c_mid, mask)
+    e.ldi(coff, lay.W_OFFSET)
+
+    def carry(k, dst):
+        """dst = w_k = lo + 2^LB hi - 2^(2 LB - 1)"""
+        m0 = e.top
+        hi = e.ldw(C.W + 2 * k + 1)
+        e.op(VX_OP_MUL, hi, CLB, hi)
+        e.op(VX_OP_ADD, hi, e.ldw(C.W + 2 * k), dst)
+        e.op(VX_OP_SUB, dst, coff, dst)
+        e.release(m0)
+
+    for k in range(2 * NL - 1):
+        m0 = e.top
+        d = tmp()
+        first = True
+        for i in range(max(0, k - NL + 1), min(NL - 1, k) + 1):
+            m1 = e.top
+            t = e.op(VX_OP_MUL, e.ldw(C.X + i), e.ldw(C.Y + k - i))
+            e.op(VX_OP_ADD, t, ZERO if first else d, d)
+            first = False
+            e.release(m1)
+        if k < NL:
+            m1 = e.top
+            t = tmp()
+            e.op(VX_OP_ADD, ZERO, ZERO, t)
+            for n_, r in enumerate(eregs):
+                m2 = e.top
+                v = reg(r, k)
+                e.op(VX_OP_MUL, v, PH[n_], v)
+                e.op(VX_OP_ADD, t, v, t)
+                e.release(m2)
+            e.op(VX_OP_ADD, d, t, d)
+            e.op(VX_OP_SUB, d, e.ldw(C.Z + k), d)
+            e.release(m1)
+        # (Q P)_k = P_0 Q_k + mask * sum_{1 <= k - j <= NL - 2} Q_j + P_{NL-1} Q_{k - NL + 1}
+        m1 = e.top
+        if k < NL:
+            t = e.op(VX_OP_MUL, e.ldw(C.Q + k), c_lo)
+            e.op(VX_OP_SUB, d, t, d)
+            e.release(m1)
+        lo, hi = max(0, k - (NL - 2)), min(NL - 1, k - 1)
+        if lo <= hi:
+            s = tmp()
+            for n_, j in enumerate(range(lo, hi + 1)):
+                q = e.ldw(C.Q + j)
+                e.op(VX_OP_ADD, q, ZERO if n_ == 0 else s, s)
+                e.release(s + 1)
+            e.op(VX_OP_MUL, s, c_mid, s)
+            e.op(VX_OP_SUB, d, s, d)
+            e.release(m1)
+        if 0 <= k - (NL - 1) < NL:
+            t = e.op(VX_OP_MUL, e.ldw(C.Q + k - (NL - 1)), c_hi)
+            e.op(VX_OP_SUB, d, t, d)
+            e.release(m1)
+        # d_k = w_{k-1} - 2^LB w_k   (w_{-1} = w_{2 NL - 2} = 0)
+        if k >= 1:
+            w = tmp()
+            carry(k - 1, w)
+            e.op(VX_OP_SUB, d, w, d)
+            e.release(m1)
+        if k <= 2 * NL - 3:
+            w = tmp()
+            carry(k, w)
+            e.op(VX_OP_MUL, w, CLB, w)
+            e.op(VX_OP_ADD, d, w, d)
+            e.release(m1)
+        e.op(VX_OP_MUL, d, NOTFREE, d)
+        push(d, VX_AIR_ALL_ROWS)
+        e.release(m0)
+    # ---- write-back; rows that must produce 1 ----
+    for r in range(NREG):
+        sum_sel([t for t, op in enumerate(OPS) if op.dst == r], PH[r])
+    for r in range(NREG):
+        for i in range(NL):
+            m0 = e.top
+            v, vn = reg(r, i), reg(r, i, nxt=True)
+            t = e.op(VX_OP_SUB, e.ldw(C.Z + i), v)
+            e.op(VX_OP_MUL, t, PH[r], t)
+            e.op(VX_OP_ADD, t, v, t)
+            push(e.op(VX_OP_SUB, vn, t), VX_AIR_TRANSITION)
+            e.release(m0)
+    s_one = PH[NREG]
+    sum_sel([t for t, op in enumerate(OPS) if op.one], s_one)
+    for i in range(NL):
+        m0 = e.top
+        z = e.ldw(C.Z + i)
+        if i == 0:
+            z = e.op(VX_OP_SUB, z, ONE)
+        push(e.op(VX_OP_MUL, z, s_one), VX_AIR_ALL_ROWS)
+        e.release(m0)
+    # ---- row type: prologue -> loop (42 rows, repeated until FIN) -> epilogue -> the next instance's prologue ----
+    fin = e.ldw(C.FIN)
+    lf = e.op(VX_OP_MUL, ADV, fin)                    # last loop row of the last step
+    lnf = e.op(VX_OP_SUB, ADV, lf)                    # last loop row of any other step
+    keep = e.top
+    for t in range(NT):
+        m0 = e.top
+        nx = e.ldw(C.RT + t, nxt=True)
+        if t == T_P0:
+            pred = e.ldw(C.RT + T_ELAST)
+        elif t == T_L0:
+            pred = e.op(VX_OP_ADD, e.ldw(C.RT + T_PLAST), lnf)
+        elif t == T_E0:
+            pred = lf
+        else:
+            pred = e.ldw(C.RT + t - 1)
+        push(e.op(VX_OP_SUB, nx, pred), VX_AIR_TRANSITION)
+        cur = e.ldw(C.RT + t)
+        push(e.op(VX_OP_SUB, cur, ONE) if t == T_P0 else cur, VX_AIR_FIRST_ROW)
+        e.release(m0)
+    # ---- step counter: POS advances after every step, J after every 32 steps (both cyclic: a new instance starts at 0 / 0) ----
+    for i in range(32):
+        m0 = e.top
+        cur, prev, nx = e.ldw(C.POS + i), e.ldw(C.POS + (i - 1) % 32), e.ldw(C.POS + i, nxt=True)
+        t = e.op(VX_OP_SUB, prev, cur)
+        e.op(VX_OP_MUL, t, ADV, t)
+        e.op(VX_OP_ADD, t, cur, t)
+        push(e.op(VX_OP_SUB, nx, t), VX_AIR_TRANSITION)
+        push(e.op(VX_OP_SUB, cur, ONE) if i == 0 else cur, VX_AIR_FIRST_ROW)
+        e.release(m0)
+    m0 = e.top
+    t = e.op(VX_OP_MUL, ADV, e.ldw(C.POS + 31))
+    push(e.op(VX_OP_SUB, BND, t), VX_AIR_ALL_ROWS)
+    t = e.op(VX_OP_MUL, BND, e.ldw(C.J + C.NW - 1))
+    push(e.op(VX_OP_SUB, fin, t), VX_AIR_ALL_ROWS)
+    e.release(m0)
+    for j in range(C.NW):
+        m0 = e.top
+        cur, prev, nx = e.ldw(C.J + j), e.ldw(C.J + (j - 1) % C.NW), e.ldw(C.J + j, nxt=True)
+        t = e.op(VX_OP_SUB, prev, cur)
+        e.op(VX_OP_MUL, t, BND, t)
+        e.op(VX_OP_ADD, t, cur, t)
+        push(e.op(VX_OP_SUB, nx, t), VX_AIR_TRANSITION)
+        push(e.op(VX_OP_SUB, cur, ONE) if j == 0 else cur, VX_AIR_FIRST_ROW)
+        e.release(m0)
+    # ---- the scalars: one bit of S and one of h per step, most significant first, packed into the instance's 32-bit words ----
+    plast = e.ldw(C.RT + T_PLAST)
+    elast = e.ldw(C.RT + T_ELAST)
+    hold = e.op(VX_OP_SUB, ONE, ADV)
+    e.op(VX_OP_SUB, hold, plast, hold)                # the bits may change after a step and when the loop is entered
+    hold_sw = e.op(VX_OP_SUB, ONE, elast)             # the scalar words may change between instances
+    keep2 = e.top
+    for s, BITr in ((0, B1), (1, B2)):
+        m0 = e.top
+        t = e.op(VX_OP_SUB, BITr, ONE)
+        push(e.op(VX_OP_MUL, t, BITr), VX_AIR_ALL_ROWS)
+        bn = e.ldw(C.BIT + s, nxt=True)
+        t = e.op(VX_OP_SUB, bn, BITr)
+        push(e.op(VX_OP_MUL, t, hold), VX_AIR_TRANSITION)
+        # K' = K + adv (K + bit') - bnd 2 K + plast (bit' - K)
+        k, kn = e.ldw(C.KACC + s), e.ldw(C.KACC + s, nxt=True)
+        t = e.op(VX_OP_ADD, k, bn)
+        e.op(VX_OP_MUL, t, ADV, t)
+        u = e.op(VX_OP_ADD, k, k)
+        e.op(VX_OP_MUL, u, BND, u)
+        e.op(VX_OP_SUB, t, u, t)
+        u2 = e.op(VX_OP_SUB, bn, k)
+        e.op(VX_OP_MUL, u2, plast, u2)
+        e.op(VX_OP_ADD, t, u2, t)
+        e.op(VX_OP_ADD, t, k, t)
+        push(e.op(VX_OP_SUB, kn, t), VX_AIR_TRANSITION)
+        # bnd (K - sum_j J_j SW_j) = 0
+        w = tmp()
+        e.op(VX_OP_ADD, ZERO, ZERO, w)
+        for j in range(C.NW):
+            m1 = e.top
+            v = e.op(VX_OP_MUL, e.ldw(C.SW + s * C.NW + j), e.ldw(C.J + j))
+            e.op(VX_OP_ADD, w, v, w)
+            e.release(m1)
+        e.op(VX_OP_SUB, k, w, w)
+        push(e.op(VX_OP_MUL, w, BND), VX_AIR_ALL_ROWS)
+        e.release(m0)
+        for j in range(C.NW):
+            m0 = e.top
+            t = e.op(VX_OP_SUB, e.ldw(C.SW + s * C.NW + j, nxt=True), e.ldw(C.SW + s * C.NW + j))
+            push(e.op(VX_OP_MUL, t, hold_sw), VX_AIR_TRANSITION)
+            e.release(m0)
+    m0 = e.top
+    act = e.ldw(C.ACT)
+    t = e.op(VX_OP_SUB, act, ONE)
+    push(e.op(VX_OP_MUL, t, act), VX_AIR_ALL_ROWS)
+    t = e.op(VX_OP_SUB, e.ldw(C.ACT, nxt=True), act)
+    push(e.op(VX_OP_MUL, t, hold_sw), VX_AIR_TRANSITION)
+    e.release(m0)
+    e.release(keep)
+    # ---- the limb table and the lookups of every limb of Z, Q, W ----
+    m0 = e.top
+    tb, tbn = e.ldw(C.TBL), e.ldw(C.TBL, nxt=True)
+    inc = e.op(VX_OP_SUB, tbn, tb)
+    e.op(VX_OP_SUB, inc, ONE, inc)
+    push(e.op(VX_OP_MUL, inc, tbn), VX_AIR_TRANSITION)
+    cmax = tmp()
+    e.ldi(cmax, mask)
+    t = e.op(VX_OP_SUB, tb, cmax)
+    push(e.op(VX_OP_MUL, t, inc), VX_AIR_TRANSITION)
+    push(tb, VX_AIR_FIRST_ROW)
+    e.release(m0)
+    m0 = e.top
+    acc, accn = e.ldw(C.AUX_ACC), e.ldw(C.AUX_ACC, nxt=True)
+    step = e.op(VX_OP_SUB, accn, acc)
+    for q in range(C.NPAIR):
+        m1 = e.top
+        g0 = e.op(VX_OP_SUB, GAMMA, e.ldw(C.Z + 2 * q))
+        g1 = e.op(VX_OP_SUB, GAMMA, e.ldw(C.Z + 2 * q + 1))
+        h = e.ldw(C.AUX_H + q)
+        e.op(VX_OP_SUB, step, h, step)
+        t = e.op(VX_OP_MUL, g0, g1)
+        e.op(VX_OP_MUL, t, h, t)
+        e.op(VX_OP_SUB, t, g0, t)
+        e.op(VX_OP_SUB, t, g1, t)
+        push(t, VX_AIR_ALL_ROWS)
+        e.release(m1)
+    gt = e.op(VX_OP_SUB, GAMMA, e.ldw(C.TBL))
+    ht = e.ldw(C.AUX_HT)
+    e.op(VX_OP_ADD, step, ht, step)
+    t = e.op(VX_OP_MUL, ht, gt)
+    push(e.op(VX_OP_SUB, t, e.ldw(C.MULT)), VX_AIR_ALL_ROWS)
+    push(step, VX_AIR_TRANSITION)
+    push(acc, VX_AIR_FIRST_ROW)
+    push(acc, VX_AIR_LAST_ROW)
+    e.release(m0)
+    # ---- the bus: the last row of an instance sends (A.x, A.y, S words, h words, x, y) ----
+    m0 = e.top
+    beta, gbus = tmp(), tmp()
+    e.ins(VX_OP_LDCH, beta, 1)
+    e.ins(VX_OP_LDCH, gbus, 2)
+    srcs = ([C.REG + NL * AX + i for i in range(NL)] + [C.REG + NL * AY + i for i in range(NL)] + [C.SW + j for j in range(2 * C.NW)]
+            + [C.REG + NL * RESULT_X_REG + i for i in range(NL)] + [C.Z + i for i in range(NL)])
+    assert len(srcs) == C.NTUPLE
+    tup = tmp()
+    e.ldw(srcs[-1], dst=tup)
+    for col in reversed(srcs[:-1]):                   # Horner: sum_k beta^k element_k
+        m1 = e.top
+        e.op(VX_OP_MUL, tup, beta, tup)
+        e.op(VX_OP_ADD, tup, e.ldw(col), tup)
+        e.release(m1)
+    dlt = e.op(VX_OP_SUB, gbus, tup)
+    u, bacc, baccn = e.ldw(C.AUX_U), e.ldw(C.AUX_BUS), e.ldw(C.AUX_BUS, nxt=True)
+    t = e.op(VX_OP_MUL, u, dlt)
+    snd = e.op(VX_OP_MUL, e.ldw(C.RT + T_ELAST), e.ldw(C.ACT))
+    push(e.op(VX_OP_SUB, t, snd), VX_AIR_ALL_ROWS)                          # u (gamma - tuple) = [last row of an active instance]
+    t = e.op(VX_OP_SUB, baccn, bacc)
+    push(e.op(VX_OP_SUB, t, u), VX_AIR_TRANSITION)
+    push(bacc, VX_AIR_FIRST_ROW)
+    closing = tmp()
+    e.ins(VX_OP_LDP, closing, 0)                      # aux public input 0 of the set: everything this table sent
+    push(e.op(VX_OP_SUB, bacc, closing), VX_AIR_LAST_ROW)
+    e.release(m0)
+    e.ins(VX_OP_END)
+    return e.w, npush
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# trace generation (vectorised over the instances of a table)
+def _simulate(lay: Layout, sigs):
+    """python-int simulation of every instance: -> per instance-row lists x, y, e, z (each [L][K])"""
+    K, NB = len(sigs), lay.NB
+    regs = [[0] * NREG for _ in range(K)]
+    xs, ys, es, zs = [], [], [], []
+    bits1 = [[(s >> (NB - 1 - st)) & 1 for st in range(NB)] for (_, s, _) in sigs]
+    bits2 = [[(h >> (NB - 1 - st)) & 1 for st in range(NB)] for (_, _, h) in sigs]
+    rows = [(op, None) for op in PROLOGUE] + [(op, st) for st in range(NB) for op in LOOP] + [(op, None) for op in EPILOGUE]
+    free_seen = [0] * K
+    for op, st in rows:
+        xr, yr, er, zr = [0] * K, [0] * K, [0] * K, [0] * K
+        for k in range(K):
+            rg = regs[k]
+            if op.free:
+                if op.dst == AX:
+                    z = sigs[k][0][0]
+                elif op.dst == AY:
+                    z = sigs[k][0][1]
+                else:
+                    z = pow(rg[Z1], Q25519 - 2, Q25519)
+                x = y = ev = 0
+            else:
+                x = rg[op.x]
+                kind = op.y[0]
+                if kind == "r":
+                    y = rg[op.y[1]]
+                elif kind == "c":
+                    y = op.y[1]
+                elif kind == "b1":
+                    y = op.y[1] if bits1[k][st] else op.y[2]
+                else:
+                    y = rg[op.y[1]] if bits2[k][st] else op.y[2]
+                ev = rg[op.e] if op.e is not None else 0
+                z = (x * y + ev) % Q25519
+            if op.one and z != 1:
+                raise ValueError("instance %d: a row that must produce 1 does not (A not on the curve, or Z = 0)" % k)
+            rg[op.dst] = z
+            xr[k], yr[k], er[k], zr[k] = x, y, ev, z
+        xs.append(xr)
+        ys.append(yr)
+        es.append(er)
+        zs.append(zr)
+    del free_seen
+    return xs, ys, es, zs, bits1, bits2
+
+
+def _limb_array(lay: Layout, vals):
+    """list of python ints (< 2^256) -> int64 [len][NL]"""
+    raw = b"".join(int(v).to_bytes(32, "little") for v in vals)
+    a = np.frombuffer(raw, dtype="<u2" if lay.LB == 16 else np.uint8)
+    return a.reshape(-1, lay.NL).astype(np.int64)
+
+
+def _instance_blocks(lay: Layout, ulist):
+    """the instance-local columns of every DISTINCT instance, side by side: -> (block [N][U * L] with registers starting from 0 in each
+    instance, final register limbs [U][NREG][NL], per-instance limb counts [U][2^LB] of the looked-up columns, results, bits of S, bits of h)"""
+    L, NL, LB, NB = lay.L, lay.NL, lay.LB, lay.NB
+    U = len(ulist)
+    xs, ys, es, zs, bits1, bits2 = _simulate(lay, ulist)
+    flat = lambda rows: [rows[rho][k] for k in range(U) for rho in range(L)]      # noqa: E731  (instance-major: row = u * L + rho)
+    xv, yv, ev, zv = flat(xs), flat(ys), flat(es), flat(zs)
+    qv = [(a * b + c - d) // Q25519 for a, b, c, d in zip(xv, yv, ev, zv)]
+    rt = np.array([t for t in range(NP_)] + [NP_ + (i % NL_) for i in range(NL_ * NB)] + [NP_ + NL_ + i for i in range(NE_)], dtype=np.int64)
+    rt_all = np.tile(rt, U)
+    free_all = np.isin(rt_all, [t for t, op in enumerate(OPS) if op.free])
+    for i in np.nonzero(free_all)[0]:
+        qv[i] = 0
+    # limb planes [NL][rows]: one contiguous vector per limb, like the trace itself
+    Xl, Yl, El, Zl, Ql = (np.ascontiguousarray(_limb_array(lay, v).T) for v in (xv, yv, ev, zv, qv))
+    del xv, yv, ev, qv
+    Pl = lay.limbs(Q25519)
+    R = U * L
+    d = np.zeros((2 * NL - 1, R), dtype=np.int64)
+    for i in range(NL):
+        for j in range(NL):
+            d[i + j] += Xl[i] * Yl[j]
+            if Pl[j]:
+                d[i + j] -= Ql[i] * Pl[j]
+    d[:NL] += El - Zl
+    d *= ~free_all                                         # the relation is off on the free rows: carries 0
+    Wl = np.zeros((2 * lay.NC, R), dtype=np.int64)
+    prev = np.zeros(R, dtype=np.int64)
+    for k in range(2 * NL - 1):
+        t = prev - d[k]
+        assert not (t & ((1 << LB) - 1)).any()
+        prev = t >> LB
+        if k <= 2 * NL - 3:
+            assert (np.abs(prev) < lay.W_OFFSET).all()
+            off = prev + lay.W_OFFSET
+            Wl[2 * k] = off & ((1 << LB) - 1)
+            Wl[2 * k + 1] = off >> LB
+    assert not prev.any()
+    del d
+    blk = np.zeros((lay.N, R), dtype=np.uint64)
+    rows = np.arange(R)
+    blk[lay.RT + rt_all, rows] = 1
+    for base, arr in ((lay.X, Xl), (lay.Y, Yl), (lay.Z, Zl), (lay.Q, Ql), (lay.W, Wl)):
+        blk[base:base + arr.shape[0]] = arr
+    # registers: the value a register holds on a row = the Z of the last earlier row OF THE SAME INSTANCE that wrote it (0 before that:
+    # what the previous instance left there is patched in when the trace is assembled)
+    start = (rows // L) * L
+    dst_of = np.array([op.dst for op in OPS], dtype=np.int64)[rt_all]
+    final = np.zeros((U, NREG, NL), dtype=np.uint64)
+    for r in range(NREG):
+        wrote = np.where(dst_of == r, rows, -1)
+        last = np.maximum.accumulate(wrote)
+        src = np.empty(R, dtype=np.int64)
+        src[0] = -1
+        src[1:] = last[:-1]
+        live = src >= start
+        vals = Zl[:, np.maximum(src, 0)] * live
+        blk[lay.REG + NL * r:lay.REG + NL * (r + 1)] = vals
+        final[:, r, :] = Zl[:, last[L - 1::L]].T                      # every register is written in every instance
+    rho = rows % L
+    step = np.clip((rho - NP_) // NL_, 0, NB - 1)          # prologue rows carry step 0's position, epilogue rows wrap to 0 / 0
+    after = rho >= NP_ + NL_ * NB
+    pos = np.where(after, 0, step % 32)
+    word = np.where(after, 0, step // 32)
+    blk[lay.POS + pos, rows] = 1
+    blk[lay.J + word, rows] = 1
+    adv = rt_all == T_LLAST
+    bnd = adv & (step % 32 == 31)
+    blk[lay.BND] = bnd
+    blk[lay.FIN] = bnd & (step // 32 == lay.NW - 1)
+    counts = np.stack([np.bincount(blk[lay.Z:lay.Z + lay.NLOOK, u * L:(u + 1) * L].astype(np.int64).reshape(-1), minlength=1 << LB) for u in range(U)])
+    results = [(zs[L - 2][u], zs[L - 1][u]) for u in range(U)]
+    return blk, final, counts, results, np.array(bits1, dtype=np.uint64), np.array(bits2, dtype=np.uint64)
+
+
+def generate_trace(lay: Layout, degree_bits: int, sigs) -> tuple:
+    """sigs = [((ax, ay), S, h)] — one instance each, in order.  The trace holds as many whole instances as were given (<= capacity)
+    followed by filler instances (A = B, S = h = 0, nothing sent; the last one unfinished).  Only DISTINCT signatures are simulated:
+    a bench that repeats 16 signatures over 97 instances pays for 16.
+    -> (trace [N][n] uint64, results [(x, y)] per given instance = affine [S]B - [h]A)"""
+    n = 1 << degree_bits
+    L, NL, LB, NB = lay.L, lay.NL, lay.LB, lay.NB
+    assert degree_bits > LB, "the limb table needs 2^limb_bits rows before the last row"
+    cap = capacity(lay, degree_bits)
+    assert len(sigs) <= cap, f"2^{degree_bits} rows hold {cap} instances"
+    K = -(-n // L)
+    allsigs = [tuple(sg) for sg in sigs] + [((BX, BY), 0, 0)] * (K - len(sigs))
+    for (_, s, h) in allsigs:
+        assert 0 <= s < (1 << NB) and 0 <= h < (1 << NB)
+    uniq = {}
+    which = np.array([uniq.setdefault(sg, len(uniq)) for sg in allsigs], dtype=np.int64)
+    blk, final, counts, ures, ubits1, ubits2 = _instance_blocks(lay, list(uniq))
+    t = np.empty((lay.N, n), dtype=np.uint64)
+    for k in range(K):
+        lo, hi = k * L, min(n, (k + 1) * L)
+        t[:, lo:hi] = blk[:, which[k] * L:which[k] * L + hi - lo]
+    # what the previous instance left in a register, up to and including the row that first writes it
+    first_write = [min(rho for rho, op in enumerate(OPS[:NP_]) if op.dst == r) if any(op.dst == r for op in OPS[:NP_]) else None for r in range(NREG)]
+    for r in range(NREG):
+        fw = first_write[r]
+        if fw is None:       # first written in the loop: row NP_ + (index in LOOP)
+            fw = NP_ + min(i for i, op in enumerate(LOOP) if op.dst == r)
+        for k in range(1, K):
+            lo = k * L
+            hi = min(n, lo + fw + 1)
+            if lo < n:
+                t[lay.REG + NL * r:lay.REG + NL * (r + 1), lo:hi] = final[which[k - 1], r][:, None]
+    rows = np.arange(n)
+    rho = rows % L
+    inst = rows // L
+    step = np.clip((rho - NP_) // NL_, 0, NB - 1)
+    after = rho >= NP_ + NL_ * NB
+    for s, ubits, sc in ((0, ubits1, [x[1] for x in allsigs]), (1, ubits2, [x[2] for x in allsigs])):
+        bits = ubits[which]                                              # [K][NB]
+        # bit column: constant over a step; prologue rows keep the PREVIOUS instance's final bit (hold constraint; the loop entry may change
+        # it), epilogue rows keep the last step's bit
+        cur = bits[inst, step]
+        prev_last = np.where(inst > 0, bits[np.maximum(inst - 1, 0), NB - 1], bits[0, 0])
+        t[lay.BIT + s] = np.where(rho < NP_, prev_last, cur)
+        # KACC: the bits of the current word so far on loop rows; K' = K + adv (K + bit') - bnd 2 K + plast (bit' - K) elsewhere: the FIN row
+        # leaves the held last bit, which the epilogue and the next prologue keep
+        words = np.array([[(int(v) >> (32 * (lay.NW - 1 - j))) & 0xFFFFFFFF for j in range(lay.NW)] for v in sc], dtype=np.uint64)   # [K][NW]
+        kacc = words[inst, step // 32] >> (np.uint64(31) - (step % 32).astype(np.uint64))
+        kprev = np.where(inst > 0, prev_last, kacc[0])
+        t[lay.KACC + s] = np.where(rho < NP_, kprev, np.where(after, cur, kacc))
+        t[lay.SW + s * lay.NW:lay.SW + (s + 1) * lay.NW] = words[inst].T
+    t[lay.ACT] = inst < len(sigs)
+    t[lay.TBL] = rows % (1 << LB)
+    # multiplicities over rows 0 .. n-2: whole instances from the per-instance counts, the unfinished tail counted directly
+    whole = (n - 1) // L
+    look = counts[which[:whole]].sum(axis=0)
+    if whole * L < n - 1:
+        look = look + np.bincount(t[lay.Z:lay.Z + lay.NLOOK, whole * L:n - 1].astype(np.int64).reshape(-1), minlength=1 << LB)
+    t[lay.MULT] = 0
+    t[lay.MULT, :1 << LB] = look.astype(np.uint64)
+    return t, [ures[which[k]] for k in range(len(sigs))]
+
+
+def capacity(lay: Layout, degree_bits: int) -> int:
+    """whole instances whose last row is not the trace's last row (that row's send is not counted by the running sum)"""
+    n = 1 << degree_bits
+    return (n - 1) // lay.L
+
+
+def send_tuples(lay: Layout, trace):
+    """-> (rows that send, [rows][NTUPLE] elements) read off the trace the way the program reads them"""
+    n = trace.shape[1]
+    rows = np.nonzero(trace[lay.RT + T_ELAST, :n - 1] * trace[lay.ACT, :n - 1])[0]
+    NL = lay.NL
+    cols = ([lay.REG + NL * AX + i for i in range(NL)] + [lay.REG + NL * AY + i for i in range(NL)] + [lay.SW + j for j in range(2 * lay.NW)]
+            + [lay.REG + NL * RESULT_X_REG + i for i in range(NL)] + [lay.Z + i for i in range(NL)])
+    return rows, trace[np.array(cols)][:, rows].T
+
+
+def tuple_of(lay: Layout, a, s, h, r):
+    """the bus tuple of a signature equation: A, S, h and the point R the equation must produce"""
+    sw = lambda v: [(int(v) >> (32 * (lay.NW - 1 - j))) & 0xFFFFFFFF for j in range(lay.NW)]   # noqa: E731
+    return lay.limbs(a[0]) + lay.limbs(a[1]) + sw(s) + sw(h) + lay.limbs(r[0]) + lay.limbs(r[1])
+
+
+def _horner(elems, beta):
+    """sum_k beta^k elems[:, k] mod p, vectorised over rows"""
+    acc = np.asarray(elems[:, -1], dtype=np.uint64) % np.uint64(P)
+    b = np.full(acc.shape, beta, dtype=np.uint64)
+    for k in range(elems.shape[1] - 2, -1, -1):
+        acc = hf.addmod(hf.mulmod(acc, b), np.asarray(elems[:, k], dtype=np.uint64) % np.uint64(P))
+    return acc
+
+
+def aux_columns(lay: Layout, trace, chal):
+    """second-round columns of ONE challenge set [pair helpers, ht, lookup sum, bus helper, bus sum] and the closing sum of the sends"""
+    n = trace.shape[1]
+    g, beta, gbus = (int(c) for c in chal[:3])
+    tab = hf.invmod(hf.submod(np.full(1 << lay.LB, g, dtype=np.uint64), np.arange(1 << lay.LB, dtype=np.uint64)))
+    out = np.zeros((lay.NAUX, n), dtype=np.uint64)
+    step = np.zeros(n, dtype=np.uint64)
+    for q in range(lay.NPAIR):
+        a = trace[lay.Z + 2 * q]
+        b = trace[lay.Z + 2 * q + 1]
+        if int(a.max()) >> lay.LB or int(b.max()) >> lay.LB:          # a limb outside the table (corrupted traces in the tests)
+            ia = hf.invmod(hf.submod(np.full(n, g, dtype=np.uint64), a % np.uint64(P)))
+            ib = hf.invmod(hf.submod(np.full(n, g, dtype=np.uint64), b % np.uint64(P)))
+        else:
+            ia, ib = tab[a.astype(np.int64)], tab[b.astype(np.int64)]
+        h = hf.addmod(ia, ib)
+        out[q] = h
+        step = hf.addmod(step, h)
+    tb = trace[lay.TBL]
+    inv_t = tab[tb.astype(np.int64)] if not int(tb.max()) >> lay.LB else hf.invmod(hf.submod(np.full(n, g, dtype=np.uint64), tb % np.uint64(P)))
+    ht = hf.mulmod(trace[lay.MULT] % np.uint64(P), inv_t)
+    out[lay.NPAIR] = ht
+    step = hf.submod(step, ht)
+    out[lay.NPAIR + 1], _ = hf.exclusive_prefix_sum(step)
+    rows = np.nonzero(trace[lay.RT + T_ELAST] * trace[lay.ACT])[0]
+    u = np.zeros(n, dtype=np.uint64)
+    if rows.size:
+        NL = lay.NL
+        cols = ([lay.REG + NL * AX + i for i in range(NL)] + [lay.REG + NL * AY + i for i in range(NL)] + [lay.SW + j for j in range(2 * lay.NW)]
+                + [lay.REG + NL * RESULT_X_REG + i for i in range(NL)] + [lay.Z + i for i in range(NL)])
+        tup = _horner(trace[np.array(cols)][:, rows].T, beta)
+        u[rows] = hf.invmod(hf.submod(np.full(rows.size, gbus, dtype=np.uint64), tup))
+    out[lay.NPAIR + 2] = u
+    acc, total = hf.exclusive_prefix_sum(u)
+    out[lay.NPAIR + 3] = acc
+    closing = int(acc[n - 1])                                         # the last row's own term is not part of the sum
+    _ = total
+    return out, np.array([closing], dtype=np.uint64)
+
+
+def make_stark(lay: Layout, degree_bits: int, **cfg) -> Stark:
+    assert degree_bits > lay.LB
+    prog, _ = build_program(lay)
+    cfg.setdefault("rate_bits", 1)
+    return Stark(degree_bits, lay.N, 0, prog, constraint_degree=3, num_aux_columns=lay.NAUX, num_aux_challenges=3,
+                 aux_fn=lambda tr, ch: aux_columns(lay, tr, ch), num_aux_public_inputs=1, **cfg)
+
+
+# ---- the other end of the bus: a table holding the signatures' public data (A, S, h, R), one per flagged row ----------------------
+def sink_program(ntuple: int):
+    """columns e_0 .. e_{ntuple-1}, flag; second round [u, acc]; challenges [unused, beta, gamma]; aux public input 0 = minus what was received"""
+    e = _Emit(scratch=40)
+    ONE = 63
+    e.ldi(ONE, 1)
+    beta, g = 61, 60
+    e.ins(VX_OP_LDCH, beta, 1)
+    e.ins(VX_OP_LDCH, g, 2)
+    flag = e.ldw(ntuple)
+    t = e.op(VX_OP_SUB, flag, ONE)
+    e.push(e.op(VX_OP_MUL, t, flag), VX_AIR_ALL_ROWS)
+    tup = e.tmp()
+    e.ldw(ntuple - 1, dst=tup)
+    for col in range(ntuple - 2, -1, -1):
+        m = e.top
+        e.op(VX_OP_MUL, tup, beta, tup)
+        e.op(VX_OP_ADD, tup, e.ldw(col), tup)
+        e.release(m)
+    d = e.op(VX_OP_SUB, g, tup)
+    u, acc, accn = e.ldw(ntuple + 1), e.ldw(ntuple + 2), e.ldw(ntuple + 2, nxt=True)
+    t = e.op(VX_OP_MUL, u, d)
+    e.push(e.op(VX_OP_ADD, t, flag), VX_AIR_ALL_ROWS)                  # u (gamma - tuple) = -flag: a receive
+    t = e.op(VX_OP_SUB, accn, acc)
+    e.push(e.op(VX_OP_SUB, t, u), VX_AIR_TRANSITION)
+    e.push(acc, VX_AIR_FIRST_ROW)
+    closing = e.tmp()
+    e.ins(VX_OP_LDP, closing, 0)
+    e.push(e.op(VX_OP_SUB, acc, closing), VX_AIR_LAST_ROW)
+    e.ins(VX_OP_END)
+    return e.w
+
+
+def make_sink(lay: Layout, tuples, degree_bits=None, **cfg):
+    """-> (Stark, trace, public inputs (none)) of a table that receives `tuples` (lists of NTUPLE elements), one per row"""
+    k = len(tuples)
+    db = max(2, (k + 1).bit_length()) if degree_bits is None else degree_bits      # the last row receives nothing
+    n = 1 << db
+    assert k <= n - 1
+    nt = lay.NTUPLE
+    t = np.zeros((nt + 1, n), dtype=np.uint64)
+    for i, tp in enumerate(tuples):
+        t[:nt, i] = np.array(tp, dtype=np.uint64)
+        t[nt, i] = 1
+
+    def aux(trace, chal):
+        beta, g = int(chal[1]), int(chal[2])
+        rows = np.nonzero(trace[nt])[0]
+        u = np.zeros(n, dtype=np.uint64)
+        if rows.size:
+            tup = _horner(trace[:nt][:, rows].T, beta)
+            inv = hf.invmod(hf.submod(np.full(rows.size, g, dtype=np.uint64), tup))
+            u[rows] = hf.submod(np.zeros(rows.size, dtype=np.uint64), inv)
+        acc, _ = hf.exclusive_prefix_sum(u)
+        return np.stack([u, acc]), np.array([int(acc[n - 1])], dtype=np.uint64)
+
+    cfg.setdefault("rate_bits", 1)
+    stark = Stark(db, nt + 1, 0, sink_program(nt), constraint_degree=3, num_aux_columns=2, num_aux_challenges=3, aux_fn=aux,
+                  num_aux_public_inputs=1, **cfg)
+    return stark, t, np.zeros(0, dtype=np.uint64)
+
+
+# ---- RFC 8032 on the host: what produces (A, S, h, R) for the table -------------------------------------------------------------
+def decompress(b: bytes):
+    """RFC 8032 5.1.3 — stays on the host (see the module docstring)"""
+    y = int.from_bytes(b, "little")
+    sign = y >> 255
+    y &= (1 << 255) - 1
+    if y >= Q25519:
+        raise ValueError("non-canonical y")
+    u, v = (y * y - 1) % Q25519, (D_ED * y * y + 1) % Q25519
+    x = u * pow(v, 3, Q25519) * pow(u * pow(v, 7, Q25519) % Q25519, (Q25519 - 5) // 8, Q25519) % Q25519
+    if (v * x * x - u) % Q25519:
+        x = x * pow(2, (Q25519 - 1) // 4, Q25519) % Q25519
+        if (v * x * x - u) % Q25519:
+            raise ValueError("not a curve point")
+    if x == 0 and sign:
+        raise ValueError("x = 0 with the sign bit set")
+    if x & 1 != sign:
+        x = Q25519 - x
+    return x, y
+
+
+def equation_inputs(public_key: bytes, message: bytes, signature: bytes):
+    """(A, S, h, R) of an Ed25519 signature: the table proves [S]B - [h]A = R"""
+    import hashlib
+    a = decompress(public_key)
+    r = decompress(signature[:32])
+    s = int.from_bytes(signature[32:], "little")
+    if s >= ELL:
+        raise ValueError("S >= L")
+    h = int.from_bytes(hashlib.sha512(signature[:32] + public_key + message).digest(), "little") % ELL
+    return a, s, h, r
+
+
+def sign(secret: bytes, message: bytes):
+    """RFC 8032 5.1.6 with the reference affine arithmetic — test / bench data generator -> (public key, signature)"""
+    import hashlib
+
+    from .ed25519_air import compress
+    hd = hashlib.sha512(secret).digest()
+    a = (int.from_bytes(hd[:32], "little") & ((1 << 254) - 8)) | (1 << 254)
+    pk = compress(affine_scalar_mult(a))
+    r = int.from_bytes(hashlib.sha512(hd[32:] + message).digest(), "little") % ELL
+    rb = compress(affine_scalar_mult(r))
+    h = int.from_bytes(hashlib.sha512(rb + pk + message).digest(), "little") % ELL
+    s = (r + h * a) % ELL
+    return pk, rb + s.to_bytes(32, "little")
+
+
+def reference_result(a, s, h):
+    """affine [S]B - [h]A by the independent implementation"""
+    na = ((-a[0]) % Q25519, a[1])
+    return affine_add(affine_scalar_mult(s), affine_scalar_mult(h, na))
