@@ -363,3 +363,53 @@ def test_two_tables_on_one_bus_bytes_identical_to_oracle(ctx, oracle):
         stark_bus.verify_bus([(sha_stark, pis), (other_sink, other_pis)], proofs2)          # valid proofs, unbalanced bus
     with pytest.raises(vx.VxError):
         stark_bus.verify_tables([(sha_stark, pis), (sink_stark, sink_pis)], [proofs2[0], proofs[1]])   # a proof from another bus
+
+
+@pytest.mark.parametrize("limb_bits,scalar_bits,degree_bits,nsigs", [(8, 32, 12, 2), (8, 64, 13, 2), (16, 32, 17, 40)])
+def test_batched_eddsa_table_and_its_sink_bytes_identical_to_oracle(ctx, oracle, limb_bits, scalar_bits, degree_bits, nsigs):
+    """vectorx_amd/eddsa_air.py: many signature equations per trace, results on a bus.  Table + sink through
+    vx_stark_begin / set_aux_challenges / finish2: both proofs byte-identical to the oracle's, vx_stark_verify_bus accepts, a sink
+    with another R leaves the bus unbalanced.  (16, 32, 17): the 65 536-entry limb table of the production shape, 40 instances."""
+    import random
+
+    from vectorx_amd import eddsa_air as ea
+    from vectorx_amd import stark_bus
+    lay = ea.Layout(limb_bits, scalar_bits)
+    rng = random.Random(degree_bits)
+    base = [(ea.affine_scalar_mult(rng.randrange(1, ea.ELL)), rng.randrange(1 << scalar_bits), rng.randrange(1 << scalar_bits)) for _ in range(min(nsigs, 4))]
+    sigs = [base[i % len(base)] for i in range(nsigs)]
+    cfg = dict(num_query_rounds=12, pow_bits=5)
+    stark = ea.make_stark(lay, degree_bits, **cfg)
+    t, res = ea.generate_trace(lay, degree_bits, sigs)
+    assert res[:len(base)] == [ea.reference_result(a, s, h) for a, s, h in base]
+    nopi = np.zeros(0, dtype=np.uint64)
+    honest = [ea.tuple_of(lay, a, s, h, r) for (a, s, h), r in zip(sigs, res)]
+    sink, sink_t, _ = ea.make_sink(lay, honest, **cfg)
+    tables = [(stark, t, nopi), (sink, sink_t, nopi)]
+    proofs, shared = stark_bus.prove_tables(ctx, tables)
+    expect, shared_o = oracle_lib.stark_prove_tables(oracle, tables)
+    assert (shared == shared_o).all() and proofs[0] == expect[0] and proofs[1] == expect[1]
+    sums = vx.stark_verify_bus([(stark, nopi), (sink, nopi)], proofs)
+    assert int(sums[0][0]) != 0 and int(sums[0][1]) != 0
+    forged = [list(tp) for tp in honest]
+    forged[-1][-1] ^= 1
+    sink2, sink2_t, _ = ea.make_sink(lay, forged, **cfg)
+    proofs2, _ = stark_bus.prove_tables(ctx, [(stark, t, nopi), (sink2, sink2_t, nopi)])
+    with pytest.raises(vx.VxError, match="cancel"):
+        vx.stark_verify_bus([(stark, nopi), (sink2, nopi)], proofs2)
+
+
+def test_batched_eddsa_interpreted_equals_compiled(ctx):
+    import os
+
+    from vectorx_amd import eddsa_air as ea
+    lay = ea.Layout(8, 32)
+    stark = ea.make_stark(lay, 12, pow_bits=6, num_query_rounds=12)
+    t, _ = ea.generate_trace(lay, 12, [((ea.BX, ea.BY), 0xC0FFEE, 0xBADF00D)])
+    nopi = np.zeros(0, dtype=np.uint64)
+    expect = stark.prove(ctx, t, nopi)
+    os.environ["VX_NO_JIT"] = "1"
+    try:
+        assert stark.prove(ctx, t, nopi) == expect
+    finally:
+        del os.environ["VX_NO_JIT"]
