@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--poseidon-percent", type=int, default=50, help="share of PoseidonGate rows in the synthetic circuit")
     ap.add_argument("--no-dag-leg", action="store_true",
                     help="skip the extra (untimed-by-the-contract) leg that proves one whole header_range_512 DAG: 64 map + 63 reduce + 1 outer proofs")
+    ap.add_argument("--no-dag-stark-leg", action="store_true",
+                    help="skip the extra leg that proves the header_range_512 DAG WITH the STARK tables of every job (BLAKE2b / SHA-256 / SHA-512 / batched EdDSA)")
     ap.add_argument("--no-chip-leg", action="store_true",
                     help="skip the extra leg that proves the three chip-sized STARK tables (SHA-256, BLAKE2b, Ed25519 scalar multiplication; SURVEY §8 f-3)")
     ap.add_argument("--circuit-flags", type=int, default=0,
@@ -216,6 +218,13 @@ def main():
         except Exception as e:   # noqa: BLE001 — an extra leg must never cost the contract's line
             dag_leg = {"error": repr(e)}
 
+    dag_stark_leg = None
+    if args.workload == "prove" and world == 1 and not args.no_dag_leg and not args.no_dag_stark_leg and args.log_n >= 20 and not args.circuit_flags:
+        try:
+            dag_stark_leg = bench_prove.dag_with_starks_leg(ctx, local_rank)
+        except Exception as e:   # noqa: BLE001
+            dag_stark_leg = {"error": repr(e)}
+
     chip_leg = None
     if args.workload == "prove" and world == 1 and not args.no_chip_leg and args.log_n >= 20 and not args.circuit_flags:
         try:
@@ -326,6 +335,8 @@ def main():
             out["value_from_host_witness"] = host_leg
         if dag_leg is not None:
             out["dag_header_range_512"] = dag_leg
+        if dag_stark_leg is not None:
+            out["dag_header_range_512_with_starks"] = dag_stark_leg
         if sharded_leg is not None:
             out["sharded_one_proof"] = sharded_leg
         if dag_n_leg is not None:

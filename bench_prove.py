@@ -250,6 +250,113 @@ def dag_leg_ranks(ctx, args, local_rank, dist, device, in_flight=3):
                     "NOT the contract's timed region"}
 
 
+def dag_stark_tables(ctx, eddsa_log_n=20, blake_log_n=18, verbose=False):
+    """The STARK tables a header_range_512 job mix proves next to its plonky2 proofs — own AIRs standing in for Curta's chips, sized
+    from the reference's constants: a MAP job hashes 8 headers of up to MAX_HEADER_SIZE = 35 840 bytes = 280 BLAKE2b blocks each
+    (/root/reference/circuits/consts.rs:6-16, builder/header.rs:18) = 2240 compressions = one 2^18-row BLAKE2b table, and two 8-leaf
+    SHA-256 trees (subchain_verification.rs:148-231) = 28 compressions = a 2^11-row SHA-256 table; a REDUCE job merges two
+    commitments (4 compressions, 2^9 rows); the OUTER proof chains SHA-256 over 300 authority keys (justification.rs:140-156: 600
+    compressions, 2^16 rows), hashes 300 signed messages with SHA-512 (117 bytes = 2 blocks each: 2^16 rows) and checks 300 EdDSA
+    equations (justification.rs:237-243) = four 2^20-row batched tables of 97 signatures each (ONE resident trace proven four times:
+    the proving work does not depend on the values).  -> ({kind: [(label, table)]}, [tables to free], setup record)"""
+    from vectorx_amd import blake2b_air, eddsa_air, sha256_air, sha512_air, stark_chips
+    rec, tables = {}, []
+    nopi = np.zeros(0, dtype=np.uint64)
+
+    def resident(label, stark, trace, pis):
+        t0 = time.perf_counter()
+        tab = stark_chips.ResidentTable(ctx, stark, trace, pis, label)
+        tab.prove()                      # warm-up: loads the compiled evaluator, computes and uploads the second-round columns
+        tab.drop_host_trace()
+        tables.append(tab)
+        rec[label]["first_proof_incl_second_round_columns_s"] = round(time.perf_counter() - t0, 2)
+        return tab
+
+    def hash_table(label, air, log_n, msgs):
+        t0 = time.perf_counter()
+        trace, pis, digests = air.generate_trace(log_n, msgs)
+        assert len(digests) == len(msgs), f"{label}: {len(digests)} of {len(msgs)} messages fit 2^{log_n} rows"
+        stark = air.make_stark(log_n)
+        rec[label] = {"rows_log2": log_n, "columns": f"{stark.desc.num_columns} + {stark.desc.num_aux_columns}", "messages": len(msgs),
+                      "trace_generation_s": round(time.perf_counter() - t0, 2)}
+        return resident(label, stark, trace, pis)
+
+    blake = hash_table("blake2b_map", blake2b_air, blake_log_n, [bytes([17 * i & 255]) * 35840 for i in range(8)])
+    sha_map = hash_table("sha256_map", sha256_air, 11, [bytes([i]) * 64 for i in range(14)])
+    sha_red = hash_table("sha256_reduce", sha256_air, 9, [bytes([i + 50]) * 64 for i in range(2)])
+    sha_out = hash_table("sha256_outer", sha256_air, 16, [bytes([i & 255, i >> 8]) * 32 for i in range(300)])
+    s512 = hash_table("sha512_outer", sha512_air, 16, [bytes([i & 255, i >> 8]) * 58 + b"x" for i in range(300)])
+    t0 = time.perf_counter()
+    lay = eddsa_air.Layout()
+    cap = eddsa_air.capacity(lay, eddsa_log_n)
+    sigs, rs = stark_chips.eddsa_signatures(cap, 8)
+    trace, res = eddsa_air.generate_trace(lay, eddsa_log_n, sigs)
+    assert res == rs
+    stark = eddsa_air.make_stark(lay, eddsa_log_n)
+    ntab = -(-300 // cap)
+    rec["eddsa_outer"] = {"rows_log2": eddsa_log_n, "columns": f"{stark.desc.num_columns} + {stark.desc.num_aux_columns}", "signatures_per_table": cap,
+                          "tables": ntab, "trace_generation_s": round(time.perf_counter() - t0, 2)}
+    ed = resident("eddsa_outer", stark, trace, nopi)
+    del trace
+    per_kind = {"map": [("blake2b", blake), ("sha256", sha_map)], "reduce": [("sha256", sha_red)],
+                "outer": [("sha256", sha_out), ("sha512", s512), ("eddsa", stark_chips.Repeated(ed, ntab))]}
+    return per_kind, tables, rec
+
+
+def dag_with_starks_leg(ctx, local_rank, in_flight=3):
+    """the real job mix — every plonky2 proof of the header_range_512 DAG WITH the STARK tables its circuit embeds (see
+    dag_stark_tables), on one GPU, `in_flight` jobs in flight.  Reports the DAG's wall time and, per kind of work, the LANE-seconds spent
+    in it (the lanes overlap, so the kinds add up to about in_flight x the wall time)."""
+    import vectorx_amd as vx
+    from vectorx_amd import mapreduce as mr
+    t_setup = time.perf_counter()
+    per_kind, tables, setup = dag_stark_tables(ctx)
+    lanes = [vx.Context(local_rank) for _ in range(in_flight - 1)]
+    spec = mr.DagSpec(64, 18, 16, 19)
+    provers, split = {}, {}
+
+    def make(kind, log_n, jobs):
+        if kind not in provers:
+            provers[kind] = mr.GpuProver(ctx, kind, log_n, jobs, spec.poseidon_percent, extra_lanes=lanes, distinct_witnesses=4,
+                                         starks=per_kind[kind], split=split)
+        return provers[kind]
+
+    def sync():
+        ctx.sync()
+        for l in lanes:
+            l.sync()
+
+    try:
+        runs = []
+        for _ in range(2):
+            split.clear()
+            r = mr.run_dag(spec, make, None, sync, in_flight=in_flight)
+            r["split"] = dict(split)
+            runs.append(r)
+        assert runs[0]["root"] == runs[1]["root"]
+    finally:
+        for p in provers.values():
+            p.free()
+        for t in tables:
+            t.free()
+        for l in lanes:
+            l.close()
+    res = runs[0]                       # the FIRST pass is the headline
+    secs = res["seconds"]
+    stark_proofs = 64 * 2 + 63 * 1 + 2 + setup["eddsa_outer"]["tables"]
+    return {"header_range_512_per_sec": 1.0 / secs, "dag_seconds": secs, "dag_seconds_all_passes": [round(r["seconds"], 4) for r in runs],
+            "plonky2_proofs": res["proofs"], "stark_proofs": stark_proofs, "in_flight_per_gpu": in_flight, "schedule": "layer barriers",
+            "lane_seconds_by_kind": {k: round(v, 4) for k, v in sorted(res["split"].items())},
+            "per_layer_ms": [(l["kind"], l["jobs"], round(l["ms"], 1)) for l in res["per_layer"]],
+            "tables": setup, "setup_seconds_untimed": round(time.perf_counter() - t_setup - sum(r["seconds"] for r in runs), 2),
+            "root": res["root"].hex(),
+            "what": "64 map jobs = plonky2 2^18 + BLAKE2b table 2^18 rows (2240 compressions) + SHA-256 table 2^11; 63 reduce jobs = plonky2 2^16 + SHA-256 "
+                    "table 2^9; outer = plonky2 2^19 + SHA-256 chain 2^16 + SHA-512 2^16 + 4 batched EdDSA tables 2^20 (388 signature slots for 300 "
+                    "signatures); own AIRs standing in for Curta's chips, synthetic stand-in circuits; every trace, witness and second-round column "
+                    "resident in HBM before the clock starts (one trace per table kind, proven once per job); the STARK proofs are part of a job's "
+                    "digest; NOT the contract's timed region"}
+
+
 def chip_leg(ctx, log_n=13):
     """SURVEY §8 f-3 outside the contract's timed region: the STARK path (`vx_stark_begin` / `vx_stark_finish`) on the three chip-sized
     AIRs of this repository's own design — SHA-256, BLAKE2b-256, Ed25519 scalar multiplication (the chips Curta proves under every

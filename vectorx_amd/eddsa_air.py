@@ -818,7 +818,7 @@ def sink_program(ntuple: int):
 def make_sink(lay: Layout, tuples, degree_bits=None, **cfg):
     """-> (Stark, trace, public inputs (none)) of a table that receives `tuples` (lists of NTUPLE elements), one per row"""
     k = len(tuples)
-    db = max(2, (k + 1).bit_length()) if degree_bits is None else degree_bits      # the last row receives nothing
+    db = max(4, (k + 1).bit_length()) if degree_bits is None else degree_bits      # the last row receives nothing; 2^4 rows: room for a cap of height 4
     n = 1 << db
     assert k <= n - 1
     nt = lay.NTUPLE

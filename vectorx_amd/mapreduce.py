@@ -231,12 +231,16 @@ class GpuProver:
     """One circuit kind on one GPU: circuit loaded once (constants_sigmas resident), one device-resident witness per
     job; `prove` patches the two witness rows that depend on the public inputs and calls vx_prove."""
 
-    def __init__(self, ctx, kind, log_n, jobs, poseidon_percent=50, extra_lanes=(), distinct_witnesses=None):
+    def __init__(self, ctx, kind, log_n, jobs, poseidon_percent=50, extra_lanes=(), distinct_witnesses=None, starks=(), split=None):
         """extra_lanes: more contexts on the SAME GPU; lane k proves on its own stream with its own copy of the circuit
         (run_dag(in_flight=...)).  distinct_witnesses = None: every job has its own generated witness (device-global, shared by
         the lanes).  distinct_witnesses = k: only k base witnesses are generated per circuit kind and job j proves base witness
         j mod k with ITS public inputs patched in — every lane then holds its own copies (two jobs in flight must never patch
-        the same buffer).  Same proving work per job, a fraction of the (untimed, CPU) witness generation: the bench's DAG leg."""
+        the same buffer).  Same proving work per job, a fraction of the (untimed, CPU) witness generation: the bench's DAG leg.
+        starks: [(label, table)] — the STARK tables every job of this kind proves NEXT TO its plonky2 proof (`table.prove(ctx)` -> bytes:
+        vectorx_amd.stark_chips.ResidentTable): in the reference every map / reduce / outer circuit embeds Curta STARKs
+        (/root/reference/circuits/builder/header.rs:18, justification.rs:140-156, 237-243); a job's result is the plonky2 proof followed
+        by its STARK proofs, so the digest the parent consumes covers them.  split: dict label -> lane-seconds, accumulated here."""
         import threading
 
         import vectorx_amd as vx
@@ -244,6 +248,7 @@ class GpuProver:
         self.ctx, self.n, self.kind = ctx, 1 << log_n, kind
         self.lanes = [ctx] + list(extra_lanes)
         self._lock = threading.Lock()
+        self.starks, self.split = list(starks), split
         circuit_seed = {"map": 101, "reduce": 202, "outer": 303}[kind]
         self.sc = SynthCircuit(log_n, seed=circuit_seed, poseidon_percent=poseidon_percent, witness_seed=0)
         self.circuits = [vx.Circuit(c, self.sc.desc_ptr) for c in self.lanes]
@@ -280,7 +285,20 @@ class GpuProver:
         ctx = self.lanes[lane]
         ctx.upload_row(d, self.n, 0, r0)
         ctx.upload_row(d, self.n, 2, r2)
-        return self.circuits[lane].prove(dev_ptr=d)
+        if not self.starks and self.split is None:
+            return self.circuits[lane].prove(dev_ptr=d)
+        t0 = time.perf_counter()
+        parts = [self.circuits[lane].prove(dev_ptr=d)]
+        spent = [("plonky2", time.perf_counter() - t0)]
+        for label, table in self.starks:
+            t0 = time.perf_counter()
+            parts.append(table.prove(ctx))
+            spent.append((label, time.perf_counter() - t0))
+        if self.split is not None:
+            with self._lock:
+                for label, dt in spent:
+                    self.split[label] = self.split.get(label, 0.0) + dt
+        return b"".join(parts)
 
     def free(self):
         for d in self.wit.values():

@@ -116,6 +116,16 @@ def bench_chip(ctx, which: str, log_n: int, steps: int = 3, warmup: int = 1, hos
         "trace_cells_per_s": air.Cols.N * n / dt}
 
 
+class Repeated:
+    """`times` proofs of the same resident table, one after the other (the four EdDSA tables of an outer proof share one trace in the bench)"""
+
+    def __init__(self, table, times):
+        self.table, self.times = table, times
+
+    def prove(self, ctx=None) -> bytes:
+        return b"".join(self.table.prove(ctx) for _ in range(self.times))
+
+
 class ResidentTable:
     """A STARK table whose trace — and, once the challenges are known, its second-round columns — live in HBM: `prove()` is
     vx_stark_begin -> (second-round columns: computed on the HOST by the table's aux_fn the first time a challenge vector is seen, then
@@ -135,8 +145,8 @@ class ResidentTable:
         self.api = None
         self.seen = None
         self.cap = 1 << 25
-        self.out = np.empty(self.cap, dtype=np.uint8)
         self.aux_seconds_host = 0.0
+        self.proofs = 0
 
     def drop_host_trace(self):
         """after the first proof the host copy is only needed to recompute second-round columns for OTHER challenges"""
@@ -165,12 +175,14 @@ class ResidentTable:
                     c.upload(self.d_aux, aux)
                     c.sync()
                     self.seen = key
+            out = np.empty(self.cap, dtype=np.uint8)            # per call: lanes prove the same table concurrently
             nb = ctypes.c_size_t(self.cap)
             api = None if self.api is None or self.api.size == 0 else self.api.ctypes.data
-            rc = L.vx_stark_finish2(sess, vp(self.d_aux), 1, api, None, self.out.ctypes.data, ctypes.byref(nb))
+            rc = L.vx_stark_finish2(sess, vp(self.d_aux), 1, api, None, out.ctypes.data, ctypes.byref(nb))
             if rc != 0:
                 raise RuntimeError(L.vx_last_error().decode())
-            return self.out[:nb.value].tobytes()
+            self.proofs += 1
+            return out[:nb.value].tobytes()
         finally:
             L.vx_stark_session_free(sess)
 
