@@ -101,13 +101,13 @@ def dag_leg(ctx, local_rank, in_flight=3):
             l.sync()
 
     try:
-        # three passes over the same DAG: layered (also pays each circuit's first-use allocations), layered again, and the
-        # dependency-driven schedule (no layer barriers; one process only) — same proofs, same root; the best pass is reported
+        # three passes over the same DAG: layered, layered again, and the dependency-driven schedule (no layer barriers; one process
+        # only) — same proofs, same root.  The FIRST pass is the headline (round 4: vx_circuit_create rehearses one proof, so the pool
+        # holds every buffer shape before the clock starts and the first pass no longer pays first-use allocations); all are listed.
         schedules = ["layer barriers", "layer barriers", "dependency-driven"]
         runs = [mr.run_dag(spec, make, None, sync, in_flight=in_flight, barriers=(sch == "layer barriers")) for sch in schedules]
         assert runs[0]["root"] == runs[1]["root"] == runs[2]["root"]
-        best = min(range(3), key=lambda i: runs[i]["seconds"])
-        res = runs[best]
+        res = runs[0]
     finally:
         for p in provers.values():
             p.free()
@@ -115,13 +115,15 @@ def dag_leg(ctx, local_rank, in_flight=3):
             l.close()
     secs = res["seconds"]
     return {"header_range_512_per_sec": 1.0 / secs, "dag_seconds": secs, "plonky2_proofs": res["proofs"],
-            "plonky2_proofs_per_sec": res["proofs"] / secs, "in_flight_per_gpu": in_flight, "schedule": schedules[best],
+            "plonky2_proofs_per_sec": res["proofs"] / secs, "in_flight_per_gpu": in_flight, "schedule": schedules[0], "reported_pass": "first",
             "dag_seconds_all_passes": [[sch, round(r["seconds"], 4)] for sch, r in zip(schedules, runs)],
             "per_layer_ms": [(l["kind"], l["jobs"], round(l["ms"], 1)) for l in res["per_layer"]],
+            "non_map_layers_ms": round(sum(l["ms"] for l in res["per_layer"] if l["kind"] != "map"), 1),
             "setup_seconds_untimed": round(time.perf_counter() - t_setup - sum(r["seconds"] for r in runs), 2), "root": res["root"].hex(),
-            "what": "64 map (2^18 rows) + 63 reduce (2^16) + 1 outer (2^19) proofs, layer barriers, synthetic stand-in circuits; "
-                    "witnesses HBM-resident (4 base witnesses per circuit kind, each job's own public inputs patched in: the proving "
-                    "work of 128 distinct proofs without 128 CPU witness generations); NOT the contract's timed region"}
+            "what": "64 map (2^18 rows) + 63 reduce (2^16) + 1 outer (2^19) plonky2 proofs, the FIRST pass with layer barriers (per_layer_ms add up to "
+                    "dag_seconds; the dependency-driven pass is listed in dag_seconds_all_passes only), synthetic stand-in circuits; witnesses "
+                    "HBM-resident (4 base witnesses per circuit kind, each job's own public inputs patched in: the proving work of 128 distinct "
+                    "proofs without 128 CPU witness generations); NOT the contract's timed region"}
 
 
 def guarded_collective_leg(dist, fn):

@@ -252,6 +252,11 @@ typedef struct vx_circuit_desc {
  * for every later proof of this circuit) and derive circuit_digest. */
 int vx_circuit_create(vx_ctx* ctx, const vx_circuit_desc* desc, vx_circuit** out);
 void vx_circuit_free(vx_circuit* c);
+/* One rehearsal proof of an all-zero witness, discarded: primes the context's buffer pool with every shape a proof of this circuit
+ * needs and loads its program-gate kernels, so that the first real vx_prove costs what the later ones do.  vx_circuit_create and
+ * vx_circuit_load call it themselves (best effort; VX_NO_WARM_ON_LOAD=1 turns that off); a host with several contexts per GPU calls
+ * it once per context.  Skipped (VX_OK) for circuits with lookup tables. */
+int vx_circuit_warm(vx_ctx* ctx, vx_circuit* circuit);
 
 /* `.vxcircuit`: the library's self-describing container for a compiled circuit — the role plonky2x's ./build/<name>.circuit files
  * play for `build` / `prove` (/root/reference/succinct.json:7-8,17-18; save -> load round trip as in

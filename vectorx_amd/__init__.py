@@ -93,6 +93,7 @@ _SIGNATURES = {
     "vx_merkle_digest_count": (_sz, [_sz, _i]),
     "vx_circuit_create": (_i, [_vp, _vp, ctypes.POINTER(_vp)]),
     "vx_circuit_free": (None, [_vp]),
+    "vx_circuit_warm": (_i, [_vp, _vp]),
     "vx_circuit_serialized_size": (_sz, [_vp, _i, _i]),
     "vx_circuit_serialize": (_i, [_vp, _vp, _i, _vp, ctypes.POINTER(_sz)]),
     "vx_circuit_parse": (_i, [_vp, _sz, ctypes.POINTER(_vp), ctypes.POINTER(_vp)]),

@@ -215,16 +215,20 @@ GLD void acc_push(AlphaAcc& a, const QuotientParams& p, u64 term) {
 #ifndef VX_QUOTIENT_PERM_BLOCKS
 #define VX_QUOTIENT_PERM_BLOCKS 8
 #endif
+#ifndef VX_QUOTIENT_SMALL_GATE_BLOCKS
+#define VX_QUOTIENT_SMALL_GATE_BLOCKS 8
+#endif
 // Two launches per quotient (round 3): the vanishing polynomial is a sum, and its two halves want different machines.
 //   PART 0  L_0 (Z - 1) and the partial-product checks: 640 multiplications per row on 80 wires + 80 sigmas + 20 Z columns —
 //           a long stream of loads with a small live state (two running products), so it runs at 8 blocks per CU and hides
 //           its memory latency behind other waves;  writes  out = A / Z_H.
-//   PART 1  the gate constraints (the PoseidonGate's ~19 k instructions on a 12-lane state): register-bound, 5 blocks per CU;
-//           adds  G / Z_H  to out.
+//   PART 1  the SMALL native gates (Constant, PublicInput, Arithmetic): a few loads and multiply-adds per row;  adds  G / Z_H  to out.
+//   PART 2  the PoseidonGate alone (round 4: ~19 k instructions on a 12-lane state — register-bound; inside the generic gate loop of
+//           rounds 1-3 it carried 50 spilled VGPRs and 204 B of scratch per lane at 128 VGPRs);  adds  G / Z_H  to out.
 // Fused (rounds 1-2) the kernel sat at 96 VGPRs with 81 spilled values and the VALU busy 82 % of the time
 // (profiles/r03_pmc_sq_prove.md: 4.88 cycles per instruction against 3.98 for the hash kernel).
 template <int PART>
-__global__ __launch_bounds__(256, PART == 0 ? VX_QUOTIENT_PERM_BLOCKS : VX_QUOTIENT_BLOCKS) void quotient_kernel(QuotientParams p) {
+__global__ __launch_bounds__(256, PART == 0 ? VX_QUOTIENT_PERM_BLOCKS : PART == 1 ? VX_QUOTIENT_SMALL_GATE_BLOCKS : VX_QUOTIENT_BLOCKS) void quotient_kernel(QuotientParams p) {
   const size_t il = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (il >= p.rows) return;
   const size_t N = p.N, SW = p.stride_w, i = il + p.row_base;
@@ -308,6 +312,7 @@ __global__ __launch_bounds__(256, PART == 0 ? VX_QUOTIENT_PERM_BLOCKS : VX_QUOTI
   for (int g = 0; g < p.num_gates; ++g) {
     const GateDev gd = p.gates[g];
     if (gd.type == 0 || gd.type >= 5) continue;  // NoopGate / lookup gates: no constraints; program gates: program_gates_kernel
+    if ((PART == 2) != (gd.type == 4)) continue;  // the PoseidonGate has its own launch
     const u64 s = CS(gd.selector_index);
     u64 filter = 1;
     for (int q = gd.group_start; q < gd.group_end; ++q)
@@ -318,6 +323,7 @@ __global__ __launch_bounds__(256, PART == 0 ? VX_QUOTIENT_PERM_BLOCKS : VX_QUOTI
     for (int c = 0; c < VX_MAX_CHALLENGES; ++c) G.acc[c] = dot3{0, 0, 0};
     G.idx = base_idx;
     const int c0 = p.const_base;  // gate constants start after the selectors (and the lookup selectors)
+    if constexpr (PART == 1) {
     if (gd.type == 1) {              // ConstantGate
       for (int q = 0; q < gd.param; ++q) acc_push(G, p, gl_sub(CS(c0 + q), WIRE(q)));
     } else if (gd.type == 2) {  // PublicInputGate
@@ -329,7 +335,8 @@ __global__ __launch_bounds__(256, PART == 0 ? VX_QUOTIENT_PERM_BLOCKS : VX_QUOTI
         u64 rhs = gl_mad(gl_mul_nc(m0, m1), k0, gl_mul_nc(ad, k1));
         acc_push(G, p, gl_sub(o, rhs));
       }
-    } else if (gd.type == 4) {  // PoseidonGate (gates/poseidon.rs wire layout)
+    }
+    } else {  // PART 2: PoseidonGate (gates/poseidon.rs wire layout)
       // The running state is kept as arbitrary u64 representatives ("nc", poseidon.hip.h): wires are canonical, so
       // state - wire and state + constant need one carry fix each, and acc_push's multiply-add takes any representative.
       const u64 swap = WIRE(24);

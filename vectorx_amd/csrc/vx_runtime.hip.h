@@ -54,6 +54,7 @@ struct vx_ctx {
   u64* root_hi = nullptr;  // w_{2^24}^(4096k)
   u64* hash_clk = nullptr; // {shader ticks, 100 MHz ticks} samples written by hash_leaves_colmajor_kernel while profiling
   bool prof_on = false;
+  bool rehearsal = false;  // vx_circuit_warm: a proof of an all-zero witness that only exists to prime the pool and the kernel caches
   std::vector<ProfPending> pending;
   std::vector<hipEvent_t> event_pool;
   std::map<std::string, ProfEntry> prof;

@@ -553,12 +553,45 @@ int vx_hash_rows_dev(vx_ctx* c, const uint64_t* cols, size_t col_stride, size_t 
 // ---------------------------------------------------------------------------------------------
 // L3
 // ---------------------------------------------------------------------------------------------
+// One rehearsal proof of an all-zero witness (discarded; the two "witness does not satisfy the circuit" checks are off): every device
+// buffer shape a proof of this circuit asks the pool for is allocated once and cached, the circuit's program-gate kernels are loaded,
+// the twiddle / scale tables of its sizes exist — so that the FIRST real proof costs what every later one does (round 3 measured 250 ms
+// instead of 57 for the first 2^19-row proof on some boxes: first-use hipMallocs).  Circuits with lookup tables are skipped (their host
+// recurrences divide by witness-dependent values).
+int vx_circuit_warm(vx_ctx* c, vx_circuit* k) {
+  if (!c || !k) return vx_fail(VX_E_INVALID, "vx_circuit_warm: NULL argument");
+  if (k->ctx != c) return vx_fail(VX_E_INVALID, "vx_circuit_warm: circuit belongs to a different context");
+  if (k->num_luts > 0) return VX_OK;
+  HIPCHK(hipSetDevice(c->device));
+  const size_t bytes = (size_t)k->num_wires * k->n() * 8;
+  void* zero = nullptr;
+  if (c->pool_alloc(&zero, bytes) != hipSuccess) return vx_fail(VX_E_NOMEM, "vx_circuit_warm: out of device memory");
+  int rc = VX_OK;
+  const bool prof_was = c->prof_on;
+  c->prof_on = false;
+  c->rehearsal = true;
+  try {
+    if (hipMemsetAsync(zero, 0, bytes, c->stream) != hipSuccess) rc = vx_fail(VX_E_HIP, "vx_circuit_warm: hipMemsetAsync failed");
+    std::vector<uint8_t> discard;
+    if (rc == VX_OK) rc = prove_impl(c, k, (const u64*)zero, /*wires_on_device=*/true, nullptr, discard);
+  } catch (const std::exception& e) {
+    rc = vx_fail(VX_E_INVALID, "vx_circuit_warm: %s", e.what());
+  }
+  c->rehearsal = false;
+  c->prof_on = prof_was;
+  hipStreamSynchronize(c->stream);
+  c->pool_free(zero);
+  return rc;
+}
 int vx_circuit_create(vx_ctx* c, const vx_circuit_desc* desc, vx_circuit** out) {
   if (!c || !desc || !out) return vx_fail(VX_E_INVALID, "vx_circuit_create: NULL argument");
   *out = nullptr;
   HIPCHK(hipSetDevice(c->device));
   try {  // nothing unwinds across the ABI
-    return circuit_create(c, desc, out);
+    const int rc = circuit_create(c, desc, out);
+    // best effort, on by default (VX_NO_WARM_ON_LOAD=1 turns it off): a failed rehearsal leaves a perfectly usable circuit
+    if (rc == VX_OK && !getenv("VX_NO_WARM_ON_LOAD")) (void)vx_circuit_warm(c, *out);
+    return rc;
   } catch (const std::bad_alloc&) {
     return vx_fail(VX_E_NOMEM, "vx_circuit_create: out of host memory");
   } catch (const std::exception& e) {
