@@ -261,7 +261,7 @@ def dag_stark_tables(ctx, eddsa_log_n=20, blake_log_n=18, verbose=False):
     compressions, 2^16 rows), hashes 300 signed messages with SHA-512 (117 bytes = 2 blocks each: 2^16 rows) and checks 300 EdDSA
     equations (justification.rs:237-243) = four 2^20-row batched tables of 97 signatures each (ONE resident trace proven four times:
     the proving work does not depend on the values).  -> ({kind: [(label, table)]}, [tables to free], setup record)"""
-    from vectorx_amd import blake2b_air, eddsa_air, sha256_air, sha512_air, stark_chips
+    from vectorx_amd import blake2b_air, blake2b_bytes_air, eddsa_air, sha256_air, sha512_air, stark_chips
     rec, tables = {}, []
     nopi = np.zeros(0, dtype=np.uint64)
 
@@ -283,7 +283,13 @@ def dag_stark_tables(ctx, eddsa_log_n=20, blake_log_n=18, verbose=False):
                       "trace_generation_s": round(time.perf_counter() - t0, 2)}
         return resident(label, stark, trace, pis)
 
-    blake = hash_table("blake2b_map", blake2b_air, blake_log_n, [bytes([17 * i & 255]) * 35840 for i in range(8)])
+    # round 4: the byte / XOR-lookup table (641 + 188 columns, 34 rows per compression: 2240 compressions fit 2^17 rows); round 3's bit
+    # table (1063 + 12 columns, 106 rows per compression, 2^18 rows) with VX_DAG_BLAKE2B_BITS=1, for comparison
+    import os
+    if os.environ.get("VX_DAG_BLAKE2B_BITS"):
+        blake = hash_table("blake2b_map", blake2b_air, blake_log_n, [bytes([17 * i & 255]) * 35840 for i in range(8)])
+    else:
+        blake = hash_table("blake2b_map", blake2b_bytes_air, 17, [bytes([17 * i & 255]) * 35840 for i in range(8)])
     sha_map = hash_table("sha256_map", sha256_air, 11, [bytes([i]) * 64 for i in range(14)])
     sha_red = hash_table("sha256_reduce", sha256_air, 9, [bytes([i + 50]) * 64 for i in range(2)])
     sha_out = hash_table("sha256_outer", sha256_air, 16, [bytes([i & 255, i >> 8]) * 32 for i in range(300)])
@@ -352,7 +358,7 @@ def dag_with_starks_leg(ctx, local_rank, in_flight=3):
             "per_layer_ms": [(l["kind"], l["jobs"], round(l["ms"], 1)) for l in res["per_layer"]],
             "tables": setup, "setup_seconds_untimed": round(time.perf_counter() - t_setup - sum(r["seconds"] for r in runs), 2),
             "root": res["root"].hex(),
-            "what": "64 map jobs = plonky2 2^18 + BLAKE2b table 2^18 rows (2240 compressions) + SHA-256 table 2^11; 63 reduce jobs = plonky2 2^16 + SHA-256 "
+            "what": "64 map jobs = plonky2 2^18 + BLAKE2b table (2240 compressions: 2^17 rows of the byte / XOR-lookup table) + SHA-256 table 2^11; 63 reduce jobs = plonky2 2^16 + SHA-256 "
                     "table 2^9; outer = plonky2 2^19 + SHA-256 chain 2^16 + SHA-512 2^16 + 4 batched EdDSA tables 2^20 (388 signature slots for 300 "
                     "signatures); own AIRs standing in for Curta's chips, synthetic stand-in circuits; every trace, witness and second-round column "
                     "resident in HBM before the clock starts (one trace per table kind, proven once per job); the STARK proofs are part of a job's "

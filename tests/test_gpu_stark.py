@@ -413,3 +413,27 @@ def test_batched_eddsa_interpreted_equals_compiled(ctx):
         assert stark.prove(ctx, t, nopi) == expect
     finally:
         del os.environ["VX_NO_JIT"]
+
+
+def test_blake2b_bytes_table_bytes_identical_to_oracle(ctx, oracle):
+    """vectorx_amd/blake2b_bytes_air.py (round 4: bytes + a 65 536-entry XOR lookup, four G functions per row, 641 + 188 columns): the
+    table cannot be smaller than 2^17 rows, so this is the one proof of it against the oracle — here, where the oracle has the GPU
+    box's 16 cores.  GPU proof == oracle proof; the product's host verifier accepts it and rejects another digest / a flipped byte."""
+    import hashlib
+
+    from vectorx_amd import blake2b_bytes_air as b2
+    msgs = [b"abc", b"", bytes(range(200)), b"y" * 129, bytes([7]) * 5000]
+    stark = b2.make_stark(17, num_query_rounds=10, pow_bits=4)
+    t, pis, digests = b2.generate_trace(17, msgs)
+    assert digests == [hashlib.blake2b(m, digest_size=32).digest() for m in msgs]
+    gp = stark.prove(ctx, t, pis)
+    assert gp == oracle_lib.stark_prove(oracle, stark, t, pis)
+    stark.verify(pis, gp)
+    wrong = pis.copy()
+    wrong[3] = (int(wrong[3]) + 1) % P
+    with pytest.raises(vx.VxError):
+        stark.verify(wrong, gp)
+    bad = bytearray(gp)
+    bad[len(bad) // 3] ^= 1
+    with pytest.raises(vx.VxError):
+        stark.verify(pis, bytes(bad))

@@ -29,7 +29,7 @@ def main():
     ap.add_argument("--groups", type=int, default=16, help="blocks of 4 trace columns")
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--air", default="mulchain", choices=["mulchain", "sha256", "blake2b", "ed25519", "eddsa"],
+    ap.add_argument("--air", default="mulchain", choices=["mulchain", "sha256", "blake2b", "ed25519", "eddsa", "blake2b_bytes"],
                     help="sha256: vectorx_amd/sha256_air.py — 1024 + 3 columns, 2072 constraints, two commitment rounds (own AIR, not Curta's)")
     ap.add_argument("--check", action="store_true", help="verify the last proof with vx_stark_verify")
     ap.add_argument("--host-trace", action="store_true", help="chip AIRs: the trace starts in page-locked HOST memory on every proof (PCIe-inclusive rate; "
@@ -42,6 +42,12 @@ def main():
         return sha256_bench(args, vx, "blake2b")
     if args.air == "ed25519":
         return sha256_bench(args, vx, "ed25519")
+    if args.air == "blake2b_bytes":   # bytes + XOR lookup, four G per row (vectorx_amd/blake2b_bytes_air.py): --log-n 17 = one map job's 2240 compressions
+        from vectorx_amd import stark_chips
+        ctx = vx.Context(0)
+        print(json.dumps(stark_chips.bench_blake2b_bytes(ctx, max(17, args.log_n), args.steps, args.warmup)), flush=True)
+        ctx.close()
+        return
     if args.air == "eddsa":          # the batched signature table (vectorx_amd/eddsa_air.py): --log-n 20 = 97 signatures per proof
         from vectorx_amd import stark_chips
         ctx = vx.Context(0)

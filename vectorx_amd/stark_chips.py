@@ -255,3 +255,50 @@ def bench_eddsa(ctx, log_n: int = 20, steps: int = 3, warmup: int = 1, distinct:
             "stage_ms_per_proof": stages, "evaluator_ms": ev, "hashing_ms": hashing, "first_proof_seconds_incl_jit": round(t_first, 2),
             "trace_generation_seconds_host": round(t_gen, 2), "second_round_columns_seconds_host": round(tab.aux_seconds_host, 2),
             "steps": steps, "warmup": warmup, "n_gpus": 1, "data": "synthetic", "trace_cells_per_s": (ncols + naux) * (1 << log_n) / dt}
+
+
+def bench_table(ctx, stark, trace, public_inputs, name: str, steps: int = 3, warmup: int = 1, extra=None) -> dict:
+    """any table through ResidentTable: trace and second-round columns resident in HBM, HIP-event stage times"""
+    t0 = time.perf_counter()
+    tab = ResidentTable(ctx, stark, trace, public_inputs, name)
+    try:
+        proof = tab.prove()
+        t_first = time.perf_counter() - t0 - tab.aux_seconds_host
+        for _ in range(warmup):
+            tab.prove()
+        ctx.prof_enable(True)
+        ctx.prof_reset()
+        ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            proof = tab.prove()
+        ctx.sync()
+        dt = (time.perf_counter() - t0) / steps
+        stages = {k: round(v["ms"] / steps, 3) for k, v in ctx.prof().items()}
+        ctx.prof_enable(False)
+    finally:
+        tab.free()
+    d = stark.desc
+    rec = {"table": name, "ms_per_proof": dt * 1e3, "rows_log2": d.degree_bits, "columns": f"{d.num_columns} + {d.num_aux_columns}",
+           "trace_cells_per_s": (d.num_columns + d.num_aux_columns) * (1 << d.degree_bits) / dt, "proof_bytes": len(proof),
+           "stage_ms_per_proof": stages, "evaluator": "compiled" if "air_quotient_eval_jit" in stages else "interpreted",
+           "first_proof_seconds_incl_upload": round(t_first, 2), "second_round_columns_seconds_host": round(tab.aux_seconds_host, 2),
+           "steps": steps, "warmup": warmup}
+    rec.update(extra or {})
+    return rec
+
+
+def bench_blake2b_bytes(ctx, log_n: int = 17, steps: int = 3, warmup: int = 1, compressions: int = 2240) -> dict:
+    """the byte / XOR-lookup BLAKE2b table (blake2b_bytes_air.py) loaded like a header_range map job: 8 headers of 280 blocks"""
+    from . import blake2b_bytes_air as b2
+    t0 = time.perf_counter()
+    per = compressions // 8
+    msgs = [bytes([17 * i & 255]) * (128 * per) for i in range(8)]
+    trace, pis, digests = b2.generate_trace(log_n, msgs)
+    assert digests == b2.reference_digests(msgs)
+    t_gen = time.perf_counter() - t0
+    stark = b2.make_stark(log_n)
+    rec = bench_table(ctx, stark, trace, pis, "blake2b_bytes", steps, warmup,
+                      {"compressions_in_messages": compressions, "compression_slots": (1 << log_n) // b2.PERIOD, "trace_generation_seconds_host": round(t_gen, 2)})
+    rec["compressions_per_s"] = compressions / (rec["ms_per_proof"] * 1e-3)
+    return rec
