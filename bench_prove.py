@@ -311,12 +311,16 @@ def dag_stark_tables(ctx, eddsa_log_n=20, blake_log_n=18, verbose=False):
     return per_kind, tables, rec
 
 
-def dag_with_starks_leg(ctx, local_rank, in_flight=3):
+def dag_with_starks_leg(ctx, local_rank, in_flight=None):
     """the real job mix — every plonky2 proof of the header_range_512 DAG WITH the STARK tables its circuit embeds (see
     dag_stark_tables), on one GPU, `in_flight` jobs in flight.  Reports the DAG's wall time and, per kind of work, the LANE-seconds spent
     in it (the lanes overlap, so the kinds add up to about in_flight x the wall time)."""
+    import os
+
     import vectorx_amd as vx
     from vectorx_amd import mapreduce as mr
+    if in_flight is None:
+        in_flight = int(os.environ.get("VX_DAG_STARKS_IN_FLIGHT", "3"))
     t_setup = time.perf_counter()
     per_kind, tables, setup = dag_stark_tables(ctx)
     lanes = [vx.Context(local_rank) for _ in range(in_flight - 1)]

@@ -352,6 +352,14 @@ int vx_stark_begin(vx_ctx* ctx, const vx_stark_desc* desc, const uint64_t* trace
                    uint64_t* aux_challenges_out /* [num_aux_challenges] */, vx_stark_session** out);
 int vx_stark_finish(vx_stark_session* session, const uint64_t* aux_columns, int aux_on_device, const uint64_t* pow_witness_hint,
                     uint8_t* out_buf, size_t* out_len);
+/* ONE STARK proof across `world` GPUs, split by LDE coset exactly like vx_prove_sharded (declared below, with vx_allgather_fn): every
+ * rank holds the whole trace (and later the whole second-round columns), extends and hashes only ITS cosets, the owners of the
+ * quotient domain's blocks evaluate the constraints there, and the ranks meet in small all-gathers (caps, quotient coset coefficients,
+ * first FRI layer, query openings).  world a power of two <= 2^rate_bits (starky's rate_bits = 1: two ranks) and <= 2^cap_height.
+ * vx_stark_finish / vx_stark_finish2 of such a session return the full proof on every rank, byte-identical to the unsharded one. */
+typedef int (*vx_allgather_fn)(void* user, void* dev_buf, size_t bytes_per_rank);
+int vx_stark_begin_sharded(vx_ctx* ctx, const vx_stark_desc* desc, const uint64_t* trace, int trace_on_device, const uint64_t* public_inputs,
+                           int rank, int world, vx_allgather_fn allgather, void* user, uint64_t* aux_challenges_out, vx_stark_session** out);
 void vx_stark_session_free(vx_stark_session* session);
 int vx_stark_verify(const vx_stark_desc* desc, const uint64_t* public_inputs, const uint8_t* proof, size_t proof_len);
 /* The same for the constraint-program gates of a circuit (one kernel per program gate): returns the number compiled now. */
@@ -402,7 +410,7 @@ int vx_stark_verify_bus(const vx_stark_desc* const* descs, const uint64_t* const
  * in-process vx_group below (host threads + xGMI peer copies).  The callback is invoked on the calling thread with
  * the context's stream idle; `dev_buf` holds world * bytes_per_rank bytes of device memory with slot `rank`
  * filled; on return (0 = ok) every slot must hold the corresponding rank's data. */
-typedef int (*vx_allgather_fn)(void* user, void* dev_buf, size_t bytes_per_rank);
+/* vx_allgather_fn: declared above, with vx_stark_begin_sharded */
 int vx_prove_sharded(vx_ctx* ctx, vx_circuit* circuit, const uint64_t* wires, int wires_on_device, int rank, int world,
                      vx_allgather_fn allgather, void* user, const uint64_t* pow_witness_hint, uint8_t* out_buf,
                      size_t* out_len);

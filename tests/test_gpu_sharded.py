@@ -424,3 +424,51 @@ def test_sharded_proof_with_a_quotient_degree_factor_below_the_blowup(oracle, de
             assert p == expect
     finally:
         _free(ctxs, circuits)
+
+
+# ---- STARKs sharded by coset (vx_stark_begin_sharded) -------------------------------------------------------------
+def _stark_case(name, degree_bits, rate_bits):
+    import stark_airs as airs
+    cfg = dict(rate_bits=rate_bits, num_query_rounds=10, pow_bits=4)
+    if name == "sha256":
+        from vectorx_amd import sha256_air as sha
+        stark = sha.make_stark(degree_bits, **cfg)
+        trace, pis, _ = sha.generate_trace(degree_bits, [b"abc", b"", bytes(range(100))])
+        return stark, trace, pis
+    return getattr(airs, name)(degree_bits, **cfg)
+
+
+@pytest.mark.parametrize("name,degree_bits,rate_bits,world", [
+    ("mulchain", 10, 1, 2), ("logup", 9, 1, 2), ("sha256", 9, 1, 2),              # starky's rate_bits = 1: two ranks, one coset each
+    ("fibonacci", 8, 3, 8), ("fibonacci", 8, 2, 2), ("cubic", 8, 3, 4), ("cubic", 9, 2, 4), ("mulchain", 10, 3, 8), ("mulchain", 9, 3, 2),
+    ("logup", 9, 3, 4), ("logup", 8, 3, 8), ("sha256", 8, 2, 4)])
+def test_stark_proof_sharded_by_coset_is_byte_identical(ctx, name, degree_bits, rate_bits, world):
+    """the G ranks as host threads with one context each ON ONE DEVICE (single-device emulation, like the plonk path's tests): every
+    rank's proof equals the unsharded vx_stark_prove / begin + finish proof byte for byte — quotient domains of 1 (fibonacci), 2
+    (degree-3 AIRs) blocks, with fewer, as many and more ranks than quotient blocks, with and without a second commitment round"""
+    stark, trace, pis = _stark_case(name, degree_bits, rate_bits)
+    expect = stark.prove(ctx, trace, pis)
+    ctxs = [vx.Context(0) for _ in range(world)]
+    try:
+        proofs = sharded.prove_stark_sharded_threads(ctxs, stark, trace, pis)
+        assert all(p == expect for p in proofs)
+    finally:
+        for c in ctxs:
+            c.close()
+    stark.verify(pis, expect) if stark.desc.num_aux_public_inputs == 0 else None
+
+
+def test_stark_sharded_refuses_bad_worlds(ctx):
+    import ctypes
+    import stark_airs as airs
+    stark, trace, pis = airs.mulchain(8, rate_bits=1, num_query_rounds=10, pow_bits=4)
+    L = vx.lib()
+    sess = ctypes.c_void_p()
+    t = np.ascontiguousarray(trace, dtype=np.uint64)
+    for rank, world in ((0, 4), (0, 3), (2, 2), (-1, 2)):       # 4 > 2^rate_bits, not a power of two, rank outside the world
+        rc = L.vx_stark_begin_sharded(ctx._h, ctypes.cast(stark.desc_ptr, ctypes.c_void_p), t.ctypes.data, 0, pis.ctypes.data, rank, world,
+                                      ctypes.cast(L.vx_group_allgather, ctypes.c_void_p), None, None, ctypes.byref(sess))
+        assert rc == vx.VX_E_INVALID, (rank, world)
+    rc = L.vx_stark_begin_sharded(ctx._h, ctypes.cast(stark.desc_ptr, ctypes.c_void_p), t.ctypes.data, 0, pis.ctypes.data, 0, 2, None, None, None,
+                                  ctypes.byref(sess))
+    assert rc == vx.VX_E_INVALID                                # two ranks need an all-gather

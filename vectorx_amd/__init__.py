@@ -109,6 +109,7 @@ _SIGNATURES = {
     "vx_stark_verify": (_i, [_vp, _vp, _vp, _sz]),
     "vx_stark_begin": (_i, [_vp, _vp, _vp, _i, _vp, _vp, ctypes.POINTER(_vp)]),
     "vx_stark_finish": (_i, [_vp, _vp, _i, _vp, _vp, ctypes.POINTER(_sz)]),
+    "vx_stark_begin_sharded": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, ctypes.POINTER(_vp)]),
     "vx_stark_session_free": (None, [_vp]),
     "vx_stark_precompile": (_i, [_vp, ctypes.POINTER(_i)]),
     "vx_circuit_precompile": (_i, [_vp, ctypes.POINTER(_i)]),
@@ -564,6 +565,33 @@ class Stark:
         chal = np.zeros(max(1, self.desc.num_aux_challenges), dtype=np.uint64)
         sess = _vp()
         _chk(lib().vx_stark_begin(ctx._h, ctypes.cast(self.desc_ptr, _vp), t.ctypes.data, 0, pi.ctypes.data, chal.ctypes.data, ctypes.byref(sess)))
+        return sess, chal[:self.desc.num_aux_challenges].copy(), t
+
+    def begin_sharded(self, ctx, trace, public_inputs, rank: int, world: int, allgather, user=None):
+        """`vx_stark_begin_sharded`: this rank's part of ONE proof split over `world` GPUs by LDE coset (allgather / user as in
+        Circuit.prove_sharded: `lib().vx_group_allgather` + the member handle, or a Python callable).  Returns like `begin`; finish the
+        session with `finish` — every rank gets the full proof, byte-identical to the unsharded one."""
+        t = _as_u64(trace)
+        if t.shape != (self.desc.num_columns, 1 << self.desc.degree_bits):
+            raise VxError(VX_E_INVALID, f"trace has shape {t.shape}")
+        pi = _as_u64(public_inputs)
+        chal = np.zeros(max(1, self.desc.num_aux_challenges), dtype=np.uint64)
+        sess = _vp()
+        keep = None
+        if callable(allgather) and not isinstance(allgather, ctypes._CFuncPtr):
+            def _cb(_user, dptr, nbytes):
+                try:
+                    allgather(dptr, nbytes)
+                    return 0
+                except BaseException:   # never unwind through the C frames
+                    return 1
+            keep = ALLGATHER_FN(_cb)
+            fn_ptr = ctypes.cast(keep, ctypes.c_void_p)
+        else:
+            fn_ptr = ctypes.cast(allgather, ctypes.c_void_p) if allgather is not None else None
+        _chk(lib().vx_stark_begin_sharded(ctx._h, ctypes.cast(self.desc_ptr, _vp), t.ctypes.data, 0, pi.ctypes.data if pi.size else None, rank, world,
+                                          fn_ptr, user, chal.ctypes.data, ctypes.byref(sess)))
+        self._keep_cb = keep             # the callback must outlive the session
         return sess, chal[:self.desc.num_aux_challenges].copy(), t
 
     def session_trace_cap(self, sess) -> np.ndarray:

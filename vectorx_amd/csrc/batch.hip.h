@@ -132,8 +132,17 @@ static int batch_hash_tree(vx_ctx* c, vx_batch* b) {
   const size_t N = b->rows(), m = b->ncols;
   {
     ProfScope ps(c, "hash_leaves", (double)m * 8.0 * (double)N);
-    hipLaunchKernelGGL(hash_leaves_colmajor_kernel, dim3((unsigned)((N + HASH_THREADS - 1) / HASH_THREADS)),
-                       dim3(HASH_THREADS), 0, c->stream, b->lde, N, N, (int)m, b->tree, c->prof_on ? c->hash_clk : nullptr);
+    static const size_t coop_max = [] {   // VX_COOP_LEAF_MAX_ROWS: A/B knob (0 = never); default from the measurement in profiles/r04_small_trace_latency.md
+      const char* e = getenv("VX_COOP_LEAF_MAX_ROWS");
+      return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)COOP_COLMAJOR_MAX_ROWS;
+    }();
+    if (N <= coop_max && m > 8) {   // small trace, long sponge: 16 lanes per row
+      hipLaunchKernelGGL(hash_leaves_colmajor_coop_kernel, dim3((unsigned)((N * 16 + HASH_THREADS - 1) / HASH_THREADS)), dim3(HASH_THREADS), 0,
+                         c->stream, b->lde, N, N, (int)m, b->tree);
+    } else {
+      hipLaunchKernelGGL(hash_leaves_colmajor_kernel, dim3((unsigned)((N + HASH_THREADS - 1) / HASH_THREADS)),
+                         dim3(HASH_THREADS), 0, c->stream, b->lde, N, N, (int)m, b->tree, c->prof_on ? c->hash_clk : nullptr);
+    }
     HIPCHK(hipGetLastError());
   }
   VXCHK(build_merkle_levels(c, b->tree, N, b->local_cap_height(), &b->cap_off));

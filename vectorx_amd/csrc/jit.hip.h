@@ -368,6 +368,7 @@ struct AirParams {
   const u64* program;
   size_t stride;
   size_t rows;
+  size_t row_base;
   int log_n, rate_bits, qbits, ncols, nch, npi;
   const u64 *root_lo, *root_hi;
   u64 alphas[VX_MAX_CHALLENGES];

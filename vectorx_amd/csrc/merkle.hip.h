@@ -153,6 +153,31 @@ __global__ __launch_bounds__(HASH_THREADS) void hash_leaves_rowmajor_coop_kernel
   if (live && g < 4) digests[row * 4 + g] = gl_canon(v);
 }
 
+// Column-major leaves (the LDE of a PolynomialBatch) with 16 lanes per row, for SMALL traces (round 4): a 2^11-row x 1030-column STARK
+// table has 4096 LDE rows = 64 wavefronts in the thread-per-row kernel — one wave on 6 % of the SIMDs walking 129 dependent
+// permutations (~4.5 ms whatever the row count); here 4096 rows are 1024 wavefronts and a permutation is ~4 k dependent instructions
+// instead of 13 k.  Lane g < 8 of a row's group loads column c + g (a wave reads 4 consecutive rows of 8 columns: 32 B segments —
+// irrelevant at these sizes).
+#define COOP_COLMAJOR_MAX_ROWS 8192   /* measured (profiles/r04_small_trace_latency.jsonl): 5.0 -> 2.4 - 2.9 ms up to 8192 rows, no gain at 16384, a loss at 32768 */
+__global__ __launch_bounds__(HASH_THREADS) void hash_leaves_colmajor_coop_kernel(
+    const u64* __restrict__ cols, size_t col_stride, size_t nrows, int ncols, u64* __restrict__ digests) {
+  const size_t t = (size_t)blockIdx.x * HASH_THREADS + threadIdx.x;
+  const size_t row = t >> 4;
+  const int g = (int)(t & 15), group_base = (int)(threadIdx.x & 63) & ~15;
+  const bool live = row < nrows;
+  const size_t r = live ? row : 0;
+  u64 v = 0;
+  if (ncols <= 4) {            // hash_or_noop: short leaves are padded, not hashed
+    if (g < ncols) v = cols[(size_t)g * col_stride + r];
+  } else {
+    for (int c = 0; c < ncols; c += 8) {   // overwrite-mode sponge: the rate lanes take the next 8 columns
+      if (g < 8 && c + g < ncols) v = cols[(size_t)(c + g) * col_stride + r];
+      v = poseidon_permute_coop_nc(v, g, group_base);
+    }
+  }
+  if (live && g < 4) digests[row * 4 + g] = gl_canon(v);
+}
+
 __global__ void poseidon_permute_kernel(u64* __restrict__ states, size_t count) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count) return;

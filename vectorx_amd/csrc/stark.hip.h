@@ -26,7 +26,8 @@ struct AirParams {  // mirrored textually in jit.hip.h::jit_air_source
   const u64* aux;    // second-round columns' LDE (same stride) or null; program columns >= ncols address it
   const u64* program;
   size_t stride;
-  size_t rows;  // n << qbits: the first 2^qbits cosets of the LDE = the size-(n * 2^qbits) coset 7 * H'
+  size_t rows;  // n << qbits: the first 2^qbits cosets of the LDE = the size-(n * 2^qbits) coset 7 * H' (sharded: this rank's part of them)
+  size_t row_base;  // global LDE row of local row 0 (a STARK sharded by coset: the rank's first quotient block * n); zh / zh_inv are indexed by LOCAL block
   int log_n, rate_bits, qbits, ncols, nch, npi;
   const u64 *root_lo, *root_hi;
   u64 alphas[VX_MAX_CHALLENGES];
@@ -45,7 +46,7 @@ __global__ __launch_bounds__(256) void air_row_factors_kernel(AirParams p) {
   if (i >= p.rows) return;
   const int LG = p.log_n + p.rate_bits;
   const u32 z = (u32)(i >> p.log_n);
-  const u32 j = bitrev32((u32)i, LG);
+  const u32 j = bitrev32((u32)(i + p.row_base), LG);
   const u64 x = gl_mul7(root_pow24(p.root_lo, p.root_hi, j << (ROOT_TABLE_LOG - LG)));
   const u64 z_last = gl_sub(x, p.last), xm1 = gl_sub(x, 1);
   const u64 inv_both = gl_inv(gl_mul(z_last, xm1));
@@ -60,9 +61,9 @@ __global__ __launch_bounds__(256) void air_quotient_kernel(AirParams p) {
   if (i >= p.rows) return;
   const int LG = p.log_n + p.rate_bits;
   const size_t n = (size_t)1 << p.log_n;
-  const u32 z = (u32)(i >> p.log_n);                       // coset block
+  const u32 z = (u32)(i >> p.log_n);                       // coset block (local)
   const u32 r = (u32)(i & (n - 1));                        // position inside the block (bit-reversed H index)
-  const u32 j = bitrev32((u32)i, LG);                      // natural index of the LDE point
+  const u32 j = bitrev32((u32)(i + p.row_base), LG);       // natural index of the LDE point
   const u64 x = gl_mul7(root_pow24(p.root_lo, p.root_hi, j << (ROOT_TABLE_LOG - LG)));
   const u32 rn = bitrev32((bitrev32(r, p.log_n) + 1) & (u32)(n - 1), p.log_n);   // row of g * x in the same block
   const size_t i_next = ((size_t)z << p.log_n) | rn;
@@ -233,6 +234,7 @@ struct vx_stark_session {
   vx_batch* trace_b = nullptr;
   vxh::Challenger ch;
   bool finished = false;
+  Shard shard;   // vx_stark_begin_sharded: this rank's share of every LDE (whole cosets), exchanges through shard.fn
   ~vx_stark_session() {
     if (c && trace_b) {
       hipSetDevice(c->device);
@@ -241,8 +243,10 @@ struct vx_stark_session {
   }
 };
 
-static int stark_begin_impl(vx_ctx* c, const vx_stark_desc* d_in, const u64* trace_in, bool on_device, const u64* pis, vx_stark_session& s) {
+static int stark_begin_impl(vx_ctx* c, const vx_stark_desc* d_in, const u64* trace_in, bool on_device, const u64* pis, vx_stark_session& s,
+                            const Shard& shard = Shard()) {
   using namespace vxh;
+  s.shard = shard;
   {
     const std::string why = stark_check(d_in, &s.sh);
     if (!why.empty()) return vx_fail(VX_E_INVALID, "%s", why.c_str());
@@ -261,11 +265,11 @@ static int stark_begin_impl(vx_ctx* c, const vx_stark_desc* d_in, const u64* tra
   s.public_inputs.assign(pis, pis + d->num_public_inputs);
   for (auto& v : s.public_inputs) v = canon(v);
   // ---- trace commitment: PolynomialBatch::from_values(trace_poly_values, rate_bits, false, cap_height) ----
-  VXCHK(batch_alloc(c, lg, ncols, rb, d->cap_height, &s.trace_b));
+  VXCHK(batch_alloc(c, lg, ncols, rb, d->cap_height, &s.trace_b, shard.rank, shard.lg));
   if (!on_device) {   // a host trace crosses PCIe behind its own transforms and leaf hashing, like a host witness in vx_prove
     u64* w = S.get((size_t)ncols * n);
     if (!w) return vx_fail(VX_E_NOMEM, "stark: out of device memory (trace)");
-    if (!getenv("VX_NO_UPLOAD_OVERLAP")) {
+    if (!getenv("VX_NO_UPLOAD_OVERLAP") && shard.world == 1) {
       VXCHK(batch_commit_host(c, s.trace_b, trace_in, w, false));
     } else {
       HIPCHK(hipMemcpyAsync(w, trace_in, (size_t)ncols * n * 8, hipMemcpyHostToDevice, c->stream));
@@ -274,8 +278,7 @@ static int stark_begin_impl(vx_ctx* c, const vx_stark_desc* d_in, const u64* tra
   } else {
     VXCHK(batch_commit_device(c, s.trace_b, trace_in, n, false));
   }
-  const Shard one;
-  VXCHK(gather_cap(c, one, S, s.trace_b->tree + s.trace_b->cap_off * 4, s.trace_b->local_cap_words(), s.trace_cap));
+  VXCHK(gather_cap(c, shard, S, s.trace_b->tree + s.trace_b->cap_off * 4, s.trace_b->local_cap_words(), s.trace_cap));
   {
     const std::vector<u64> st = stark_statement(d, s.sh, s.public_inputs.data());
     s.ch.observe_elements(st.data(), st.size());
@@ -315,7 +318,7 @@ static int stark_finish_impl(vx_stark_session& s, const u64* aux_in, bool aux_on
   const std::vector<u64>& public_inputs = s.public_inputs;
   const std::vector<u64>& trace_cap = s.trace_cap;
   Challenger ch = s.ch;  // a copy: a failed call (e.g. an output buffer that is too small) leaves the session where vx_stark_begin left it
-  const Shard one;
+  const Shard& one = s.shard;   // world 1 unless the session was begun sharded
   std::vector<u64> aux_cap, quot_cap;
   if (naux > 0) {
     // ---- the caller's second-round columns: PolynomialBatch::from_values like the trace ----
@@ -326,7 +329,7 @@ static int stark_finish_impl(vx_stark_session& s, const u64* aux_in, bool aux_on
       HIPCHK(hipMemcpyAsync(w, aux_in, (size_t)naux * n * 8, hipMemcpyHostToDevice, c->stream));
       d_aux = w;
     }
-    VXCHK(batch_alloc(c, lg, naux, rb, d->cap_height, &aux_b));
+    VXCHK(batch_alloc(c, lg, naux, rb, d->cap_height, &aux_b, one.rank, one.lg));
     VXCHK(batch_commit_device(c, aux_b, d_aux, n, false));
     VXCHK(gather_cap(c, one, S, aux_b->tree + aux_b->cap_off * 4, aux_b->local_cap_words(), aux_cap));
     ch.observe_elements(aux_cap.data(), cap_words);
@@ -336,11 +339,19 @@ static int stark_finish_impl(vx_stark_session& s, const u64* aux_in, bool aux_on
   for (int i = 0; i < nch; ++i) alphas[i] = ch.get_challenge();
 
   // ---- quotient: constraints on the coset 7 * H' of size n * 2^qbits = the first 2^qbits blocks of the trace LDE ----
+  // Sharded by coset: rank r holds LDE blocks [r zc, (r + 1) zc); the quotient domain is blocks [0, nz).  The first nz / zcq ranks
+  // ("owners", zcq = min(zc, nz) blocks each — the FIRST zcq blocks of their local LDE) evaluate the constraints on their blocks and
+  // run their per-coset inverse transforms; one all-gather of the coefficient blocks ([world][nch][zcq][n], the owners' slots filled)
+  // gives every rank what the cross-coset transform needs.  world = 1: zcq = nz, one owner, no exchange.
   const int qb = sh.qbits, nz = 1 << qb;
-  const size_t rows = n << qb;
+  const int zc = (1 << rb) >> one.lg, zcq = zc < nz ? zc : nz, owners = nz / zcq;
+  const bool own = one.rank < owners;
+  const size_t rows = own ? (size_t)zcq * n : 0;          // local quotient rows
+  const size_t slot = (size_t)nch * zcq * n;               // words per rank in the exchange
+  const size_t Nl = N >> one.lg;                           // local LDE rows = column stride of the local batches
   {
-    u64* qv = S.get((size_t)nch * rows);
-    u64* qu = S.get((size_t)nch * rows);
+    u64* qv = S.get(std::max<size_t>(slot, 1));
+    u64* qu = S.get(slot * one.world);
     u64* d_prog = S.get((size_t)d->program_len);
     if (!qv || !qu || !d_prog) return vx_fail(VX_E_NOMEM, "stark: out of device memory (quotient)");
     HIPCHK(hipMemcpyAsync(d_prog, d->program, (size_t)d->program_len * 8, hipMemcpyHostToDevice, c->stream));
@@ -349,8 +360,9 @@ static int stark_finish_impl(vx_stark_session& s, const u64* aux_in, bool aux_on
     ap.trace = trace_b->lde;
     ap.aux = aux_b ? aux_b->lde : nullptr;
     ap.program = d_prog;
-    ap.stride = N;
+    ap.stride = Nl;
     ap.rows = rows;
+    ap.row_base = (size_t)one.rank * zcq * n;
     ap.log_n = lg, ap.rate_bits = rb, ap.qbits = qb, ap.ncols = ncols, ap.nch = nch, ap.npi = d->num_public_inputs;
     ap.root_lo = c->root_lo, ap.root_hi = c->root_hi;
     for (int i = 0; i < VX_MAX_CHALLENGES; ++i) ap.alphas[i] = alphas[i];
@@ -360,9 +372,10 @@ static int stark_finish_impl(vx_stark_session& s, const u64* aux_in, bool aux_on
     {
       // Z_H(x) on LDE block z: x^n = 7^n * w_{2^rb}^(rev_rb(z))
       const u64 shift_n = pow(7, n), g_rate = root_of_unity(rb);
-      for (int z = 0; z < nz; ++z) {
-        ap.zh[z] = sub(mul(shift_n, pow(g_rate, reverse_bits((size_t)z, rb))), 1);
-        ap.zh_inv[z] = inv(ap.zh[z]);
+      for (int zl = 0; zl < zcq; ++zl) {   // indexed by LOCAL block: global block z = rank * zcq + zl
+        const size_t z = (size_t)one.rank * zcq + zl;
+        ap.zh[zl] = sub(mul(shift_n, pow(g_rate, reverse_bits(z, rb))), 1);
+        ap.zh_inv[zl] = inv(ap.zh[zl]);
       }
     }
     ap.last = inv(root_of_unity(lg));
@@ -374,7 +387,9 @@ static int stark_finish_impl(vx_stark_session& s, const u64* aux_in, bool aux_on
       std::string why;
       const std::vector<JitAirKernel> chunks = jit_air_get(d->program, nch, ncols, c->device, &why);
       ProfScope ps(c, !chunks.empty() ? "air_quotient_eval_jit" : "air_quotient_eval", 8.0 * (double)rows * 2.0 * ncols);
-      if (!chunks.empty()) {
+      if (rows == 0) {
+        // a rank without a block of the quotient domain: nothing to evaluate
+      } else if (!chunks.empty()) {
         u64* rowfac = S.get(3 * rows);
         if (!rowfac) return vx_fail(VX_E_NOMEM, "stark: out of device memory (row factors)");
         ap.rowfac = rowfac;
@@ -393,8 +408,9 @@ static int stark_finish_impl(vx_stark_session& s, const u64* aux_in, bool aux_on
     // coset_ifft(7) on the size-(n * 2^qb) domain = per-coset inverse NTTs + the cross-coset inverse DFT, which yields the
     // quotient_degree_factor chunks of n coefficients directly (same kernels as the plonk quotient, with 2^qb cosets)
     const u64 ninv = inv((u64)n % P);
-    VXCHK(run_ntt(c, qv, qu, rows, rows, n, n, lg, nch, nz, true, true, nullptr, 0, ninv, "quotient_intt", 16.0 * rows * nch));
-    VXCHK(batch_alloc(c, lg, (size_t)nch * sh.qdf, rb, d->cap_height, &quot_b));
+    if (own) VXCHK(run_ntt(c, qv, qu + (size_t)one.rank * slot, rows, rows, n, n, lg, nch, zcq, true, true, nullptr, 0, ninv, "quotient_intt", 16.0 * rows * nch));
+    VXCHK(shard_allgather(c, one, qu, slot * 8, "quotient coset coefficients"));
+    VXCHK(batch_alloc(c, lg, (size_t)nch * sh.qdf, rb, d->cap_height, &quot_b, one.rank, one.lg));
     unsigned* tail_flag = (unsigned*)S.get(1);
     if (!tail_flag) return vx_fail(VX_E_NOMEM, "stark: out of device memory");
     HIPCHK(hipMemsetAsync(tail_flag, 0, 8, c->stream));
@@ -410,7 +426,7 @@ static int stark_finish_impl(vx_stark_session& s, const u64* aux_in, bool aux_on
       cp.u = qu;
       cp.t = quot_b->coeffs;
       cp.inv_tab = tab;
-      cp.log_n = lg, cp.rb = qb, cp.bits = bits, cp.nch = nch, cp.zc = nz;
+      cp.log_n = lg, cp.rb = qb, cp.bits = bits, cp.nch = nch, cp.zc = zcq;
       cp.keep = sh.qdf;  // trim_to_len(degree * quotient_degree_factor): chunks [0, qdf) of the 2^qb the transform yields
       cp.tail_nonzero = tail_flag;
       u64 wr_inv = qb ? inv(root_of_unity(qb)) : 1, pw = 1;
@@ -424,7 +440,7 @@ static int stark_finish_impl(vx_stark_session& s, const u64* aux_in, bool aux_on
         cp.chunk_scale[q] = pw;
         pw = mul(pw, s_inv);
       }
-      ProfScope ps(c, "quotient_chunks", 16.0 * rows * nch);
+      ProfScope ps(c, "quotient_chunks", 16.0 * (double)(n << qb) * nch);
       hipLaunchKernelGGL(quotient_chunks_kernel, dim3((unsigned)((n + 255) / 256), nch), dim3(256), 0, c->stream, cp);
       HIPCHK(hipGetLastError());
     }

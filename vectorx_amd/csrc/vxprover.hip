@@ -824,14 +824,28 @@ int vx_stark_prove(vx_ctx* c, const vx_stark_desc* d, const uint64_t* trace, int
 }
 int vx_stark_begin(vx_ctx* c, const vx_stark_desc* d, const uint64_t* trace, int trace_on_device, const uint64_t* public_inputs,
                    uint64_t* aux_challenges_out, vx_stark_session** out) {
+  return vx_stark_begin_sharded(c, d, trace, trace_on_device, public_inputs, 0, 1, nullptr, nullptr, aux_challenges_out, out);
+}
+int vx_stark_begin_sharded(vx_ctx* c, const vx_stark_desc* d, const uint64_t* trace, int trace_on_device, const uint64_t* public_inputs,
+                           int rank, int world, vx_allgather_fn allgather, void* user, uint64_t* aux_challenges_out, vx_stark_session** out) {
   if (!c || !d || !trace || !out || (d->num_public_inputs > 0 && !public_inputs)) return vx_fail(VX_E_INVALID, "vx_stark_begin: NULL argument");
   *out = nullptr;
+  Shard shard;
+  shard.rank = rank;
+  shard.world = world;
+  while ((1 << shard.lg) < world) ++shard.lg;
+  if (world < 1 || (1 << shard.lg) != world || shard.lg > d->rate_bits || shard.lg > d->cap_height)
+    return vx_fail(VX_E_INVALID, "vx_stark_begin_sharded: world=%d must be a power of two <= 2^rate_bits and <= 2^cap_height", world);
+  if (rank < 0 || rank >= world) return vx_fail(VX_E_INVALID, "vx_stark_begin_sharded: rank %d outside [0, %d)", rank, world);
+  if (world > 1 && !allgather) return vx_fail(VX_E_INVALID, "vx_stark_begin_sharded: world > 1 needs an all-gather callback");
+  shard.fn = allgather;
+  shard.user = user;
   HIPCHK(hipSetDevice(c->device));
   int rc;
   vx_stark_session* s = nullptr;
   try {
     s = new vx_stark_session();
-    rc = stark_begin_impl(c, d, trace, trace_on_device != 0, public_inputs, *s);
+    rc = stark_begin_impl(c, d, trace, trace_on_device != 0, public_inputs, *s, shard);
     if (rc == VX_OK && !s->aux_challenges.empty() && !aux_challenges_out) rc = vx_fail(VX_E_INVALID, "vx_stark_begin: NULL aux_challenges_out");
   } catch (const std::bad_alloc&) {
     rc = vx_fail(VX_E_NOMEM, "vx_stark_begin: out of host memory");

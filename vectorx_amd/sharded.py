@@ -209,3 +209,50 @@ def prove_sharded_threads(circuits, wires, pow_witness=None, timeout_ms=600_000)
     if real or any(errs):
         raise (real or [e for e in errs if e is not None])[0]
     return out
+
+
+def prove_stark_sharded_threads(ctxs, stark, trace, public_inputs, timeout_ms=600_000):
+    """ONE STARK proof over len(ctxs) ranks (one host thread + one vx_ctx each, exchanging through `vx_group`): the coset split of
+    vx_stark_begin_sharded.  Every rank computes the second-round columns itself (caller-side witness generation, replicated).
+    Returns the per-rank proofs (all identical, and identical to `stark.prove`)."""
+    import ctypes
+    import threading
+
+    from . import _chk, lib
+
+    world = len(ctxs)
+    L = lib()
+    g = ctypes.c_void_p()
+    _chk(L.vx_group_create(world, ctypes.byref(g)))
+    _chk(L.vx_group_set_timeout_ms(g, int(timeout_ms)))
+    out, errs = [None] * world, [None] * world
+    try:
+        members = []
+        for r, c in enumerate(ctxs):
+            m = ctypes.c_void_p()
+            _chk(L.vx_group_join(g, r, c._h, ctypes.byref(m)))
+            members.append(m)
+
+        def run(r):
+            sess = None
+            try:
+                sess, chal, t = stark.begin_sharded(ctxs[r], trace, public_inputs, r, world, L.vx_group_allgather, members[r])
+                aux, api = (stark.run_aux(t, chal) if stark.desc.num_aux_columns else (np.zeros((0, 0), dtype=np.uint64), None))
+                out[r] = stark.finish(sess, aux, api)
+            except BaseException as e:
+                errs[r] = e
+                L.vx_group_abort(g)
+            finally:
+                if sess is not None:
+                    L.vx_stark_session_free(sess)
+
+        threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+        for t_ in threads:
+            t_.start()
+        for t_ in threads:
+            t_.join()
+    finally:
+        L.vx_group_destroy(g)
+    if any(errs):
+        raise [e for e in errs if e is not None][0]
+    return out
