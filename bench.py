@@ -66,6 +66,8 @@ def parse():
                     help="N > 1 only: skip the two extra legs after the timed region (one proof sharded over all ranks = BASELINE configs[3]; "
                          "one header_range_512 DAG over all ranks)")
     ap.add_argument("--sharded-leg-steps", type=int, default=3)
+    ap.add_argument("--dag-starks-small", action="store_true",
+                    help="N > 1 legs: the STARK tables of the DAG at the smallest shapes they allow (the single-GPU emulation test)")
     ap.add_argument("--dag-spec", default="64,18,16,19",
                     help="num_map,map_log_n,reduce_log_n,outer_log_n of the multi-rank DAG leg (tests pass tiny sizes)")
     return ap.parse_args()
@@ -236,11 +238,13 @@ def main():
     # (`value`), the strong-scaling point (one 2^21 proof over all N ranks = BASELINE configs[3]) and the real unit of work (one
     # header_range_512 DAG over all N ranks: /root/reference/circuits/builder/subchain_verification.rs:72-78).  Collective:
     # every rank takes part; an error on any rank is reported by rank 0 instead of costing the contract's line.
-    sharded_leg = dag_n_leg = None
+    sharded_leg = dag_n_leg = dag_n_stark_leg = None
     if args.workload == "prove" and world > 1 and not args.no_multi_rank_legs and not args.circuit_flags:
         dev = None if on_host else torch.device("cuda", local_rank)
         sharded_leg = bench_prove.guarded_collective_leg(dist, lambda: bench_prove.sharded_one_proof_leg(ctx, args, rank, world, dist, dev, sync))
         dag_n_leg = bench_prove.guarded_collective_leg(dist, lambda: bench_prove.dag_leg_ranks(ctx, args, local_rank, dist, dev))
+        if not args.no_dag_stark_leg:
+            dag_n_stark_leg = bench_prove.guarded_collective_leg(dist, lambda: bench_prove.dag_leg_ranks(ctx, args, local_rank, dist, dev, with_starks=True))
 
     if rank == 0:
         lde = prof.get("lde", {"ms": 0.0, "calls": 0, "alg_bytes": 0.0})
@@ -341,6 +345,8 @@ def main():
             out["sharded_one_proof"] = sharded_leg
         if dag_n_leg is not None:
             out["dag_header_range_512"] = dag_n_leg
+        if dag_n_stark_leg is not None:
+            out["dag_header_range_512_with_starks"] = dag_n_stark_leg
         if args.ranks_on_one_device:
             out["emulated_ranks_on_one_device"] = ("EVERY RANK IS A PROCESS ON DEVICE 0 over gloo: exercises the N > 1 code path on a single-GPU box; "
                                                    "no figure in this line is a multi-GPU measurement")

@@ -205,7 +205,7 @@ def sharded_one_proof_leg(ctx, args, rank, world, dist, device, sync):
             "what": "one proof coset-sharded over all ranks (vx_prove_sharded), witness HBM-resident on every rank; NOT the contract's timed region"}
 
 
-def dag_leg_ranks(ctx, args, local_rank, dist, device, in_flight=3):
+def dag_leg_ranks(ctx, args, local_rank, dist, device, in_flight=3, with_starks=False):
     """One header_range_512 DAG over ALL ranks (what tools/dag_bench.py does under a launcher): jobs of a layer dealt round-robin,
     `in_flight` proofs in flight per GPU, an all-gather of 32-byte proof digests at every layer barrier.  Runs twice; the FIRST pass
     is the headline (circuits pre-size their pools at load), the second is listed."""
@@ -215,11 +215,16 @@ def dag_leg_ranks(ctx, args, local_rank, dist, device, in_flight=3):
     num_map, lm, lr, lo = (int(x) for x in args.dag_spec.split(","))
     spec = mr.DagSpec(num_map, lm, lr, lo)
     lanes = [vx.Context(local_rank) for _ in range(in_flight - 1)]
-    provers = {}
+    provers, per_kind, tables, split = {}, {}, [], ({} if with_starks else None)
+    if with_starks:
+        # every rank proves map and reduce jobs; the outer job (and its tables) belongs to the rank job 0 of the last layer is dealt to: rank 0
+        kinds = ("map", "reduce", "outer") if dist.get_rank() == 0 else ("map", "reduce")
+        per_kind, tables, _setup = dag_stark_tables(ctx, kinds=kinds, small=bool(getattr(args, "dag_starks_small", False)))
 
     def make(kind, log_n, jobs):
         if kind not in provers:
-            provers[kind] = mr.GpuProver(ctx, kind, log_n, jobs, spec.poseidon_percent, extra_lanes=lanes, distinct_witnesses=4)
+            provers[kind] = mr.GpuProver(ctx, kind, log_n, jobs, spec.poseidon_percent, extra_lanes=lanes, distinct_witnesses=4,
+                                         starks=per_kind.get(kind, ()), split=split)
         return provers[kind]
 
     def sync():
@@ -230,13 +235,18 @@ def dag_leg_ranks(ctx, args, local_rank, dist, device, in_flight=3):
     try:
         runs = []
         for _ in range(2):
+            if split is not None:
+                split.clear()
             r = mr.run_dag(spec, make, dist, sync, in_flight=in_flight)
             r["seconds"] = _max_over_ranks(dist, device, r["seconds"])
+            r["split"] = dict(split or {})
             runs.append(r)
         assert runs[0]["root"] == runs[1]["root"]
     finally:
         for p in provers.values():
             p.free()
+        for t in tables:
+            t.free()
         for l in lanes:
             l.close()
     res = runs[0]
@@ -246,13 +256,16 @@ def dag_leg_ranks(ctx, args, local_rank, dist, device, in_flight=3):
             "dag_seconds_all_passes": [round(r["seconds"], 4) for r in runs],
             "per_layer_ms": [(l["kind"], l["jobs"], round(l["ms"], 1)) for l in res["per_layer"]],
             "setup_seconds_untimed": round(time.perf_counter() - t_setup - sum(r["seconds"] for r in runs), 2), "root": res["root"].hex(),
-            "backend": dist.get_backend(),
-            "what": f"{num_map} map (2^{lm} rows) + {num_map - 1} reduce (2^{lr}) + 1 outer (2^{lo}) plonky2 proofs over all ranks: layer jobs "
-                    "round-robin, digests all-gathered at each layer barrier, synthetic stand-in circuits, witnesses HBM-resident; "
-                    "NOT the contract's timed region"}
+            "backend": dist.get_backend(), "with_stark_tables": bool(with_starks),
+            "rank0_lane_seconds_by_kind": {k: round(v, 4) for k, v in sorted(res["split"].items())} if with_starks else None,
+            "what": f"{num_map} map (2^{lm} rows) + {num_map - 1} reduce (2^{lr}) + 1 outer (2^{lo}) plonky2 proofs over all ranks"
+                    + (", EACH WITH ITS STARK TABLES (dag_stark_tables: BLAKE2b + SHA-256 per map job, SHA-256 per reduce job, SHA-256 / SHA-512 / "
+                       "batched EdDSA for the outer job)" if with_starks else "")
+                    + ": layer jobs round-robin, digests all-gathered at each layer barrier, synthetic stand-in circuits, witnesses and traces "
+                      "HBM-resident; NOT the contract's timed region"}
 
 
-def dag_stark_tables(ctx, eddsa_log_n=20, blake_log_n=18, verbose=False):
+def dag_stark_tables(ctx, eddsa_log_n=20, blake_log_n=18, verbose=False, kinds=("map", "reduce", "outer"), small=False):
     """The STARK tables a header_range_512 job mix proves next to its plonky2 proofs — own AIRs standing in for Curta's chips, sized
     from the reference's constants: a MAP job hashes 8 headers of up to MAX_HEADER_SIZE = 35 840 bytes = 280 BLAKE2b blocks each
     (/root/reference/circuits/consts.rs:6-16, builder/header.rs:18) = 2240 compressions = one 2^18-row BLAKE2b table, and two 8-leaf
@@ -264,6 +277,10 @@ def dag_stark_tables(ctx, eddsa_log_n=20, blake_log_n=18, verbose=False):
     from vectorx_amd import blake2b_air, blake2b_bytes_air, eddsa_air, sha256_air, sha512_air, stark_chips
     rec, tables = {}, []
     nopi = np.zeros(0, dtype=np.uint64)
+    # small = True (the single-GPU emulation test of the N-rank path): the smallest shapes the tables allow, same code path
+    nkeys, nhdr_blocks = (8, 4) if small else (300, 280)
+    if small:
+        eddsa_log_n = 17
 
     def resident(label, stark, trace, pis):
         t0 = time.perf_counter()
@@ -287,27 +304,36 @@ def dag_stark_tables(ctx, eddsa_log_n=20, blake_log_n=18, verbose=False):
     # table (1063 + 12 columns, 106 rows per compression, 2^18 rows) with VX_DAG_BLAKE2B_BITS=1, for comparison
     import os
     if os.environ.get("VX_DAG_BLAKE2B_BITS"):
-        blake = hash_table("blake2b_map", blake2b_air, blake_log_n, [bytes([17 * i & 255]) * 35840 for i in range(8)])
-    else:
-        blake = hash_table("blake2b_map", blake2b_bytes_air, 17, [bytes([17 * i & 255]) * 35840 for i in range(8)])
-    sha_map = hash_table("sha256_map", sha256_air, 11, [bytes([i]) * 64 for i in range(14)])
-    sha_red = hash_table("sha256_reduce", sha256_air, 9, [bytes([i + 50]) * 64 for i in range(2)])
-    sha_out = hash_table("sha256_outer", sha256_air, 16, [bytes([i & 255, i >> 8]) * 32 for i in range(300)])
-    s512 = hash_table("sha512_outer", sha512_air, 16, [bytes([i & 255, i >> 8]) * 58 + b"x" for i in range(300)])
-    t0 = time.perf_counter()
-    lay = eddsa_air.Layout()
-    cap = eddsa_air.capacity(lay, eddsa_log_n)
-    sigs, rs = stark_chips.eddsa_signatures(cap, 8)
-    trace, res = eddsa_air.generate_trace(lay, eddsa_log_n, sigs)
-    assert res == rs
-    stark = eddsa_air.make_stark(lay, eddsa_log_n)
-    ntab = -(-300 // cap)
-    rec["eddsa_outer"] = {"rows_log2": eddsa_log_n, "columns": f"{stark.desc.num_columns} + {stark.desc.num_aux_columns}", "signatures_per_table": cap,
-                          "tables": ntab, "trace_generation_s": round(time.perf_counter() - t0, 2)}
-    ed = resident("eddsa_outer", stark, trace, nopi)
-    del trace
-    per_kind = {"map": [("blake2b", blake), ("sha256", sha_map)], "reduce": [("sha256", sha_red)],
-                "outer": [("sha256", sha_out), ("sha512", s512), ("eddsa", stark_chips.Repeated(ed, ntab))]}
+        per_kind = {}
+    if "map" in kinds:
+        # round 4: the byte / XOR-lookup table (641 + 188 columns, 34 rows per compression: 2240 compressions fit 2^17 rows); round 3's bit
+        # table (1063 + 12 columns, 106 rows per compression, 2^18 rows) with VX_DAG_BLAKE2B_BITS=1, for comparison
+        import os
+        if os.environ.get("VX_DAG_BLAKE2B_BITS"):
+            blake = hash_table("blake2b_map", blake2b_air, blake_log_n, [bytes([17 * i & 255]) * (128 * nhdr_blocks) for i in range(8)])
+        else:
+            blake = hash_table("blake2b_map", blake2b_bytes_air, 17, [bytes([17 * i & 255]) * (128 * nhdr_blocks) for i in range(8)])
+        sha_map = hash_table("sha256_map", sha256_air, 11, [bytes([i]) * 64 for i in range(14)])
+        per_kind["map"] = [("blake2b", blake), ("sha256", sha_map)]
+    if "reduce" in kinds:
+        sha_red = hash_table("sha256_reduce", sha256_air, 9, [bytes([i + 50]) * 64 for i in range(2)])
+        per_kind["reduce"] = [("sha256", sha_red)]
+    if "outer" in kinds:
+        sha_out = hash_table("sha256_outer", sha256_air, 11 if small else 16, [bytes([i & 255, i >> 8]) * 32 for i in range(nkeys)])
+        s512 = hash_table("sha512_outer", sha512_air, 11 if small else 16, [bytes([i & 255, i >> 8]) * 58 + b"x" for i in range(nkeys)])
+        t0 = time.perf_counter()
+        lay = eddsa_air.Layout()
+        cap = eddsa_air.capacity(lay, eddsa_log_n)
+        sigs, rs = stark_chips.eddsa_signatures(cap, 8 if not small else 2)
+        trace, res = eddsa_air.generate_trace(lay, eddsa_log_n, sigs)
+        assert res == rs
+        stark = eddsa_air.make_stark(lay, eddsa_log_n)
+        ntab = -(-nkeys // cap)
+        rec["eddsa_outer"] = {"rows_log2": eddsa_log_n, "columns": f"{stark.desc.num_columns} + {stark.desc.num_aux_columns}", "signatures_per_table": cap,
+                              "tables": ntab, "trace_generation_s": round(time.perf_counter() - t0, 2)}
+        ed = resident("eddsa_outer", stark, trace, nopi)
+        del trace
+        per_kind["outer"] = [("sha256", sha_out), ("sha512", s512), ("eddsa", stark_chips.Repeated(ed, ntab))]
     return per_kind, tables, rec
 
 

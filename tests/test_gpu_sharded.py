@@ -316,7 +316,7 @@ def _plain_bench(*extra):
 def test_bench_gpus_2_run_plainly_launches_two_ranks(mode):
     """the driver's command form is `python3 bench.py --gpus N ...`: it must BE an N-rank run (VERDICT r2 #1)"""
     _need_devices(2)
-    r = _plain_bench("--gpus", "2", "--mode", mode, "--dag-spec", "8,14,12,15")
+    r = _plain_bench("--gpus", "2", "--mode", mode, "--dag-spec", "8,14,12,15", "--dag-starks-small")
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
@@ -354,7 +354,8 @@ def test_bench_multi_rank_code_path_on_one_device(world):
     """`python bench.py --gpus N` exactly as the driver runs it, but with the N ranks as processes on DEVICE 0 over gloo (RCCL refuses
     duplicate devices): the weak-scaling line + the sharded-one-proof leg + the N-rank DAG leg, tiny sizes.  The single-GPU boxes
     run this every round, so the code the 8-GPU driver run takes has been executed before it gets there."""
-    r = _plain_bench("--gpus", str(world), "--ranks-on-one-device", "--log-n", "12", "--dag-spec", "4,10,9,11", "--sharded-leg-steps", "2")
+    r = _plain_bench("--gpus", str(world), "--ranks-on-one-device", "--log-n", "12", "--dag-spec", "4,10,9,11", "--sharded-leg-steps", "2",
+                     *(["--dag-starks-small"] if world == 2 else ["--no-dag-stark-leg"]))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
@@ -364,6 +365,12 @@ def test_bench_multi_rank_code_path_on_one_device(world):
     assert [d["rank"] for d in line["rank_devices"]] == list(range(world))
     _check_multi_rank_legs(line, world, "gloo")
     assert line["dag_header_range_512"]["plonky2_proofs"] == 4 + 3 + 1
+    if world == 2:      # the same DAG with every job's STARK tables (smallest shapes), over both ranks
+        ds = line["dag_header_range_512_with_starks"]
+        assert "error" not in ds, ds
+        assert ds["with_stark_tables"] is True and ds["ranks"] == 2 and ds["dag_seconds"] > 0
+        assert set(ds["rank0_lane_seconds_by_kind"]) >= {"plonky2", "blake2b", "sha256", "sha512", "eddsa"}
+        assert ds["root"] != line["dag_header_range_512"]["root"]          # the STARK proofs are part of every job's digest
 
 
 def test_bench_refuses_more_gpus_than_visible():

@@ -29,7 +29,7 @@ ctx = vx.Context(0)
 t_end = time.time() + budget
 n_ok, n_bad, by_kind = 0, 0, {}
 while time.time() < t_end:
-    kind = str(rng.choice(["fibonacci", "cubic", "mulchain", "logup", "logup", "sha256", "blake2b", "ed25519"]))
+    kind = str(rng.choice(["fibonacci", "cubic", "mulchain", "logup", "logup", "sha256", "blake2b", "ed25519", "eddsa"]))
     lg = int(rng.integers(5 if kind == "logup" else 3, db_max + 1))
     if kind == "sha256":
         lg = int(rng.integers(7, min(db_max, 10) + 1))
@@ -40,7 +40,9 @@ while time.time() < t_end:
                num_challenges=int(rng.choice([1, 2])), cap_height=int(rng.integers(0, min(4, lg + rate_bits) + 1)))
     if kind == "ed25519":
         lg = int(rng.integers(10, 12))
-    if kind in ("sha256", "blake2b", "ed25519"):      # one compiled program shape (2 challenges); the rest of the configuration varies
+    if kind == "eddsa":
+        lg = 12
+    if kind in ("sha256", "blake2b", "ed25519", "eddsa"):      # one compiled program shape (2 challenges); the rest of the configuration varies
         cfg["num_challenges"] = 2
         cfg["rate_bits"] = rate_bits = int(rng.choice([1, 2]))
     if rng.random() < 0.3:
@@ -65,6 +67,14 @@ while time.time() < t_end:
     elif kind == "ed25519":
         stark = ed25519_air.make_stark(lg, **cfg)
         trace, pis, _ = ed25519_air.generate_trace(lg, int(rng.integers(0, 1 << 32)) | (int(rng.integers(0, 1 << 32)) << 32 if lg == 11 else 0))
+    elif kind == "eddsa":     # round 4: the batched signature table (byte limbs, 32-bit scalars: 3 instances fit 2^12 rows)
+        from vectorx_amd import eddsa_air
+        lay = eddsa_air.Layout(8, 32)
+        sigs = [(eddsa_air.affine_scalar_mult(int(rng.integers(1, 1 << 62))), int(rng.integers(0, 1 << 32)), int(rng.integers(0, 1 << 32)))
+                for _ in range(int(rng.integers(1, 4)))]
+        stark = eddsa_air.make_stark(lay, lg, **cfg)
+        trace, _res = eddsa_air.generate_trace(lay, lg, sigs)
+        pis = np.zeros(0, dtype=np.uint64)
     elif kind == "blake2b":
         msgs = [bytes(rng.integers(0, 256, size=int(rng.integers(0, 300)), dtype=np.uint8)) for _ in range(6)]
         stark = blake2b_air.make_stark(lg, **cfg)
