@@ -361,6 +361,27 @@ typedef int (*vx_allgather_fn)(void* user, void* dev_buf, size_t bytes_per_rank)
 int vx_stark_begin_sharded(vx_ctx* ctx, const vx_stark_desc* desc, const uint64_t* trace, int trace_on_device, const uint64_t* public_inputs,
                            int rank, int world, vx_allgather_fn allgather, void* user, uint64_t* aux_challenges_out, vx_stark_session** out);
 void vx_stark_session_free(vx_stark_session* session);
+/* The second-round columns ON THE DEVICE (round 4; vectorx_amd/csrc/aux.hip.h).  Lookup / bus columns have one shape everywhere:
+ * FRACTIONS num(row) / den(row) of small expressions of the row's trace values and the challenges — a log-derivative helper
+ * 1/(g - x) + 1/(g - y) = ((g - x) + (g - y)) / ((g - x)(g - y)), a table term mult / (g - t), a bus term flag / (g - tuple) — and RUNNING
+ * SUMS over the rows of signed combinations of them.  The expressions arrive as one more program: VX_OP_LDW = the row's trace value,
+ * VX_OP_LDCH = challenge, LDI / ADD / SUB / MUL; the 2 k-th and (2 k + 1)-th VX_OP_PUSH give numerator and denominator of fraction k
+ * (a zero denominator yields 0).  Running sum j holds, on row i, the sum over rows 0 .. i-1 of  sum_k sum_coeffs[j][k] * fraction_k(row)
+ * (coefficients in {-1, 0, +1}); its value on the LAST row comes back in closing_sums_out[j] (what a bus announces as its closing sum).
+ * `trace_dev` = [num_columns][2^degree_bits] device memory, natural row order (the buffer vx_stark_begin was given); `out_dev` =
+ * [num_fractions + num_sums][2^degree_bits] device memory: fraction k lands in column fraction_out[k], sum j in sum_out[j] (NULL: fractions
+ * first, then sums) — hand it to vx_stark_finish2 with aux_on_device = 1.  An AIR whose second round is repeated per challenge set
+ * calls this once per set with that set's challenges and an output pointer offset by the set's columns. */
+typedef struct vx_aux_desc {
+  int32_t num_columns, num_challenges, num_fractions, num_sums;
+  int32_t program_len;
+  const uint64_t* program;
+  const int8_t* sum_coeffs;        /* [num_sums][num_fractions] */
+  const int32_t* fraction_out;     /* [num_fractions] or NULL */
+  const int32_t* sum_out;          /* [num_sums] or NULL */
+} vx_aux_desc;
+int vx_stark_aux_columns(vx_ctx* ctx, const vx_aux_desc* desc, const uint64_t* trace_dev, int degree_bits, const uint64_t* challenges,
+                         uint64_t* out_dev, uint64_t* closing_sums_out);
 int vx_stark_verify(const vx_stark_desc* desc, const uint64_t* public_inputs, const uint8_t* proof, size_t proof_len);
 /* The same for the constraint-program gates of a circuit (one kernel per program gate): returns the number compiled now. */
 int vx_circuit_precompile(const vx_circuit_desc* desc, int* num_program_gates_out);

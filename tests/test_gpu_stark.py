@@ -437,3 +437,50 @@ def test_blake2b_bytes_table_bytes_identical_to_oracle(ctx, oracle):
     bad[len(bad) // 3] ^= 1
     with pytest.raises(vx.VxError):
         stark.verify(pis, bytes(bad))
+
+
+def test_second_round_columns_on_the_gpu_equal_the_host_ones(ctx):
+    """vx_stark_aux_columns (round 4): the fractions + running sums of a table's second round computed on the device from the resident
+    trace — bit-identical to the numpy generators (every column of both challenge sets, and the closing sums) for the batched EdDSA
+    table (pair helpers, table term, bus term; two running sums) and the byte BLAKE2b table (184 triples with beta, one sum)."""
+    from vectorx_amd import blake2b_bytes_air as b2
+    from vectorx_amd import eddsa_air as ea
+    lay = ea.Layout(8, 32)
+    st = ea.make_stark(lay, 12)
+    t, _ = ea.generate_trace(lay, 12, [((ea.BX, ea.BY), 0xC0FFEE, 0xBADF00D), ((ea.BX, ea.BY), 5, 7)])
+    cases = [(st, t)]
+    st2 = b2.make_stark(17)
+    t2, _, _ = b2.generate_trace(17, [b"abc", bytes(range(200))])
+    cases.append((st2, t2))
+    rng = np.random.default_rng(7)
+    for stark, trace in cases:
+        chal = rng.integers(1, P, size=stark.desc.num_aux_challenges, dtype=np.uint64)
+        want, want_api = stark.run_aux(trace, chal)
+        d_t = ctx.alloc(trace.nbytes)
+        ctx.upload(d_t, np.ascontiguousarray(trace))
+        d_a = ctx.alloc(want.nbytes)
+        api = stark.run_aux_gpu(ctx, d_t, chal, d_a)
+        got = ctx.download(d_a, want.nbytes).view(np.uint64).reshape(want.shape)
+        assert (got == want).all(), np.nonzero((got != want).any(axis=1))[0][:8]
+        assert [int(x) for x in api] == [int(x) for x in want_api]
+        ctx.free(d_t)
+        ctx.free(d_a)
+
+
+def test_aux_program_descriptions_are_checked(ctx):
+    import ctypes
+    from vectorx_amd import eddsa_air as ea
+    ap = ea.aux_program(ea.Layout(8, 32))
+    L = vx.lib()
+    d_t = ctx.alloc(8 * 16 * 900)
+    d_o = ctx.alloc(8 * 16 * 100)
+    closing = np.zeros(4, dtype=np.uint64)
+    chal = np.ones(3, dtype=np.uint64)
+    for field, value in (("num_fractions", ap.desc.num_fractions + 1), ("num_columns", 5), ("num_challenges", 1), ("num_sums", 65), ("program_len", 3)):
+        old = getattr(ap.desc, field)
+        setattr(ap.desc, field, value)
+        rc = L.vx_stark_aux_columns(ctx._h, ctypes.byref(ap.desc), ctypes.c_void_p(d_t), 4, chal.ctypes.data, ctypes.c_void_p(d_o), closing.ctypes.data)
+        assert rc == vx.VX_E_INVALID, field
+        setattr(ap.desc, field, old)
+    ctx.free(d_t)
+    ctx.free(d_o)

@@ -111,6 +111,7 @@ _SIGNATURES = {
     "vx_stark_finish": (_i, [_vp, _vp, _i, _vp, _vp, ctypes.POINTER(_sz)]),
     "vx_stark_begin_sharded": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, ctypes.POINTER(_vp)]),
     "vx_stark_session_free": (None, [_vp]),
+    "vx_stark_aux_columns": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "vx_stark_precompile": (_i, [_vp, ctypes.POINTER(_i)]),
     "vx_circuit_precompile": (_i, [_vp, ctypes.POINTER(_i)]),
     "vx_stark_session_trace_cap": (_i, [_vp, _vp]),
@@ -526,6 +527,7 @@ class Stark:
                               constraint_degree, len(program), ctypes.cast(self._prog, ctypes.c_void_p).value, 0, 0, None,
                               num_aux_columns * self.aux_reps, num_aux_challenges * self.aux_reps, num_aux_public_inputs * self.aux_reps)
         self.aux_fn = aux_fn
+        self.aux_program = None          # an AuxProgram (one challenge set): the GPU form of aux_fn, set by the table's make_stark
         if fri_arities is not None:
             self._ar = (ctypes.c_int32 * max(1, len(fri_arities)))(*fri_arities)
             self.desc.override_flags = 2
@@ -540,6 +542,20 @@ class Stark:
         if rc < 0:
             _chk(rc)
         return rc, n.value
+
+    def run_aux_gpu(self, ctx, d_trace: int, challenges, d_aux: int) -> np.ndarray:
+        """the second-round columns of every challenge set computed ON THE GPU (`self.aux_program`: an AuxProgram for one set) into the
+        device buffer `d_aux` ([num_aux_columns][n]); -> the aux public inputs (closing sums), set-major like `run_aux`"""
+        ap = self.aux_program
+        naux, nch, _ = self.per_set
+        n = 1 << self.desc.degree_bits
+        if ap.num_out != naux:
+            raise VxError(VX_E_INVALID, f"the aux program writes {ap.num_out} columns, the table has {naux} per challenge set")
+        api = []
+        for r in range(self.aux_reps):
+            closing = ap.run(ctx, d_trace, self.desc.degree_bits, challenges[r * nch:(r + 1) * nch], d_aux + r * naux * n * 8)
+            api.extend(int(closing[j]) for j in ap.api_sums)
+        return np.array(api, dtype=np.uint64)
 
     def run_aux(self, trace, challenges):
         """-> (aux columns [num_aux_columns][n] uint64, aux public inputs [num_aux_public_inputs] uint64)"""
@@ -647,6 +663,39 @@ class Stark:
         buf = np.frombuffer(proof, dtype=np.uint8)
         _chk(lib().vx_stark_proof_trace_cap(ctypes.cast(self.desc_ptr, _vp), buf.ctypes.data, buf.size, cap.ctypes.data))
         return cap
+
+
+class AuxDesc(ctypes.Structure):
+    """ctypes mirror of `vx_aux_desc` (include/vxprover.h)"""
+    _fields_ = [("num_columns", ctypes.c_int32), ("num_challenges", ctypes.c_int32), ("num_fractions", ctypes.c_int32), ("num_sums", ctypes.c_int32),
+                ("program_len", ctypes.c_int32), ("program", ctypes.c_void_p), ("sum_coeffs", ctypes.c_void_p), ("fraction_out", ctypes.c_void_p),
+                ("sum_out", ctypes.c_void_p)]
+
+
+class AuxProgram:
+    """The second-round columns of ONE challenge set as fractions + running sums (`vx_stark_aux_columns`): computed on the GPU from the
+    device-resident trace.  `api_sums`: which running sums' closing values are the table's aux public inputs, in order."""
+
+    def __init__(self, num_columns, num_challenges, program, num_fractions, sum_coeffs, fraction_out=None, sum_out=None, api_sums=()):
+        self._prog = (ctypes.c_uint64 * len(program))(*program)
+        co = np.ascontiguousarray(np.array(sum_coeffs, dtype=np.int8).reshape(len(sum_coeffs), num_fractions))
+        self._co = co
+        self._fo = None if fraction_out is None else np.ascontiguousarray(fraction_out, dtype=np.int32)
+        self._so = None if sum_out is None else np.ascontiguousarray(sum_out, dtype=np.int32)
+        self.num_out = num_fractions + co.shape[0]
+        self.num_sums = co.shape[0]
+        self.api_sums = tuple(api_sums)
+        self.desc = AuxDesc(num_columns, num_challenges, num_fractions, co.shape[0], len(program), ctypes.cast(self._prog, ctypes.c_void_p).value,
+                            co.ctypes.data if co.size else None, None if self._fo is None else self._fo.ctypes.data,
+                            None if self._so is None else self._so.ctypes.data)
+
+    def run(self, ctx, d_trace: int, degree_bits: int, challenges, d_out: int) -> np.ndarray:
+        """-> the closing sums of the running sums (all of them); the columns are written to device memory at `d_out`"""
+        ch = np.ascontiguousarray(challenges, dtype=np.uint64)
+        closing = np.zeros(max(1, self.num_sums), dtype=np.uint64)
+        _chk(lib().vx_stark_aux_columns(ctx._h, ctypes.byref(self.desc), _vp(d_trace), degree_bits, ch.ctypes.data if ch.size else None, _vp(d_out),
+                                        closing.ctypes.data))
+        return closing[:self.num_sums]
 
 
 def stark_verify_bus(tables, proofs) -> np.ndarray:

@@ -731,11 +731,52 @@ def aux_columns(trace, chal):
     return out
 
 
+def aux_program():
+    """the GPU form of `aux_columns` (vx_stark_aux_columns): 92 pair helpers + the table term as fractions, one running sum that closes at 0"""
+    from . import AuxProgram
+    C = Cols
+    e = _Emit(scratch=40)
+    GAMMA, BETA, BETA2 = 63, 62, 61
+    e.ins(VX_OP_LDCH, GAMMA, 0)
+    e.ins(VX_OP_LDCH, BETA, 1)
+    e.op(VX_OP_MUL, BETA, BETA, BETA2)
+
+    def gamma_minus(tp, dst):
+        a, b, c = tp
+        m = e.top
+        t = e.op(VX_OP_MUL, e.ldw(c), BETA2)
+        if b is not None:
+            e.op(VX_OP_ADD, t, e.op(VX_OP_MUL, e.ldw(b), BETA), t)
+        e.op(VX_OP_ADD, t, e.ldw(a), t)
+        e.op(VX_OP_SUB, GAMMA, t, dst)
+        e.release(m)
+
+    tps = tuples()
+    for q in range(C.NPAIR):
+        m0 = e.top
+        g0, g1 = e.tmp(), e.tmp()
+        gamma_minus(tps[2 * q], g0)
+        gamma_minus(tps[2 * q + 1], g1)
+        e.push(e.op(VX_OP_ADD, g0, g1), 0)
+        e.push(e.op(VX_OP_MUL, g0, g1), 0)
+        e.release(m0)
+    m0 = e.top
+    gt = e.tmp()
+    gamma_minus((C.TA, C.TBB, C.TC), gt)
+    e.push(e.ldw(C.MULT), 0)
+    e.push(gt, 0)
+    e.release(m0)
+    e.ins(VX_OP_END)
+    return AuxProgram(C.N, 2, e.w, C.NPAIR + 1, [[1] * C.NPAIR + [-1]], api_sums=())
+
+
 def make_stark(degree_bits: int, **cfg) -> Stark:
     assert degree_bits >= 17
     prog, _ = build_program()
     cfg.setdefault("rate_bits", 1)
-    return Stark(degree_bits, Cols.N, 8, prog, constraint_degree=3, num_aux_columns=Cols.NAUX, num_aux_challenges=2, aux_fn=aux_columns, **cfg)
+    st = Stark(degree_bits, Cols.N, 8, prog, constraint_degree=3, num_aux_columns=Cols.NAUX, num_aux_challenges=2, aux_fn=aux_columns, **cfg)
+    st.aux_program = aux_program()
+    return st
 
 
 def reference_digests(messages):

@@ -11,6 +11,7 @@
 #include "prover.hip.h"
 #include "circuit_io.h"
 #include "stark.hip.h"
+#include "aux.hip.h"
 #include <memory>
 #include <cstddef>
 #include "verifier.h"
@@ -960,6 +961,100 @@ int vx_stark_finish2(vx_stark_session* s, const uint64_t* aux_columns, int aux_o
   return VX_OK;
 }
 void vx_stark_session_free(vx_stark_session* s) { delete s; }
+// The caller's second-round columns computed on the device (aux.hip.h): fractions num / den of per-row expressions + running sums.
+int vx_stark_aux_columns(vx_ctx* c, const vx_aux_desc* d, const uint64_t* trace_dev, int degree_bits, const uint64_t* challenges,
+                         uint64_t* out_dev, uint64_t* closing_sums_out) {
+  if (!c || !d || !trace_dev || !out_dev || !d->program) return vx_fail(VX_E_INVALID, "vx_stark_aux_columns: NULL argument");
+  if (degree_bits < 1 || degree_bits > ROOT_TABLE_LOG) return vx_fail(VX_E_INVALID, "vx_stark_aux_columns: degree_bits out of range");
+  if (d->num_columns < 1 || d->num_columns > 8192 || d->num_challenges < 0 || d->num_challenges > VX_AUX_MAX_CHALLENGES || d->num_fractions < 1 ||
+      d->num_fractions > 4096 || d->num_sums < 0 || d->num_sums > 64 || d->program_len < 1 || d->program_len > (1 << 22))
+    return vx_fail(VX_E_INVALID, "vx_stark_aux_columns: description out of range");
+  if (d->num_challenges > 0 && !challenges) return vx_fail(VX_E_INVALID, "vx_stark_aux_columns: NULL challenges");
+  if (d->num_sums > 0 && (!d->sum_coeffs || !closing_sums_out)) return vx_fail(VX_E_INVALID, "vx_stark_aux_columns: running sums need coefficients and a closing-sum buffer");
+  try {
+    const int nf = d->num_fractions, ns = d->num_sums, nout = nf + ns;
+    // the program: straight-line, reads only what the description declares, pushes numerator / denominator pairs
+    int pushes = 0;
+    bool ended = false;
+    for (int pc = 0; pc < d->program_len; ++pc) {
+      const uint64_t ins = d->program[pc];
+      const int op = (int)(ins & 0xFF), a = (int)((ins >> 16) & 0xFFFF);
+      if (op == VX_OP_END) {
+        ended = true;
+        break;
+      }
+      if (op == VX_OP_LDI) {
+        if (++pc >= d->program_len) return vx_fail(VX_E_INVALID, "vx_stark_aux_columns: LDI without its immediate");
+      } else if (op == VX_OP_LDW) {
+        if (a >= d->num_columns) return vx_fail(VX_E_INVALID, "vx_stark_aux_columns: the program reads column %d of %d", a, d->num_columns);
+      } else if (op == VX_OP_LDCH) {
+        if (a >= d->num_challenges) return vx_fail(VX_E_INVALID, "vx_stark_aux_columns: the program reads challenge %d of %d", a, d->num_challenges);
+      } else if (op == VX_OP_PUSH) {
+        ++pushes;
+      } else if (op != VX_OP_ADD && op != VX_OP_SUB && op != VX_OP_MUL) {
+        return vx_fail(VX_E_INVALID, "vx_stark_aux_columns: instruction %d is not allowed in an aux program", op);
+      }
+    }
+    if (!ended || pushes != 2 * nf) return vx_fail(VX_E_INVALID, "vx_stark_aux_columns: the program must END and push %d (numerator, denominator) pairs, it pushes %d values", nf, pushes);
+    std::vector<int> fo(nf), so(ns);
+    std::vector<char> used((size_t)nout, 0);
+    for (int k = 0; k < nf; ++k) fo[k] = d->fraction_out ? d->fraction_out[k] : k;
+    for (int j = 0; j < ns; ++j) so[j] = d->sum_out ? d->sum_out[j] : nf + j;
+    for (int v : fo)
+      if (v < 0 || v >= nout || used[v]++) return vx_fail(VX_E_INVALID, "vx_stark_aux_columns: output columns must be a permutation of 0 .. %d", nout - 1);
+    for (int v : so)
+      if (v < 0 || v >= nout || used[v]++) return vx_fail(VX_E_INVALID, "vx_stark_aux_columns: output columns must be a permutation of 0 .. %d", nout - 1);
+    for (int j = 0; j < ns; ++j)
+      for (int k = 0; k < nf; ++k)
+        if (d->sum_coeffs[(size_t)j * nf + k] < -1 || d->sum_coeffs[(size_t)j * nf + k] > 1) return vx_fail(VX_E_INVALID, "vx_stark_aux_columns: sum coefficients are -1, 0 or +1");
+    HIPCHK(hipSetDevice(c->device));
+    const size_t n = (size_t)1 << degree_bits;
+    Scratch S(c);
+    const size_t nblocks = (n + (size_t)VX_AUX_SCAN_THREADS * VX_AUX_SCAN_RUN - 1) / ((size_t)VX_AUX_SCAN_THREADS * VX_AUX_SCAN_RUN);
+    u64* d_prog = S.get((size_t)d->program_len);
+    int* d_fo = (int*)S.get((size_t)(nf + 1) / 2 + 1);
+    int* d_so = (int*)S.get((size_t)(ns + 1) / 2 + 1);
+    signed char* d_co = (signed char*)S.get(((size_t)ns * nf + 7) / 8 + 1);
+    u64* totals = S.get(nblocks + 1);
+    if (!d_prog || !d_fo || !d_so || !d_co || !totals) return vx_fail(VX_E_NOMEM, "vx_stark_aux_columns: out of device memory");
+    HIPCHK(hipMemcpyAsync(d_prog, d->program, (size_t)d->program_len * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(d_fo, fo.data(), (size_t)nf * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    if (ns) {
+      HIPCHK(hipMemcpyAsync(d_so, so.data(), (size_t)ns * sizeof(int), hipMemcpyHostToDevice, c->stream));
+      HIPCHK(hipMemcpyAsync(d_co, d->sum_coeffs, (size_t)ns * nf, hipMemcpyHostToDevice, c->stream));
+    }
+    {
+      ProfScope ps(c, "aux_fractions", 8.0 * (double)n * (double)nf);
+      AuxFracParams fp;
+      memset(&fp, 0, sizeof fp);
+      fp.trace = trace_dev, fp.program = d_prog, fp.frac_out = d_fo, fp.out = out_dev, fp.n = n, fp.ncols = d->num_columns, fp.nfrac = nf;
+      for (int i = 0; i < d->num_challenges; ++i) fp.chal[i] = vxh::canon(challenges[i]);
+      hipLaunchKernelGGL(aux_fraction_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, fp);
+      HIPCHK(hipGetLastError());
+    }
+    if (ns) {
+      ProfScope ps(c, "aux_running_sums", 16.0 * (double)n * (double)ns);
+      AuxSumParams sp;
+      memset(&sp, 0, sizeof sp);
+      sp.out = out_dev, sp.frac_out = d_fo, sp.sum_out = d_so, sp.coeff = d_co, sp.n = n, sp.nfrac = nf, sp.nsum = ns;
+      hipLaunchKernelGGL(aux_rowsum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, sp);
+      for (int j = 0; j < ns; ++j) {
+        u64* col = out_dev + (size_t)so[j] * n;
+        hipLaunchKernelGGL(aux_scan_blocks_kernel, dim3((unsigned)nblocks), dim3(VX_AUX_SCAN_THREADS), 0, c->stream, col, n, totals);
+        hipLaunchKernelGGL(aux_scan_totals_kernel, dim3(1), dim3(VX_AUX_SCAN_THREADS), 0, c->stream, totals, nblocks, totals + nblocks);
+        hipLaunchKernelGGL(aux_scan_offsets_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, col, n, totals);
+        HIPCHK(hipMemcpyAsync(&closing_sums_out[j], col + (n - 1), 8, hipMemcpyDeviceToHost, c->stream));   // exclusive prefix on the last row = the sum over rows 0 .. n-2
+      }
+      HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return VX_OK;
+  } catch (const std::bad_alloc&) {
+    return vx_fail(VX_E_NOMEM, "vx_stark_aux_columns: out of host memory");
+  } catch (const std::exception& e) {
+    return vx_fail(VX_E_INVALID, "vx_stark_aux_columns: %s", e.what());
+  }
+}
 int vx_stark_verify(const vx_stark_desc* d, const uint64_t* public_inputs, const uint8_t* proof, size_t proof_len) {
   // A table that announces closing sums is only proven once somebody has looked at them.  This entry point has no argument for
   // them, so it takes the one meaning a lone table can have: every sum is zero (what it sent it received itself).  Tables whose

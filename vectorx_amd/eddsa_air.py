@@ -774,12 +774,55 @@ def aux_columns(lay: Layout, trace, chal):
     return out, np.array([closing], dtype=np.uint64)
 
 
+def aux_program(lay: Layout):
+    """the GPU form of `aux_columns` (vx_stark_aux_columns): the pair helpers, the table term and the bus term as fractions, the two running
+    sums; challenges [gamma, beta, gamma_bus] of one set; the bus sum's closing value is the set's aux public input"""
+    from . import AuxProgram
+    e = _Emit(scratch=40)
+    ZERO, GAMMA, BETA, GBUS = 63, 62, 61, 60
+    e.ldi(ZERO, 0)
+    e.ins(VX_OP_LDCH, GAMMA, 0)
+    e.ins(VX_OP_LDCH, BETA, 1)
+    e.ins(VX_OP_LDCH, GBUS, 2)
+    for q in range(lay.NPAIR):
+        m0 = e.top
+        g0 = e.op(VX_OP_SUB, GAMMA, e.ldw(lay.Z + 2 * q))
+        g1 = e.op(VX_OP_SUB, GAMMA, e.ldw(lay.Z + 2 * q + 1))
+        e.push(e.op(VX_OP_ADD, g0, g1), 0)
+        e.push(e.op(VX_OP_MUL, g0, g1), 0)
+        e.release(m0)
+    m0 = e.top
+    e.push(e.ldw(lay.MULT), 0)
+    e.push(e.op(VX_OP_SUB, GAMMA, e.ldw(lay.TBL)), 0)
+    e.release(m0)
+    NL = lay.NL
+    srcs = ([lay.REG + NL * AX + i for i in range(NL)] + [lay.REG + NL * AY + i for i in range(NL)] + [lay.SW + j for j in range(2 * lay.NW)]
+            + [lay.REG + NL * RESULT_X_REG + i for i in range(NL)] + [lay.Z + i for i in range(NL)])
+    tup = e.tmp()
+    e.ldw(srcs[-1], dst=tup)
+    for col in reversed(srcs[:-1]):
+        m1 = e.top
+        e.op(VX_OP_MUL, tup, BETA, tup)
+        e.op(VX_OP_ADD, tup, e.ldw(col), tup)
+        e.release(m1)
+    e.push(e.op(VX_OP_MUL, e.ldw(lay.RT + T_ELAST), e.ldw(lay.ACT)), 0)
+    e.push(e.op(VX_OP_SUB, GBUS, tup), 0)
+    e.ins(VX_OP_END)
+    nf = lay.NPAIR + 2
+    acc = [1] * lay.NPAIR + [-1, 0]
+    bus = [0] * (lay.NPAIR + 1) + [1]
+    fraction_out = list(range(lay.NPAIR)) + [lay.NPAIR, lay.NPAIR + 2]
+    return AuxProgram(lay.N, 3, e.w, nf, [acc, bus], fraction_out=fraction_out, sum_out=[lay.NPAIR + 1, lay.NPAIR + 3], api_sums=(1,))
+
+
 def make_stark(lay: Layout, degree_bits: int, **cfg) -> Stark:
     assert degree_bits > lay.LB
     prog, _ = build_program(lay)
     cfg.setdefault("rate_bits", 1)
-    return Stark(degree_bits, lay.N, 0, prog, constraint_degree=3, num_aux_columns=lay.NAUX, num_aux_challenges=3,
-                 aux_fn=lambda tr, ch: aux_columns(lay, tr, ch), num_aux_public_inputs=1, **cfg)
+    st = Stark(degree_bits, lay.N, 0, prog, constraint_degree=3, num_aux_columns=lay.NAUX, num_aux_challenges=3,
+               aux_fn=lambda tr, ch: aux_columns(lay, tr, ch), num_aux_public_inputs=1, **cfg)
+    st.aux_program = aux_program(lay)
+    return st
 
 
 # ---- the other end of the bus: a table holding the signatures' public data (A, S, h, R), one per flagged row ----------------------

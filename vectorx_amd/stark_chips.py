@@ -4,6 +4,7 @@ Caller-side code (trace generation and second-round columns are host arithmetic,
 from __future__ import annotations
 
 import ctypes
+import os
 import time
 
 import numpy as np
@@ -147,6 +148,7 @@ class ResidentTable:
         self.cap = 1 << 25
         self.aux_seconds_host = 0.0
         self.proofs = 0
+        self.gpu_aux = not os.environ.get("VX_HOST_AUX")        # tables that have an AuxProgram compute their second round on the GPU
 
     def drop_host_trace(self):
         """after the first proof the host copy is only needed to recompute second-round columns for OTHER challenges"""
@@ -164,7 +166,10 @@ class ResidentTable:
         if rc != 0:
             raise RuntimeError(L.vx_last_error().decode())
         try:
-            if self.naux:
+            if self.naux and self.stark.aux_program is not None and self.gpu_aux:
+                # round 4: the second-round columns are computed ON THE GPU on every proof (vx_stark_aux_columns) — part of what is timed
+                self.api = self.stark.run_aux_gpu(c, self.d_trace, chal[:self.stark.desc.num_aux_challenges], self.d_aux)
+            elif self.naux:
                 key = tuple(int(x) for x in chal)
                 if self.seen != key:
                     if self.trace is None:
