@@ -452,6 +452,10 @@ def test_second_round_columns_on_the_gpu_equal_the_host_ones(ctx):
     st2 = b2.make_stark(17)
     t2, _, _ = b2.generate_trace(17, [b"abc", bytes(range(200))])
     cases.append((st2, t2))
+    from vectorx_amd import sha256_air as sha
+    from vectorx_amd import sha512_air as s5
+    cases.append((sha.make_stark(9), sha.generate_trace(9, SHA_MESSAGES)[0]))
+    cases.append((s5.make_stark(8), s5.generate_trace(8, [b"abc", b""])[0]))
     rng = np.random.default_rng(7)
     for stark, trace in cases:
         chal = rng.integers(1, P, size=stark.desc.num_aux_challenges, dtype=np.uint64)

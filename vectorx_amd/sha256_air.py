@@ -628,13 +628,33 @@ def aux_columns_bus(trace, chal):
     return np.concatenate([base, np.stack([u, acc])]), np.array([int(acc[n - 1])], dtype=np.uint64)
 
 
+def aux_program():
+    """the GPU form of `aux_columns` (vx_stark_aux_columns; the table without the bus): h1 = 1/(g - ca) + 1/(g - ce),
+    h2 = 1/(g - cw) - mult/(g - tbl) as fractions, acc = the running sum of h1 + h2"""
+    from . import AuxProgram
+    C = Cols
+    e = _Emit(scratch=40)
+    GAMMA = 63
+    e.ins(VX_OP_LDCH, GAMMA, 0)
+    ga, ge, gw, gt = (e.op(VX_OP_SUB, GAMMA, e.ldw(c)) for c in (C.CA, C.CE, C.CW, C.TBL))
+    e.push(e.op(VX_OP_ADD, ga, ge), 0)
+    e.push(e.op(VX_OP_MUL, ga, ge), 0)
+    t = e.op(VX_OP_MUL, e.ldw(C.MULT), gw)
+    e.push(e.op(VX_OP_SUB, gt, t), 0)
+    e.push(e.op(VX_OP_MUL, gw, gt), 0)
+    e.ins(VX_OP_END)
+    return AuxProgram(C.N, 1, e.w, 2, [[1, 1]])
+
+
 def make_stark(degree_bits: int, bus=False, **cfg) -> Stark:
     prog, _ = build_program(bus)
     cfg.setdefault("rate_bits", 1)
     if bus:
         return Stark(degree_bits, Cols.N, 8, prog, constraint_degree=3, num_aux_columns=5, num_aux_challenges=3, aux_fn=aux_columns_bus,
                      num_aux_public_inputs=1, **cfg)
-    return Stark(degree_bits, Cols.N, 8, prog, constraint_degree=3, num_aux_columns=3, num_aux_challenges=1, aux_fn=aux_columns, **cfg)
+    st = Stark(degree_bits, Cols.N, 8, prog, constraint_degree=3, num_aux_columns=3, num_aux_challenges=1, aux_fn=aux_columns, **cfg)
+    st.aux_program = aux_program()
+    return st
 
 
 # ---- the other end of the bus: a table that RECEIVES digests (one per flagged row) -------------------------------------------

@@ -505,10 +505,31 @@ def aux_columns(trace, chal):
     return np.stack([np.array(c, dtype=np.uint64) for c in h + [ht, acc]])
 
 
+def aux_program():
+    """the GPU form of `aux_columns` (vx_stark_aux_columns): three pair helpers and the table term as fractions, one running sum"""
+    from . import AuxProgram
+    C = Cols
+    e = _Emit(scratch=40)
+    GAMMA = 63
+    e.ins(VX_OP_LDCH, GAMMA, 0)
+    for base in (C.CA, C.CE, C.CW):
+        m0 = e.top
+        g0, g1 = e.op(VX_OP_SUB, GAMMA, e.ldw(base)), e.op(VX_OP_SUB, GAMMA, e.ldw(base + 1))
+        e.push(e.op(VX_OP_ADD, g0, g1), 0)
+        e.push(e.op(VX_OP_MUL, g0, g1), 0)
+        e.release(m0)
+    e.push(e.ldw(C.MULT), 0)
+    e.push(e.op(VX_OP_SUB, GAMMA, e.ldw(C.TBL)), 0)
+    e.ins(VX_OP_END)
+    return AuxProgram(C.N, 1, e.w, 4, [[1, 1, 1, -1]])
+
+
 def make_stark(degree_bits: int, **cfg) -> Stark:
     prog, _ = build_program()
     cfg.setdefault("rate_bits", 1)
-    return Stark(degree_bits, Cols.N, 16, prog, constraint_degree=3, num_aux_columns=Cols.NAUX, num_aux_challenges=1, aux_fn=aux_columns, **cfg)
+    st = Stark(degree_bits, Cols.N, 16, prog, constraint_degree=3, num_aux_columns=Cols.NAUX, num_aux_challenges=1, aux_fn=aux_columns, **cfg)
+    st.aux_program = aux_program()
+    return st
 
 
 def reference_digests(messages):
