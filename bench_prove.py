@@ -300,11 +300,7 @@ def dag_stark_tables(ctx, eddsa_log_n=20, blake_log_n=18, verbose=False, kinds=(
                       "trace_generation_s": round(time.perf_counter() - t0, 2)}
         return resident(label, stark, trace, pis)
 
-    # round 4: the byte / XOR-lookup table (641 + 188 columns, 34 rows per compression: 2240 compressions fit 2^17 rows); round 3's bit
-    # table (1063 + 12 columns, 106 rows per compression, 2^18 rows) with VX_DAG_BLAKE2B_BITS=1, for comparison
-    import os
-    if os.environ.get("VX_DAG_BLAKE2B_BITS"):
-        per_kind = {}
+    per_kind = {}
     if "map" in kinds:
         # round 4: the byte / XOR-lookup table (641 + 188 columns, 34 rows per compression: 2240 compressions fit 2^17 rows); round 3's bit
         # table (1063 + 12 columns, 106 rows per compression, 2^18 rows) with VX_DAG_BLAKE2B_BITS=1, for comparison
