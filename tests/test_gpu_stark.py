@@ -488,3 +488,40 @@ def test_aux_program_descriptions_are_checked(ctx):
         setattr(ap.desc, field, old)
     ctx.free(d_t)
     ctx.free(d_o)
+
+
+def test_lanes_proving_the_same_resident_table_concurrently(ctx):
+    """the DAG scheduler's lanes prove ONE resident table from several host threads (vectorx_amd/stark_chips.py::ResidentTable): the
+    second round is computed on the GPU per proof with the running sums scanned in place, so every lane needs its own buffer — a shared
+    one made the proofs of a pass differ (found by the DAG leg's root check in round 4)"""
+    import threading
+
+    from vectorx_amd import eddsa_air as ea
+    from vectorx_amd import stark_chips
+    lay = ea.Layout(8, 32)
+    stark = ea.make_stark(lay, 12, num_query_rounds=12, pow_bits=4)
+    t, _ = ea.generate_trace(lay, 12, [((ea.BX, ea.BY), 0xC0FFEE, 0xBADF00D), ((ea.BX, ea.BY), 5, 7), ((ea.BX, ea.BY), 11, 13)])
+    tab = stark_chips.ResidentTable(ctx, stark, t, np.zeros(0, dtype=np.uint64), "eddsa-small")
+    lanes = [vx.Context(0) for _ in range(3)]
+    try:
+        want = tab.prove()
+        assert want == stark.prove(ctx, t, np.zeros(0, dtype=np.uint64))      # GPU second round == host second round, through whole proofs
+        got, errs = [[] for _ in lanes], []
+
+        def run(k):
+            try:
+                for _ in range(6):
+                    got[k].append(tab.prove(lanes[k]))
+            except BaseException as e:   # noqa: BLE001
+                errs.append(e)
+        threads = [threading.Thread(target=run, args=(k,)) for k in range(len(lanes))]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+        assert not errs, errs
+        assert all(p == want for g in got for p in g)
+    finally:
+        tab.free()
+        for l in lanes:
+            l.close()

@@ -128,10 +128,11 @@ class Repeated:
 
 
 class ResidentTable:
-    """A STARK table whose trace — and, once the challenges are known, its second-round columns — live in HBM: `prove()` is
-    vx_stark_begin -> (second-round columns: computed on the HOST by the table's aux_fn the first time a challenge vector is seen, then
-    reused — the same trace always draws the same challenges) -> vx_stark_finish2.  What the DAG leg and the chip benches time is the
-    prover; trace generation and the second-round columns are the caller's witness generation (disclosed in every record)."""
+    """A STARK table whose trace lives in HBM: `prove()` is vx_stark_begin -> second-round columns -> vx_stark_finish2.  Tables with an
+    AuxProgram (round 4: every table the DAG proves) compute their second round ON THE GPU on every proof (vx_stark_aux_columns, a buffer
+    per lane) — it is part of what the benches time; the others compute it on the HOST with the table's aux_fn the first time a
+    challenge vector is seen and reuse it (the same trace always draws the same challenges; VX_HOST_AUX=1 forces this path).  Trace
+    generation is the caller's witness generation (disclosed in every record)."""
 
     def __init__(self, ctx, stark, trace, public_inputs, name=""):
         self.ctx, self.stark, self.name = ctx, stark, name
@@ -148,6 +149,8 @@ class ResidentTable:
         self.cap = 1 << 25
         self.aux_seconds_host = 0.0
         self.proofs = 0
+        self.lane_aux = {}
+        self._lock = __import__("threading").Lock()
         self.gpu_aux = not os.environ.get("VX_HOST_AUX")        # tables that have an AuxProgram compute their second round on the GPU
 
     def drop_host_trace(self):
@@ -166,9 +169,15 @@ class ResidentTable:
         if rc != 0:
             raise RuntimeError(L.vx_last_error().decode())
         try:
+            d_aux, api_now = self.d_aux, None
             if self.naux and self.stark.aux_program is not None and self.gpu_aux:
-                # round 4: the second-round columns are computed ON THE GPU on every proof (vx_stark_aux_columns) — part of what is timed
-                self.api = self.stark.run_aux_gpu(c, self.d_trace, chal[:self.stark.desc.num_aux_challenges], self.d_aux)
+                # round 4: the second-round columns are computed ON THE GPU on every proof (vx_stark_aux_columns) — part of what is timed.
+                # One buffer per lane: the running sums are scanned in place, so two lanes proving the same table must not share it.
+                with self._lock:
+                    d_aux = self.lane_aux.get(id(c))
+                    if d_aux is None:
+                        d_aux = self.lane_aux[id(c)] = self.ctx.alloc(max(8, self.naux * self.n * 8))
+                api_now = self.stark.run_aux_gpu(c, self.d_trace, chal[:self.stark.desc.num_aux_challenges], d_aux)
             elif self.naux:
                 key = tuple(int(x) for x in chal)
                 if self.seen != key:
@@ -182,8 +191,9 @@ class ResidentTable:
                     self.seen = key
             out = np.empty(self.cap, dtype=np.uint8)            # per call: lanes prove the same table concurrently
             nb = ctypes.c_size_t(self.cap)
-            api = None if self.api is None or self.api.size == 0 else self.api.ctypes.data
-            rc = L.vx_stark_finish2(sess, vp(self.d_aux), 1, api, None, out.ctypes.data, ctypes.byref(nb))
+            api_arr = api_now if api_now is not None else self.api
+            api = None if api_arr is None or api_arr.size == 0 else api_arr.ctypes.data
+            rc = L.vx_stark_finish2(sess, vp(d_aux), 1, api, None, out.ctypes.data, ctypes.byref(nb))
             if rc != 0:
                 raise RuntimeError(L.vx_last_error().decode())
             self.proofs += 1
@@ -194,6 +204,9 @@ class ResidentTable:
     def free(self):
         self.ctx.free(self.d_trace)
         self.ctx.free(self.d_aux)
+        for d in self.lane_aux.values():
+            self.ctx.free(d)
+        self.lane_aux = {}
 
 
 def eddsa_signatures(count: int, distinct: int = 8, seed: int = 2024):
