@@ -156,3 +156,29 @@ def test_torch_allgather_gloo():
         assert out["world"] == world
         assert all(ok for _, ok, _, _ in out["results"])
         assert all(calls == 3 and nbytes == (4 + 64 + 1000) * 8 * (world - 1) for _, _, calls, nbytes in out["results"])
+
+
+def test_a_job_is_its_plonky2_proof_followed_by_its_stark_proofs():
+    """vectorx_amd/mapreduce.py::prove_with_tables: the composition GpuProver.prove uses — order, digest coverage, per-kind seconds"""
+    import hashlib
+    import threading
+
+    from vectorx_amd import mapreduce as mr
+
+    class Table:
+        def __init__(self, blob):
+            self.blob, self.seen = blob, []
+
+        def prove(self, ctx):
+            self.seen.append(ctx)
+            return self.blob
+
+    a, b = Table(b"AA"), Table(b"B")
+    split, lock = {}, threading.Lock()
+    job = mr.prove_with_tables(lambda: b"main", [("blake2b", a), ("sha256", b)], "lane-1", split, lock)
+    assert job == b"mainAAB" and a.seen == ["lane-1"] and set(split) == {"plonky2", "blake2b", "sha256"}
+    assert mr.prove_with_tables(lambda: b"main", [], None) == b"main"
+    # a parent's public inputs change when a child's STARK proof changes
+    d0 = hashlib.sha256(job).digest()
+    d1 = hashlib.sha256(mr.prove_with_tables(lambda: b"main", [("blake2b", Table(b"AX")), ("sha256", b)], None)).digest()
+    assert (mr.child_inputs(1, 0, {0: d0, 1: d0}) != mr.child_inputs(1, 0, {0: d1, 1: d0})).any()

@@ -227,6 +227,29 @@ def run_dag(spec: DagSpec, make_prover, dist=None, sync=lambda: None, in_flight:
     return {"root": prev[0], "seconds": seconds, "proofs": spec.num_proofs(), "per_layer": per_layer, "my_proofs": all_proofs}
 
 
+def prove_with_tables(prove_main, tables, lane_ctx=None, split=None, lock=None) -> bytes:
+    """One job of the DAG = its plonky2 proof followed by the proofs of the STARK tables its circuit embeds (`tables`: [(label, object
+    with .prove(ctx) -> bytes)]): the concatenation is what the job's digest — and so its parent's public inputs — covers.
+    `split` (dict, guarded by `lock`) accumulates the wall seconds spent per kind of work."""
+    t0 = time.perf_counter()
+    parts = [prove_main()]
+    spent = [("plonky2", time.perf_counter() - t0)]
+    for label, table in tables:
+        t0 = time.perf_counter()
+        parts.append(table.prove(lane_ctx))
+        spent.append((label, time.perf_counter() - t0))
+    if split is not None:
+        if lock is not None:
+            lock.acquire()
+        try:
+            for label, dt in spent:
+                split[label] = split.get(label, 0.0) + dt
+        finally:
+            if lock is not None:
+                lock.release()
+    return b"".join(parts)
+
+
 class GpuProver:
     """One circuit kind on one GPU: circuit loaded once (constants_sigmas resident), one device-resident witness per
     job; `prove` patches the two witness rows that depend on the public inputs and calls vx_prove."""
@@ -285,20 +308,7 @@ class GpuProver:
         ctx = self.lanes[lane]
         ctx.upload_row(d, self.n, 0, r0)
         ctx.upload_row(d, self.n, 2, r2)
-        if not self.starks and self.split is None:
-            return self.circuits[lane].prove(dev_ptr=d)
-        t0 = time.perf_counter()
-        parts = [self.circuits[lane].prove(dev_ptr=d)]
-        spent = [("plonky2", time.perf_counter() - t0)]
-        for label, table in self.starks:
-            t0 = time.perf_counter()
-            parts.append(table.prove(ctx))
-            spent.append((label, time.perf_counter() - t0))
-        if self.split is not None:
-            with self._lock:
-                for label, dt in spent:
-                    self.split[label] = self.split.get(label, 0.0) + dt
-        return b"".join(parts)
+        return prove_with_tables(lambda: self.circuits[lane].prove(dev_ptr=d), self.starks, ctx, self.split, self._lock)
 
     def free(self):
         for d in self.wit.values():
