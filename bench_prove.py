@@ -220,6 +220,10 @@ def dag_leg_ranks(ctx, args, local_rank, dist, device, in_flight=3, with_starks=
         # every rank proves map and reduce jobs; the outer job (and its tables) belongs to the rank job 0 of the last layer is dealt to: rank 0
         kinds = ("map", "reduce", "outer") if dist.get_rank() == 0 else ("map", "reduce")
         per_kind, tables, _setup = dag_stark_tables(ctx, kinds=kinds, small=bool(getattr(args, "dag_starks_small", False)))
+        for lane in lanes:
+            for tabs in per_kind.values():
+                for _, tab in tabs:
+                    getattr(tab, "table", tab).prove(lane)
 
     def make(kind, log_n, jobs):
         if kind not in provers:
@@ -346,6 +350,10 @@ def dag_with_starks_leg(ctx, local_rank, in_flight=None):
     t_setup = time.perf_counter()
     per_kind, tables, setup = dag_stark_tables(ctx)
     lanes = [vx.Context(local_rank) for _ in range(in_flight - 1)]
+    for lane in lanes:                  # every lane proves every table once (untimed): its pool then holds the STARK shapes too, like
+        for tabs in per_kind.values():  # vx_circuit_warm does for the plonky2 shapes — the first timed pass allocates nothing
+            for _, tab in tabs:
+                getattr(tab, "table", tab).prove(lane)
     spec = mr.DagSpec(64, 18, 16, 19)
     provers, split = {}, {}
 

@@ -7,6 +7,8 @@ copies here) are not representative; their volume is reported instead so the xGM
 
 usage: python tools/sharded_prove_bench.py [degree_bits] [worlds, e.g. 1,2,4,8] [dev]      ("dev": witness already in HBM)
 """
+import os
+os.environ.setdefault("VX_NO_WARM_ON_LOAD", "1")   # G ranks share ONE device here: no rank may cache a full-size unsharded working set
 import ctypes
 import json
 import sys

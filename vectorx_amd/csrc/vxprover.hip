@@ -564,6 +564,18 @@ int vx_circuit_warm(vx_ctx* c, vx_circuit* k) {
   if (k->ctx != c) return vx_fail(VX_E_INVALID, "vx_circuit_warm: circuit belongs to a different context");
   if (k->num_luts > 0) return VX_OK;
   HIPCHK(hipSetDevice(c->device));
+  {
+    // a proof's working set is about 8 N (wires + Z / partial products + quotient chunks) for the LDEs plus trees, coefficients and
+    // scratch: rehearse only when twice a generous estimate is free — a host that packs many contexts onto one device (the
+    // single-device emulation of a sharded proof) must not have every one of them cache a full-size working set
+    size_t free_b = 0, total_b = 0;
+    const size_t N = k->n() << k->rate_bits;
+    const size_t need = (size_t)16 * N * ((size_t)k->num_wires + 40);
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < 2 * need) {
+      (void)hipGetLastError();
+      return VX_OK;
+    }
+  }
   const size_t bytes = (size_t)k->num_wires * k->n() * 8;
   void* zero = nullptr;
   if (c->pool_alloc(&zero, bytes) != hipSuccess) return vx_fail(VX_E_NOMEM, "vx_circuit_warm: out of device memory");
