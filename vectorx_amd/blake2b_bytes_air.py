@@ -593,13 +593,15 @@ def generate_trace(degree_bits: int, messages) -> tuple:
             m, tcount, fin = [0] * 16, (tb_prev + 128), 0
         base = b * PERIOD
         rows = range(base, min(n, base + PERIOD))
-        for row in rows:
-            s = row - base
-            t[C.SEL + s, row] = 1
-            put_limbs(C.H, h, row)
-            put_limbs(C.M, m, row)
-            t[C.T, row], t[C.F, row], t[C.TB, row] = tcount, fin, tb_prev
-            put_limbs(C.D, dlatch, row)
+        r0, r1 = base, min(n, base + PERIOD)
+        t[C.SEL + np.arange(r1 - r0), np.arange(r0, r1)] = 1
+        hm = [x for w in h for x in lim2(w)]
+        mm = [x for w in m for x in lim2(w)]
+        dd = [x for w in dlatch for x in lim2(w)]
+        t[C.H:C.H + 16, r0:r1] = np.array(hm, dtype=np.uint64)[:, None]
+        t[C.M:C.M + 32, r0:r1] = np.array(mm, dtype=np.uint64)[:, None]
+        t[C.D:C.D + 8, r0:r1] = np.array(dd, dtype=np.uint64)[:, None]
+        t[C.T, r0:r1], t[C.F, r0:r1], t[C.TB, r0:r1] = tcount, fin, tb_prev
         v = list(h) + list(IV[:4]) + [IV[4] ^ tcount, IV[5], IV[6] ^ (MASK64 if fin else 0), IV[7]]
         # row 0: the initial work vector in the diagonal-output arrangement; the tuples stay valid XOR triples
         row = base
@@ -629,19 +631,18 @@ def generate_trace(degree_bits: int, messages) -> tuple:
                     idx = (i, 4 + (i + 1) % 4, 8 + (i + 2) % 4, 12 + (i + 3) % 4)
                 x, y = m[_msg_index(s, i, 0)], m[_msg_index(s, i, 1)]
                 gr = _g(v[idx[0]], v[idx[1]], v[idx[2]], v[idx[3]], x, y)
-                for name in FIELDS:
-                    put_bytes(C.f(i, name), gr[name], row)
-                t[C.al(i, 0), row], t[C.al(i, 1), row] = lim2(gr["AL"])
-                t[C.cl(i, 0), row], t[C.cl(i, 1), row] = lim2(gr["CL"])
-                for q in range(8):
-                    t[C.k(i, q), row] = gr["K"][q]
+                # the slot's 12 byte fields are 96 contiguous columns, then AL(2), CL(2), K(8): two assignments per slot
+                base_col = C.f(i, FIELDS[0])
+                t[base_col:base_col + 96, row] = np.frombuffer(b"".join(gr[name].to_bytes(8, "little") for name in FIELDS), dtype=np.uint8)
+                t[base_col + 96:base_col + 108, row] = [*lim2(gr["AL"]), *lim2(gr["CL"]), *gr["K"]]
                 outs.append((idx, gr["out"]))
             for idx, o in outs:
                 for q in range(4):
                     v[idx[q]] = o[q]
             if s <= 16:
                 put_bytes(C.BY, m[s - 1], row)
-            put_limbs(C.HN, hn, row)
+        if base + 1 < n:                 # HN holds through the G rows
+            t[C.HN:C.HN + 16, base + 1:min(n, base + ROW_GLAST + 1)] = np.array([x for w in hn for x in lim2(w)], dtype=np.uint64)[:, None]
         # rows 25..32: finalisation
         for k in range(8):
             row = base + ROW_FIN0 + k
