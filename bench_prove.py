@@ -306,13 +306,13 @@ def dag_stark_tables(ctx, eddsa_log_n=20, blake_log_n=18, verbose=False, kinds=(
 
     per_kind = {}
     if "map" in kinds:
-        # round 4: the byte / XOR-lookup table (641 + 188 columns, 34 rows per compression: 2240 compressions fit 2^17 rows); round 3's bit
+        # round 4: the byte / XOR-lookup table (775 + 238 columns, 28 rows per compression: 2240 compressions fit 2^16 rows); round 3's bit
         # table (1063 + 12 columns, 106 rows per compression, 2^18 rows) with VX_DAG_BLAKE2B_BITS=1, for comparison
         import os
         if os.environ.get("VX_DAG_BLAKE2B_BITS"):
             blake = hash_table("blake2b_map", blake2b_air, blake_log_n, [bytes([17 * i & 255]) * (128 * nhdr_blocks) for i in range(8)])
         else:
-            blake = hash_table("blake2b_map", blake2b_bytes_air, 17, [bytes([17 * i & 255]) * (128 * nhdr_blocks) for i in range(8)])
+            blake = hash_table("blake2b_map", blake2b_bytes_air, 16, [bytes([17 * i & 255]) * (128 * nhdr_blocks) for i in range(8)])
         sha_map = hash_table("sha256_map", sha256_air, 11, [bytes([i]) * 64 for i in range(14)])
         per_kind["map"] = [("blake2b", blake), ("sha256", sha_map)]
     if "reduce" in kinds:
@@ -392,7 +392,7 @@ def dag_with_starks_leg(ctx, local_rank, in_flight=None):
             "per_layer_ms": [(l["kind"], l["jobs"], round(l["ms"], 1)) for l in res["per_layer"]],
             "tables": setup, "setup_seconds_untimed": round(time.perf_counter() - t_setup - sum(r["seconds"] for r in runs), 2),
             "root": res["root"].hex(),
-            "what": "64 map jobs = plonky2 2^18 + BLAKE2b table (2240 compressions: 2^17 rows of the byte / XOR-lookup table) + SHA-256 table 2^11; 63 reduce jobs = plonky2 2^16 + SHA-256 "
+            "what": "64 map jobs = plonky2 2^18 + BLAKE2b table (2240 compressions: 2^16 rows of the byte / XOR-lookup table) + SHA-256 table 2^11; 63 reduce jobs = plonky2 2^16 + SHA-256 "
                     "table 2^9; outer = plonky2 2^19 + SHA-256 chain 2^16 + SHA-512 2^16 + 4 batched EdDSA tables 2^20 (388 signature slots for 300 "
                     "signatures); own AIRs standing in for Curta's chips, synthetic stand-in circuits; every trace, witness and second-round column "
                     "resident in HBM before the clock starts (one trace per table kind, proven once per job); the STARK proofs are part of a job's "

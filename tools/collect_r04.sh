@@ -16,7 +16,7 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write" -- python3 bench.py --workload commit --steps 1 --warmup 0 --no-cpu-baseline > "$OUT/pmc_write.json" 2> "$OUT/pmc_write.err"
 # the STARK path: the batched EdDSA table, the byte BLAKE2b table, the round-3 chip tables, kernel stats of one EdDSA proof
 python3 tools/stark_bench.py --air eddsa --log-n 20 --steps 3 --warmup 1 --check >> "$OUT/stark_bench.jsonl" 2>> "$OUT/stark_bench.err"
-python3 tools/stark_bench.py --air blake2b_bytes --log-n 17 --steps 3 --warmup 1 >> "$OUT/stark_bench.jsonl" 2>> "$OUT/stark_bench.err"
+python3 tools/stark_bench.py --air blake2b_bytes --log-n 16 --steps 3 --warmup 1 >> "$OUT/stark_bench.jsonl" 2>> "$OUT/stark_bench.err"
 for air in sha256 blake2b ed25519; do python3 tools/stark_bench.py --air $air --log-n 13 --steps 3 --warmup 1 --check >> "$OUT/stark_bench.jsonl" 2>> "$OUT/stark_bench.err"; done
 python3 tools/stark_bench.py --air blake2b --log-n 18 --steps 3 --warmup 1 >> "$OUT/stark_bench.jsonl" 2>> "$OUT/stark_bench.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_eddsa" -- python3 tools/stark_bench.py --air eddsa --log-n 20 --steps 3 --warmup 1 > "$OUT/eddsa_under_rocprof.json" 2> "$OUT/rocprof_eddsa.err"

@@ -42,10 +42,10 @@ def main():
         return sha256_bench(args, vx, "blake2b")
     if args.air == "ed25519":
         return sha256_bench(args, vx, "ed25519")
-    if args.air == "blake2b_bytes":   # bytes + XOR lookup, four G per row (vectorx_amd/blake2b_bytes_air.py): --log-n 17 = one map job's 2240 compressions
+    if args.air == "blake2b_bytes":   # bytes + XOR lookup, four G per row (vectorx_amd/blake2b_bytes_air.py): --log-n 16 = one map job's 2240 compressions
         from vectorx_amd import stark_chips
         ctx = vx.Context(0)
-        print(json.dumps(stark_chips.bench_blake2b_bytes(ctx, max(17, args.log_n), args.steps, args.warmup)), flush=True)
+        print(json.dumps(stark_chips.bench_blake2b_bytes(ctx, max(16, args.log_n) if args.log_n != 18 else 16, args.steps, args.warmup)), flush=True)
         ctx.close()
         return
     if args.air == "eddsa":          # the batched signature table (vectorx_amd/eddsa_air.py): --log-n 20 = 97 signatures per proof

@@ -6,7 +6,7 @@ NOT CURTA'S (the starkyx sources are not in the tree), but closer to how a byte-
 eight lookups of (a, b, a ^ b) in a 65 536-entry table, the rotations by 32, 24 and 16 are byte permutations (free: wiring), the
 rotation by 63 is one top bit per byte, additions run on 32-bit limbs with carries.
 
-Layout: a 128-byte block occupies 34 rows (cyclic one-hot SEL):
+Layout: a 128-byte block occupies 28 rows (cyclic one-hot SEL):
   row 0        init: the slot columns present the initial work vector as if a diagonal step had produced it; T ^ IV4 through the
                finalisation XOR columns;
   rows 1..24   the 12 rounds, FOUR G functions per row (odd rows: the column step, even rows: the diagonal step).  Slot i of a row
@@ -15,13 +15,17 @@ Layout: a 128-byte block occupies 34 rows (cyclic one-hot SEL):
                  a1 = a + b + x;  e1 = d ^ a1 (d1 = e1 >>> 32);  c1 = c + d1;  f1 = b ^ c1 (b1 = f1 >>> 24);
                  a2 = a1 + b1 + y; e2 = d1 ^ a2 (d2 = e2 >>> 16);  c2 = c1 + d2;  f2 = b1 ^ c2;  b2 = f2 <<< 1 (TOP bits);
                rows 1..16 also hold the bytes of m[row - 1] (range check of the message);
-  rows 25..32  finalisation, word k: HN[k] = v[k] ^ v[k + 8] ^ h[k] through FA, FB, FE, FH, FO (the work vector is latched in V);
-  row 33       hand-over: the next block's chaining value is HN, or the parameterised IV after a final block, whose digest is latched in D.
-40 lookups per slot (32 XOR triples + the 8 bytes of b2 as (b2, 0, b2)), 16 for the finalisation, 8 for the message bytes: 184 per row,
-all into ONE table whose columns (TA, TB, TC = TA ^ TB) are themselves constrained (counters + 16 bit columns): a triple enters the
-argument as a + beta b + beta^2 c with a second challenge beta, so that no combination of non-bytes aliases a table entry.
-641 + 2 x 94 columns x 34 rows = 28 k cells per compression — a quarter of round 3's; 2240 compressions fit 2^17 rows instead of 2^18.
-The table needs 65 536 rows before the last one: traces of >= 2^17 rows.
+  rows 25, 26  finalisation, four words per row (groups g = 0..3 of FA, FB, FE, FH, FO): HN[k] = v[k] ^ v[k + 8] ^ h[k] for k = 4 r + g
+               (the work vector is latched in V);
+  row 27       hand-over: the next block's chaining value is HN, or the parameterised IV after a final block, whose digest is latched in D.
+40 lookups per slot (32 XOR triples + the 8 bytes of b2 as (b2, 0, b2)), 64 for the finalisation, 8 for the message bytes: 232 per row,
+into a XOR table held as TWO half tables side by side (rows i < 32 768 of half k list a = 128 k + (i >> 8), b = i & 255): each half's
+columns (TA, TB, TC = TA ^ TB) are constrained through 16 bit columns, so EVERY table row is a valid triple whatever the prover puts
+there — the argument needs no counter constraints, only that the prover lists the entries it uses.  A triple enters as
+a + beta b + beta^2 c with a second challenge beta, so that no combination of non-bytes aliases a table entry.
+775 + 2 x 119 columns x 28 rows = 28 k cells per compression — a quarter of round 3's — and, what counts, 2240 compressions (one map
+job) fit 2^16 rows instead of 2^18: the first version of this table (one 65 536-row table, 34 rows per compression, 8 finalisation
+rows) needed 2^17 rows for them and proved in 26 ms; this one needs half the rows.  Traces of >= 2^16 rows.
 
 Public inputs: the 8 limbs of D in the last row = the digest of the last message completed inside the trace.
 Plain host code: it emits a constraint program (include/vxprover.h VX_OP_*), generates the trace and the second-round columns; checked
@@ -38,8 +42,10 @@ from . import hostfield as hf
 from .blake2b_air import IV, IVP, MASK64, SIGMA, split_message
 from .sha256_air import P, _Emit
 
-PERIOD = 34
-ROW_INIT, ROW_G0, ROW_GLAST, ROW_FIN0, ROW_HAND = 0, 1, 24, 25, 33
+PERIOD = 28
+ROW_INIT, ROW_G0, ROW_GLAST, ROW_FIN0, ROW_HAND = 0, 1, 24, 25, 27
+NFINROW, NFING = 2, 4         # finalisation: 2 rows x 4 word groups
+NTAB, TAB_ROWS = 2, 32768     # two half tables of 32 768 entries
 NSLOT = 4
 FIELDS = ["BIN", "DIN", "A1", "E1", "C1", "F1", "A2", "E2", "C2", "F2", "TOP", "B2"]      # 8 byte columns each
 K_A1, K_C1, K_A2, K_C2 = 0, 2, 4, 6
@@ -55,18 +61,24 @@ class Cols:
     V = M + 35                # the work vector after the 12 rounds, latched for the finalisation rows
     SLOT = V + 32             # per slot: 12 byte fields, then AL(2), CL(2) limbs, then 8 carries
     SLOT_W = 8 * len(FIELDS) + 4 + 8
-    FA = SLOT + NSLOT * SLOT_W
-    FB, FE, FH, FO = FA + 8, FA + 16, FA + 24, FA + 32
-    BY = FA + 40
-    TA = BY + 8               # table: TA, TB, TC = TA ^ TB, the bits of TA and TB, multiplicities
-    TBB, TC, TBITS, MULT = TA + 1, TA + 2, TA + 3, TA + 19
-    N = MULT + 1
-    NTUP = NSLOT * 40 + 16 + 8
+    FIN = SLOT + NSLOT * SLOT_W    # per group g: FA, FB, FE, FH, FO (8 bytes each)
+    BY = FIN + 40 * NFING
+    TAB = BY + 8                   # per half table: TA, TB, TC = TA ^ TB, the bits of TA and TB (16), multiplicities
+    N = TAB + 20 * NTAB
+    NTUP = NSLOT * 40 + 16 * NFING + 8
     NPAIR = NTUP // 2
     AUX_H = N
-    AUX_HT = N + NPAIR
-    AUX_ACC = AUX_HT + 1
-    NAUX = NPAIR + 2
+    AUX_HT = N + NPAIR             # one table helper per half table
+    AUX_ACC = AUX_HT + NTAB
+    NAUX = NPAIR + NTAB + 1
+
+    @staticmethod
+    def fin(g, name, j=0):
+        return Cols.FIN + 40 * g + 8 * ("FA", "FB", "FE", "FH", "FO").index(name) + j
+
+    @staticmethod
+    def tab(k, name, j=0):
+        return Cols.TAB + 20 * k + {"TA": 0, "TB": 1, "TC": 2, "BITS": 3, "MULT": 19}[name] + j
 
     @staticmethod
     def f(g, name, j=0):
@@ -95,9 +107,10 @@ def tuples():
             out.append((C.f(g, "E1", (j + 4) % 8), C.f(g, "A2", j), C.f(g, "E2", j)))        # d1 = e1 >>> 32
             out.append((C.f(g, "F1", (j + 3) % 8), C.f(g, "C2", j), C.f(g, "F2", j)))        # b1 = f1 >>> 24
             out.append((C.f(g, "B2", j), None, C.f(g, "B2", j)))                             # range: (b2, 0, b2)
-    for j in range(8):
-        out.append((C.FA + j, C.FB + j, C.FE + j))
-        out.append((C.FE + j, C.FH + j, C.FO + j))
+    for g in range(NFING):
+        for j in range(8):
+            out.append((C.fin(g, "FA", j), C.fin(g, "FB", j), C.fin(g, "FE", j)))
+            out.append((C.fin(g, "FE", j), C.fin(g, "FH", j), C.fin(g, "FO", j)))
     for j in range(8):
         out.append((C.BY + j, None, C.BY + j))
     assert len(out) == C.NTUP
@@ -170,8 +183,8 @@ def build_program():
 
     g_rows = list(range(ROW_G0, ROW_GLAST + 1))
     sum_sel(g_rows, ISG)
-    sum_sel(range(ROW_FIN0, ROW_FIN0 + 8), ISFIN)
-    sum_sel(range(ROW_FIN0, ROW_FIN0 + 7), FINHOLD)
+    sum_sel(range(ROW_FIN0, ROW_FIN0 + NFINROW), ISFIN)
+    sum_sel(range(ROW_FIN0, ROW_FIN0 + NFINROW - 1), FINHOLD)
     sum_sel([s for s in g_rows if s % 2 == 1], COLN, nxt=True)
     sum_sel([s for s in g_rows if s % 2 == 0], DIAGN, nxt=True)
     e.ldw(C.SEL + ROW_INIT, dst=S0)
@@ -188,8 +201,9 @@ def build_program():
         for i in (K_C1, K_C1 + 1, K_C2, K_C2 + 1):
             boolean(C.k(g, i))
     boolean(C.F)
-    for i in range(16):
-        boolean(C.TBITS + i)
+    for k in range(NTAB):
+        for i in range(16):
+            boolean(C.tab(k, "BITS", i))
     # ---- wiring: the inputs of a G row are the previous row's outputs (column step <-> diagonal step) ----
     isgn = tmp()
     e.op(VX_OP_ADD, COLN, DIAGN, isgn)
@@ -303,40 +317,43 @@ def build_program():
             e.op(VX_OP_MUL, u, FINHOLD, u)
             push(e.op(VX_OP_ADD, t, u), VX_AIR_TRANSITION)
             e.release(m0)
-    # ---- finalisation rows: FA = v[k], FB = v[k + 8], FH = h[k]; HN[k] <- FO = FA ^ FB ^ FH.  Init row: FA = T, FB = IV4 ----
-    for l in (0, 1):
-        for base, src, extra in ((C.FA, C.V, "T"), (C.FB, C.V + 16, "IV4"), (C.FH, C.H, None)):
+    # ---- finalisation rows r = 0, 1, group g: FA = v[4 r + g], FB = v[4 r + g + 8], FH = h[4 r + g]; HN[4 r + g] <- FO = FA ^ FB ^ FH.
+    #      Init row: group 0 holds FA = T, FB = IV4 ----
+    for g in range(NFING):
+        for l in (0, 1):
+            for name, src, extra in (("FA", C.V, "T"), ("FB", C.V + 16, "IV4"), ("FH", C.H, None)):
+                m0 = e.top
+                t = tmp()
+                limb([C.fin(g, name, 4 * l + q) for q in range(4)], t)
+                gate = e.op(VX_OP_ADD, ISFIN, S0 if (extra and g == 0) else ZERO)
+                e.op(VX_OP_MUL, t, gate, t)
+                for r in range(NFINROW):
+                    m1 = e.top
+                    v = e.op(VX_OP_MUL, e.ldw(src + 2 * (4 * r + g) + l), e.ldw(C.SEL + ROW_FIN0 + r))
+                    e.op(VX_OP_SUB, t, v, t)
+                    e.release(m1)
+                if g == 0 and extra == "T" and l == 0:
+                    e.op(VX_OP_SUB, t, e.op(VX_OP_MUL, e.ldw(C.T), S0), t)
+                if g == 0 and extra == "IV4":
+                    c = tmp()
+                    e.ldi(c, (IV[4] >> (32 * l)) & 0xFFFFFFFF)
+                    e.op(VX_OP_MUL, c, S0, c)
+                    e.op(VX_OP_SUB, t, c, t)
+                push(t, VX_AIR_ALL_ROWS)
+                e.release(m0)
             m0 = e.top
-            t = tmp()
-            limb([base + 4 * l + q for q in range(4)], t)
-            g = e.op(VX_OP_ADD, ISFIN, S0 if extra else ZERO)
-            e.op(VX_OP_MUL, t, g, t)
-            for k in range(8):
+            wx = tmp()
+            limb([C.fin(g, "FO", 4 * l + q) for q in range(4)], wx)
+            for r in range(NFINROW):
                 m1 = e.top
-                v = e.op(VX_OP_MUL, e.ldw(src + 2 * k + l), e.ldw(C.SEL + ROW_FIN0 + k))
-                e.op(VX_OP_SUB, t, v, t)
+                k = 4 * r + g
+                hn, hnn = e.ldw(C.HN + 2 * k + l), e.ldw(C.HN + 2 * k + l, nxt=True)
+                t = e.op(VX_OP_SUB, wx, hn)
+                e.op(VX_OP_MUL, t, e.ldw(C.SEL + ROW_FIN0 + r), t)
+                u = e.op(VX_OP_SUB, hnn, hn)
+                push(e.op(VX_OP_SUB, u, t), VX_AIR_TRANSITION)          # HN'[k] = HN[k] + s_{25+r} (FO_g - HN[k])
                 e.release(m1)
-            if extra == "T" and l == 0:
-                e.op(VX_OP_SUB, t, e.op(VX_OP_MUL, e.ldw(C.T), S0), t)
-            if extra == "IV4":
-                c = tmp()
-                e.ldi(c, (IV[4] >> (32 * l)) & 0xFFFFFFFF)
-                e.op(VX_OP_MUL, c, S0, c)
-                e.op(VX_OP_SUB, t, c, t)
-            push(t, VX_AIR_ALL_ROWS)
             e.release(m0)
-        m0 = e.top
-        wx = tmp()
-        limb([C.FO + 4 * l + q for q in range(4)], wx)
-        for k in range(8):
-            m1 = e.top
-            hn, hnn = e.ldw(C.HN + 2 * k + l), e.ldw(C.HN + 2 * k + l, nxt=True)
-            t = e.op(VX_OP_SUB, wx, hn)
-            e.op(VX_OP_MUL, t, e.ldw(C.SEL + ROW_FIN0 + k), t)
-            u = e.op(VX_OP_SUB, hnn, hn)
-            push(e.op(VX_OP_SUB, u, t), VX_AIR_TRANSITION)              # HN'[k] = HN[k] + s_{25+k} (FO - HN[k])
-            e.release(m1)
-        e.release(m0)
     # ---- init row: the slots present v = (h, IV[0..4], IV4 ^ T, IV5, IV6 ^ (F ? ~0 : 0), IV7) in the diagonal-output arrangement ----
     for w in range(16):
         g, name, rot = out_of[w]
@@ -348,7 +365,7 @@ def build_program():
                 e.op(VX_OP_SUB, t, e.ldw(C.H + 2 * w + l), t)
             elif w == 12:
                 v = tmp()
-                limb([C.FE + 4 * l + q for q in range(4)], v)
+                limb([C.fin(0, "FE", 4 * l + q) for q in range(4)], v)
                 e.op(VX_OP_SUB, t, v, t)
             elif w == 14:
                 iv = (IV[6] >> (32 * l)) & 0xFFFFFFFF
@@ -367,7 +384,7 @@ def build_program():
             e.release(m0)
     m0 = e.top
     t = tmp()
-    limb([C.FA + 4 + q for q in range(4)], t)
+    limb([C.fin(0, "FA", 4 + q) for q in range(4)], t)
     push(e.op(VX_OP_MUL, t, S0), VX_AIR_ALL_ROWS)                        # the counter has no high limb (messages < 2^32 bytes)
     e.release(m0)
     # ---- chaining value, digest latch, message / counter / flag constancy (as in blake2b_air.py) ----
@@ -442,47 +459,28 @@ def build_program():
         push(w, VX_AIR_ALL_ROWS)
         e.release(m1)
     e.release(m0)
-    # ---- the XOR table: TB counts 0..255, TA advances when TB wraps, TC = TA ^ TB through their bits ----
-    m0 = e.top
-    c255 = tmp()
-    e.ldi(c255, 255)
-    tb, tbn = e.ldw(C.TBB), e.ldw(C.TBB, nxt=True)
-    inc = e.op(VX_OP_SUB, tbn, tb)
-    e.op(VX_OP_SUB, inc, ONE, inc)                                       # 0, or -256 on a wrap
-    push(e.op(VX_OP_MUL, inc, tbn), VX_AIR_TRANSITION)
-    t = e.op(VX_OP_SUB, tb, c255)
-    push(e.op(VX_OP_MUL, t, inc), VX_AIR_TRANSITION)
-    push(tb, VX_AIR_FIRST_ROW)
-    ta, tan = e.ldw(C.TA), e.ldw(C.TA, nxt=True)
-    # wrapped = -inc / 256: inc_a = 256 (ta' - ta) + inc is 0, or -65536 when TA itself wraps
-    inca = e.op(VX_OP_SUB, tan, ta)
-    e.op(VX_OP_MUL, inca, C256, inca)
-    e.op(VX_OP_ADD, inca, inc, inca)
-    push(e.op(VX_OP_MUL, inca, tan), VX_AIR_TRANSITION)
-    t = e.op(VX_OP_SUB, ta, c255)
-    push(e.op(VX_OP_MUL, t, inca), VX_AIR_TRANSITION)
-    push(ta, VX_AIR_FIRST_ROW)
-    e.release(m0)
-    m0 = e.top
-    sa, sb, sc = tmp(), tmp(), tmp()
-    for i in range(7, -1, -1):
-        m1 = e.top
-        a, b = e.ldw(C.TBITS + i), e.ldw(C.TBITS + 8 + i)
-        x = e.op(VX_OP_MUL, a, b)
-        e.op(VX_OP_ADD, x, x, x)
-        s = e.op(VX_OP_ADD, a, b)
-        e.op(VX_OP_SUB, s, x, s)                                         # a ^ b
-        for acc, bit in ((sa, a), (sb, b), (sc, s)):
-            if i == 7:
-                e.op(VX_OP_ADD, bit, ZERO, acc)
-            else:
-                e.op(VX_OP_ADD, acc, acc, acc)
-                e.op(VX_OP_ADD, acc, bit, acc)
-        e.release(m1)
-    push(e.op(VX_OP_SUB, e.ldw(C.TA), sa), VX_AIR_ALL_ROWS)
-    push(e.op(VX_OP_SUB, e.ldw(C.TBB), sb), VX_AIR_ALL_ROWS)
-    push(e.op(VX_OP_SUB, e.ldw(C.TC), sc), VX_AIR_ALL_ROWS)
-    e.release(m0)
+    # ---- the XOR table, two halves: TA, TB and TC = TA ^ TB are tied to 16 bit columns — every row is a valid triple by construction ----
+    for k in range(NTAB):
+        m0 = e.top
+        sa, sb, sc = tmp(), tmp(), tmp()
+        for i in range(7, -1, -1):
+            m1 = e.top
+            a, b = e.ldw(C.tab(k, "BITS", i)), e.ldw(C.tab(k, "BITS", 8 + i))
+            x = e.op(VX_OP_MUL, a, b)
+            e.op(VX_OP_ADD, x, x, x)
+            sx = e.op(VX_OP_ADD, a, b)
+            e.op(VX_OP_SUB, sx, x, sx)                                   # a ^ b
+            for acc, bit in ((sa, a), (sb, b), (sc, sx)):
+                if i == 7:
+                    e.op(VX_OP_ADD, bit, ZERO, acc)
+                else:
+                    e.op(VX_OP_ADD, acc, acc, acc)
+                    e.op(VX_OP_ADD, acc, bit, acc)
+            e.release(m1)
+        push(e.op(VX_OP_SUB, e.ldw(C.tab(k, "TA")), sa), VX_AIR_ALL_ROWS)
+        push(e.op(VX_OP_SUB, e.ldw(C.tab(k, "TB")), sb), VX_AIR_ALL_ROWS)
+        push(e.op(VX_OP_SUB, e.ldw(C.tab(k, "TC")), sc), VX_AIR_ALL_ROWS)
+        e.release(m0)
     # ---- the lookups: every triple enters as a + beta b + beta^2 c ----
     m0 = e.top
     acc, accn = e.ldw(C.AUX_ACC), e.ldw(C.AUX_ACC, nxt=True)
@@ -514,12 +512,15 @@ def build_program():
         e.op(VX_OP_SUB, t, g1, t)
         push(t, VX_AIR_ALL_ROWS)                                         # h (g - t0)(g - t1) = (g - t0) + (g - t1)
         e.release(m1)
-    gt = gamma_minus((C.TA, C.TBB, C.TC))
-    ht = e.ldw(C.AUX_HT)
-    e.op(VX_OP_ADD, step, ht, step)
-    t = e.op(VX_OP_MUL, ht, gt)
-    push(e.op(VX_OP_SUB, t, e.ldw(C.MULT)), VX_AIR_ALL_ROWS)             # ht (g - table triple) = mult
-    push(step, VX_AIR_TRANSITION)                                        # acc' = acc + sum h - ht
+    for k in range(NTAB):
+        m1 = e.top
+        gt = gamma_minus((C.tab(k, "TA"), C.tab(k, "TB"), C.tab(k, "TC")))
+        ht = e.ldw(C.AUX_HT + k)
+        e.op(VX_OP_ADD, step, ht, step)
+        t = e.op(VX_OP_MUL, ht, gt)
+        push(e.op(VX_OP_SUB, t, e.ldw(C.tab(k, "MULT"))), VX_AIR_ALL_ROWS)   # ht_k (g - table triple) = mult_k
+        e.release(m1)
+    push(step, VX_AIR_TRANSITION)                                        # acc' = acc + sum h - ht_0 - ht_1
     push(acc, VX_AIR_FIRST_ROW)
     push(acc, VX_AIR_LAST_ROW)
     e.release(m0)
@@ -569,7 +570,7 @@ def generate_trace(degree_bits: int, messages) -> tuple:
     one after the other; the rows that remain keep hashing blocks of an endless zero-message (never final)."""
     C = Cols
     n = 1 << degree_bits
-    assert degree_bits >= 17, "the XOR table needs 65 536 rows before the last row"
+    assert degree_bits >= 16, "each half of the XOR table needs 32 768 rows before the last row"
     t = np.zeros((C.N, n), dtype=np.uint64)
     blocks = [blk for m in messages for blk in split_message(m)]
     nblocks = -(-n // PERIOD)
@@ -612,10 +613,10 @@ def generate_trace(degree_bits: int, messages) -> tuple:
                 e1 = _rotr(e2 ^ a2, 32)                  # tuple 3: e2_j = e1_{(j+4)%8} ^ a2_j
                 for name, val in (("A2", a2), ("B2", b2), ("C2", c2), ("E2", e2), ("E1", e1), ("A1", e1), ("F2", c2)):
                     put_bytes(C.f(j, name), val, row)
-            put_bytes(C.FA, tcount, row)
-            put_bytes(C.FB, IV[4], row)
-            put_bytes(C.FE, tcount ^ IV[4], row)
-            put_bytes(C.FO, tcount ^ IV[4], row)
+            put_bytes(C.fin(0, "FA"), tcount, row)
+            put_bytes(C.fin(0, "FB"), IV[4], row)
+            put_bytes(C.fin(0, "FE"), tcount ^ IV[4], row)
+            put_bytes(C.fin(0, "FO"), tcount ^ IV[4], row)
             put_limbs(C.HN, hn, row)
         # rows 1..24
         for s in range(ROW_G0, ROW_GLAST + 1):
@@ -643,20 +644,22 @@ def generate_trace(degree_bits: int, messages) -> tuple:
                 put_bytes(C.BY, m[s - 1], row)
         if base + 1 < n:                 # HN holds through the G rows
             t[C.HN:C.HN + 16, base + 1:min(n, base + ROW_GLAST + 1)] = np.array([x for w in hn for x in lim2(w)], dtype=np.uint64)[:, None]
-        # rows 25..32: finalisation
-        for k in range(8):
-            row = base + ROW_FIN0 + k
+        # rows 25, 26: finalisation, four words per row
+        for r in range(NFINROW):
+            row = base + ROW_FIN0 + r
             if row >= n:
                 break
             put_limbs(C.V, v, row)
-            put_bytes(C.FA, v[k], row)
-            put_bytes(C.FB, v[k + 8], row)
-            put_bytes(C.FE, v[k] ^ v[k + 8], row)
-            put_bytes(C.FH, h[k], row)
-            put_bytes(C.FO, v[k] ^ v[k + 8] ^ h[k], row)
             put_limbs(C.HN, hn, row)
             hn = list(hn)
-            hn[k] = v[k] ^ v[k + 8] ^ h[k]
+            for g in range(NFING):
+                k = 4 * r + g
+                put_bytes(C.fin(g, "FA"), v[k], row)
+                put_bytes(C.fin(g, "FB"), v[k + 8], row)
+                put_bytes(C.fin(g, "FE"), v[k] ^ v[k + 8], row)
+                put_bytes(C.fin(g, "FH"), h[k], row)
+                put_bytes(C.fin(g, "FO"), v[k] ^ v[k + 8] ^ h[k], row)
+                hn[k] = v[k] ^ v[k + 8] ^ h[k]
         row = base + ROW_HAND
         if row < n:
             put_limbs(C.HN, hn, row)
@@ -668,24 +671,25 @@ def generate_trace(degree_bits: int, messages) -> tuple:
             else:
                 h, tb_prev = list(hn), tcount
     rows = np.arange(n)
-    t[C.TA] = (rows >> 8) & 255
-    t[C.TBB] = rows & 255
-    t[C.TC] = t[C.TA] ^ t[C.TBB]
-    for i in range(8):
-        t[C.TBITS + i] = (t[C.TA] >> np.uint64(i)) & np.uint64(1)
-        t[C.TBITS + 8 + i] = (t[C.TBB] >> np.uint64(i)) & np.uint64(1)
     mult = np.zeros(65536, dtype=np.int64)
     for a, b, _ in tuples():
         idx = t[a, :n - 1].astype(np.int64) * 256 + (t[b, :n - 1].astype(np.int64) if b is not None else 0)
         mult += np.bincount(idx, minlength=65536)
-    t[C.MULT, :65536] = mult.astype(np.uint64)
+    for k in range(NTAB):                                     # half k, row i (repeating every 32 768 rows): a = 128 k + (i >> 8) % 128, b = i & 255
+        ta = np.uint64(128 * k) + ((rows >> 8) & 127).astype(np.uint64)
+        tb = (rows & 255).astype(np.uint64)
+        t[C.tab(k, "TA")], t[C.tab(k, "TB")], t[C.tab(k, "TC")] = ta, tb, ta ^ tb
+        for i in range(8):
+            t[C.tab(k, "BITS", i)] = (ta >> np.uint64(i)) & np.uint64(1)
+            t[C.tab(k, "BITS", 8 + i)] = (tb >> np.uint64(i)) & np.uint64(1)
+        t[C.tab(k, "MULT"), :TAB_ROWS] = mult[TAB_ROWS * k:TAB_ROWS * (k + 1)].astype(np.uint64)
     pis = np.array([x for w in dlatch for x in lim2(w)], dtype=np.uint64)
     _ = filler_t
     return t, pis, digests
 
 
 def aux_columns(trace, chal):
-    """second-round columns [92 pair helpers, ht, acc] for the challenges [gamma, beta]"""
+    """second-round columns [116 pair helpers, ht of each half table, acc] for the challenges [gamma, beta]"""
     C = Cols
     n = trace.shape[1]
     g, beta = int(chal[0]) % P, int(chal[1]) % P
@@ -720,20 +724,22 @@ def aux_columns(trace, chal):
         h = hf.addmod(inv[2 * q], inv[2 * q + 1])
         out[q] = h
         step = hf.addmod(step, h)
-    tv, tbv, tcv = trace[C.TA], trace[C.TBB], trace[C.TC]
-    okt = (tv < 256) & (tbv < 256) & (tcv == (tv ^ tbv))
-    it = tab[((tv & np.uint64(255)) * np.uint64(256) + (tbv & np.uint64(255))).astype(np.int64)].copy()
-    if not okt.all():
-        bad = np.nonzero(~okt)[0]
-        it[bad] = hf.invmod(hf.submod(np.full(bad.size, g, dtype=np.uint64), triple(tv[bad], tbv[bad], tcv[bad])))
-    ht = hf.mulmod(trace[C.MULT] % np.uint64(P), it)
-    out[C.NPAIR] = ht
-    out[C.NPAIR + 1], _ = hf.exclusive_prefix_sum(hf.submod(step, ht))
+    for k in range(NTAB):
+        tv, tbv, tcv = trace[C.tab(k, "TA")], trace[C.tab(k, "TB")], trace[C.tab(k, "TC")]
+        okt = (tv < 256) & (tbv < 256) & (tcv == (tv ^ tbv))
+        it = tab[((tv & np.uint64(255)) * np.uint64(256) + (tbv & np.uint64(255))).astype(np.int64)].copy()
+        if not okt.all():
+            bad = np.nonzero(~okt)[0]
+            it[bad] = hf.invmod(hf.submod(np.full(bad.size, g, dtype=np.uint64), triple(tv[bad], tbv[bad], tcv[bad])))
+        ht = hf.mulmod(trace[C.tab(k, "MULT")] % np.uint64(P), it)
+        out[C.NPAIR + k] = ht
+        step = hf.submod(step, ht)
+    out[C.NPAIR + NTAB], _ = hf.exclusive_prefix_sum(step)
     return out
 
 
 def aux_program():
-    """the GPU form of `aux_columns` (vx_stark_aux_columns): 92 pair helpers + the table term as fractions, one running sum that closes at 0"""
+    """the GPU form of `aux_columns` (vx_stark_aux_columns): 116 pair helpers + the two table terms as fractions, one running sum that closes at 0"""
     from . import AuxProgram
     C = Cols
     e = _Emit(scratch=40)
@@ -761,18 +767,19 @@ def aux_program():
         e.push(e.op(VX_OP_ADD, g0, g1), 0)
         e.push(e.op(VX_OP_MUL, g0, g1), 0)
         e.release(m0)
-    m0 = e.top
-    gt = e.tmp()
-    gamma_minus((C.TA, C.TBB, C.TC), gt)
-    e.push(e.ldw(C.MULT), 0)
-    e.push(gt, 0)
-    e.release(m0)
+    for k in range(NTAB):
+        m0 = e.top
+        gt = e.tmp()
+        gamma_minus((C.tab(k, "TA"), C.tab(k, "TB"), C.tab(k, "TC")), gt)
+        e.push(e.ldw(C.tab(k, "MULT")), 0)
+        e.push(gt, 0)
+        e.release(m0)
     e.ins(VX_OP_END)
-    return AuxProgram(C.N, 2, e.w, C.NPAIR + 1, [[1] * C.NPAIR + [-1]], api_sums=())
+    return AuxProgram(C.N, 2, e.w, C.NPAIR + NTAB, [[1] * C.NPAIR + [-1] * NTAB], api_sums=())
 
 
 def make_stark(degree_bits: int, **cfg) -> Stark:
-    assert degree_bits >= 17
+    assert degree_bits >= 16
     prog, _ = build_program()
     cfg.setdefault("rate_bits", 1)
     st = Stark(degree_bits, Cols.N, 8, prog, constraint_degree=3, num_aux_columns=Cols.NAUX, num_aux_challenges=2, aux_fn=aux_columns, **cfg)

@@ -356,6 +356,30 @@ __global__ __launch_bounds__(NTT2_THREADS) void ntt2_pass_kernel(Ntt2Params p) {
       }
     }
   } else {
+#ifdef VX_NTT2_DIRECT_STORE
+    // EXPERIMENT (round 4, VERDICT r3 #7's bounded attempt): the last contiguous round stores straight from registers — the 2^EL outputs
+    // of a thread's DFT are 2^EL CONSECUTIVE words of the output (LO = 0), so the LDS write-back, the barrier and the copy loop go away;
+    // the price is 64-byte-per-lane stores (a wave still covers 4 KB contiguous, in 2^EL / 2 instructions of 16 B per lane at a 64 B stride)
+    constexpr u32 n_groups = 1u << (NTT2_TILE_LOG - EL);
+#pragma unroll
+    for (u32 g0 = 0; g0 < n_groups; g0 += NTT2_THREADS) {
+      const u32 g = g0 + threadIdx.x;
+      const u32 base_high = g & ((1u << (R_LOG - EL)) - 1);
+      const u32 t = g >> (R_LOG - EL);
+      const u32 m0 = base_high << EL;
+      u64 x[1 << EL];
+#pragma unroll
+      for (int q = 0; q < (1 << EL); ++q) x[q] = tile[tile_idx<R_LOG, false>(m0 | (u32)q, t)];
+      dft_regs<EL, INV>(x);
+      u64* dst = out + base + (((size_t)t << R_LOG) | m0);
+#pragma unroll
+      for (int q = 0; q < (1 << EL); q += 2) {
+        u64 v0 = x[q], v1 = x[q + 1];
+        if (p.post_scale != 1) v0 = gl_mul(v0, p.post_scale), v1 = gl_mul(v1, p.post_scale);
+        *reinterpret_cast<ulonglong2*>(dst + q) = make_ulonglong2(v0, v1);
+      }
+    }
+#else
     ntt2_round_lds<R_LOG, 0, EL, false, INV>(tile, W);
     __syncthreads();
     for (u32 idx = threadIdx.x * 2; idx < TILE; idx += NTT2_THREADS * 2) {  // 16 bytes per lane
@@ -363,5 +387,6 @@ __global__ __launch_bounds__(NTT2_THREADS) void ntt2_pass_kernel(Ntt2Params p) {
       if (p.post_scale != 1) v0 = gl_mul(v0, p.post_scale), v1 = gl_mul(v1, p.post_scale);
       *reinterpret_cast<ulonglong2*>(out + base + idx) = make_ulonglong2(v0, v1);
     }
+#endif
   }
 }

@@ -306,7 +306,7 @@ def bench_table(ctx, stark, trace, public_inputs, name: str, steps: int = 3, war
     return rec
 
 
-def bench_blake2b_bytes(ctx, log_n: int = 17, steps: int = 3, warmup: int = 1, compressions: int = 2240) -> dict:
+def bench_blake2b_bytes(ctx, log_n: int = 16, steps: int = 3, warmup: int = 1, compressions: int = 2240) -> dict:
     """the byte / XOR-lookup BLAKE2b table (blake2b_bytes_air.py) loaded like a header_range map job: 8 headers of 280 blocks"""
     from . import blake2b_bytes_air as b2
     t0 = time.perf_counter()
