@@ -25,6 +25,8 @@ struct AuxFracParams {
   u64* out;                // [num_out][n]
   size_t n;
   int ncols, nfrac;
+  int parts;               // blockIdx.y = part: every thread interprets the whole program (cheap) but inverts and stores only the fractions
+                           // k with k % parts == part — short traces get `parts` times the waves and a `parts` times shorter chain of inversions
   u64 chal[VX_AUX_MAX_CHALLENGES];
 };
 __global__ __launch_bounds__(256) void aux_fraction_kernel(AuxFracParams p) {
@@ -34,6 +36,7 @@ __global__ __launch_bounds__(256) void aux_fraction_kernel(AuxFracParams p) {
   const u64* __restrict__ prog = p.program;
   u64 num = 0;
   int pushes = 0;
+  const int part = (int)blockIdx.y;
   for (int pc = 0;; ++pc) {
     const u64 ins = prog[pc];
     const int op = (int)(ins & 0xFF), dst = (int)((ins >> 8) & 63), a = (int)((ins >> 16) & 0xFFFF), b = (int)((ins >> 32) & 0xFFFF);
@@ -51,7 +54,7 @@ __global__ __launch_bounds__(256) void aux_fraction_kernel(AuxFracParams p) {
           num = v;
         } else {
           const int k = pushes >> 1;
-          if (k < p.nfrac) p.out[(size_t)p.frac_out[k] * p.n + i] = gl_mul(num, gl_inv(v));   // den = 0: gl_inv(0) = 0, the fraction is 0
+          if (k < p.nfrac && k % p.parts == part) p.out[(size_t)p.frac_out[k] * p.n + i] = gl_mul(num, gl_inv(v));   // den = 0: gl_inv(0) = 0, the fraction is 0
         }
         ++pushes;
         break;

@@ -357,7 +357,8 @@ __global__ __launch_bounds__(NTT2_THREADS) void ntt2_pass_kernel(Ntt2Params p) {
     }
   } else {
 #ifdef VX_NTT2_DIRECT_STORE
-    // EXPERIMENT (round 4, VERDICT r3 #7's bounded attempt): the last contiguous round stores straight from registers — the 2^EL outputs
+    // EXPERIMENT (round 4, VERDICT r3 #7's bounded attempt; MEASURED 2 % SLOWER, not adopted: profiles/r04_ntt_experiment.md) — the last
+    // contiguous round stores straight from registers: the 2^EL outputs
     // of a thread's DFT are 2^EL CONSECUTIVE words of the output (LO = 0), so the LDS write-back, the barrier and the copy loop go away;
     // the price is 64-byte-per-lane stores (a wave still covers 4 KB contiguous, in 2^EL / 2 instructions of 16 B per lane at a 64 B stride)
     constexpr u32 n_groups = 1u << (NTT2_TILE_LOG - EL);

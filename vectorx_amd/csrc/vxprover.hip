@@ -1041,7 +1041,11 @@ int vx_stark_aux_columns(vx_ctx* c, const vx_aux_desc* d, const uint64_t* trace_
       memset(&fp, 0, sizeof fp);
       fp.trace = trace_dev, fp.program = d_prog, fp.frac_out = d_fo, fp.out = out_dev, fp.n = n, fp.ncols = d->num_columns, fp.nfrac = nf;
       for (int i = 0; i < d->num_challenges; ++i) fp.chal[i] = vxh::canon(challenges[i]);
-      hipLaunchKernelGGL(aux_fraction_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, fp);
+      // short traces: fewer than ~4 waves per SIMD (1024 SIMDs x 64 lanes) -> split the fractions over up to 8 parts
+      int parts = (int)(((size_t)4 * 1024 * 64 + n - 1) / n);
+      parts = std::max(1, std::min(std::min(parts, 8), nf));
+      fp.parts = parts;
+      hipLaunchKernelGGL(aux_fraction_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)parts), dim3(256), 0, c->stream, fp);
       HIPCHK(hipGetLastError());
     }
     if (ns) {
