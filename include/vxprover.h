@@ -382,6 +382,9 @@ typedef struct vx_aux_desc {
 } vx_aux_desc;
 int vx_stark_aux_columns(vx_ctx* ctx, const vx_aux_desc* desc, const uint64_t* trace_dev, int degree_bits, const uint64_t* challenges,
                          uint64_t* out_dev, uint64_t* closing_sums_out);
+/* The program is compiled to native gfx950 code with hiprtc on first use (same cache as gate / AIR programs; VX_NO_JIT=1 keeps the
+ * on-GPU interpreter); this compiles it ahead of time, without a GPU: 1 = compiled now, 0 = already cached, negative VX_E_*. */
+int vx_stark_aux_precompile(const vx_aux_desc* desc);
 int vx_stark_verify(const vx_stark_desc* desc, const uint64_t* public_inputs, const uint8_t* proof, size_t proof_len);
 /* The same for the constraint-program gates of a circuit (one kernel per program gate): returns the number compiled now. */
 int vx_circuit_precompile(const vx_circuit_desc* desc, int* num_program_gates_out);

@@ -112,6 +112,7 @@ _SIGNATURES = {
     "vx_stark_begin_sharded": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, ctypes.POINTER(_vp)]),
     "vx_stark_session_free": (None, [_vp]),
     "vx_stark_aux_columns": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp]),
+    "vx_stark_aux_precompile": (_i, [_vp]),
     "vx_stark_precompile": (_i, [_vp, ctypes.POINTER(_i)]),
     "vx_circuit_precompile": (_i, [_vp, ctypes.POINTER(_i)]),
     "vx_stark_session_trace_cap": (_i, [_vp, _vp]),
@@ -688,6 +689,13 @@ class AuxProgram:
         self.desc = AuxDesc(num_columns, num_challenges, num_fractions, co.shape[0], len(program), ctypes.cast(self._prog, ctypes.c_void_p).value,
                             co.ctypes.data if co.size else None, None if self._fo is None else self._fo.ctypes.data,
                             None if self._so is None else self._so.ctypes.data)
+
+    def precompile(self) -> int:
+        """`vx_stark_aux_precompile`: compile the program with hiprtc into the cache (no GPU needed) -> 1 compiled now, 0 cached"""
+        rc = lib().vx_stark_aux_precompile(ctypes.byref(self.desc))
+        if rc < 0:
+            _chk(rc)
+        return rc
 
     def run(self, ctx, d_trace: int, degree_bits: int, challenges, d_out: int) -> np.ndarray:
         """-> the closing sums of the running sums (all of them); the columns are written to device memory at `d_out`"""

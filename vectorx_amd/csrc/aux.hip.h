@@ -5,8 +5,9 @@
 // the host in numpy they cost 10 - 20 x the proof they belong to (1.65 s for the 2^20-row EdDSA table against a 94 ms proof); here the
 // expressions arrive as one more VX_OP program and the columns are produced where the trace already lives:
 //   aux_fraction_kernel   one thread per row interprets the program (VX_OP_LDW local trace value, VX_OP_LDCH challenge, LDI / ADD / SUB /
-//                         MUL; every pair of PUSHes = numerator, denominator of the next fraction) and writes num * den^-1 — one Fermat
-//                         inversion per fraction per row: 5 * 10^7 of them for that table, a few ms of integer ALU;
+//                         MUL; every pair of PUSHes = numerator, denominator of the next fraction) and writes num * den^-1 — the
+//                         denominators of a row inverted 8 at a time (Montgomery's trick: one Fermat inversion per batch); on short
+//                         traces the fractions are dealt to several threads per row (blockIdx.y) so that the chip has waves to run;
 //   aux_rowsum_kernel     the signed combination of a row's fractions that each running sum accumulates;
 //   aux_scan_*            the EXCLUSIVE prefix sum over rows (mod p) in three phases: thread-sequential runs of 16, an LDS scan of the
 //                         block's 256 run totals, a scan of the block totals, and the offsets added back.
@@ -29,6 +30,7 @@ struct AuxFracParams {
                            // k with k % parts == part — short traces get `parts` times the waves and a `parts` times shorter chain of inversions
   u64 chal[VX_AUX_MAX_CHALLENGES];
 };
+#define VX_AUX_BATCH 8   /* fractions inverted together (Montgomery's trick): one Fermat inversion + 3 multiplications each instead of ~75 */
 __global__ __launch_bounds__(256) void aux_fraction_kernel(AuxFracParams p) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= p.n) return;
@@ -37,6 +39,23 @@ __global__ __launch_bounds__(256) void aux_fraction_kernel(AuxFracParams p) {
   u64 num = 0;
   int pushes = 0;
   const int part = (int)blockIdx.y;
+  u64 bn[VX_AUX_BATCH], bd[VX_AUX_BATCH], pre[VX_AUX_BATCH];
+  int bk[VX_AUX_BATCH], cnt = 0;
+  auto flush = [&]() {                      // a zero denominator takes part as 1 and yields the fraction 0 (what gl_inv(0) = 0 gave)
+    u64 acc = 1;
+    for (int j = 0; j < cnt; ++j) {
+      pre[j] = acc;
+      acc = gl_mul(acc, bd[j] ? bd[j] : 1);
+    }
+    u64 inv = gl_inv(acc);
+    for (int j = cnt - 1; j >= 0; --j) {
+      const u64 d = bd[j] ? bd[j] : 1;
+      const u64 dinv = gl_mul(inv, pre[j]);
+      inv = gl_mul(inv, d);
+      p.out[(size_t)p.frac_out[bk[j]] * p.n + i] = bd[j] ? gl_mul(bn[j], dinv) : 0;
+    }
+    cnt = 0;
+  };
   for (int pc = 0;; ++pc) {
     const u64 ins = prog[pc];
     const int op = (int)(ins & 0xFF), dst = (int)((ins >> 8) & 63), a = (int)((ins >> 16) & 0xFFFF), b = (int)((ins >> 32) & 0xFFFF);
@@ -54,7 +73,10 @@ __global__ __launch_bounds__(256) void aux_fraction_kernel(AuxFracParams p) {
           num = v;
         } else {
           const int k = pushes >> 1;
-          if (k < p.nfrac && k % p.parts == part) p.out[(size_t)p.frac_out[k] * p.n + i] = gl_mul(num, gl_inv(v));   // den = 0: gl_inv(0) = 0, the fraction is 0
+          if (k < p.nfrac && k % p.parts == part) {
+            bn[cnt] = num, bd[cnt] = v, bk[cnt] = k;
+            if (++cnt == VX_AUX_BATCH) flush();
+          }
         }
         ++pushes;
         break;
@@ -62,6 +84,7 @@ __global__ __launch_bounds__(256) void aux_fraction_kernel(AuxFracParams p) {
       default: break;
     }
   }
+  if (cnt) flush();
 }
 
 struct AuxSumParams {

@@ -119,6 +119,13 @@ static std::vector<JitIns> jit_decode(const uint64_t* prog) {
   }
   return code;
 }
+// aux mode (jit_aux_source): PUSHes are (numerator, denominator) pairs of fractions, inverted in batches of VX_AUX_JIT_BATCH
+#define VX_AUX_JIT_BATCH 8
+struct JitAuxMode {
+  bool on = false;
+  int nfrac = 0;
+};
+static thread_local JitAuxMode g_jit_aux;
 static void jit_emit_code(std::ostringstream& s, std::vector<JitIns> code, int nch, bool air, int air_ncols);
 static void jit_emit_program(std::ostringstream& s, const uint64_t* prog, int nch, bool air, int air_ncols = 0) {
   jit_emit_code(s, jit_decode(prog), nch, air, air_ncols);
@@ -208,7 +215,28 @@ static void jit_emit_code(std::ostringstream& s, std::vector<JitIns> code, int n
         break;
       case VX_OP_MUL: s << "  R[" << I.dst << "] = gl_mul_nc(R[" << I.a << "], R[" << I.b << "]);\n"; canon_reg[I.dst] = false; break;
       case VX_OP_PUSH:
-        if (air) {
+        if (g_jit_aux.on) {
+          // fraction f = k / 2: numerator (any representative) then denominator (canonical: tested against zero); after every
+          // VX_AUX_JIT_BATCH denominators — or the last one — the batch is inverted with ONE Fermat inversion (Montgomery's trick)
+          const int f = k / 2;
+          if ((k & 1) == 0) {
+            s << "  const u64 num" << f << " = R[" << I.a << "];\n";
+          } else {
+            need_canon(I.a);
+            s << "  const u64 den" << f << " = R[" << I.a << "];\n";
+            const bool last = f + 1 == g_jit_aux.nfrac;
+            if ((f + 1) % VX_AUX_JIT_BATCH == 0 || last) {
+              const int f0 = f - (f % VX_AUX_JIT_BATCH);
+              s << "  {\n    u64 acc = 1;\n";
+              for (int j = f0; j <= f; ++j) s << "    const u64 z" << j << " = den" << j << " ? den" << j << " : 1; const u64 pre" << j << " = acc; acc = gl_mul(acc, z" << j << ");\n";
+              s << "    u64 inv = aux_inv(acc);\n";
+              for (int j = f; j >= f0; --j)
+                s << "    { const u64 di = gl_mul(inv, pre" << j << "); inv = gl_mul(inv, z" << j << "); p.out[(size_t)p.frac_out[" << j << "] * p.n + il] = den" << j
+                  << " ? gl_mul(num" << j << ", di) : 0; }\n";
+              s << "  }\n";
+            }
+          }
+        } else if (air) {
           const char* factor = I.b == VX_AIR_TRANSITION ? "z_last" : I.b == VX_AIR_FIRST_ROW ? "l_first" : I.b == VX_AIR_LAST_ROW ? "l_last" : nullptr;
           if (factor) s << "  { const u64 t = gl_mul_nc(R[" << I.a << "], " << factor << ");\n";
           else s << "  { const u64 t = R[" << I.a << "];\n";
@@ -761,4 +789,84 @@ static int jit_gates_precompile(const std::vector<const uint64_t*>& progs, int n
   std::vector<const std::string*> srcs;
   for (const std::string& k : keep) srcs.push_back(&k);
   return jit_precompile_sources(srcs, why);
+}
+
+// ---- the second-round column programs (aux.hip.h / vx_stark_aux_columns) compiled like AIR programs: one kernel per program ----
+static std::string jit_aux_source(const uint64_t* prog, int nfrac) {
+  std::ostringstream s;
+  s << "typedef unsigned long long uint64_t;\ntypedef unsigned int uint32_t;\n" << jit_limits_defines() << "#define VX_AUX_MAX_CHALLENGES " << VX_AUX_MAX_CHALLENGES
+    << "\n" << JIT_PRELUDE << R"VXJIT(
+struct AuxFracParams {
+  const u64* trace;
+  const u64* program;
+  const int* frac_out;
+  u64* out;
+  size_t n;
+  int ncols, nfrac;
+  int parts;
+  u64 chal[VX_AUX_MAX_CHALLENGES];
+};
+__device__ __noinline__ u64 aux_inv(u64 a) { return gl_inv(a); }
+extern "C" __global__ __launch_bounds__(256) void vx_aux_fractions(AuxFracParams p) {
+  const size_t il = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (il >= p.n) return;
+  const u64* __restrict__ W = p.trace;
+  const size_t SW = p.n;
+  u64 R[VX_PROGRAM_REGS];
+)VXJIT";
+  g_jit_aux.on = true;
+  g_jit_aux.nfrac = nfrac;
+  jit_emit_code(s, jit_decode(prog), 1, false, 0);
+  g_jit_aux.on = false;
+  s << "}\n";
+  return s.str();
+}
+static int jit_aux_precompile(const uint64_t* prog, int nfrac, std::string* why) {
+  if (!jit_api().ok) {
+    *why = "libhiprtc.so not available";
+    return -1;
+  }
+  const std::string src = jit_aux_source(prog, nfrac);
+  return jit_precompile_sources({&src}, why);
+}
+// the loaded kernel of an aux program on `device`, or nullptr (interpreter): compiled once per (program, device), failures remembered
+static hipFunction_t jit_aux_get(const uint64_t* prog, int nfrac, int device, std::string* why) {
+  if (getenv("VX_NO_JIT")) {
+    *why = "VX_NO_JIT is set";
+    return nullptr;
+  }
+  if (!jit_api().ok) {
+    *why = "libhiprtc.so not available";
+    return nullptr;
+  }
+  struct Entry {
+    std::mutex m;
+    bool done = false;
+    hipFunction_t fn = nullptr;
+    std::string why;
+  };
+  static std::mutex mu;
+  static std::map<std::vector<uint64_t>, std::shared_ptr<Entry>> loaded;
+  std::vector<uint64_t> key = {(uint64_t)nfrac, (uint64_t)device};
+  for (int pc = 0;; ++pc) {
+    key.push_back(prog[pc]);
+    if ((prog[pc] & 0xFF) == VX_OP_END) break;
+    if ((prog[pc] & 0xFF) == VX_OP_LDI) key.push_back(prog[++pc]);
+  }
+  std::shared_ptr<Entry> e;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    std::shared_ptr<Entry>& slot = loaded[key];
+    if (!slot) slot = std::make_shared<Entry>();
+    e = slot;
+  }
+  std::lock_guard<std::mutex> lk(e->m);
+  if (e->done) {
+    if (!e->fn) *why = e->why;
+    return e->fn;
+  }
+  e->done = true;
+  e->fn = jit_get_kernel(jit_aux_source(prog, nfrac), "vx_aux_fractions", device, why);
+  if (!e->fn) e->why = *why;
+  return e->fn;
 }

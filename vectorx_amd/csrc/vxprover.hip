@@ -7,11 +7,11 @@
 #include <condition_variable>
 #include <mutex>
 #include "plonk_kernels.hip.h"
+#include "aux.hip.h"
 #include "jit.hip.h"
 #include "prover.hip.h"
 #include "circuit_io.h"
 #include "stark.hip.h"
-#include "aux.hip.h"
 #include <memory>
 #include <cstddef>
 #include "verifier.h"
@@ -973,6 +973,28 @@ int vx_stark_finish2(vx_stark_session* s, const uint64_t* aux_columns, int aux_o
   return VX_OK;
 }
 void vx_stark_session_free(vx_stark_session* s) { delete s; }
+// Compile an aux program ahead of time (no GPU): -> 1 if compiled now, 0 if it was cached, negative VX_E_*.
+int vx_stark_aux_precompile(const vx_aux_desc* d) {
+  if (!d || !d->program || d->program_len < 1 || d->num_fractions < 1) return vx_fail(VX_E_INVALID, "vx_stark_aux_precompile: bad argument");
+  try {
+    bool ended = false;
+    for (int pc = 0; pc < d->program_len; ++pc) {
+      const int op = (int)(d->program[pc] & 0xFF);
+      if (op == VX_OP_END) {
+        ended = true;
+        break;
+      }
+      if (op == VX_OP_LDI) ++pc;
+    }
+    if (!ended) return vx_fail(VX_E_INVALID, "vx_stark_aux_precompile: the program does not END");
+    std::string why;
+    const int rc = jit_aux_precompile(d->program, d->num_fractions, &why);
+    if (rc < 0) return vx_fail(VX_E_INVALID, "vx_stark_aux_precompile: %s", why.c_str());
+    return rc;
+  } catch (const std::exception& e) {
+    return vx_fail(VX_E_INVALID, "vx_stark_aux_precompile: %s", e.what());
+  }
+}
 // The caller's second-round columns computed on the device (aux.hip.h): fractions num / den of per-row expressions + running sums.
 int vx_stark_aux_columns(vx_ctx* c, const vx_aux_desc* d, const uint64_t* trace_dev, int degree_bits, const uint64_t* challenges,
                          uint64_t* out_dev, uint64_t* closing_sums_out) {
@@ -1045,7 +1067,17 @@ int vx_stark_aux_columns(vx_ctx* c, const vx_aux_desc* d, const uint64_t* trace_
       int parts = (int)(((size_t)4 * 1024 * 64 + n - 1) / n);
       parts = std::max(1, std::min(std::min(parts, 8), nf));
       fp.parts = parts;
-      hipLaunchKernelGGL(aux_fraction_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)parts), dim3(256), 0, c->stream, fp);
+      // the program compiled to native code (jit.hip.h::jit_aux_source: registers in VGPRs, fused multiply-adds, the denominators
+      // inverted 8 at a time) — the interpreter walks ~400 cycles per instruction per wavefront; it stays as the fallback (VX_NO_JIT=1)
+      std::string why;
+      hipFunction_t fn = jit_aux_get(d->program, nf, c->device, &why);
+      if (fn) {
+        fp.parts = 1;
+        void* args[] = {&fp};
+        HIPCHK(hipModuleLaunchKernel(fn, (unsigned)((n + 255) / 256), 1, 1, 256, 1, 1, 0, c->stream, args, nullptr));
+      } else {
+        hipLaunchKernelGGL(aux_fraction_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)parts), dim3(256), 0, c->stream, fp);
+      }
       HIPCHK(hipGetLastError());
     }
     if (ns) {
