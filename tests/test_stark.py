@@ -141,6 +141,14 @@ def test_programs_can_be_compiled_ahead_of_time_without_a_gpu():
     sc.desc.num_gates = 0
     with pytest.raises(vx.VxError):
         vx.circuit_precompile(sc.desc_ptr)
+    # the second-round (aux) programs compile ahead of time too (vx_stark_aux_precompile): one kernel per program
+    from vectorx_amd import eddsa_air, sha256_air
+    for ap in (sha256_air.make_stark(8).aux_program, eddsa_air.make_stark(eddsa_air.Layout(8, 32), 12).aux_program):
+        assert ap.precompile() in (0, 1) and ap.precompile() == 0
+    ap = sha256_air.make_stark(8).aux_program
+    ap.desc.num_fractions = 0
+    with pytest.raises(vx.VxError):
+        ap.precompile()
 
 
 def test_second_round_is_repeated_per_challenge_set(oracle):
