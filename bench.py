@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--poseidon-percent", type=int, default=50, help="share of PoseidonGate rows in the synthetic circuit")
     ap.add_argument("--no-dag-leg", action="store_true",
                     help="skip the extra (untimed-by-the-contract) leg that proves one whole header_range_512 DAG: 64 map + 63 reduce + 1 outer proofs")
+    ap.add_argument("--multi-rank-leg-deadline", type=float, default=900.0,
+                    help="seconds the world > 1 legs may take together before every rank gives up on them and rank 0 prints the line without them")
     ap.add_argument("--no-dag-stark-leg", action="store_true",
                     help="skip the extra leg that proves the header_range_512 DAG WITH the STARK tables of every job (BLAKE2b / SHA-256 / SHA-512 / batched EdDSA)")
     ap.add_argument("--no-chip-leg", action="store_true",
@@ -132,9 +134,17 @@ def launch_ranks(args) -> int:
     if r.returncode == 0 and line is None:
         print("bench.py: the ranks exited 0 but rank 0 printed no result line", file=sys.stderr)
         return 4
-    if line is not None and r.returncode == 0:
-        print(line, flush=True)
-    return r.returncode
+    if line is None:
+        return r.returncode
+    if r.returncode != 0:
+        # rank 0 prints its line once the timed region and every single-rank leg are complete; only the multi-rank legs and the teardown come
+        # after it.  A rank lost there must not cost the measurement: the line goes out, carrying the launcher's exit code.
+        d = json.loads(line)
+        d["ranks_exit_code_after_the_line"] = r.returncode
+        line = json.dumps(d)
+        print(f"bench.py: the ranks ended with exit code {r.returncode} AFTER rank 0 had printed its line", file=sys.stderr)
+    print(line, flush=True)
+    return 0
 
 
 def main():
@@ -238,14 +248,7 @@ def main():
     # (`value`), the strong-scaling point (one 2^21 proof over all N ranks = BASELINE configs[3]) and the real unit of work (one
     # header_range_512 DAG over all N ranks: /root/reference/circuits/builder/subchain_verification.rs:72-78).  Collective:
     # every rank takes part; an error on any rank is reported by rank 0 instead of costing the contract's line.
-    sharded_leg = dag_n_leg = dag_n_stark_leg = None
-    if args.workload == "prove" and world > 1 and not args.no_multi_rank_legs and not args.circuit_flags:
-        dev = None if on_host else torch.device("cuda", local_rank)
-        sharded_leg = bench_prove.guarded_collective_leg(dist, lambda: bench_prove.sharded_one_proof_leg(ctx, args, rank, world, dist, dev, sync))
-        dag_n_leg = bench_prove.guarded_collective_leg(dist, lambda: bench_prove.dag_leg_ranks(ctx, args, local_rank, dist, dev))
-        if not args.no_dag_stark_leg:
-            dag_n_stark_leg = bench_prove.guarded_collective_leg(dist, lambda: bench_prove.dag_leg_ranks(ctx, args, local_rank, dist, dev, with_starks=True))
-
+    out = None
     if rank == 0:
         lde = prof.get("lde", {"ms": 0.0, "calls": 0, "alg_bytes": 0.0})
         roof = None
@@ -341,12 +344,6 @@ def main():
             out["dag_header_range_512"] = dag_leg
         if dag_stark_leg is not None:
             out["dag_header_range_512_with_starks"] = dag_stark_leg
-        if sharded_leg is not None:
-            out["sharded_one_proof"] = sharded_leg
-        if dag_n_leg is not None:
-            out["dag_header_range_512"] = dag_n_leg
-        if dag_n_stark_leg is not None:
-            out["dag_header_range_512_with_starks"] = dag_n_stark_leg
         if args.ranks_on_one_device:
             out["emulated_ranks_on_one_device"] = ("EVERY RANK IS A PROCESS ON DEVICE 0 over gloo: exercises the N > 1 code path on a single-GPU box; "
                                                    "no figure in this line is a multi-GPU measurement")
@@ -354,7 +351,53 @@ def main():
             out["chip_starks"] = chip_leg
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline_commit(args) if args.workload == "commit" else bench_prove.cpu_baseline(args)
-        print(json.dumps(out), flush=True)
+
+    # The contract's line is complete at this point.  The legs below are collective, and a rank that hangs inside one (a lost peer, a
+    # wedged collective) would otherwise take the line with it: a watchdog in EVERY rank ends the process cleanly at the deadline, rank 0
+    # printing the line without the legs first.
+    import threading
+    line_lock = threading.Lock()
+    state = {"printed": False}
+
+    def emit_line():
+        with line_lock:
+            if rank == 0 and not state["printed"]:
+                print(json.dumps(out), flush=True)
+            state["printed"] = True
+
+    def give_up(why=None):
+        if rank == 0:
+            why = why or f"the multi-rank legs did not finish within {args.multi_rank_leg_deadline} s"
+            out["multi_rank_legs"] = {"error": why + "; everything else in this line is complete"}
+        emit_line()
+        os._exit(0)
+
+    sharded_leg = dag_n_leg = dag_n_stark_leg = None
+    watchdog = None
+    if args.workload == "prove" and world > 1 and not args.no_multi_rank_legs and not args.circuit_flags:
+        watchdog = threading.Timer(args.multi_rank_leg_deadline, give_up)
+        watchdog.daemon = True
+        watchdog.start()
+        import signal
+        # a launcher that loses one rank sends the others SIGTERM: rank 0 answers with the line (the handler runs as soon as the main
+        # thread is back in Python, which every leg is between its library calls)
+        signal.signal(signal.SIGTERM, lambda *_: give_up("the launcher ended the ranks (SIGTERM) during the multi-rank legs"))
+        dev = None if on_host else torch.device("cuda", local_rank)
+        sharded_leg = bench_prove.guarded_collective_leg(dist, lambda: bench_prove.sharded_one_proof_leg(ctx, args, rank, world, dist, dev, sync))
+        dag_n_leg = bench_prove.guarded_collective_leg(dist, lambda: bench_prove.dag_leg_ranks(ctx, args, local_rank, dist, dev))
+        if not args.no_dag_stark_leg:
+            dag_n_stark_leg = bench_prove.guarded_collective_leg(dist, lambda: bench_prove.dag_leg_ranks(ctx, args, local_rank, dist, dev, with_starks=True))
+
+    if watchdog is not None:
+        watchdog.cancel()
+    if rank == 0:
+        if sharded_leg is not None:
+            out["sharded_one_proof"] = sharded_leg
+        if dag_n_leg is not None:
+            out["dag_header_range_512"] = dag_n_leg
+        if dag_n_stark_leg is not None:
+            out["dag_header_range_512_with_starks"] = dag_n_stark_leg
+    emit_line()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -373,6 +373,17 @@ def test_bench_multi_rank_code_path_on_one_device(world):
         assert ds["root"] != line["dag_header_range_512"]["root"]          # the STARK proofs are part of every job's digest
 
 
+def test_bench_line_survives_multi_rank_legs_that_never_finish():
+    """a collective leg that hangs must not cost the contract's line: at the deadline every rank ends cleanly, rank 0 having printed the
+    line without the legs (here the deadline is already over when the legs start)"""
+    r = _plain_bench("--gpus", "2", "--ranks-on-one-device", "--log-n", "12", "--dag-spec", "4,10,9,11", "--multi-rank-leg-deadline", "0.001")
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and "did not finish" in line["multi_rank_legs"]["error"]
+
+
 def test_bench_refuses_more_gpus_than_visible():
     """asking for more GPUs than the box has must fail loudly — never a smaller run that prints a result line"""
     n = vx.lib().vx_device_count()
