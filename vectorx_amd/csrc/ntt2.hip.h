@@ -50,7 +50,20 @@ GLD u64 gl_mul_2exp(u64 x) {
   } else if constexpr (S < 64) {
     return gl_reduce128(x << S, x >> (64 - S));
   } else {
+#ifdef VX_NTT2_NO_SHIFT64
     return gl_mul(x, gl_pow2_const(S));
+#else
+    // S = 64 + k:  x 2^k = Yh 2^32 + y0  (y0 = its low 32 bits, Yh = x >> (32 - k) < 2^63)  =>  x 2^S = y0 2^64 + Yh 2^96 = y0 EPS - Yh.
+    // y0 EPS <= (2^32 - 1)^2 < p and Yh < p, so one canonical subtraction finishes it: 8 instructions against the 17 of a general multiply
+    // by the constant (round 4; two of the eight first-stage twiddles of a radix-16 DFT and one of the four of its second stage land here)
+    constexpr int K = S - 64;
+    const u32 y0 = (u32)x << K;
+    const u64 Yh = x >> (32 - K);
+    u64 T, cT;
+    const u32 eps = 0xFFFFFFFFu;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(T), "=s"(cT) : "v"(y0), "v"(eps));
+    return gl_sub(T, Yh);
+#endif
   }
 }
 
@@ -161,7 +174,25 @@ struct Ntt2Params {
   // coefficient tile (one per coset of an LDE) are dispatched back to back on the SAME XCD — workgroups go to XCDs
   // round-robin, so block id = ((tile / 8) * nz + z) * 8 + tile % 8 — and 7 of the 8 reads hit that XCD's L2.
   int nz_fold;
+  // Full-size inter-pass twiddle table (round 4), or null: entry (m << b_lo) | l = w_span^(+-l * rev(m)) * post_scale for a strided pass of
+  // 2^(b_lo + R_LOG) points.  Composing that factor from the two-level root tables costs one general multiply per element (16 VALU
+  // instructions) on top of the multiply that applies it; read from the table it costs a load — which pays where the load hits L2: in a
+  // coset LDE the nz blocks of a tile run back to back on one XCD and share the tile's 64 KB slice (vx_runtime.hip.h decides).
+  const u64* tw_full;
 };
+// table builder (one launch per table and context: vx_runtime.hip.h caches them)
+__global__ void ntt2_tw_table_kernel(u64* __restrict__ tab, int span_log, int r_log, int b_lo, int inv, u64 post_scale,
+                                     const u64* __restrict__ root_lo, const u64* __restrict__ root_hi) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >> span_log) return;
+  const u64 m = idx >> b_lo, l = idx & (((u64)1 << b_lo) - 1);
+  const u64 ex = (l * (u64)bitrev32((u32)m, r_log)) & (((u64)1 << span_log) - 1);
+  u32 e = (u32)(ex << (ROOT_TABLE_LOG - span_log));
+  if (inv) e = ((1u << ROOT_TABLE_LOG) - e) & ((1u << ROOT_TABLE_LOG) - 1);
+  u64 v = root_pow24(root_lo, root_hi, e);
+  if (post_scale != 1) v = gl_mul(v, post_scale);
+  tab[idx] = v;
+}
 
 // LDS index of tile element (m, t): strided tiles are [m][t], contiguous tiles are [t][m]
 template <int R_LOG, bool STRIDED>
@@ -333,6 +364,24 @@ __global__ __launch_bounds__(NTT2_THREADS) void ntt2_pass_kernel(Ntt2Params p) {
       if (INV) e = ((1u << ROOT_TABLE_LOG) - e) & ((1u << ROOT_TABLE_LOG) - 1);
       return root_pow24_nc(p.root_lo, p.root_hi, e);  // only ever a factor of the products below
     };
+    if (p.tw_full) {
+      // the twiddle of output (m, l) sits at the output's own offset inside the transform: (m << b_lo) | l
+      const u64* __restrict__ twp = p.tw_full + l;
+#pragma unroll
+      for (u32 g0 = 0; g0 < n_groups; g0 += NTT2_THREADS) {
+        const u32 g = g0 + threadIdx.x;
+        const u32 m0 = (g >> T_LOG) << EL;
+        u64 x[1 << EL], tw[1 << EL];
+#pragma unroll
+        for (int q = 0; q < (1 << EL); ++q) tw[q] = twp[(size_t)(m0 | (u32)q) << p.b_lo];
+#pragma unroll
+        for (int q = 0; q < (1 << EL); ++q) x[q] = tile[tile_idx<R_LOG, true>(m0 | (u32)q, t)];
+        dft_regs<EL, INV>(x);
+#pragma unroll
+        for (int q = 0; q < (1 << EL); ++q) out[base + ((size_t)(m0 | (u32)q) << p.b_lo) + t] = gl_mul(x[q], tw[q]);
+      }
+      return;
+    }
     u64 step[1 << EL];
 #pragma unroll
     for (int k = 1; k < (1 << EL); ++k) step[k] = root_at(l * ((u64)k << (R_LOG - EL)));

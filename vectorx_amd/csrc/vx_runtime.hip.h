@@ -267,7 +267,26 @@ static hipError_t launch_ntt2_r(const NttPassParams& p, const Ntt2Params& q, dim
   if (br && !pre && inv) return launch_ntt2_k<R, E2, E3, STRIDED, true, false, true>(q, grid, s);
   return hipErrorInvalidValue;  // combination not instantiated: caller falls back
 }
-static hipError_t launch_ntt2_pass(const NttPass& ps, const NttPassParams& p, dim3 grid, hipStream_t s) {
+// Full-size inter-pass twiddle table of the second-generation strided pass (ntt2.hip.h: tw_full), built on first use and kept for the life
+// of the context.
+static const u64* ntt2_tw_table(vx_ctx* c, const NttPassParams& p, int r_log) {
+  const int span_log = p.b_lo + r_log;
+  const std::string key = "tw:" + std::to_string(span_log) + ":" + std::to_string(r_log) + ":" + std::to_string(p.inverse) + ":" + std::to_string(p.post_scale);
+  auto it = c->scale_cache.find(key);
+  if (it != c->scale_cache.end()) return it->second;
+  u64* d = nullptr;
+  const size_t n = (size_t)1 << span_log;
+  if (hipMalloc(&d, n * 8) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;                       // no memory for the table: the kernel composes the factors as before
+  }
+  hipLaunchKernelGGL(ntt2_tw_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, d, span_log, r_log, p.b_lo, p.inverse ? 1 : 0,
+                     p.post_scale, p.root_lo, p.root_hi);
+  c->scale_cache[key] = d;
+  return d;
+}
+static hipError_t launch_ntt2_pass(vx_ctx* c, const NttPass& ps, const NttPassParams& p, dim3 grid, hipStream_t s) {
+  static const bool no_tw_table = getenv("VX_NTT2_NO_TW_TABLE") != nullptr;   // A/B switch
   Ntt2Params q;
   q.in = p.in;
   q.out = p.out;
@@ -284,7 +303,13 @@ static hipError_t launch_ntt2_pass(const NttPass& ps, const NttPassParams& p, di
   q.pre_bits = p.pre_bits;
   q.post_scale = p.post_scale;
   q.nz_fold = 0;
-  if (p.pre && grid.z > 1 && p.in_z_stride == 0 && grid.x % 8 == 0 && !getenv("VX_NTT_NO_ZFOLD")) {  // coset LDE from shared coefficients
+  q.tw_full = nullptr;
+  const bool shared_tiles = p.pre && grid.z > 1 && p.in_z_stride == 0 && grid.x % 8 == 0;   // coset LDE from shared coefficients
+  // The twiddle table pays where its slices are re-read from L2: the nz blocks of a tile of a coset LDE run back to back on one XCD and share
+  // the tile's 64 KB slice (LDE -3 %, profiles/r04_ntt_experiment.md); a plain transform would read every slice once per column from HBM
+  // (iNTT +8 %), so it keeps composing its factors.
+  if (ps.b_lo > 0 && shared_tiles && !no_tw_table) q.tw_full = ntt2_tw_table(c, p, ps.r_log);
+  if (shared_tiles && !getenv("VX_NTT_NO_ZFOLD")) {
     q.nz_fold = (int)grid.z;
     grid = dim3(grid.x * grid.z, grid.y, 1);
   }
@@ -396,7 +421,7 @@ static int run_ntt(vx_ctx* c, const u64* in, u64* out, size_t in_col_stride, siz
     dim3 grid((unsigned)((size_t)1 << (log_n - ps_.r_log - ps_.t_log)), (unsigned)ncols, (unsigned)nz);
     // gridDim.y is limited to 65535; column counts here are < 1000.
     hipError_t e = hipErrorInvalidValue;
-    if (ntt2_eligible(ps_, ps_.b_lo > 0)) e = launch_ntt2_pass(ps_, p, grid, c->stream);
+    if (ntt2_eligible(ps_, ps_.b_lo > 0)) e = launch_ntt2_pass(c, ps_, p, grid, c->stream);
     if (e == hipErrorInvalidValue) {  // not a hot shape (or a variant that is not instantiated): generic kernel
       (void)hipGetLastError();
       e = launch_ntt_pass(ps_.r_log, p, grid, lds, c->stream);
