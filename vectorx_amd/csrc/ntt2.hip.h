@@ -332,7 +332,9 @@ __global__ __launch_bounds__(NTT2_THREADS) void ntt2_pass_kernel(Ntt2Params p) {
         const u64 s = gl_mul_nc(pre[j >> p.pre_bits], pre[((size_t)1 << (p.log_n - p.pre_bits)) + (j & (((size_t)1 << p.pre_bits) - 1))]);
         v = gl_mul(v, s);
       } else {
-        v = gl_canon(v);
+        // a first pass may be handed any u64 representative; the contiguous pass is never first (run_ntt: plans of >= 2 passes end in it)
+        // and reads a strided pass's canonical products
+        if constexpr (STRIDED) v = gl_canon(v);
       }
       x[q] = v;
     }
