@@ -151,8 +151,10 @@ GLD void round_twiddles(u64 (&x)[1 << E], const u64* __restrict__ W, u32 base_lo
       const u32 k = rev_c<E>((u32)q);
       const u32 idx = ((k * base_low) << (R_LOG - LO - E)) & ((1u << R_LOG) - 1);
       if constexpr (R_LOG > 10) {
-        const u64 v = gl_mul(x[q], W[idx & ((1u << (R_LOG - 1)) - 1)]);
-        x[q] = (idx >> (R_LOG - 1)) ? gl_neg(v) : v;
+        // w^(j + R/2) = -w^j: the sign goes onto the TABLE value (never zero, so p - w is canonical without a zero test)
+        u64 w = W[idx & ((1u << (R_LOG - 1)) - 1)];
+        if (idx >> (R_LOG - 1)) w = GL_P - w;
+        x[q] = gl_mul(x[q], w);
       } else {
         x[q] = gl_mul(x[q], W[idx]);
       }
