@@ -258,7 +258,7 @@ def main():
             achieved = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9
             # HBM bytes per launch: PMC counters cannot be read from inside this process, so the measured
             # traffic-per-algorithmic-byte ratio of this kernel (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
-            # passes, gfx950 correction applied — profiles/r03_pmc_traffic.md via tools/summarize_pmc.py) scales the launch's algorithmic bytes.
+            # passes, gfx950 correction applied — profiles/r04_pmc_traffic.md via tools/summarize_pmc.py, re-measured after the round-4 NTT change: 3.02) scales the launch's algorithmic bytes.
             traffic, traffic_source = None, None
             try:
                 pmc = json.loads((ROOT / "profiles" / "pmc_traffic_lde.json").read_text())
