@@ -286,8 +286,8 @@ def main():
                    "ms_per_proof": round(ms, 2), "gperms_per_s": round(perms / (ms * 1e-3) / 1e9, 3)}
             try:
                 # per-permutation VALU instruction count: PMC-measured (SQ_INSTS_VALU), reproduced by the loop-weighted static
-                # histogram of the gfx950 assembly (tools/alu_ceiling.py -> profiles/r03_alu_ceiling.json)
-                ceil_info = json.loads((ROOT / "profiles" / "r03_alu_ceiling.json").read_text())
+                # histogram of the gfx950 assembly (tools/alu_ceiling.py -> profiles/r04_alu_ceiling.json: re-derived after the round-4 hashing schedule)
+                ceil_info = json.loads((ROOT / "profiles" / "r04_alu_ceiling.json").read_text())
                 ipp = float(ceil_info["valu_insts_per_perm_pmc"] or ceil_info["valu_insts_per_perm_static"])
                 achieved = perms / (ms * 1e-3) * ipp / 64.0
                 # THE CEILING IS A BOUND: the fastest rate ANY measured instruction stream containing this kernel's
@@ -312,7 +312,7 @@ def main():
                             "frac_at_pmc_run_clock": (round(achieved / (ceil_info["simds"] * float(ceil_info["pmc_run"]["clock_ghz"]) * 1e9 / 4.0), 4)
                                                       if (ceil_info.get("pmc_run") or {}).get("clock_ghz") else None),
                             "ubench_cycles_per_inst": ceil_info["cycles"],
-                            "source": "profiles/r03_alu_ceiling.json (tools/alu_ceiling.py), profiles/r03_ubench_int.md, profiles/r03_pmc_sq_prove.md"})
+                            "source": "profiles/r04_alu_ceiling.json (tools/alu_ceiling.py), profiles/r03_ubench_int.md, profiles/r04_pmc_sq_prove.md"})
             except Exception as e:  # the bench line must not die on a missing evidence file
                 alu["ceiling_error"] = repr(e)
         sharded_mode = args.mode == "sharded" and world > 1 and args.workload == "prove"

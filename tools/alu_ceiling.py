@@ -9,7 +9,7 @@ with
     the shader clock read from s_memtime / s_memrealtime in the same run), and
   * the dynamic per-class counts taken from the gfx950 assembly of the kernel (`hipcc -S`), every basic block weighted
     by the trip counts of the loops around it (sponge loop: ceil(ncols / 8) permutations; inside one permutation:
-    2 x 4 full rounds, 5 blocks of four partial rounds + one block of two), cross-checked against the PMC count SQ_INSTS_VALU.
+    3 + 4 full rounds in loops, 4 blocks of four partial rounds in a loop, the rest straight-line), cross-checked against the PMC count SQ_INSTS_VALU.
 
     hipcc -O3 -std=c++17 --offload-arch=gfx950 -S --cuda-device-only -o /tmp/vxprover.s vectorx_amd/csrc/vxprover.hip
     python3 tools/alu_ceiling.py /tmp/vxprover.s profiles/r02_ubench_int.md [SQ_INSTS_VALU per permutation] [PMC clock GHz] [PMC cycles per VALU instruction] > profiles/r02_alu_ceiling.json
@@ -27,7 +27,7 @@ from collections import Counter
 KERNEL = "_Z27hash_leaves_colmajor_kernel"   # mangled-name prefix
 NCOLS = 135
 PERMS = (NCOLS + 7) // 8  # sponge permutations per row
-INNER_TRIPS = (4, 5, 4)   # loops inside one permutation: first 4 full rounds, 5 blocks of 4 partial rounds (+ 1 block of 2 straight-line), last 4 full rounds
+INNER_TRIPS = (3, 4, 4)   # loops inside one permutation since round 4's hashing schedule: full rounds 0..2, [round 3's S-boxes and the block its dense layer opens: straight-line], blocks 1..4 of 4 partial rounds, [block of 3: straight-line], last 4 full rounds
 
 # plain 32-bit VOP1/VOP2 ops without carry-out: the only class that issues faster than 4.4 cycles
 FAST = {"v_mov_b32_e32", "v_add_u32_e32", "v_sub_u32_e32", "v_subrev_u32_e32", "v_and_b32_e32", "v_or_b32_e32", "v_xor_b32_e32",

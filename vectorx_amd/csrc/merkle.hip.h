@@ -35,7 +35,7 @@ __global__ __launch_bounds__(HASH_THREADS, 4) void hash_leaves_colmajor_kernel(
 #pragma unroll
       for (int i = 0; i < 8; ++i)
         if (c + i < ncols) s[i] = cols[(size_t)(c + i) * col_stride + row];   // any u64 representative: the permutation works on those
-      poseidon_permute_nc(s);
+      poseidon_sponge_step_nc(s, c + 16 <= ncols, c + 8 >= ncols);
     }
   }
   u64* d = digests + row * 4;
@@ -69,7 +69,8 @@ __global__ __launch_bounds__(HASH_THREADS, 4) void hash_leaves_colmajor_part_ker
 #pragma unroll
     for (int i = 0; i < 8; ++i)
       if (c + i < c1) s[i] = cols[(size_t)(c + i) * col_stride + row];
-    poseidon_permute_nc(s);
+    // inside a launch the next chunk is known; across a launch boundary it is not (the full layer), unless this is the last launch
+    poseidon_sponge_step_nc(s, c + 16 <= c1, last && c + 8 >= c1);
   }
   if (last) {
     u64* d = digests + row * 4;
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(HASH_THREADS, 4) void hash_leaves_rowmajor_kernel(
 #pragma unroll
       for (int i = 0; i < 8; ++i)
         if (c + i < width) s[i] = src[c + i];
-      poseidon_permute_nc(s);
+      poseidon_sponge_step_nc(s, c + 16 <= width, c + 8 >= width);
     }
   }
   u64* d = digests + row * 4;

@@ -12,7 +12,7 @@
 //    half per term into plain 64-bit accumulators — no carries) and folds once per output (5 instructions);
 //  * round constants are never added on their own: they are the initial values of the accumulators of the linear
 //    layer in front of them;
-//  * the 22 partial rounds run in blocks of 4 (schedule 4·5 + 2) through integer powers of the MDS matrix (below) — upstream's "fast"
+//  * the 22 partial rounds run in blocks of 4 (hashing: [dense layer of full round 3 + 3] + 4·4 + 3, POSEIDON_SCHED_H; gate evaluation: 4·5 + 2) through integer powers of the MDS matrix (below) — upstream's "fast"
 //    sparse form needs full-size constants, i.e. six multiply-adds per term instead of two.
 // The 12-lane state lives in VGPRs; constants sit in constant memory and, because the loops are unrolled, are fetched
 // with scalar loads shared by the whole wavefront.
@@ -220,7 +220,7 @@ GLD u64 dot3_reduce_add_nc(const dot3& D, u64 addend) {
 //   state after the block:    u'  = M Q^(B-1) w  +  sum_{1<=i<B} y_i (M Q^(B-1-i)) e_0  +  K
 // (lane 0 is REPLACED by the S-box output before each layer, hence Q: no subtraction appears).  kappa_j and K collect the
 // round constants (K also those of the round that follows the block) and ride in as the accumulators' initial values.
-// Schedule: 5 blocks of 4 + 1 block of 2.  B = 4 is the longest block whose coefficients still fit 32-bit multipliers
+// Schedule (PoseidonGate evaluation; the hashing permutation uses POSEIDON_SCHED_H below): 5 blocks of 4 + 1 block of 2.  B = 4 is the longest block whose coefficients still fit 32-bit multipliers
 // (entries of M Q^3 < 2^28.3) and whose accumulators still fit 64 bits (row sums incl. the y terms < 2^31.72 — checked by
 // static_assert below); the final layer's accumulators then reach 2^63.8 and are folded by mds_fold_wide_nc.  B = 5 would
 // need 37-bit coefficients.
@@ -301,12 +301,13 @@ struct PoseidonBlockConsts {
 constexpr u64 gl_mulmod_const(u64 a, u64 b) { return (u64)(((unsigned __int128)a * b) % (unsigned __int128)GL_P); }
 constexpr u64 POSEIDON_RC_RAW[VX_POSEIDON_N_ROUND_CONSTANTS] = VX_POSEIDON_ROUND_CONSTANTS_INIT;
 constexpr u64 gl_addmod_const(u64 a, u64 b) { return (u64)(((unsigned __int128)a + b) % (unsigned __int128)GL_P); }
-constexpr PoseidonBlockConsts make_block_consts() {
+// `sched` / `r0`: the block lengths and the round the first block starts in (4 = the first partial round; 3 for the hashing schedule
+// below, whose first block opens with the dense layer of full round 3)
+constexpr PoseidonBlockConsts make_block_consts_g(const int (&sched)[POSEIDON_NBLOCKS], int r0) {
   PoseidonBlockConsts R{};
   const PoseidonMat M = poseidon_mds_int();
-  int r0 = 4;
   for (int blk = 0; blk < POSEIDON_NBLOCKS; ++blk) {
-    const int B = POSEIDON_SCHED[blk];
+    const int B = sched[blk];
     u64 cv[12] = {};  // constant part of w^(j) (the block's first-round constants are already inside u)
     for (int j = 1; j <= B; ++j) {
       u64 t[12] = {};
@@ -333,7 +334,19 @@ constexpr PoseidonBlockConsts make_block_consts() {
 }
 static_assert(POSEIDON_SCHED[0] + POSEIDON_SCHED[1] + POSEIDON_SCHED[2] + POSEIDON_SCHED[3] + POSEIDON_SCHED[4] + POSEIDON_SCHED[5] == 22,
               "the blocks must cover the 22 partial rounds");
+constexpr PoseidonBlockConsts make_block_consts() { return make_block_consts_g(POSEIDON_SCHED, 4); }
 __constant__ PoseidonBlockConsts POSEIDON_BLK = make_block_consts();
+// THE HASHING SCHEDULE (round 4): the dense layer that ends full round 3 is itself "a partial round whose lane 0 has already been
+// through its S-box" — so it opens the first block instead of standing alone: block 0 = that layer + partial rounds 4, 5, 6 (a block of
+// 4 whose first S-box is the identity, same coefficient matrices M Q^0..3), then 4 + 4 + 4 + 4 + 3 for rounds 7 .. 25.  One dense
+// layer and its twelve folds (348 instructions) leave the permutation, and the odd block is a 3 instead of a 2: 3494 -> 3201 linear-layer
+// instructions over the 22 partial rounds + that layer, 2.3 % of the permutation.  The PoseidonGate evaluation (plonk_kernels.hip.h) keeps
+// the schedule above: its wires sit between the layer and the first partial round's S-box either way, and it is 4 % of a proof.
+constexpr int POSEIDON_SCHED_H[POSEIDON_NBLOCKS] = {4, 4, 4, 4, 4, 3};
+static_assert(POSEIDON_SCHED_H[0] + POSEIDON_SCHED_H[1] + POSEIDON_SCHED_H[2] + POSEIDON_SCHED_H[3] + POSEIDON_SCHED_H[4] + POSEIDON_SCHED_H[5] == 23,
+              "the hashing blocks must cover the dense layer of round 3 and the 22 partial rounds");
+static_assert(make_int_block(3).max_row_sum < ((u64)1 << 25), "block of 3: simple fold range (accumulators < 2^57)");
+__constant__ PoseidonBlockConsts POSEIDON_BLK_H = make_block_consts_g(POSEIDON_SCHED_H, 3);
 // round constants with one all-zero round appended, so "the constants of the next round" exists after round 29 too; stored
 // pre-split — {low dword, high dword} as two u64 — because each half seeds its own 64-bit accumulator: a scalar load puts
 // it into an SGPR pair that is the 64-bit ADDEND of the row's first v_mad_u64_u32 (no instruction spent on the constant)
@@ -374,11 +387,16 @@ GLD void poseidon_mds_rc_nc(u64 (&s)[12], int round_next) {
 // block's round j and returns the value that actually goes through the S-box: the identity for the permutation; the
 // quotient kernel's PoseidonGate passes the wire the gate constrains to equal x (and pushes x - wire as a constraint) —
 // the recurrences are linear in everything but the S-box outputs, so that is exactly the gate's eval_unfiltered.
-template <int B, class SBOX, class LANE0>
+// FIRST_ID: the block opens with a dense layer whose input lane 0 is used as it is (the hashing schedule's block 0: every lane of `s` has
+// just been through the S-boxes of full round 3).
+template <int B, bool FIRST_ID = false, class SBOX, class LANE0>
 GLD void poseidon_partial_block_g(u64 (&s)[12], const u64* __restrict__ kappa, const u64* __restrict__ K, SBOX&& sbox, LANE0&& lane0) {
   constexpr PoseidonIntBlock T = make_int_block(B);
   u64 y[B];
-  y[0] = sbox(lane0(0, s[0]));
+  if constexpr (FIRST_ID)
+    y[0] = s[0];
+  else
+    y[0] = sbox(lane0(0, s[0]));
   s[0] = y[0];  // s is now w = (y_0, u_1 .. u_11)
 #pragma unroll
   for (int j = 1; j < B; ++j) {
@@ -405,36 +423,70 @@ GLD void poseidon_partial_block_g(u64 (&s)[12], const u64* __restrict__ kappa, c
 #pragma unroll
   for (int r = 0; r < 12; ++r) s[r] = out[r];
 }
-template <int B>
+template <int B, bool FIRST_ID = false>
 GLD void poseidon_partial_block_nc(u64 (&s)[12], const u64* __restrict__ kappa, const u64* __restrict__ K) {
-  poseidon_partial_block_g<B>(s, kappa, K, [](u64 x) { return poseidon_sbox_fx(x); }, [](int, u64 x) { return x; });
+  auto sb = [](u64 x) { return poseidon_sbox_fx(x); };
+  auto id = [](int, u64 x) { return x; };
+  poseidon_partial_block_g<B, FIRST_ID>(s, kappa, K, sb, id);
+}
+// full round 3's dense layer + the 22 partial rounds, hashing schedule; `s` = the state right after the S-boxes of round 3
+GLD void poseidon_partial_rounds_h_nc(u64 (&s)[12]) {
+  poseidon_partial_block_nc<POSEIDON_BLOCK_B, true>(s, POSEIDON_BLK_H.kappa[0], POSEIDON_BLK_H.K[0]);
+#pragma unroll 1
+  for (int blk = 1; blk < POSEIDON_NBLOCKS - 1; ++blk) poseidon_partial_block_nc<POSEIDON_BLOCK_B>(s, POSEIDON_BLK_H.kappa[blk], POSEIDON_BLK_H.K[blk]);
+  poseidon_partial_block_nc<3>(s, POSEIDON_BLK_H.kappa[POSEIDON_NBLOCKS - 1], POSEIDON_BLK_H.K[POSEIDON_NBLOCKS - 1]);
 }
 
-// Permutation on arbitrary-u64 lanes; outputs are arbitrary u64 representatives (NOT canonical).
-GLD void poseidon_permute_nc(u64 (&s)[12]) {
+// The permutation WITHOUT its last dense layer: everything up to and including the S-boxes of round 29.  A sponge decides which rows of
+// that layer it needs (below); poseidon_permute_nc = this + all twelve.
+GLD void poseidon_permute_body_nc(u64 (&s)[12]) {
 #pragma unroll
   for (int i = 0; i < 12; ++i) s[i] = gl_add_nc_c(s[i], POSEIDON_RC_EXT.v[i]);
 #pragma unroll 1
-  for (int r = 0; r < 4; ++r) {
+  for (int r = 0; r < 3; ++r) {
 #pragma unroll
     for (int i = 0; i < 12; ++i) s[i] = poseidon_sbox_fx(s[i]);
     poseidon_mds_rc_nc(s, r + 1);
   }
+#pragma unroll
+  for (int i = 0; i < 12; ++i) s[i] = poseidon_sbox_fx(s[i]);   // round 3; its dense layer opens the first block
+  poseidon_partial_rounds_h_nc(s);
 #pragma unroll 1
-  for (int blk = 0; blk < POSEIDON_NBLOCKS - 1; ++blk) poseidon_partial_block_nc<POSEIDON_BLOCK_B>(s, POSEIDON_BLK.kappa[blk], POSEIDON_BLK.K[blk]);
-  poseidon_partial_block_nc<2>(s, POSEIDON_BLK.kappa[POSEIDON_NBLOCKS - 1], POSEIDON_BLK.K[POSEIDON_NBLOCKS - 1]);
-#pragma unroll 1
-  for (int r = 26; r < 30; ++r) {
+  for (int r = 26; r < 29; ++r) {
 #pragma unroll
     for (int i = 0; i < 12; ++i) s[i] = poseidon_sbox_fx(s[i]);
     poseidon_mds_rc_nc(s, r + 1);
   }
+#pragma unroll
+  for (int i = 0; i < 12; ++i) s[i] = poseidon_sbox_fx(s[i]);   // round 29
+}
+// Permutation on arbitrary-u64 lanes; outputs are arbitrary u64 representatives (NOT canonical).
+GLD void poseidon_permute_nc(u64 (&s)[12]) {
+  poseidon_permute_body_nc(s);
+  poseidon_mds_rc_nc(s, 30);
+}
+// THE OVERWRITE-MODE SPONGE ONLY EVER READS PART OF A PERMUTATION'S OUTPUT (round 4): when the next chunk is full its eight words
+// REPLACE lanes 0..7, so of the last dense layer only the capacity rows 8..11 are live — 8 rows x 29 instructions less, on every
+// permutation of a leaf but its last two; the last permutation hands out lanes 0..3 only (rows4 below, as in two_to_one).
+// s[0..7] are garbage afterwards.
+GLD void poseidon_last_layer_capacity_rows_nc(u64 (&s)[12]) {
+  u32 lo[12], hi[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) {
+    lo[i] = (u32)s[i];
+    hi[i] = (u32)(s[i] >> 32);
+  }
+  const u64(*__restrict__ rc)[2] = POSEIDON_RC_EXT.split + 30 * 12;   // the all-zero "round 30"
+  s[8] = poseidon_mds_row8_asm(lo, hi, rc[8][0], rc[8][1]);
+  s[9] = poseidon_mds_row9_asm(lo, hi, rc[9][0], rc[9][1]);
+  s[10] = poseidon_mds_row10_asm(lo, hi, rc[10][0], rc[10][1]);
+  s[11] = poseidon_mds_row11_asm(lo, hi, rc[11][0], rc[11][1]);
 }
 
 // The permutation of PoseidonHash::two_to_one — lanes 8..11 enter as ZERO and only lanes 0..3 leave — with the two things that
 // buys: in round 0 the four capacity lanes hold their round constants, so their S-box outputs are the compile-time constants
 // rc^7 (4 of 12 S-boxes gone), and the last dense layer only needs its first four rows (8 of 12 rows gone): 488 of the
-// 13,000 instructions, on the 5·10^7 node permutations of a proof.  s[8..11] are ignored on entry; s[4..11] are garbage on exit.
+// 12,800 instructions, on the 5·10^7 node permutations of a proof.  s[8..11] are ignored on entry; s[4..11] are garbage on exit.
 constexpr u64 gl_pow7_const(u64 x) {
   const u64 x2 = gl_mulmod_const(x, x), x4 = gl_mulmod_const(x2, x2), x3 = gl_mulmod_const(x2, x);
   return gl_mulmod_const(x3, x4);
@@ -461,7 +513,19 @@ GLD void poseidon_mds_rows4_rc_nc(u64 (&s)[12], int round_next) {
   s[2] = poseidon_mds_row2_asm(lo, hi, rc[2][0], rc[2][1]);
   s[3] = poseidon_mds_row3_asm(lo, hi, rc[3][0], rc[3][1]);
 }
-// (The same two savings inside the leaf sponge — first permutation of a leaf: capacity lanes zero, last one: four lanes out —
+// One absorption step of hash_n_to_m_no_pad's overwrite-mode sponge after the chunk has been written into lanes 0..7: the permutation
+// with exactly the rows of its last layer that stay live.  `next_full`: another chunk of eight follows; `last`: this was the final
+// chunk (only the digest lanes 0..3 leave).  Both wave-uniform.
+GLD void poseidon_sponge_step_nc(u64 (&s)[12], bool next_full, bool last) {
+  poseidon_permute_body_nc(s);
+  if (next_full)
+    poseidon_last_layer_capacity_rows_nc(s);
+  else if (last)
+    poseidon_mds_rows4_rc_nc(s, 30);
+  else
+    poseidon_mds_rc_nc(s, 30);
+}
+// (Round 3 tried two savings inside the leaf sponge — first permutation of a leaf: capacity lanes zero, last one: four lanes out —
 // under wave-uniform flags measured NO gain on hash_leaves_colmajor_kernel, 125.65 / 125.98 ms against 125.70 / 125.95: the
 // branches cost what the 488 instructions per leaf save.  Not kept; profiles/r03_hash_experiments.md.)
 GLD void poseidon_two_to_one_permute_nc(u64 (&s)[12]) {
@@ -473,14 +537,14 @@ GLD void poseidon_two_to_one_permute_nc(u64 (&s)[12]) {
   for (int i = 0; i < 4; ++i) s[8 + i] = POSEIDON_CAP_SBOX.v[i];   // (0 + rc)^7
   poseidon_mds_rc_nc(s, 1);
 #pragma unroll 1
-  for (int r = 1; r < 4; ++r) {
+  for (int r = 1; r < 3; ++r) {
 #pragma unroll
     for (int i = 0; i < 12; ++i) s[i] = poseidon_sbox_fx(s[i]);
     poseidon_mds_rc_nc(s, r + 1);
   }
-#pragma unroll 1
-  for (int blk = 0; blk < POSEIDON_NBLOCKS - 1; ++blk) poseidon_partial_block_nc<POSEIDON_BLOCK_B>(s, POSEIDON_BLK.kappa[blk], POSEIDON_BLK.K[blk]);
-  poseidon_partial_block_nc<2>(s, POSEIDON_BLK.kappa[POSEIDON_NBLOCKS - 1], POSEIDON_BLK.K[POSEIDON_NBLOCKS - 1]);
+#pragma unroll
+  for (int i = 0; i < 12; ++i) s[i] = poseidon_sbox_fx(s[i]);   // round 3
+  poseidon_partial_rounds_h_nc(s);
 #pragma unroll 1
   for (int r = 26; r < 29; ++r) {
 #pragma unroll
