@@ -113,7 +113,10 @@ def test_ntt_argument_errors(ctx):
 
 @pytest.mark.parametrize("n_leaves,width,cap_h", [(1, 5, 0), (2, 1, 0), (2, 4, 1), (16, 3, 4), (64, 8, 2), (64, 9, 0),
                                                    (256, 135, 4), (1024, 20, 4), (4096, 16, 4), (512, 32, 4),
-                                                   (128, 86, 7), (65536, 4, 0), (131072, 2, 3), (32768, 9, 4)])
+                                                   (128, 86, 7), (65536, 4, 0), (131072, 2, 3), (32768, 9, 4),
+                                                   # every live-row case of the sponge's last layer (round 4): one chunk, a partial chunk
+                                                   # after a full one, full after full, widths around the multiples of eight
+                                                   (64, 7, 2), (64, 15, 2), (64, 17, 2), (64, 24, 2), (64, 25, 2), (64, 31, 3), (64, 33, 0)])
 def test_merkle_matches_oracle(ctx, oracle, n_leaves, width, cap_h):
     rng = np.random.default_rng(n_leaves * 1000 + width)
     leaves = rand_field(rng, (n_leaves, width))
@@ -133,7 +136,8 @@ def test_merkle_argument_errors(ctx):
 
 @pytest.mark.parametrize("log_n,ncols,rate_bits,cap_h", [(1, 2, 3, 0), (3, 5, 3, 4), (5, 135, 3, 4), (8, 20, 3, 4),
                                                          (10, 16, 3, 4), (12, 9, 1, 2), (13, 4, 3, 4), (14, 3, 2, 4),
-                                                         (16, 2, 3, 4)])
+                                                         (16, 2, 3, 4), (6, 7, 3, 4), (6, 15, 2, 4), (6, 17, 3, 4), (6, 24, 1, 2),
+                                                         (6, 31, 3, 4), (6, 33, 2, 4)])
 def test_polynomial_batch_matches_oracle(ctx, oracle, log_n, ncols, rate_bits, cap_h):
     rng = np.random.default_rng(log_n * 131 + ncols)
     vals = rand_field(rng, (ncols, 1 << log_n))
