@@ -38,3 +38,26 @@ def test_extra_legs_import_without_a_gpu_and_the_chip_harness_knows_its_tables()
     assert stark_chips.CHIPS == ("sha256", "blake2b", "ed25519")
     r = _run(["--help"])
     assert r.returncode == 0 and "--no-chip-leg" in r.stdout and "--no-dag-leg" in r.stdout
+
+
+def test_launcher_keeps_rank0s_line_when_a_rank_dies_after_it(monkeypatch, capsys):
+    """`python bench.py --gpus N` run plainly relays rank 0's line; a rank lost AFTER the line (in the multi-rank legs or the teardown)
+    must not cost the measurement: the line goes out with the launcher's exit code in it and the launcher returns 0; no line -> the code."""
+    import json
+    import types
+    sys.path.insert(0, str(ROOT))
+    import bench
+    import torch
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    args = types.SimpleNamespace(gpus=2, ranks_on_one_device=False)
+    line = json.dumps({"metric": "header_range_512 proofs/sec", "value": 9.9, "n_gpus": 2})
+    monkeypatch.setattr(bench.subprocess, "run", lambda *a, **k: types.SimpleNamespace(returncode=1, stdout="noise\n" + line + "\n"))
+    assert bench.launch_ranks(args) == 0
+    out = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+    assert out["value"] == 9.9 and out["ranks_exit_code_after_the_line"] == 1
+    monkeypatch.setattr(bench.subprocess, "run", lambda *a, **k: types.SimpleNamespace(returncode=7, stdout="noise only\n"))
+    assert bench.launch_ranks(args) == 7
+    assert not [ln for ln in capsys.readouterr().out.splitlines() if ln.startswith("{")]
+    monkeypatch.setattr(bench.subprocess, "run", lambda *a, **k: types.SimpleNamespace(returncode=0, stdout=line + "\n"))
+    assert bench.launch_ranks(args) == 0
+    assert "ranks_exit_code_after_the_line" not in json.loads(capsys.readouterr().out.strip().splitlines()[-1])
