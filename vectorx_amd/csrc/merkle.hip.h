@@ -135,6 +135,80 @@ __global__ __launch_bounds__(HASH_THREADS) void merkle_level_coop_kernel(const u
   v = poseidon_permute_coop_nc(v, g, group_base);
   if (live && g < 4) parents[node * 4 + g] = gl_canon(v);
 }
+// The TOP of a tree in ONE launch (round 5): every level from `n` children (n <= MTOP_MAX_CHILDREN) down to the cap.  Until round 4
+// these were up to 11 launches of merkle_level_coop_kernel, each a single dependent permutation 24 us long whatever its size
+// (profiles/r04_prove_kernel_stats.md: 145 launches = 3.5 ms of a 2^21 proof, a third of the kernel time of a 2^14-row one).
+//   phase 1: a workgroup takes 2^cw_log consecutive children (<= 128) into LDS and reduces them to ONE node, 16 lanes per node,
+//            levels ping-ponging between two LDS buffers (every level is also written to the level-concatenated tree);
+//   phase 2: the workgroups of one cap subtree count themselves on a counter; the LAST one to arrive (agent-scope release /
+//            acquire around the atomic) gathers the subtree's phase-1 nodes and reduces them to the cap entry.  Nobody waits for
+//            anybody: no spinning, so no forward-progress assumption; the last arriver re-zeroes the counter for the next launch.
+#define MTOP_THREADS 1024
+#define MTOP_GROUPS (MTOP_THREADS / 16)
+#define MTOP_MAX_CHILDREN (2 * COOP_MAX_NODES)
+#define MTOP_MAX_COUNTERS 256
+GLD void merkle_top_reduce(u64 (*buf)[256 * 4], int& cur, unsigned cnt, int nlev, u64* __restrict__ tree, size_t& lvl_off,
+                           size_t& lvl_n, size_t& idx0, const u64* rc) {
+  const int tid = (int)threadIdx.x, grp = tid >> 4, g = tid & 15, group_base = (tid & 63) & ~15;
+  for (int lev = 0; lev < nlev; ++lev) {
+    const unsigned parents = cnt >> 1;
+    lvl_off += lvl_n;
+    lvl_n >>= 1;
+    idx0 >>= 1;
+    for (unsigned base = 0; base < parents; base += MTOP_GROUPS) {
+      if (base + (unsigned)(grp & ~3) < parents) {   // wave-uniform: a wavefront none of whose four groups has a node sits the level out
+        const unsigned p = base + grp;
+        const bool live = p < parents;
+        u64 v = (live && g < 8) ? buf[cur][p * 8 + g] : 0;
+        v = poseidon_permute_coop_lds_nc(v, g, group_base, rc);
+        if (live && g < 4) {
+          v = gl_canon(v);
+          buf[cur ^ 1][p * 4 + g] = v;
+          tree[(lvl_off + idx0 + p) * 4 + g] = v;
+        }
+      }
+    }
+    __syncthreads();
+    cur ^= 1;
+    cnt = parents;
+  }
+}
+__global__ __launch_bounds__(MTOP_THREADS) void merkle_top_kernel(u64* __restrict__ tree, size_t off, unsigned n, unsigned ncap,
+                                                                  int cw_log, unsigned* __restrict__ counters) {
+  __shared__ u64 rc[VX_POSEIDON_N_ROUND_CONSTANTS];
+  __shared__ u64 buf[2][256 * 4];
+  __shared__ unsigned s_last;
+  const int tid = (int)threadIdx.x;
+  for (int i = tid; i < VX_POSEIDON_N_ROUND_CONSTANTS; i += MTOP_THREADS) rc[i] = POSEIDON_RC[i];
+  const unsigned cw = 1u << cw_log;
+  const u64* src = tree + (off + (size_t)blockIdx.x * cw) * 4;
+  for (unsigned i = tid; i < cw * 4; i += MTOP_THREADS) buf[0][i] = src[i];
+  __syncthreads();
+  int cur = 0;
+  size_t lvl_off = off, lvl_n = n, idx0 = (size_t)blockIdx.x * cw;
+  merkle_top_reduce(buf, cur, cw, cw_log, tree, lvl_off, lvl_n, idx0, rc);
+  const unsigned nwg = n >> cw_log;
+  if (nwg <= ncap) return;                 // one workgroup per cap subtree: done
+  const unsigned m = nwg / ncap, sub = blockIdx.x / m;   // m workgroups (= m phase-1 nodes) per cap subtree
+  __threadfence();                         // this workgroup's node (written by group 0) is visible device-wide before it is counted
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned prev = __hip_atomic_fetch_add(&counters[sub], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = prev == m - 1;
+    if (prev == m - 1) __hip_atomic_store(&counters[sub], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();                         // acquire: the other workgroups' nodes
+  const u64* nodes = tree + (lvl_off + (size_t)sub * m) * 4;
+  for (unsigned i = tid; i < m * 4; i += MTOP_THREADS) buf[cur][i] = __builtin_nontemporal_load(nodes + i);
+  __syncthreads();
+  idx0 = (size_t)sub * m;
+  int mlog = 0;
+  while ((1u << mlog) < m) ++mlog;
+  merkle_top_reduce(buf, cur, m, mlog, tree, lvl_off, lvl_n, idx0, rc);
+}
+
 __global__ __launch_bounds__(HASH_THREADS) void hash_leaves_rowmajor_coop_kernel(
     const u64* __restrict__ leaves, size_t nrows, int width, u64* __restrict__ digests) {
   const size_t t = (size_t)blockIdx.x * HASH_THREADS + threadIdx.x;

@@ -38,6 +38,10 @@ struct PermParams {
 };
 
 #define PERM_MAX_CHUNKS 40  /* ceil(80 routed wires / quotient_degree_factor 2) */
+// MAXC bounds nchunks at compile time: every loop over chunks is fully unrolled under a `k < nchunks` guard, so the three per-chunk
+// arrays are indexed statically and live in REGISTERS (round 5; the dynamically indexed form kept 976 B per lane in scratch and ran
+// at 7.5 cycles per instruction: profiles/r04_kernel_resources.md).  MAXC = 10 is standard_recursion_config (80 routed wires / 8).
+template <int MAXC>
 __global__ __launch_bounds__(256) void perm_chunk_products_kernel(PermParams p) {
   size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= p.n) return;
@@ -45,34 +49,46 @@ __global__ __launch_bounds__(256) void perm_chunk_products_kernel(PermParams p) 
   const u64 beta = p.betas[ch], gamma = p.gammas[ch];
   const u64 x = root_pow24(p.root_lo, p.root_hi, (u32)(i << (ROOT_TABLE_LOG - p.log_n)));
   const u64 bx = gl_mul(beta, x);
-  u64 np[PERM_MAX_CHUNKS], dp[PERM_MAX_CHUNKS];
-  for (int k = 0; k < p.nchunks; ++k) {
+  u64 np[MAXC], dp[MAXC], pre[MAXC];
+#pragma unroll
+  for (int k = 0; k < MAXC; ++k) {
     u64 a = 1, b = 1;
-    int j1 = min(p.nr, (k + 1) * p.deg);
-    for (int j = k * p.deg; j < j1; ++j) {
-      u64 w = gl_canon(p.wires[(size_t)j * p.n + i]);
-      u64 wg = gl_add(w, gamma);
-      u64 num = gl_mad(p.k_is[j], bx, wg);
-      u64 den = gl_mad(beta, p.sigmas[(size_t)j * p.n + i], wg);
-      a = gl_mul(a, num);
-      b = gl_mul(b, den);
+    if (k < p.nchunks) {
+      const int j1 = min(p.nr, (k + 1) * p.deg);
+      for (int j = k * p.deg; j < j1; ++j) {
+        u64 w = gl_canon(p.wires[(size_t)j * p.n + i]);
+        u64 wg = gl_add(w, gamma);
+        u64 num = gl_mad(p.k_is[j], bx, wg);
+        u64 den = gl_mad(beta, p.sigmas[(size_t)j * p.n + i], wg);
+        a = gl_mul(a, num);
+        b = gl_mul(b, den);
+      }
     }
     np[k] = a;
     dp[k] = b;
   }
-  // Montgomery batch inversion of dp[0..nchunks)
-  u64 pre[PERM_MAX_CHUNKS];
+  // Montgomery batch inversion of dp[0..nchunks) (the chunks beyond nchunks hold 1 and drop out)
   u64 acc = 1;
-  for (int k = 0; k < p.nchunks; ++k) {
+#pragma unroll
+  for (int k = 0; k < MAXC; ++k) {
     pre[k] = acc;
     acc = gl_mul(acc, dp[k]);
   }
   u64 ia = gl_inv(acc);
-  for (int k = p.nchunks - 1; k >= 0; --k) {
-    u64 inv_k = gl_mul(ia, pre[k]);
-    ia = gl_mul(ia, dp[k]);
-    p.cp[((size_t)ch * p.nchunks + k) * p.n + i] = gl_mul(np[k], inv_k);
+#pragma unroll
+  for (int k = MAXC - 1; k >= 0; --k) {
+    if (k < p.nchunks) {
+      u64 inv_k = gl_mul(ia, pre[k]);
+      ia = gl_mul(ia, dp[k]);
+      p.cp[((size_t)ch * p.nchunks + k) * p.n + i] = gl_mul(np[k], inv_k);
+    }
   }
+}
+static void launch_perm_chunk_products(const PermParams& pp, dim3 grid, hipStream_t s) {
+  if (pp.nchunks <= 10) hipLaunchKernelGGL(perm_chunk_products_kernel<10>, grid, dim3(256), 0, s, pp);
+  else if (pp.nchunks <= 16) hipLaunchKernelGGL(perm_chunk_products_kernel<16>, grid, dim3(256), 0, s, pp);
+  else if (pp.nchunks <= 27) hipLaunchKernelGGL(perm_chunk_products_kernel<27>, grid, dim3(256), 0, s, pp);
+  else hipLaunchKernelGGL(perm_chunk_products_kernel<PERM_MAX_CHUNKS>, grid, dim3(256), 0, s, pp);
 }
 
 // step 2: product of each 256-row block  (the prefix product over rows is the one serial loop of the
@@ -543,17 +559,46 @@ struct FoldParams {
   u64 w_inv_pows[16];   // w_arity^(-k)
   u64 arity_inv;        // 1/arity
 };
+// AB = arity_bits at compile time (round 5): the 2^AB values of a leaf stay in registers (the dynamically sized form kept 272 B per
+// lane in scratch) and the size-2^AB inverse DFT is a radix-2 decimation-in-time network — the leaf stores e_s at position rev(s),
+// which IS the bit-reversed input order that network wants — instead of a 2^AB x 2^AB matrix product: 17 twiddle multiplies per
+// component at arity 16 instead of 256.  Exact field arithmetic: the folded values are the same field elements.
+template <int AB>
 __global__ __launch_bounds__(256) void fri_fold_kernel(FoldParams p) {
-  const size_t Mo = p.M >> p.arity_bits;
+  constexpr int AR = 1 << AB;
+  const size_t Mo = p.M >> AB;
   size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (k >= Mo) return;
-  const int ar = 1 << p.arity_bits;
-  const int log_Mo = p.log_M - p.arity_bits;
-  ext2 e[16];
-  const ulonglong2* src = reinterpret_cast<const ulonglong2*>(p.in) + k * ar;
-  for (int t = 0; t < ar; ++t) {
+  const int log_Mo = p.log_M - AB;
+  u64 ea[AR], eb[AR];
+  const ulonglong2* src = reinterpret_cast<const ulonglong2*>(p.in) + k * AR;
+#pragma unroll
+  for (int t = 0; t < AR; ++t) {
     ulonglong2 v = src[t];
-    e[bitrev32((u32)t, p.arity_bits)] = ext_make(v.x, v.y);
+    ea[t] = gl_canon(v.x);
+    eb[t] = gl_canon(v.y);
+  }
+  // d_t = sum_s w^(-st) e_s for t = 0..AR-1 in natural order, in place
+#pragma unroll
+  for (int len = 2; len <= AR; len <<= 1) {
+#pragma unroll
+    for (int i = 0; i < AR; i += len) {
+#pragma unroll
+      for (int j = 0; j < len / 2; ++j) {
+        const int lo = i + j, hi = i + j + len / 2;
+        u64 va = ea[hi], vb = eb[hi];
+        if (j) {
+          const u64 w = p.w_inv_pows[(AR / len) * j];
+          va = gl_mul(va, w);
+          vb = gl_mul(vb, w);
+        }
+        const u64 ua = ea[lo], ub = eb[lo];
+        ea[lo] = gl_add(ua, va);
+        eb[lo] = gl_add(ub, vb);
+        ea[hi] = gl_sub(ua, va);
+        eb[hi] = gl_sub(ub, vb);
+      }
+    }
   }
   // y0^-1 = shift^-1 * w_M^(-rev(k))
   u32 kr = bitrev32((u32)(k + p.k_base), log_Mo);
@@ -563,17 +608,21 @@ __global__ __launch_bounds__(256) void fri_fold_kernel(FoldParams p) {
   ext2 bq = ext_scale(ext_make(p.beta[0], p.beta[1]), y0inv);  // beta / y0
   // Horner over t from the top: acc = acc * bq + d_t
   ext2 acc = ext_make(0, 0);
-  for (int t = ar - 1; t >= 0; --t) {
-    u64 da = 0, db = 0;
-    for (int s = 0; s < ar; ++s) {
-      u64 w = p.w_inv_pows[(s * t) & (ar - 1)];
-      da = gl_mad(e[s].a, w, da);
-      db = gl_mad(e[s].b, w, db);
-    }
-    acc = ext_add(ext_mul(acc, bq), ext_make(da, db));
-  }
+#pragma unroll
+  for (int t = AR - 1; t >= 0; --t) acc = ext_add(ext_mul(acc, bq), ext_make(ea[t], eb[t]));
   acc = ext_scale(acc, p.arity_inv);
   reinterpret_cast<ulonglong2*>(p.out)[k] = make_ulonglong2(acc.a, acc.b);
+}
+static hipError_t launch_fri_fold(const FoldParams& fp, size_t leaves, hipStream_t s) {
+  const dim3 grid((unsigned)((leaves + 255) / 256)), block(256);
+  switch (fp.arity_bits) {
+    case 1: hipLaunchKernelGGL(fri_fold_kernel<1>, grid, block, 0, s, fp); break;
+    case 2: hipLaunchKernelGGL(fri_fold_kernel<2>, grid, block, 0, s, fp); break;
+    case 3: hipLaunchKernelGGL(fri_fold_kernel<3>, grid, block, 0, s, fp); break;
+    case 4: hipLaunchKernelGGL(fri_fold_kernel<4>, grid, block, 0, s, fp); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------

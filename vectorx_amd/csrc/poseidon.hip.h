@@ -614,3 +614,21 @@ GLD u64 poseidon_permute_coop_nc(u64 v, int g, int group_base) {
   }
   return v;
 }
+
+// The same permutation with the round constants in LDS (`rc`: the 360 constants, copied there once per workgroup) and the next
+// round's constant fetched while the current round computes: in the fused tree-top kernel (merkle.hip.h) a workgroup walks up to
+// 11 levels = 11 dependent permutations, and 30 per-lane constant loads from global memory per permutation were pure latency.
+GLD u64 poseidon_permute_coop_lds_nc(u64 v, int g, int group_base, const u64* rc) {
+  const int gi = g < 12 ? g : g - 12;
+  u64 k = rc[gi];
+#pragma unroll 1
+  for (int r = 0; r < 30; ++r) {
+    const u64 kn = rc[(r < 29 ? r + 1 : r) * 12 + gi];
+    v = gl_add_nc_c(v, k);
+    const bool full = r < 4 || r >= 26;
+    if (full || g == 0) v = poseidon_sbox_nc(v);
+    v = poseidon_coop_mds_nc(v, g, group_base);
+    k = kn;
+  }
+  return v;
+}

@@ -467,8 +467,7 @@ static int fri_prove_openings(vx_ctx* c, const FriProverParams& fpp, const std::
       fp.arity_inv = inv((u64)1 << ab);
       {
         ProfScope ps(c, "fri_fold", 16.0 * M);
-        hipLaunchKernelGGL(fri_fold_kernel, dim3((unsigned)((leaves + 255) / 256)), dim3(256), 0, c->stream, fp);
-        HIPCHK(hipGetLastError());
+        HIPCHK(launch_fri_fold(fp, leaves, c->stream));
       }
       VXCHK(shard_allgather(c, shr, fvals[r + 1], 16 * leaves, "folded FRI layer"));
       shift = pow(shift, (u64)1 << ab);
@@ -872,7 +871,7 @@ static int prove_impl(vx_ctx* c, vx_circuit* k, const u64* wires_in, bool wires_
       pp.nch = nch;
       for (int i = 0; i < VX_MAX_CHALLENGES; ++i) pp.betas[i] = betas[i], pp.gammas[i] = gammas[i];
       pp.cp = cp;
-      hipLaunchKernelGGL(perm_chunk_products_kernel, dim3((unsigned)nblocks, nch), dim3(256), 0, c->stream, pp);
+      launch_perm_chunk_products(pp, dim3((unsigned)nblocks, nch), c->stream);
       hipLaunchKernelGGL(perm_block_products_kernel, dim3((unsigned)nblocks, nch), dim3(256), 0, c->stream, cp, n, nchunks, bp);
       hipLaunchKernelGGL(perm_scan_blocks_kernel, dim3(nch), dim3(64), 0, c->stream, bp, nblocks);
       hipLaunchKernelGGL(perm_write_kernel, dim3((unsigned)nblocks, nch), dim3(256), 0, c->stream, cp, n, nchunks, nch, bp, zs_vals);

@@ -52,6 +52,7 @@ struct vx_ctx {
   hipStream_t copy_stream = nullptr;  // host->device witness upload, overlapped with the first transforms (prover.hip.h)
   u64* root_lo = nullptr;  // w_{2^24}^k
   u64* root_hi = nullptr;  // w_{2^24}^(4096k)
+  unsigned* merkle_counters = nullptr;  // merkle_top_kernel: arrival counters per cap subtree, zero between launches
   u64* hash_clk = nullptr; // {shader ticks, 100 MHz ticks} samples written by hash_leaves_colmajor_kernel while profiling
   bool prof_on = false;
   bool rehearsal = false;  // vx_circuit_warm: a proof of an all-zero witness that only exists to prime the pool and the kernel caches
@@ -446,9 +447,23 @@ static size_t merkle_tree_digest_count(size_t n_leaves, int cap_height) {
 static int build_merkle_levels(vx_ctx* c, u64* tree, size_t n_leaves, int cap_height, size_t* cap_offset_digests) {
   ProfScope ps(c, "merkle_levels");
   size_t off = 0, n = n_leaves;
-  while (n > ((size_t)1 << cap_height)) {
+  const size_t ncap = (size_t)1 << cap_height;
+  while (n > ncap) {
+    if (n <= MTOP_MAX_CHILDREN && ncap <= MTOP_MAX_COUNTERS) {
+      // every remaining level in one launch (merkle.hip.h: merkle_top_kernel)
+      int sub_log = 0;
+      while (((size_t)ncap << (sub_log + 1)) <= n) ++sub_log;   // children per cap subtree = 2^sub_log
+      const int cw_log = sub_log < 7 ? sub_log : 7;
+      hipLaunchKernelGGL(merkle_top_kernel, dim3((unsigned)(n >> cw_log)), dim3(MTOP_THREADS), 0, c->stream, tree, off, (unsigned)n,
+                         (unsigned)ncap, cw_log, c->merkle_counters);
+      while (n > ncap) {
+        off += n;
+        n >>= 1;
+      }
+      break;
+    }
     size_t np = n >> 1;
-    if (np <= COOP_MAX_NODES)  // latency-bound level: 16 lanes per node
+    if (np <= COOP_MAX_NODES)  // latency-bound level: 16 lanes per node (only reached with a cap wider than MTOP_MAX_COUNTERS)
       hipLaunchKernelGGL(merkle_level_coop_kernel, dim3((unsigned)((np * 16 + HASH_THREADS - 1) / HASH_THREADS)),
                          dim3(HASH_THREADS), 0, c->stream, tree + off * 4, tree + (off + n) * 4, np);
     else

@@ -92,6 +92,8 @@ int vx_ctx_create(int device, vx_ctx** out) {
     HIPCHK(hipMemcpy(c->root_hi, hi.data(), 4096 * 8, hipMemcpyHostToDevice));
     HIPCHK(hipMalloc(&c->hash_clk, 2 * HASH_CLK_SLOTS * 8));
     HIPCHK(hipMemset(c->hash_clk, 0, 2 * HASH_CLK_SLOTS * 8));
+    HIPCHK(hipMalloc(&c->merkle_counters, MTOP_MAX_COUNTERS * sizeof(unsigned)));
+    HIPCHK(hipMemset(c->merkle_counters, 0, MTOP_MAX_COUNTERS * sizeof(unsigned)));
   }
   *out = c;
   return VX_OK;
@@ -109,6 +111,7 @@ void vx_ctx_destroy(vx_ctx* c) {
   hipFree(c->root_lo);
   hipFree(c->root_hi);
   hipFree(c->hash_clk);
+  hipFree(c->merkle_counters);
   if (c->copy_stream) hipStreamDestroy(c->copy_stream);
   hipStreamDestroy(c->stream);
   delete c;
