@@ -51,6 +51,15 @@ def parse():
                     help="seconds the world > 1 legs may take together before every rank gives up on them and rank 0 prints the line without them")
     ap.add_argument("--no-dag-stark-leg", action="store_true",
                     help="skip the extra leg that proves the header_range_512 DAG WITH the STARK tables of every job (BLAKE2b / SHA-256 / SHA-512 / batched EdDSA)")
+    ap.add_argument("--dag-workers", type=int, default=2,
+                    help="worker PROCESSES per GPU of the DAG legs (vectorx_amd/dag_pool.py; each keeps --dag-lanes jobs in flight); 0 = the one-process scheduler of rounds 1-4")
+    ap.add_argument("--dag-lanes", type=int, default=3)
+    ap.add_argument("--dag-table-mode", default="per_job", choices=["per_job", "resident"],
+                    help="STARK tables of the DAG: per_job = every job's own inputs, traces generated on the GPU inside the clock; resident = one host-generated trace per table kind (rounds 3-4)")
+    ap.add_argument("--extra-legs-deadline", type=float, default=1500.0,
+                    help="seconds the legs AFTER the contract's line may take at N = 1 before the process prints what it has and exits")
+    ap.add_argument("--cpu-baseline-full", action="store_true",
+                    help="cpu_baseline: ALSO prove the full-size circuit once with the oracle (minutes of CPU) and record it (profiles/r05_cpu_full_size.json holds such a run)")
     ap.add_argument("--no-chip-leg", action="store_true",
                     help="skip the extra leg that proves the three chip-sized STARK tables (SHA-256, BLAKE2b, Ed25519 scalar multiplication; SURVEY §8 f-3)")
     ap.add_argument("--circuit-flags", type=int, default=0,
@@ -156,6 +165,19 @@ def main():
             sys.exit(launch_ranks(args))
     elif int(os.environ["WORLD_SIZE"]) != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ['WORLD_SIZE']} ranks")
+    # The DAG legs' worker processes (vectorx_amd/dag_pool.py) are started HERE, before this process makes its first GPU call (children,
+    # never an exec); they connect back and idle — no GPU work, no CPU load — until the legs configure them, after the timed region.
+    jit_cache = ROOT / ".jit_cache"
+    if "VX_JIT_CACHE_DIR" not in os.environ and jit_cache.is_dir():     # compiled constraint programs (__graft_entry__.build); the workers inherit it
+        os.environ["VX_JIT_CACHE_DIR"] = str(jit_cache)
+    dag_pool = None
+    if ("WORLD_SIZE" not in os.environ and args.gpus == 1 and args.workload == "prove" and not args.no_dag_leg and args.log_n >= 20
+            and not args.circuit_flags and args.dag_workers > 0):
+        from vectorx_amd import mapreduce as mr
+        from vectorx_amd.dag_pool import DagPool
+        dag_pool = DagPool(mr.DagSpec(*(int(x) for x in args.dag_spec.split(","))), devices=(0,), workers_per_device=args.dag_workers,
+                           lanes=args.dag_lanes, with_starks=not args.no_dag_stark_leg, small_tables=args.dag_starks_small,
+                           table_mode=args.dag_table_mode).start()
     import torch
     import vectorx_amd as vx
     from vectorx_amd import dist_harness as H
@@ -216,33 +238,13 @@ def main():
     hash_clock_ghz = ctx.clock_ghz() if args.workload == "prove" else None   # before anything else runs: the timed region's own samples
     ctx.prof_enable(False)
 
-    # Extra leg, OUTSIDE the contract's timed region (`value` stays "inputs resident in HBM"): the same K proofs from a
-    # page-locked HOST witness — SURVEY.md §8d's end-to-end definition (witness in host memory -> proof bytes, PCIe included).
+    # Still before the line: the same K proofs from a page-locked HOST witness — SURVEY.md §8d's end-to-end definition (witness in
+    # host memory -> proof bytes, PCIe included).  bench.py's contract keeps `value` = "inputs resident in HBM when the timed region
+    # starts" (the PCIe-inclusive rate is never `value`), so the end-to-end figure rides next to it as `value_end_to_end`.
     host_leg = None
     if args.workload == "prove" and world == 1 and not args.no_host_witness_leg:
         import bench_prove
         host_leg = bench_prove.host_witness_leg(ctx, args, sync)
-
-    dag_leg = None
-    if args.workload == "prove" and world == 1 and not args.no_dag_leg and args.log_n >= 20 and not args.circuit_flags:
-        try:
-            dag_leg = bench_prove.dag_leg(ctx, local_rank)
-        except Exception as e:   # noqa: BLE001 — an extra leg must never cost the contract's line
-            dag_leg = {"error": repr(e)}
-
-    dag_stark_leg = None
-    if args.workload == "prove" and world == 1 and not args.no_dag_leg and not args.no_dag_stark_leg and args.log_n >= 20 and not args.circuit_flags:
-        try:
-            dag_stark_leg = bench_prove.dag_with_starks_leg(ctx, local_rank)
-        except Exception as e:   # noqa: BLE001
-            dag_stark_leg = {"error": repr(e)}
-
-    chip_leg = None
-    if args.workload == "prove" and world == 1 and not args.no_chip_leg and args.log_n >= 20 and not args.circuit_flags:
-        try:
-            chip_leg = bench_prove.chip_leg(ctx)
-        except Exception as e:   # noqa: BLE001
-            chip_leg = {"error": repr(e)}
 
     # N > 1: two more legs after the timed region so that ONE `bench.py --gpus N` yields the weak-scaling point
     # (`value`), the strong-scaling point (one 2^21 proof over all N ranks = BASELINE configs[3]) and the real unit of work (one
@@ -338,66 +340,101 @@ def main():
             ag = bench_prove._LEG["allgather"]
             out["exchange"] = {"allgather_calls_per_proof": ag.calls / args.steps, "inbound_bytes_per_rank_per_proof": ag.bytes / args.steps,
                                "backend": dist.get_backend(), "what": "in-place all-gathers vx_prove_sharded asked its host for (RCCL over xGMI)"}
+        out["value_hbm_resident"] = out["value"]
         if host_leg is not None:
+            out["value_end_to_end"] = host_leg["value"]          # witness in host memory -> proof bytes
+            out["ms_per_step_end_to_end"] = host_leg["ms_per_step"]
             out["value_from_host_witness"] = host_leg
-        if dag_leg is not None:
-            out["dag_header_range_512"] = dag_leg
-        if dag_stark_leg is not None:
-            out["dag_header_range_512_with_starks"] = dag_stark_leg
         if args.ranks_on_one_device:
             out["emulated_ranks_on_one_device"] = ("EVERY RANK IS A PROCESS ON DEVICE 0 over gloo: exercises the N > 1 code path on a single-GPU box; "
                                                    "no figure in this line is a multi-GPU measurement")
-        if chip_leg is not None:
-            out["chip_starks"] = chip_leg
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline_commit(args) if args.workload == "commit" else bench_prove.cpu_baseline(args)
 
-    # The contract's line is complete at this point.  The legs below are collective, and a rank that hangs inside one (a lost peer, a
-    # wedged collective) would otherwise take the line with it: a watchdog in EVERY rank ends the process cleanly at the deadline, rank 0
-    # printing the line without the legs first.
+    # ---- THE CONTRACT'S LINE IS COMPLETE: it goes out NOW.  Everything below is optional legs; when they finish, rank 0 prints the same
+    # line again with their results added (a reader that wants one line takes the last).  A leg that hangs — a lost peer, a wedged
+    # collective, a worker that never comes up — can therefore cost the legs, never the measurement: a watchdog in every rank ends the
+    # process at the deadline, and a SIGTERM from a launcher that lost a rank only sets a flag that the main thread acts on.
     import threading
-    line_lock = threading.Lock()
-    state = {"printed": False}
+    line_lock = threading.RLock()
+    state = {"lines": 0, "stop": None}
 
-    def emit_line():
+    def emit_line(extra=None):
         with line_lock:
-            if rank == 0 and not state["printed"]:
-                print(json.dumps(out), flush=True)
-            state["printed"] = True
+            if rank == 0:
+                d = dict(out)
+                if extra:
+                    d.update(extra)
+                print(json.dumps(d), flush=True)
+            state["lines"] += 1
 
-    def give_up(why=None):
-        if rank == 0:
-            why = why or f"the multi-rank legs did not finish within {args.multi_rank_leg_deadline} s"
-            out["multi_rank_legs"] = {"error": why + "; everything else in this line is complete"}
-        emit_line()
+    emit_line()
+
+    def give_up(why):
+        emit_line({"extra_legs": {"error": why + "; everything else in this line is complete"}})
         os._exit(0)
 
-    sharded_leg = dag_n_leg = dag_n_stark_leg = None
-    watchdog = None
-    if args.workload == "prove" and world > 1 and not args.no_multi_rank_legs and not args.circuit_flags:
-        watchdog = threading.Timer(args.multi_rank_leg_deadline, give_up)
-        watchdog.daemon = True
-        watchdog.start()
+    multi = args.workload == "prove" and world > 1 and not args.no_multi_rank_legs and not args.circuit_flags
+    deadline = args.multi_rank_leg_deadline if world > 1 else args.extra_legs_deadline
+    watchdog = threading.Timer(deadline, lambda: give_up(f"the legs after the contract's line did not finish within {deadline} s"))
+    watchdog.daemon = True
+    watchdog.start()
+    if multi:
         import signal
-        # a launcher that loses one rank sends the others SIGTERM: rank 0 answers with the line (the handler runs as soon as the main
-        # thread is back in Python, which every leg is between its library calls)
-        signal.signal(signal.SIGTERM, lambda *_: give_up("the launcher ended the ranks (SIGTERM) during the multi-rank legs"))
+        # the handler only records the request; `check_stop` (between library calls of the legs) acts on it from the main thread
+        signal.signal(signal.SIGTERM, lambda *_: state.__setitem__("stop", "the launcher ended the ranks (SIGTERM) during the multi-rank legs"))
+
+    def check_stop():
+        if state["stop"]:
+            give_up(state["stop"])
+
+    legs = {}
+    single = args.workload == "prove" and world == 1 and args.log_n >= 20 and not args.circuit_flags
+
+    def leg(name, fn):
+        try:
+            legs[name] = fn()
+        except Exception as e:   # noqa: BLE001 — an extra leg must never cost the line
+            legs[name] = {"error": repr(e)}
+
+    if single and not args.no_dag_leg:
+        if dag_pool is not None:
+            ctx.trim()           # the workers need the HBM this process's buffer pool is sitting on
+            leg("dag_header_range_512", lambda: bench_prove.dag_pool_legs(dag_pool, with_starks=not args.no_dag_stark_leg))
+            both = legs["dag_header_range_512"]
+            if "error" not in both:
+                legs.update(both)
+        else:
+            leg("dag_header_range_512", lambda: bench_prove.dag_leg(ctx, local_rank))
+            if not args.no_dag_stark_leg:
+                leg("dag_header_range_512_with_starks", lambda: bench_prove.dag_with_starks_leg(ctx, local_rank, table_mode=args.dag_table_mode))
+    if single and not args.no_chip_leg:
+        leg("chip_starks", lambda: bench_prove.chip_leg(ctx))
+
+    sharded_leg = dag_n_leg = dag_n_stark_leg = None
+    if multi:
         dev = None if on_host else torch.device("cuda", local_rank)
+        check_stop()
         sharded_leg = bench_prove.guarded_collective_leg(dist, lambda: bench_prove.sharded_one_proof_leg(ctx, args, rank, world, dist, dev, sync))
+        check_stop()
         dag_n_leg = bench_prove.guarded_collective_leg(dist, lambda: bench_prove.dag_leg_ranks(ctx, args, local_rank, dist, dev))
+        check_stop()
         if not args.no_dag_stark_leg:
             dag_n_stark_leg = bench_prove.guarded_collective_leg(dist, lambda: bench_prove.dag_leg_ranks(ctx, args, local_rank, dist, dev, with_starks=True))
 
-    if watchdog is not None:
-        watchdog.cancel()
+    watchdog.cancel()
     if rank == 0:
+        out.update(legs)
         if sharded_leg is not None:
             out["sharded_one_proof"] = sharded_leg
         if dag_n_leg is not None:
             out["dag_header_range_512"] = dag_n_leg
         if dag_n_stark_leg is not None:
             out["dag_header_range_512_with_starks"] = dag_n_stark_leg
-    emit_line()
+    if legs or multi:
+        emit_line()
+    if dag_pool is not None:
+        dag_pool.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

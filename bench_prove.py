@@ -126,6 +126,53 @@ def dag_leg(ctx, local_rank, in_flight=3):
                     "proofs without 128 CPU witness generations); NOT the contract's timed region"}
 
 
+def dag_pool_legs(pool, with_starks=True, passes=2):
+    """The header_range_512 DAG on a pool of worker PROCESSES per GPU (vectorx_amd/dag_pool.py: started before this process's first GPU
+    call, configured here): 64 map + 63 reduce + 1 outer jobs, a job to whichever worker has a free lane, 32-byte digests back over a
+    pipe.  Two figures: the plonky2 proofs alone, and every job WITH its STARK tables (per-job inputs, traces generated on the GPU
+    inside the clock).  The FIRST pass of each is the headline; all passes are listed.
+    -> {"dag_header_range_512": {...}, "dag_header_range_512_with_starks": {...}}"""
+    t0 = time.perf_counter()
+    ready = pool.wait_ready()
+    setup_s = time.perf_counter() - t0
+    spec, out = pool.spec, {}
+    common = {"workers_per_gpu": pool.wpd, "lanes_per_worker": pool.lanes, "schedule": "layer barriers; a job goes to the worker with most free lanes",
+              "setup_seconds_untimed": round(setup_s, 2),
+              "setup_seconds_by_worker": [r["setup_seconds"] for r in ready],
+              "setup_is": "worker start-up: circuit builds (synthetic generator + constants/sigmas commitment + one rehearsal proof per lane), "
+                          "loading compiled constraint programs, one warm-up proof of every table per lane; NO trace generation for the per-job tables"}
+
+    def record(runs, what):
+        res = runs[0]
+        secs = res["seconds"]
+        return {"header_range_512_per_sec": 1.0 / secs, "dag_seconds": secs, "dag_seconds_all_passes": [round(r["seconds"], 4) for r in runs],
+                "plonky2_proofs": res["proofs"], "plonky2_proofs_per_sec": res["proofs"] / secs, **common,
+                "lane_seconds_by_kind": {k: round(v, 4) for k, v in sorted(res["split"].items())},
+                "per_layer_ms": [(l["kind"], l["jobs"], round(l["ms"], 1)) for l in res["per_layer"]],
+                "non_map_layers_ms": round(sum(l["ms"] for l in res["per_layer"] if l["kind"] != "map"), 1),
+                "jobs_by_worker": res["jobs_by_worker"], "root": res["root"].hex(), "what": what}
+
+    sizes = f"{spec.num_map} map (2^{spec.map_log_n} rows) + {spec.num_map - 1} reduce (2^{spec.reduce_log_n}) + 1 outer (2^{spec.outer_log_n}) plonky2 proofs"
+    runs = [pool.run(b"bench request", with_tables=False) for _ in range(passes)]
+    assert len({r["root"] for r in runs}) == 1
+    out["dag_header_range_512"] = record(runs, sizes + ", synthetic stand-in circuits; witnesses HBM-resident (4 base witnesses per circuit kind and lane, "
+                                         "each job's own public inputs patched in); NOT the contract's timed region")
+    if with_starks:
+        runs = [pool.run(b"bench request") for _ in range(passes)]
+        assert len({r["root"] for r in runs}) == 1
+        tables = next((r.get("tables") for r in ready if r.get("worker") == 0), None)
+        rec = record(runs, sizes + ", EACH JOB WITH ITS STARK TABLES (own AIRs standing in for Curta's chips): map = BLAKE2b over the job's own 8 headers "
+                                  "(2240 compressions, 2^16 rows) + SHA-256 over its 14 tree nodes; reduce = SHA-256 over its 2 merge nodes; outer = SHA-256 over "
+                                  "300 keys + SHA-512 over 300 messages + 4 batched EdDSA tables (2^20 rows).  Per-job tables: inputs derived from the "
+                                  "request seed and the job's position, TRACES GENERATED ON THE GPU INSIDE THE CLOCK (vx_trace_*: lane-seconds "
+                                  "`trace_generation`); the EdDSA table keeps one resident trace (no native generator yet).  The STARK proofs are part "
+                                  "of a job's digest; NOT the contract's timed region")
+        rec["tables"] = tables
+        rec["stark_proofs"] = spec.num_map * 2 + (spec.num_map - 1) + 2 + ((tables or {}).get("eddsa_outer", {}).get("tables", 0))
+        out["dag_header_range_512_with_starks"] = rec
+    return out
+
+
 def guarded_collective_leg(dist, fn):
     """Run a leg in which EVERY rank takes part; an exception on any rank becomes {"error": ...} in the line instead of
     costing it.  (A rank that fails inside a collective can still leave its peers waiting: the backend's own timeout ends that.)"""
@@ -219,11 +266,8 @@ def dag_leg_ranks(ctx, args, local_rank, dist, device, in_flight=3, with_starks=
     if with_starks:
         # every rank proves map and reduce jobs; the outer job (and its tables) belongs to the rank job 0 of the last layer is dealt to: rank 0
         kinds = ("map", "reduce", "outer") if dist.get_rank() == 0 else ("map", "reduce")
-        per_kind, tables, _setup = dag_stark_tables(ctx, kinds=kinds, small=bool(getattr(args, "dag_starks_small", False)))
-        for lane in lanes:
-            for tabs in per_kind.values():
-                for _, tab in tabs:
-                    getattr(tab, "table", tab).prove(lane)
+        per_kind, tables, _setup = dag_stark_tables(ctx, kinds=kinds, small=bool(getattr(args, "dag_starks_small", False)),
+                                                    mode=getattr(args, "dag_table_mode", "per_job"), lanes=[ctx] + lanes)
 
     def make(kind, log_n, jobs):
         if kind not in provers:
@@ -269,75 +313,13 @@ def dag_leg_ranks(ctx, args, local_rank, dist, device, in_flight=3, with_starks=
                       "HBM-resident; NOT the contract's timed region"}
 
 
-def dag_stark_tables(ctx, eddsa_log_n=20, blake_log_n=18, verbose=False, kinds=("map", "reduce", "outer"), small=False):
-    """The STARK tables a header_range_512 job mix proves next to its plonky2 proofs — own AIRs standing in for Curta's chips, sized
-    from the reference's constants: a MAP job hashes 8 headers of up to MAX_HEADER_SIZE = 35 840 bytes = 280 BLAKE2b blocks each
-    (/root/reference/circuits/consts.rs:6-16, builder/header.rs:18) = 2240 compressions = one 2^18-row BLAKE2b table, and two 8-leaf
-    SHA-256 trees (subchain_verification.rs:148-231) = 28 compressions = a 2^11-row SHA-256 table; a REDUCE job merges two
-    commitments (4 compressions, 2^9 rows); the OUTER proof chains SHA-256 over 300 authority keys (justification.rs:140-156: 600
-    compressions, 2^16 rows), hashes 300 signed messages with SHA-512 (117 bytes = 2 blocks each: 2^16 rows) and checks 300 EdDSA
-    equations (justification.rs:237-243) = four 2^20-row batched tables of 97 signatures each (ONE resident trace proven four times:
-    the proving work does not depend on the values).  -> ({kind: [(label, table)]}, [tables to free], setup record)"""
-    from vectorx_amd import blake2b_air, blake2b_bytes_air, eddsa_air, sha256_air, sha512_air, stark_chips
-    rec, tables = {}, []
-    nopi = np.zeros(0, dtype=np.uint64)
-    # small = True (the single-GPU emulation test of the N-rank path): the smallest shapes the tables allow, same code path
-    nkeys, nhdr_blocks = (8, 4) if small else (300, 280)
-    if small:
-        eddsa_log_n = 17
-
-    def resident(label, stark, trace, pis):
-        t0 = time.perf_counter()
-        tab = stark_chips.ResidentTable(ctx, stark, trace, pis, label)
-        tab.prove()                      # warm-up: loads the compiled evaluator, computes and uploads the second-round columns
-        tab.drop_host_trace()
-        tables.append(tab)
-        rec[label]["first_proof_incl_second_round_columns_s"] = round(time.perf_counter() - t0, 2)
-        return tab
-
-    def hash_table(label, air, log_n, msgs):
-        t0 = time.perf_counter()
-        trace, pis, digests = air.generate_trace(log_n, msgs)
-        assert len(digests) == len(msgs), f"{label}: {len(digests)} of {len(msgs)} messages fit 2^{log_n} rows"
-        stark = air.make_stark(log_n)
-        rec[label] = {"rows_log2": log_n, "columns": f"{stark.desc.num_columns} + {stark.desc.num_aux_columns}", "messages": len(msgs),
-                      "trace_generation_s": round(time.perf_counter() - t0, 2)}
-        return resident(label, stark, trace, pis)
-
-    per_kind = {}
-    if "map" in kinds:
-        # round 4: the byte / XOR-lookup table (775 + 238 columns, 28 rows per compression: 2240 compressions fit 2^16 rows); round 3's bit
-        # table (1063 + 12 columns, 106 rows per compression, 2^18 rows) with VX_DAG_BLAKE2B_BITS=1, for comparison
-        import os
-        if os.environ.get("VX_DAG_BLAKE2B_BITS"):
-            blake = hash_table("blake2b_map", blake2b_air, blake_log_n, [bytes([17 * i & 255]) * (128 * nhdr_blocks) for i in range(8)])
-        else:
-            blake = hash_table("blake2b_map", blake2b_bytes_air, 16, [bytes([17 * i & 255]) * (128 * nhdr_blocks) for i in range(8)])
-        sha_map = hash_table("sha256_map", sha256_air, 11, [bytes([i]) * 64 for i in range(14)])
-        per_kind["map"] = [("blake2b", blake), ("sha256", sha_map)]
-    if "reduce" in kinds:
-        sha_red = hash_table("sha256_reduce", sha256_air, 9, [bytes([i + 50]) * 64 for i in range(2)])
-        per_kind["reduce"] = [("sha256", sha_red)]
-    if "outer" in kinds:
-        sha_out = hash_table("sha256_outer", sha256_air, 11 if small else 16, [bytes([i & 255, i >> 8]) * 32 for i in range(nkeys)])
-        s512 = hash_table("sha512_outer", sha512_air, 11 if small else 16, [bytes([i & 255, i >> 8]) * 58 + b"x" for i in range(nkeys)])
-        t0 = time.perf_counter()
-        lay = eddsa_air.Layout()
-        cap = eddsa_air.capacity(lay, eddsa_log_n)
-        sigs, rs = stark_chips.eddsa_signatures(cap, 8 if not small else 2)
-        trace, res = eddsa_air.generate_trace(lay, eddsa_log_n, sigs)
-        assert res == rs
-        stark = eddsa_air.make_stark(lay, eddsa_log_n)
-        ntab = -(-nkeys // cap)
-        rec["eddsa_outer"] = {"rows_log2": eddsa_log_n, "columns": f"{stark.desc.num_columns} + {stark.desc.num_aux_columns}", "signatures_per_table": cap,
-                              "tables": ntab, "trace_generation_s": round(time.perf_counter() - t0, 2)}
-        ed = resident("eddsa_outer", stark, trace, nopi)
-        del trace
-        per_kind["outer"] = [("sha256", sha_out), ("sha512", s512), ("eddsa", stark_chips.Repeated(ed, ntab))]
-    return per_kind, tables, rec
+def dag_stark_tables(ctx, kinds=("map", "reduce", "outer"), small=False, mode="resident", lanes=None):
+    """vectorx_amd.dag_tables.build (kept under this name for tools/)"""
+    from vectorx_amd import dag_tables
+    return dag_tables.build(ctx, kinds=kinds, small=small, mode=mode, lanes=lanes)
 
 
-def dag_with_starks_leg(ctx, local_rank, in_flight=None):
+def dag_with_starks_leg(ctx, local_rank, in_flight=None, table_mode="per_job"):
     """the real job mix — every plonky2 proof of the header_range_512 DAG WITH the STARK tables its circuit embeds (see
     dag_stark_tables), on one GPU, `in_flight` jobs in flight.  Reports the DAG's wall time and, per kind of work, the LANE-seconds spent
     in it (the lanes overlap, so the kinds add up to about in_flight x the wall time)."""
@@ -348,12 +330,10 @@ def dag_with_starks_leg(ctx, local_rank, in_flight=None):
     if in_flight is None:
         in_flight = int(os.environ.get("VX_DAG_STARKS_IN_FLIGHT", "3"))
     t_setup = time.perf_counter()
-    per_kind, tables, setup = dag_stark_tables(ctx)
     lanes = [vx.Context(local_rank) for _ in range(in_flight - 1)]
-    for lane in lanes:                  # every lane proves every table once (untimed): its pool then holds the STARK shapes too, like
-        for tabs in per_kind.values():  # vx_circuit_warm does for the plonky2 shapes — the first timed pass allocates nothing
-            for _, tab in tabs:
-                getattr(tab, "table", tab).prove(lane)
+    # every lane proves every table once (untimed, inside build): its pool then holds the STARK shapes too, like vx_circuit_warm does
+    # for the plonky2 shapes — the first timed pass allocates nothing
+    per_kind, tables, setup = dag_stark_tables(ctx, mode=table_mode, lanes=[ctx] + lanes)
     spec = mr.DagSpec(64, 18, 16, 19)
     provers, split = {}, {}
 
@@ -386,6 +366,11 @@ def dag_with_starks_leg(ctx, local_rank, in_flight=None):
     res = runs[0]                       # the FIRST pass is the headline
     secs = res["seconds"]
     stark_proofs = 64 * 2 + 63 * 1 + 2 + setup["eddsa_outer"]["tables"]
+    what_tables = ("EVERY JOB ITS OWN TABLES: a map job's 8 headers / tree nodes, a reduce job's merge nodes, the outer job's authority set and signed "
+                   "messages are derived from the request seed and the job's position, and the traces are generated on the GPU (vx_trace_*) INSIDE "
+                   "the clock (lane-seconds `trace_generation`); the batched EdDSA table keeps one resident trace proven 4 times"
+                   if table_mode == "per_job" else
+                   "every trace, witness and second-round column resident in HBM before the clock starts (one trace per table kind, proven once per job)")
     return {"header_range_512_per_sec": 1.0 / secs, "dag_seconds": secs, "dag_seconds_all_passes": [round(r["seconds"], 4) for r in runs],
             "plonky2_proofs": res["proofs"], "stark_proofs": stark_proofs, "in_flight_per_gpu": in_flight, "schedule": "layer barriers",
             "lane_seconds_by_kind": {k: round(v, 4) for k, v in sorted(res["split"].items())},
@@ -394,30 +379,55 @@ def dag_with_starks_leg(ctx, local_rank, in_flight=None):
             "root": res["root"].hex(),
             "what": "64 map jobs = plonky2 2^18 + BLAKE2b table (2240 compressions: 2^16 rows of the byte / XOR-lookup table) + SHA-256 table 2^11; 63 reduce jobs = plonky2 2^16 + SHA-256 "
                     "table 2^9; outer = plonky2 2^19 + SHA-256 chain 2^16 + SHA-512 2^16 + 4 batched EdDSA tables 2^20 (388 signature slots for 300 "
-                    "signatures); own AIRs standing in for Curta's chips, synthetic stand-in circuits; every trace, witness and second-round column "
-                    "resident in HBM before the clock starts (one trace per table kind, proven once per job); the STARK proofs are part of a job's "
-                    "digest; NOT the contract's timed region"}
+                    "signatures); own AIRs standing in for Curta's chips, synthetic stand-in circuits; " + what_tables + "; the STARK proofs are part of a "
+                    "job's digest; NOT the contract's timed region"}
 
 
-def chip_leg(ctx, log_n=13):
-    """SURVEY §8 f-3 outside the contract's timed region: the STARK path (`vx_stark_begin` / `vx_stark_finish`) on the three chip-sized
-    AIRs of this repository's own design — SHA-256, BLAKE2b-256, Ed25519 scalar multiplication (the chips Curta proves under every
-    VectorX map / outer proof: /root/reference/circuits/builder/header.rs:18, justification.rs:140-156, 237) — 2^13 rows each, trace
-    and second-round columns resident in HBM.  Compiled constraint programs come from .jit_cache/ when __graft_entry__.build() filled it."""
+def chip_leg(ctx):
+    """SURVEY §8 f-3 outside the contract's timed region: the STARK path on the four chip tables the header_range jobs prove — SHA-256,
+    SHA-512, BLAKE2b (bytes + XOR lookup) and the batched EdDSA equations, own AIRs standing in for Curta's chips
+    (/root/reference/circuits/builder/header.rs:18, justification.rs:140-156, 237) — ONE table each, lone proofs.  Every figure comes
+    through stark_chips.ResidentTable: the second-round columns are computed ON THE GPU inside every timed proof (round 4's leg cached a
+    host computation).  The hash tables' traces are generated on the GPU (vx_trace_*), timed separately; the EdDSA trace comes from the
+    host generator.  Compiled constraint programs come from .jit_cache/ when __graft_entry__.build() filled it."""
     import os
     from pathlib import Path
 
-    from vectorx_amd import stark_chips
+    from vectorx_amd import blake2b_bytes_air, eddsa_air, sha256_air, sha512_air, stark_chips
     cache = Path(__file__).resolve().parent / ".jit_cache"
     if "VX_JIT_CACHE_DIR" not in os.environ and cache.is_dir():
         os.environ["VX_JIT_CACHE_DIR"] = str(cache)
-    out = {"what": "own AIRs, not Curta's; 2^%d rows each; rate_bits 1, 84 queries, 16 PoW bits; NOT the contract's timed region" % log_n}
-    for which in stark_chips.CHIPS:
-        r = stark_chips.bench_chip(ctx, which, log_n, steps=3, warmup=1)
-        out[which] = {"ms_per_proof": round(r["ms_per_proof"], 3), "columns": r["config"]["columns"],
-                      "evaluator_ms": r["evaluator_ms"], "hashing_ms": round(r["hashing_ms"], 3), "proof_bytes": r["config"]["proof_bytes"],
-                      "evaluator": r["config"]["evaluator"], "first_proof_seconds_incl_jit": r["first_proof_seconds_incl_jit"],
-                      "trace_generation_seconds_host": r["trace_generation_seconds_host"]}
+    out = {"what": "own AIRs, not Curta's; rate_bits 1, 84 queries, 16 PoW bits; lone proofs, trace resident in HBM, second-round columns computed "
+                   "on the GPU inside every proof; NOT the contract's timed region"}
+    rng = np.random.default_rng(5)
+    cases = [("sha256", "sha256", sha256_air, 13, 120, 64), ("sha512", "sha512", sha512_air, 13, 48, 117),
+             ("blake2b_bytes", "blake2b", blake2b_bytes_air, 16, 8, 128 * 280)]
+    for name, which, air, log_n, nmsg, mlen in cases:
+        msgs = [rng.integers(0, 256, size=mlen, dtype=np.uint8).tobytes() for _ in range(nmsg)]
+        stark = air.make_stark(log_n)
+        ncols = stark.desc.num_columns
+        d = ctx.alloc(ncols * (1 << log_n) * 8)
+        ctx.trace_hash_table(which, log_n, msgs, d)            # warm
+        t0 = time.perf_counter()
+        pis, _ = ctx.trace_hash_table(which, log_n, msgs, d)
+        gen_ms = (time.perf_counter() - t0) * 1e3
+        r = stark_chips.bench_table(ctx, stark, None, pis, name, steps=3, warmup=1, d_trace=d)
+        out[name] = {"ms_per_proof": round(r["ms_per_proof"], 3), "rows_log2": log_n, "columns": r["columns"], "messages": nmsg,
+                     "trace_generation_ms_gpu": round(gen_ms, 3), "trace_GB": round(ncols * (1 << log_n) * 8 / 1e9, 3),
+                     "stage_ms_per_proof": r["stage_ms_per_proof"], "proof_bytes": r["proof_bytes"], "evaluator": r["evaluator"]}
+    lay = eddsa_air.Layout()
+    log_n = 17
+    cap = eddsa_air.capacity(lay, log_n)
+    t0 = time.perf_counter()
+    sigs, rs = stark_chips.eddsa_signatures(cap, 2)
+    trace, res = eddsa_air.generate_trace(lay, log_n, sigs)
+    assert res == rs
+    gen_s = time.perf_counter() - t0
+    stark = eddsa_air.make_stark(lay, log_n)
+    r = stark_chips.bench_table(ctx, stark, trace, np.zeros(0, dtype=np.uint64), "eddsa", steps=3, warmup=1)
+    out["eddsa"] = {"ms_per_proof": round(r["ms_per_proof"], 3), "rows_log2": log_n, "columns": r["columns"], "signatures": cap,
+                    "trace_generation_s_host_numpy": round(gen_s, 2), "stage_ms_per_proof": r["stage_ms_per_proof"], "proof_bytes": r["proof_bytes"],
+                    "evaluator": r["evaluator"]}
     return out
 
 
@@ -453,8 +463,42 @@ def cpu_baseline(args):
     dt = time.perf_counter() - t0
     assert oc.verify(proof) == ""
     scale = float(1 << (args.log_n - s_log))
-    return {
+    out = {
         "value": 1.0 / (dt * scale), "unit": "proofs/sec", "cores": cores, "kind": "port",
         "sample": (f"oracle prove() of the same synthetic circuit family at 2^{s_log} rows took {dt:.2f} s on {cores} OpenMP threads "
                    f"(stages s: {', '.join(f'{k}={v:.2f}' for k, v in tm.items())}); scaled x{int(scale)} (linear in rows) to 2^{args.log_n}"),
     }
+    sc.free()
+    # The full-size figure, MEASURED (no scaling): run here with --cpu-baseline-full (minutes of CPU), else quoted from the record of such a
+    # run on a GPU box of this pool (profiles/r05_cpu_full_size.json, written by this very code path) — clearly marked as a citation.
+    import json
+    from pathlib import Path
+    rec_path = Path(__file__).resolve().parent / "profiles" / "r05_cpu_full_size.json"
+    if getattr(args, "cpu_baseline_full", False):
+        scf = SynthCircuit(args.log_n, seed=0x5EED0000, poseidon_percent=args.poseidon_percent)
+        ocf = oracle_lib.OracleCircuit(oracle, scf.desc_ptr)
+        t0 = time.perf_counter()
+        proof, tmf = ocf.prove(scf.witness(), want_timings=True)
+        dtf = time.perf_counter() - t0
+        full = {"value": 1.0 / dtf, "unit": "proofs/sec", "seconds": round(dtf, 2), "cores": cores, "kind": "port", "log_n": args.log_n,
+                "stages_s": {k: round(v, 2) for k, v in tmf.items()}, "measured": "in this run", "proof_sha256": __import__("hashlib").sha256(proof).hexdigest()}
+        out["full_size_measured"] = full
+        out["value_bounded_sample_scaled"] = out["value"]
+        out["value"] = full["value"]
+        out["sample"] = f"oracle prove() of the bench circuit itself at 2^{args.log_n} rows: {dtf:.1f} s on {cores} OpenMP threads, measured in this run (no scaling); " + out["sample"]
+        try:
+            import os
+            os.makedirs("gpurun_out", exist_ok=True)
+            Path("gpurun_out/cpu_full_size.json").write_text(json.dumps(full))
+        except Exception:
+            pass
+        scf.free()
+    elif rec_path.exists():
+        try:
+            full = json.loads(rec_path.read_text())
+            if full.get("log_n") == args.log_n:
+                full["measured"] = "earlier run on a GPU box of this pool (profiles/r05_cpu_full_size.json): a citation, not this run's clock"
+                out["full_size_measured"] = full
+        except Exception:
+            pass
+    return out

@@ -55,6 +55,9 @@ int vx_device_max_clock_khz(int device); /* hipDeviceAttributeClockRate: the eng
 int vx_ctx_create(int device, vx_ctx** out);
 void vx_ctx_destroy(vx_ctx* ctx);
 int vx_ctx_sync(vx_ctx* ctx);
+/* Give the context's cached device buffers (the size-bucketed pool a prover recycles proof after proof) back to the driver: for a
+ * host that is about to hand the GPU to other processes (vectorx_amd/dag_pool.py).  Live objects are untouched. */
+int vx_ctx_trim(vx_ctx* ctx);
 /* Opaque hipStream_t of the context (so a harness can record its own events on the right stream). */
 void* vx_ctx_stream(vx_ctx* ctx);
 
@@ -386,6 +389,22 @@ int vx_stark_aux_columns(vx_ctx* ctx, const vx_aux_desc* desc, const uint64_t* t
  * on-GPU interpreter); this compiles it ahead of time, without a GPU: 1 = compiled now, 0 = already cached, negative VX_E_*. */
 int vx_stark_aux_precompile(const vx_aux_desc* desc);
 int vx_stark_verify(const vx_stark_desc* desc, const uint64_t* public_inputs, const uint8_t* proof, size_t proof_len);
+/* ---- trace generation for the hash-chip tables, on the device (round 5).  The reference's witness generation for these tables is
+ * Curta's (starkyx, un-vendored): `curta_blake2b_variable` over a map job's 8 headers (/root/reference/circuits/builder/header.rs:14-19),
+ * `curta_sha256` over the data-root / state-root trees and the authority-set chain (builder/subchain_verification.rs:148-231,
+ * builder/justification.rs:140-156), SHA-512 inside the EdDSA gadget (justification.rs:237-243).  These entry points fill the
+ * corresponding table of THIS repository's AIRs (vectorx_amd/{sha256,sha512,blake2b_bytes}_air.py: same column maps) for `num_msgs`
+ * messages hashed one after the other — `msgs` holds them back to back, message i = bytes [offsets[i], offsets[i + 1]) — directly
+ * into `trace_dev` = [columns][2^degree_bits] device memory (1024 / 1995 / 775 columns), the buffer vx_stark_begin then takes with
+ * trace_on_device = 1.  The host pads and walks the chain of chaining values; every cell is written by a device thread.
+ * public_inputs_out (8 / 16 / 8 values, may be NULL) = what the table's AIR takes as public inputs; digests_out (32 / 64 / 32 bytes per
+ * message, may be NULL) = the digests.  VX_E_INVALID when a message does not complete inside the rows (BLAKE2b: degree_bits >= 16). */
+int vx_trace_sha256(vx_ctx* ctx, int degree_bits, const uint8_t* msgs, const uint64_t* offsets, int num_msgs, void* trace_dev,
+                    uint64_t* public_inputs_out, uint8_t* digests_out);
+int vx_trace_sha512(vx_ctx* ctx, int degree_bits, const uint8_t* msgs, const uint64_t* offsets, int num_msgs, void* trace_dev,
+                    uint64_t* public_inputs_out, uint8_t* digests_out);
+int vx_trace_blake2b(vx_ctx* ctx, int degree_bits, const uint8_t* msgs, const uint64_t* offsets, int num_msgs, void* trace_dev,
+                     uint64_t* public_inputs_out, uint8_t* digests_out);
 /* The same for the constraint-program gates of a circuit (one kernel per program gate): returns the number compiled now. */
 int vx_circuit_precompile(const vx_circuit_desc* desc, int* num_program_gates_out);
 /* Compile an AIR program ahead of time: every chunk of the program (jit.hip.h cuts long programs into kernels of ~1200

@@ -1,0 +1,39 @@
+"""A stand-in prover for the scheduler tests of vectorx_amd/dag_pool.py (no GPU, no oracle): a job's "proof" is a hash of everything
+that must determine it — kind, position, public inputs, request seed — and takes a few milliseconds."""
+import hashlib
+import time
+
+
+class FakeProver:
+    takes_input_seed = True
+
+    def __init__(self, kind, delay=0.002):
+        self.kind, self.delay = kind, delay
+
+    def prove(self, key, public_inputs, lane=0, input_seed=b"", spent_out=None, with_tables=True):
+        t0 = time.perf_counter()
+        time.sleep(self.delay * (1 + (key[1] % 3)))
+        proof = hashlib.sha256(b"|".join([self.kind.encode(), b"%d,%d" % tuple(key), bytes(public_inputs.tobytes()), bytes(input_seed),
+                                          b"T" if with_tables else b"P"])).digest() * 4
+        if spent_out is not None:
+            spent_out.append(("plonky2", time.perf_counter() - t0))
+            if with_tables:
+                spent_out.append(("trace_generation", 0.0001))
+        return proof
+
+
+def make(cfg, device):
+    kinds = ("map", "reduce", "outer") if cfg["worker_index"] == 0 else ("map", "reduce")
+    return {k: FakeProver(k) for k in kinds}, (lambda: None), {"fake": True}
+
+
+def make_failing(cfg, device):
+    provers, close, info = make(cfg, device)
+
+    class Boom(FakeProver):
+        def prove(self, key, *a, **kw):
+            if key == (1, 1):
+                raise RuntimeError("boom in reduce job 1")
+            return super().prove(key, *a, **kw)
+    provers["reduce"] = Boom("reduce")
+    return provers, close, info

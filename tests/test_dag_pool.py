@@ -1,0 +1,67 @@
+"""vectorx_amd/dag_pool.py on the CPU: worker processes, job placement, the layer barriers, error propagation — with the stand-in
+prover of tests/_pool_factory.py.  The GPU counterpart (real proofs, root == the one-process root) is tests/test_gpu_dag_pool.py."""
+import pytest
+
+from vectorx_amd import mapreduce as mr
+from vectorx_amd.dag_pool import DagPool
+
+import os
+from pathlib import Path
+
+import _pool_factory
+
+
+@pytest.fixture(autouse=True)
+def workers_find_the_factory(monkeypatch):
+    monkeypatch.setenv("PYTHONPATH", str(Path(__file__).resolve().parent) + os.pathsep + os.environ.get("PYTHONPATH", ""))
+
+
+def one_process_root(spec, seed, with_tables=True):
+    class P(_pool_factory.FakeProver):
+        def prove(self, key, pis, lane=0, input_seed=b"", **kw):
+            return super().prove(key, pis, lane, input_seed=input_seed, with_tables=with_tables)
+    res = mr.run_dag(spec, lambda kind, log_n, jobs: P(kind, delay=0.0), None, in_flight=2, input_seed=seed)
+    return res["root"]
+
+
+@pytest.mark.parametrize("workers,lanes", [(1, 1), (2, 2), (3, 1)])
+def test_pool_root_equals_the_one_process_root(workers, lanes):
+    spec = mr.DagSpec(8, 10, 9, 11)
+    pool = DagPool(spec, devices=(0,), workers_per_device=workers, lanes=lanes, factory="_pool_factory:make").start()
+    try:
+        ready = pool.wait_ready(timeout=120)
+        assert sorted(r["worker"] for r in ready) == list(range(workers))
+        for seed in (b"", b"request 7"):
+            res = pool.run(seed)
+            assert res["root"] == one_process_root(spec, seed)
+            assert res["proofs"] == 8 + 7 + 1 and sum(res["jobs_by_worker"]) == 16
+            assert [l["jobs"] for l in res["per_layer"]] == [8, 4, 2, 1, 1]
+            assert set(res["split"]) == {"plonky2", "trace_generation"}
+        if workers > 1:
+            assert min(res["jobs_by_worker"]) > 0, "every worker takes jobs"
+        res = pool.run(b"x", with_tables=False)
+        assert res["root"] == one_process_root(spec, b"x", with_tables=False) != pool.run(b"x")["root"]
+    finally:
+        pool.close()
+
+
+def test_the_outer_job_goes_to_worker_0_and_a_worker_error_surfaces():
+    spec = mr.DagSpec(4, 10, 9, 11)
+    pool = DagPool(spec, workers_per_device=2, lanes=1, factory="_pool_factory:make_failing").start()
+    try:
+        pool.wait_ready(timeout=120)
+        with pytest.raises(RuntimeError, match="boom in reduce job 1"):
+            pool.run(b"")
+    finally:
+        pool.close()
+
+
+def test_two_devices_worth_of_workers_share_one_coordinator():
+    spec = mr.DagSpec(4, 10, 9, 11)
+    pool = DagPool(spec, devices=(0, 1), workers_per_device=1, lanes=2, factory="_pool_factory:make").start()
+    try:
+        ready = pool.wait_ready(timeout=120)
+        assert [r["device"] for r in sorted(ready, key=lambda r: r["worker"])] == [0, 1]
+        assert pool.run(b"s")["root"] == one_process_root(spec, b"s")
+    finally:
+        pool.close()

@@ -1,0 +1,74 @@
+"""vx_trace_sha256 / vx_trace_sha512 / vx_trace_blake2b on the GPU (csrc/tracegen.hip.h) through the C ABI: the trace the device writes
+equals the numpy generator's cell for cell, the digests equal hashlib, and the table proves from the device-generated trace to the same
+bytes as from the host-generated one.  (The row writers themselves are compared on the CPU in tests/test_tracegen.py.)"""
+import hashlib
+
+import numpy as np
+import pytest
+
+from vectorx_amd import blake2b_bytes_air, sha256_air, sha512_air, stark_chips
+
+pytestmark = pytest.mark.gpu
+
+AIRS = {"sha256": sha256_air, "sha512": sha512_air, "blake2b": blake2b_bytes_air}
+HASH = {"sha256": lambda m: hashlib.sha256(m).digest(), "sha512": lambda m: hashlib.sha512(m).digest(),
+        "blake2b": lambda m: hashlib.blake2b(m, digest_size=32).digest()}
+
+
+def seeded(n, lens, seed):
+    rng = np.random.default_rng(seed)
+    return [rng.integers(0, 256, size=lens[i % len(lens)], dtype=np.uint8).tobytes() for i in range(n)]
+
+
+CASES = [("sha256", 9, [b"abc", b"", b"x" * 55, b"y" * 56, b"z" * 64]), ("sha256", 11, seeded(14, [64], 5)), ("sha256", 8, []),
+         ("sha512", 9, [b"abc", b"", b"x" * 111, b"y" * 112]), ("sha512", 11, seeded(8, [117], 6)),
+         ("blake2b", 16, [b"abc", b"", b"x" * 128, b"y" * 129] + seeded(4, [128 * 30, 128 * 30 - 7], 7)),
+         ("blake2b", 16, [b"\x00" * 4096, b"\xff" * 4096, b"\x11" * 4096])]          # constant bytes: the hot-key path of the lookup histogram
+
+
+@pytest.mark.parametrize("which,log_n,msgs", CASES, ids=[f"{c[0]}-2^{c[1]}-{len(c[2])}msgs" for c in CASES])
+def test_device_trace_equals_the_numpy_generator(ctx, which, log_n, msgs):
+    ncols = ctx.TRACE_TABLES[which][0]
+    n = 1 << log_n
+    d = ctx.alloc(ncols * n * 8)
+    try:
+        ctx.upload(d, np.full((ncols, n), 0xDEAD, dtype=np.uint64))          # every cell must be written by the kernels
+        pis, digests = ctx.trace_hash_table(which, log_n, msgs, d)
+        got = ctx.download(d, ncols * n * 8).reshape(ncols, n)
+    finally:
+        ctx.free(d)
+    ref, rpis, rdig = AIRS[which].generate_trace(log_n, msgs)
+    bad = np.argwhere(got != ref)
+    assert bad.size == 0, f"first differing cells (column, row): {bad[:8].tolist()}"
+    assert (pis == rpis).all()
+    assert digests == [HASH[which](m) for m in msgs] == rdig
+
+
+def test_a_message_that_does_not_fit_is_an_error_not_a_truncated_table(ctx):
+    import vectorx_amd as vx
+    d = ctx.alloc(1024 * 128 * 8)
+    try:
+        with pytest.raises(vx.VxError, match="do not complete"):
+            ctx.trace_hash_table("sha256", 7, [b"a" * 64] * 2, d)
+        with pytest.raises(vx.VxError, match="degree_bits >= 16"):
+            ctx.trace_hash_table("blake2b", 15, [b"a"], d)
+    finally:
+        ctx.free(d)
+
+
+@pytest.mark.parametrize("which,log_n,msgs", [("sha256", 9, seeded(2, [64], 11)), ("blake2b", 16, seeded(8, [128 * 16], 12))])
+def test_a_table_proves_from_the_device_generated_trace(ctx, which, log_n, msgs):
+    air = AIRS[which]
+    stark = air.make_stark(log_n)
+    tab = stark_chips.GeneratedHashTable(ctx, which, stark, log_n, lambda job: msgs, [ctx], which)
+    ref_trace, ref_pis, _ = air.generate_trace(log_n, msgs)
+    res = stark_chips.ResidentTable(ctx, stark, ref_trace, ref_pis, which)
+    try:
+        proof = tab.prove(ctx, ("map", 0, 0, b""))
+        spent = tab.take_spent(ctx)
+        assert spent and spent[0][0] == "trace_generation" and spent[0][1] > 0
+        stark.verify(ref_pis, proof)
+        assert proof == res.prove(), "same trace, same transcript: the proofs must be the same bytes"
+    finally:
+        tab.free()
+        res.free()

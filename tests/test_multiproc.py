@@ -169,14 +169,19 @@ def test_a_job_is_its_plonky2_proof_followed_by_its_stark_proofs():
         def __init__(self, blob):
             self.blob, self.seen = blob, []
 
-        def prove(self, ctx):
-            self.seen.append(ctx)
+        def prove(self, ctx, job=None):
+            self.seen.append((ctx, job))
             return self.blob
 
+        def take_spent(self, ctx):          # a table may report finer-grained work: trace generation next to proving
+            return [("trace_generation", 0.0)]
+
     a, b = Table(b"AA"), Table(b"B")
-    split, lock = {}, threading.Lock()
-    job = mr.prove_with_tables(lambda: b"main", [("blake2b", a), ("sha256", b)], "lane-1", split, lock)
-    assert job == b"mainAAB" and a.seen == ["lane-1"] and set(split) == {"plonky2", "blake2b", "sha256"}
+    split, lock, mine = {}, threading.Lock(), []
+    key = ("map", 0, 5, b"seed")
+    job = mr.prove_with_tables(lambda: b"main", [("blake2b", a), ("sha256", b)], "lane-1", split, lock, job=key, spent_out=mine)
+    assert job == b"mainAAB" and a.seen == [("lane-1", key)] and set(split) == {"plonky2", "blake2b", "sha256", "trace_generation"}
+    assert [k for k, _ in mine] == ["plonky2", "trace_generation", "blake2b", "trace_generation", "sha256"]
     assert mr.prove_with_tables(lambda: b"main", [], None) == b"main"
     # a parent's public inputs change when a child's STARK proof changes
     d0 = hashlib.sha256(job).digest()

@@ -61,6 +61,7 @@ _SIGNATURES = {
     "vx_ctx_create": (_i, [_i, ctypes.POINTER(_vp)]),
     "vx_ctx_destroy": (None, [_vp]),
     "vx_ctx_sync": (_i, [_vp]),
+    "vx_ctx_trim": (_i, [_vp]),
     "vx_ctx_stream": (_vp, [_vp]),
     "vx_clock_probe": (_i, [_vp, ctypes.POINTER(ctypes.c_double)]),
     "vx_prof_enable": (_i, [_vp, _i]),
@@ -112,6 +113,9 @@ _SIGNATURES = {
     "vx_stark_begin_sharded": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, ctypes.POINTER(_vp)]),
     "vx_stark_session_free": (None, [_vp]),
     "vx_stark_aux_columns": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp]),
+    "vx_trace_sha256": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
+    "vx_trace_sha512": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
+    "vx_trace_blake2b": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "vx_stark_aux_precompile": (_i, [_vp]),
     "vx_stark_precompile": (_i, [_vp, ctypes.POINTER(_i)]),
     "vx_circuit_precompile": (_i, [_vp, ctypes.POINTER(_i)]),
@@ -206,6 +210,10 @@ class Context:
     def sync(self):
         _chk(lib().vx_ctx_sync(self._h))
 
+    def trim(self):
+        """return the cached device buffers of this context's pool to the driver (live objects stay)"""
+        _chk(lib().vx_ctx_trim(self._h))
+
     @property
     def stream(self) -> int:
         return lib().vx_ctx_stream(self._h)
@@ -232,6 +240,24 @@ class Context:
             _chk(lib().vx_prof_get(self._h, k, name, 64, ctypes.byref(ms), ctypes.byref(calls), ctypes.byref(by)))
             out[name.value.decode()] = {"ms": ms.value, "calls": calls.value, "alg_bytes": by.value}
         return out
+
+    # ---- chip-table traces generated on the device (vx_trace_*) ----
+    TRACE_TABLES = {"sha256": (1024, 8, 32), "sha512": (1995, 16, 64), "blake2b": (775, 8, 32)}   # columns, public inputs, digest bytes
+
+    def trace_hash_table(self, which: str, degree_bits: int, messages, d_trace: int):
+        """Fill the `which` table ("sha256" | "sha512" | "blake2b": the AIRs of vectorx_amd/{sha256,sha512,blake2b_bytes}_air.py) for
+        `messages` (byte strings, hashed one after the other) into device memory d_trace = [columns][2^degree_bits]
+        -> (public inputs of the table's AIR, [digest bytes per message])."""
+        ncols, npis, dlen = self.TRACE_TABLES[which]
+        blob = b"".join(messages)
+        off = np.zeros(len(messages) + 1, dtype=np.uint64)
+        np.cumsum([len(m) for m in messages], out=off[1:])
+        buf = np.frombuffer(blob, dtype=np.uint8) if blob else np.zeros(1, dtype=np.uint8)
+        pis = np.zeros(npis, dtype=np.uint64)
+        dig = np.zeros(max(1, dlen * len(messages)), dtype=np.uint8)
+        _chk(getattr(lib(), "vx_trace_" + which)(self._h, degree_bits, buf.ctypes.data, off.ctypes.data, len(messages), _vp(d_trace),
+                                                 pis.ctypes.data, dig.ctypes.data))
+        return pis, [dig[dlen * i:dlen * (i + 1)].tobytes() for i in range(len(messages))]
 
     # ---- device buffers ----
     def alloc(self, nbytes: int) -> int:

@@ -1,0 +1,191 @@
+// Trace generation for the chip tables ON THE GPU (round 5): vx_trace_sha256 / vx_trace_sha512 / vx_trace_blake2b.
+//
+// In the reference the Curta chips' witness generation fills the hash tables of every map / reduce / outer job on the CPU
+// (/root/reference/circuits/builder/header.rs:14-19, subchain_verification.rs:148-231, justification.rs:140-156); until round 4
+// this repository did the same in numpy, 100x slower than the proof the trace feeds.  Here the host only pads the messages and walks
+// the chain of chaining values (tracegen_prep.h); the device expands:
+//   * one thread per BLOCK computes the message schedule / work vectors the rows of that block need (tg_*_expand_kernel);
+//   * one thread per ROW writes that row's cells, column-major — the 64 lanes of a wavefront write 64 consecutive rows of one
+//     column (512 B coalesced) for each of the ~1000 columns (tg_*_rows_kernel), and counts the row's lookups;
+//   * a last small kernel writes the lookup multiplicities into the table rows.
+// HBM-bound by construction: 8 B per cell written once, nothing re-read (a 2^16 x 775 BLAKE2b table = 406 MB).
+// Row semantics: tracegen_core.h (compared cell by cell with the numpy generators in tests/test_tracegen.py on the CPU and in
+// tests/test_gpu_tracegen.py through this file).
+#pragma once
+#include "tracegen_prep.h"
+#include "vx_runtime.hip.h"
+
+#define TG_THREADS 256
+
+// a lookup histogram update for one value per lane: lanes holding the same key are merged (two leader rounds), so that the
+// all-zero triples of the inactive gadgets — most of a BLAKE2b table's lookups — cost one atomic per wavefront instead of 64 on one address
+__device__ __forceinline__ void tg_hist_add(unsigned* __restrict__ hist, unsigned key, bool valid) {
+  unsigned long long active = __ballot(valid);
+  const int lane = (int)(threadIdx.x & 63);
+#pragma unroll 1
+  for (int round = 0; round < 2 && active; ++round) {
+    const int leader = __ffsll((long long)active) - 1;
+    const unsigned k0 = (unsigned)__shfl((int)key, leader, 64);
+    const unsigned long long same = __ballot(valid && key == k0);
+    if (lane == leader) atomicAdd(&hist[k0], (unsigned)__popcll(same));
+    active &= ~same;
+    if (key == k0) valid = false;
+  }
+  if (valid) atomicAdd(&hist[key], 1u);
+}
+
+template <class T>
+__global__ __launch_bounds__(TG_THREADS) void tg_sha2_expand_kernel(const tg::Sha2Block<T>* __restrict__ blocks, int nb,
+                                                                    tg::Sha2Expanded<T>* __restrict__ exp) {
+  const int b = blockIdx.x * TG_THREADS + threadIdx.x;
+  if (b >= nb) return;
+  tg::sha2_expand<T>(blocks[b], tg::Sha2Consts<T>::K(), exp[b]);
+}
+template <class T>
+__global__ __launch_bounds__(TG_THREADS) void tg_sha2_rows_kernel(const tg::Sha2Block<T>* __restrict__ blocks,
+                                                                  const tg::Sha2Expanded<T>* __restrict__ exp, u64* __restrict__ trace,
+                                                                  size_t n, unsigned* __restrict__ hist) {
+  __shared__ unsigned lh[8];
+  if (threadIdx.x < 8) lh[threadIdx.x] = 0;
+  __syncthreads();
+  const size_t row = (size_t)blockIdx.x * TG_THREADS + threadIdx.x;
+  if (row < n) {
+    const size_t b = row / T::PERIOD;
+    const int r = (int)(row % T::PERIOD);
+    unsigned carries[T::NCARRY];
+    tg::sha2_row<T>(blocks[b], exp[b], b ? &exp[b - 1] : nullptr, r, row, tg::Sha2Consts<T>::K(),
+                    [&](int col, uint64_t v) { trace[(size_t)col * n + row] = v; }, carries);
+    if (row + 1 < n)       // the last row is inert: its lookups are not counted
+      for (int q = 0; q < T::NCARRY; ++q) atomicAdd(&lh[carries[q] & 7], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < 8 && lh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], lh[threadIdx.x]);
+}
+// trace[col][i] = hist[base + i] for i < count
+__global__ void tg_patch_mult_kernel(u64* __restrict__ col, const unsigned* __restrict__ hist, unsigned count) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) col[i] = hist[i];
+}
+
+__global__ __launch_bounds__(TG_THREADS) void tg_b2_expand_kernel(const tg::b2::Block* __restrict__ blocks, int nb,
+                                                                  tg::b2::Expanded* __restrict__ exp) {
+  const int b = blockIdx.x * TG_THREADS + threadIdx.x;
+  if (b >= nb) return;
+  tg::b2::expand(blocks[b], tg::B2_IV, tg::B2_SIGMA, exp[b]);
+}
+__global__ __launch_bounds__(TG_THREADS) void tg_b2_rows_kernel(const tg::b2::Block* __restrict__ blocks,
+                                                                const tg::b2::Expanded* __restrict__ exp, u64* __restrict__ trace, size_t n,
+                                                                unsigned* __restrict__ hist) {
+  const size_t row_raw = (size_t)blockIdx.x * TG_THREADS + threadIdx.x;
+  const bool in = row_raw < n;
+  const size_t row = in ? row_raw : n - 1;          // every lane walks the row (the histogram merge is wave-wide); only real rows store
+  const size_t b = row / tg::b2::PERIOD;
+  const int r = (int)(row % tg::b2::PERIOD);
+  const tg::b2::Block& blk = blocks[b];
+  uint64_t zero8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const uint64_t* hn_prev = b ? exp[b - 1].hn : zero8;
+  const uint64_t* dl = blk.dsrc >= 0 ? exp[blk.dsrc].hn : zero8;
+  const bool count = in && row + 1 < n;
+  tg::b2::row(blk, exp[b], hn_prev, dl, r, row, tg::B2_IV, tg::B2_SIGMA,
+              [&](int col, uint64_t v) { if (in) trace[(size_t)col * n + row] = v; },
+              [&](unsigned a, unsigned bb) { tg_hist_add(hist, a * 256u + bb, count); });
+}
+
+// ---- C ABI ----------------------------------------------------------------------------------------------------------------------
+template <class T>
+static int tg_trace_sha2(vx_ctx* c, int degree_bits, const uint8_t* msgs, const uint64_t* off, int nmsg, void* d_trace,
+                         uint64_t* pis_out, uint8_t* digests_out, const char* name) {
+  if (!c || !d_trace) return vx_fail(VX_E_INVALID, "%s: NULL argument", name);
+  HIPCHK(hipSetDevice(c->device));
+  tg::Sha2Prep<T> prep;
+  const int pr = tg::sha2_prepare<T>(degree_bits, msgs, off, nmsg, prep);
+  if (pr == tg::PREP_TOO_MANY_BLOCKS) return vx_fail(VX_E_INVALID, "%s: the messages do not complete inside 2^%d rows", name, degree_bits);
+  if (pr != tg::PREP_OK) return vx_fail(VX_E_INVALID, "%s: bad arguments", name);
+  const size_t n = (size_t)1 << degree_bits;
+  const int nb = (int)prep.blocks.size();
+  void *d_blocks = nullptr, *d_exp = nullptr, *d_hist = nullptr;
+  const size_t bb = (size_t)nb * sizeof(tg::Sha2Block<T>), eb = (size_t)nb * sizeof(tg::Sha2Expanded<T>);
+  if (c->pool_alloc(&d_blocks, bb) != hipSuccess || c->pool_alloc(&d_exp, eb) != hipSuccess || c->pool_alloc(&d_hist, 8 * sizeof(unsigned)) != hipSuccess) {
+    c->pool_free(d_blocks), c->pool_free(d_exp), c->pool_free(d_hist);
+    return vx_fail(VX_E_NOMEM, "%s: out of device memory", name);
+  }
+  int rc = VX_OK;
+  {
+    ProfScope ps(c, "trace_generation", 8.0 * T::N * n);
+    hipError_t e = hipMemcpyAsync(d_blocks, prep.blocks.data(), bb, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_hist, 0, 8 * sizeof(unsigned), c->stream);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(tg_sha2_expand_kernel<T>, dim3((nb + TG_THREADS - 1) / TG_THREADS), dim3(TG_THREADS), 0, c->stream,
+                         (const tg::Sha2Block<T>*)d_blocks, nb, (tg::Sha2Expanded<T>*)d_exp);
+      hipLaunchKernelGGL(tg_sha2_rows_kernel<T>, dim3((unsigned)((n + TG_THREADS - 1) / TG_THREADS)), dim3(TG_THREADS), 0, c->stream,
+                         (const tg::Sha2Block<T>*)d_blocks, (const tg::Sha2Expanded<T>*)d_exp, (u64*)d_trace, n, (unsigned*)d_hist);
+      hipLaunchKernelGGL(tg_patch_mult_kernel, dim3(1), dim3(64), 0, c->stream, (u64*)d_trace + (size_t)T::MULT * n, (const unsigned*)d_hist, 8u);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);   // the host block list goes out of scope
+    if (e != hipSuccess) rc = vx_fail(VX_E_HIP, "%s: %s", name, hipGetErrorString(e));
+  }
+  c->pool_free(d_blocks), c->pool_free(d_exp), c->pool_free(d_hist);
+  if (rc != VX_OK) return rc;
+  if (pis_out) memcpy(pis_out, prep.pis, sizeof prep.pis);
+  if (digests_out)
+    for (int mi = 0; mi < nmsg; ++mi)
+      for (int k = 0; k < 8; ++k) {
+        const typename T::W w = prep.digests[(size_t)mi * 8 + k];
+        for (size_t q = 0; q < sizeof w; ++q) digests_out[((size_t)mi * 8 + k) * sizeof w + q] = (uint8_t)(w >> (8 * (sizeof w - 1 - q)));
+      }
+  return VX_OK;
+}
+
+int vx_trace_sha256(vx_ctx* c, int degree_bits, const uint8_t* msgs, const uint64_t* offsets, int num_msgs, void* trace_dev,
+                    uint64_t* public_inputs_out, uint8_t* digests_out) {
+  return tg_trace_sha2<tg::Sha256T>(c, degree_bits, msgs, offsets, num_msgs, trace_dev, public_inputs_out, digests_out, "vx_trace_sha256");
+}
+int vx_trace_sha512(vx_ctx* c, int degree_bits, const uint8_t* msgs, const uint64_t* offsets, int num_msgs, void* trace_dev,
+                    uint64_t* public_inputs_out, uint8_t* digests_out) {
+  return tg_trace_sha2<tg::Sha512T>(c, degree_bits, msgs, offsets, num_msgs, trace_dev, public_inputs_out, digests_out, "vx_trace_sha512");
+}
+int vx_trace_blake2b(vx_ctx* c, int degree_bits, const uint8_t* msgs, const uint64_t* offsets, int num_msgs, void* trace_dev,
+                     uint64_t* public_inputs_out, uint8_t* digests_out) {
+  if (!c || !trace_dev) return vx_fail(VX_E_INVALID, "vx_trace_blake2b: NULL argument");
+  HIPCHK(hipSetDevice(c->device));
+  tg::B2Prep prep;
+  const int pr = tg::b2_prepare(degree_bits, msgs, offsets, num_msgs, prep);
+  if (pr == tg::PREP_TOO_MANY_BLOCKS) return vx_fail(VX_E_INVALID, "vx_trace_blake2b: the messages do not complete inside 2^%d rows", degree_bits);
+  if (pr != tg::PREP_OK) return vx_fail(VX_E_INVALID, "vx_trace_blake2b: bad arguments (the XOR table needs degree_bits >= 16)");
+  const size_t n = (size_t)1 << degree_bits;
+  const int nb = (int)prep.blocks.size();
+  void *d_blocks = nullptr, *d_exp = nullptr, *d_hist = nullptr;
+  const size_t bb = (size_t)nb * sizeof(tg::b2::Block), eb = (size_t)nb * sizeof(tg::b2::Expanded), hb = 65536 * sizeof(unsigned);
+  if (c->pool_alloc(&d_blocks, bb) != hipSuccess || c->pool_alloc(&d_exp, eb) != hipSuccess || c->pool_alloc(&d_hist, hb) != hipSuccess) {
+    c->pool_free(d_blocks), c->pool_free(d_exp), c->pool_free(d_hist);
+    return vx_fail(VX_E_NOMEM, "vx_trace_blake2b: out of device memory");
+  }
+  int rc = VX_OK;
+  {
+    ProfScope ps(c, "trace_generation", 8.0 * tg::b2::N * n);
+    hipError_t e = hipMemcpyAsync(d_blocks, prep.blocks.data(), bb, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_hist, 0, hb, c->stream);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(tg_b2_expand_kernel, dim3((nb + TG_THREADS - 1) / TG_THREADS), dim3(TG_THREADS), 0, c->stream,
+                         (const tg::b2::Block*)d_blocks, nb, (tg::b2::Expanded*)d_exp);
+      hipLaunchKernelGGL(tg_b2_rows_kernel, dim3((unsigned)((n + TG_THREADS - 1) / TG_THREADS)), dim3(TG_THREADS), 0, c->stream,
+                         (const tg::b2::Block*)d_blocks, (const tg::b2::Expanded*)d_exp, (u64*)trace_dev, n, (unsigned*)d_hist);
+      for (int k = 0; k < tg::b2::NTAB; ++k)
+        hipLaunchKernelGGL(tg_patch_mult_kernel, dim3(tg::b2::TAB_ROWS / 256), dim3(256), 0, c->stream,
+                           (u64*)trace_dev + (size_t)tg::b2::tabcol(k, 19) * n, (const unsigned*)d_hist + (size_t)tg::b2::TAB_ROWS * k,
+                           (unsigned)tg::b2::TAB_ROWS);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) rc = vx_fail(VX_E_HIP, "vx_trace_blake2b: %s", hipGetErrorString(e));
+  }
+  c->pool_free(d_blocks), c->pool_free(d_exp), c->pool_free(d_hist);
+  if (rc != VX_OK) return rc;
+  if (public_inputs_out) memcpy(public_inputs_out, prep.pis, sizeof prep.pis);
+  if (digests_out)
+    for (int mi = 0; mi < num_msgs; ++mi)
+      for (int k = 0; k < 4; ++k)
+        for (int q = 0; q < 8; ++q) digests_out[((size_t)mi * 4 + k) * 8 + q] = (uint8_t)(prep.digests[(size_t)mi * 4 + k] >> (8 * q));
+  return VX_OK;
+}

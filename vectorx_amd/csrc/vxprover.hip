@@ -12,6 +12,7 @@
 #include "prover.hip.h"
 #include "circuit_io.h"
 #include "stark.hip.h"
+#include "tracegen.hip.h"
 #include <memory>
 #include <cstddef>
 #include "verifier.h"
@@ -120,6 +121,12 @@ void vx_ctx_destroy(vx_ctx* c) {
 int vx_ctx_sync(vx_ctx* c) {
   if (!c) return vx_fail(VX_E_INVALID, "ctx is NULL");
   HIPCHK(hipStreamSynchronize(c->stream));
+  return VX_OK;
+}
+int vx_ctx_trim(vx_ctx* c) {
+  if (!c) return vx_fail(VX_E_INVALID, "ctx is NULL");
+  HIPCHK(hipSetDevice(c->device));
+  c->pool_trim();
   return VX_OK;
 }
 void* vx_ctx_stream(vx_ctx* c) { return c ? (void*)c->stream : nullptr; }

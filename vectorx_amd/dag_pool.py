@@ -1,0 +1,257 @@
+"""A pool of prover PROCESSES per GPU for the header_range MapReduce DAG (round 5).
+
+The reference fans a header_range proof out into independent map / reduce jobs
+(/root/reference/circuits/builder/subchain_verification.rs:72-78, 233-289).  `mapreduce.run_dag` keeps several of those jobs in
+flight on one GPU from ONE process (host threads, one context per lane) — and measurably leaves the GPU waiting for its host: one
+interpreter, one HIP runtime queue lock (profiles/r04_bench_2ranks_on_one_device.json: two processes of three lanes each finish the
+same DAG 13 % sooner on the same GPU).  This module is that observation built in:
+
+  * `DagPool(...).start()` launches W worker processes per device (`python -m vectorx_amd.dag_pool --worker ...` as CHILD
+    processes — never by exec of a process that has touched the GPU; call it BEFORE the caller's own first GPU call);
+  * a worker connects back over a unix socket, waits for its configuration, and only THEN touches the GPU: it opens `lanes`
+    contexts on its device, loads the three circuits (+ the STARK tables of every job kind) and reports ready;
+  * `run()` walks the DAG layer by layer: a job goes to whichever worker has a free lane, the worker proves it and sends back
+    the 32-byte digest of the job's proofs (+ the lane-seconds it spent per kind of work); a parent's public inputs come from its
+    children's digests, so the root is the same as the one-process root whatever the placement
+    (tests/test_gpu_dag_pool.py, tests/test_dag_pool.py);
+  * no collective, no shared device memory: proof-level data parallelism, 32 bytes per job over a pipe.
+
+Workers may sit on different devices (`devices=[0, 1, ...]`): the same coordinator then drives a whole node.
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import subprocess
+import sys
+import tempfile
+import threading
+import time
+import traceback
+from collections import deque
+from multiprocessing.connection import Client, Listener, wait
+from pathlib import Path
+
+import numpy as np
+
+from . import mapreduce as mr
+
+_ROOT = Path(__file__).resolve().parent.parent
+
+
+class DagPool:
+    def __init__(self, spec: mr.DagSpec, devices=(0,), workers_per_device: int = 2, lanes: int = 3, with_starks: bool = False,
+                 small_tables: bool = False, table_mode: str = "per_job", factory: str = "vectorx_amd.dag_pool:gpu_provers", distinct_witnesses: int = 4):
+        """factory = "module:function" the worker imports to build its provers: function(cfg, device) -> ({kind: prover}, close, info),
+        prover.prove(key, public_inputs, lane, input_seed, spent_out) -> proof bytes.  The default is the GPU library; the scheduler's
+        CPU tests plug in their own (tests/_pool_factory.py)."""
+        self.spec, self.devices, self.wpd, self.lanes = spec, list(devices), int(workers_per_device), int(lanes)
+        self.cfg = {"spec": (spec.num_map, spec.map_log_n, spec.reduce_log_n, spec.outer_log_n, spec.poseidon_percent), "lanes": self.lanes,
+                    "with_starks": bool(with_starks), "small_tables": bool(small_tables), "table_mode": table_mode, "factory": factory,
+                    "distinct_witnesses": distinct_witnesses}
+        self.procs, self.conns, self.ready = [], [], []
+        self._dir = None
+        self._listener = None
+
+    # ---- life cycle ------------------------------------------------------------------------------------------------------------
+    def start(self):
+        """spawn the workers; returns at once (they idle until `wait_ready` sends them their configuration)"""
+        self._dir = tempfile.TemporaryDirectory(prefix="vxpool")
+        addr = os.path.join(self._dir.name, "s")
+        self._authkey = os.urandom(16)
+        self._listener = Listener(addr, family="AF_UNIX", authkey=self._authkey)
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env["PYTHONPATH"] = str(_ROOT) + os.pathsep + env.get("PYTHONPATH", "")
+        env["VX_POOL_AUTHKEY"] = self._authkey.hex()
+        for dev in self.devices:
+            for w in range(self.wpd):
+                p = subprocess.Popen([sys.executable, "-m", "vectorx_amd.dag_pool", "--worker", addr, str(dev), str(len(self.procs))],
+                                     env=env, stdout=sys.stderr, stderr=sys.stderr)
+                self.procs.append(p)
+        return self
+
+    def wait_ready(self, timeout: float = 3600.0):
+        """accept the workers' connections, send the configuration, wait until every worker has its circuits loaded -> setup records"""
+        t0 = time.perf_counter()
+        self._listener._listener._socket.settimeout(timeout)
+        byindex = {}
+        for _ in self.procs:
+            c = self._listener.accept()
+            hello = c.recv()                   # ("hello", worker index): connections arrive in any order
+            byindex[hello[1]] = c
+        self.conns = [byindex[i] for i in range(len(self.procs))]
+        for c in self.conns:
+            c.send(("setup", self.cfg))
+        for c in self.conns:
+            if not c.poll(max(1.0, timeout - (time.perf_counter() - t0))):
+                raise TimeoutError("a DAG worker did not finish its setup in time")
+            msg = c.recv()
+            if msg[0] != "ready":
+                raise RuntimeError(f"DAG worker failed during setup:\n{msg[1]}")
+            self.ready.append(msg[1])
+        return self.ready
+
+    def close(self):
+        for c in self.conns:
+            try:
+                c.send(("stop",))
+            except Exception:
+                pass
+        for p in self.procs:
+            try:
+                p.wait(timeout=60)
+            except Exception:
+                p.kill()
+        for c in self.conns:
+            c.close()
+        if self._listener is not None:
+            self._listener.close()
+        if self._dir is not None:
+            self._dir.cleanup()
+        self.procs, self.conns = [], []
+
+    # ---- one DAG ---------------------------------------------------------------------------------------------------------------
+    def run(self, input_seed: bytes = b"", with_tables: bool = True) -> dict:
+        """one DAG.  with_tables = False: the plonky2 proofs only (workers loaded with tables skip them)"""
+        layers = self.spec.layers()
+        free = [self.lanes] * len(self.conns)
+        split, per_layer, prev = {}, [], {}
+        jobs_by_worker = [0] * len(self.conns)
+        t0 = time.perf_counter()
+        for li, (kind, jobs) in enumerate(layers):
+            tl = time.perf_counter()
+            pending, outstanding, mine = deque(jobs), 0, {}
+            while pending or outstanding:
+                while pending and max(free) > 0:
+                    w = 0 if kind == "outer" else max(range(len(free)), key=lambda i: free[i])   # worker 0 holds the outer circuit
+                    j = pending.popleft()
+                    pis = mr.child_inputs(li, j, prev, input_seed)
+                    self.conns[w].send(("job", li, j, kind, pis.tobytes(), input_seed, with_tables))
+                    free[w] -= 1
+                    outstanding += 1
+                    jobs_by_worker[w] += 1
+                for c in wait(self.conns):
+                    msg = c.recv()
+                    if msg[0] == "error":
+                        raise RuntimeError(f"DAG worker failed:\n{msg[1]}")
+                    _, rli, rj, dg, spent = msg
+                    assert rli == li
+                    mine[rj] = dg
+                    free[self.conns.index(c)] += 1
+                    outstanding -= 1
+                    for k, v in spent.items():
+                        split[k] = split.get(k, 0.0) + v
+            prev = mine
+            assert sorted(prev) == jobs
+            per_layer.append({"kind": kind, "jobs": len(jobs), "ms": (time.perf_counter() - tl) * 1e3})
+        seconds = time.perf_counter() - t0
+        return {"root": prev[0], "seconds": seconds, "proofs": self.spec.num_proofs(), "per_layer": per_layer, "split": split,
+                "jobs_by_worker": jobs_by_worker}
+
+
+# ---- the worker process ------------------------------------------------------------------------------------------------------------
+def gpu_provers(cfg: dict, device: int):
+    """the default factory: `lanes` contexts on `device`, the three circuits (+ the STARK tables of every job kind) loaded on each"""
+    import vectorx_amd as vx
+    num_map, lm, lr, lo, pp = cfg["spec"]
+    spec = mr.DagSpec(num_map, lm, lr, lo, pp)
+    ctx = vx.Context(device)
+    lanes = [vx.Context(device) for _ in range(cfg["lanes"] - 1)]
+    per_kind, tables, table_rec = {}, [], {}
+    kinds = ("map", "reduce", "outer") if cfg["worker_index"] == 0 else ("map", "reduce")
+    if cfg["with_starks"]:
+        from . import dag_tables
+        per_kind, tables, table_rec = dag_tables.build(ctx, kinds=("map", "reduce"), small=cfg["small_tables"], mode=cfg["table_mode"], lanes=[ctx] + lanes)
+        if "outer" in kinds:
+            pk, tb, tr = dag_tables.build(ctx, kinds=("outer",), small=cfg["small_tables"], mode=cfg["table_mode"], lanes=[ctx])
+            per_kind.update(pk)
+            tables += tb
+            table_rec.update(tr)
+    provers = {}
+    for kind in kinds:
+        # the outer proof (2^19 rows + four 2^20-row EdDSA tables) runs alone, after the last layer barrier: ONE lane of ONE worker
+        # holds its circuit and its buffers — every lane of every worker doing so would cost ~40 GB of HBM per lane for nothing
+        provers[kind] = mr.GpuProver(ctx, kind, spec.log_n(kind), [], pp, extra_lanes=() if kind == "outer" else lanes,
+                                     distinct_witnesses=cfg["distinct_witnesses"], starks=per_kind.get(kind, ()))
+
+    def close():
+        for p in provers.values():
+            p.free()
+        for t in tables:
+            t.free()
+        for l in lanes:
+            l.close()
+        ctx.close()
+    return provers, close, {"tables": table_rec}
+
+
+def _worker(addr: str, device: int, index: int):
+    import importlib
+    import queue
+    conn = Client(addr, family="AF_UNIX", authkey=bytes.fromhex(os.environ["VX_POOL_AUTHKEY"]))
+    send_lock = threading.Lock()
+    conn.send(("hello", index))
+    try:
+        msg = conn.recv()                      # nothing has touched the GPU so far
+        assert msg[0] == "setup"
+        cfg = dict(msg[1])
+        cfg["worker_index"] = index
+        t0 = time.perf_counter()
+        mod, fn = cfg["factory"].split(":")
+        provers, close, info = getattr(importlib.import_module(mod), fn)(cfg, device)
+        info = dict(info or {})
+        info.update({"worker": index, "device": device, "pid": os.getpid(), "setup_seconds": round(time.perf_counter() - t0, 2)})
+        conn.send(("ready", info))
+        todo = queue.Queue()
+
+        def lane_main(lane):
+            while True:
+                item = todo.get()
+                if item is None:
+                    return
+                _, li, j, kind, pis, seed, with_tables = item
+                try:
+                    spent = []
+                    proof = provers[kind].prove((li, j), np.frombuffer(pis, dtype=np.uint64), 0 if kind == "outer" else lane, input_seed=seed,
+                                                spent_out=spent, with_tables=with_tables)
+                    dg = hashlib.sha256(proof).digest()
+                    acc = {}
+                    for label, dt in spent:
+                        acc[label] = acc.get(label, 0.0) + dt
+                    with send_lock:
+                        conn.send(("done", li, j, dg, acc))
+                except BaseException:
+                    with send_lock:
+                        conn.send(("error", traceback.format_exc()))
+                    return
+
+        threads = [threading.Thread(target=lane_main, args=(lane,), daemon=True) for lane in range(cfg["lanes"])]
+        for t in threads:
+            t.start()
+        while True:
+            msg = conn.recv()
+            if msg[0] == "stop":
+                break
+            todo.put(msg)
+        for _ in threads:
+            todo.put(None)
+        for t in threads:
+            t.join(timeout=30)
+        close()
+    except EOFError:
+        pass
+    except BaseException:
+        try:
+            with send_lock:
+                conn.send(("error", traceback.format_exc()))
+        except Exception:
+            pass
+        raise
+
+
+if __name__ == "__main__":
+    if len(sys.argv) == 5 and sys.argv[1] == "--worker":
+        _worker(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]))
+    else:
+        sys.exit("usage: python -m vectorx_amd.dag_pool --worker <socket> <device> <index>   (started by DagPool.start)")

@@ -66,6 +66,11 @@ def child_inputs(layer_idx: int, job: int, prev_digests: dict, input_seed: bytes
     return digest_to_field(hashlib.sha256(prev_digests[2 * job] + prev_digests[2 * job + 1]).digest())
 
 
+def _seed_kw(prover, input_seed):
+    """provers that derive per-job table inputs from the request take `input_seed`; plain ones (the tests' stand-ins) do not"""
+    return {"input_seed": input_seed} if getattr(prover, "takes_input_seed", False) else {}
+
+
 def _run_dag_dependency_driven(layers, provers, in_flight, input_seed, sync):
     """One process, no layer barriers: a job starts as soon as ITS children are proven (a reduce job needs its two children, the
     outer proof the root reduce proof), `in_flight` lanes pull from one ready queue — the upper reduce layers, too narrow to fill
@@ -108,7 +113,7 @@ def _run_dag_dependency_driven(layers, provers, in_flight, input_seed, sync):
                     prev = dict(digests[li - 1]) if li else {}
                     if span[li][0] is None:
                         span[li][0] = time.perf_counter()
-                proof = provers[kind].prove((li, j), child_inputs(li, j, prev, input_seed), lane)
+                proof = provers[kind].prove((li, j), child_inputs(li, j, prev, input_seed), lane, **_seed_kw(provers[kind], input_seed))
                 dg = hashlib.sha256(proof).digest()
                 with lock:
                     digests[li][j] = dg
@@ -192,7 +197,7 @@ def run_dag(spec: DagSpec, make_prover, dist=None, sync=lambda: None, in_flight:
                     except queue.Empty:
                         return
                     try:
-                        proof = provers[kind].prove((li, j), child_inputs(li, j, prev, input_seed), lane)
+                        proof = provers[kind].prove((li, j), child_inputs(li, j, prev, input_seed), lane, **_seed_kw(provers[kind], input_seed))
                         mine[j] = hashlib.sha256(proof).digest()
                         all_proofs[(li, j)] = proof
                     except BaseException as e:   # surfaces after the join
@@ -209,7 +214,7 @@ def run_dag(spec: DagSpec, make_prover, dist=None, sync=lambda: None, in_flight:
         else:
             for j in my_jobs[li]:
                 pi = child_inputs(li, j, prev, input_seed)
-                proof = provers[kind].prove((li, j), pi)
+                proof = provers[kind].prove((li, j), pi, **_seed_kw(provers[kind], input_seed))
                 mine[j] = hashlib.sha256(proof).digest()
                 all_proofs[(li, j)] = proof
         sync()
@@ -227,17 +232,27 @@ def run_dag(spec: DagSpec, make_prover, dist=None, sync=lambda: None, in_flight:
     return {"root": prev[0], "seconds": seconds, "proofs": spec.num_proofs(), "per_layer": per_layer, "my_proofs": all_proofs}
 
 
-def prove_with_tables(prove_main, tables, lane_ctx=None, split=None, lock=None) -> bytes:
+def prove_with_tables(prove_main, tables, lane_ctx=None, split=None, lock=None, job=None, spent_out=None) -> bytes:
     """One job of the DAG = its plonky2 proof followed by the proofs of the STARK tables its circuit embeds (`tables`: [(label, object
-    with .prove(ctx) -> bytes)]): the concatenation is what the job's digest — and so its parent's public inputs — covers.
-    `split` (dict, guarded by `lock`) accumulates the wall seconds spent per kind of work."""
+    with .prove(ctx, job) -> bytes)]): the concatenation is what the job's digest — and so its parent's public inputs — covers.
+    `job` = (kind, layer, index, input_seed): what a per-job table derives ITS inputs from (the headers a map job hashes, the keys and
+    signatures of the outer job); a table with one resident trace ignores it.  A table may report finer-grained work through
+    `table.last_spent(ctx)` -> [(label, seconds)] (trace generation next to proving).
+    `split` (dict, guarded by `lock`) accumulates the wall seconds spent per kind of work; `spent_out` (list) receives this job's own."""
     t0 = time.perf_counter()
     parts = [prove_main()]
     spent = [("plonky2", time.perf_counter() - t0)]
     for label, table in tables:
         t0 = time.perf_counter()
-        parts.append(table.prove(lane_ctx))
-        spent.append((label, time.perf_counter() - t0))
+        parts.append(table.prove(lane_ctx, job))
+        dt = time.perf_counter() - t0
+        fine = table.take_spent(lane_ctx) if hasattr(table, "take_spent") else None
+        if fine:
+            spent.extend(fine)
+            dt -= sum(x for _, x in fine)
+        spent.append((label, dt))
+    if spent_out is not None:
+        spent_out.extend(spent)
     if split is not None:
         if lock is not None:
             lock.acquire()
@@ -253,6 +268,7 @@ def prove_with_tables(prove_main, tables, lane_ctx=None, split=None, lock=None) 
 class GpuProver:
     """One circuit kind on one GPU: circuit loaded once (constants_sigmas resident), one device-resident witness per
     job; `prove` patches the two witness rows that depend on the public inputs and calls vx_prove."""
+    takes_input_seed = True
 
     def __init__(self, ctx, kind, log_n, jobs, poseidon_percent=50, extra_lanes=(), distinct_witnesses=None, starks=(), split=None):
         """extra_lanes: more contexts on the SAME GPU; lane k proves on its own stream with its own copy of the circuit
@@ -301,14 +317,15 @@ class GpuProver:
                 sj.free()
         self.sc.release_host_buffers(witness=True, preprocessed=True)
 
-    def prove(self, key, public_inputs, lane=0):
+    def prove(self, key, public_inputs, lane=0, input_seed=b"", spent_out=None, with_tables=True):
         d = self.wit[key] if self.distinct is None else self.lane_wit[lane][key[1] % self.distinct]
         with self._lock:                      # the generator keeps the current public inputs: one caller at a time
             r0, r2 = self.sc.patch_public_inputs(public_inputs)
         ctx = self.lanes[lane]
         ctx.upload_row(d, self.n, 0, r0)
         ctx.upload_row(d, self.n, 2, r2)
-        return prove_with_tables(lambda: self.circuits[lane].prove(dev_ptr=d), self.starks, ctx, self.split, self._lock)
+        return prove_with_tables(lambda: self.circuits[lane].prove(dev_ptr=d), self.starks if with_tables else (), ctx, self.split, self._lock,
+                                 job=(self.kind, key[0], key[1], input_seed), spent_out=spent_out)
 
     def free(self):
         for d in self.wit.values():

@@ -123,8 +123,8 @@ class Repeated:
     def __init__(self, table, times):
         self.table, self.times = table, times
 
-    def prove(self, ctx=None) -> bytes:
-        return b"".join(self.table.prove(ctx) for _ in range(self.times))
+    def prove(self, ctx=None, job=None) -> bytes:
+        return b"".join(self.table.prove(ctx, job) for _ in range(self.times))
 
 
 class ResidentTable:
@@ -134,13 +134,18 @@ class ResidentTable:
     challenge vector is seen and reuse it (the same trace always draws the same challenges; VX_HOST_AUX=1 forces this path).  Trace
     generation is the caller's witness generation (disclosed in every record)."""
 
-    def __init__(self, ctx, stark, trace, public_inputs, name=""):
+    def __init__(self, ctx, stark, trace, public_inputs, name="", d_trace=None):
+        """`trace`: host array, uploaded here — or None with `d_trace` = a device buffer that already holds the trace (e.g. filled by
+        Context.trace_hash_table); the table takes ownership of it"""
         self.ctx, self.stark, self.name = ctx, stark, name
-        self.trace = np.ascontiguousarray(trace, dtype=np.uint64)
         self.pis = np.ascontiguousarray(public_inputs, dtype=np.uint64)
         self.n = 1 << stark.desc.degree_bits
-        self.d_trace = ctx.alloc(self.trace.nbytes)
-        ctx.upload(self.d_trace, self.trace)
+        if d_trace is not None:
+            self.trace, self.d_trace = None, d_trace
+        else:
+            self.trace = np.ascontiguousarray(trace, dtype=np.uint64)
+            self.d_trace = ctx.alloc(self.trace.nbytes)
+            ctx.upload(self.d_trace, self.trace)
         self.naux = stark.desc.num_aux_columns
         self.d_aux = ctx.alloc(max(8, self.naux * self.n * 8))
         self.chal = np.zeros(max(1, stark.desc.num_aux_challenges), dtype=np.uint64)
@@ -157,8 +162,9 @@ class ResidentTable:
         """after the first proof the host copy is only needed to recompute second-round columns for OTHER challenges"""
         self.trace = None
 
-    def prove(self, ctx=None) -> bytes:
-        """`ctx`: another context of the same device (a lane of the DAG scheduler); the buffers are device-global"""
+    def prove(self, ctx=None, job=None) -> bytes:
+        """`ctx`: another context of the same device (a lane of the DAG scheduler); the buffers are device-global.  `job` is ignored:
+        a resident table proves the same trace for every job (GeneratedHashTable is the per-job form)"""
         import vectorx_amd as vx
         L, vp = vx.lib(), ctypes.c_void_p
         c = self.ctx if ctx is None else ctx
@@ -207,6 +213,68 @@ class ResidentTable:
         for d in self.lane_aux.values():
             self.ctx.free(d)
         self.lane_aux = {}
+
+
+def prove_device_trace(ctx, stark, d_trace: int, pis, d_aux: int, cap: int = 1 << 25) -> bytes:
+    """vx_stark_begin -> second-round columns ON THE GPU (the table's AuxProgram) -> vx_stark_finish2, for a trace in device memory;
+    `d_aux` = [num_aux_columns][n] scratch of the calling lane."""
+    import vectorx_amd as vx
+    L, vp = vx.lib(), ctypes.c_void_p
+    sess = vp()
+    chal = np.zeros(max(1, stark.desc.num_aux_challenges), dtype=np.uint64)
+    pis = np.ascontiguousarray(pis, dtype=np.uint64)
+    rc = L.vx_stark_begin(ctx._h, ctypes.cast(stark.desc_ptr, vp), vp(d_trace), 1, pis.ctypes.data if pis.size else None, chal.ctypes.data, ctypes.byref(sess))
+    if rc != 0:
+        raise RuntimeError(L.vx_last_error().decode())
+    try:
+        api = None
+        if stark.desc.num_aux_columns:
+            if stark.aux_program is None:
+                raise RuntimeError("prove_device_trace: the table has second-round columns but no AuxProgram to compute them on the GPU")
+            api = stark.run_aux_gpu(ctx, d_trace, chal[:stark.desc.num_aux_challenges], d_aux)
+        out = np.empty(cap, dtype=np.uint8)
+        nb = ctypes.c_size_t(cap)
+        rc = L.vx_stark_finish2(sess, vp(d_aux), 1, None if api is None or api.size == 0 else api.ctypes.data, None, out.ctypes.data, ctypes.byref(nb))
+        if rc != 0:
+            raise RuntimeError(L.vx_last_error().decode())
+        return out[:nb.value].tobytes()
+    finally:
+        L.vx_stark_session_free(sess)
+
+
+class GeneratedHashTable:
+    """A hash-chip table whose trace is generated PER JOB on the GPU (round 5): `messages_fn(job)` -> the byte strings this job hashes
+    (a map job's 8 headers, a job's SHA-256 tree nodes ...), `Context.trace_hash_table` fills the lane's trace buffer with native
+    kernels (vx_trace_*), then the table is proven from that buffer.  One trace + one second-round buffer per lane, allocated up
+    front.  `take_spent(ctx)` reports the seconds of the last prove that went into trace generation (incl. deriving the messages)."""
+
+    def __init__(self, ctx, which: str, stark, log_n: int, messages_fn, lanes, name=""):
+        self.ctx, self.which, self.stark, self.log_n, self.messages_fn, self.name = ctx, which, stark, log_n, messages_fn, name
+        ncols = ctx.TRACE_TABLES[which][0]
+        assert ncols == stark.desc.num_columns, (which, ncols, stark.desc.num_columns)
+        n = 1 << log_n
+        self.bufs = {id(c): (ctx.alloc(ncols * n * 8), ctx.alloc(max(8, stark.desc.num_aux_columns * n * 8))) for c in lanes}
+        self.spent = {}
+        self.last = {}
+
+    def prove(self, ctx=None, job=None) -> bytes:
+        c = self.ctx if ctx is None else ctx
+        d_trace, d_aux = self.bufs[id(c)]
+        t0 = time.perf_counter()
+        msgs = self.messages_fn(job)
+        pis, digests = c.trace_hash_table(self.which, self.log_n, msgs, d_trace)
+        self.spent[id(c)] = [("trace_generation", time.perf_counter() - t0)]
+        self.last[id(c)] = (msgs, digests)
+        return prove_device_trace(c, self.stark, d_trace, pis, d_aux)
+
+    def take_spent(self, ctx=None):
+        return self.spent.pop(id(self.ctx if ctx is None else ctx), None)
+
+    def free(self):
+        for a, b in self.bufs.values():
+            self.ctx.free(a)
+            self.ctx.free(b)
+        self.bufs = {}
 
 
 def eddsa_signatures(count: int, distinct: int = 8, seed: int = 2024):
@@ -275,10 +343,11 @@ def bench_eddsa(ctx, log_n: int = 20, steps: int = 3, warmup: int = 1, distinct:
             "steps": steps, "warmup": warmup, "n_gpus": 1, "data": "synthetic", "trace_cells_per_s": (ncols + naux) * (1 << log_n) / dt}
 
 
-def bench_table(ctx, stark, trace, public_inputs, name: str, steps: int = 3, warmup: int = 1, extra=None) -> dict:
-    """any table through ResidentTable: trace and second-round columns resident in HBM, HIP-event stage times"""
+def bench_table(ctx, stark, trace, public_inputs, name: str, steps: int = 3, warmup: int = 1, extra=None, d_trace=None) -> dict:
+    """any table through ResidentTable: trace resident in HBM, second-round columns computed on the GPU in every proof (tables with an
+    AuxProgram), HIP-event stage times"""
     t0 = time.perf_counter()
-    tab = ResidentTable(ctx, stark, trace, public_inputs, name)
+    tab = ResidentTable(ctx, stark, trace, public_inputs, name, d_trace=d_trace)
     try:
         proof = tab.prove()
         t_first = time.perf_counter() - t0 - tab.aux_seconds_host
