@@ -13,13 +13,23 @@ class FakeProver:
     def prove(self, key, public_inputs, lane=0, input_seed=b"", spent_out=None, with_tables=True):
         t0 = time.perf_counter()
         time.sleep(self.delay * (1 + (key[1] % 3)))
-        proof = hashlib.sha256(b"|".join([self.kind.encode(), b"%d,%d" % tuple(key), bytes(public_inputs.tobytes()), bytes(input_seed),
-                                          b"T" if with_tables else b"P"])).digest() * 4
+        proof = hashlib.sha256(b"|".join([self.kind.encode(), b"%d,%d" % tuple(key), bytes(public_inputs.tobytes()), bytes(input_seed)])).digest() * 4
+        if with_tables:
+            proof += self._tables(key, input_seed)
         if spent_out is not None:
             spent_out.append(("plonky2", time.perf_counter() - t0))
             if with_tables:
                 spent_out.append(("trace_generation", 0.0001))
         return proof
+
+    def _tables(self, key, input_seed):
+        return hashlib.sha256(b"tables|" + self.kind.encode() + b"%d,%d" % tuple(key) + bytes(input_seed)).digest()
+
+    def prove_tables(self, key, lane=0, input_seed=b"", spent_out=None):
+        time.sleep(self.delay * 3)
+        if spent_out is not None:
+            spent_out.append(("eddsa", self.delay * 3))
+        return self._tables(key, input_seed)
 
 
 def make(cfg, device):

@@ -25,18 +25,21 @@ def one_process_root(spec, seed, with_tables=True):
 
 
 @pytest.mark.parametrize("workers,lanes", [(1, 1), (2, 2), (3, 1)])
-def test_pool_root_equals_the_one_process_root(workers, lanes):
+@pytest.mark.parametrize("with_starks", [False, True])
+def test_pool_root_equals_the_one_process_root(workers, lanes, with_starks):
     spec = mr.DagSpec(8, 10, 9, 11)
-    pool = DagPool(spec, devices=(0,), workers_per_device=workers, lanes=lanes, factory="_pool_factory:make").start()
+    pool = DagPool(spec, devices=(0,), workers_per_device=workers, lanes=lanes, factory="_pool_factory:make", with_starks=with_starks).start()
     try:
         ready = pool.wait_ready(timeout=120)
         assert sorted(r["worker"] for r in ready) == list(range(workers))
+        cfg_tables = pool.cfg["with_starks"]
         for seed in (b"", b"request 7"):
             res = pool.run(seed)
-            assert res["root"] == one_process_root(spec, seed)
+            assert res["root"] == one_process_root(spec, seed) == pool.run(seed, schedule="layers")["root"]
             assert res["proofs"] == 8 + 7 + 1 and sum(res["jobs_by_worker"]) == 16
             assert [l["jobs"] for l in res["per_layer"]] == [8, 4, 2, 1, 1]
-            assert set(res["split"]) == {"plonky2", "trace_generation"}
+            assert res["outer_tables_hoisted"] == with_starks
+            assert set(res["split"]) == {"plonky2", "trace_generation"} | ({"eddsa"} if cfg_tables else set())
         if workers > 1:
             assert min(res["jobs_by_worker"]) > 0, "every worker takes jobs"
         res = pool.run(b"x", with_tables=False)

@@ -18,7 +18,8 @@ def test_pool_root_equals_the_one_process_root_with_per_job_tables(ctx):
         ready = pool.wait_ready(timeout=1500)
         assert len(ready) == 2 and {r["device"] for r in ready} == {0}
         with_tables = pool.run(b"request 1")
-        again = pool.run(b"request 1")
+        again = pool.run(b"request 1", schedule="layers")
+        assert with_tables["outer_tables_hoisted"] and not again["outer_tables_hoisted"]
         other = pool.run(b"request 2")
         plain = pool.run(b"request 1", with_tables=False)
     finally:

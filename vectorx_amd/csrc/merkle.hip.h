@@ -147,8 +147,10 @@ __global__ __launch_bounds__(HASH_THREADS) void merkle_level_coop_kernel(const u
 #define MTOP_GROUPS (MTOP_THREADS / 16)
 #define MTOP_MAX_CHILDREN (2 * COOP_MAX_NODES)
 #define MTOP_MAX_COUNTERS 256
+// `publish`: the LAST level's nodes are what another workgroup will read — they are stored with agent-scope atomic stores (sc1: to
+// memory, not into this XCD's L2, whose 128-byte lines are shared with nodes of workgroups on other XCDs).
 GLD void merkle_top_reduce(u64 (*buf)[256 * 4], int& cur, unsigned cnt, int nlev, u64* __restrict__ tree, size_t& lvl_off,
-                           size_t& lvl_n, size_t& idx0, const u64* rc) {
+                           size_t& lvl_n, size_t& idx0, const u64* rc, bool publish) {
   const int tid = (int)threadIdx.x, grp = tid >> 4, g = tid & 15, group_base = (tid & 63) & ~15;
   for (int lev = 0; lev < nlev; ++lev) {
     const unsigned parents = cnt >> 1;
@@ -164,7 +166,8 @@ GLD void merkle_top_reduce(u64 (*buf)[256 * 4], int& cur, unsigned cnt, int nlev
         if (live && g < 4) {
           v = gl_canon(v);
           buf[cur ^ 1][p * 4 + g] = v;
-          tree[(lvl_off + idx0 + p) * 4 + g] = v;
+          if (publish && lev == nlev - 1) __hip_atomic_store(&tree[(lvl_off + idx0 + p) * 4 + g], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          else tree[(lvl_off + idx0 + p) * 4 + g] = v;
         }
       }
     }
@@ -186,27 +189,34 @@ __global__ __launch_bounds__(MTOP_THREADS) void merkle_top_kernel(u64* __restric
   __syncthreads();
   int cur = 0;
   size_t lvl_off = off, lvl_n = n, idx0 = (size_t)blockIdx.x * cw;
-  merkle_top_reduce(buf, cur, cw, cw_log, tree, lvl_off, lvl_n, idx0, rc);
   const unsigned nwg = n >> cw_log;
+  merkle_top_reduce(buf, cur, cw, cw_log, tree, lvl_off, lvl_n, idx0, rc, nwg > ncap);
   if (nwg <= ncap) return;                 // one workgroup per cap subtree: done
   const unsigned m = nwg / ncap, sub = blockIdx.x / m;   // m workgroups (= m phase-1 nodes) per cap subtree
-  __threadfence();                         // this workgroup's node (written by group 0) is visible device-wide before it is counted
+  // hand-off (cdna_hip_programming.md Guideline 16): the node went out with agent-scope stores; every wave drains its stores, the
+  // workgroup meets, ONE lane releases at agent scope and THEN draws its ticket (this order; the asm wait after the fence is the one the
+  // compiler may not drop)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid == 0) {
-    const unsigned prev = __hip_atomic_fetch_add(&counters[sub], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned prev = __hip_atomic_fetch_add(&counters[sub], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_last = prev == m - 1;
-    if (prev == m - 1) __hip_atomic_store(&counters[sub], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (prev == m - 1) {
+      __hip_atomic_store(&counters[sub], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
   }
   __syncthreads();
   if (!s_last) return;
-  __threadfence();                         // acquire: the other workgroups' nodes
-  const u64* nodes = tree + (lvl_off + (size_t)sub * m) * 4;
-  for (unsigned i = tid; i < m * 4; i += MTOP_THREADS) buf[cur][i] = __builtin_nontemporal_load(nodes + i);
+  const u64* nodes = tree + (lvl_off + (size_t)sub * m) * 4;   // agent-scope loads: served past this CU's L1, like the stores that wrote them
+  for (unsigned i = tid; i < m * 4; i += MTOP_THREADS) buf[cur][i] = __hip_atomic_load(nodes + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
   idx0 = (size_t)sub * m;
   int mlog = 0;
   while ((1u << mlog) < m) ++mlog;
-  merkle_top_reduce(buf, cur, m, mlog, tree, lvl_off, lvl_n, idx0, rc);
+  merkle_top_reduce(buf, cur, m, mlog, tree, lvl_off, lvl_n, idx0, rc, false);
 }
 
 __global__ __launch_bounds__(HASH_THREADS) void hash_leaves_rowmajor_coop_kernel(

@@ -17,9 +17,20 @@
 
 #define TG_THREADS 256
 
-// a lookup histogram update for one value per lane: lanes holding the same key are merged (two leader rounds), so that the
-// all-zero triples of the inactive gadgets — most of a BLAKE2b table's lookups — cost one atomic per wavefront instead of 64 on one address
-__device__ __forceinline__ void tg_hist_add(unsigned* __restrict__ hist, unsigned key, bool valid) {
+// The lookup histogram of a BLAKE2b table takes 232 increments per row — 15 M per map job — into 65 536 bins.  Device-scope atomics
+// are performed at the fabric, not in an XCD's L2 (the eight L2s are not coherent with each other): measured 1.2 G/s, 12.9 ms per
+// table (profiles/r05_tracegen.md).  So every XCD counts into ITS OWN copy of the histogram with atomics that stay in its L2
+// (workgroup scope: no sc1 — all the CUs that touch copy x sit behind L2 x, which serialises them; HW_REG_XCC_ID names the XCD a
+// workgroup runs on and a workgroup never moves), the copies reach memory at the end of the kernel, and the kernel that writes the
+// multiplicity columns adds the eight up.  Lanes holding the same key are merged first (two leader rounds): the all-zero triples of
+// the inactive gadgets — most of a table's lookups — cost one atomic per wavefront instead of 64 on one address.
+#define TG_HIST_COPIES 8
+__device__ __forceinline__ unsigned tg_xcc_id() {
+  unsigned v;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+  return v & (TG_HIST_COPIES - 1);
+}
+__device__ __forceinline__ void tg_hist_add(unsigned* __restrict__ hist /* this XCD's copy */, unsigned key, bool valid) {
   unsigned long long active = __ballot(valid);
   const int lane = (int)(threadIdx.x & 63);
 #pragma unroll 1
@@ -27,11 +38,11 @@ __device__ __forceinline__ void tg_hist_add(unsigned* __restrict__ hist, unsigne
     const int leader = __ffsll((long long)active) - 1;
     const unsigned k0 = (unsigned)__shfl((int)key, leader, 64);
     const unsigned long long same = __ballot(valid && key == k0);
-    if (lane == leader) atomicAdd(&hist[k0], (unsigned)__popcll(same));
+    if (lane == leader) __hip_atomic_fetch_add(&hist[k0], (unsigned)__popcll(same), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     active &= ~same;
     if (key == k0) valid = false;
   }
-  if (valid) atomicAdd(&hist[key], 1u);
+  if (valid) __hip_atomic_fetch_add(&hist[key], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 template <class T>
@@ -61,10 +72,13 @@ __global__ __launch_bounds__(TG_THREADS) void tg_sha2_rows_kernel(const tg::Sha2
   __syncthreads();
   if (threadIdx.x < 8 && lh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], lh[threadIdx.x]);
 }
-// trace[col][i] = hist[base + i] for i < count
-__global__ void tg_patch_mult_kernel(u64* __restrict__ col, const unsigned* __restrict__ hist, unsigned count) {
+// trace[col][i] = sum over the `copies` histograms (each `stride` entries apart) of hist[i], for i < count
+__global__ void tg_patch_mult_kernel(u64* __restrict__ col, const unsigned* __restrict__ hist, unsigned count, int copies, size_t stride) {
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < count) col[i] = hist[i];
+  if (i >= count) return;
+  u64 s = 0;
+  for (int x = 0; x < copies; ++x) s += hist[(size_t)x * stride + i];
+  col[i] = s;
 }
 
 __global__ __launch_bounds__(TG_THREADS) void tg_b2_expand_kernel(const tg::b2::Block* __restrict__ blocks, int nb,
@@ -86,9 +100,10 @@ __global__ __launch_bounds__(TG_THREADS) void tg_b2_rows_kernel(const tg::b2::Bl
   const uint64_t* hn_prev = b ? exp[b - 1].hn : zero8;
   const uint64_t* dl = blk.dsrc >= 0 ? exp[blk.dsrc].hn : zero8;
   const bool count = in && row + 1 < n;
+  unsigned* my_hist = hist + (size_t)tg_xcc_id() * 65536;
   tg::b2::row(blk, exp[b], hn_prev, dl, r, row, tg::B2_IV, tg::B2_SIGMA,
               [&](int col, uint64_t v) { if (in) trace[(size_t)col * n + row] = v; },
-              [&](unsigned a, unsigned bb) { tg_hist_add(hist, a * 256u + bb, count); });
+              [&](unsigned a, unsigned bb) { tg_hist_add(my_hist, a * 256u + bb, count); });
 }
 
 // ---- C ABI ----------------------------------------------------------------------------------------------------------------------
@@ -119,7 +134,7 @@ static int tg_trace_sha2(vx_ctx* c, int degree_bits, const uint8_t* msgs, const 
                          (const tg::Sha2Block<T>*)d_blocks, nb, (tg::Sha2Expanded<T>*)d_exp);
       hipLaunchKernelGGL(tg_sha2_rows_kernel<T>, dim3((unsigned)((n + TG_THREADS - 1) / TG_THREADS)), dim3(TG_THREADS), 0, c->stream,
                          (const tg::Sha2Block<T>*)d_blocks, (const tg::Sha2Expanded<T>*)d_exp, (u64*)d_trace, n, (unsigned*)d_hist);
-      hipLaunchKernelGGL(tg_patch_mult_kernel, dim3(1), dim3(64), 0, c->stream, (u64*)d_trace + (size_t)T::MULT * n, (const unsigned*)d_hist, 8u);
+      hipLaunchKernelGGL(tg_patch_mult_kernel, dim3(1), dim3(64), 0, c->stream, (u64*)d_trace + (size_t)T::MULT * n, (const unsigned*)d_hist, 8u, 1, (size_t)0);
       e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);   // the host block list goes out of scope
@@ -156,7 +171,7 @@ int vx_trace_blake2b(vx_ctx* c, int degree_bits, const uint8_t* msgs, const uint
   const size_t n = (size_t)1 << degree_bits;
   const int nb = (int)prep.blocks.size();
   void *d_blocks = nullptr, *d_exp = nullptr, *d_hist = nullptr;
-  const size_t bb = (size_t)nb * sizeof(tg::b2::Block), eb = (size_t)nb * sizeof(tg::b2::Expanded), hb = 65536 * sizeof(unsigned);
+  const size_t bb = (size_t)nb * sizeof(tg::b2::Block), eb = (size_t)nb * sizeof(tg::b2::Expanded), hb = (size_t)TG_HIST_COPIES * 65536 * sizeof(unsigned);
   if (c->pool_alloc(&d_blocks, bb) != hipSuccess || c->pool_alloc(&d_exp, eb) != hipSuccess || c->pool_alloc(&d_hist, hb) != hipSuccess) {
     c->pool_free(d_blocks), c->pool_free(d_exp), c->pool_free(d_hist);
     return vx_fail(VX_E_NOMEM, "vx_trace_blake2b: out of device memory");
@@ -174,7 +189,7 @@ int vx_trace_blake2b(vx_ctx* c, int degree_bits, const uint8_t* msgs, const uint
       for (int k = 0; k < tg::b2::NTAB; ++k)
         hipLaunchKernelGGL(tg_patch_mult_kernel, dim3(tg::b2::TAB_ROWS / 256), dim3(256), 0, c->stream,
                            (u64*)trace_dev + (size_t)tg::b2::tabcol(k, 19) * n, (const unsigned*)d_hist + (size_t)tg::b2::TAB_ROWS * k,
-                           (unsigned)tg::b2::TAB_ROWS);
+                           (unsigned)tg::b2::TAB_ROWS, TG_HIST_COPIES, (size_t)65536);
       e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);

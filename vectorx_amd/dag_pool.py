@@ -112,42 +112,112 @@ class DagPool:
         self.procs, self.conns = [], []
 
     # ---- one DAG ---------------------------------------------------------------------------------------------------------------
-    def run(self, input_seed: bytes = b"", with_tables: bool = True) -> dict:
-        """one DAG.  with_tables = False: the plonky2 proofs only (workers loaded with tables skip them)"""
+    def run(self, input_seed: bytes = b"", with_tables: bool = True, schedule: str = "dependency") -> dict:
+        """One DAG.  with_tables = False: the plonky2 proofs only (workers loaded with tables skip them).
+        schedule = "dependency" (default): a job starts as soon as ITS children are proven — the narrow top of the reduce tree runs while
+        the last map jobs finish — and the outer job's STARK tables, which depend on the REQUEST (the justification: authority set,
+        signed messages, signatures — /root/reference/circuits/builder/justification.rs:140-156, 237-243) and not on any child proof, are
+        one more task, queued behind the map jobs, that worker 0's outer lane proves while the tree is still being reduced; the outer
+        plonky2 proof then only waits for the root reduce proof.  schedule = "layers": strict layer barriers, nothing hoisted (rounds 1-4).
+        Same proofs, same digests, same root either way."""
         layers = self.spec.layers()
+        nl = len(layers)
+        hoist = schedule == "dependency" and with_tables and self.cfg["with_starks"]
         free = [self.lanes] * len(self.conns)
-        split, per_layer, prev = {}, [], {}
-        jobs_by_worker = [0] * len(self.conns)
+        outer_free = 1                      # worker 0's dedicated outer lane
+        split, jobs_by_worker = {}, [0] * len(self.conns)
+        digests = [dict() for _ in range(nl)]
+        span = [[None, None] for _ in range(nl)]
+        ready = deque((0, j) for j in layers[0][1])
+        if hoist:
+            ready.append(("outer_tables",))
+        tables_done = not hoist
+        outer_waiting = None                # the outer job, ready but for its hoisted tables
+        done, total, outstanding = 0, sum(len(j) for _, j in layers), 0
         t0 = time.perf_counter()
-        for li, (kind, jobs) in enumerate(layers):
-            tl = time.perf_counter()
-            pending, outstanding, mine = deque(jobs), 0, {}
-            while pending or outstanding:
-                while pending and max(free) > 0:
-                    w = 0 if kind == "outer" else max(range(len(free)), key=lambda i: free[i])   # worker 0 holds the outer circuit
-                    j = pending.popleft()
-                    pis = mr.child_inputs(li, j, prev, input_seed)
-                    self.conns[w].send(("job", li, j, kind, pis.tobytes(), input_seed, with_tables))
+
+        def children(li, j):
+            if li == 0:
+                return []
+            return [0] if len(layers[li - 1][1]) == 1 else [2 * j, 2 * j + 1]
+
+        def parent(li, j):
+            if li + 1 >= nl:
+                return None
+            return (li + 1, 0 if len(layers[li][1]) == 1 else j // 2)
+
+        def dispatch(item):
+            nonlocal outer_free, outstanding
+            now = time.perf_counter()
+            if item[0] == "outer_tables":
+                self.conns[0].send(("outer_tables", nl - 1, 0, input_seed))
+                outer_free -= 1
+            else:
+                li, j = item
+                kind = layers[li][0]
+                prev = digests[li - 1] if li else {}
+                pis = mr.child_inputs(li, j, prev, input_seed)
+                if span[li][0] is None:
+                    span[li][0] = now
+                if kind == "outer":
+                    w = 0
+                    outer_free -= 1
+                else:
+                    w = max(range(len(free)), key=lambda i: free[i])
                     free[w] -= 1
-                    outstanding += 1
-                    jobs_by_worker[w] += 1
-                for c in wait(self.conns):
-                    msg = c.recv()
-                    if msg[0] == "error":
-                        raise RuntimeError(f"DAG worker failed:\n{msg[1]}")
-                    _, rli, rj, dg, spent = msg
-                    assert rli == li
-                    mine[rj] = dg
-                    free[self.conns.index(c)] += 1
-                    outstanding -= 1
-                    for k, v in spent.items():
-                        split[k] = split.get(k, 0.0) + v
-            prev = mine
-            assert sorted(prev) == jobs
-            per_layer.append({"kind": kind, "jobs": len(jobs), "ms": (time.perf_counter() - tl) * 1e3})
+                self.conns[w].send(("job", li, j, kind, pis.tobytes(), input_seed, with_tables, hoist and kind == "outer"))
+                jobs_by_worker[w] += 1
+            outstanding += 1
+
+        def can_run(item):
+            if item[0] == "outer_tables" or layers[item[0]][0] == "outer":
+                return outer_free > 0
+            return max(free) > 0
+
+        while done < total or not tables_done:
+            # hand out what can run now, in queue order (a blocked outer task does not hold back the jobs behind it)
+            for item in list(ready):
+                if can_run(item):
+                    ready.remove(item)
+                    dispatch(item)
+            if not outstanding:
+                raise RuntimeError("DAG scheduler stalled: nothing running and nothing can start")
+            for c in wait(self.conns):
+                msg = c.recv()
+                if msg[0] == "error":
+                    raise RuntimeError(f"DAG worker failed:\n{msg[1]}")
+                w = self.conns.index(c)
+                outstanding -= 1
+                for k, v in msg[-1].items():
+                    split[k] = split.get(k, 0.0) + v
+                if msg[0] == "tables_done":
+                    tables_done = True
+                    outer_free += 1
+                    if outer_waiting is not None:
+                        ready.appendleft(outer_waiting)
+                        outer_waiting = None
+                    continue
+                _, li, j, dg, _spent = msg
+                digests[li][j] = dg
+                span[li][1] = time.perf_counter()
+                done += 1
+                if layers[li][0] == "outer":
+                    outer_free += 1
+                else:
+                    free[w] += 1
+                if schedule == "dependency":
+                    par = parent(li, j)
+                    if par is not None and all(ch in digests[li] for ch in children(*par)):
+                        if layers[par[0]][0] == "outer" and not tables_done:
+                            outer_waiting = par
+                        else:
+                            ready.append(par)
+                elif li + 1 < nl and len(digests[li]) == len(layers[li][1]):       # layer barrier
+                    ready.extend((li + 1, jj) for jj in layers[li + 1][1])
         seconds = time.perf_counter() - t0
-        return {"root": prev[0], "seconds": seconds, "proofs": self.spec.num_proofs(), "per_layer": per_layer, "split": split,
-                "jobs_by_worker": jobs_by_worker}
+        per_layer = [{"kind": layers[li][0], "jobs": len(layers[li][1]), "ms": (span[li][1] - span[li][0]) * 1e3} for li in range(nl)]
+        return {"root": digests[-1][0], "seconds": seconds, "proofs": total, "per_layer": per_layer, "split": split,
+                "jobs_by_worker": jobs_by_worker, "schedule": schedule, "outer_tables_hoisted": hoist}
 
 
 # ---- the worker process ------------------------------------------------------------------------------------------------------------
@@ -160,20 +230,28 @@ def gpu_provers(cfg: dict, device: int):
     lanes = [vx.Context(device) for _ in range(cfg["lanes"] - 1)]
     per_kind, tables, table_rec = {}, [], {}
     kinds = ("map", "reduce", "outer") if cfg["worker_index"] == 0 else ("map", "reduce")
+    # The outer proof (2^19 rows) and its tables (four 2^20-row EdDSA tables, two 2^16-row hash tables) belong to ONE more context of
+    # ONE worker — the "outer lane", with a host thread of its own — so that they can run next to map / reduce jobs; every lane of
+    # every worker holding those shapes would cost ~40 GB of HBM per lane for nothing.
+    octx = vx.Context(device) if "outer" in kinds else None
     if cfg["with_starks"]:
         from . import dag_tables
         per_kind, tables, table_rec = dag_tables.build(ctx, kinds=("map", "reduce"), small=cfg["small_tables"], mode=cfg["table_mode"], lanes=[ctx] + lanes)
-        if "outer" in kinds:
-            pk, tb, tr = dag_tables.build(ctx, kinds=("outer",), small=cfg["small_tables"], mode=cfg["table_mode"], lanes=[ctx])
+        if octx is not None:
+            pk, tb, tr = dag_tables.build(octx, kinds=("outer",), small=cfg["small_tables"], mode=cfg["table_mode"], lanes=[octx])
             per_kind.update(pk)
             tables += tb
             table_rec.update(tr)
     provers = {}
+    layers = spec.layers()
     for kind in kinds:
-        # the outer proof (2^19 rows + four 2^20-row EdDSA tables) runs alone, after the last layer barrier: ONE lane of ONE worker
-        # holds its circuit and its buffers — every lane of every worker doing so would cost ~40 GB of HBM per lane for nothing
-        provers[kind] = mr.GpuProver(ctx, kind, spec.log_n(kind), [], pp, extra_lanes=() if kind == "outer" else lanes,
-                                     distinct_witnesses=cfg["distinct_witnesses"], starks=per_kind.get(kind, ()))
+        # the job list only sizes the set of base witnesses (min(distinct_witnesses, jobs of this kind)): the same as one process would build
+        jobs = [(li, j) for li, (k, js) in enumerate(layers) if k == kind for j in js]
+        if kind == "outer":
+            provers[kind] = mr.GpuProver(octx, kind, spec.log_n(kind), jobs, pp, distinct_witnesses=cfg["distinct_witnesses"], starks=per_kind.get(kind, ()))
+        else:
+            provers[kind] = mr.GpuProver(ctx, kind, spec.log_n(kind), jobs, pp, extra_lanes=lanes, distinct_witnesses=cfg["distinct_witnesses"],
+                                         starks=per_kind.get(kind, ()))
 
     def close():
         for p in provers.values():
@@ -182,6 +260,8 @@ def gpu_provers(cfg: dict, device: int):
             t.free()
         for l in lanes:
             l.close()
+        if octx is not None:
+            octx.close()
         ctx.close()
     return provers, close, {"tables": table_rec}
 
@@ -203,39 +283,51 @@ def _worker(addr: str, device: int, index: int):
         info = dict(info or {})
         info.update({"worker": index, "device": device, "pid": os.getpid(), "setup_seconds": round(time.perf_counter() - t0, 2)})
         conn.send(("ready", info))
-        todo = queue.Queue()
+        todo, todo_outer = queue.Queue(), queue.Queue()
+        hoisted = {}                            # request seed -> the outer job's table proofs, proven ahead of its plonky2 proof
 
-        def lane_main(lane):
+        def lane_main(lane, q):
             while True:
-                item = todo.get()
+                item = q.get()
                 if item is None:
                     return
-                _, li, j, kind, pis, seed, with_tables = item
                 try:
                     spent = []
-                    proof = provers[kind].prove((li, j), np.frombuffer(pis, dtype=np.uint64), 0 if kind == "outer" else lane, input_seed=seed,
-                                                spent_out=spent, with_tables=with_tables)
-                    dg = hashlib.sha256(proof).digest()
+                    if item[0] == "outer_tables":
+                        _, li, j, seed = item
+                        hoisted[bytes(seed)] = provers["outer"].prove_tables((li, j), 0, input_seed=seed, spent_out=spent)
+                        reply = ("tables_done",)
+                    else:
+                        _, li, j, kind, pis, seed, with_tables, tables_hoisted = item
+                        own = with_tables and not tables_hoisted
+                        proof = provers[kind].prove((li, j), np.frombuffer(pis, dtype=np.uint64), 0 if kind == "outer" else lane, input_seed=seed,
+                                                    spent_out=spent, with_tables=own)
+                        if tables_hoisted:
+                            proof += hoisted.pop(bytes(seed))
+                        reply = ("done", li, j, hashlib.sha256(proof).digest())
                     acc = {}
                     for label, dt in spent:
                         acc[label] = acc.get(label, 0.0) + dt
                     with send_lock:
-                        conn.send(("done", li, j, dg, acc))
+                        conn.send(reply + (acc,))
                 except BaseException:
                     with send_lock:
                         conn.send(("error", traceback.format_exc()))
                     return
 
-        threads = [threading.Thread(target=lane_main, args=(lane,), daemon=True) for lane in range(cfg["lanes"])]
+        threads = [threading.Thread(target=lane_main, args=(lane, todo), daemon=True) for lane in range(cfg["lanes"])]
+        if "outer" in provers:
+            threads.append(threading.Thread(target=lane_main, args=(0, todo_outer), daemon=True))
         for t in threads:
             t.start()
         while True:
             msg = conn.recv()
             if msg[0] == "stop":
                 break
-            todo.put(msg)
+            (todo_outer if msg[0] == "outer_tables" or msg[3] == "outer" else todo).put(msg)
         for _ in threads:
             todo.put(None)
+        todo_outer.put(None)
         for t in threads:
             t.join(timeout=30)
         close()

@@ -232,7 +232,7 @@ def run_dag(spec: DagSpec, make_prover, dist=None, sync=lambda: None, in_flight:
     return {"root": prev[0], "seconds": seconds, "proofs": spec.num_proofs(), "per_layer": per_layer, "my_proofs": all_proofs}
 
 
-def prove_with_tables(prove_main, tables, lane_ctx=None, split=None, lock=None, job=None, spent_out=None) -> bytes:
+def prove_with_tables(prove_main, tables, lane_ctx=None, split=None, lock=None, job=None, spent_out=None, main_label="plonky2") -> bytes:
     """One job of the DAG = its plonky2 proof followed by the proofs of the STARK tables its circuit embeds (`tables`: [(label, object
     with .prove(ctx, job) -> bytes)]): the concatenation is what the job's digest — and so its parent's public inputs — covers.
     `job` = (kind, layer, index, input_seed): what a per-job table derives ITS inputs from (the headers a map job hashes, the keys and
@@ -241,7 +241,7 @@ def prove_with_tables(prove_main, tables, lane_ctx=None, split=None, lock=None, 
     `split` (dict, guarded by `lock`) accumulates the wall seconds spent per kind of work; `spent_out` (list) receives this job's own."""
     t0 = time.perf_counter()
     parts = [prove_main()]
-    spent = [("plonky2", time.perf_counter() - t0)]
+    spent = [(main_label, time.perf_counter() - t0)] if main_label else []
     for label, table in tables:
         t0 = time.perf_counter()
         parts.append(table.prove(lane_ctx, job))
@@ -326,6 +326,12 @@ class GpuProver:
         ctx.upload_row(d, self.n, 2, r2)
         return prove_with_tables(lambda: self.circuits[lane].prove(dev_ptr=d), self.starks if with_tables else (), ctx, self.split, self._lock,
                                  job=(self.kind, key[0], key[1], input_seed), spent_out=spent_out)
+
+    def prove_tables(self, key, lane=0, input_seed=b"", spent_out=None) -> bytes:
+        """the STARK proofs of job `key` alone, in the order `prove` appends them: for a job whose tables do not depend on its children
+        (the outer job's: vectorx_amd/dag_pool.py proves them while the reduce tree is still running)"""
+        return prove_with_tables(lambda: b"", self.starks, self.lanes[lane], self.split, self._lock, job=(self.kind, key[0], key[1], input_seed),
+                                 spent_out=spent_out, main_label=None)
 
     def free(self):
         for d in self.wit.values():
