@@ -51,9 +51,10 @@ def parse():
                     help="seconds the world > 1 legs may take together before every rank gives up on them and rank 0 prints the line without them")
     ap.add_argument("--no-dag-stark-leg", action="store_true",
                     help="skip the extra leg that proves the header_range_512 DAG WITH the STARK tables of every job (BLAKE2b / SHA-256 / SHA-512 / batched EdDSA)")
-    ap.add_argument("--dag-workers", type=int, default=2,
+    ap.add_argument("--dag-workers", type=int, default=3,
                     help="worker PROCESSES per GPU of the DAG legs (vectorx_amd/dag_pool.py; each keeps --dag-lanes jobs in flight); 0 = the one-process scheduler of rounds 1-4")
-    ap.add_argument("--dag-lanes", type=int, default=3)
+    ap.add_argument("--dag-lanes", type=int, default=2,
+                    help="jobs in flight per worker process (3 workers x 2 lanes measured 2.7 %% ahead of 2 x 3 on the DAG with its tables: profiles/r05_dag_pool.jsonl)")
     ap.add_argument("--dag-table-mode", default="per_job", choices=["per_job", "resident"],
                     help="STARK tables of the DAG: per_job = every job's own inputs, traces generated on the GPU inside the clock; resident = one host-generated trace per table kind (rounds 3-4)")
     ap.add_argument("--extra-legs-deadline", type=float, default=1500.0,
@@ -351,24 +352,27 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline_commit(args) if args.workload == "commit" else bench_prove.cpu_baseline(args)
 
-    # ---- THE CONTRACT'S LINE IS COMPLETE: it goes out NOW.  Everything below is optional legs; when they finish, rank 0 prints the same
-    # line again with their results added (a reader that wants one line takes the last).  A leg that hangs — a lost peer, a wedged
-    # collective, a worker that never comes up — can therefore cost the legs, never the measurement: a watchdog in every rank ends the
-    # process at the deadline, and a SIGTERM from a launcher that lost a rank only sets a flag that the main thread acts on.
+    # ---- THE CONTRACT'S LINE IS COMPLETE.  Everything below is optional legs, and ONE line goes to stdout whatever happens to them:
+    #   * when they finish: the line with their results;
+    #   * at the deadline (a worker that never comes up, a collective that never returns): a watchdog THREAD prints the line as it
+    #     stands and ends the process — the main thread may be stuck inside a library call;
+    #   * on SIGTERM (a launcher that lost a rank, a driver that ran out of patience): the C-level handler writes the signal number to a
+    #     wake-up pipe at once, in whatever thread it lands; a second thread blocked on that pipe prints the line and ends the process —
+    #     no Python-level handler has to wait for the main thread to come back from a collective.
+    # The line lock is re-entrant and the line is built from a snapshot, so none of the three can deadlock or tear the others' output.
+    import signal
     import threading
     line_lock = threading.RLock()
-    state = {"lines": 0, "stop": None}
+    state = {"printed": False}
 
     def emit_line(extra=None):
         with line_lock:
-            if rank == 0:
+            if rank == 0 and not state["printed"]:
                 d = dict(out)
                 if extra:
                     d.update(extra)
                 print(json.dumps(d), flush=True)
-            state["lines"] += 1
-
-    emit_line()
+            state["printed"] = True
 
     def give_up(why):
         emit_line({"extra_legs": {"error": why + "; everything else in this line is complete"}})
@@ -376,17 +380,24 @@ def main():
 
     multi = args.workload == "prove" and world > 1 and not args.no_multi_rank_legs and not args.circuit_flags
     deadline = args.multi_rank_leg_deadline if world > 1 else args.extra_legs_deadline
-    watchdog = threading.Timer(deadline, lambda: give_up(f"the legs after the contract's line did not finish within {deadline} s"))
+    watchdog = threading.Timer(deadline, lambda: give_up(f"the legs after the timed region did not finish within {deadline} s"))
     watchdog.daemon = True
     watchdog.start()
-    if multi:
-        import signal
-        # the handler only records the request; `check_stop` (between library calls of the legs) acts on it from the main thread
-        signal.signal(signal.SIGTERM, lambda *_: state.__setitem__("stop", "the launcher ended the ranks (SIGTERM) during the multi-rank legs"))
+    wake_r, wake_w = os.pipe()
+    os.set_blocking(wake_w, False)
+    signal.signal(signal.SIGTERM, lambda *_: None)          # a handler must exist for the wake-up fd to be written; the work is done below
+    signal.set_wakeup_fd(wake_w, warn_on_full_buffer=False)
 
-    def check_stop():
-        if state["stop"]:
-            give_up(state["stop"])
+    def on_signal():
+        while True:
+            b = os.read(wake_r, 1)
+            if not b:
+                return
+            if b[0] == signal.SIGTERM:
+                give_up("the process was told to terminate (SIGTERM) during the legs after the timed region")
+
+    sig_thread = threading.Thread(target=on_signal, daemon=True)
+    sig_thread.start()
 
     legs = {}
     single = args.workload == "prove" and world == 1 and args.log_n >= 20 and not args.circuit_flags
@@ -414,11 +425,8 @@ def main():
     sharded_leg = dag_n_leg = dag_n_stark_leg = None
     if multi:
         dev = None if on_host else torch.device("cuda", local_rank)
-        check_stop()
         sharded_leg = bench_prove.guarded_collective_leg(dist, lambda: bench_prove.sharded_one_proof_leg(ctx, args, rank, world, dist, dev, sync))
-        check_stop()
         dag_n_leg = bench_prove.guarded_collective_leg(dist, lambda: bench_prove.dag_leg_ranks(ctx, args, local_rank, dist, dev))
-        check_stop()
         if not args.no_dag_stark_leg:
             dag_n_stark_leg = bench_prove.guarded_collective_leg(dist, lambda: bench_prove.dag_leg_ranks(ctx, args, local_rank, dist, dev, with_starks=True))
 
@@ -431,8 +439,8 @@ def main():
             out["dag_header_range_512"] = dag_n_leg
         if dag_n_stark_leg is not None:
             out["dag_header_range_512_with_starks"] = dag_n_stark_leg
-    if legs or multi:
-        emit_line()
+    emit_line()
+    signal.set_wakeup_fd(-1)
     if dag_pool is not None:
         dag_pool.close()
     if dist is not None:

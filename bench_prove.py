@@ -251,10 +251,11 @@ def sharded_one_proof_leg(ctx, args, rank, world, dist, device, sync):
     return {"ms_per_proof": round(dt / steps * 1e3, 3), "proofs_per_sec": steps / dt, "ranks": world, "steps": steps,
             "log_n": args.log_n, "scaling": "strong", "backend": dist.get_backend(),
             "allgather_calls_per_proof": ag.calls / steps, "inbound_bytes_per_rank_per_proof": ag.bytes / steps,
-            "exchange_host_wait_ms_rank0": round(wait, 3),
+            "exchange_host_wait_ms_rank0": round(wait, 3), "exchange_host_wait_ms": round(wait, 3),
             "rank0_stage_ms": {k: round(v["ms"] / steps, 3) for k, v in prof.items() if v["ms"] / steps >= 0.05},
             "all_ranks_returned_the_same_proof": len(set(same)) == 1,
             "byte_identical_to_unsharded_vx_prove": (proof == whole) if rank == 0 else None,
+            "identical_to_unsharded": (proof == whole) if rank == 0 else None, "rccl_ranks": world,
             "what": "one proof coset-sharded over all ranks (vx_prove_sharded), witness HBM-resident on every rank; NOT the contract's timed region"}
 
 

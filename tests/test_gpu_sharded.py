@@ -342,19 +342,24 @@ def _check_multi_rank_legs(line, world, backend):
     assert sh["ranks"] == world and sh["ms_per_proof"] > 0 and sh["backend"] == backend
     assert sh["allgather_calls_per_proof"] == EXCHANGES_PER_PROOF["device"] and sh["inbound_bytes_per_rank_per_proof"] > 0
     assert sh["all_ranks_returned_the_same_proof"] is True and sh["byte_identical_to_unsharded_vx_prove"] is True
+    assert sh["identical_to_unsharded"] is True and sh["rccl_ranks"] == world and sh["exchange_host_wait_ms"] >= 0
     assert "exchange_host_wait_ms_rank0" in sh
+    # the line names every rank's device: N ranks, each with a PCI bus id (N DISTINCT ids on a real node, one on the emulation)
+    assert line["rccl_ranks"] == world and len(line["rank_devices"]) == world
+    assert all(isinstance(d["pci_bus_id"], int) and d["pci_bus_id"] >= 0 for d in line["rank_devices"])
     dag = line["dag_header_range_512"]
     assert "error" not in dag, dag
     assert dag["ranks"] == world and dag["dag_seconds"] > 0 and len(dag["root"]) == 64
     assert dag["plonky2_proofs"] == sum(l[1] for l in dag["per_layer_ms"])
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_bench_multi_rank_code_path_on_one_device(world):
     """`python bench.py --gpus N` exactly as the driver runs it, but with the N ranks as processes on DEVICE 0 over gloo (RCCL refuses
     duplicate devices): the weak-scaling line + the sharded-one-proof leg + the N-rank DAG leg, tiny sizes.  The single-GPU boxes
     run this every round, so the code the 8-GPU driver run takes has been executed before it gets there."""
-    r = _plain_bench("--gpus", str(world), "--ranks-on-one-device", "--log-n", "12", "--dag-spec", "4,10,9,11", "--sharded-leg-steps", "2",
+    r = _plain_bench("--gpus", str(world), "--ranks-on-one-device", "--log-n", "12" if world < 8 else "10", "--dag-spec", "4,10,9,11" if world < 8 else "8,9,8,10",
+                     "--sharded-leg-steps", "2",
                      *(["--dag-starks-small"] if world == 2 else ["--no-dag-stark-leg"]))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -364,7 +369,7 @@ def test_bench_multi_rank_code_path_on_one_device(world):
     assert line["scaling"] == "weak" and "emulated_ranks_on_one_device" in line
     assert [d["rank"] for d in line["rank_devices"]] == list(range(world))
     _check_multi_rank_legs(line, world, "gloo")
-    assert line["dag_header_range_512"]["plonky2_proofs"] == 4 + 3 + 1
+    assert line["dag_header_range_512"]["plonky2_proofs"] == (4 + 3 + 1 if world < 8 else 8 + 7 + 1)
     if world == 2:      # the same DAG with every job's STARK tables (smallest shapes), over both ranks
         ds = line["dag_header_range_512_with_starks"]
         assert "error" not in ds, ds
@@ -381,7 +386,7 @@ def test_bench_line_survives_multi_rank_legs_that_never_finish():
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     line = json.loads(lines[0])
-    assert line["n_gpus"] == 2 and line["value"] > 0 and "did not finish" in line["multi_rank_legs"]["error"]
+    assert line["n_gpus"] == 2 and line["value"] > 0 and "did not finish" in line["extra_legs"]["error"]
 
 
 def test_bench_refuses_more_gpus_than_visible():

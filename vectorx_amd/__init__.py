@@ -634,7 +634,11 @@ class Stark:
             fn_ptr = ctypes.cast(allgather, ctypes.c_void_p) if allgather is not None else None
         _chk(lib().vx_stark_begin_sharded(ctx._h, ctypes.cast(self.desc_ptr, _vp), t.ctypes.data, 0, pi.ctypes.data if pi.size else None, rank, world,
                                           fn_ptr, user, chal.ctypes.data, ctypes.byref(sess)))
-        self._keep_cb = keep             # the callback must outlive the session
+        # the ctypes trampoline must outlive the session — one entry PER SESSION (several sharded sessions of one Stark may be open at once:
+        # ranks as threads, overlapping proofs); dropped when the session has produced its proof (finish) or is freed (session_free)
+        if not isinstance(getattr(self, "_keep_cb", None), dict):
+            self._keep_cb = {}
+        self._keep_cb[sess.value] = keep
         return sess, chal[:self.desc.num_aux_challenges].copy(), t
 
     def session_trace_cap(self, sess) -> np.ndarray:
@@ -649,7 +653,11 @@ class Stark:
         hint = ctypes.c_uint64(pow_witness) if pow_witness is not None else None
         hint_p = None if hint is None else ctypes.cast(ctypes.pointer(hint), _vp)
         api = None if aux_public_inputs is None or len(aux_public_inputs) == 0 else np.ascontiguousarray(aux_public_inputs, dtype=np.uint64)
-        _chk(lib().vx_stark_finish2(sess, aux.ctypes.data, 0, None if api is None else api.ctypes.data, hint_p, out.ctypes.data, ctypes.byref(n)))
+        try:
+            _chk(lib().vx_stark_finish2(sess, aux.ctypes.data, 0, None if api is None else api.ctypes.data, hint_p, out.ctypes.data, ctypes.byref(n)))
+        finally:
+            if isinstance(getattr(self, "_keep_cb", None), dict):     # the session makes no exchange after its proof is out
+                self._keep_cb.pop(getattr(sess, "value", None), None)
         return out[:n.value].tobytes()
 
     def prove(self, ctx, trace, public_inputs, pow_witness=None) -> bytes:

@@ -6,6 +6,9 @@
 #include <chrono>
 #include <condition_variable>
 #include <mutex>
+#include <fcntl.h>
+#include <sys/file.h>
+#include <unistd.h>
 #include "plonk_kernels.hip.h"
 #include "aux.hip.h"
 #include "jit.hip.h"
@@ -574,6 +577,29 @@ int vx_circuit_warm(vx_ctx* c, vx_circuit* k) {
   if (k->ctx != c) return vx_fail(VX_E_INVALID, "vx_circuit_warm: circuit belongs to a different context");
   if (k->num_luts > 0) return VX_OK;
   HIPCHK(hipSetDevice(c->device));
+  // Several processes (the DAG's worker pool, ranks emulated on one device) and several contexts of one process load circuits on the same
+  // device at the same time; each would see the same free memory below and then all allocate.  One rehearsal at a time per device: an
+  // advisory file lock for the other processes, a mutex for this one's threads (both best effort: a rehearsal is an optimisation).
+  static std::mutex warm_mutex;
+  std::lock_guard<std::mutex> in_process(warm_mutex);
+  struct FileLock {
+    int fd = -1;
+    explicit FileLock(int device) {
+      char path[64];
+      snprintf(path, sizeof path, "/tmp/vxprover_warm_dev%d.lock", device);
+      fd = open(path, O_CREAT | O_RDWR, 0666);
+      if (fd >= 0 && flock(fd, LOCK_EX) != 0) {
+        close(fd);
+        fd = -1;
+      }
+    }
+    ~FileLock() {
+      if (fd >= 0) {
+        flock(fd, LOCK_UN);
+        close(fd);
+      }
+    }
+  } across_processes(c->device);
   {
     // a proof's working set is about 8 N (wires + Z / partial products + quotient chunks) for the LDEs plus trees, coefficients and
     // scratch: rehearse only when twice a generous estimate is free — a host that packs many contexts onto one device (the
@@ -604,7 +630,16 @@ int vx_circuit_warm(vx_ctx* c, vx_circuit* k) {
   c->prof_on = prof_was;
   hipStreamSynchronize(c->stream);
   c->pool_free(zero);
+  if (rc != VX_OK) c->pool_trim();   // a rehearsal that ran out of memory must not sit on what it did get
   return rc;
+}
+// circuit load: the rehearsal is best effort — a failed one leaves a perfectly usable circuit AND no stale error string behind
+static void warm_on_load(vx_ctx* c, vx_circuit* k) {
+  if (getenv("VX_NO_WARM_ON_LOAD")) return;
+  if (vx_circuit_warm(c, k) != VX_OK) {
+    (void)hipGetLastError();
+    g_err[0] = 0;
+  }
 }
 int vx_circuit_create(vx_ctx* c, const vx_circuit_desc* desc, vx_circuit** out) {
   if (!c || !desc || !out) return vx_fail(VX_E_INVALID, "vx_circuit_create: NULL argument");
@@ -612,8 +647,7 @@ int vx_circuit_create(vx_ctx* c, const vx_circuit_desc* desc, vx_circuit** out) 
   HIPCHK(hipSetDevice(c->device));
   try {  // nothing unwinds across the ABI
     const int rc = circuit_create(c, desc, out);
-    // best effort, on by default (VX_NO_WARM_ON_LOAD=1 turns it off): a failed rehearsal leaves a perfectly usable circuit
-    if (rc == VX_OK && !getenv("VX_NO_WARM_ON_LOAD")) (void)vx_circuit_warm(c, *out);
+    if (rc == VX_OK) warm_on_load(c, *out);   // on by default (VX_NO_WARM_ON_LOAD=1 turns it off)
     return rc;
   } catch (const std::bad_alloc&) {
     return vx_fail(VX_E_NOMEM, "vx_circuit_create: out of host memory");

@@ -20,13 +20,18 @@ def init(backend: str, local_rank: int):
     _, world, _ = env_rank()
     if world <= 1 and not os.environ.get("VX_FORCE_DIST"):   # VX_FORCE_DIST=1: exercise the collective path at world 1
         return None
+    import datetime
+    import os
+
     import torch
     import torch.distributed as dist
+    # an explicit collective timeout (the first exchange of a run is where a missing peer shows): VX_DIST_TIMEOUT_S, default 10 minutes
+    timeout = datetime.timedelta(seconds=float(os.environ.get("VX_DIST_TIMEOUT_S", "600")))
     if backend == "nccl":
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=timeout)
     else:
-        dist.init_process_group(backend)
+        dist.init_process_group(backend, timeout=timeout)
     return dist
 
 
