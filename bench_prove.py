@@ -171,8 +171,8 @@ def dag_pool_legs(pool, with_starks=True, passes=2):
                                   "(2240 compressions, 2^16 rows) + SHA-256 over its 14 tree nodes; reduce = SHA-256 over its 2 merge nodes; outer = SHA-256 over "
                                   "300 keys + SHA-512 over 300 messages + 4 batched EdDSA tables (2^20 rows).  Per-job tables: inputs derived from the "
                                   "request seed and the job's position, TRACES GENERATED ON THE GPU INSIDE THE CLOCK (vx_trace_*: lane-seconds "
-                                  "`trace_generation`); the EdDSA table keeps one resident trace (no native generator yet).  The STARK proofs are part "
-                                  "of a job's digest; NOT the contract's timed region")
+                                  "`trace_generation`), the four EdDSA tables included.  The STARK proofs are part of a job's digest; "
+                                  "NOT the contract's timed region")
         rec["tables"] = tables
         rec["stark_proofs"] = spec.num_map * 2 + (spec.num_map - 1) + 2 + ((tables or {}).get("eddsa_outer", {}).get("tables", 0))
         out["dag_header_range_512_with_starks"] = rec
@@ -375,7 +375,7 @@ def dag_with_starks_leg(ctx, local_rank, in_flight=None, table_mode="per_job"):
     stark_proofs = 64 * 2 + 63 * 1 + 2 + setup["eddsa_outer"]["tables"]
     what_tables = ("EVERY JOB ITS OWN TABLES: a map job's 8 headers / tree nodes, a reduce job's merge nodes, the outer job's authority set and signed "
                    "messages are derived from the request seed and the job's position, and the traces are generated on the GPU (vx_trace_*) INSIDE "
-                   "the clock (lane-seconds `trace_generation`); the batched EdDSA table keeps one resident trace proven 4 times"
+                   "the clock (lane-seconds `trace_generation`), the four batched EdDSA tables included"
                    if table_mode == "per_job" else
                    "every trace, witness and second-round column resident in HBM before the clock starts (one trace per table kind, proven once per job)")
     return {"header_range_512_per_sec": 1.0 / secs, "dag_seconds": secs, "dag_seconds_all_passes": [round(r["seconds"], 4) for r in runs],
@@ -425,16 +425,18 @@ def chip_leg(ctx):
     lay = eddsa_air.Layout()
     log_n = 17
     cap = eddsa_air.capacity(lay, log_n)
-    t0 = time.perf_counter()
     sigs, rs = stark_chips.eddsa_signatures(cap, 2)
-    trace, res = eddsa_air.generate_trace(lay, log_n, sigs)
-    assert res == rs
-    gen_s = time.perf_counter() - t0
     stark = eddsa_air.make_stark(lay, log_n)
-    r = stark_chips.bench_table(ctx, stark, trace, np.zeros(0, dtype=np.uint64), "eddsa", steps=3, warmup=1)
+    d = ctx.alloc(lay.N * (1 << log_n) * 8)
+    ctx.trace_eddsa_table(log_n, lay.NB, sigs, d)              # warm
+    t0 = time.perf_counter()
+    res = ctx.trace_eddsa_table(log_n, lay.NB, sigs, d)
+    gen_ms = (time.perf_counter() - t0) * 1e3
+    assert res == rs, "a generated EdDSA instance does not arrive at R"
+    r = stark_chips.bench_table(ctx, stark, None, np.zeros(0, dtype=np.uint64), "eddsa", steps=3, warmup=1, d_trace=d)
     out["eddsa"] = {"ms_per_proof": round(r["ms_per_proof"], 3), "rows_log2": log_n, "columns": r["columns"], "signatures": cap,
-                    "trace_generation_s_host_numpy": round(gen_s, 2), "stage_ms_per_proof": r["stage_ms_per_proof"], "proof_bytes": r["proof_bytes"],
-                    "evaluator": r["evaluator"]}
+                    "trace_generation_ms_gpu": round(gen_ms, 3), "trace_GB": round(lay.N * (1 << log_n) * 8 / 1e9, 3),
+                    "stage_ms_per_proof": r["stage_ms_per_proof"], "proof_bytes": r["proof_bytes"], "evaluator": r["evaluator"]}
     return out
 
 

@@ -72,3 +72,50 @@ def test_a_table_proves_from_the_device_generated_trace(ctx, which, log_n, msgs)
     finally:
         tab.free()
         res.free()
+
+
+@pytest.mark.parametrize("scalar_bits,nsig,distinct", [(32, 5, 3), (256, 7, 4)])
+def test_device_eddsa_trace_equals_the_numpy_generator(ctx, scalar_bits, nsig, distinct):
+    from vectorx_amd import eddsa_air as ea
+    log_n = 17
+    lay = ea.Layout(16, scalar_bits)
+    full, full_r = stark_chips.eddsa_signatures(nsig, distinct)
+    mask = (1 << scalar_bits) - 1
+    sigs = [(a, s & mask, h & mask) for (a, s, h) in full]
+    n = 1 << log_n
+    d = ctx.alloc(lay.N * n * 8)
+    try:
+        ctx.upload(d, np.full((lay.N, n), 0xDEAD, dtype=np.uint64))
+        res = ctx.trace_eddsa_table(log_n, scalar_bits, sigs, d)
+        got = ctx.download(d, lay.N * n * 8).reshape(lay.N, n)
+    finally:
+        ctx.free(d)
+    ref, rres = ea.generate_trace(lay, log_n, sigs)
+    bad = np.argwhere(got != ref)
+    assert bad.size == 0, f"first differing cells (column, row): {bad[:8].tolist()}"
+    assert res == rres
+    if scalar_bits == 256:
+        assert res == full_r          # the instance arrives at R of the RFC 8032 signature
+
+
+def test_eddsa_table_proves_from_the_device_generated_trace_and_refuses_a_point_off_the_curve(ctx):
+    import vectorx_amd as vx
+    from vectorx_amd import eddsa_air as ea
+    log_n, lay = 17, ea.Layout()
+    sigs, rs = stark_chips.eddsa_signatures(ea.capacity(lay, log_n), 2)
+    stark = ea.make_stark(lay, log_n)
+    tabs = stark_chips.GeneratedEddsaTables(ctx, stark, lay, log_n, lambda job: sigs, [ctx])
+    ref_trace, ref_res = ea.generate_trace(lay, log_n, sigs)
+    res = stark_chips.ResidentTable(ctx, stark, ref_trace, np.zeros(0, dtype=np.uint64), "eddsa")
+    try:
+        proof = tabs.prove(ctx, None)
+        assert tabs.last[id(ctx)][1] == rs == ref_res
+        sums = stark.verify(np.zeros(0, dtype=np.uint64), proof)
+        assert any(int(x) for x in sums)                 # the bus carries the results out
+        assert proof == res.prove()
+        (ax, ay), s_, h_ = sigs[0]
+        with pytest.raises(vx.VxError, match="not on the curve"):
+            ctx.trace_eddsa_table(log_n, 256, [((ax, (ay + 1) % ea.Q25519), s_, h_)], tabs.bufs[id(ctx)][0])
+    finally:
+        tabs.free()
+        res.free()

@@ -102,3 +102,30 @@ def test_a_message_that_does_not_fit_is_refused(tgh):
     assert rc == 1
     rc, *_ = run(tgh.tgh_blake2b, 775, 8, 4, 15, [b"a"])                 # the XOR table needs 2^16 rows
     assert rc == 2
+
+
+@pytest.mark.parametrize("scalar_bits,log_n,nsig,distinct", [(32, 17, 5, 3), (64, 17, 46, 2), (256, 17, 3, 3)])
+def test_eddsa_rows_equal_the_numpy_generator(tgh, scalar_bits, log_n, nsig, distinct):
+    """the batched EdDSA table: real signature equations (cut to `scalar_bits` bits of S and h), then filler instances, an unfinished tail"""
+    from vectorx_amd import eddsa_air as ea
+    from vectorx_amd import stark_chips
+    lay = ea.Layout(16, scalar_bits)
+    full, _ = stark_chips.eddsa_signatures(nsig, distinct)
+    mask = (1 << scalar_bits) - 1
+    sigs = [(a, s & mask, h & mask) for (a, s, h) in full]
+    ref, rres = ea.generate_trace(lay, log_n, sigs)
+    arr = np.zeros((nsig, 4, 4), dtype=np.uint64)
+    for i, ((ax, ay), s_, h_) in enumerate(sigs):
+        for k, v in enumerate((ax, ay, s_, h_)):
+            arr[i, k] = [(int(v) >> (64 * w)) & 0xFFFFFFFFFFFFFFFF for w in range(4)]
+    trace = np.full((lay.N, 1 << log_n), 0xDEAD, dtype=np.uint64)
+    res = np.zeros((nsig, 2, 4), dtype=np.uint64)
+    tgh.tgh_eddsa.restype = ctypes.c_int
+    tgh.tgh_eddsa.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    assert tgh.tgh_eddsa(log_n, scalar_bits, arr.ctypes.data, nsig, trace.ctypes.data, res.ctypes.data) == 0
+    bad = np.argwhere(trace != ref)
+    assert bad.size == 0, f"first differing cells (column, row): {bad[:8].tolist()}"
+    val = lambda w: sum(int(w[k]) << (64 * k) for k in range(4))      # noqa: E731
+    assert [(val(res[i, 0]), val(res[i, 1])) for i in range(nsig)] == rres
+    if scalar_bits == 256:          # whole scalars: the instance arrives at R of the RFC 8032 signature
+        assert rres == stark_chips.eddsa_signatures(nsig, distinct)[1]

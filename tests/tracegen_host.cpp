@@ -3,6 +3,7 @@
 // numpy generators WITHOUT a GPU.  Not part of the product: libvxprover.so has no host trace generator (nothing under vectorx_amd/
 // loads this file's library).   g++ -O2 -shared -fPIC -o tests/libtracegen_host.so tests/tracegen_host.cpp
 #include "../vectorx_amd/csrc/tracegen_prep.h"
+#include "../vectorx_amd/csrc/tracegen_eddsa.h"
 
 template <class T>
 static int sha2_host(int degree_bits, const uint8_t* msgs, const uint64_t* off, int nmsg, uint64_t* trace, uint64_t* pis, uint64_t* digest_words) {
@@ -55,6 +56,29 @@ int tgh_blake2b(int degree_bits, const uint8_t* msgs, const uint64_t* off, int n
     for (int i = 0; i < tg::b2::TAB_ROWS; ++i) trace[(size_t)tg::b2::tabcol(k, 19) * n + i] = hist[(size_t)tg::b2::TAB_ROWS * k + i];
   memcpy(pis, prep.pis, sizeof prep.pis);
   for (size_t i = 0; i < prep.digests.size(); ++i) digest_words[i] = prep.digests[i];
+  return 0;
+}
+int tgh_eddsa(int degree_bits, int scalar_bits, const uint64_t* sigs, int nsig, uint64_t* trace, uint64_t* results) {
+  const tg::ed::Cols cl = tg::ed::cols(scalar_bits);
+  const size_t n = (size_t)1 << degree_bits;
+  if ((size_t)nsig > (n - 1) / cl.L) return 1;
+  const int ninst = (int)((n + cl.L - 1) / cl.L);
+  tg::ed::Sig filler;
+  memset(&filler, 0, sizeof filler);
+  for (int k = 0; k < 4; ++k) filler.ax[k] = tg::ed::BX[k], filler.ay[k] = tg::ed::BY[k];
+  const tg::ed::Sig* sg = (const tg::ed::Sig*)sigs;
+  std::vector<tg::ed::RowVals> vals((size_t)ninst * cl.L);
+  for (int u = 0; u < ninst; ++u)
+    if (tg::ed::simulate_instance(u < nsig ? sg[u] : filler, scalar_bits, vals.data() + (size_t)u * cl.L) && u < nsig) return 3;
+  std::vector<uint64_t> hist(65536, 0);
+  for (size_t row = 0; row < n; ++row) {
+    const bool count = row + 1 < n;
+    tg::ed::row(cl, vals.data(), sg, nsig, filler, row, [&](int col, uint64_t v) { trace[(size_t)col * n + row] = v; },
+                [&](unsigned limb) { if (count) hist[limb]++; });
+  }
+  for (int i = 0; i < 65536; ++i) trace[(size_t)cl.MULT * n + i] = hist[i];
+  for (int u = 0; u < nsig; ++u)
+    for (int w = 0; w < 2; ++w) memcpy(results + ((size_t)u * 2 + w) * 4, vals[(size_t)u * cl.L + cl.L - 2 + w].z, 32);
   return 0;
 }
 }

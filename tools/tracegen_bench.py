@@ -40,6 +40,29 @@ def main():
         ctx.free(d)
         print(json.dumps({"table": which, "rows_log2": log_n, "what": what, "trace_MB": round(nbytes / 1e6, 1), "wall_ms": round(wall, 3),
                           "device_ms": round(ev, 3), "write_GBps_device": round(nbytes / (ev * 1e-3) / 1e9, 1)}), flush=True)
+    # the batched EdDSA table of the outer job: 97 signature equations per 2^20 rows
+    from vectorx_amd import eddsa_air as ea
+    from vectorx_amd import stark_chips
+    lay = ea.Layout()
+    for log_n in (17, 20):
+        cap = ea.capacity(lay, log_n)
+        sigs, rs = stark_chips.eddsa_signatures(cap, 8)
+        nbytes = lay.N * (1 << log_n) * 8
+        d = ctx.alloc(nbytes)
+        assert ctx.trace_eddsa_table(log_n, lay.NB, sigs, d) == rs
+        steps = 5
+        ctx.prof_enable(True)
+        ctx.prof_reset()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ctx.trace_eddsa_table(log_n, lay.NB, sigs, d)
+        ctx.sync()
+        wall = (time.perf_counter() - t0) / steps * 1e3
+        ev = ctx.prof()["trace_generation"]["ms"] / steps
+        ctx.prof_enable(False)
+        ctx.free(d)
+        print(json.dumps({"table": "eddsa", "rows_log2": log_n, "what": f"{cap} signature equations", "trace_MB": round(nbytes / 1e6, 1),
+                          "wall_ms": round(wall, 3), "device_ms": round(ev, 3), "write_GBps_device": round(nbytes / (ev * 1e-3) / 1e9, 1)}), flush=True)
     ctx.close()
 
 

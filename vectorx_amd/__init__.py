@@ -116,6 +116,7 @@ _SIGNATURES = {
     "vx_trace_sha256": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "vx_trace_sha512": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "vx_trace_blake2b": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
+    "vx_trace_eddsa": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp]),
     "vx_stark_aux_precompile": (_i, [_vp]),
     "vx_stark_precompile": (_i, [_vp, ctypes.POINTER(_i)]),
     "vx_circuit_precompile": (_i, [_vp, ctypes.POINTER(_i)]),
@@ -258,6 +259,18 @@ class Context:
         _chk(getattr(lib(), "vx_trace_" + which)(self._h, degree_bits, buf.ctypes.data, off.ctypes.data, len(messages), _vp(d_trace),
                                                  pis.ctypes.data, dig.ctypes.data))
         return pis, [dig[dlen * i:dlen * (i + 1)].tobytes() for i in range(len(messages))]
+
+    def trace_eddsa_table(self, degree_bits: int, scalar_bits: int, sigs, d_trace: int):
+        """Fill the batched EdDSA table (eddsa_air.Layout(16, scalar_bits)) for sigs = [((ax, ay), S, h)] into device memory d_trace
+        -> [(x, y)] per signature = the affine [S]B - [h]A the instance arrives at (Python integers)."""
+        arr = np.zeros((max(1, len(sigs)), 4, 4), dtype=np.uint64)
+        for i, ((ax, ay), s_, h_) in enumerate(sigs):
+            for k, v in enumerate((ax, ay, s_, h_)):
+                arr[i, k] = [(int(v) >> (64 * w)) & 0xFFFFFFFFFFFFFFFF for w in range(4)]
+        res = np.zeros((max(1, len(sigs)), 2, 4), dtype=np.uint64)
+        _chk(lib().vx_trace_eddsa(self._h, degree_bits, scalar_bits, arr.ctypes.data, len(sigs), _vp(d_trace), res.ctypes.data))
+        val = lambda w: sum(int(w[k]) << (64 * k) for k in range(4))      # noqa: E731
+        return [(val(res[i, 0]), val(res[i, 1])) for i in range(len(sigs))]
 
     # ---- device buffers ----
     def alloc(self, nbytes: int) -> int:

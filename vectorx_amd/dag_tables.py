@@ -109,8 +109,7 @@ def build_per_job(ctx, lanes, kinds=("map", "reduce", "outer"), small=False, edd
       map    : BLAKE2b over its 8 headers (280 blocks each: 2240 compressions, 2^16 rows) + SHA-256 over its 14 tree nodes (2^11 rows);
       reduce : SHA-256 over the 2 nodes that merge its children's commitments (2^9 rows);
       outer  : SHA-256 over the authority set (300 keys: 600 compressions, 2^16 rows), SHA-512 over the 300 signed messages (2^16
-               rows); the batched EdDSA table keeps ONE resident trace proven 4 times (no native generator yet: listed under
-               "resident_trace" in the setup record).
+               rows), the 300 signature equations in 4 batched EdDSA tables of 2^20 rows (97 instances each).
     -> ({kind: [(label, table)]}, [tables to free], setup record)"""
     from . import blake2b_bytes_air, sha256_air, sha512_air, stark_chips
     lanes = list(lanes)
@@ -140,13 +139,32 @@ def build_per_job(ctx, lanes, kinds=("map", "reduce", "outer"), small=False, edd
         lg = 11 if small else 16
         sha_out = gen("sha256_outer", "sha256", sha256_air, lg, lambda job: job_bytes(job, b"authority set", nkeys, 64))
         s512 = gen("sha512_outer", "sha512", sha512_air, lg, lambda job: job_bytes(job, b"signed messages", nkeys, 117))
-        res_kind, res_tabs, res_rec = build_resident(ctx, eddsa_log_n=eddsa_log_n, kinds=("outer_eddsa",), small=small)
-        tables.extend(res_tabs)
-        rec.update(res_rec)
-        rec["resident_trace"].append("eddsa_outer")
-        for lane in lanes[1:]:
-            res_kind["outer_eddsa"][0][1].table.prove(lane)
-        per_kind["outer"] = [("sha256", sha_out), ("sha512", s512)] + res_kind["outer_eddsa"]
+        # the 300 signatures of the justification: REAL Ed25519 signatures (RFC 8032 signing on the host, untimed: they are the request's
+        # input, not the prover's work), 8 distinct ones; a job takes them in an order of its own
+        t0 = time.perf_counter()
+        from . import eddsa_air
+        lay = eddsa_air.Layout()
+        lg_ed = 17 if small else eddsa_log_n
+        base, base_r = stark_chips.eddsa_signatures(8 if not small else 2, 8 if not small else 2)
+        stark = eddsa_air.make_stark(lay, lg_ed)
+
+        def sigs_of(job):
+            rot = job_bytes(job, b"signatures", 1, 2)[0]
+            k = int.from_bytes(rot, "little")
+            return [base[(k + i) % len(base)] for i in range(nkeys)]
+
+        ed = stark_chips.GeneratedEddsaTables(ctx, stark, lay, lg_ed, sigs_of, lanes, "eddsa_outer")
+        for lane in lanes:
+            ed.prove(lane, None)
+            ed.take_spent(lane)
+            sigs, results = ed.last[id(lane)]
+            want = {b: r for b, r in zip(base, base_r)}
+            assert all(results[i] == want[sg] for i, sg in enumerate(sigs)), "a generated EdDSA instance does not arrive at R"
+        tables.append(ed)
+        rec["eddsa_outer"] = {"rows_log2": lg_ed, "columns": f"{stark.desc.num_columns} + {stark.desc.num_aux_columns}", "signatures_per_table": ed.cap,
+                              "tables": ed.tables_for(nkeys), "signatures": nkeys, "trace": "generated per job on the GPU",
+                              "setup_incl_signing_and_one_proof_per_lane_s": round(time.perf_counter() - t0, 2)}
+        per_kind["outer"] = [("sha256", sha_out), ("sha512", s512), ("eddsa", ed)]
     return per_kind, tables, rec
 
 

@@ -21,7 +21,6 @@ def init(backend: str, local_rank: int):
     if world <= 1 and not os.environ.get("VX_FORCE_DIST"):   # VX_FORCE_DIST=1: exercise the collective path at world 1
         return None
     import datetime
-    import os
 
     import torch
     import torch.distributed as dist

@@ -277,6 +277,49 @@ class GeneratedHashTable:
         self.bufs = {}
 
 
+class GeneratedEddsaTables:
+    """The batched EdDSA tables of ONE job, traces generated per job on the GPU (vx_trace_eddsa): `sigs_fn(job)` -> the job's signature
+    equations [((ax, ay), S, h)]; they fill ceil(len / capacity) tables of 2^log_n rows, each generated into the lane's trace buffer and
+    proven from it, one after the other.  `take_spent` as GeneratedHashTable."""
+
+    def __init__(self, ctx, stark, lay, log_n: int, sigs_fn, lanes, name="eddsa"):
+        from . import eddsa_air as ea
+        self.ctx, self.stark, self.lay, self.log_n, self.sigs_fn, self.name = ctx, stark, lay, log_n, sigs_fn, name
+        assert lay.LB == 16 and lay.N == stark.desc.num_columns
+        self.cap = ea.capacity(lay, log_n)
+        n = 1 << log_n
+        self.bufs = {id(c): (ctx.alloc(lay.N * n * 8), ctx.alloc(max(8, stark.desc.num_aux_columns * n * 8))) for c in lanes}
+        self.spent, self.last = {}, {}
+        self.nopi = np.zeros(0, dtype=np.uint64)
+
+    def tables_for(self, nsigs: int) -> int:
+        return max(1, -(-nsigs // self.cap))
+
+    def prove(self, ctx=None, job=None) -> bytes:
+        c = self.ctx if ctx is None else ctx
+        d_trace, d_aux = self.bufs[id(c)]
+        sigs = self.sigs_fn(job)
+        parts, gen, results = [], 0.0, []
+        for t in range(self.tables_for(len(sigs))):
+            chunk = sigs[t * self.cap:(t + 1) * self.cap]
+            t0 = time.perf_counter()
+            results += c.trace_eddsa_table(self.log_n, self.lay.NB, chunk, d_trace)
+            gen += time.perf_counter() - t0
+            parts.append(prove_device_trace(c, self.stark, d_trace, self.nopi, d_aux))
+        self.spent[id(c)] = [("trace_generation", gen)]
+        self.last[id(c)] = (sigs, results)
+        return b"".join(parts)
+
+    def take_spent(self, ctx=None):
+        return self.spent.pop(id(self.ctx if ctx is None else ctx), None)
+
+    def free(self):
+        for a, b in self.bufs.values():
+            self.ctx.free(a)
+            self.ctx.free(b)
+        self.bufs = {}
+
+
 def eddsa_signatures(count: int, distinct: int = 8, seed: int = 2024):
     """`count` signature equations (A, S, h) cycling over `distinct` real Ed25519 signatures (fresh keys, RFC 8032 signing on the host)
     -> (sigs, expected R per entry)"""
