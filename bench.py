@@ -53,8 +53,8 @@ def parse():
                     help="skip the extra leg that proves the header_range_512 DAG WITH the STARK tables of every job (BLAKE2b / SHA-256 / SHA-512 / batched EdDSA)")
     ap.add_argument("--dag-workers", type=int, default=3,
                     help="worker PROCESSES per GPU of the DAG legs (vectorx_amd/dag_pool.py; each keeps --dag-lanes jobs in flight); 0 = the one-process scheduler of rounds 1-4")
-    ap.add_argument("--dag-lanes", type=int, default=2,
-                    help="jobs in flight per worker process (3 workers x 2 lanes measured 2.7 %% ahead of 2 x 3 on the DAG with its tables: profiles/r05_dag_pool.jsonl)")
+    ap.add_argument("--dag-lanes", type=int, default=3,
+                    help="jobs in flight per worker process (3 workers x 3 lanes: 3.38 s against 3.50 for 2 x 3 and 3 x 2, 3.42 for 4 x 2 on one box — profiles/r05_dag_pool.jsonl)")
     ap.add_argument("--dag-table-mode", default="per_job", choices=["per_job", "resident"],
                     help="STARK tables of the DAG: per_job = every job's own inputs, traces generated on the GPU inside the clock; resident = one host-generated trace per table kind (rounds 3-4)")
     ap.add_argument("--extra-legs-deadline", type=float, default=1500.0,

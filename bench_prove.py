@@ -274,7 +274,8 @@ def dag_leg_ranks(ctx, args, local_rank, dist, device, in_flight=3, with_starks=
         # every rank proves map and reduce jobs; the outer job (and its tables) belongs to the rank job 0 of the last layer is dealt to: rank 0
         kinds = ("map", "reduce", "outer") if dist.get_rank() == 0 else ("map", "reduce")
         per_kind, tables, _setup = dag_stark_tables(ctx, kinds=kinds, small=bool(getattr(args, "dag_starks_small", False)),
-                                                    mode=getattr(args, "dag_table_mode", "per_job"), lanes=[ctx] + lanes)
+                                                    mode=getattr(args, "dag_table_mode", "per_job"), lanes=[ctx] + lanes,
+                                                    outer_lanes=[ctx])     # layer barriers: the outer job is alone and runs on lane 0
 
     def make(kind, log_n, jobs):
         if kind not in provers:
@@ -320,10 +321,10 @@ def dag_leg_ranks(ctx, args, local_rank, dist, device, in_flight=3, with_starks=
                       "HBM-resident; NOT the contract's timed region"}
 
 
-def dag_stark_tables(ctx, kinds=("map", "reduce", "outer"), small=False, mode="resident", lanes=None):
+def dag_stark_tables(ctx, kinds=("map", "reduce", "outer"), small=False, mode="resident", lanes=None, outer_lanes=None):
     """vectorx_amd.dag_tables.build (kept under this name for tools/)"""
     from vectorx_amd import dag_tables
-    return dag_tables.build(ctx, kinds=kinds, small=small, mode=mode, lanes=lanes)
+    return dag_tables.build(ctx, kinds=kinds, small=small, mode=mode, lanes=lanes, outer_lanes=outer_lanes)
 
 
 def dag_with_starks_leg(ctx, local_rank, in_flight=None, table_mode="per_job"):

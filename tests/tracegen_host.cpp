@@ -68,12 +68,15 @@ int tgh_eddsa(int degree_bits, int scalar_bits, const uint64_t* sigs, int nsig, 
   for (int k = 0; k < 4; ++k) filler.ax[k] = tg::ed::BX[k], filler.ay[k] = tg::ed::BY[k];
   const tg::ed::Sig* sg = (const tg::ed::Sig*)sigs;
   std::vector<tg::ed::RowVals> vals((size_t)ninst * cl.L);
+  uint64_t regs[tg::ed::NREG][4];
   for (int u = 0; u < ninst; ++u)
-    if (tg::ed::simulate_instance(u < nsig ? sg[u] : filler, scalar_bits, vals.data() + (size_t)u * cl.L) && u < nsig) return 3;
+    if (tg::ed::simulate_instance(u < nsig ? sg[u] : filler, scalar_bits, vals.data() + (size_t)u * cl.L, regs) && u < nsig) return 3;
+  tg::ed::RegSrc rsrc;
+  tg::ed::make_reg_src(scalar_bits, rsrc);
   std::vector<uint64_t> hist(65536, 0);
   for (size_t row = 0; row < n; ++row) {
     const bool count = row + 1 < n;
-    tg::ed::row(cl, vals.data(), sg, nsig, filler, row, [&](int col, uint64_t v) { trace[(size_t)col * n + row] = v; },
+    tg::ed::row(cl, rsrc, vals.data(), sg, nsig, filler, row, [&](int col, uint64_t v) { trace[(size_t)col * n + row] = v; },
                 [&](unsigned limb) { if (count) hist[limb]++; });
   }
   for (int i = 0; i < 65536; ++i) trace[(size_t)cl.MULT * n + i] = hist[i];

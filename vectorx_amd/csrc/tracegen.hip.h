@@ -210,12 +210,20 @@ int vx_trace_blake2b(vx_ctx* c, int degree_bits, const uint8_t* msgs, const uint
 // ---- the batched EdDSA table -------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void tg_ed_simulate_kernel(const tg::ed::Sig* __restrict__ sigs, int nsig, tg::ed::Sig filler, int ninst, int NB,
                                                             tg::ed::RowVals* __restrict__ vals, int* __restrict__ bad) {
+  __shared__ uint64_t regs[64][tg::ed::NREG][4];
   const int u = blockIdx.x * 64 + threadIdx.x;
   if (u >= ninst) return;
   const int L = tg::ed::NP + tg::ed::NLOOP * NB + tg::ed::NE;
-  if (tg::ed::simulate_instance(u < nsig ? sigs[u] : filler, NB, vals + (size_t)u * L) && u < nsig) atomicExch(bad, u + 1);
+  if (tg::ed::simulate_instance(u < nsig ? sigs[u] : filler, NB, vals + (size_t)u * L, regs[threadIdx.x]) && u < nsig) atomicExch(bad, u + 1);
 }
-__global__ __launch_bounds__(TG_THREADS) void tg_ed_rows_kernel(tg::ed::Cols c, const tg::ed::RowVals* __restrict__ vals,
+// results[u][w] = z of row L - 2 + w of instance u (the affine x, y the instance arrives at)
+__global__ void tg_ed_results_kernel(const tg::ed::RowVals* __restrict__ vals, int nsig, int L, u64* __restrict__ results) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nsig * 8) return;
+  const int u = i >> 3, w = (i >> 2) & 1, k = i & 3;
+  results[i] = vals[(size_t)u * L + L - 2 + w].z[k];
+}
+__global__ __launch_bounds__(TG_THREADS) void tg_ed_rows_kernel(tg::ed::Cols c, const tg::ed::RegSrc* __restrict__ rsrc, const tg::ed::RowVals* __restrict__ vals,
                                                                 const tg::ed::Sig* __restrict__ sigs, int nsig, tg::ed::Sig filler,
                                                                 u64* __restrict__ trace, size_t n, unsigned* __restrict__ hist) {
   const size_t row_raw = (size_t)blockIdx.x * TG_THREADS + threadIdx.x;
@@ -223,7 +231,7 @@ __global__ __launch_bounds__(TG_THREADS) void tg_ed_rows_kernel(tg::ed::Cols c, 
   const size_t row = in ? row_raw : n - 1;
   const bool count = in && row + 1 < n;
   unsigned* my_hist = hist + (size_t)tg_xcc_id() * 65536;
-  tg::ed::row(c, vals, sigs, nsig, filler, row, [&](int col, uint64_t v) { if (in) trace[(size_t)col * n + row] = v; },
+  tg::ed::row(c, *rsrc, vals, sigs, nsig, filler, row, [&](int col, uint64_t v) { if (in) trace[(size_t)col * n + row] = v; },
               [&](unsigned limb) { tg_hist_add(my_hist, limb, count); });
 }
 
@@ -244,14 +252,16 @@ int vx_trace_eddsa(vx_ctx* c, int degree_bits, int scalar_bits, const uint64_t* 
   tg::ed::Sig filler;
   memset(&filler, 0, sizeof filler);
   for (int k = 0; k < 4; ++k) filler.ax[k] = tg::ed::BX[k], filler.ay[k] = tg::ed::BY[k];
-  void *d_sigs = nullptr, *d_vals = nullptr, *d_hist = nullptr, *d_bad = nullptr;
+  void *d_sigs = nullptr, *d_vals = nullptr, *d_hist = nullptr, *d_bad = nullptr, *d_rsrc = nullptr, *d_res = nullptr;
   const size_t sb = (size_t)(num_sigs ? num_sigs : 1) * sizeof(tg::ed::Sig), vb = (size_t)ninst * cl.L * sizeof(tg::ed::RowVals),
-               hb = (size_t)TG_HIST_COPIES * 65536 * sizeof(unsigned);
+               hb = (size_t)TG_HIST_COPIES * 65536 * sizeof(unsigned), rb = (size_t)(num_sigs ? num_sigs : 1) * 64;
   if (c->pool_alloc(&d_sigs, sb) != hipSuccess || c->pool_alloc(&d_vals, vb) != hipSuccess || c->pool_alloc(&d_hist, hb) != hipSuccess ||
-      c->pool_alloc(&d_bad, 256) != hipSuccess) {
-    c->pool_free(d_sigs), c->pool_free(d_vals), c->pool_free(d_hist), c->pool_free(d_bad);
+      c->pool_alloc(&d_bad, 256) != hipSuccess || c->pool_alloc(&d_rsrc, sizeof(tg::ed::RegSrc)) != hipSuccess || c->pool_alloc(&d_res, rb) != hipSuccess) {
+    c->pool_free(d_sigs), c->pool_free(d_vals), c->pool_free(d_hist), c->pool_free(d_bad), c->pool_free(d_rsrc), c->pool_free(d_res);
     return vx_fail(VX_E_NOMEM, "vx_trace_eddsa: out of device memory");
   }
+  tg::ed::RegSrc rsrc;
+  tg::ed::make_reg_src(scalar_bits, rsrc);
   int rc = VX_OK, bad = 0;
   {
     ProfScope ps(c, "trace_generation", 8.0 * cl.N * n);
@@ -259,25 +269,26 @@ int vx_trace_eddsa(vx_ctx* c, int degree_bits, int scalar_bits, const uint64_t* 
     if (num_sigs) e = hipMemcpyAsync(d_sigs, sigs, (size_t)num_sigs * sizeof(tg::ed::Sig), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(d_hist, 0, hb, c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(d_bad, 0, 256, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_rsrc, &rsrc, sizeof rsrc, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) {
       hipLaunchKernelGGL(tg_ed_simulate_kernel, dim3((ninst + 63) / 64), dim3(64), 0, c->stream, (const tg::ed::Sig*)d_sigs, num_sigs, filler, ninst,
                          scalar_bits, (tg::ed::RowVals*)d_vals, (int*)d_bad);
       hipLaunchKernelGGL(tg_ed_rows_kernel, dim3((unsigned)((n + TG_THREADS - 1) / TG_THREADS)), dim3(TG_THREADS), 0, c->stream, cl,
-                         (const tg::ed::RowVals*)d_vals, (const tg::ed::Sig*)d_sigs, num_sigs, filler, (u64*)trace_dev, n, (unsigned*)d_hist);
+                         (const tg::ed::RegSrc*)d_rsrc, (const tg::ed::RowVals*)d_vals, (const tg::ed::Sig*)d_sigs, num_sigs, filler, (u64*)trace_dev, n, (unsigned*)d_hist);
       hipLaunchKernelGGL(tg_patch_mult_kernel, dim3(65536 / 256), dim3(256), 0, c->stream, (u64*)trace_dev + (size_t)cl.MULT * n, (const unsigned*)d_hist,
                          65536u, TG_HIST_COPIES, (size_t)65536);
       e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(&bad, d_bad, sizeof bad, hipMemcpyDeviceToHost, c->stream);
-    // the results: affine (x, y) of [S]B - [h]A = z of the last two rows of every given instance
-    if (e == hipSuccess && results_out)
-      for (int u = 0; u < num_sigs && e == hipSuccess; ++u)
-        for (int w = 0; w < 2 && e == hipSuccess; ++w)
-          e = hipMemcpyAsync(results_out + ((size_t)u * 2 + w) * 4, ((const tg::ed::RowVals*)d_vals)[(size_t)u * cl.L + cl.L - 2 + w].z, 32, hipMemcpyDeviceToHost, c->stream);
+    // the results: affine (x, y) of [S]B - [h]A = z of the last two rows of every given instance, gathered on the device, one copy
+    if (e == hipSuccess && results_out && num_sigs) {
+      hipLaunchKernelGGL(tg_ed_results_kernel, dim3((num_sigs * 8 + 255) / 256), dim3(256), 0, c->stream, (const tg::ed::RowVals*)d_vals, num_sigs, cl.L, (u64*)d_res);
+      e = hipMemcpyAsync(results_out, d_res, (size_t)num_sigs * 64, hipMemcpyDeviceToHost, c->stream);
+    }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) rc = vx_fail(VX_E_HIP, "vx_trace_eddsa: %s", hipGetErrorString(e));
   }
-  c->pool_free(d_sigs), c->pool_free(d_vals), c->pool_free(d_hist), c->pool_free(d_bad);
+  c->pool_free(d_sigs), c->pool_free(d_vals), c->pool_free(d_hist), c->pool_free(d_bad), c->pool_free(d_rsrc), c->pool_free(d_res);
   if (rc == VX_OK && bad) rc = vx_fail(VX_E_INVALID, "vx_trace_eddsa: instance %d: a row that must produce 1 does not (A not on the curve, or Z = 0)", bad - 1);
   return rc;
 }

@@ -138,8 +138,9 @@ TG_HD int row_type(int rho, int NB) {
 }
 
 // phase 1: one instance.  out[rho], rho < L.  Returns 0, or 1 when a row that must produce 1 does not (A not on the curve, Z = 0).
-TG_HD int simulate_instance(const Sig& sg, int NB, RowVals* out) {
-  uint64_t regs[NREG][4];
+// `regs` = the instance's register file, NREG x 4 words (the device keeps it in LDS: indexed by the row's op, it would otherwise live in
+// scratch memory, whose latency every one of the 10 772 dependent rows would pay several times)
+TG_HD int simulate_instance(const Sig& sg, int NB, RowVals* out, uint64_t (*regs)[4]) {
   for (int r = 0; r < NREG; ++r)
     for (int k = 0; k < 4; ++k) regs[r][k] = 0;
   const int L = NP + NLOOP * NB + NE;
@@ -210,12 +211,43 @@ TG_HD int reg_source(int rho, int r, int NB) {
   }
   return f - L;
 }
+// The same as a table: class of the row (prologue row | loop row of step 0 | loop row of a later step | epilogue row) x register ->
+// {kind, value}: kind 0: the row `value` rows above; kind 1: row `value` of this instance; kind 2: row `value` of the PREVIOUS instance.
+constexpr int NCLASS = NP + 2 * NLOOP + NE;
+struct RegSrc {
+  short kind[NCLASS][NREG];
+  int value[NCLASS][NREG];
+};
+TG_HD int row_class(int rho, int NB) {
+  if (rho < NP) return rho;
+  if (rho < NP + NLOOP * NB) return NP + ((rho - NP) / NLOOP ? NLOOP : 0) + (rho - NP) % NLOOP;
+  return NP + 2 * NLOOP + (rho - NP - NLOOP * NB);
+}
+inline void make_reg_src(int NB, RegSrc& t) {
+  const int L = NP + NLOOP * NB + NE;
+  for (int c = 0; c < NCLASS; ++c) {
+    // a representative row of the class (NB >= 32: step 1 exists)
+    const int rho = c < NP ? c : (c < NP + NLOOP ? c : (c < NP + 2 * NLOOP ? c : NP + NLOOP * NB + (c - NP - 2 * NLOOP)));
+    for (int r = 0; r < NREG; ++r) {
+      const int src = reg_source(rho, r, NB);
+      if (src < 0) t.kind[c][r] = 2, t.value[c][r] = src + L;
+      else if (src < NP || c < NP) t.kind[c][r] = 1, t.value[c][r] = src;
+      else t.kind[c][r] = 0, t.value[c][r] = rho - src;
+    }
+  }
+}
+TG_HD long long reg_source_of(const RegSrc& t, int rho, int r, int NB) {
+  const int c = row_class(rho, NB);
+  const int v = t.value[c][r];
+  const int L = NP + NLOOP * NB + NE;
+  return t.kind[c][r] == 0 ? rho - v : (t.kind[c][r] == 1 ? v : (long long)v - L);
+}
 TG_HD unsigned limb16(const uint64_t* v, int i) { return (unsigned)((v[i >> 2] >> (16 * (i & 3))) & 0xFFFF); }
 
 // phase 2: the cells of trace row `row` (instance `inst`, position `rho`).  vals = the side buffer of ALL instances ([inst * L + rho]);
 // sigs[inst] for inst < nsig, the filler signature (A = B, S = h = 0) above.  look(limb) once per looked-up limb (Z, Q, W columns).
 template <class Put, class Look>
-TG_HD void row(const Cols& c, const RowVals* vals, const Sig* sigs, int nsig, const Sig& filler, size_t rowi, Put put, Look look) {
+TG_HD void row(const Cols& c, const RegSrc& rsrc, const RowVals* vals, const Sig* sigs, int nsig, const Sig& filler, size_t rowi, Put put, Look look) {
   const int L = c.L, NB = c.NB;
   const size_t inst = rowi / L;
   const int rho = (int)(rowi % L);
@@ -226,7 +258,7 @@ TG_HD void row(const Cols& c, const RowVals* vals, const Sig* sigs, int nsig, co
   // registers
   uint64_t ev[4] = {0, 0, 0, 0};
   for (int r = 0; r < NREG; ++r) {
-    const int src = reg_source(rho, r, NB);
+    const long long src = reg_source_of(rsrc, rho, r, NB);
     uint64_t v[4] = {0, 0, 0, 0};
     if (src >= 0 || inst > 0) {
       const RowVals& s = vals[(size_t)((long long)(inst * L) + src)];

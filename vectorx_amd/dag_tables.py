@@ -104,7 +104,7 @@ def job_bytes(job, label: bytes, count: int, length: int) -> list:
     return [blob[i * length:(i + 1) * length] for i in range(count)]
 
 
-def build_per_job(ctx, lanes, kinds=("map", "reduce", "outer"), small=False, eddsa_log_n=20):
+def build_per_job(ctx, lanes, kinds=("map", "reduce", "outer"), small=False, eddsa_log_n=20, outer_lanes=None):
     """Every job proves tables of ITS OWN inputs, traces generated on the GPU inside the job (vx_trace_*):
       map    : BLAKE2b over its 8 headers (280 blocks each: 2240 compressions, 2^16 rows) + SHA-256 over its 14 tree nodes (2^11 rows);
       reduce : SHA-256 over the 2 nodes that merge its children's commitments (2^9 rows);
@@ -137,6 +137,8 @@ def build_per_job(ctx, lanes, kinds=("map", "reduce", "outer"), small=False, edd
         per_kind["reduce"] = [("sha256", sha_red)]
     if "outer" in kinds:
         lg = 11 if small else 16
+        if outer_lanes is not None:          # a scheduler that only ever proves the outer job on one lane need not hold its buffers on all
+            lanes = list(outer_lanes)
         sha_out = gen("sha256_outer", "sha256", sha256_air, lg, lambda job: job_bytes(job, b"authority set", nkeys, 64))
         s512 = gen("sha512_outer", "sha512", sha512_air, lg, lambda job: job_bytes(job, b"signed messages", nkeys, 117))
         # the 300 signatures of the justification: REAL Ed25519 signatures (RFC 8032 signing on the host, untimed: they are the request's
@@ -168,7 +170,7 @@ def build_per_job(ctx, lanes, kinds=("map", "reduce", "outer"), small=False, edd
     return per_kind, tables, rec
 
 
-def build(ctx, kinds=("map", "reduce", "outer"), small=False, mode="per_job", lanes=None):
+def build(ctx, kinds=("map", "reduce", "outer"), small=False, mode="per_job", lanes=None, outer_lanes=None):
     """mode "per_job" (default) or "resident" (rounds 3-4: one host-generated trace per table kind)"""
     if mode == "resident":
         per_kind, tables, rec = build_resident(ctx, kinds=kinds, small=small)
@@ -180,4 +182,4 @@ def build(ctx, kinds=("map", "reduce", "outer"), small=False, mode="per_job", la
         return per_kind, tables, rec
     if mode != "per_job":
         raise ValueError(mode)
-    return build_per_job(ctx, lanes or [ctx], kinds=kinds, small=small)
+    return build_per_job(ctx, lanes or [ctx], kinds=kinds, small=small, outer_lanes=outer_lanes)
