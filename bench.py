@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--poseidon-percent", type=int, default=50, help="share of PoseidonGate rows in the synthetic circuit")
     ap.add_argument("--no-dag-leg", action="store_true",
                     help="skip the extra (untimed-by-the-contract) leg that proves one whole header_range_512 DAG: 64 map + 63 reduce + 1 outer proofs")
-    ap.add_argument("--multi-rank-leg-deadline", type=float, default=900.0,
+    ap.add_argument("--multi-rank-leg-deadline", type=float, default=1500.0,
                     help="seconds the world > 1 legs may take together before every rank gives up on them and rank 0 prints the line without them")
     ap.add_argument("--no-dag-stark-leg", action="store_true",
                     help="skip the extra leg that proves the header_range_512 DAG WITH the STARK tables of every job (BLAKE2b / SHA-256 / SHA-512 / batched EdDSA)")
@@ -55,6 +55,8 @@ def parse():
                     help="worker PROCESSES per GPU of the DAG legs (vectorx_amd/dag_pool.py; each keeps --dag-lanes jobs in flight); 0 = the one-process scheduler of rounds 1-4")
     ap.add_argument("--dag-lanes", type=int, default=3,
                     help="jobs in flight per worker process (3 workers x 3 lanes: 3.38 s against 3.50 for 2 x 3 and 3 x 2, 3.42 for 4 x 2 on one box — profiles/r05_dag_pool.jsonl)")
+    ap.add_argument("--no-dag-pool-leg", action="store_true",
+                    help="N > 1 only: skip the leg that runs the DAG on ONE pool of worker processes spanning all N GPUs (rank 0 coordinates; vectorx_amd/dag_pool.py)")
     ap.add_argument("--dag-table-mode", default="per_job", choices=["per_job", "resident"],
                     help="STARK tables of the DAG: per_job = every job's own inputs, traces generated on the GPU inside the clock; resident = one host-generated trace per table kind (rounds 3-4)")
     ap.add_argument("--extra-legs-deadline", type=float, default=1500.0,
@@ -172,11 +174,20 @@ def main():
     if "VX_JIT_CACHE_DIR" not in os.environ and jit_cache.is_dir():     # compiled constraint programs (__graft_entry__.build); the workers inherit it
         os.environ["VX_JIT_CACHE_DIR"] = str(jit_cache)
     dag_pool = None
+    pool_multi = (args.gpus > 1 and args.workload == "prove" and not args.no_dag_leg and not args.no_multi_rank_legs and not args.no_dag_pool_leg
+                  and not args.circuit_flags and args.dag_workers > 0)        # the same on every rank: decided from the arguments alone
     if ("WORLD_SIZE" not in os.environ and args.gpus == 1 and args.workload == "prove" and not args.no_dag_leg and args.log_n >= 20
             and not args.circuit_flags and args.dag_workers > 0):
+        pool_devices = (0,)
+    elif pool_multi and int(os.environ.get("RANK", "0")) == 0:
+        # N > 1: rank 0 coordinates ONE pool whose workers sit on all N GPUs (on device 0, all of them, under --ranks-on-one-device)
+        pool_devices = tuple([0] * args.gpus if args.ranks_on_one_device else range(args.gpus))
+    else:
+        pool_devices = None
+    if pool_devices is not None:
         from vectorx_amd import mapreduce as mr
         from vectorx_amd.dag_pool import DagPool
-        dag_pool = DagPool(mr.DagSpec(*(int(x) for x in args.dag_spec.split(","))), devices=(0,), workers_per_device=args.dag_workers,
+        dag_pool = DagPool(mr.DagSpec(*(int(x) for x in args.dag_spec.split(","))), devices=pool_devices, workers_per_device=args.dag_workers,
                            lanes=args.dag_lanes, with_starks=not args.no_dag_stark_leg, small_tables=args.dag_starks_small,
                            table_mode=args.dag_table_mode).start()
     import torch
@@ -191,6 +202,9 @@ def main():
         sys.exit(f"bench.py: rank {rank} has LOCAL_RANK={local_rank} but only {torch.cuda.device_count()} GPU(s) are visible")
     dist = H.init(args.dist_backend, local_rank)
     on_host = dist is not None and dist.get_backend() != "nccl"     # gloo: collectives on host tensors
+    # a HOST-side barrier group for the leg in which rank 0 alone drives the GPUs (the worker pool): waiting inside an RCCL collective would
+    # park a kernel on every GPU the pool's workers are trying to use
+    host_group = dist.new_group(backend="gloo") if (dist is not None and pool_multi and not on_host) else None
     ctx = vx.Context(local_rank)  # no CPU fallback: raises if the HIP library / GPU is missing
     n = 1 << args.log_n
     if args.cpu_sample_log_n is None:
@@ -429,6 +443,22 @@ def main():
         dag_n_leg = bench_prove.guarded_collective_leg(dist, lambda: bench_prove.dag_leg_ranks(ctx, args, local_rank, dist, dev))
         if not args.no_dag_stark_leg:
             dag_n_stark_leg = bench_prove.guarded_collective_leg(dist, lambda: bench_prove.dag_leg_ranks(ctx, args, local_rank, dist, dev, with_starks=True))
+    pool_all = None
+    if multi and pool_multi:
+        # the same DAG on ONE pool of worker processes over all N GPUs: every rank hands its cached device buffers back and waits on the
+        # host; rank 0 coordinates (jobs out / 32-byte digests back over a unix socket; no collective)
+        cleanup()
+        cleanup = lambda: None      # noqa: E731
+        ctx.trim()
+        sync()
+        dist.barrier(group=host_group)
+        if rank == 0:
+            try:
+                pool_all = bench_prove.dag_pool_legs(dag_pool, with_starks=not args.no_dag_stark_leg)
+                pool_all["devices"] = list(pool_devices)
+            except Exception as e:   # noqa: BLE001
+                pool_all = {"error": repr(e)}
+        dist.barrier(group=host_group)
 
     watchdog.cancel()
     if rank == 0:
@@ -439,6 +469,8 @@ def main():
             out["dag_header_range_512"] = dag_n_leg
         if dag_n_stark_leg is not None:
             out["dag_header_range_512_with_starks"] = dag_n_stark_leg
+        if pool_all is not None:
+            out["dag_on_one_pool_over_all_gpus"] = pool_all
     emit_line()
     signal.set_wakeup_fd(-1)
     if dag_pool is not None:

@@ -114,6 +114,9 @@ def test_ntt_argument_errors(ctx):
 @pytest.mark.parametrize("n_leaves,width,cap_h", [(1, 5, 0), (2, 1, 0), (2, 4, 1), (16, 3, 4), (64, 8, 2), (64, 9, 0),
                                                    (256, 135, 4), (1024, 20, 4), (4096, 16, 4), (512, 32, 4),
                                                    (128, 86, 7), (65536, 4, 0), (131072, 2, 3), (32768, 9, 4),
+                                                   # the one-launch tree top (round 5): 4 / 16 / 256 phase-1 nodes per cap subtree, one
+                                                   # workgroup per subtree, a cap wider than the counter array (per-level kernels instead)
+                                                   (8192, 5, 4), (16384, 5, 5), (2048, 3, 0), (4096, 3, 8), (8192, 3, 9), (32768, 5, 0),
                                                    # every live-row case of the sponge's last layer (round 4): one chunk, a partial chunk
                                                    # after a full one, full after full, widths around the multiples of eight
                                                    (64, 7, 2), (64, 15, 2), (64, 17, 2), (64, 24, 2), (64, 25, 2), (64, 31, 3), (64, 33, 0)])

@@ -359,8 +359,8 @@ def test_bench_multi_rank_code_path_on_one_device(world):
     duplicate devices): the weak-scaling line + the sharded-one-proof leg + the N-rank DAG leg, tiny sizes.  The single-GPU boxes
     run this every round, so the code the 8-GPU driver run takes has been executed before it gets there."""
     r = _plain_bench("--gpus", str(world), "--ranks-on-one-device", "--log-n", "12" if world < 8 else "10", "--dag-spec", "4,10,9,11" if world < 8 else "8,9,8,10",
-                     "--sharded-leg-steps", "2",
-                     *(["--dag-starks-small"] if world == 2 else ["--no-dag-stark-leg"]))
+                     "--sharded-leg-steps", "2", "--dag-workers", "1", "--dag-lanes", "2",
+                     *(["--dag-starks-small"] if world == 2 else ["--no-dag-stark-leg"]), *(["--no-dag-pool-leg"] if world == 8 else []))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
@@ -370,6 +370,14 @@ def test_bench_multi_rank_code_path_on_one_device(world):
     assert [d["rank"] for d in line["rank_devices"]] == list(range(world))
     _check_multi_rank_legs(line, world, "gloo")
     assert line["dag_header_range_512"]["plonky2_proofs"] == (4 + 3 + 1 if world < 8 else 8 + 7 + 1)
+    if world < 8:       # the same DAG once more on ONE pool of worker processes over all "GPUs" (here: one worker per rank's device, all on device 0)
+        pool = line["dag_on_one_pool_over_all_gpus"]
+        assert "error" not in pool, pool
+        assert pool["devices"] == [0] * world
+        p0 = pool["dag_header_range_512"]
+        assert p0["plonky2_proofs"] == 8 and len(p0["jobs_by_worker"]) == world and len(p0["root"]) == 64
+        if world == 2:
+            assert pool["dag_header_range_512_with_starks"]["lane_seconds_by_kind"]["trace_generation"] > 0
     if world == 2:      # the same DAG with every job's STARK tables (smallest shapes), over both ranks
         ds = line["dag_header_range_512_with_starks"]
         assert "error" not in ds, ds
