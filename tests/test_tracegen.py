@@ -16,10 +16,13 @@ HERE = Path(__file__).resolve().parent
 
 @pytest.fixture(scope="module")
 def tgh():
+    import os
     so = HERE / "libtracegen_host.so"
     src = HERE / "tracegen_host.cpp"
     deps = [src] + sorted((HERE.parent / "vectorx_amd" / "csrc").glob("tracegen_*.h"))
-    if not so.exists() or so.stat().st_mtime < max(d.stat().st_mtime for d in deps):
+    if os.environ.get("VX_TRACEGEN_HOST_SO"):            # tools/sanitize_host.sh: an ASan + UBSan build of the same file
+        so = Path(os.environ["VX_TRACEGEN_HOST_SO"])
+    elif not so.exists() or so.stat().st_mtime < max(d.stat().st_mtime for d in deps):
         subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", str(so), str(src)], check=True)
     L = ctypes.CDLL(str(so))
     for f in (L.tgh_sha256, L.tgh_sha512, L.tgh_blake2b):

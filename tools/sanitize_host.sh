@@ -18,6 +18,8 @@ $LLVM/bin/clang++ $SAN -fopenmp -march=x86-64-v3 -o "$OUT/liboracle_san.so" "$RO
 $LLVM/bin/clang++ $SAN -o "$OUT/libvxsynth_san.so" "$ROOT/vectorx_amd/synth/synth_circuit.cpp"
 make -C "$ROOT/vectorx_amd/csrc" jit_prelude.inc >/dev/null 2>&1 || true
 (cd "$ROOT/vectorx_amd/csrc" && /opt/rocm/bin/hipcc $SAN --offload-arch=gfx950 -fno-gpu-sanitize -w -o "$OUT/libvxprover_san.so" vxprover.hip -ldl)
+# round 5: the host preparation and the row writers of the native trace generators (test-only host build, tests/tracegen_host.cpp)
+$LLVM/bin/clang++ $SAN -o "$OUT/libtracegen_host_san.so" "$ROOT/tests/tracegen_host.cpp"
 cat > "$OUT/run.py" <<EOF
 import pathlib, sys
 sys.path.insert(0, "$ROOT"); sys.path.insert(0, "$ROOT/tests")
@@ -27,6 +29,8 @@ import vectorx_amd.synth as _synth
 _synth._SO = pathlib.Path("$OUT/libvxsynth_san.so")
 import oracle_lib
 oracle_lib.build = lambda: pathlib.Path("$OUT/liboracle_san.so")
+import os
+os.environ["VX_TRACEGEN_HOST_SO"] = "$OUT/libtracegen_host_san.so"
 import pytest
 sys.exit(pytest.main(sys.argv[1:]))
 EOF
