@@ -399,6 +399,47 @@ def test_batched_eddsa_table_and_its_sink_bytes_identical_to_oracle(ctx, oracle,
         vx.stark_verify_bus([(stark, nopi), (sink2, nopi)], proofs2)
 
 
+@pytest.mark.parametrize("limb_bits,degree_bits", [(8, 14), (16, 17)])
+def test_full_eddsa_table_verifies_signatures_from_their_bytes_and_is_byte_identical_to_the_oracle(ctx, oracle, limb_bits, degree_bits):
+    """The FULL program (round 5; Layout(full=True)): point decompression of A and R, h = SHA-512 digest mod L and S < L
+    INSIDE the table — the bus tuple is the verifier's bytes (public key, S, digest, R's encoding).  RFC 8032 section 7.1 signatures,
+    table + sink on the GPU: both proofs byte-identical to the oracle's, the bus balances; with S + L, a flipped sign bit of R or another
+    digest in the verifier's bytes it does not.  (16, 17) = the production layout: 16-bit limbs, 12 instances per 2^17 rows."""
+    import hashlib
+
+    from test_eddsa_air import RFC8032
+    from vectorx_amd import eddsa_air as ea
+    from vectorx_amd import stark_bus
+    lay = ea.Layout(limb_bits, 256, full=True)
+    raw = []
+    for sk, pk, msg, sig in RFC8032[:ea.capacity(lay, degree_bits)]:
+        pk, msg, sig = bytes.fromhex(pk), bytes.fromhex(msg), bytes.fromhex(sig)
+        raw.append((pk, msg, sig, hashlib.sha512(sig[:32] + pk + msg).digest()))
+    sigs = [ea.equation_inputs_full(pk, msg, sig) for pk, msg, sig, _ in raw]
+    cfg = dict(num_query_rounds=12, pow_bits=5)
+    stark = ea.make_stark(lay, degree_bits, **cfg)
+    t, res = ea.generate_trace(lay, degree_bits, sigs)
+    assert res == [ea.decompress(sig[:32]) for _, _, sig, _ in raw]
+    nopi = np.zeros(0, dtype=np.uint64)
+    honest = [ea.tuple_of_full(lay, pk, sig, dig) for pk, _, sig, dig in raw]
+    sink, sink_t, _ = ea.make_sink(lay, honest, **cfg)
+    tables = [(stark, t, nopi), (sink, sink_t, nopi)]
+    proofs, shared = stark_bus.prove_tables(ctx, tables)
+    expect, shared_o = oracle_lib.stark_prove_tables(oracle, tables)
+    assert (shared == shared_o).all() and proofs[0] == expect[0] and proofs[1] == expect[1]
+    sums = vx.stark_verify_bus([(stark, nopi), (sink, nopi)], proofs)
+    assert int(sums[0][0]) != 0 and int(sums[0][1]) != 0
+    pk, _, sig, dig = raw[-1]
+    s = int.from_bytes(sig[32:], "little")
+    for forged_last in (ea.tuple_of_full(lay, pk, sig[:32] + (s + ea.ELL).to_bytes(32, "little"), dig),                       # S + L
+                        ea.tuple_of_full(lay, pk, bytes(sig[:31]) + bytes([sig[31] ^ 0x80]) + sig[32:], dig),                # R's sign bit
+                        ea.tuple_of_full(lay, pk, sig, hashlib.sha512(b"another message").digest())):                         # a wrong h
+        sink2, sink2_t, _ = ea.make_sink(lay, honest[:-1] + [forged_last], **cfg)
+        proofs2, _ = stark_bus.prove_tables(ctx, [(stark, t, nopi), (sink2, sink2_t, nopi)])
+        with pytest.raises(vx.VxError, match="cancel"):
+            vx.stark_verify_bus([(stark, nopi), (sink2, nopi)], proofs2)
+
+
 def test_batched_eddsa_interpreted_equals_compiled(ctx):
     import os
 

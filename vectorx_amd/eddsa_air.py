@@ -18,11 +18,16 @@ point baked into the program on 2^13 rows of 713 columns; this one differs in ev
   signatures — `make_sink`, in a real integration the plonky2 circuit that verifies the STARK — receives (A, S, h, R): the bus
   balances iff every equation holds.  No per-instance public inputs.
 
-What stays OUTSIDE the table (stated precisely): decompressing A and R from their 32-byte encodings (recovering x from y
-and the sign bit — the table takes affine (x, y) and checks the curve equation for A; R only has to EQUAL a computed point, which is on
-the curve by construction), h = SHA-512(R || A || M) mod L (the SHA-512 table of sha512_air.py gives the digest; the reduction mod L is
-host arithmetic) and the range check S < L.  Non-canonical limbs (a value in [p, 2^256)) cannot make a false equation pass: every
-relation holds mod p, and the result must equal the sink's canonical R limb by limb.
+What stays OUTSIDE the BASE table (Layout(full=False): the shape the DAG, the bench and the native trace generator use): decompressing
+A and R from their 32-byte encodings, h = SHA-512(R || A || M) mod L and the range check S < L — the table takes affine (x, y) and the
+reduced h, and checks the curve equation for A.  **The FULL program (Layout(full=True), round 5) takes them in**: 16 more prologue rows and
+7 more epilogue rows of the same multiply-add gadget — comparison rows (an integer identity v + c = bound - 1 with Q forced to 0 and Z
+forced to the constant), parity rows (x = 2 u + b), two rows whose modulus is L instead of p (digest mod L), and 32 word columns that
+tie the limbs to the 32-bit words of the statement — so that the bus tuple is the verifier's raw bytes: the public key's encoding, S, the
+64-byte digest, R's encoding (see FULL_PROLOGUE_TAIL below; tests/test_eddsa_full_air.py: the RFC 8032 signatures verify from their
+bytes; a flipped sign bit, S + L, a wrong h, a non-canonical coordinate fail).  What a caller still owes there: the digest itself.
+Non-canonical limbs cannot make a false equation pass in the base table either: every relation holds mod p, and the result must equal
+the sink's canonical R limb by limb.
 
 Plain host code: emits a constraint program (include/vxprover.h VX_OP_*), generates the trace (vectorised over the instances) and the
 second-round columns; checked against an independent affine implementation and RFC 8032 signatures (tests/test_eddsa_air.py)."""
@@ -52,6 +57,14 @@ class Op:
     dst: int = 0
     free: bool = False         # Z is a free (range-checked) witness, the relation is off
     one: bool = False          # Z must be 1
+    # ---- only used by the FULL program (Layout(full=True): signature bytes in, see FULL_PROLOGUE_TAIL) ----
+    mod: str = "p"             # the row's modulus: "p" = 2^255 - 19, "L" = the group order
+    zconst: int | None = None  # Z must equal this constant (`one` is zconst = 1)
+    zreg: int | None = None    # Z must equal this register
+    qzero: bool = False        # Q must be 0: the row is an INTEGER identity x y + e = z
+    bit: bool = False          # free row whose Z is 0 or 1
+    wit: tuple | None = None   # free rows: what the honest witness is — ("ax",) ("ay",) ("inv", reg) ("cmp", bound, reg) ("half", reg) ("bit", reg) ("dhi",) ("dlo",) ("s",)
+    bind: tuple | None = None  # 32-bit word columns this row ties to limbs: (column group, source "z" | register, register holding the top bit | None)
 
 
 def _cached(x, y):
@@ -93,20 +106,59 @@ T_P0, T_PLAST, T_L0, T_LLAST, T_E0, T_ELAST = 0, NP_ - 1, NP_, NP_ + NL_ - 1, NP
 NT = len(OPS)
 RESULT_X_REG = 6               # the affine x is in register 6 on the last row of an instance, y is that row's Z
 assert (NP_, NL_, NE_) == (16, 42, 4)
+# ---- the FULL program (round 5: VERDICT r4 #6): the instance takes what a verifier holds — the ENCODINGS of A and R, S, and the SHA-512
+# digest of R || A || M — and checks everything RFC 8032 5.1.7 asks between them and the group equation:
+#   * A: x and y canonical (x + c = p - 1, y + c' = p - 1 over the integers: rows with Q = 0 and Z a constant), the encoding's sign bit is
+#     the parity of x (x = 2 u + b with b a bit), the encoding's 255 low bits are y; the curve equation was there already;
+#   * h = digest mod L: two rows of the same multiply-add relation with L as the row's modulus (u = D_hi 2^128, v = u 2^128 + D_lo),
+#     v canonical (v + c = L - 1), and v IS the scalar h whose bits drive the ladder;
+#   * S canonical (S + c = L - 1) and the scalar whose bits drive the ladder;
+#   * R: the result's x and y canonical, its sign bit the parity of x — the tuple carries R's encoding, so nothing outside the table
+#     has to decompress it.
+# The bus tuple becomes (A encoding, S, digest, R encoding) as 32-bit words: exactly the bytes of the public key, the signature and the
+# digest.  What a caller still owes: the digest itself (the SHA-512 table's output for R || A || M — its binding to the message bytes is a
+# bus between that table and this tuple, not built).
+TWO128 = 1 << 128
+FULL_PROLOGUE_TAIL = [
+    Op(free=True, dst=4, wit=("cmp", Q25519, AX)), Op(AX, ("c", 1), 4, 5, zconst=Q25519 - 1, qzero=True),           # A.x < p
+    Op(free=True, dst=4, wit=("cmp", Q25519, AY)), Op(AY, ("c", 1), 4, 5, zconst=Q25519 - 1, qzero=True),           # A.y < p
+    Op(free=True, dst=4, wit=("half", AX)), Op(free=True, dst=5, wit=("bit", AX), bit=True),
+    Op(4, ("c", 2), 5, 6, zreg=AX, qzero=True, bind=("AENC", AY, 5)),                                                 # A.x = 2 u + b; the encoding
+    Op(free=True, dst=4, wit=("dhi",), bind=("DHI", "z", None)), Op(free=True, dst=5, wit=("dlo",), bind=("DLO", "z", None)),
+    Op(4, ("c", TWO128), None, 6, mod="L"), Op(6, ("c", TWO128), 5, 6, mod="L"),                                      # v = digest mod L
+    Op(free=True, dst=7, wit=("cmp", ELL, 6)), Op(6, ("c", 1), 7, 4, zconst=ELL - 1, qzero=True, bind=("H", 6, None)),  # v < L; v = h
+    Op(free=True, dst=4, wit=("s",), bind=("S", "z", None)),
+    Op(free=True, dst=5, wit=("cmp", ELL, 4)), Op(4, ("c", 1), 5, 6, zconst=ELL - 1, qzero=True),                     # S < L
+]
+FULL_EPILOGUE_TAIL = [
+    Op(free=True, dst=8, wit=("cmp", Q25519, 6)), Op(6, ("c", 1), 8, 9, zconst=Q25519 - 1, qzero=True),               # x < p
+    Op(free=True, dst=8, wit=("cmp", Q25519, 7)), Op(7, ("c", 1), 8, 9, zconst=Q25519 - 1, qzero=True),               # y < p
+    Op(free=True, dst=8, wit=("half", 6)), Op(free=True, dst=9, wit=("bit", 6), bit=True),
+    Op(8, ("c", 2), 9, 10, zreg=6, qzero=True, bind=("RENC", 7, 9)),                                                  # x = 2 u + b; R's encoding
+]
 
 
 class Layout:
     """column map for a limb width and a scalar length (steps per instance; a multiple of 32)"""
 
-    def __init__(self, limb_bits=16, scalar_bits=256):
+    def __init__(self, limb_bits=16, scalar_bits=256, full=False):
         assert limb_bits in (8, 16) and scalar_bits % 32 == 0 and 32 <= scalar_bits <= 256
         self.LB, self.NB = limb_bits, scalar_bits
+        self.full = bool(full)
+        assert not full or scalar_bits == 256, "the full program reduces a SHA-512 digest mod L: 256-bit scalars"
+        self.PRO = PROLOGUE + (FULL_PROLOGUE_TAIL if full else [])
+        self.LOOPOPS = LOOP
+        self.EPI = EPILOGUE + (FULL_EPILOGUE_TAIL if full else [])
+        self.OPS = self.PRO + self.LOOPOPS + self.EPI
+        self.NP, self.NLOOP, self.NE, self.NT = len(self.PRO), len(self.LOOPOPS), len(self.EPI), len(self.OPS)
+        self.T_P0, self.T_PLAST, self.T_L0 = 0, self.NP - 1, self.NP
+        self.T_LLAST, self.T_E0, self.T_ELAST = self.NP + self.NLOOP - 1, self.NP + self.NLOOP, self.NT - 1
         self.NL = 256 // limb_bits
         self.NW = scalar_bits // 32
         self.NC = 2 * self.NL - 2                 # carries
-        self.L = NP_ + NL_ * scalar_bits + NE_    # rows per instance
+        self.L = self.NP + self.NLOOP * scalar_bits + self.NE    # rows per instance
         self.RT = 0
-        self.REG = self.RT + NT
+        self.REG = self.RT + self.NT
         self.X = self.REG + self.NL * NREG
         self.Y = self.X + self.NL
         self.Z = self.Y + self.NL
@@ -121,7 +173,11 @@ class Layout:
         self.J = self.POS + 32                    # one-hot word being filled, NW
         self.SW = self.J + self.NW                # the instance's scalar words, most significant first: S (NW), then h (NW)
         self.ACT = self.SW + 2 * self.NW          # 1 when the instance's result goes out on the bus (filler instances: 0)
-        self.TBL = self.ACT + 1
+        # full program: the instance's statement as 32-bit words, least significant first, constant over the instance
+        self.AENC = self.ACT + 1                  # the public key's encoding, 8 words
+        self.DW = self.AENC + 8                   # the SHA-512 digest, 16 words
+        self.RENC = self.DW + 16                  # R's encoding, 8 words
+        self.TBL = self.RENC + 8 if full else self.ACT + 1
         self.MULT = self.TBL + 1
         self.N = self.MULT + 1
         self.NPAIR = self.NLOOK // 2
@@ -132,7 +188,22 @@ class Layout:
         self.AUX_BUS = self.AUX_U + 1
         self.NAUX = self.NPAIR + 4
         self.W_OFFSET = 1 << (2 * limb_bits - 1)
-        self.NTUPLE = 4 * self.NL + 2 * self.NW   # A.x, A.y, S words, h words, x, y
+        self.NTUPLE = 8 + self.NW + 16 + 8 if full else 4 * self.NL + 2 * self.NW   # (A encoding, S, digest, R encoding) | (A.x, A.y, S, h, x, y)
+        self.XROW, self.YROW = self.L - self.NE + 2, self.L - self.NE + 3          # the rows of an instance whose Z are the affine x, y
+
+    def tuple_cols(self):
+        """the columns the instance's last row sends on the bus, in tuple order"""
+        NL = self.NL
+        if self.full:
+            return ([self.AENC + j for j in range(8)] + [self.SW + j for j in range(self.NW)] + [self.DW + j for j in range(16)]
+                    + [self.RENC + j for j in range(8)])
+        return ([self.REG + NL * AX + i for i in range(NL)] + [self.REG + NL * AY + i for i in range(NL)] + [self.SW + j for j in range(2 * self.NW)]
+                + [self.REG + NL * RESULT_X_REG + i for i in range(NL)] + [self.Z + i for i in range(NL)])
+
+    def word_limbs(self, j):
+        """the limb indices (least significant first) of 32-bit word j (least significant word = 0) of a 256-bit value"""
+        per = 32 // self.LB
+        return [per * j + m for m in range(per)]
 
     def limbs(self, v):
         return [(int(v) >> (self.LB * i)) & ((1 << self.LB) - 1) for i in range(self.NL)]
@@ -153,7 +224,7 @@ def build_program(lay: Layout):
     e.ldi(ZERO, 0)
     e.ldi(CLB, 1 << LB)
     e.ins(VX_OP_LDCH, GAMMA, 0)
-    e.ldw(C.RT + T_LLAST, dst=ADV)
+    e.ldw(C.RT + lay.T_LLAST, dst=ADV)
     e.ldw(C.BND, dst=BND)
     e.ldw(C.BIT, dst=B1)
     e.ldw(C.BIT + 1, dst=B2)
@@ -176,7 +247,7 @@ def build_program(lay: Layout):
         if first:
             e.op(VX_OP_ADD, ZERO, ZERO, dst)
 
-    free_rows = [t for t, op in enumerate(OPS) if op.free]
+    free_rows = [t for t, op in enumerate(lay.OPS) if op.free]
     sum_sel(free_rows, NOTFREE)
     e.op(VX_OP_SUB, ONE, NOTFREE, NOTFREE)
 
@@ -184,10 +255,10 @@ def build_program(lay: Layout):
         return e.ldw(C.REG + NL * r + i, nxt=nxt)
 
     # ---- X slot = the register the row type names (free rows: 0) ----
-    xregs = sorted({op.x for op in OPS if not op.free})
+    xregs = sorted({op.x for op in lay.OPS if not op.free})
     assert len(xregs) <= len(PH)
     for k, r in enumerate(xregs):
-        sum_sel([t for t, op in enumerate(OPS) if not op.free and op.x == r], PH[k])
+        sum_sel([t for t, op in enumerate(lay.OPS) if not op.free and op.x == r], PH[k])
     for i in range(NL):
         m0 = e.top
         t = tmp()
@@ -202,14 +273,14 @@ def build_program(lay: Layout):
         push(e.op(VX_OP_SUB, e.ldw(C.X + i), t), VX_AIR_ALL_ROWS)
         e.release(m0)
     # ---- Y slot = a register, a constant, a constant picked by the bit of S, or a register / constant picked by the bit of h ----
-    yregs = sorted({op.y[1] for op in OPS if not op.free and op.y[0] == "r"})
-    consts = sorted({op.y[1] for op in OPS if not op.free and op.y[0] == "c"})
-    b1s = sorted({op.y[1:] for op in OPS if not op.free and op.y[0] == "b1"})
-    b2s = sorted({op.y[1:] for op in OPS if not op.free and op.y[0] == "b2"})
+    yregs = sorted({op.y[1] for op in lay.OPS if not op.free and op.y[0] == "r"})
+    consts = sorted({op.y[1] for op in lay.OPS if not op.free and op.y[0] == "c"})
+    b1s = sorted({op.y[1:] for op in lay.OPS if not op.free and op.y[0] == "b1"})
+    b2s = sorted({op.y[1:] for op in lay.OPS if not op.free and op.y[0] == "b2"})
     groups = [("r", r) for r in yregs] + [("c", c) for c in consts] + [("b1",) + b for b in b1s] + [("b2",) + b for b in b2s]
     assert len(groups) <= len(PH)
     for k, g in enumerate(groups):
-        sum_sel([t for t, op in enumerate(OPS) if not op.free and op.y == g], PH[k])
+        sum_sel([t for t, op in enumerate(lay.OPS) if not op.free and op.y == g], PH[k])
     for i in range(NL):
         m0 = e.top
         t = tmp()
@@ -247,9 +318,10 @@ def build_program(lay: Layout):
         push(e.op(VX_OP_SUB, e.ldw(C.Y + i), t), VX_AIR_ALL_ROWS)
         e.release(m0)
     # ---- the multiply-add relation, coefficient by coefficient (off on the free rows) ----
-    eregs = sorted({op.e for op in OPS if not op.free and op.e is not None})
+    eregs = sorted({op.e for op in lay.OPS if not op.free and op.e is not None})
+    assert len(eregs) <= 16, "PH[16..20] hold the modulus constants and the mod-L selector"
     for k, r in enumerate(eregs):
-        sum_sel([t for t, op in enumerate(OPS) if not op.free and op.e == r], PH[k])
+        sum_sel([t for t, op in enumerate(lay.OPS) if not op.free and op.e == r], PH[k])
     pl = lay.limbs(Q25519)
     mask = (1 << LB) - 1
     assert pl[0] == mask - 18 and pl[NL - 1] == mask >> 1 and all(b == mask for b in pl[1:NL - 1])
@@ -258,6 +330,13 @@ def build_program(lay: Layout):
     e.ldi(c_hi, pl[NL - 1])
     e.ldi(c_mid, mask)
     e.ldi(coff, lay.W_OFFSET)
+    # full program: rows whose modulus is L — (Q P)_k gets  SL * sum_j Q_j (L - p)_{k-j}  on top of the p form
+    modl_rows = [t for t, op in enumerate(lay.OPS) if not op.free and op.mod == "L"]
+    SL = PH[20]
+    if modl_rows:
+        sum_sel(modl_rows, SL)
+        ll = lay.limbs(ELL)
+        delta = [(ll[j] - pl[j]) % P for j in range(NL)]
 
     def carry(k, dst):
         """dst = w_k = lo + 2^LB hi - 2^(2 LB - 1)"""
@@ -311,6 +390,23 @@ def build_program(lay: Layout):
             t = e.op(VX_OP_MUL, e.ldw(C.Q + k - (NL - 1)), c_hi)
             e.op(VX_OP_SUB, d, t, d)
             e.release(m1)
+        if modl_rows:
+            s2 = tmp()
+            first2 = True
+            for j in range(max(0, k - NL + 1), min(NL - 1, k) + 1):
+                if delta[k - j] == 0:
+                    continue
+                m2 = e.top
+                c2 = tmp()
+                e.ldi(c2, delta[k - j])
+                t2 = e.op(VX_OP_MUL, e.ldw(C.Q + j), c2)
+                e.op(VX_OP_ADD, t2, ZERO if first2 else s2, s2)
+                first2 = False
+                e.release(m2)
+            if not first2:
+                e.op(VX_OP_MUL, s2, SL, s2)
+                e.op(VX_OP_SUB, d, s2, d)
+            e.release(m1)
         # d_k = w_{k-1} - 2^LB w_k   (w_{-1} = w_{2 NL - 2} = 0)
         if k >= 1:
             w = tmp()
@@ -328,7 +424,7 @@ def build_program(lay: Layout):
         e.release(m0)
     # ---- write-back; rows that must produce 1 ----
     for r in range(NREG):
-        sum_sel([t for t, op in enumerate(OPS) if op.dst == r], PH[r])
+        sum_sel([t for t, op in enumerate(lay.OPS) if op.dst == r], PH[r])
     for r in range(NREG):
         for i in range(NL):
             m0 = e.top
@@ -339,7 +435,7 @@ def build_program(lay: Layout):
             push(e.op(VX_OP_SUB, vn, t), VX_AIR_TRANSITION)
             e.release(m0)
     s_one = PH[NREG]
-    sum_sel([t for t, op in enumerate(OPS) if op.one], s_one)
+    sum_sel([t for t, op in enumerate(lay.OPS) if op.one], s_one)
     for i in range(NL):
         m0 = e.top
         z = e.ldw(C.Z + i)
@@ -347,25 +443,102 @@ def build_program(lay: Layout):
             z = e.op(VX_OP_SUB, z, ONE)
         push(e.op(VX_OP_MUL, z, s_one), VX_AIR_ALL_ROWS)
         e.release(m0)
+    # ---- full program: Z a constant / Z a register / Q = 0 / bit rows / the statement's words tied to limbs ----
+    if lay.full:
+        keepf = e.top
+        zconsts = sorted({op.zconst for op in lay.OPS if op.zconst is not None})
+        zregs = sorted({op.zreg for op in lay.OPS if op.zreg is not None})
+        assert len(zconsts) <= 3 and len(zregs) <= 2
+        s_zc = [PH[15 + n_] for n_ in range(len(zconsts))]
+        s_zr = [PH[18 + n_] for n_ in range(len(zregs))]
+        s_q, s_bit = PH[20], PH[21]
+        for K, sK in zip(zconsts, s_zc):
+            sum_sel([t for t, op in enumerate(lay.OPS) if op.zconst == K], sK)
+        for r, sr in zip(zregs, s_zr):
+            sum_sel([t for t, op in enumerate(lay.OPS) if op.zreg == r], sr)
+        sum_sel([t for t, op in enumerate(lay.OPS) if op.qzero], s_q)
+        sum_sel([t for t, op in enumerate(lay.OPS) if op.bit], s_bit)
+        for i in range(NL):
+            m0 = e.top
+            z = e.ldw(C.Z + i)
+            acc = tmp()
+            e.op(VX_OP_ADD, ZERO, ZERO, acc)
+            for K, sK in zip(zconsts, s_zc):                      # sum_K s_K (Z_i - K_i)
+                m1 = e.top
+                c = tmp()
+                e.ldi(c, lay.limbs(K)[i])
+                t = e.op(VX_OP_SUB, z, c)
+                e.op(VX_OP_MUL, t, sK, t)
+                e.op(VX_OP_ADD, acc, t, acc)
+                e.release(m1)
+            for r, sr in zip(zregs, s_zr):                        # + sum_r s_r (Z_i - REG[r]_i)
+                m1 = e.top
+                t = e.op(VX_OP_SUB, z, reg(r, i))
+                e.op(VX_OP_MUL, t, sr, t)
+                e.op(VX_OP_ADD, acc, t, acc)
+                e.release(m1)
+            push(acc, VX_AIR_ALL_ROWS)
+            push(e.op(VX_OP_MUL, e.ldw(C.Q + i), s_q), VX_AIR_ALL_ROWS)        # an integer identity: no multiple of the modulus
+            if i == 0:                                            # bit rows: Z = 0 or 1
+                t = e.op(VX_OP_SUB, z, ONE)
+                e.op(VX_OP_MUL, t, z, t)
+                push(e.op(VX_OP_MUL, t, s_bit), VX_AIR_ALL_ROWS)
+            else:
+                push(e.op(VX_OP_MUL, z, s_bit), VX_AIR_ALL_ROWS)
+            e.release(m0)
+        # the statement's 32-bit words = the limbs they name, on the row that holds those limbs
+        groups = {"AENC": (C.AENC, list(range(8))), "RENC": (C.RENC, list(range(8))), "DHI": (C.DW + 8, list(range(8))), "DLO": (C.DW, list(range(8))),
+                  "H": (C.SW + C.NW, [C.NW - 1 - j for j in range(C.NW)]), "S": (C.SW, [C.NW - 1 - j for j in range(C.NW)])}
+        for t_, op in enumerate(lay.OPS):
+            if op.bind is None:
+                continue
+            gname, src, bitreg = op.bind
+            base, words = groups[gname]
+            m0 = e.top
+            sel = e.ldw(C.RT + t_)
+            for j, wd in enumerate(words):                        # column base + j  <->  word `wd` of the source
+                m1 = e.top
+                v = tmp()
+                e.op(VX_OP_ADD, ZERO, ZERO, v)
+                for m_, li in enumerate(C.word_limbs(wd)):
+                    m2 = e.top
+                    limb = e.ldw(C.Z + li) if src == "z" else reg(src, li)
+                    if m_:
+                        c = tmp()
+                        e.ldi(c, 1 << (C.LB * m_))
+                        e.op(VX_OP_MUL, limb, c, limb)
+                    e.op(VX_OP_ADD, v, limb, v)
+                    e.release(m2)
+                if bitreg is not None and wd == 7:                # the encoding's top bit: the sign = the parity of x
+                    m2 = e.top
+                    c = tmp()
+                    e.ldi(c, 1 << 31)
+                    e.op(VX_OP_ADD, v, e.op(VX_OP_MUL, reg(bitreg, 0), c), v)
+                    e.release(m2)
+                t = e.op(VX_OP_SUB, e.ldw(base + j), v)
+                push(e.op(VX_OP_MUL, t, sel), VX_AIR_ALL_ROWS)
+                e.release(m1)
+            e.release(m0)
+        e.release(keepf)
     # ---- row type: prologue -> loop (42 rows, repeated until FIN) -> epilogue -> the next instance's prologue ----
     fin = e.ldw(C.FIN)
     lf = e.op(VX_OP_MUL, ADV, fin)                    # last loop row of the last step
     lnf = e.op(VX_OP_SUB, ADV, lf)                    # last loop row of any other step
     keep = e.top
-    for t in range(NT):
+    for t in range(lay.NT):
         m0 = e.top
         nx = e.ldw(C.RT + t, nxt=True)
-        if t == T_P0:
-            pred = e.ldw(C.RT + T_ELAST)
-        elif t == T_L0:
-            pred = e.op(VX_OP_ADD, e.ldw(C.RT + T_PLAST), lnf)
-        elif t == T_E0:
+        if t == lay.T_P0:
+            pred = e.ldw(C.RT + lay.T_ELAST)
+        elif t == lay.T_L0:
+            pred = e.op(VX_OP_ADD, e.ldw(C.RT + lay.T_PLAST), lnf)
+        elif t == lay.T_E0:
             pred = lf
         else:
             pred = e.ldw(C.RT + t - 1)
         push(e.op(VX_OP_SUB, nx, pred), VX_AIR_TRANSITION)
         cur = e.ldw(C.RT + t)
-        push(e.op(VX_OP_SUB, cur, ONE) if t == T_P0 else cur, VX_AIR_FIRST_ROW)
+        push(e.op(VX_OP_SUB, cur, ONE) if t == lay.T_P0 else cur, VX_AIR_FIRST_ROW)
         e.release(m0)
     # ---- step counter: POS advances after every step, J after every 32 steps (both cyclic: a new instance starts at 0 / 0) ----
     for i in range(32):
@@ -393,8 +566,8 @@ def build_program(lay: Layout):
         push(e.op(VX_OP_SUB, cur, ONE) if j == 0 else cur, VX_AIR_FIRST_ROW)
         e.release(m0)
     # ---- the scalars: one bit of S and one of h per step, most significant first, packed into the instance's 32-bit words ----
-    plast = e.ldw(C.RT + T_PLAST)
-    elast = e.ldw(C.RT + T_ELAST)
+    plast = e.ldw(C.RT + lay.T_PLAST)
+    elast = e.ldw(C.RT + lay.T_ELAST)
     hold = e.op(VX_OP_SUB, ONE, ADV)
     e.op(VX_OP_SUB, hold, plast, hold)                # the bits may change after a step and when the loop is entered
     hold_sw = e.op(VX_OP_SUB, ONE, elast)             # the scalar words may change between instances
@@ -432,6 +605,12 @@ def build_program(lay: Layout):
         for j in range(C.NW):
             m0 = e.top
             t = e.op(VX_OP_SUB, e.ldw(C.SW + s * C.NW + j, nxt=True), e.ldw(C.SW + s * C.NW + j))
+            push(e.op(VX_OP_MUL, t, hold_sw), VX_AIR_TRANSITION)
+            e.release(m0)
+    if lay.full:                                                  # the statement's words hold over an instance
+        for col in range(C.AENC, C.RENC + 8):
+            m0 = e.top
+            t = e.op(VX_OP_SUB, e.ldw(col, nxt=True), e.ldw(col))
             push(e.op(VX_OP_MUL, t, hold_sw), VX_AIR_TRANSITION)
             e.release(m0)
     m0 = e.top
@@ -483,8 +662,7 @@ def build_program(lay: Layout):
     beta, gbus = tmp(), tmp()
     e.ins(VX_OP_LDCH, beta, 1)
     e.ins(VX_OP_LDCH, gbus, 2)
-    srcs = ([C.REG + NL * AX + i for i in range(NL)] + [C.REG + NL * AY + i for i in range(NL)] + [C.SW + j for j in range(2 * C.NW)]
-            + [C.REG + NL * RESULT_X_REG + i for i in range(NL)] + [C.Z + i for i in range(NL)])
+    srcs = C.tuple_cols()
     assert len(srcs) == C.NTUPLE
     tup = tmp()
     e.ldw(srcs[-1], dst=tup)
@@ -496,7 +674,7 @@ def build_program(lay: Layout):
     dlt = e.op(VX_OP_SUB, gbus, tup)
     u, bacc, baccn = e.ldw(C.AUX_U), e.ldw(C.AUX_BUS), e.ldw(C.AUX_BUS, nxt=True)
     t = e.op(VX_OP_MUL, u, dlt)
-    snd = e.op(VX_OP_MUL, e.ldw(C.RT + T_ELAST), e.ldw(C.ACT))
+    snd = e.op(VX_OP_MUL, e.ldw(C.RT + lay.T_ELAST), e.ldw(C.ACT))
     push(e.op(VX_OP_SUB, t, snd), VX_AIR_ALL_ROWS)                          # u (gamma - tuple) = [last row of an active instance]
     t = e.op(VX_OP_SUB, baccn, bacc)
     push(e.op(VX_OP_SUB, t, u), VX_AIR_TRANSITION)
@@ -511,26 +689,48 @@ def build_program(lay: Layout):
 
 # ---------------------------------------------------------------------------------------------------------------------
 # trace generation (vectorised over the instances of a table)
-def _simulate(lay: Layout, sigs):
-    """python-int simulation of every instance: -> per instance-row lists x, y, e, z (each [L][K])"""
+def _simulate(lay: Layout, sigs, strict=True):
+    """python-int simulation of every instance: -> per instance-row lists x, y, e, z (each [L][K]).  sigs: ((ax, ay), S, h) — the full
+    program: ((ax, ay), S, h, digest).  strict=False (tests): a row whose required Z (a constant, a register) is not what the row computes
+    takes the REQUIRED value and a comparison witness that would be negative wraps mod 2^256 — the trace then violates constraints
+    instead of the generator refusing it."""
     K, NB = len(sigs), lay.NB
     regs = [[0] * NREG for _ in range(K)]
     xs, ys, es, zs = [], [], [], []
-    bits1 = [[(s >> (NB - 1 - st)) & 1 for st in range(NB)] for (_, s, _) in sigs]
-    bits2 = [[(h >> (NB - 1 - st)) & 1 for st in range(NB)] for (_, _, h) in sigs]
-    rows = [(op, None) for op in PROLOGUE] + [(op, st) for st in range(NB) for op in LOOP] + [(op, None) for op in EPILOGUE]
-    free_seen = [0] * K
+    bits1 = [[(sg[1] >> (NB - 1 - st)) & 1 for st in range(NB)] for sg in sigs]
+    bits2 = [[(sg[2] >> (NB - 1 - st)) & 1 for st in range(NB)] for sg in sigs]
+    rows = [(op, None) for op in lay.PRO] + [(op, st) for st in range(NB) for op in lay.LOOPOPS] + [(op, None) for op in lay.EPI]
     for op, st in rows:
         xr, yr, er, zr = [0] * K, [0] * K, [0] * K, [0] * K
         for k in range(K):
             rg = regs[k]
             if op.free:
-                if op.dst == AX:
+                w = op.wit
+                if w is None:                                     # the base program's three free rows
+                    w = ("ax",) if op.dst == AX else (("ay",) if op.dst == AY else ("inv", Z1))
+                if w[0] == "ax":
                     z = sigs[k][0][0]
-                elif op.dst == AY:
+                elif w[0] == "ay":
                     z = sigs[k][0][1]
+                elif w[0] == "inv":
+                    z = pow(rg[w[1]], Q25519 - 2, Q25519)
+                elif w[0] == "cmp":                               # bound - 1 - value: exists iff value < bound
+                    z = w[1] - 1 - rg[w[2]]
+                    if z < 0:
+                        if strict:
+                            raise ValueError("instance %d: a value that must be below %s is not" % (k, "p" if w[1] == Q25519 else "L"))
+                        z %= 1 << 256
+                elif w[0] == "half":
+                    z = rg[w[1]] >> 1
+                elif w[0] == "bit":
+                    z = rg[w[1]] & 1
+                elif w[0] == "dhi":
+                    z = sigs[k][3] >> 256
+                elif w[0] == "dlo":
+                    z = sigs[k][3] & ((1 << 256) - 1)
                 else:
-                    z = pow(rg[Z1], Q25519 - 2, Q25519)
+                    assert w[0] == "s"
+                    z = sigs[k][1]
                 x = y = ev = 0
             else:
                 x = rg[op.x]
@@ -544,7 +744,15 @@ def _simulate(lay: Layout, sigs):
                 else:
                     y = rg[op.y[1]] if bits2[k][st] else op.y[2]
                 ev = rg[op.e] if op.e is not None else 0
-                z = (x * y + ev) % Q25519
+                if op.qzero:                                      # an integer identity: Z is what the row REQUIRES
+                    z = x * y + ev
+                    want = op.zconst if op.zconst is not None else rg[op.zreg]
+                    if z != want:
+                        if strict:
+                            raise ValueError("instance %d: an integer identity of the full program does not hold" % k)
+                        z = want
+                else:
+                    z = (x * y + ev) % (ELL if op.mod == "L" else Q25519)
             if op.one and z != 1:
                 raise ValueError("instance %d: a row that must produce 1 does not (A not on the curve, or Z = 0)" % k)
             rg[op.dst] = z
@@ -553,7 +761,6 @@ def _simulate(lay: Layout, sigs):
         ys.append(yr)
         es.append(er)
         zs.append(zr)
-    del free_seen
     return xs, ys, es, zs, bits1, bits2
 
 
@@ -564,30 +771,34 @@ def _limb_array(lay: Layout, vals):
     return a.reshape(-1, lay.NL).astype(np.int64)
 
 
-def _instance_blocks(lay: Layout, ulist):
+def _instance_blocks(lay: Layout, ulist, strict=True):
     """the instance-local columns of every DISTINCT instance, side by side: -> (block [N][U * L] with registers starting from 0 in each
     instance, final register limbs [U][NREG][NL], per-instance limb counts [U][2^LB] of the looked-up columns, results, bits of S, bits of h)"""
     L, NL, LB, NB = lay.L, lay.NL, lay.LB, lay.NB
     U = len(ulist)
-    xs, ys, es, zs, bits1, bits2 = _simulate(lay, ulist)
+    xs, ys, es, zs, bits1, bits2 = _simulate(lay, ulist, strict)
     flat = lambda rows: [rows[rho][k] for k in range(U) for rho in range(L)]      # noqa: E731  (instance-major: row = u * L + rho)
     xv, yv, ev, zv = flat(xs), flat(ys), flat(es), flat(zs)
-    qv = [(a * b + c - d) // Q25519 for a, b, c, d in zip(xv, yv, ev, zv)]
-    rt = np.array([t for t in range(NP_)] + [NP_ + (i % NL_) for i in range(NL_ * NB)] + [NP_ + NL_ + i for i in range(NE_)], dtype=np.int64)
+    rt = np.array([t for t in range(lay.NP)] + [lay.NP + (i % lay.NLOOP) for i in range(lay.NLOOP * NB)] + [lay.NP + lay.NLOOP + i for i in range(lay.NE)], dtype=np.int64)
     rt_all = np.tile(rt, U)
-    free_all = np.isin(rt_all, [t for t, op in enumerate(OPS) if op.free])
-    for i in np.nonzero(free_all)[0]:
-        qv[i] = 0
+    free_all = np.isin(rt_all, [t for t, op in enumerate(lay.OPS) if op.free])
+    modl_all = np.isin(rt_all, [t for t, op in enumerate(lay.OPS) if not op.free and op.mod == "L"])
+    qzero_all = np.isin(rt_all, [t for t, op in enumerate(lay.OPS) if op.qzero])
+    # the quotient by the ROW's modulus (p; L on the full program's two reduction rows); 0 on free rows and on the integer identities
+    qv = [0 if (fr or qz) else (a * b + c - d) // (ELL if ml else Q25519)
+          for a, b, c, d, fr, qz, ml in zip(xv, yv, ev, zv, free_all, qzero_all, modl_all)]
     # limb planes [NL][rows]: one contiguous vector per limb, like the trace itself
     Xl, Yl, El, Zl, Ql = (np.ascontiguousarray(_limb_array(lay, v).T) for v in (xv, yv, ev, zv, qv))
     del xv, yv, ev, qv
-    Pl = lay.limbs(Q25519)
+    Pl, Ll = lay.limbs(Q25519), lay.limbs(ELL)
     R = U * L
     d = np.zeros((2 * NL - 1, R), dtype=np.int64)
     for i in range(NL):
         for j in range(NL):
             d[i + j] += Xl[i] * Yl[j]
-            if Pl[j]:
+            if modl_all.any():
+                d[i + j] -= Ql[i] * np.where(modl_all, Ll[j], Pl[j])
+            elif Pl[j]:
                 d[i + j] -= Ql[i] * Pl[j]
     d[:NL] += El - Zl
     d *= ~free_all                                         # the relation is off on the free rows: carries 0
@@ -595,14 +806,14 @@ def _instance_blocks(lay: Layout, ulist):
     prev = np.zeros(R, dtype=np.int64)
     for k in range(2 * NL - 1):
         t = prev - d[k]
-        assert not (t & ((1 << LB) - 1)).any()
+        assert not strict or not (t & ((1 << LB) - 1)).any()
         prev = t >> LB
         if k <= 2 * NL - 3:
-            assert (np.abs(prev) < lay.W_OFFSET).all()
+            assert not strict or (np.abs(prev) < lay.W_OFFSET).all()
             off = prev + lay.W_OFFSET
             Wl[2 * k] = off & ((1 << LB) - 1)
-            Wl[2 * k + 1] = off >> LB
-    assert not prev.any()
+            Wl[2 * k + 1] = (off >> LB) & ((1 << LB) - 1)
+    assert not strict or not prev.any()
     del d
     blk = np.zeros((lay.N, R), dtype=np.uint64)
     rows = np.arange(R)
@@ -612,7 +823,7 @@ def _instance_blocks(lay: Layout, ulist):
     # registers: the value a register holds on a row = the Z of the last earlier row OF THE SAME INSTANCE that wrote it (0 before that:
     # what the previous instance left there is patched in when the trace is assembled)
     start = (rows // L) * L
-    dst_of = np.array([op.dst for op in OPS], dtype=np.int64)[rt_all]
+    dst_of = np.array([op.dst for op in lay.OPS], dtype=np.int64)[rt_all]
     final = np.zeros((U, NREG, NL), dtype=np.uint64)
     for r in range(NREG):
         wrote = np.where(dst_of == r, rows, -1)
@@ -625,23 +836,29 @@ def _instance_blocks(lay: Layout, ulist):
         blk[lay.REG + NL * r:lay.REG + NL * (r + 1)] = vals
         final[:, r, :] = Zl[:, last[L - 1::L]].T                      # every register is written in every instance
     rho = rows % L
-    step = np.clip((rho - NP_) // NL_, 0, NB - 1)          # prologue rows carry step 0's position, epilogue rows wrap to 0 / 0
-    after = rho >= NP_ + NL_ * NB
+    step = np.clip((rho - lay.NP) // lay.NLOOP, 0, NB - 1)          # prologue rows carry step 0's position, epilogue rows wrap to 0 / 0
+    after = rho >= lay.NP + lay.NLOOP * NB
     pos = np.where(after, 0, step % 32)
     word = np.where(after, 0, step // 32)
     blk[lay.POS + pos, rows] = 1
     blk[lay.J + word, rows] = 1
-    adv = rt_all == T_LLAST
+    adv = rt_all == lay.T_LLAST
     bnd = adv & (step % 32 == 31)
     blk[lay.BND] = bnd
     blk[lay.FIN] = bnd & (step // 32 == lay.NW - 1)
     counts = np.stack([np.bincount(blk[lay.Z:lay.Z + lay.NLOOK, u * L:(u + 1) * L].astype(np.int64).reshape(-1), minlength=1 << LB) for u in range(U)])
-    results = [(zs[L - 2][u], zs[L - 1][u]) for u in range(U)]
+    results = [(zs[lay.XROW][u], zs[lay.YROW][u]) for u in range(U)]
     return blk, final, counts, results, np.array(bits1, dtype=np.uint64), np.array(bits2, dtype=np.uint64)
 
 
-def generate_trace(lay: Layout, degree_bits: int, sigs) -> tuple:
-    """sigs = [((ax, ay), S, h)] — one instance each, in order.  The trace holds as many whole instances as were given (<= capacity)
+def compress_words(x, y):
+    """the 8 little-endian 32-bit words of a point's RFC 8032 encoding: y with the parity of x as bit 255"""
+    v = int(y) | ((int(x) & 1) << 255)
+    return [(v >> (32 * j)) & 0xFFFFFFFF for j in range(8)]
+
+
+def generate_trace(lay: Layout, degree_bits: int, sigs, strict=True) -> tuple:
+    """sigs = [((ax, ay), S, h)] — the full program: [((ax, ay), S, h, digest)] — one instance each, in order.  The trace holds as many whole instances as were given (<= capacity)
     followed by filler instances (A = B, S = h = 0, nothing sent; the last one unfinished).  Only DISTINCT signatures are simulated:
     a bench that repeats 16 signatures over 97 instances pays for 16.
     -> (trace [N][n] uint64, results [(x, y)] per given instance = affine [S]B - [h]A)"""
@@ -651,22 +868,23 @@ def generate_trace(lay: Layout, degree_bits: int, sigs) -> tuple:
     cap = capacity(lay, degree_bits)
     assert len(sigs) <= cap, f"2^{degree_bits} rows hold {cap} instances"
     K = -(-n // L)
-    allsigs = [tuple(sg) for sg in sigs] + [((BX, BY), 0, 0)] * (K - len(sigs))
-    for (_, s, h) in allsigs:
-        assert 0 <= s < (1 << NB) and 0 <= h < (1 << NB)
+    filler = ((BX, BY), 0, 0, 0) if lay.full else ((BX, BY), 0, 0)
+    allsigs = [tuple(sg) for sg in sigs] + [filler] * (K - len(sigs))
+    for sg in allsigs:
+        assert len(sg) == len(filler) and 0 <= sg[1] < (1 << 256 if lay.full else 1 << NB) and 0 <= sg[2] < (1 << NB)
     uniq = {}
     which = np.array([uniq.setdefault(sg, len(uniq)) for sg in allsigs], dtype=np.int64)
-    blk, final, counts, ures, ubits1, ubits2 = _instance_blocks(lay, list(uniq))
+    blk, final, counts, ures, ubits1, ubits2 = _instance_blocks(lay, list(uniq), strict)
     t = np.empty((lay.N, n), dtype=np.uint64)
     for k in range(K):
         lo, hi = k * L, min(n, (k + 1) * L)
         t[:, lo:hi] = blk[:, which[k] * L:which[k] * L + hi - lo]
     # what the previous instance left in a register, up to and including the row that first writes it
-    first_write = [min(rho for rho, op in enumerate(OPS[:NP_]) if op.dst == r) if any(op.dst == r for op in OPS[:NP_]) else None for r in range(NREG)]
+    first_write = [min(rho for rho, op in enumerate(lay.OPS[:lay.NP]) if op.dst == r) if any(op.dst == r for op in lay.OPS[:lay.NP]) else None for r in range(NREG)]
     for r in range(NREG):
         fw = first_write[r]
-        if fw is None:       # first written in the loop: row NP_ + (index in LOOP)
-            fw = NP_ + min(i for i, op in enumerate(LOOP) if op.dst == r)
+        if fw is None:       # first written in the loop: row lay.NP + (index in lay.LOOPOPS)
+            fw = lay.NP + min(i for i, op in enumerate(lay.LOOPOPS) if op.dst == r)
         for k in range(1, K):
             lo = k * L
             hi = min(n, lo + fw + 1)
@@ -675,23 +893,30 @@ def generate_trace(lay: Layout, degree_bits: int, sigs) -> tuple:
     rows = np.arange(n)
     rho = rows % L
     inst = rows // L
-    step = np.clip((rho - NP_) // NL_, 0, NB - 1)
-    after = rho >= NP_ + NL_ * NB
+    step = np.clip((rho - lay.NP) // lay.NLOOP, 0, NB - 1)
+    after = rho >= lay.NP + lay.NLOOP * NB
     for s, ubits, sc in ((0, ubits1, [x[1] for x in allsigs]), (1, ubits2, [x[2] for x in allsigs])):
         bits = ubits[which]                                              # [K][NB]
         # bit column: constant over a step; prologue rows keep the PREVIOUS instance's final bit (hold constraint; the loop entry may change
         # it), epilogue rows keep the last step's bit
         cur = bits[inst, step]
         prev_last = np.where(inst > 0, bits[np.maximum(inst - 1, 0), NB - 1], bits[0, 0])
-        t[lay.BIT + s] = np.where(rho < NP_, prev_last, cur)
+        t[lay.BIT + s] = np.where(rho < lay.NP, prev_last, cur)
         # KACC: the bits of the current word so far on loop rows; K' = K + adv (K + bit') - bnd 2 K + plast (bit' - K) elsewhere: the FIN row
         # leaves the held last bit, which the epilogue and the next prologue keep
         words = np.array([[(int(v) >> (32 * (lay.NW - 1 - j))) & 0xFFFFFFFF for j in range(lay.NW)] for v in sc], dtype=np.uint64)   # [K][NW]
         kacc = words[inst, step // 32] >> (np.uint64(31) - (step % 32).astype(np.uint64))
         kprev = np.where(inst > 0, prev_last, kacc[0])
-        t[lay.KACC + s] = np.where(rho < NP_, kprev, np.where(after, cur, kacc))
+        t[lay.KACC + s] = np.where(rho < lay.NP, kprev, np.where(after, cur, kacc))
         t[lay.SW + s * lay.NW:lay.SW + (s + 1) * lay.NW] = words[inst].T
     t[lay.ACT] = inst < len(sigs)
+    if lay.full:                                                         # the statement's words, constant over the instance
+        aenc = np.array([compress_words(*sg[0]) for sg in allsigs], dtype=np.uint64)
+        dw = np.array([[(int(sg[3]) >> (32 * j)) & 0xFFFFFFFF for j in range(16)] for sg in allsigs], dtype=np.uint64)
+        renc = np.array([compress_words(*ures[which[k]]) for k in range(K)], dtype=np.uint64)
+        t[lay.AENC:lay.AENC + 8] = aenc[inst].T
+        t[lay.DW:lay.DW + 16] = dw[inst].T
+        t[lay.RENC:lay.RENC + 8] = renc[inst].T
     t[lay.TBL] = rows % (1 << LB)
     # multiplicities over rows 0 .. n-2: whole instances from the per-instance counts, the unfinished tail counted directly
     whole = (n - 1) // L
@@ -712,11 +937,18 @@ def capacity(lay: Layout, degree_bits: int) -> int:
 def send_tuples(lay: Layout, trace):
     """-> (rows that send, [rows][NTUPLE] elements) read off the trace the way the program reads them"""
     n = trace.shape[1]
-    rows = np.nonzero(trace[lay.RT + T_ELAST, :n - 1] * trace[lay.ACT, :n - 1])[0]
+    rows = np.nonzero(trace[lay.RT + lay.T_ELAST, :n - 1] * trace[lay.ACT, :n - 1])[0]
     NL = lay.NL
-    cols = ([lay.REG + NL * AX + i for i in range(NL)] + [lay.REG + NL * AY + i for i in range(NL)] + [lay.SW + j for j in range(2 * lay.NW)]
-            + [lay.REG + NL * RESULT_X_REG + i for i in range(NL)] + [lay.Z + i for i in range(NL)])
+    cols = lay.tuple_cols()
     return rows, trace[np.array(cols)][:, rows].T
+
+
+def tuple_of_full(lay: Layout, public_key: bytes, signature: bytes, digest: bytes):
+    """the bus tuple of the FULL program, straight from the bytes a verifier holds: the public key's 8 words, S (most significant word first,
+    like the scalar columns), the 16 words of SHA-512(R || A || M), R's 8 words — nothing decompressed, nothing reduced"""
+    le = lambda b: [int.from_bytes(b[4 * j:4 * j + 4], "little") for j in range(len(b) // 4)]   # noqa: E731
+    s_words = le(signature[32:])
+    return le(public_key) + s_words[::-1] + le(digest) + le(signature[:32])
 
 
 def tuple_of(lay: Layout, a, s, h, r):
@@ -758,12 +990,11 @@ def aux_columns(lay: Layout, trace, chal):
     out[lay.NPAIR] = ht
     step = hf.submod(step, ht)
     out[lay.NPAIR + 1], _ = hf.exclusive_prefix_sum(step)
-    rows = np.nonzero(trace[lay.RT + T_ELAST] * trace[lay.ACT])[0]
+    rows = np.nonzero(trace[lay.RT + lay.T_ELAST] * trace[lay.ACT])[0]
     u = np.zeros(n, dtype=np.uint64)
     if rows.size:
         NL = lay.NL
-        cols = ([lay.REG + NL * AX + i for i in range(NL)] + [lay.REG + NL * AY + i for i in range(NL)] + [lay.SW + j for j in range(2 * lay.NW)]
-                + [lay.REG + NL * RESULT_X_REG + i for i in range(NL)] + [lay.Z + i for i in range(NL)])
+        cols = lay.tuple_cols()
         tup = _horner(trace[np.array(cols)][:, rows].T, beta)
         u[rows] = hf.invmod(hf.submod(np.full(rows.size, gbus, dtype=np.uint64), tup))
     out[lay.NPAIR + 2] = u
@@ -796,8 +1027,7 @@ def aux_program(lay: Layout):
     e.push(e.op(VX_OP_SUB, GAMMA, e.ldw(lay.TBL)), 0)
     e.release(m0)
     NL = lay.NL
-    srcs = ([lay.REG + NL * AX + i for i in range(NL)] + [lay.REG + NL * AY + i for i in range(NL)] + [lay.SW + j for j in range(2 * lay.NW)]
-            + [lay.REG + NL * RESULT_X_REG + i for i in range(NL)] + [lay.Z + i for i in range(NL)])
+    srcs = lay.tuple_cols()
     tup = e.tmp()
     e.ldw(srcs[-1], dst=tup)
     for col in reversed(srcs[:-1]):
@@ -805,7 +1035,7 @@ def aux_program(lay: Layout):
         e.op(VX_OP_MUL, tup, BETA, tup)
         e.op(VX_OP_ADD, tup, e.ldw(col), tup)
         e.release(m1)
-    e.push(e.op(VX_OP_MUL, e.ldw(lay.RT + T_ELAST), e.ldw(lay.ACT)), 0)
+    e.push(e.op(VX_OP_MUL, e.ldw(lay.RT + lay.T_ELAST), e.ldw(lay.ACT)), 0)
     e.push(e.op(VX_OP_SUB, GBUS, tup), 0)
     e.ins(VX_OP_END)
     nf = lay.NPAIR + 2
@@ -918,6 +1148,19 @@ def equation_inputs(public_key: bytes, message: bytes, signature: bytes):
         raise ValueError("S >= L")
     h = int.from_bytes(hashlib.sha512(signature[:32] + public_key + message).digest(), "little") % ELL
     return a, s, h, r
+
+
+def equation_inputs_full(public_key: bytes, message: bytes, signature: bytes, check=True):
+    """what the FULL program's trace generator takes for an Ed25519 signature: ((A.x, A.y), S, h, digest) — A decompressed and h reduced
+    on the host only to WRITE the witness; the table re-derives both from the encodings and the digest.  check=False skips the host-side
+    refusals (S >= L) so that a test can show the TABLE refusing."""
+    import hashlib
+    a = decompress(public_key)
+    s = int.from_bytes(signature[32:], "little")
+    if check and s >= ELL:
+        raise ValueError("S >= L")
+    d = int.from_bytes(hashlib.sha512(signature[:32] + public_key + message).digest(), "little")
+    return a, s, d % ELL, d
 
 
 def sign(secret: bytes, message: bytes):
