@@ -405,13 +405,16 @@ int vx_trace_sha512(vx_ctx* ctx, int degree_bits, const uint8_t* msgs, const uin
                     uint64_t* public_inputs_out, uint8_t* digests_out);
 int vx_trace_blake2b(vx_ctx* ctx, int degree_bits, const uint8_t* msgs, const uint64_t* offsets, int num_msgs, void* trace_dev,
                      uint64_t* public_inputs_out, uint8_t* digests_out);
-/* The batched EdDSA table (vectorx_amd/eddsa_air.py, Layout(limb_bits = 16, scalar_bits)): one instance of 16 + 42 * scalar_bits + 4 rows
- * per signature equation [S]B - [h]A, `sigs` = [num_sigs][4][4] little-endian 64-bit words: A.x, A.y (affine), S, h (< 2^scalar_bits);
- * the rows that remain hold filler instances (A = B, S = h = 0).  Replaces the witness generation of Curta's
- * `curta_eddsa_verify_sigs_conditional` (/root/reference/circuits/builder/justification.rs:237-243).  trace_dev = [475 for
- * scalar_bits 256][2^degree_bits]; results_out ([num_sigs][2][4] words, may be NULL) = the affine (x, y) every instance arrives at —
- * what the bus sink compares with R.  VX_E_INVALID when an A is not on the curve or num_sigs exceeds (2^degree_bits - 1) / rows. */
-int vx_trace_eddsa(vx_ctx* ctx, int degree_bits, int scalar_bits, const uint64_t* sigs, int num_sigs, void* trace_dev, uint64_t* results_out);
+/* The batched EdDSA table (vectorx_amd/eddsa_air.py, Layout(limb_bits = 16, scalar_bits, full)): one instance of 16 + 42 * scalar_bits + 4
+ * rows per signature equation [S]B - [h]A (the FULL program, full = 1, scalar_bits = 256: 32 + 42 * 256 + 11 rows — it also decompresses
+ * A and R, reduces the SHA-512 digest mod L and checks S < L inside the instance).  `sigs` = [num_sigs][16] little-endian 64-bit words:
+ * A.x, A.y (affine), S, h — full: [num_sigs][24], followed by the 512-bit digest (low half, high half; h must be digest mod L).  The rows
+ * that remain hold filler instances (A = B, S = h = 0).  Replaces the witness generation of Curta's
+ * `curta_eddsa_verify_sigs_conditional` (/root/reference/circuits/builder/justification.rs:237-243).  trace_dev = [475 | 530 full]
+ * [2^degree_bits] at 256-bit scalars; results_out ([num_sigs][2][4] words, may be NULL) = the affine (x, y) every instance arrives at.
+ * VX_E_INVALID when an A is not on the curve, a value the full program must find canonical is not (S >= L, ...), or num_sigs exceeds
+ * (2^degree_bits - 1) / rows. */
+int vx_trace_eddsa(vx_ctx* ctx, int degree_bits, int scalar_bits, int full, const uint64_t* sigs, int num_sigs, void* trace_dev, uint64_t* results_out);
 /* The same for the constraint-program gates of a circuit (one kernel per program gate): returns the number compiled now. */
 int vx_circuit_precompile(const vx_circuit_desc* desc, int* num_program_gates_out);
 /* Compile an AIR program ahead of time: every chunk of the program (jit.hip.h cuts long programs into kernels of ~1200

@@ -98,6 +98,31 @@ def test_device_eddsa_trace_equals_the_numpy_generator(ctx, scalar_bits, nsig, d
         assert res == full_r          # the instance arrives at R of the RFC 8032 signature
 
 
+def test_device_full_eddsa_trace_equals_the_numpy_generator_and_refuses_what_it_refuses(ctx):
+    """the FULL program on the device (decompression, digest mod L, S < L inside the instance): RFC 8032 signatures from their bytes"""
+    import vectorx_amd as vx
+    from test_eddsa_air import RFC8032
+    from vectorx_amd import eddsa_air as ea
+    lay, log_n = ea.Layout(16, 256, full=True), 17
+    raw = [(bytes.fromhex(pk), bytes.fromhex(msg), bytes.fromhex(sig)) for _, pk, msg, sig in RFC8032]
+    sigs = [ea.equation_inputs_full(pk, msg, sig) for pk, msg, sig in raw]
+    n = 1 << log_n
+    d = ctx.alloc(lay.N * n * 8)
+    try:
+        ctx.upload(d, np.full((lay.N, n), 0xDEAD, dtype=np.uint64))
+        res = ctx.trace_eddsa_table(log_n, 256, sigs, d, full=True)
+        got = ctx.download(d, lay.N * n * 8).reshape(lay.N, n)
+        ref, rres = ea.generate_trace(lay, log_n, sigs)
+        bad = np.argwhere(got != ref)
+        assert bad.size == 0, f"first differing cells (column, row): {bad[:8].tolist()}"
+        assert res == rres == [ea.decompress(sig[:32]) for _, _, sig in raw]
+        a, s, h, dg = sigs[0]
+        with pytest.raises(vx.VxError, match="canonical"):
+            ctx.trace_eddsa_table(log_n, 256, [(a, s + ea.ELL, h, dg)], d, full=True)            # S >= L
+    finally:
+        ctx.free(d)
+
+
 def test_eddsa_table_proves_from_the_device_generated_trace_and_refuses_a_point_off_the_curve(ctx):
     import vectorx_amd as vx
     from vectorx_amd import eddsa_air as ea

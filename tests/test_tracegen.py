@@ -107,6 +107,24 @@ def test_a_message_that_does_not_fit_is_refused(tgh):
     assert rc == 2
 
 
+def _eddsa_host(tgh, lay, log_n, sigs):
+    full = lay.full
+    stride = 6 if full else 4
+    arr = np.zeros((max(1, len(sigs)), stride, 4), dtype=np.uint64)
+    words = lambda v: [(int(v) >> (64 * w)) & 0xFFFFFFFFFFFFFFFF for w in range(4)]      # noqa: E731
+    for i, sg in enumerate(sigs):
+        arr[i, 0], arr[i, 1], arr[i, 2], arr[i, 3] = words(sg[0][0]), words(sg[0][1]), words(sg[1]), words(sg[2])
+        if full:
+            arr[i, 4], arr[i, 5] = words(sg[3]), words(int(sg[3]) >> 256)
+    trace = np.full((lay.N, 1 << log_n), 0xDEAD, dtype=np.uint64)
+    res = np.zeros((max(1, len(sigs)), 2, 4), dtype=np.uint64)
+    tgh.tgh_eddsa.restype = ctypes.c_int
+    tgh.tgh_eddsa.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    rc = tgh.tgh_eddsa(log_n, lay.NB, int(full), arr.ctypes.data, len(sigs), trace.ctypes.data, res.ctypes.data)
+    val = lambda w: sum(int(w[k]) << (64 * k) for k in range(4))      # noqa: E731
+    return rc, trace, [(val(res[i, 0]), val(res[i, 1])) for i in range(len(sigs))]
+
+
 @pytest.mark.parametrize("scalar_bits,log_n,nsig,distinct", [(32, 17, 5, 3), (64, 17, 46, 2), (256, 17, 3, 3)])
 def test_eddsa_rows_equal_the_numpy_generator(tgh, scalar_bits, log_n, nsig, distinct):
     """the batched EdDSA table: real signature equations (cut to `scalar_bits` bits of S and h), then filler instances, an unfinished tail"""
@@ -117,18 +135,28 @@ def test_eddsa_rows_equal_the_numpy_generator(tgh, scalar_bits, log_n, nsig, dis
     mask = (1 << scalar_bits) - 1
     sigs = [(a, s & mask, h & mask) for (a, s, h) in full]
     ref, rres = ea.generate_trace(lay, log_n, sigs)
-    arr = np.zeros((nsig, 4, 4), dtype=np.uint64)
-    for i, ((ax, ay), s_, h_) in enumerate(sigs):
-        for k, v in enumerate((ax, ay, s_, h_)):
-            arr[i, k] = [(int(v) >> (64 * w)) & 0xFFFFFFFFFFFFFFFF for w in range(4)]
-    trace = np.full((lay.N, 1 << log_n), 0xDEAD, dtype=np.uint64)
-    res = np.zeros((nsig, 2, 4), dtype=np.uint64)
-    tgh.tgh_eddsa.restype = ctypes.c_int
-    tgh.tgh_eddsa.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
-    assert tgh.tgh_eddsa(log_n, scalar_bits, arr.ctypes.data, nsig, trace.ctypes.data, res.ctypes.data) == 0
+    rc, trace, res = _eddsa_host(tgh, lay, log_n, sigs)
+    assert rc == 0
     bad = np.argwhere(trace != ref)
     assert bad.size == 0, f"first differing cells (column, row): {bad[:8].tolist()}"
-    val = lambda w: sum(int(w[k]) << (64 * k) for k in range(4))      # noqa: E731
-    assert [(val(res[i, 0]), val(res[i, 1])) for i in range(nsig)] == rres
+    assert res == rres
     if scalar_bits == 256:          # whole scalars: the instance arrives at R of the RFC 8032 signature
         assert rres == stark_chips.eddsa_signatures(nsig, distinct)[1]
+
+
+def test_full_eddsa_rows_equal_the_numpy_generator_and_refuse_what_it_refuses(tgh):
+    """the FULL program (decompression, digest mod L, S < L inside the instance): RFC 8032 signatures from their bytes"""
+    from test_eddsa_air import RFC8032
+    from vectorx_amd import eddsa_air as ea
+    lay, log_n = ea.Layout(16, 256, full=True), 17
+    raw = [(bytes.fromhex(pk), bytes.fromhex(msg), bytes.fromhex(sig)) for _, pk, msg, sig in RFC8032]
+    sigs = [ea.equation_inputs_full(pk, msg, sig) for pk, msg, sig in raw]
+    ref, rres = ea.generate_trace(lay, log_n, sigs)
+    rc, trace, res = _eddsa_host(tgh, lay, log_n, sigs)
+    assert rc == 0
+    bad = np.argwhere(trace != ref)
+    assert bad.size == 0, f"first differing cells (column, row): {bad[:8].tolist()}"
+    assert res == rres == [ea.decompress(sig[:32]) for _, _, sig in raw]
+    a, s, h, d = sigs[0]
+    assert _eddsa_host(tgh, lay, log_n, [(a, s + ea.ELL, h, d)])[0] == 12                       # S >= L: no comparison witness
+    assert _eddsa_host(tgh, lay, log_n, [((a[0] + ea.Q25519, a[1]), s, h, d)])[0] in (11, 12)   # a non-canonical x

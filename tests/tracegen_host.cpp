@@ -58,30 +58,40 @@ int tgh_blake2b(int degree_bits, const uint8_t* msgs, const uint64_t* off, int n
   for (size_t i = 0; i < prep.digests.size(); ++i) digest_words[i] = prep.digests[i];
   return 0;
 }
-int tgh_eddsa(int degree_bits, int scalar_bits, const uint64_t* sigs, int nsig, uint64_t* trace, uint64_t* results) {
-  const tg::ed::Cols cl = tg::ed::cols(scalar_bits);
+int tgh_eddsa(int degree_bits, int scalar_bits, int full, const uint64_t* sigs, int nsig, uint64_t* trace, uint64_t* results) {
+  const tg::ed::Cols cl = tg::ed::cols(scalar_bits, full);
   const size_t n = (size_t)1 << degree_bits;
   if ((size_t)nsig > (n - 1) / cl.L) return 1;
   const int ninst = (int)((n + cl.L - 1) / cl.L);
   tg::ed::Sig filler;
   memset(&filler, 0, sizeof filler);
   for (int k = 0; k < 4; ++k) filler.ax[k] = tg::ed::BX[k], filler.ay[k] = tg::ed::BY[k];
-  const tg::ed::Sig* sg = (const tg::ed::Sig*)sigs;
+  const int stride = full ? 24 : 16;
+  std::vector<tg::ed::Sig> sg((size_t)(nsig ? nsig : 1));
+  memset(sg.data(), 0, sg.size() * sizeof(tg::ed::Sig));
+  for (int i = 0; i < nsig; ++i) {
+    const uint64_t* w = sigs + (size_t)i * stride;
+    memcpy(sg[i].ax, w, 32), memcpy(sg[i].ay, w + 4, 32), memcpy(sg[i].s, w + 8, 32), memcpy(sg[i].h, w + 12, 32);
+    if (full) memcpy(sg[i].d, w + 16, 64);
+  }
   std::vector<tg::ed::RowVals> vals((size_t)ninst * cl.L);
   uint64_t regs[tg::ed::NREG][4];
-  for (int u = 0; u < ninst; ++u)
-    if (tg::ed::simulate_instance(u < nsig ? sg[u] : filler, scalar_bits, vals.data() + (size_t)u * cl.L, regs) && u < nsig) return 3;
+  for (int u = 0; u < ninst; ++u) {
+    const int why = tg::ed::simulate_instance(cl, u < nsig ? sg[u] : filler, vals.data() + (size_t)u * cl.L, regs);
+    if (why && u < nsig) return 10 + why;
+  }
   tg::ed::RegSrc rsrc;
-  tg::ed::make_reg_src(scalar_bits, rsrc);
+  memset(&rsrc, 0, sizeof rsrc);
+  tg::ed::make_reg_src(cl, rsrc);
   std::vector<uint64_t> hist(65536, 0);
   for (size_t row = 0; row < n; ++row) {
     const bool count = row + 1 < n;
-    tg::ed::row(cl, rsrc, vals.data(), sg, nsig, filler, row, [&](int col, uint64_t v) { trace[(size_t)col * n + row] = v; },
+    tg::ed::row(cl, rsrc, vals.data(), sg.data(), nsig, filler, row, [&](int col, uint64_t v) { trace[(size_t)col * n + row] = v; },
                 [&](unsigned limb) { if (count) hist[limb]++; });
   }
   for (int i = 0; i < 65536; ++i) trace[(size_t)cl.MULT * n + i] = hist[i];
   for (int u = 0; u < nsig; ++u)
-    for (int w = 0; w < 2; ++w) memcpy(results + ((size_t)u * 2 + w) * 4, vals[(size_t)u * cl.L + cl.L - 2 + w].z, 32);
+    for (int w = 0; w < 2; ++w) memcpy(results + ((size_t)u * 2 + w) * 4, vals[(size_t)u * cl.L + cl.XROW + w].z, 32);
   return 0;
 }
 }

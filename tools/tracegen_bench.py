@@ -43,25 +43,25 @@ def main():
     # the batched EdDSA table of the outer job: 97 signature equations per 2^20 rows
     from vectorx_amd import eddsa_air as ea
     from vectorx_amd import stark_chips
-    lay = ea.Layout()
-    for log_n in (17, 20):
+    for full, log_n in ((False, 17), (False, 20), (True, 20)):
+        lay = ea.Layout(full=full)
         cap = ea.capacity(lay, log_n)
-        sigs, rs = stark_chips.eddsa_signatures(cap, 8)
+        sigs, rs = (stark_chips.eddsa_signatures_full if full else stark_chips.eddsa_signatures)(cap, 8)
         nbytes = lay.N * (1 << log_n) * 8
         d = ctx.alloc(nbytes)
-        assert ctx.trace_eddsa_table(log_n, lay.NB, sigs, d) == rs
+        assert ctx.trace_eddsa_table(log_n, lay.NB, sigs, d, full=full) == rs
         steps = 5
         ctx.prof_enable(True)
         ctx.prof_reset()
         t0 = time.perf_counter()
         for _ in range(steps):
-            ctx.trace_eddsa_table(log_n, lay.NB, sigs, d)
+            ctx.trace_eddsa_table(log_n, lay.NB, sigs, d, full=full)
         ctx.sync()
         wall = (time.perf_counter() - t0) / steps * 1e3
         ev = ctx.prof()["trace_generation"]["ms"] / steps
         ctx.prof_enable(False)
         ctx.free(d)
-        print(json.dumps({"table": "eddsa", "rows_log2": log_n, "what": f"{cap} signature equations", "trace_MB": round(nbytes / 1e6, 1),
+        print(json.dumps({"table": "eddsa full" if full else "eddsa", "rows_log2": log_n, "what": f"{cap} signature equations", "trace_MB": round(nbytes / 1e6, 1),
                           "wall_ms": round(wall, 3), "device_ms": round(ev, 3), "write_GBps_device": round(nbytes / (ev * 1e-3) / 1e9, 1)}), flush=True)
     ctx.close()
 

@@ -116,7 +116,7 @@ _SIGNATURES = {
     "vx_trace_sha256": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "vx_trace_sha512": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "vx_trace_blake2b": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
-    "vx_trace_eddsa": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp]),
+    "vx_trace_eddsa": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp]),
     "vx_stark_aux_precompile": (_i, [_vp]),
     "vx_stark_precompile": (_i, [_vp, ctypes.POINTER(_i)]),
     "vx_circuit_precompile": (_i, [_vp, ctypes.POINTER(_i)]),
@@ -260,15 +260,19 @@ class Context:
                                                  pis.ctypes.data, dig.ctypes.data))
         return pis, [dig[dlen * i:dlen * (i + 1)].tobytes() for i in range(len(messages))]
 
-    def trace_eddsa_table(self, degree_bits: int, scalar_bits: int, sigs, d_trace: int):
-        """Fill the batched EdDSA table (eddsa_air.Layout(16, scalar_bits)) for sigs = [((ax, ay), S, h)] into device memory d_trace
-        -> [(x, y)] per signature = the affine [S]B - [h]A the instance arrives at (Python integers)."""
-        arr = np.zeros((max(1, len(sigs)), 4, 4), dtype=np.uint64)
-        for i, ((ax, ay), s_, h_) in enumerate(sigs):
-            for k, v in enumerate((ax, ay, s_, h_)):
-                arr[i, k] = [(int(v) >> (64 * w)) & 0xFFFFFFFFFFFFFFFF for w in range(4)]
+    def trace_eddsa_table(self, degree_bits: int, scalar_bits: int, sigs, d_trace: int, full: bool = False):
+        """Fill the batched EdDSA table (eddsa_air.Layout(16, scalar_bits, full)) for sigs = [((ax, ay), S, h)] — full: [((ax, ay), S, h,
+        digest)] — into device memory d_trace -> [(x, y)] per signature = the affine [S]B - [h]A the instance arrives at (Python integers)."""
+        stride = 6 if full else 4
+        arr = np.zeros((max(1, len(sigs)), stride, 4), dtype=np.uint64)
+        words = lambda v: [(int(v) >> (64 * w)) & 0xFFFFFFFFFFFFFFFF for w in range(4)]      # noqa: E731
+        for i, sg in enumerate(sigs):
+            (ax, ay), s_, h_ = sg[0], sg[1], sg[2]
+            arr[i, 0], arr[i, 1], arr[i, 2], arr[i, 3] = words(ax), words(ay), words(s_), words(h_)
+            if full:
+                arr[i, 4], arr[i, 5] = words(sg[3]), words(int(sg[3]) >> 256)
         res = np.zeros((max(1, len(sigs)), 2, 4), dtype=np.uint64)
-        _chk(lib().vx_trace_eddsa(self._h, degree_bits, scalar_bits, arr.ctypes.data, len(sigs), _vp(d_trace), res.ctypes.data))
+        _chk(lib().vx_trace_eddsa(self._h, degree_bits, scalar_bits, 1 if full else 0, arr.ctypes.data, len(sigs), _vp(d_trace), res.ctypes.data))
         val = lambda w: sum(int(w[k]) << (64 * k) for k in range(4))      # noqa: E731
         return [(val(res[i, 0]), val(res[i, 1])) for i in range(len(sigs))]
 

@@ -208,20 +208,20 @@ int vx_trace_blake2b(vx_ctx* c, int degree_bits, const uint8_t* msgs, const uint
 
 
 // ---- the batched EdDSA table -------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void tg_ed_simulate_kernel(const tg::ed::Sig* __restrict__ sigs, int nsig, tg::ed::Sig filler, int ninst, int NB,
+__global__ __launch_bounds__(64) void tg_ed_simulate_kernel(tg::ed::Cols c, const tg::ed::Sig* __restrict__ sigs, int nsig, tg::ed::Sig filler, int ninst,
                                                             tg::ed::RowVals* __restrict__ vals, int* __restrict__ bad) {
   __shared__ uint64_t regs[64][tg::ed::NREG][4];
   const int u = blockIdx.x * 64 + threadIdx.x;
   if (u >= ninst) return;
-  const int L = tg::ed::NP + tg::ed::NLOOP * NB + tg::ed::NE;
-  if (tg::ed::simulate_instance(u < nsig ? sigs[u] : filler, NB, vals + (size_t)u * L, regs[threadIdx.x]) && u < nsig) atomicExch(bad, u + 1);
+  const int why = tg::ed::simulate_instance(c, u < nsig ? sigs[u] : filler, vals + (size_t)u * c.L, regs[threadIdx.x]);
+  if (why && u < nsig) atomicExch(bad, (why << 24) | (u + 1));
 }
-// results[u][w] = z of row L - 2 + w of instance u (the affine x, y the instance arrives at)
-__global__ void tg_ed_results_kernel(const tg::ed::RowVals* __restrict__ vals, int nsig, int L, u64* __restrict__ results) {
+// results[u][w] = z of rows XROW / YROW of instance u (the affine x, y the instance arrives at)
+__global__ void tg_ed_results_kernel(const tg::ed::RowVals* __restrict__ vals, int nsig, int L, int xrow, u64* __restrict__ results) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nsig * 8) return;
   const int u = i >> 3, w = (i >> 2) & 1, k = i & 3;
-  results[i] = vals[(size_t)u * L + L - 2 + w].z[k];
+  results[i] = vals[(size_t)u * L + xrow + w].z[k];
 }
 __global__ __launch_bounds__(TG_THREADS) void tg_ed_rows_kernel(tg::ed::Cols c, const tg::ed::RegSrc* __restrict__ rsrc, const tg::ed::RowVals* __restrict__ vals,
                                                                 const tg::ed::Sig* __restrict__ sigs, int nsig, tg::ed::Sig filler,
@@ -235,60 +235,75 @@ __global__ __launch_bounds__(TG_THREADS) void tg_ed_rows_kernel(tg::ed::Cols c, 
               [&](unsigned limb) { tg_hist_add(my_hist, limb, count); });
 }
 
-int vx_trace_eddsa(vx_ctx* c, int degree_bits, int scalar_bits, const uint64_t* sigs, int num_sigs, void* trace_dev, uint64_t* results_out) {
+int vx_trace_eddsa(vx_ctx* c, int degree_bits, int scalar_bits, int full, const uint64_t* sigs, int num_sigs, void* trace_dev, uint64_t* results_out) {
   if (!c || !trace_dev || (num_sigs && !sigs)) return vx_fail(VX_E_INVALID, "vx_trace_eddsa: NULL argument");
   if (scalar_bits < 32 || scalar_bits > 256 || scalar_bits % 32) return vx_fail(VX_E_INVALID, "vx_trace_eddsa: scalar_bits must be a multiple of 32 in [32, 256]");
-  const tg::ed::Cols cl = tg::ed::cols(scalar_bits);
+  if (full && scalar_bits != 256) return vx_fail(VX_E_INVALID, "vx_trace_eddsa: the full program reduces a SHA-512 digest mod L: scalar_bits must be 256");
+  const tg::ed::Cols cl = tg::ed::cols(scalar_bits, full ? 1 : 0);
   if (degree_bits <= tg::ed::LB || degree_bits > 26) return vx_fail(VX_E_INVALID, "vx_trace_eddsa: the 16-bit limb table needs more than 2^16 rows");
   const size_t n = (size_t)1 << degree_bits;
   const size_t cap = (n - 1) / cl.L;
   if (num_sigs < 0 || (size_t)num_sigs > cap) return vx_fail(VX_E_INVALID, "vx_trace_eddsa: 2^%d rows hold %zu instances, %d given", degree_bits, cap, num_sigs);
-  for (int i = 0; i < num_sigs; ++i)
-    for (int s = 2; s < 4; ++s)
-      for (int w = 0; w < 4; ++w)
-        if (64 * w >= scalar_bits && sigs[(size_t)i * 16 + 4 * s + w]) return vx_fail(VX_E_INVALID, "vx_trace_eddsa: a scalar of signature %d exceeds %d bits", i, scalar_bits);
+  const int stride = full ? 24 : 16;                       // words per signature: A.x, A.y, S, h [, digest low half, digest high half]
+  std::vector<tg::ed::Sig> host((size_t)(num_sigs ? num_sigs : 1));
+  memset(host.data(), 0, host.size() * sizeof(tg::ed::Sig));
+  for (int i = 0; i < num_sigs; ++i) {
+    const uint64_t* w = sigs + (size_t)i * stride;
+    memcpy(host[i].ax, w, 32), memcpy(host[i].ay, w + 4, 32), memcpy(host[i].s, w + 8, 32), memcpy(host[i].h, w + 12, 32);
+    if (full) memcpy(host[i].d, w + 16, 64);
+    for (int k = 0; k < 4; ++k)
+      if (64 * k >= scalar_bits && (host[i].h[k] || (!full && host[i].s[k])))
+        return vx_fail(VX_E_INVALID, "vx_trace_eddsa: a scalar of signature %d exceeds %d bits", i, scalar_bits);
+  }
   HIPCHK(hipSetDevice(c->device));
   const int ninst = (int)((n + cl.L - 1) / cl.L);
   tg::ed::Sig filler;
   memset(&filler, 0, sizeof filler);
   for (int k = 0; k < 4; ++k) filler.ax[k] = tg::ed::BX[k], filler.ay[k] = tg::ed::BY[k];
   void *d_sigs = nullptr, *d_vals = nullptr, *d_hist = nullptr, *d_bad = nullptr, *d_rsrc = nullptr, *d_res = nullptr;
-  const size_t sb = (size_t)(num_sigs ? num_sigs : 1) * sizeof(tg::ed::Sig), vb = (size_t)ninst * cl.L * sizeof(tg::ed::RowVals),
-               hb = (size_t)TG_HIST_COPIES * 65536 * sizeof(unsigned), rb = (size_t)(num_sigs ? num_sigs : 1) * 64;
+  const size_t sb = host.size() * sizeof(tg::ed::Sig), vb = (size_t)ninst * cl.L * sizeof(tg::ed::RowVals),
+               hb = (size_t)TG_HIST_COPIES * 65536 * sizeof(unsigned), rb = host.size() * 64;
   if (c->pool_alloc(&d_sigs, sb) != hipSuccess || c->pool_alloc(&d_vals, vb) != hipSuccess || c->pool_alloc(&d_hist, hb) != hipSuccess ||
       c->pool_alloc(&d_bad, 256) != hipSuccess || c->pool_alloc(&d_rsrc, sizeof(tg::ed::RegSrc)) != hipSuccess || c->pool_alloc(&d_res, rb) != hipSuccess) {
     c->pool_free(d_sigs), c->pool_free(d_vals), c->pool_free(d_hist), c->pool_free(d_bad), c->pool_free(d_rsrc), c->pool_free(d_res);
     return vx_fail(VX_E_NOMEM, "vx_trace_eddsa: out of device memory");
   }
   tg::ed::RegSrc rsrc;
-  tg::ed::make_reg_src(scalar_bits, rsrc);
+  memset(&rsrc, 0, sizeof rsrc);
+  tg::ed::make_reg_src(cl, rsrc);
   int rc = VX_OK, bad = 0;
   {
     ProfScope ps(c, "trace_generation", 8.0 * cl.N * n);
-    hipError_t e = hipSuccess;
-    if (num_sigs) e = hipMemcpyAsync(d_sigs, sigs, (size_t)num_sigs * sizeof(tg::ed::Sig), hipMemcpyHostToDevice, c->stream);
+    hipError_t e = hipMemcpyAsync(d_sigs, host.data(), sb, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(d_hist, 0, hb, c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(d_bad, 0, 256, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_rsrc, &rsrc, sizeof rsrc, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) {
-      hipLaunchKernelGGL(tg_ed_simulate_kernel, dim3((ninst + 63) / 64), dim3(64), 0, c->stream, (const tg::ed::Sig*)d_sigs, num_sigs, filler, ninst,
-                         scalar_bits, (tg::ed::RowVals*)d_vals, (int*)d_bad);
+      hipLaunchKernelGGL(tg_ed_simulate_kernel, dim3((ninst + 63) / 64), dim3(64), 0, c->stream, cl, (const tg::ed::Sig*)d_sigs, num_sigs, filler, ninst,
+                         (tg::ed::RowVals*)d_vals, (int*)d_bad);
       hipLaunchKernelGGL(tg_ed_rows_kernel, dim3((unsigned)((n + TG_THREADS - 1) / TG_THREADS)), dim3(TG_THREADS), 0, c->stream, cl,
-                         (const tg::ed::RegSrc*)d_rsrc, (const tg::ed::RowVals*)d_vals, (const tg::ed::Sig*)d_sigs, num_sigs, filler, (u64*)trace_dev, n, (unsigned*)d_hist);
+                         (const tg::ed::RegSrc*)d_rsrc, (const tg::ed::RowVals*)d_vals, (const tg::ed::Sig*)d_sigs, num_sigs, filler, (u64*)trace_dev, n,
+                         (unsigned*)d_hist);
       hipLaunchKernelGGL(tg_patch_mult_kernel, dim3(65536 / 256), dim3(256), 0, c->stream, (u64*)trace_dev + (size_t)cl.MULT * n, (const unsigned*)d_hist,
                          65536u, TG_HIST_COPIES, (size_t)65536);
       e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(&bad, d_bad, sizeof bad, hipMemcpyDeviceToHost, c->stream);
-    // the results: affine (x, y) of [S]B - [h]A = z of the last two rows of every given instance, gathered on the device, one copy
+    // the results: affine (x, y) every given instance arrives at, gathered on the device, one copy
     if (e == hipSuccess && results_out && num_sigs) {
-      hipLaunchKernelGGL(tg_ed_results_kernel, dim3((num_sigs * 8 + 255) / 256), dim3(256), 0, c->stream, (const tg::ed::RowVals*)d_vals, num_sigs, cl.L, (u64*)d_res);
+      hipLaunchKernelGGL(tg_ed_results_kernel, dim3((num_sigs * 8 + 255) / 256), dim3(256), 0, c->stream, (const tg::ed::RowVals*)d_vals, num_sigs, cl.L, cl.XROW,
+                         (u64*)d_res);
       e = hipMemcpyAsync(results_out, d_res, (size_t)num_sigs * 64, hipMemcpyDeviceToHost, c->stream);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) rc = vx_fail(VX_E_HIP, "vx_trace_eddsa: %s", hipGetErrorString(e));
   }
   c->pool_free(d_sigs), c->pool_free(d_vals), c->pool_free(d_hist), c->pool_free(d_bad), c->pool_free(d_rsrc), c->pool_free(d_res);
-  if (rc == VX_OK && bad) rc = vx_fail(VX_E_INVALID, "vx_trace_eddsa: instance %d: a row that must produce 1 does not (A not on the curve, or Z = 0)", bad - 1);
+  if (rc == VX_OK && bad) {
+    const int why = bad >> 24, who = (bad & 0xFFFFFF) - 1;
+    rc = why == 1 ? vx_fail(VX_E_INVALID, "vx_trace_eddsa: instance %d: a row that must produce 1 does not (A not on the curve, or Z = 0)", who)
+       : why == 2 ? vx_fail(VX_E_INVALID, "vx_trace_eddsa: instance %d: a value that must be canonical is not (a coordinate >= p, or S / the reduced digest >= L)", who)
+                  : vx_fail(VX_E_INVALID, "vx_trace_eddsa: instance %d: an integer identity of the full program does not hold", who);
+  }
   return rc;
 }

@@ -17,21 +17,29 @@ namespace ed {
 
 constexpr int NL = 16, LB = 16, NC = 2 * NL - 2;
 // column map of eddsa_air.Layout(limb_bits = 16, scalar_bits = NB)
+// `full` = the FULL program (eddsa_air.Layout(full=True): decompression, digest mod L, S < L inside the instance): longer prologue and
+// epilogue, 32 word columns for the statement (A's encoding, the digest, R's encoding)
 struct Cols {
-  int NB, NW, L, RT, REG, X, Y, Z, Q, W, NLOOK, BIT, KACC, BND, FIN, POS, J, SW, ACT, TBL, MULT, N;
+  int full, NP, NE, NT;      // the program: prologue rows, epilogue rows, row types
+  int NB, NW, L, RT, REG, X, Y, Z, Q, W, NLOOK, BIT, KACC, BND, FIN, POS, J, SW, ACT, AENC, DW, RENC, TBL, MULT, N, XROW, YROW;
 };
-TG_HD Cols cols(int NB) {
+TG_HD Cols cols(int NB, int full = 0) {
   Cols c;
-  c.NB = NB, c.NW = NB / 32, c.L = NP + NLOOP * NB + NE;
-  c.RT = 0, c.REG = c.RT + NT, c.X = c.REG + NL * NREG, c.Y = c.X + NL, c.Z = c.Y + NL, c.Q = c.Z + NL, c.W = c.Q + NL;
+  c.full = full, c.NP = full ? NP_FULL : NP, c.NE = full ? NE_FULL : NE, c.NT = full ? NT_FULL : NT;
+  c.NB = NB, c.NW = NB / 32, c.L = c.NP + NLOOP * NB + c.NE;
+  c.RT = 0, c.REG = c.RT + c.NT, c.X = c.REG + NL * NREG, c.Y = c.X + NL, c.Z = c.Y + NL, c.Q = c.Z + NL, c.W = c.Q + NL;
   c.NLOOK = 2 * NL + 2 * NC;
   c.BIT = c.W + 2 * NC, c.KACC = c.BIT + 2, c.BND = c.KACC + 2, c.FIN = c.BND + 1, c.POS = c.FIN + 1, c.J = c.POS + 32, c.SW = c.J + c.NW;
-  c.ACT = c.SW + 2 * c.NW, c.TBL = c.ACT + 1, c.MULT = c.TBL + 1, c.N = c.MULT + 1;
+  c.ACT = c.SW + 2 * c.NW, c.AENC = c.ACT + 1, c.DW = c.AENC + 8, c.RENC = c.DW + 16;
+  c.TBL = full ? c.RENC + 8 : c.ACT + 1, c.MULT = c.TBL + 1, c.N = c.MULT + 1;
+  c.XROW = c.L - c.NE + 2, c.YROW = c.L - c.NE + 3;
   return c;
 }
+TG_HD const Op& op_at(const Cols& c, int t) { return c.full ? OPS_FULL[t] : OPS[t]; }
 
 struct Sig {
   uint64_t ax[4], ay[4], s[4], h[4];   // the public key (affine) and the two scalars, little-endian 64-bit words
+  uint64_t d[8];                       // full program: the SHA-512 digest of R || A || M as a little-endian integer
 };
 struct RowVals {
   uint64_t x[4], y[4], z[4], q[4];
@@ -111,6 +119,51 @@ TG_HD void mul_add_divmod(const uint64_t* x, const uint64_t* y, const uint64_t* 
     }
   }
 }
+// the same for the modulus L (the group order), for the FULL program's two reduction rows: plain shift-and-subtract long division of the
+// 512-bit x y + e — two rows per instance, speed is irrelevant
+TG_HD void mul_add_divmod_l(const uint64_t* x, const uint64_t* y, const uint64_t* e, uint64_t* z, uint64_t* quo) {
+  uint64_t v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < 4; ++i) {
+    uint64_t carry = 0;
+    for (int j = 0; j < 4; ++j) {
+      const u128 t = (u128)x[i] * y[j] + v[i + j] + carry;
+      v[i + j] = (uint64_t)t;
+      carry = (uint64_t)(t >> 64);
+    }
+    v[i + 4] = carry;
+  }
+  uint64_t carry = 0;
+  for (int k = 0; k < 8; ++k) {
+    const u128 t = (u128)v[k] + (k < 4 ? e[k] : 0) + carry;
+    v[k] = (uint64_t)t;
+    carry = (uint64_t)(t >> 64);
+  }
+  uint64_t r[5] = {0, 0, 0, 0, 0}, q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int bit = 511; bit >= 0; --bit) {
+    for (int k = 4; k > 0; --k) r[k] = (r[k] << 1) | (r[k - 1] >> 63);       // r = 2 r + bit  (r < L < 2^253 before: no overflow of 5 words)
+    r[0] = (r[0] << 1) | ((v[bit >> 6] >> (bit & 63)) & 1);
+    bool ge = r[4] != 0;
+    if (!ge) {
+      ge = true;
+      for (int k = 3; k >= 0; --k)
+        if (r[k] != ELL[k]) {
+          ge = r[k] > ELL[k];
+          break;
+        }
+    }
+    if (ge) {
+      uint64_t borrow = 0;
+      for (int k = 0; k < 5; ++k) {
+        const uint64_t sub = (k < 4 ? ELL[k] : 0);
+        const uint64_t t1 = r[k] - sub, t2 = t1 - borrow;
+        borrow = (r[k] < sub) | (t1 < borrow);
+        r[k] = t2;
+      }
+      q[bit >> 6] |= (uint64_t)1 << (bit & 63);
+    }
+  }
+  for (int k = 0; k < 4; ++k) z[k] = r[k], quo[k] = q[k];     // the quotient fits 256 bits for the operands the program feeds (x y < 2^384)
+}
 TG_HD void mulmod(const uint64_t* x, const uint64_t* y, uint64_t* z) {
   const uint64_t zero[4] = {0, 0, 0, 0};
   uint64_t q[4], t[4];
@@ -131,29 +184,49 @@ TG_HD int scalar_bit(const uint64_t* v, int NB, int step) {   // bit of step `st
   const int b = NB - 1 - step;
   return (int)((v[b >> 6] >> (b & 63)) & 1);
 }
-TG_HD int row_type(int rho, int NB) {
-  if (rho < NP) return rho;
-  if (rho < NP + NLOOP * NB) return NP + (rho - NP) % NLOOP;
-  return NP + NLOOP + (rho - NP - NLOOP * NB);
+TG_HD int row_type(int rho, int NB, int np = NP) {
+  if (rho < np) return rho;
+  if (rho < np + NLOOP * NB) return np + (rho - np) % NLOOP;
+  return np + NLOOP + (rho - np - NLOOP * NB);
 }
 
-// phase 1: one instance.  out[rho], rho < L.  Returns 0, or 1 when a row that must produce 1 does not (A not on the curve, Z = 0).
+// phase 1: one instance.  out[rho], rho < L.  Returns 0, or 1 when a row that must produce 1 does not (A not on the curve, Z = 0), 2 when
+// a value that must be canonical is not (full program: a coordinate >= p, S or the reduced digest >= L), 3 when an integer identity of
+// the full program does not hold (cannot happen for honest inputs).
 // `regs` = the instance's register file, NREG x 4 words (the device keeps it in LDS: indexed by the row's op, it would otherwise live in
 // scratch memory, whose latency every one of the 10 772 dependent rows would pay several times)
-TG_HD int simulate_instance(const Sig& sg, int NB, RowVals* out, uint64_t (*regs)[4]) {
+TG_HD int simulate_instance(const Cols& c, const Sig& sg, RowVals* out, uint64_t (*regs)[4]) {
   for (int r = 0; r < NREG; ++r)
     for (int k = 0; k < 4; ++k) regs[r][k] = 0;
-  const int L = NP + NLOOP * NB + NE;
+  const int NB = c.NB, L = c.L;
   int bad = 0;
   for (int rho = 0; rho < L; ++rho) {
-    const Op& op = OPS[row_type(rho, NB)];
-    const int step = rho < NP ? 0 : (rho - NP) / NLOOP;
+    const Op& op = op_at(c, row_type(rho, NB, c.NP));
+    const int step = rho < c.NP ? 0 : (rho - c.NP) / NLOOP;
     RowVals& rv = out[rho];
-    uint64_t x[4] = {0, 0, 0, 0}, y[4] = {0, 0, 0, 0}, e[4] = {0, 0, 0, 0}, z[4], q[4] = {0, 0, 0, 0};
+    uint64_t x[4] = {0, 0, 0, 0}, y[4] = {0, 0, 0, 0}, e[4] = {0, 0, 0, 0}, z[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
     if (op.free_) {
-      if (op.dst == AX) for (int k = 0; k < 4; ++k) z[k] = sg.ax[k];
-      else if (op.dst == AY) for (int k = 0; k < 4; ++k) z[k] = sg.ay[k];
-      else inverse(regs[Z1], z);
+      switch (op.wit) {
+        case 0: for (int k = 0; k < 4; ++k) z[k] = sg.ax[k]; break;
+        case 1: for (int k = 0; k < 4; ++k) z[k] = sg.ay[k]; break;
+        case 2: inverse(regs[op.witreg], z); break;
+        case 3: {                                       // bound - 1 - value
+          uint64_t borrow = 1;                          // start from "- 1"
+          for (int k = 0; k < 4; ++k) {
+            const uint64_t a = op.bound[k], b = regs[op.witreg][k];
+            const uint64_t t1 = a - b, t2 = t1 - borrow;
+            borrow = (a < b) | (t1 < borrow);
+            z[k] = t2;
+          }
+          if (borrow) bad = 2;
+          break;
+        }
+        case 4: for (int k = 0; k < 4; ++k) z[k] = (regs[op.witreg][k] >> 1) | (k < 3 ? regs[op.witreg][k + 1] << 63 : 0); break;
+        case 5: z[0] = regs[op.witreg][0] & 1; break;
+        case 6: for (int k = 0; k < 4; ++k) z[k] = sg.d[4 + k]; break;
+        case 7: for (int k = 0; k < 4; ++k) z[k] = sg.d[k]; break;
+        default: for (int k = 0; k < 4; ++k) z[k] = sg.s[k]; break;
+      }
     } else {
       for (int k = 0; k < 4; ++k) x[k] = regs[op.x][k];
       bool from_reg = op.ykind == 0, on = true;
@@ -161,9 +234,28 @@ TG_HD int simulate_instance(const Sig& sg, int NB, RowVals* out, uint64_t (*regs
       if (op.ykind == 3) on = scalar_bit(sg.h, NB, step) != 0, from_reg = on;
       for (int k = 0; k < 4; ++k) y[k] = from_reg ? regs[op.yreg][k] : (op.ykind == 1 || (op.ykind == 2 && on) ? op.con[k] : op.coff[k]);
       if (op.e >= 0) for (int k = 0; k < 4; ++k) e[k] = regs[op.e][k];
-      mul_add_divmod(x, y, e, z, q);
+      if (op.qzero) {                                   // an integer identity: Z is what the row requires, x y + e must BE it
+        const uint64_t* want = op.zkind == 1 ? op.zconst : regs[op.zreg];
+        // y is 1 or 2 here: x y + e in 5 words
+        uint64_t t[5] = {0, 0, 0, 0, 0}, carry = 0;
+        for (int k = 0; k < 4; ++k) {
+          const u128 w = (u128)x[k] * y[0] + e[k] + carry;
+          t[k] = (uint64_t)w;
+          carry = (uint64_t)(w >> 64);
+        }
+        t[4] = carry;
+        if (y[1] | y[2] | y[3] | t[4]) bad = bad ? bad : 3;
+        for (int k = 0; k < 4; ++k) {
+          if (t[k] != want[k]) bad = bad ? bad : 3;
+          z[k] = want[k];
+        }
+      } else if (op.modl) {
+        mul_add_divmod_l(x, y, e, z, q);
+      } else {
+        mul_add_divmod(x, y, e, z, q);
+      }
     }
-    if (op.one && !(z[0] == 1 && z[1] == 0 && z[2] == 0 && z[3] == 0)) bad = 1;
+    if (op.one && !(z[0] == 1 && z[1] == 0 && z[2] == 0 && z[3] == 0)) bad = bad ? bad : 1;
     for (int k = 0; k < 4; ++k) regs[op.dst][k] = z[k], rv.x[k] = x[k], rv.y[k] = y[k], rv.z[k] = z[k], rv.q[k] = q[k];
   }
   return bad;
@@ -175,11 +267,11 @@ TG_HD int last_writer_in(const Op* ops, int count, int before, int r) {   // hig
     if (ops[t].dst == r) return t;
   return -1;
 }
-TG_HD int reg_source(int rho, int r, int NB) {
-  const int L = NP + NLOOP * NB + NE;
-  const Op* PRO = OPS;
-  const Op* LOOP = OPS + NP;
-  const Op* EPI = OPS + NP + NLOOP;
+TG_HD int reg_source(const Cols& c, int rho, int r) {
+  const int NB = c.NB, NP = c.NP, NE = c.NE, L = c.L;      // (shadow the base program's constants)
+  const Op* PRO = c.full ? OPS_FULL : OPS;
+  const Op* LOOP = PRO + NP;
+  const Op* EPI = PRO + NP + NLOOP;
   if (rho >= NP + NLOOP * NB) {                         // epilogue
     const int t = last_writer_in(EPI, NE, rho - NP - NLOOP * NB, r);
     if (t >= 0) return NP + NLOOP * NB + t;
@@ -213,34 +305,34 @@ TG_HD int reg_source(int rho, int r, int NB) {
 }
 // The same as a table: class of the row (prologue row | loop row of step 0 | loop row of a later step | epilogue row) x register ->
 // {kind, value}: kind 0: the row `value` rows above; kind 1: row `value` of this instance; kind 2: row `value` of the PREVIOUS instance.
-constexpr int NCLASS = NP + 2 * NLOOP + NE;
+constexpr int NCLASS = NP_FULL + 2 * NLOOP + NE_FULL;      // room for either program
 struct RegSrc {
   short kind[NCLASS][NREG];
   int value[NCLASS][NREG];
 };
-TG_HD int row_class(int rho, int NB) {
-  if (rho < NP) return rho;
-  if (rho < NP + NLOOP * NB) return NP + ((rho - NP) / NLOOP ? NLOOP : 0) + (rho - NP) % NLOOP;
-  return NP + 2 * NLOOP + (rho - NP - NLOOP * NB);
+TG_HD int row_class(const Cols& c, int rho) {
+  const int np = c.NP;
+  if (rho < np) return rho;
+  if (rho < np + NLOOP * c.NB) return np + ((rho - np) / NLOOP ? NLOOP : 0) + (rho - np) % NLOOP;
+  return np + 2 * NLOOP + (rho - np - NLOOP * c.NB);
 }
-inline void make_reg_src(int NB, RegSrc& t) {
-  const int L = NP + NLOOP * NB + NE;
-  for (int c = 0; c < NCLASS; ++c) {
+inline void make_reg_src(const Cols& c, RegSrc& t) {
+  const int np = c.NP, nclass = np + 2 * NLOOP + c.NE;
+  for (int cl = 0; cl < nclass; ++cl) {
     // a representative row of the class (NB >= 32: step 1 exists)
-    const int rho = c < NP ? c : (c < NP + NLOOP ? c : (c < NP + 2 * NLOOP ? c : NP + NLOOP * NB + (c - NP - 2 * NLOOP)));
+    const int rho = cl < np + 2 * NLOOP ? cl : np + NLOOP * c.NB + (cl - np - 2 * NLOOP);
     for (int r = 0; r < NREG; ++r) {
-      const int src = reg_source(rho, r, NB);
-      if (src < 0) t.kind[c][r] = 2, t.value[c][r] = src + L;
-      else if (src < NP || c < NP) t.kind[c][r] = 1, t.value[c][r] = src;
-      else t.kind[c][r] = 0, t.value[c][r] = rho - src;
+      const int src = reg_source(c, rho, r);
+      if (src < 0) t.kind[cl][r] = 2, t.value[cl][r] = src + c.L;
+      else if (src < np || cl < np) t.kind[cl][r] = 1, t.value[cl][r] = src;
+      else t.kind[cl][r] = 0, t.value[cl][r] = rho - src;
     }
   }
 }
-TG_HD long long reg_source_of(const RegSrc& t, int rho, int r, int NB) {
-  const int c = row_class(rho, NB);
-  const int v = t.value[c][r];
-  const int L = NP + NLOOP * NB + NE;
-  return t.kind[c][r] == 0 ? rho - v : (t.kind[c][r] == 1 ? v : (long long)v - L);
+TG_HD long long reg_source_of(const Cols& c, const RegSrc& t, int rho, int r) {
+  const int cl = row_class(c, rho);
+  const int v = t.value[cl][r];
+  return t.kind[cl][r] == 0 ? rho - v : (t.kind[cl][r] == 1 ? v : (long long)v - c.L);
 }
 TG_HD unsigned limb16(const uint64_t* v, int i) { return (unsigned)((v[i >> 2] >> (16 * (i & 3))) & 0xFFFF); }
 
@@ -248,17 +340,17 @@ TG_HD unsigned limb16(const uint64_t* v, int i) { return (unsigned)((v[i >> 2] >
 // sigs[inst] for inst < nsig, the filler signature (A = B, S = h = 0) above.  look(limb) once per looked-up limb (Z, Q, W columns).
 template <class Put, class Look>
 TG_HD void row(const Cols& c, const RegSrc& rsrc, const RowVals* vals, const Sig* sigs, int nsig, const Sig& filler, size_t rowi, Put put, Look look) {
-  const int L = c.L, NB = c.NB;
+  const int L = c.L, NB = c.NB, np = c.NP;
   const size_t inst = rowi / L;
   const int rho = (int)(rowi % L);
-  const int rt = row_type(rho, NB);
-  const Op& op = OPS[rt];
+  const int rt = row_type(rho, NB, np);
+  const Op& op = op_at(c, rt);
   const RowVals& rv = vals[rowi];
-  for (int t = 0; t < NT; ++t) put(c.RT + t, (uint64_t)(t == rt));
+  for (int t = 0; t < c.NT; ++t) put(c.RT + t, (uint64_t)(t == rt));
   // registers
   uint64_t ev[4] = {0, 0, 0, 0};
   for (int r = 0; r < NREG; ++r) {
-    const long long src = reg_source_of(rsrc, rho, r, NB);
+    const long long src = reg_source_of(c, rsrc, rho, r);
     uint64_t v[4] = {0, 0, 0, 0};
     if (src >= 0 || inst > 0) {
       const RowVals& s = vals[(size_t)((long long)(inst * L) + src)];
@@ -268,7 +360,7 @@ TG_HD void row(const Cols& c, const RegSrc& rsrc, const RowVals* vals, const Sig
     if (!op.free_ && op.e == r)
       for (int k = 0; k < 4; ++k) ev[k] = v[k];
   }
-  // X Y Z Q limbs and the carries of  X(t) Y(t) + E(t) - Z(t) - Q(t) P(t) = (t - 2^16) W(t)
+  // X Y Z Q limbs and the carries of  X(t) Y(t) + E(t) - Z(t) - Q(t) P(t) = (t - 2^16) W(t);  P = p, or L on the full program's reduction rows
   long long d[2 * NL - 1];
   for (int k = 0; k < 2 * NL - 1; ++k) d[k] = 0;
   unsigned xl[NL], yl[NL], zl[NL], ql[NL];
@@ -281,7 +373,7 @@ TG_HD void row(const Cols& c, const RegSrc& rsrc, const RowVals* vals, const Sig
   if (!op.free_) {
     for (int i = 0; i < NL; ++i)
       for (int j = 0; j < NL; ++j) {
-        const long long pj = j == 0 ? 0xFFED : (j == NL - 1 ? 0x7FFF : 0xFFFF);
+        const long long pj = op.modl ? (long long)limb16(ELL, j) : (j == 0 ? 0xFFED : (j == NL - 1 ? 0x7FFF : 0xFFFF));
         d[i + j] += (long long)xl[i] * yl[j] - (long long)ql[i] * pj;
       }
     for (int i = 0; i < NL; ++i) d[i] += (long long)limb16(ev, i) - (long long)zl[i];
@@ -292,16 +384,15 @@ TG_HD void row(const Cols& c, const RegSrc& rsrc, const RowVals* vals, const Sig
     prev = t >> LB;                                      // exact: the low 16 bits of t are zero when the relation holds
     if (k <= 2 * NL - 3) {
       const long long off = prev + (1ll << (2 * LB - 1));
-      const unsigned w0 = (unsigned)(off & 0xFFFF), w1 = (unsigned)(off >> LB);
+      const unsigned w0 = (unsigned)(off & 0xFFFF), w1 = (unsigned)((off >> LB) & 0xFFFF);
       put(c.W + 2 * k, (uint64_t)w0), put(c.W + 2 * k + 1, (uint64_t)w1);
       look(w0), look(w1);
     }
   }
   // scalar bookkeeping
-  const int in_loop_or_after = rho >= NP;
-  int step = in_loop_or_after ? (rho - NP) / NLOOP : 0;
+  int step = rho >= np ? (rho - np) / NLOOP : 0;
   if (step > NB - 1) step = NB - 1;
-  const bool after = rho >= NP + NLOOP * NB;
+  const bool after = rho >= np + NLOOP * NB;
   const Sig& me = (int)inst < nsig ? sigs[inst] : filler;
   const Sig& before = inst > 0 ? ((int)(inst - 1) < nsig ? sigs[inst - 1] : filler) : me;
   for (int s = 0; s < 2; ++s) {
@@ -309,13 +400,13 @@ TG_HD void row(const Cols& c, const RegSrc& rsrc, const RowVals* vals, const Sig
     const uint64_t* theirs = s ? before.h : before.s;
     const uint64_t cur = (uint64_t)scalar_bit(mine, NB, step);
     const uint64_t prev_last = inst > 0 ? (uint64_t)scalar_bit(theirs, NB, NB - 1) : (uint64_t)scalar_bit(mine, NB, 0);
-    put(c.BIT + s, rho < NP ? prev_last : cur);
+    put(c.BIT + s, rho < np ? prev_last : cur);
     // the scalar's 32-bit words, most significant first; kacc = the bits of the current word so far
     const int wj = step / 32, hi_bit = NB - 32 * wj;      // word j covers bits [hi_bit - 32, hi_bit)
     const int lo_bit = hi_bit - 32;
     const uint64_t word = (mine[lo_bit >> 6] >> (lo_bit & 63)) & 0xFFFFFFFFull;
     const uint64_t kacc = word >> (31 - step % 32);
-    put(c.KACC + s, rho < NP ? prev_last : (after ? cur : kacc));
+    put(c.KACC + s, rho < np ? prev_last : (after ? cur : kacc));
     for (int j = 0; j < c.NW; ++j) {
       const int lb = NB - 32 * (j + 1);
       put(c.SW + s * c.NW + j, (mine[lb >> 6] >> (lb & 63)) & 0xFFFFFFFFull);
@@ -324,11 +415,23 @@ TG_HD void row(const Cols& c, const RegSrc& rsrc, const RowVals* vals, const Sig
   const int pos = after ? 0 : step % 32, word = after ? 0 : step / 32;
   for (int i = 0; i < 32; ++i) put(c.POS + i, (uint64_t)(i == pos));
   for (int j = 0; j < c.NW; ++j) put(c.J + j, (uint64_t)(j == word));
-  const bool adv = rt == NP + NLOOP - 1;
+  const bool adv = rt == np + NLOOP - 1;
   const bool bnd = adv && step % 32 == 31;
   put(c.BND, (uint64_t)bnd);
   put(c.FIN, (uint64_t)(bnd && step / 32 == c.NW - 1));
   put(c.ACT, (uint64_t)((int)inst < nsig));
+  if (c.full) {
+    // the statement's 32-bit words, least significant first, constant over the instance: A's encoding (y, the parity of x as bit 255),
+    // the digest, the encoding of the point the instance arrives at
+    const uint64_t* rx = vals[inst * L + c.XROW].z;
+    const uint64_t* ry = vals[inst * L + c.YROW].z;
+    for (int j = 0; j < 8; ++j) {
+      uint64_t a = (me.ay[j >> 1] >> (32 * (j & 1))) & 0xFFFFFFFFull, r = (ry[j >> 1] >> (32 * (j & 1))) & 0xFFFFFFFFull;
+      if (j == 7) a |= (me.ax[0] & 1) << 31, r |= (rx[0] & 1) << 31;
+      put(c.AENC + j, a), put(c.RENC + j, r);
+    }
+    for (int j = 0; j < 16; ++j) put(c.DW + j, (me.d[j >> 1] >> (32 * (j & 1))) & 0xFFFFFFFFull);
+  }
   put(c.TBL, (uint64_t)(rowi & 0xFFFF));
   put(c.MULT, (uint64_t)0);
 }

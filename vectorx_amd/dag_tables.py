@@ -109,7 +109,8 @@ def build_per_job(ctx, lanes, kinds=("map", "reduce", "outer"), small=False, edd
       map    : BLAKE2b over its 8 headers (280 blocks each: 2240 compressions, 2^16 rows) + SHA-256 over its 14 tree nodes (2^11 rows);
       reduce : SHA-256 over the 2 nodes that merge its children's commitments (2^9 rows);
       outer  : SHA-256 over the authority set (300 keys: 600 compressions, 2^16 rows), SHA-512 over the 300 signed messages (2^16
-               rows), the 300 signature equations in 4 batched EdDSA tables of 2^20 rows (97 instances each).
+               rows), the 300 signatures — from their bytes: decompression, digest mod L, S < L inside the table (the FULL program of eddsa_air.py) —
+               in 4 batched EdDSA tables of 2^20 rows (97 instances each).
     -> ({kind: [(label, table)]}, [tables to free], setup record)"""
     from . import blake2b_bytes_air, sha256_air, sha512_air, stark_chips
     lanes = list(lanes)
@@ -145,9 +146,11 @@ def build_per_job(ctx, lanes, kinds=("map", "reduce", "outer"), small=False, edd
         # input, not the prover's work), 8 distinct ones; a job takes them in an order of its own
         t0 = time.perf_counter()
         from . import eddsa_air
-        lay = eddsa_air.Layout()
+        # the FULL program: the instance takes the public key's and R's encodings, S and the SHA-512 digest, and decompresses, reduces
+        # mod L and range-checks inside the table (eddsa_air.Layout(full=True))
+        lay = eddsa_air.Layout(full=True)
         lg_ed = 17 if small else eddsa_log_n
-        base, base_r = stark_chips.eddsa_signatures(8 if not small else 2, 8 if not small else 2)
+        base, base_r = stark_chips.eddsa_signatures_full(8 if not small else 2, 8 if not small else 2)
         stark = eddsa_air.make_stark(lay, lg_ed)
 
         def sigs_of(job):

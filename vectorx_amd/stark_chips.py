@@ -303,7 +303,7 @@ class GeneratedEddsaTables:
         for t in range(self.tables_for(len(sigs))):
             chunk = sigs[t * self.cap:(t + 1) * self.cap]
             t0 = time.perf_counter()
-            results += c.trace_eddsa_table(self.log_n, self.lay.NB, chunk, d_trace)
+            results += c.trace_eddsa_table(self.log_n, self.lay.NB, chunk, d_trace, full=self.lay.full)
             gen += time.perf_counter() - t0
             parts.append(prove_device_trace(c, self.stark, d_trace, self.nopi, d_aux))
         self.spent[id(c)] = [("trace_generation", gen)]
@@ -331,6 +331,19 @@ def eddsa_signatures(count: int, distinct: int = 8, seed: int = 2024):
         pk, sig = ea.sign(sk, msg)
         a, s, h, r = ea.equation_inputs(pk, msg, sig)
         base.append(((a, s, h), r))
+    return [base[i % distinct][0] for i in range(count)], [base[i % distinct][1] for i in range(count)]
+
+
+def eddsa_signatures_full(count: int, distinct: int = 8, seed: int = 2024):
+    """the same signatures as the FULL program takes them (eddsa_air.Layout(full=True)): [((ax, ay), S, h, digest)] and the R every
+    instance must arrive at — keys, messages and signatures are real (RFC 8032 signing on the host)"""
+    from . import eddsa_air as ea
+    base = []
+    for i in range(distinct):
+        sk = bytes([(seed + 7 * i + j) & 255 for j in range(32)])
+        msg = b"precommit %d" % i
+        pk, sig = ea.sign(sk, msg)
+        base.append((ea.equation_inputs_full(pk, msg, sig), ea.decompress(sig[:32])))
     return [base[i % distinct][0] for i in range(count)], [base[i % distinct][1] for i in range(count)]
 
 
