@@ -440,6 +440,50 @@ def test_full_eddsa_table_verifies_signatures_from_their_bytes_and_is_byte_ident
             vx.stark_verify_bus([(stark, nopi), (sink2, nopi)], proofs2)
 
 
+def test_signatures_verify_through_tables_only_on_the_gpu(ctx, oracle):
+    """The whole signature bus on the GPU (round 5): SHA-512 table (bus variant: sends R, A, digest) + EdDSA table (full
+    program, production layout: sends A, S, digest, R) + link table (joins them on the digest, sends A, S, R) + a verifier's sink holding
+    the bytes of the RFC 8032 section 7.1 public keys and signatures.  All four proofs byte-identical to the oracle's, the bus balances; with
+    S + L in the verifier's bytes it does not."""
+    import hashlib
+
+    from test_eddsa_air import RFC8032
+    from vectorx_amd import eddsa_air as ea
+    from vectorx_amd import sha512_air as s5
+    from vectorx_amd import sig_link_air as link
+    from vectorx_amd import stark_bus
+    cfg = dict(num_query_rounds=12, pow_bits=5)
+    raw = []
+    for _, pk, msg, sig in RFC8032:
+        pk, msg, sig = bytes.fromhex(pk), bytes.fromhex(msg), bytes.fromhex(sig)
+        raw.append((pk, msg, sig, hashlib.sha512(sig[:32] + pk + msg).digest()))
+    lay = ea.Layout(16, 256, full=True)
+    nopi = np.zeros(0, dtype=np.uint64)
+    sha = s5.make_stark(9, bus=True, **cfg)
+    sha_t, sha_pis, digs = s5.generate_trace(9, [sig[:32] + pk + msg for pk, msg, sig, _ in raw], bus=True)
+    assert digs == [d for _, _, _, d in raw]
+    ed = ea.make_stark(lay, 17, **cfg)
+    ed_t, res = ea.generate_trace(lay, 17, [ea.equation_inputs_full(pk, msg, sig) for pk, msg, sig, _ in raw])
+    lk, lk_t, _ = link.make_link([link.row_of(pk, sig, dig) for pk, _, sig, dig in raw], **cfg)
+    honest = [link.verifier_tuple(pk, sig) for pk, _, sig, _ in raw]
+    sink, sink_t, _ = ea.make_sink(lay, honest, ntuple=25, **cfg)
+    tables = [(sha, sha_t, sha_pis), (ed, ed_t, nopi), (lk, lk_t, nopi), (sink, sink_t, nopi)]
+    descs = [(sha, sha_pis), (ed, nopi), (lk, nopi), (sink, nopi)]
+    proofs, shared = stark_bus.prove_tables(ctx, tables)
+    expect, shared_o = oracle_lib.stark_prove_tables(oracle, tables)
+    assert (shared == shared_o).all() and proofs == expect
+    sums = vx.stark_verify_bus(descs, proofs)
+    assert all(int(x) != 0 for x in sums[:, 0])
+    pk, _, sig, dig = raw[-1]
+    s = int.from_bytes(sig[32:], "little")
+    forged_sig = sig[:32] + (s + ea.ELL).to_bytes(32, "little")
+    sink2, sink2_t, _ = ea.make_sink(lay, honest[:-1] + [link.verifier_tuple(pk, forged_sig)], ntuple=25, **cfg)
+    lk2, lk2_t, _ = link.make_link([link.row_of(p_, s_, d_) for p_, _, s_, d_ in raw[:-1]] + [link.row_of(pk, forged_sig, dig)], **cfg)
+    proofs2, _ = stark_bus.prove_tables(ctx, tables[:2] + [(lk2, lk2_t, nopi), (sink2, sink2_t, nopi)])
+    with pytest.raises(vx.VxError, match="cancel"):
+        vx.stark_verify_bus(descs[:2] + [(lk2, nopi), (sink2, nopi)], proofs2)
+
+
 def test_batched_eddsa_interpreted_equals_compiled(ctx):
     import os
 

@@ -1,0 +1,90 @@
+"""Ed25519 signatures verified THROUGH TABLES ONLY (round 5): the SHA-512 table hashes R || A || M and sends (R, A, digest),
+the EdDSA table (full program) decompresses, reduces the digest mod L, checks S < L and the group equation and sends (A, S, digest, R),
+the link table joins the two on the digest and sends what a verifier holds — (A, S, R): the bytes of the public key and of the signature.
+RFC 8032 section 7.1 vectors; the bus balances for them and for nothing else.  CPU: constraints in Python, the four tables proven by the
+oracle, the product's host verifier (vx_stark_verify_bus) judging the bus.  GPU twin: tests/test_gpu_stark.py."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import oracle_lib
+import vectorx_amd as vx
+from test_eddsa_air import CHAL, RFC8032
+from test_sha256_air import eval_program, violations
+from vectorx_amd import eddsa_air as ea
+from vectorx_amd import sha512_air as s5
+from vectorx_amd import sig_link_air as link
+
+CFG = dict(num_query_rounds=12, pow_bits=4)
+
+
+def _raw(k=3):
+    out = []
+    for _, pk, msg, sig in RFC8032[:k]:
+        pk, msg, sig = bytes.fromhex(pk), bytes.fromhex(msg), bytes.fromhex(sig)
+        out.append((pk, msg, sig, hashlib.sha512(sig[:32] + pk + msg).digest()))
+    return out
+
+
+def test_sha512_bus_variant_sends_the_first_64_bytes_and_the_digest():
+    msgs = [sig[:32] + pk + msg for pk, msg, sig, _ in _raw()] + [b"short", bytes(range(200))]
+    t, pis, digs = s5.generate_trace(10, msgs, bus=True)
+    assert digs == [hashlib.sha512(m).digest() for m in msgs]
+    base, _, _ = s5.generate_trace(10, msgs)
+    assert (t[:s5.Cols.N] == base).all()                                   # the 1995 columns of the plain table are untouched
+    prog, npush = s5.build_program(True)
+    aux, closing = s5.aux_columns_bus(t, CHAL)
+    pub = list(pis) + [int(closing[0])]
+    assert violations(eval_program(prog, t, aux, CHAL, pub), t.shape[1]) == []
+    rows, tuples = s5.bus_tuples(t)
+    assert len(rows) == len(msgs)
+    for m, tp in zip(msgs, tuples):
+        padded = (m + b"\x80" + bytes(64))[:64]
+        assert [int(x) for x in tp] == s5.le_words(padded) + s5.le_words(hashlib.sha512(m).digest()) + [s5.TAG_SHA512]
+    C = s5.Cols
+    for col, row in [(C.LW + 3, 100), (C.LW + 15, 7), (C.FIRST, 82), (C.FIRST, 0), (C.LW, 81)]:
+        bad = t.copy()
+        bad[col, row] = (int(bad[col, row]) + 1) % s5.P
+        a, cl = s5.aux_columns_bus(bad, CHAL)
+        assert violations(eval_program(prog, bad, a, CHAL, list(pis) + [int(cl[0])]), t.shape[1]), (col, row)
+
+
+def test_link_table_constraints():
+    raw = _raw()
+    stark, t, _ = link.make_link([link.row_of(pk, sig, dig) for pk, _, sig, dig in raw], **CFG)
+    aux, closing = link.aux_columns(t, CHAL)
+    prog = link.build_program()
+    assert violations(eval_program(prog, t, aux, CHAL, [int(closing[0])]), t.shape[1]) == []
+    bad = t.copy()
+    bad[link.DW + 5, 1] ^= 1
+    assert violations(eval_program(prog, bad, aux, CHAL, [int(closing[0])]), t.shape[1])
+
+
+def test_signatures_verify_through_tables_only_and_forgeries_unbalance_the_bus(oracle):
+    raw = _raw(1)
+    lay = ea.Layout(8, 256, full=True)
+    nopi = np.zeros(0, dtype=np.uint64)
+    sha = s5.make_stark(9, bus=True, **CFG)
+    sha_t, sha_pis, digs = s5.generate_trace(9, [sig[:32] + pk + msg for pk, msg, sig, _ in raw], bus=True)
+    assert digs == [d for _, _, _, d in raw]
+    ed = ea.make_stark(lay, 14, **CFG)
+    ed_t, res = ea.generate_trace(lay, 14, [ea.equation_inputs_full(pk, msg, sig) for pk, msg, sig, _ in raw])
+    lk, lk_t, _ = link.make_link([link.row_of(pk, sig, dig) for pk, _, sig, dig in raw], **CFG)
+    honest = [link.verifier_tuple(pk, sig) for pk, _, sig, _ in raw]
+    sink, sink_t, _ = ea.make_sink(lay, honest, ntuple=25, **CFG)
+    tables = [(sha, sha_t, sha_pis), (ed, ed_t, nopi), (lk, lk_t, nopi), (sink, sink_t, nopi)]
+    proofs, _ = oracle_lib.stark_prove_tables(oracle, tables)
+    descs = [(sha, sha_pis), (ed, nopi), (lk, nopi), (sink, nopi)]
+    sums = vx.stark_verify_bus(descs, proofs)
+    assert all(int(x) != 0 for x in sums[:, 0])                           # every table sent or received something; the four sums cancel
+    # a verifier holding S + L: no row of the link table can produce its tuple from what the EdDSA table accepted (a link row with S + L
+    # would need the EdDSA table to have sent it; the honest link row leaves the verifier's tuple unmatched) — both ways the sums do not cancel
+    pk, _, sig, dig = raw[0]
+    s = int.from_bytes(sig[32:], "little")
+    forged_sig = sig[:32] + (s + ea.ELL).to_bytes(32, "little")
+    sink2, sink2_t, _ = ea.make_sink(lay, [link.verifier_tuple(pk, forged_sig)], ntuple=25, **CFG)
+    lk2, lk2_t, _ = link.make_link([link.row_of(pk, forged_sig, dig)], **CFG)
+    proofs2, _ = oracle_lib.stark_prove_tables(oracle, tables[:2] + [(lk2, lk2_t, nopi), (sink2, sink2_t, nopi)])
+    with pytest.raises(vx.VxError, match="cancel"):
+        vx.stark_verify_bus(descs[:2] + [(lk2, nopi), (sink2, nopi)], proofs2)

@@ -119,6 +119,7 @@ assert (NP_, NL_, NE_) == (16, 42, 4)
 # digest.  What a caller still owes: the digest itself (the SHA-512 table's output for R || A || M — its binding to the message bytes is a
 # bus between that table and this tuple, not built).
 TWO128 = 1 << 128
+TAG_EDDSA, TAG_SHA512, TAG_VERIFIER = 1, 2, 3       # the last element of a tuple on the signature bus: which format it is
 FULL_PROLOGUE_TAIL = [
     Op(free=True, dst=4, wit=("cmp", Q25519, AX)), Op(AX, ("c", 1), 4, 5, zconst=Q25519 - 1, qzero=True),           # A.x < p
     Op(free=True, dst=4, wit=("cmp", Q25519, AY)), Op(AY, ("c", 1), 4, 5, zconst=Q25519 - 1, qzero=True),           # A.y < p
@@ -188,7 +189,11 @@ class Layout:
         self.AUX_BUS = self.AUX_U + 1
         self.NAUX = self.NPAIR + 4
         self.W_OFFSET = 1 << (2 * limb_bits - 1)
-        self.NTUPLE = 8 + self.NW + 16 + 8 if full else 4 * self.NL + 2 * self.NW   # (A encoding, S, digest, R encoding) | (A.x, A.y, S, h, x, y)
+        # (A encoding, S, digest, R encoding, TAG) | (A.x, A.y, S, h, x, y).  The full tuple ends in a constant tag: several tuple FORMATS
+        # share its bus (the SHA-512 table's (R, A, digest), a verifier's (A, S, R): vectorx_amd/sig_link_air.py) and a tuple is a
+        # polynomial in beta — a non-zero leading coefficient that names the format keeps one format from aliasing another
+        self.NTUPLE = 8 + self.NW + 16 + 8 + 1 if full else 4 * self.NL + 2 * self.NW
+        self.TAG = TAG_EDDSA if full else None
         self.XROW, self.YROW = self.L - self.NE + 2, self.L - self.NE + 3          # the rows of an instance whose Z are the affine x, y
 
     def tuple_cols(self):
@@ -663,9 +668,13 @@ def build_program(lay: Layout):
     e.ins(VX_OP_LDCH, beta, 1)
     e.ins(VX_OP_LDCH, gbus, 2)
     srcs = C.tuple_cols()
-    assert len(srcs) == C.NTUPLE
+    assert len(srcs) + (C.TAG is not None) == C.NTUPLE
     tup = tmp()
-    e.ldw(srcs[-1], dst=tup)
+    if C.TAG is not None:                             # the format tag is the tuple's last element
+        e.ldi(tup, C.TAG)
+        srcs = srcs + [None]
+    else:
+        e.ldw(srcs[-1], dst=tup)
     for col in reversed(srcs[:-1]):                   # Horner: sum_k beta^k element_k
         m1 = e.top
         e.op(VX_OP_MUL, tup, beta, tup)
@@ -940,7 +949,10 @@ def send_tuples(lay: Layout, trace):
     rows = np.nonzero(trace[lay.RT + lay.T_ELAST, :n - 1] * trace[lay.ACT, :n - 1])[0]
     NL = lay.NL
     cols = lay.tuple_cols()
-    return rows, trace[np.array(cols)][:, rows].T
+    elems = trace[np.array(cols)][:, rows].T
+    if lay.TAG is not None:
+        elems = np.concatenate([elems, np.full((rows.size, 1), lay.TAG, dtype=np.uint64)], axis=1)
+    return rows, elems
 
 
 def tuple_of_full(lay: Layout, public_key: bytes, signature: bytes, digest: bytes):
@@ -948,7 +960,7 @@ def tuple_of_full(lay: Layout, public_key: bytes, signature: bytes, digest: byte
     like the scalar columns), the 16 words of SHA-512(R || A || M), R's 8 words — nothing decompressed, nothing reduced"""
     le = lambda b: [int.from_bytes(b[4 * j:4 * j + 4], "little") for j in range(len(b) // 4)]   # noqa: E731
     s_words = le(signature[32:])
-    return le(public_key) + s_words[::-1] + le(digest) + le(signature[:32])
+    return le(public_key) + s_words[::-1] + le(digest) + le(signature[:32]) + [TAG_EDDSA]
 
 
 def tuple_of(lay: Layout, a, s, h, r):
@@ -995,7 +1007,10 @@ def aux_columns(lay: Layout, trace, chal):
     if rows.size:
         NL = lay.NL
         cols = lay.tuple_cols()
-        tup = _horner(trace[np.array(cols)][:, rows].T, beta)
+        elems = trace[np.array(cols)][:, rows].T
+        if lay.TAG is not None:
+            elems = np.concatenate([elems, np.full((rows.size, 1), lay.TAG, dtype=np.uint64)], axis=1)
+        tup = _horner(elems, beta)
         u[rows] = hf.invmod(hf.submod(np.full(rows.size, gbus, dtype=np.uint64), tup))
     out[lay.NPAIR + 2] = u
     acc, total = hf.exclusive_prefix_sum(u)
@@ -1029,7 +1044,11 @@ def aux_program(lay: Layout):
     NL = lay.NL
     srcs = lay.tuple_cols()
     tup = e.tmp()
-    e.ldw(srcs[-1], dst=tup)
+    if lay.TAG is not None:
+        e.ldi(tup, lay.TAG)
+        srcs = srcs + [None]
+    else:
+        e.ldw(srcs[-1], dst=tup)
     for col in reversed(srcs[:-1]):
         m1 = e.top
         e.op(VX_OP_MUL, tup, BETA, tup)
@@ -1088,13 +1107,14 @@ def sink_program(ntuple: int):
     return e.w
 
 
-def make_sink(lay: Layout, tuples, degree_bits=None, **cfg):
-    """-> (Stark, trace, public inputs (none)) of a table that receives `tuples` (lists of NTUPLE elements), one per row"""
+def make_sink(lay: Layout, tuples, degree_bits=None, ntuple=None, **cfg):
+    """-> (Stark, trace, public inputs (none)) of a table that receives `tuples` (lists of NTUPLE elements — or of `ntuple` elements:
+    any format of the signature bus), one per row"""
     k = len(tuples)
     db = max(4, (k + 1).bit_length()) if degree_bits is None else degree_bits      # the last row receives nothing; 2^4 rows: room for a cap of height 4
     n = 1 << db
     assert k <= n - 1
-    nt = lay.NTUPLE
+    nt = lay.NTUPLE if ntuple is None else ntuple
     t = np.zeros((nt + 1, n), dtype=np.uint64)
     for i, tp in enumerate(tuples):
         t[:nt, i] = np.array(tp, dtype=np.uint64)

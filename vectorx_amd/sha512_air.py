@@ -65,16 +65,36 @@ class Cols:
     N = 1995
     AUX_H, AUX_HT, AUX_ACC = 1995, 1998, 1999        # three pair helpers, the table helper, the running sum
     NAUX = 5
+    # bus variant (round 5: the digest of R || A || M travels to the EdDSA table — vectorx_amd/sig_link_air.py): 17 more trace columns
+    LW = 1995                  # the first 64 bytes of the CURRENT message as 16 little-endian 32-bit words (an Ed25519 R, then A), latched
+    FIRST = 2011               # 1 on the rows of a message's first block
+    N_BUS = 2012
+    NAUX_BUS = 7               # + the bus helper and the bus sum
 
 
 def _rotr(x, r):
     return ((x >> r) | (x << (64 - r))) & M64
 
 
-def build_program():
-    """-> (program words, number of constraints)"""
+TAG_SHA512 = 2                 # eddsa_air.TAG_SHA512: the last element of this table's tuple on the signature bus
+
+
+def le_word_of_bits(base, j):
+    """[(bit column, weight)]: little-endian 32-bit word j of the BYTE STRING whose big-endian 64-bit words sit, as bits, at base + 64 m + i
+    (bit i of word m): byte q of word m is its bits 56 - 8 q .. 63 - 8 q"""
+    m, q0 = j // 2, 4 * (j % 2)
+    return [(base + 64 * m + 56 - 8 * (q0 + q) + t, 1 << (8 * q + t)) for q in range(4) for t in range(8)]
+
+
+def build_program(bus=False):
+    """-> (program words, number of constraints).  bus=True: the table also SENDS, when a message ends, the tuple (first 64 bytes of
+    the message, digest, TAG_SHA512) — 16 + 16 little-endian 32-bit words — on the signature bus: for an Ed25519 verification the
+    message is R || A || M, so the tuple is (R's encoding, A's encoding, the digest the EdDSA table reduces mod L).  Aux challenges
+    [gamma_range, beta, gamma_bus]; two more second-round columns; the closing sum of the sends is aux public input 0."""
     C = Cols
     e = _Emit()
+    N = C.N_BUS if bus else C.N
+    AUX_H, AUX_HT, AUX_ACC, AUX_U, AUX_BUS = N, N + 3, N + 4, N + 5, N + 6
     ONE, TWO32, GAMMA, IS_ROUND, S80, S81, SCHED, NFr, ZERO = 63, 62, 61, 60, 59, 58, 57, 56, 55
     KLO, KHI = 54, 53
     e.ldi(ONE, 1)
@@ -356,13 +376,13 @@ def build_program():
     push(tb, VX_AIR_FIRST_ROW)
     e.release(m0)
     m0 = e.top
-    acc, accn = e.ldw(C.AUX_ACC), e.ldw(C.AUX_ACC, nxt=True)
+    acc, accn = e.ldw(AUX_ACC), e.ldw(AUX_ACC, nxt=True)
     step = e.op(VX_OP_SUB, accn, acc)
     for q, base in enumerate((C.CA, C.CE, C.CW)):
         m1 = e.top
         g0 = e.op(VX_OP_SUB, GAMMA, e.ldw(base))
         g1 = e.op(VX_OP_SUB, GAMMA, e.ldw(base + 1))
-        h = e.ldw(C.AUX_H + q)
+        h = e.ldw(AUX_H + q)
         e.op(VX_OP_SUB, step, h, step)
         t = e.op(VX_OP_MUL, g0, g1)
         e.op(VX_OP_MUL, t, h, t)
@@ -371,7 +391,7 @@ def build_program():
         push(t, VX_AIR_ALL_ROWS)
         e.release(m1)
     gt = e.op(VX_OP_SUB, GAMMA, e.ldw(C.TBL))
-    ht = e.ldw(C.AUX_HT)
+    ht = e.ldw(AUX_HT)
     e.op(VX_OP_ADD, step, ht, step)
     t = e.op(VX_OP_MUL, ht, gt)
     push(e.op(VX_OP_SUB, t, e.ldw(C.MULT)), VX_AIR_ALL_ROWS)
@@ -379,6 +399,79 @@ def build_program():
     push(acc, VX_AIR_FIRST_ROW)
     push(acc, VX_AIR_LAST_ROW)
     e.release(m0)
+    if bus:
+        from . import VX_OP_LDP as _LDP
+        # ---- the latch: FIRST marks a message's first block; LW holds its first 64 bytes as little-endian words over the whole message ----
+        keep = e.top
+        fr, frn = e.ldw(C.FIRST), e.ldw(C.FIRST, nxt=True)
+        t = e.op(VX_OP_SUB, fr, ONE)
+        push(e.op(VX_OP_MUL, t, fr), VX_AIR_ALL_ROWS)
+        push(e.op(VX_OP_SUB, fr, ONE), VX_AIR_FIRST_ROW)
+        t = e.op(VX_OP_SUB, NFr, fr)                         # FIRST' = FIRST + S81 (NF - FIRST)
+        e.op(VX_OP_MUL, t, S81, t)
+        e.op(VX_OP_ADD, t, fr, t)
+        push(e.op(VX_OP_SUB, frn, t), VX_AIR_TRANSITION)
+        ends = e.op(VX_OP_MUL, S81, NFr)                     # this row ends a message
+        holds = e.op(VX_OP_SUB, ONE, ends)
+        bind = e.op(VX_OP_MUL, e.ldw(C.SEL + 7), fr)         # row 7 of a first block: the window holds W_7 .. W_0
+        keep2 = e.top
+        for j in range(16):
+            m1 = e.top
+            lw, lwn = e.ldw(C.LW + j), e.ldw(C.LW + j, nxt=True)
+            t = e.op(VX_OP_SUB, lwn, lw)
+            push(e.op(VX_OP_MUL, t, holds), VX_AIR_TRANSITION)
+            v = e.tmp()
+            e.op(VX_OP_ADD, ZERO, ZERO, v)
+            for col, wgt in le_word_of_bits(0, j):           # word m of the message = window entry 7 - m on row 7
+                m2 = e.top
+                mm, bit = col // 64, col % 64
+                b = e.ldw(C.WB + 64 * (7 - mm) + bit)
+                c = e.tmp()
+                e.ldi(c, wgt)
+                e.op(VX_OP_MUL, b, c, b)
+                e.op(VX_OP_ADD, v, b, v)
+                e.release(m2)
+            t = e.op(VX_OP_SUB, lw, v)
+            push(e.op(VX_OP_MUL, t, bind), VX_AIR_ALL_ROWS)
+            e.release(m1)
+        e.release(keep2)
+        # ---- the send: (LW[0..16), digest as 16 little-endian words, TAG) on the row that ends a message ----
+        beta, gbus = e.tmp(), e.tmp()
+        e.ins(VX_OP_LDCH, beta, 1)
+        e.ins(VX_OP_LDCH, gbus, 2)
+        tup = e.tmp()
+        e.ldi(tup, TAG_SHA512)
+        for j in range(15, -1, -1):                          # the digest = the new chaining value, as bits in S on row 81
+            m1 = e.top
+            v = e.tmp()
+            e.op(VX_OP_ADD, ZERO, ZERO, v)
+            for col, wgt in le_word_of_bits(C.S, j):
+                m2 = e.top
+                b = e.ldw(col)
+                c = e.tmp()
+                e.ldi(c, wgt)
+                e.op(VX_OP_MUL, b, c, b)
+                e.op(VX_OP_ADD, v, b, v)
+                e.release(m2)
+            e.op(VX_OP_MUL, tup, beta, tup)
+            e.op(VX_OP_ADD, tup, v, tup)
+            e.release(m1)
+        for j in range(15, -1, -1):
+            m1 = e.top
+            e.op(VX_OP_MUL, tup, beta, tup)
+            e.op(VX_OP_ADD, tup, e.ldw(C.LW + j), tup)
+            e.release(m1)
+        dlt = e.op(VX_OP_SUB, gbus, tup)
+        u, bacc, baccn = e.ldw(AUX_U), e.ldw(AUX_BUS), e.ldw(AUX_BUS, nxt=True)
+        t = e.op(VX_OP_MUL, u, dlt)
+        push(e.op(VX_OP_SUB, t, ends), VX_AIR_ALL_ROWS)      # u (gamma - tuple) = [this row ends a message]
+        t = e.op(VX_OP_SUB, baccn, bacc)
+        push(e.op(VX_OP_SUB, t, u), VX_AIR_TRANSITION)
+        push(bacc, VX_AIR_FIRST_ROW)
+        closing = e.tmp()
+        e.ins(_LDP, closing, 16)                             # aux public input 0 (after the 16 public inputs): everything this table sent
+        push(e.op(VX_OP_SUB, bacc, closing), VX_AIR_LAST_ROW)
+        e.release(keep)
     e.ins(VX_OP_END)
     return e.w, npush
 
@@ -390,8 +483,12 @@ def pad_message(msg: bytes) -> list:
     return [list(struct.unpack(">16Q", data[i:i + 128])) for i in range(0, len(data), 128)]
 
 
-def generate_trace(degree_bits: int, messages) -> tuple:
-    """-> (trace [1995][n] uint64, public inputs [16], digests of the messages completed inside the trace)"""
+def le_words(b: bytes) -> list:
+    return [int.from_bytes(b[4 * j:4 * j + 4], "little") for j in range(len(b) // 4)]
+
+
+def generate_trace(degree_bits: int, messages, bus=False) -> tuple:
+    """-> (trace [1995 | 2012 bus][n] uint64, public inputs [16], digests of the messages completed inside the trace)"""
     C = Cols
     n = 1 << degree_bits
     blocks = []
@@ -402,8 +499,9 @@ def generate_trace(degree_bits: int, messages) -> tuple:
     lim = lambda w: (w & 0xFFFFFFFF, w >> 32)   # noqa: E731
     words = np.zeros((24, n), dtype=np.uint64)      # 8 state + 16 window words per row
     aux = np.zeros((5, n), dtype=np.uint64)         # x0 x1 m y0 y1
-    t = np.zeros((C.N, n), dtype=np.uint64)
+    t = np.zeros((C.N_BUS if bus else C.N, n), dtype=np.uint64)
     state, H, D = list(IV), list(IV), [0] * 8
+    first_of_message, latched = True, [0] * 16
     wwin = [0] * 16
     digests = []
     carries = np.zeros((6, n), dtype=np.int64)
@@ -413,10 +511,15 @@ def generate_trace(degree_bits: int, messages) -> tuple:
         real = bi < len(blocks)
         bi += 1
         W = list(wordsb) + [0] * 64
+        if bus and first_of_message:                     # a new message: latch its first 64 bytes as little-endian 32-bit words
+            latched = le_words(struct.pack(">8Q", *W[:8]))
         for r in range(PERIOD):
             if row >= n:
                 break
             t[C.SEL + r, row] = 1
+            if bus:
+                t[C.LW:C.LW + 16, row] = latched
+                t[C.FIRST, row] = 1 if first_of_message else 0
             for k in range(8):
                 t[C.H + 2 * k, row], t[C.H + 2 * k + 1, row] = lim(H[k])
                 t[C.D + 2 * k, row], t[C.D + 2 * k + 1, row] = lim(D[k])
@@ -470,6 +573,7 @@ def generate_trace(degree_bits: int, messages) -> tuple:
                     state = list(IV)
                 H = list(state)
             row += 1
+        first_of_message = bool(last and real)           # the next block starts a message iff this one ended one
     for k in range(24):
         base = C.S + 64 * k if k < 8 else C.WB + 64 * (k - 8)
         for i in range(64):
@@ -505,6 +609,36 @@ def aux_columns(trace, chal):
     return np.stack([np.array(c, dtype=np.uint64) for c in h + [ht, acc]])
 
 
+def bus_tuples(trace):
+    """-> (rows that send, [rows][33] elements: the message's first 64 bytes and its digest as little-endian 32-bit words, TAG_SHA512)"""
+    C = Cols
+    rows = np.nonzero((trace[C.SEL + 81] == 1) & (trace[C.NF] == 1))[0]
+    out = np.zeros((rows.size, 33), dtype=np.uint64)
+    for j in range(16):
+        out[:, j] = trace[C.LW + j, rows]
+        acc = np.zeros(rows.size, dtype=np.uint64)
+        for col, wgt in le_word_of_bits(C.S, j):
+            acc += trace[col, rows] * np.uint64(wgt)
+        out[:, 16 + j] = acc
+    out[:, 32] = TAG_SHA512
+    return rows, out
+
+
+def aux_columns_bus(trace, chal):
+    """second-round columns of the bus variant: [h_a, h_e, h_w, ht, acc, bus_u, bus_acc] and the closing sum of the sends"""
+    from . import hostfield as hf
+    from .eddsa_air import _horner
+    n = trace.shape[1]
+    base = aux_columns(trace, chal[:1])
+    beta, g = int(chal[1]), int(chal[2])
+    rows, tuples = bus_tuples(trace)
+    u = np.zeros(n, dtype=np.uint64)
+    if rows.size:
+        u[rows] = hf.invmod(hf.submod(np.full(rows.size, g, dtype=np.uint64), _horner(tuples, beta)))
+    acc, _ = hf.exclusive_prefix_sum(u)
+    return np.concatenate([base, np.stack([u, acc])]), np.array([int(acc[n - 1])], dtype=np.uint64)
+
+
 def aux_program():
     """the GPU form of `aux_columns` (vx_stark_aux_columns): three pair helpers and the table term as fractions, one running sum"""
     from . import AuxProgram
@@ -524,9 +658,13 @@ def aux_program():
     return AuxProgram(C.N, 1, e.w, 4, [[1, 1, 1, -1]])
 
 
-def make_stark(degree_bits: int, **cfg) -> Stark:
-    prog, _ = build_program()
+def make_stark(degree_bits: int, bus=False, **cfg) -> Stark:
     cfg.setdefault("rate_bits", 1)
+    if bus:
+        prog, _ = build_program(True)
+        return Stark(degree_bits, Cols.N_BUS, 16, prog, constraint_degree=3, num_aux_columns=Cols.NAUX_BUS, num_aux_challenges=3, aux_fn=aux_columns_bus,
+                     num_aux_public_inputs=1, **cfg)
+    prog, _ = build_program()
     st = Stark(degree_bits, Cols.N, 16, prog, constraint_degree=3, num_aux_columns=Cols.NAUX, num_aux_challenges=1, aux_fn=aux_columns, **cfg)
     st.aux_program = aux_program()
     return st
