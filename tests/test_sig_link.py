@@ -78,13 +78,27 @@ def test_signatures_verify_through_tables_only_and_forgeries_unbalance_the_bus(o
     descs = [(sha, sha_pis), (ed, nopi), (lk, nopi), (sink, nopi)]
     sums = vx.stark_verify_bus(descs, proofs)
     assert all(int(x) != 0 for x in sums[:, 0])                           # every table sent or received something; the four sums cancel
-    # a verifier holding S + L: no row of the link table can produce its tuple from what the EdDSA table accepted (a link row with S + L
-    # would need the EdDSA table to have sent it; the honest link row leaves the verifier's tuple unmatched) — both ways the sums do not cancel
+    # Forgeries, judged where the bus is judged — the closing sums of the four tables under shared challenges must cancel (computed here
+    # with the tables' own second-round functions; the GPU twin proves a forged bus outright).  The honest four cancel:
+    P = ea.P
+    closing = lambda fn, tr: int(fn(tr, CHAL)[1][0])      # noqa: E731
+    ed_cl = int(ea.aux_columns(lay, ed_t, CHAL)[1][0])
+    sha_cl = closing(s5.aux_columns_bus, sha_t)
+    assert (sha_cl + ed_cl + closing(link.aux_columns, lk_t) + closing(sink.aux_fn, sink_t)) % P == 0
+    # a verifier holding S + L: the link row that would produce its tuple does not match what the EdDSA table sent; the honest link row
+    # leaves the verifier's tuple unmatched — either way the sums do not cancel
     pk, _, sig, dig = raw[0]
     s = int.from_bytes(sig[32:], "little")
     forged_sig = sig[:32] + (s + ea.ELL).to_bytes(32, "little")
     sink2, sink2_t, _ = ea.make_sink(lay, [link.verifier_tuple(pk, forged_sig)], ntuple=25, **CFG)
-    lk2, lk2_t, _ = link.make_link([link.row_of(pk, forged_sig, dig)], **CFG)
-    proofs2, _ = oracle_lib.stark_prove_tables(oracle, tables[:2] + [(lk2, lk2_t, nopi), (sink2, sink2_t, nopi)])
-    with pytest.raises(vx.VxError, match="cancel"):
-        vx.stark_verify_bus(descs[:2] + [(lk2, nopi), (sink2, nopi)], proofs2)
+    for link_rows in ([link.row_of(pk, forged_sig, dig)], [link.row_of(pk, sig, dig)]):
+        _, lk2_t, _ = link.make_link(link_rows, **CFG)
+        assert (sha_cl + ed_cl + closing(link.aux_columns, lk2_t) + closing(sink2.aux_fn, sink2_t)) % P != 0
+    # a link row claiming a digest the SHA-512 table never produced for R || A
+    _, lk3_t, _ = link.make_link([link.row_of(pk, sig, hashlib.sha512(b"other").digest())], **CFG)
+    assert (sha_cl + ed_cl + closing(link.aux_columns, lk3_t) + closing(sink.aux_fn, sink_t)) % P != 0
+    # R with its sign bit flipped in the verifier's bytes
+    sig_flip = bytes(sig[:31]) + bytes([sig[31] ^ 0x80]) + sig[32:]
+    sink4, sink4_t, _ = ea.make_sink(lay, [link.verifier_tuple(pk, sig_flip)], ntuple=25, **CFG)
+    _, lk4_t, _ = link.make_link([link.row_of(pk, sig_flip, dig)], **CFG)
+    assert (sha_cl + ed_cl + closing(link.aux_columns, lk4_t) + closing(sink4.aux_fn, sink4_t)) % P != 0
