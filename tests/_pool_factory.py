@@ -47,3 +47,11 @@ def make_failing(cfg, device):
             return super().prove(key, *a, **kw)
     provers["reduce"] = Boom("reduce")
     return provers, close, info
+
+
+def make_dying(cfg, device):
+    """worker 1 dies during its setup (the coordinator must notice within seconds, not wait for a timeout)"""
+    if cfg["worker_index"] == 1:
+        import os
+        os._exit(7)
+    return make(cfg, device)

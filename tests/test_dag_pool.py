@@ -68,3 +68,16 @@ def test_two_devices_worth_of_workers_share_one_coordinator():
         assert pool.run(b"s")["root"] == one_process_root(spec, b"s")
     finally:
         pool.close()
+
+
+def test_a_worker_that_dies_during_setup_is_an_error_within_seconds():
+    import time
+    spec = mr.DagSpec(4, 10, 9, 11)
+    pool = DagPool(spec, workers_per_device=2, lanes=1, factory="_pool_factory:make_dying").start()
+    try:
+        t0 = time.perf_counter()
+        with pytest.raises(RuntimeError, match="exited with code 7"):
+            pool.wait_ready(timeout=600)
+        assert time.perf_counter() - t0 < 30
+    finally:
+        pool.close()

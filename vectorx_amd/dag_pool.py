@@ -71,21 +71,38 @@ class DagPool:
                 self.procs.append(p)
         return self
 
+    def _check_alive(self, what):
+        for i, p in enumerate(self.procs):
+            rc = p.poll()
+            if rc is not None:
+                raise RuntimeError(f"DAG worker {i} exited with code {rc} {what}")
+
     def wait_ready(self, timeout: float = 3600.0):
-        """accept the workers' connections, send the configuration, wait until every worker has its circuits loaded -> setup records"""
+        """accept the workers' connections, send the configuration, wait until every worker has its circuits loaded -> setup records.
+        A worker that dies (or never comes up) is an error within seconds, not a wait until the timeout."""
         t0 = time.perf_counter()
-        self._listener._listener._socket.settimeout(timeout)
+        sock = getattr(getattr(self._listener, "_listener", None), "_socket", None)
+        if sock is not None:
+            sock.settimeout(2.0)
         byindex = {}
-        for _ in self.procs:
-            c = self._listener.accept()
+        while len(byindex) < len(self.procs):
+            try:
+                c = self._listener.accept()
+            except OSError:                    # the accept timed out: is everybody still there?
+                self._check_alive("before connecting back")
+                if time.perf_counter() - t0 > timeout:
+                    raise TimeoutError("the DAG workers did not connect in time")
+                continue
             hello = c.recv()                   # ("hello", worker index): connections arrive in any order
             byindex[hello[1]] = c
         self.conns = [byindex[i] for i in range(len(self.procs))]
         for c in self.conns:
             c.send(("setup", self.cfg))
         for c in self.conns:
-            if not c.poll(max(1.0, timeout - (time.perf_counter() - t0))):
-                raise TimeoutError("a DAG worker did not finish its setup in time")
+            while not c.poll(2.0):
+                self._check_alive("during setup")
+                if time.perf_counter() - t0 > timeout:
+                    raise TimeoutError("a DAG worker did not finish its setup in time")
             msg = c.recv()
             if msg[0] != "ready":
                 raise RuntimeError(f"DAG worker failed during setup:\n{msg[1]}")
@@ -184,8 +201,15 @@ class DagPool:
                     dispatch(item)
             if not outstanding:
                 raise RuntimeError("DAG scheduler stalled: nothing running and nothing can start")
-            for c in wait(self.conns):
-                msg = c.recv()
+            got = wait(self.conns, timeout=5.0)
+            if not got:
+                self._check_alive("while jobs were outstanding")
+                continue
+            for c in got:
+                try:
+                    msg = c.recv()
+                except EOFError:
+                    raise RuntimeError(f"DAG worker {self.conns.index(c)} closed its connection while jobs were outstanding") from None
                 if msg[0] == "error":
                     raise RuntimeError(f"DAG worker failed:\n{msg[1]}")
                 w = self.conns.index(c)
