@@ -103,7 +103,12 @@ class DagPool:
                 self._check_alive("during setup")
                 if time.perf_counter() - t0 > timeout:
                     raise TimeoutError("a DAG worker did not finish its setup in time")
-            msg = c.recv()
+            try:
+                msg = c.recv()
+            except EOFError:                   # the worker is gone: say how it ended
+                time.sleep(0.5)
+                self._check_alive("during setup")
+                raise RuntimeError("a DAG worker closed its connection during setup") from None
             if msg[0] != "ready":
                 raise RuntimeError(f"DAG worker failed during setup:\n{msg[1]}")
             self.ready.append(msg[1])
