@@ -405,6 +405,11 @@ int vx_trace_sha512(vx_ctx* ctx, int degree_bits, const uint8_t* msgs, const uin
                     uint64_t* public_inputs_out, uint8_t* digests_out);
 int vx_trace_blake2b(vx_ctx* ctx, int degree_bits, const uint8_t* msgs, const uint64_t* offsets, int num_msgs, void* trace_dev,
                      uint64_t* public_inputs_out, uint8_t* digests_out);
+/* The SHA-512 table's BUS variant (sha512_air.py, bus = True: 2012 columns): the same table plus the first 64 bytes of every message —
+ * for an Ed25519 verification R || A — latched as 16 little-endian 32-bit words and the first-block flag; that table sends
+ * (R, A, digest) on the signature bus (vectorx_amd/sig_link_air.py). */
+int vx_trace_sha512_bus(vx_ctx* ctx, int degree_bits, const uint8_t* msgs, const uint64_t* offsets, int num_msgs, void* trace_dev,
+                        uint64_t* public_inputs_out, uint8_t* digests_out);
 /* The batched EdDSA table (vectorx_amd/eddsa_air.py, Layout(limb_bits = 16, scalar_bits, full)): one instance of 16 + 42 * scalar_bits + 4
  * rows per signature equation [S]B - [h]A (the FULL program, full = 1, scalar_bits = 256: 32 + 42 * 256 + 11 rows — it also decompresses
  * A and R, reduces the SHA-512 digest mod L and checks S < L inside the instance).  `sigs` = [num_sigs][16] little-endian 64-bit words:

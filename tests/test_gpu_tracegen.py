@@ -11,6 +11,23 @@ from vectorx_amd import blake2b_bytes_air, sha256_air, sha512_air, stark_chips
 pytestmark = pytest.mark.gpu
 
 AIRS = {"sha256": sha256_air, "sha512": sha512_air, "blake2b": blake2b_bytes_air}
+
+
+def test_device_sha512_bus_variant_equals_the_numpy_generator(ctx):
+    """the SHA-512 table that sends (R, A, digest) on the signature bus (2012 columns), generated on the device"""
+    msgs = [b"R" * 32 + b"A" * 32 + b"message", seeded(1, [300], 8)[0], b"short", b""]
+    n = 1 << 10
+    d = ctx.alloc(2012 * n * 8)
+    try:
+        ctx.upload(d, np.full((2012, n), 0xDEAD, dtype=np.uint64))
+        pis, digests = ctx.trace_hash_table("sha512_bus", 10, msgs, d)
+        got = ctx.download(d, 2012 * n * 8).reshape(2012, n)
+    finally:
+        ctx.free(d)
+    ref, rpis, rdig = sha512_air.generate_trace(10, msgs, bus=True)
+    bad = np.argwhere(got != ref)
+    assert bad.size == 0, f"first differing cells (column, row): {bad[:8].tolist()}"
+    assert (pis == rpis).all() and digests == rdig == [hashlib.sha512(m).digest() for m in msgs]
 HASH = {"sha256": lambda m: hashlib.sha256(m).digest(), "sha512": lambda m: hashlib.sha512(m).digest(),
         "blake2b": lambda m: hashlib.blake2b(m, digest_size=32).digest()}
 

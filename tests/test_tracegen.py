@@ -25,7 +25,7 @@ def tgh():
     elif not so.exists() or so.stat().st_mtime < max(d.stat().st_mtime for d in deps):
         subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", str(so), str(src)], check=True)
     L = ctypes.CDLL(str(so))
-    for f in (L.tgh_sha256, L.tgh_sha512, L.tgh_blake2b):
+    for f in (L.tgh_sha256, L.tgh_sha512, L.tgh_blake2b, L.tgh_sha512_bus):
         f.restype = ctypes.c_int
         f.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 2 + [ctypes.c_int] + [ctypes.c_void_p] * 3
     return L
@@ -81,6 +81,17 @@ def test_sha512_rows_equal_the_numpy_generator(tgh, log_n, msgs):
     assert (pis == rpis).all()
     for i, m in enumerate(msgs):
         assert b"".join(int(w).to_bytes(8, "big") for w in dig[8 * i:8 * i + 8]) == hashlib.sha512(m).digest() == rdig[i]
+
+
+def test_sha512_bus_variant_rows_equal_the_numpy_generator(tgh):
+    """the table that sends (R, A, digest) on the signature bus: 17 more columns (the message's first 64 bytes latched, the first-block flag)"""
+    msgs = [b"R" * 32 + b"A" * 32 + b"message", seeded(1, [300], 8)[0], b"short", b"", seeded(1, [64], 9)[0]]
+    rc, trace, pis, dig = run(tgh.tgh_sha512_bus, 2012, 16, 8, 10, msgs)
+    assert rc == 0
+    ref, rpis, rdig = sha512_air.generate_trace(10, msgs, bus=True)
+    bad = np.argwhere(trace != ref)
+    assert bad.size == 0, f"first differing cells (column, row): {bad[:8].tolist()}"
+    assert (pis == rpis).all() and len(rdig) == len(msgs)
 
 
 @pytest.mark.parametrize("msgs", [

@@ -35,6 +35,9 @@ int tgh_sha256(int degree_bits, const uint8_t* msgs, const uint64_t* off, int nm
 int tgh_sha512(int degree_bits, const uint8_t* msgs, const uint64_t* off, int nmsg, uint64_t* trace, uint64_t* pis, uint64_t* digest_words) {
   return sha2_host<tg::Sha512T>(degree_bits, msgs, off, nmsg, trace, pis, digest_words);
 }
+int tgh_sha512_bus(int degree_bits, const uint8_t* msgs, const uint64_t* off, int nmsg, uint64_t* trace, uint64_t* pis, uint64_t* digest_words) {
+  return sha2_host<tg::Sha512BusT>(degree_bits, msgs, off, nmsg, trace, pis, digest_words);
+}
 int tgh_blake2b(int degree_bits, const uint8_t* msgs, const uint64_t* off, int nmsg, uint64_t* trace, uint64_t* pis, uint64_t* digest_words) {
   tg::B2Prep prep;
   const int pr = tg::b2_prepare(degree_bits, msgs, off, nmsg, prep);

@@ -116,6 +116,7 @@ _SIGNATURES = {
     "vx_trace_sha256": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "vx_trace_sha512": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "vx_trace_blake2b": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
+    "vx_trace_sha512_bus": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "vx_trace_eddsa": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp]),
     "vx_stark_aux_precompile": (_i, [_vp]),
     "vx_stark_precompile": (_i, [_vp, ctypes.POINTER(_i)]),
@@ -243,7 +244,8 @@ class Context:
         return out
 
     # ---- chip-table traces generated on the device (vx_trace_*) ----
-    TRACE_TABLES = {"sha256": (1024, 8, 32), "sha512": (1995, 16, 64), "blake2b": (775, 8, 32)}   # columns, public inputs, digest bytes
+    TRACE_TABLES = {"sha256": (1024, 8, 32), "sha512": (1995, 16, 64), "blake2b": (775, 8, 32),
+                    "sha512_bus": (2012, 16, 64)}                                                   # columns, public inputs, digest bytes
 
     def trace_hash_table(self, which: str, degree_bits: int, messages, d_trace: int):
         """Fill the `which` table ("sha256" | "sha512" | "blake2b": the AIRs of vectorx_amd/{sha256,sha512,blake2b_bytes}_air.py) for

@@ -161,6 +161,10 @@ int vx_trace_sha512(vx_ctx* c, int degree_bits, const uint8_t* msgs, const uint6
                     uint64_t* public_inputs_out, uint8_t* digests_out) {
   return tg_trace_sha2<tg::Sha512T>(c, degree_bits, msgs, offsets, num_msgs, trace_dev, public_inputs_out, digests_out, "vx_trace_sha512");
 }
+int vx_trace_sha512_bus(vx_ctx* c, int degree_bits, const uint8_t* msgs, const uint64_t* offsets, int num_msgs, void* trace_dev,
+                        uint64_t* public_inputs_out, uint8_t* digests_out) {
+  return tg_trace_sha2<tg::Sha512BusT>(c, degree_bits, msgs, offsets, num_msgs, trace_dev, public_inputs_out, digests_out, "vx_trace_sha512_bus");
+}
 int vx_trace_blake2b(vx_ctx* c, int degree_bits, const uint8_t* msgs, const uint64_t* offsets, int num_msgs, void* trace_dev,
                      uint64_t* public_inputs_out, uint8_t* digests_out) {
   if (!c || !trace_dev) return vx_fail(VX_E_INVALID, "vx_trace_blake2b: NULL argument");

@@ -25,6 +25,7 @@ namespace tg {
 // ================================================================================================================================
 struct Sha256T {
   typedef uint32_t W;
+  static constexpr bool BUS = false;
   static constexpr int BITS = 32, ROUNDS = 64, PERIOD = 66, LIMBS = 1, NCARRY = 3;
   static constexpr int S = 0, WB = 256, X0 = 768, X1 = 800, M = 832, Y0 = 864, Y1 = 896, SEL = 928, H = 994, D = 1002, FFC = 1010,
                        NF = 1018, CA = 1019, CE = 1020, CW = 1021, TBL = 1022, MULT = 1023, N = 1024;
@@ -33,11 +34,19 @@ struct Sha256T {
 };
 struct Sha512T {
   typedef uint64_t W;
+  static constexpr bool BUS = false;
   static constexpr int BITS = 64, ROUNDS = 80, PERIOD = 82, LIMBS = 2, NCARRY = 6;
   static constexpr int S = 0, WB = 512, X0 = 1536, X1 = 1600, M = 1664, Y0 = 1728, Y1 = 1792, SEL = 1856, H = 1938, D = 1954,
                        FFC = 1970, NF = 1986, CA = 1987, CE = 1989, CW = 1991, TBL = 1993, MULT = 1994, N = 1995;
   static constexpr int R_S0a = 28, R_S0b = 34, R_S0c = 39, R_S1a = 14, R_S1b = 18, R_S1c = 41, R_s0a = 1, R_s0b = 8, SH_s0 = 7,
                        R_s1a = 19, R_s1b = 61, SH_s1 = 6;
+};
+
+// the bus variant of the SHA-512 table (sha512_air.py, bus=True; vectorx_amd/sig_link_air.py): 17 more columns — the first 64 bytes of the
+// current message as 16 little-endian 32-bit words (an Ed25519 R, then A), latched over the whole message, and the first-block flag
+struct Sha512BusT : Sha512T {
+  static constexpr bool BUS = true;
+  static constexpr int LW = 1995, FIRST = 2011, N = 2012;
 };
 
 template <class T>
@@ -52,7 +61,8 @@ struct Sha2Block {
   typename T::W h_in[8];   // chaining value the block starts from (the IV after a message's last block)
   typename T::W d[8];      // digest of the last message completed BEFORE this block's hand-over row (zeros: none yet)
   uint32_t nf;             // hand-over row: the next block starts a new message (last block of a real message)
-  uint32_t pad_;
+  uint32_t first;          // bus variant: this block is the first of its message
+  uint32_t lw[16];         // bus variant: the first 64 bytes of the block's message as little-endian 32-bit words
 };
 // what a thread per block precomputes for the row writers: the message schedule and the working state before every row
 template <class T>
@@ -215,6 +225,10 @@ TG_HD void sha2_row(const Sha2Block<T>& blk, const Sha2Expanded<T>& e, const Sha
   }
   put(T::TBL, (uint64_t)(row & 7));
   put(T::MULT, (uint64_t)0);
+  if constexpr (T::BUS) {
+    for (int j = 0; j < 16; ++j) put(T::LW + j, (uint64_t)blk.lw[j]);
+    put(T::FIRST, (uint64_t)blk.first);
+  }
 }
 
 // ================================================================================================================================

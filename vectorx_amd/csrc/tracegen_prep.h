@@ -25,6 +25,8 @@ struct Sha2Consts<Sha512T> {
   static TG_HD const uint64_t* K() { return K512; }
   static TG_HD const uint64_t* IV() { return IV512; }
 };
+template <>
+struct Sha2Consts<Sha512BusT> : Sha2Consts<Sha512T> {};
 
 template <class T>
 struct Sha2Prep {
@@ -49,6 +51,20 @@ int sha2_prepare(int degree_bits, const uint8_t* msgs, const uint64_t* off, int 
   W h[8], d[8];
   for (int k = 0; k < 8; ++k) h[k] = IV[k], d[k] = 0;
   std::vector<uint8_t> buf;
+  bool first_of_message = true;                // bus variant: the next block starts a message
+  uint32_t latched[16] = {0};
+  auto latch = [&](Sha2Block<T>& b) {          // the first 64 bytes of the message = big-endian words 0..7 of its first block, as LE 32-bit words
+    if (first_of_message)
+      for (int j = 0; j < 16; ++j) {
+        const uint64_t w = (uint64_t)b.w[(j * 4) / sizeof(W)];
+        const int byte0 = (j * 4) % (int)sizeof(W);                 // first byte (most significant = 0) of the LE word inside the BE word
+        uint32_t v = 0;
+        for (int q = 0; q < 4; ++q) v |= (uint32_t)((w >> (8 * (sizeof(W) - 1 - (byte0 + q)))) & 0xFF) << (8 * q);
+        latched[j] = v;
+      }
+    b.first = first_of_message;
+    for (int j = 0; j < 16; ++j) b.lw[j] = latched[j];
+  };
   for (int mi = 0; mi < nmsg; ++mi) {
     const size_t ml = (size_t)(off[mi + 1] - off[mi]);
     const size_t total = ((ml + 1 + LB + BB - 1) / BB) * BB;
@@ -69,6 +85,8 @@ int sha2_prepare(int degree_bits, const uint8_t* msgs, const uint64_t* off, int 
       }
       for (int k = 0; k < 8; ++k) b.h_in[k] = h[k], b.d[k] = d[k];
       b.nf = j + 1 == nblk;
+      latch(b);
+      first_of_message = b.nf;
       sha2_compress<T>(h, b.w, K);
       // the block's hand-over row must exist for the digest to be latched (and a later block to start from the IV)
       if ((out.blocks.size() + 1) * T::PERIOD > n) return PREP_TOO_MANY_BLOCKS;
@@ -82,6 +100,8 @@ int sha2_prepare(int degree_bits, const uint8_t* msgs, const uint64_t* off, int 
     Sha2Block<T> b;
     memset(&b, 0, sizeof b);
     for (int k = 0; k < 8; ++k) b.h_in[k] = h[k], b.d[k] = d[k];
+    latch(b);
+    first_of_message = false;                    // the endless zero-message never ends
     sha2_compress<T>(h, b.w, K);
     out.blocks.push_back(b);
   }
