@@ -474,6 +474,25 @@ def test_signatures_verify_through_tables_only_on_the_gpu(ctx, oracle):
     assert (shared == shared_o).all() and proofs == expect
     sums = vx.stark_verify_bus(descs, proofs)
     assert all(int(x) != 0 for x in sums[:, 0])
+    # the same bus with every trace resident in HBM and every second round computed on the GPU (stark_chips.prove_bus_device — what the
+    # DAG's outer job runs; the SHA-512 and EdDSA traces generated on the device): the same four proofs
+    from vectorx_amd import stark_chips
+    bufs, items = [], []
+    try:
+        for st, tr, pi in tables:
+            n_ = tr.shape[1]
+            d_t, d_a = ctx.alloc(tr.shape[0] * n_ * 8), ctx.alloc(st.desc.num_aux_columns * n_ * 8)
+            bufs += [d_t, d_a]
+            ctx.upload(d_t, tr)
+            items.append((st, d_t, pi, d_a))
+        ctx.trace_hash_table("sha512_bus", 9, [sig[:32] + pk + msg for pk, msg, sig, _ in raw], items[0][1])
+        assert ctx.trace_eddsa_table(17, 256, [ea.equation_inputs_full(pk, msg, sig) for pk, msg, sig, _ in raw], items[1][1], full=True) == res
+        dev_proofs, dev_shared, dev_sums = stark_chips.prove_bus_device(ctx, items)
+        assert (dev_shared == shared).all() and dev_proofs == proofs
+        assert [[int(x) for x in a] for a in dev_sums] == [[int(x) for x in row] for row in sums]
+    finally:
+        for d_ in bufs:
+            ctx.free(d_)
     pk, _, sig, dig = raw[-1]
     s = int.from_bytes(sig[32:], "little")
     forged_sig = sig[:32] + (s + ea.ELL).to_bytes(32, "little")

@@ -1134,7 +1134,29 @@ def make_sink(lay: Layout, tuples, degree_bits=None, ntuple=None, **cfg):
     cfg.setdefault("rate_bits", 1)
     stark = Stark(db, nt + 1, 0, sink_program(nt), constraint_degree=3, num_aux_columns=2, num_aux_challenges=3, aux_fn=aux,
                   num_aux_public_inputs=1, **cfg)
+    stark.aux_program = sink_aux_program(nt)
     return stark, t, np.zeros(0, dtype=np.uint64)
+
+
+def sink_aux_program(ntuple: int):
+    """the GPU form of the sink's second round: the fraction -flag / (gamma_bus - tuple) and its running sum"""
+    from . import AuxProgram
+    e = _Emit(scratch=40)
+    ZERO, BETA, G = 63, 62, 61
+    e.ldi(ZERO, 0)
+    e.ins(VX_OP_LDCH, BETA, 1)
+    e.ins(VX_OP_LDCH, G, 2)
+    tup = e.tmp()
+    e.ldw(ntuple - 1, dst=tup)
+    for col in range(ntuple - 2, -1, -1):
+        m = e.top
+        e.op(VX_OP_MUL, tup, BETA, tup)
+        e.op(VX_OP_ADD, tup, e.ldw(col), tup)
+        e.release(m)
+    e.push(e.op(VX_OP_SUB, ZERO, e.ldw(ntuple)), 0)
+    e.push(e.op(VX_OP_SUB, G, tup), 0)
+    e.ins(VX_OP_END)
+    return AuxProgram(ntuple + 1, 3, e.w, 1, [[1]], fraction_out=[0], sum_out=[1], api_sums=(0,))
 
 
 # ---- RFC 8032 on the host: what produces (A, S, h, R) for the table -------------------------------------------------------------

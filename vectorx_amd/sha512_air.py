@@ -658,12 +658,62 @@ def aux_program():
     return AuxProgram(C.N, 1, e.w, 4, [[1, 1, 1, -1]])
 
 
+def aux_program_bus():
+    """the GPU form of `aux_columns_bus`: the four range-check fractions, the bus fraction [this row ends a message] / (gamma_bus - tuple),
+    the two running sums; the bus sum's closing value is the set's aux public input"""
+    from . import VX_OP_MUL as _MUL
+    from . import AuxProgram
+    C = Cols
+    e = _Emit(scratch=40)
+    GAMMA, BETA, GBUS, ZERO = 63, 62, 61, 60
+    e.ldi(ZERO, 0)
+    e.ins(VX_OP_LDCH, GAMMA, 0)
+    e.ins(VX_OP_LDCH, BETA, 1)
+    e.ins(VX_OP_LDCH, GBUS, 2)
+    for base in (C.CA, C.CE, C.CW):
+        m0 = e.top
+        g0, g1 = e.op(VX_OP_SUB, GAMMA, e.ldw(base)), e.op(VX_OP_SUB, GAMMA, e.ldw(base + 1))
+        e.push(e.op(VX_OP_ADD, g0, g1), 0)
+        e.push(e.op(_MUL, g0, g1), 0)
+        e.release(m0)
+    e.push(e.ldw(C.MULT), 0)
+    e.push(e.op(VX_OP_SUB, GAMMA, e.ldw(C.TBL)), 0)
+    tup = e.tmp()
+    e.ldi(tup, TAG_SHA512)
+    for j in range(15, -1, -1):
+        m1 = e.top
+        v = e.tmp()
+        e.op(VX_OP_ADD, ZERO, ZERO, v)
+        for col, wgt in le_word_of_bits(C.S, j):
+            m2 = e.top
+            b = e.ldw(col)
+            c = e.tmp()
+            e.ldi(c, wgt)
+            e.op(_MUL, b, c, b)
+            e.op(VX_OP_ADD, v, b, v)
+            e.release(m2)
+        e.op(_MUL, tup, BETA, tup)
+        e.op(VX_OP_ADD, tup, v, tup)
+        e.release(m1)
+    for j in range(15, -1, -1):
+        m1 = e.top
+        e.op(_MUL, tup, BETA, tup)
+        e.op(VX_OP_ADD, tup, e.ldw(C.LW + j), tup)
+        e.release(m1)
+    e.push(e.op(_MUL, e.ldw(C.SEL + 81), e.ldw(C.NF)), 0)
+    e.push(e.op(VX_OP_SUB, GBUS, tup), 0)
+    e.ins(VX_OP_END)
+    return AuxProgram(C.N_BUS, 3, e.w, 5, [[1, 1, 1, -1, 0], [0, 0, 0, 0, 1]], fraction_out=[0, 1, 2, 3, 5], sum_out=[4, 6], api_sums=(1,))
+
+
 def make_stark(degree_bits: int, bus=False, **cfg) -> Stark:
     cfg.setdefault("rate_bits", 1)
     if bus:
         prog, _ = build_program(True)
-        return Stark(degree_bits, Cols.N_BUS, 16, prog, constraint_degree=3, num_aux_columns=Cols.NAUX_BUS, num_aux_challenges=3, aux_fn=aux_columns_bus,
-                     num_aux_public_inputs=1, **cfg)
+        st = Stark(degree_bits, Cols.N_BUS, 16, prog, constraint_degree=3, num_aux_columns=Cols.NAUX_BUS, num_aux_challenges=3, aux_fn=aux_columns_bus,
+                   num_aux_public_inputs=1, **cfg)
+        st.aux_program = aux_program_bus()
+        return st
     prog, _ = build_program()
     st = Stark(degree_bits, Cols.N, 16, prog, constraint_degree=3, num_aux_columns=Cols.NAUX, num_aux_challenges=1, aux_fn=aux_columns, **cfg)
     st.aux_program = aux_program()

@@ -101,6 +101,30 @@ def aux_columns(trace, chal):
     return np.stack(us + [acc]), np.array([int(acc[n - 1])], dtype=np.uint64)
 
 
+def aux_program():
+    """the GPU form of `aux_columns`: three fractions flag / (gamma_bus - tuple_k), one running sum u3 - u1 - u2"""
+    from . import AuxProgram
+    e = _Emit(scratch=40)
+    BETA, G = 62, 61
+    e.ins(VX_OP_LDCH, BETA, 1)
+    e.ins(VX_OP_LDCH, G, 2)
+    for name in ("eddsa", "sha512", "verifier"):
+        m0 = e.top
+        cols, tag = FORMATS[name]
+        tup = e.tmp()
+        e.ldi(tup, tag)
+        for col in reversed(cols):
+            m1 = e.top
+            e.op(VX_OP_MUL, tup, BETA, tup)
+            e.op(VX_OP_ADD, tup, e.ldw(col), tup)
+            e.release(m1)
+        e.push(e.ldw(FLAG), 0)
+        e.push(e.op(VX_OP_SUB, G, tup), 0)
+        e.release(m0)
+    e.ins(VX_OP_END)
+    return AuxProgram(N, 3, e.w, 3, [[-1, -1, 1]], fraction_out=[0, 1, 2], sum_out=[3], api_sums=(0,))
+
+
 def make_link(rows, degree_bits=None, **cfg):
     """-> (Stark, trace, public inputs (none)) of the link table for `rows` = [row_of(...)] (the last trace row stays empty: it is inert
     in a running sum)"""
@@ -115,4 +139,5 @@ def make_link(rows, degree_bits=None, **cfg):
     cfg.setdefault("rate_bits", 1)
     stark = Stark(db, N, 0, build_program(), constraint_degree=3, num_aux_columns=NAUX, num_aux_challenges=3, aux_fn=aux_columns,
                   num_aux_public_inputs=1, **cfg)
+    stark.aux_program = aux_program()
     return stark, t, np.zeros(0, dtype=np.uint64)

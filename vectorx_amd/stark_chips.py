@@ -242,6 +242,46 @@ def prove_device_trace(ctx, stark, d_trace: int, pis, d_aux: int, cap: int = 1 <
         L.vx_stark_session_free(sess)
 
 
+def prove_bus_device(ctx, items, cap: int = 1 << 25):
+    """Several tables on ONE bus, every trace already in device memory (vectorx_amd/stark_bus.py is the host-trace form): one session per
+    table -> every trace cap -> the joint challenges -> each table's second-round columns ON THE GPU (its AuxProgram) with those
+    challenges -> one proof per table.  items: [(stark, d_trace, public_inputs, d_aux)] -> (proofs, shared challenges, closing sums)"""
+    import vectorx_amd as vx
+    L, vp = vx.lib(), ctypes.c_void_p
+    n_shared = {st.desc.num_aux_challenges for st, _, _, _ in items}
+    if len(n_shared) != 1:
+        raise ValueError("every table on the bus declares the same number of shared challenges")
+    sessions = []
+    try:
+        for st, d_trace, pis, _ in items:
+            sess = vp()
+            pis = np.ascontiguousarray(pis, dtype=np.uint64)
+            own = np.zeros(max(1, st.desc.num_aux_challenges), dtype=np.uint64)
+            rc = L.vx_stark_begin(ctx._h, ctypes.cast(st.desc_ptr, vp), vp(d_trace), 1, pis.ctypes.data if pis.size else None, own.ctypes.data, ctypes.byref(sess))
+            if rc != 0:
+                raise RuntimeError(L.vx_last_error().decode())
+            sessions.append(sess)
+        caps = [st.session_trace_cap(sess) for (st, _, _, _), sess in zip(items, sessions)]
+        shared = vx.stark_joint_challenges(caps, [st.desc.cap_height for st, _, _, _ in items], n_shared.pop())
+        proofs, sums = [], []
+        for (st, d_trace, _, d_aux), sess in zip(items, sessions):
+            vx._chk(L.vx_stark_set_aux_challenges(sess, shared.ctypes.data))
+            if st.aux_program is None:
+                raise RuntimeError("prove_bus_device: a table without an AuxProgram cannot compute its second round on the GPU")
+            api = st.run_aux_gpu(ctx, d_trace, shared, d_aux)
+            out = np.empty(cap, dtype=np.uint8)
+            nb = ctypes.c_size_t(cap)
+            rc = L.vx_stark_finish2(sess, vp(d_aux), 1, None if api.size == 0 else api.ctypes.data, None, out.ctypes.data, ctypes.byref(nb))
+            if rc != 0:
+                raise RuntimeError(L.vx_last_error().decode())
+            proofs.append(out[:nb.value].tobytes())
+            sums.append(api)
+        return proofs, shared, sums
+    finally:
+        for sess in sessions:
+            L.vx_stark_session_free(sess)
+
+
 class GeneratedHashTable:
     """A hash-chip table whose trace is generated PER JOB on the GPU (round 5): `messages_fn(job)` -> the byte strings this job hashes
     (a map job's 8 headers, a job's SHA-256 tree nodes ...), `Context.trace_hash_table` fills the lane's trace buffer with native
