@@ -169,12 +169,14 @@ def dag_pool_legs(pool, with_starks=True, passes=2):
         tables = next((r.get("tables") for r in ready if r.get("worker") == 0), None)
         rec = record(runs, sizes + ", EACH JOB WITH ITS STARK TABLES (own AIRs standing in for Curta's chips): map = BLAKE2b over the job's own 8 headers "
                                   "(2240 compressions, 2^16 rows) + SHA-256 over its 14 tree nodes; reduce = SHA-256 over its 2 merge nodes; outer = SHA-256 over "
-                                  "300 keys + SHA-512 over 300 messages + 4 batched EdDSA tables (2^20 rows).  Per-job tables: inputs derived from the "
+                                  "300 keys + the 300 signatures verified THROUGH TABLES ONLY as one bus (SHA-512 over R || A || M, 4 batched EdDSA tables "
+                                  "running the full program, the link table).  Per-job tables: inputs derived from the "
                                   "request seed and the job's position, TRACES GENERATED ON THE GPU INSIDE THE CLOCK (vx_trace_*: lane-seconds "
                                   "`trace_generation`), the four EdDSA tables included.  The STARK proofs are part of a job's digest; "
                                   "NOT the contract's timed region")
         rec["tables"] = tables
-        rec["stark_proofs"] = spec.num_map * 2 + (spec.num_map - 1) + 2 + ((tables or {}).get("eddsa_outer", {}).get("tables", 0))
+        rec["stark_proofs"] = spec.num_map * 2 + (spec.num_map - 1) + 2 + ((tables or {}).get("eddsa_outer", {}).get("tables", 0)) \
+            + (1 if "signature_bus" in (tables or {}) else 0)
         out["dag_header_range_512_with_starks"] = rec
     return out
 
@@ -373,7 +375,7 @@ def dag_with_starks_leg(ctx, local_rank, in_flight=None, table_mode="per_job"):
             l.close()
     res = runs[0]                       # the FIRST pass is the headline
     secs = res["seconds"]
-    stark_proofs = 64 * 2 + 63 * 1 + 2 + setup["eddsa_outer"]["tables"]
+    stark_proofs = 64 * 2 + 63 * 1 + 2 + setup["eddsa_outer"]["tables"] + (1 if "signature_bus" in setup else 0)
     what_tables = ("EVERY JOB ITS OWN TABLES: a map job's 8 headers / tree nodes, a reduce job's merge nodes, the outer job's authority set and signed "
                    "messages are derived from the request seed and the job's position, and the traces are generated on the GPU (vx_trace_*) INSIDE "
                    "the clock (lane-seconds `trace_generation`), the four batched EdDSA tables included"

@@ -382,7 +382,7 @@ def test_bench_multi_rank_code_path_on_one_device(world):
         ds = line["dag_header_range_512_with_starks"]
         assert "error" not in ds, ds
         assert ds["with_stark_tables"] is True and ds["ranks"] == 2 and ds["dag_seconds"] > 0
-        assert set(ds["rank0_lane_seconds_by_kind"]) >= {"plonky2", "blake2b", "sha256", "sha512", "eddsa"}
+        assert set(ds["rank0_lane_seconds_by_kind"]) >= {"plonky2", "blake2b", "sha256", "signature_bus", "trace_generation"}
         assert ds["root"] != line["dag_header_range_512"]["root"]          # the STARK proofs are part of every job's digest
 
 

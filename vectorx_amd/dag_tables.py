@@ -108,9 +108,9 @@ def build_per_job(ctx, lanes, kinds=("map", "reduce", "outer"), small=False, edd
     """Every job proves tables of ITS OWN inputs, traces generated on the GPU inside the job (vx_trace_*):
       map    : BLAKE2b over its 8 headers (280 blocks each: 2240 compressions, 2^16 rows) + SHA-256 over its 14 tree nodes (2^11 rows);
       reduce : SHA-256 over the 2 nodes that merge its children's commitments (2^9 rows);
-      outer  : SHA-256 over the authority set (300 keys: 600 compressions, 2^16 rows), SHA-512 over the 300 signed messages (2^16
-               rows), the 300 signatures — from their bytes: decompression, digest mod L, S < L inside the table (the FULL program of eddsa_air.py) —
-               in 4 batched EdDSA tables of 2^20 rows (97 instances each).
+      outer  : SHA-256 over the authority set (300 keys: 600 compressions, 2^16 rows) + the justification's 300 signatures verified
+               through tables only, as ONE bus: SHA-512 over R || A || M (2^16 rows), 4 batched EdDSA tables running the full program
+               (2^20 rows, 97 instances each), the link table.
     -> ({kind: [(label, table)]}, [tables to free], setup record)"""
     from . import blake2b_bytes_air, sha256_air, sha512_air, stark_chips
     lanes = list(lanes)
@@ -141,35 +141,35 @@ def build_per_job(ctx, lanes, kinds=("map", "reduce", "outer"), small=False, edd
         if outer_lanes is not None:          # a scheduler that only ever proves the outer job on one lane need not hold its buffers on all
             lanes = list(outer_lanes)
         sha_out = gen("sha256_outer", "sha256", sha256_air, lg, lambda job: job_bytes(job, b"authority set", nkeys, 64))
-        s512 = gen("sha512_outer", "sha512", sha512_air, lg, lambda job: job_bytes(job, b"signed messages", nkeys, 117))
-        # the 300 signatures of the justification: REAL Ed25519 signatures (RFC 8032 signing on the host, untimed: they are the request's
-        # input, not the prover's work), 8 distinct ones; a job takes them in an order of its own
+        # The justification's signatures, verified THROUGH TABLES ONLY and proven as one bus (stark_chips.GeneratedSignatureBus): the SHA-512
+        # table over the 300 signed messages R || A || M (117 bytes each) sends (R, A, digest); four batched EdDSA tables running the FULL
+        # program (decompression, digest mod L, S < L, the group equation) send (A, S, digest, R); the link table joins them and sends what
+        # a verifier holds.  REAL Ed25519 signatures (RFC 8032 signing on the host, untimed: they are the request's input), 8 distinct
+        # ones; a job takes them in an order of its own.
         t0 = time.perf_counter()
         from . import eddsa_air
-        # the FULL program: the instance takes the public key's and R's encodings, S and the SHA-512 digest, and decompresses, reduces
-        # mod L and range-checks inside the table (eddsa_air.Layout(full=True))
-        lay = eddsa_air.Layout(full=True)
         lg_ed = 17 if small else eddsa_log_n
-        base, base_r = stark_chips.eddsa_signatures_full(8 if not small else 2, 8 if not small else 2)
-        stark = eddsa_air.make_stark(lay, lg_ed)
+        base_raw, base_eq = stark_chips.real_signatures(8 if not small else 2)
 
         def sigs_of(job):
-            rot = job_bytes(job, b"signatures", 1, 2)[0]
-            k = int.from_bytes(rot, "little")
-            return [base[(k + i) % len(base)] for i in range(nkeys)]
+            k = int.from_bytes(job_bytes(job, b"signatures", 1, 2)[0], "little")
+            idx = [(k + i) % len(base_raw) for i in range(nkeys)]
+            return [base_raw[i] for i in idx], [base_eq[i] for i in idx]
 
-        ed = stark_chips.GeneratedEddsaTables(ctx, stark, lay, lg_ed, sigs_of, lanes, "eddsa_outer")
+        bus = stark_chips.GeneratedSignatureBus(ctx, sigs_of, lanes, nkeys, sha_log_n=lg, ed_log_n=lg_ed)
         for lane in lanes:
-            ed.prove(lane, None)
-            ed.take_spent(lane)
-            sigs, results = ed.last[id(lane)]
-            want = {b: r for b, r in zip(base, base_r)}
-            assert all(results[i] == want[sg] for i, sg in enumerate(sigs)), "a generated EdDSA instance does not arrive at R"
-        tables.append(ed)
-        rec["eddsa_outer"] = {"rows_log2": lg_ed, "columns": f"{stark.desc.num_columns} + {stark.desc.num_aux_columns}", "signatures_per_table": ed.cap,
-                              "tables": ed.tables_for(nkeys), "signatures": nkeys, "trace": "generated per job on the GPU",
-                              "setup_incl_signing_and_one_proof_per_lane_s": round(time.perf_counter() - t0, 2)}
-        per_kind["outer"] = [("sha256", sha_out), ("sha512", s512), ("eddsa", ed)]
+            bus.prove(lane, None)
+            bus.take_spent(lane)
+            raw, results, sums = bus.last[id(lane)]
+            assert results == [eddsa_air.decompress(sig[:32]) for _, _, sig in raw], "a generated EdDSA instance does not arrive at R"
+        tables.append(bus)
+        rec["signature_bus"] = {"tables": f"SHA-512 bus variant 2^{lg} x 2012 + {bus.ntab} x EdDSA full program 2^{lg_ed} x {bus.lay.N} + link 2^{bus.link_log_n} x 41",
+                                "signatures": nkeys, "signatures_per_eddsa_table": bus.cap, "eddsa_tables": bus.ntab,
+                                "traces": "SHA-512 and EdDSA generated per job on the GPU; link rows written by the host",
+                                "proven_as": "one bus: joint challenges over the 6 trace caps, second rounds on the GPU",
+                                "setup_incl_signing_and_one_bus_per_lane_s": round(time.perf_counter() - t0, 2)}
+        rec["eddsa_outer"] = {"tables": bus.ntab, "rows_log2": lg_ed, "signatures_per_table": bus.cap}
+        per_kind["outer"] = [("sha256", sha_out), ("signature_bus", bus)]
     return per_kind, tables, rec
 
 

@@ -125,6 +125,25 @@ def aux_program():
     return AuxProgram(N, 3, e.w, 3, [[-1, -1, 1]], fraction_out=[0, 1, 2], sum_out=[3], api_sums=(0,))
 
 
+def make_stark(degree_bits: int, **cfg) -> Stark:
+    cfg.setdefault("rate_bits", 1)
+    stark = Stark(degree_bits, N, 0, build_program(), constraint_degree=3, num_aux_columns=NAUX, num_aux_challenges=3, aux_fn=aux_columns,
+                  num_aux_public_inputs=1, **cfg)
+    stark.aux_program = aux_program()
+    return stark
+
+
+def trace_of(rows, degree_bits: int) -> np.ndarray:
+    """[41][2^degree_bits]: one flagged row per signature (`rows` = [row_of(...)]), the rest empty"""
+    n = 1 << degree_bits
+    assert len(rows) <= n - 1
+    t = np.zeros((N, n), dtype=np.uint64)
+    if rows:
+        t[:FLAG, :len(rows)] = np.array(rows, dtype=np.uint64).T
+        t[FLAG, :len(rows)] = 1
+    return t
+
+
 def make_link(rows, degree_bits=None, **cfg):
     """-> (Stark, trace, public inputs (none)) of the link table for `rows` = [row_of(...)] (the last trace row stays empty: it is inert
     in a running sum)"""

@@ -360,6 +360,83 @@ class GeneratedEddsaTables:
         self.bufs = {}
 
 
+class GeneratedSignatureBus:
+    """A job's Ed25519 signatures verified THROUGH TABLES ONLY, proven as one bus (round 5): from the raw (public key, message, signature)
+    triples `sigs_fn(job)` returns —
+      * the SHA-512 table (bus variant) over R || A || M, its trace generated on the GPU (vx_trace_sha512_bus): sends (R, A, digest);
+      * ceil(len / capacity) batched EdDSA tables running the FULL program, traces generated on the GPU (vx_trace_eddsa): each
+        signature sends (A, S, digest, R) after decompressing both points, reducing the digest mod L and checking S < L;
+      * the link table (40 words per signature, written by the host): joins the two on the digest, sends (A, S, R);
+    all committed first, then the joint challenges, every second round on the GPU, one proof per table (prove_bus_device).  What leaves the
+    bus unbalanced is the link table's sends: the bytes of the public keys and signatures — the closing sum the job's plonky2 circuit
+    would take as the statement.  One set of buffers per lane."""
+
+    def __init__(self, ctx, sigs_fn, lanes, nsigs: int, sha_log_n: int = 16, ed_log_n: int = 20, name="signature_bus"):
+        from . import eddsa_air as ea
+        from . import sha512_air as s5
+        from . import sig_link_air as link
+        self.ctx, self.sigs_fn, self.name = ctx, sigs_fn, name
+        self.lay = ea.Layout(full=True)
+        self.sha_log_n, self.ed_log_n = sha_log_n, ed_log_n
+        self.link_log_n = max(4, (nsigs + 1).bit_length())
+        self.cap = ea.capacity(self.lay, ed_log_n)
+        self.ntab = max(1, -(-nsigs // self.cap))
+        self.sha = s5.make_stark(sha_log_n, bus=True)
+        self.ed = ea.make_stark(self.lay, ed_log_n)
+        self.link = link.make_stark(self.link_log_n)
+        self._link_mod = link
+        sizes = [(2012, self.sha.desc.num_aux_columns, sha_log_n)] + [(self.lay.N, self.ed.desc.num_aux_columns, ed_log_n)] * self.ntab \
+            + [(link.N, self.link.desc.num_aux_columns, self.link_log_n)]
+        self.bufs = {id(c): [(ctx.alloc(nc * (8 << lg)), ctx.alloc(max(8, na * (8 << lg)))) for nc, na, lg in sizes] for c in lanes}
+        self.spent, self.last = {}, {}
+
+    def prove(self, ctx=None, job=None) -> bytes:
+        from . import eddsa_air as ea
+        c = self.ctx if ctx is None else ctx
+        bufs = self.bufs[id(c)]
+        t0 = time.perf_counter()
+        raw, eq = self.sigs_fn(job)                     # [(pk, msg, sig)], [((ax, ay), S, h, digest)]
+        nopi = np.zeros(0, dtype=np.uint64)
+        pis, digests = c.trace_hash_table("sha512_bus", self.sha_log_n, [sig[:32] + pk + msg for pk, msg, sig in raw], bufs[0][0])
+        items = [(self.sha, bufs[0][0], pis, bufs[0][1])]
+        results = []
+        for t in range(self.ntab):
+            results += c.trace_eddsa_table(self.ed_log_n, 256, eq[t * self.cap:(t + 1) * self.cap], bufs[1 + t][0], full=True)
+            items.append((self.ed, bufs[1 + t][0], nopi, bufs[1 + t][1]))
+        rows = [self._link_mod.row_of(pk, sig, dg) for (pk, _, sig), dg in zip(raw, digests)]
+        c.upload(bufs[-1][0], self._link_mod.trace_of(rows, self.link_log_n))
+        items.append((self.link, bufs[-1][0], nopi, bufs[-1][1]))
+        gen = time.perf_counter() - t0
+        proofs, _, sums = prove_bus_device(c, items)
+        self.spent[id(c)] = [("trace_generation", gen)]
+        self.last[id(c)] = (raw, results, sums)
+        return b"".join(proofs)
+
+    def take_spent(self, ctx=None):
+        return self.spent.pop(id(self.ctx if ctx is None else ctx), None)
+
+    def free(self):
+        for pairs in self.bufs.values():
+            for a, b in pairs:
+                self.ctx.free(a)
+                self.ctx.free(b)
+        self.bufs = {}
+
+
+def real_signatures(distinct: int = 8, seed: int = 2024):
+    """`distinct` real Ed25519 signatures (fresh keys, RFC 8032 signing on the host) of 53-byte messages — the size of VectorX's precommit
+    message, so that R || A || M is 117 bytes — as raw bytes AND as the full program's inputs: -> ([(pk, msg, sig)], [((ax, ay), S, h, digest)])"""
+    from . import eddsa_air as ea
+    raw, eq = [], []
+    for i in range(distinct):
+        sk = bytes([(seed + 7 * i + j) & 255 for j in range(32)])
+        msg = (b"precommit %d " % i).ljust(53, b".")
+        pk, sig = ea.sign(sk, msg)
+        raw.append((pk, msg, sig))
+        eq.append(ea.equation_inputs_full(pk, msg, sig))
+    return raw, eq
+
+
 def eddsa_signatures(count: int, distinct: int = 8, seed: int = 2024):
     """`count` signature equations (A, S, h) cycling over `distinct` real Ed25519 signatures (fresh keys, RFC 8032 signing on the host)
     -> (sigs, expected R per entry)"""
