@@ -176,7 +176,7 @@ def dag_pool_legs(pool, with_starks=True, passes=2):
                                   "NOT the contract's timed region")
         rec["tables"] = tables
         rec["stark_proofs"] = spec.num_map * 2 + (spec.num_map - 1) + 2 + ((tables or {}).get("eddsa_outer", {}).get("tables", 0)) \
-            + (1 if "signature_bus" in (tables or {}) else 0)
+            + (2 if "signature_bus" in (tables or {}) else 0)
         out["dag_header_range_512_with_starks"] = rec
     return out
 
@@ -375,7 +375,7 @@ def dag_with_starks_leg(ctx, local_rank, in_flight=None, table_mode="per_job"):
             l.close()
     res = runs[0]                       # the FIRST pass is the headline
     secs = res["seconds"]
-    stark_proofs = 64 * 2 + 63 * 1 + 2 + setup["eddsa_outer"]["tables"] + (1 if "signature_bus" in setup else 0)
+    stark_proofs = 64 * 2 + 63 * 1 + 2 + setup["eddsa_outer"]["tables"] + (2 if "signature_bus" in setup else 0)
     what_tables = ("EVERY JOB ITS OWN TABLES: a map job's 8 headers / tree nodes, a reduce job's merge nodes, the outer job's authority set and signed "
                    "messages are derived from the request seed and the job's position, and the traces are generated on the GPU (vx_trace_*) INSIDE "
                    "the clock (lane-seconds `trace_generation`), the four batched EdDSA tables included"

@@ -45,3 +45,35 @@ def test_pool_root_equals_the_one_process_root_with_per_job_tables(ctx):
         for t in tables:
             t.free()
     assert one["root"] == with_tables["root"]
+
+
+def test_signature_bus_balances_only_when_every_signature_verifies(ctx):
+    """The outer job's bus (SHA-512 bus variant + EdDSA full program + link + verifier sink, traces generated on the device): every proof
+    verifies under the joint challenges and the closing sums add up to zero; with one signature's S replaced by S + 1 the EdDSA table
+    arrives at another R, every table still proves, and the bus no longer balances — the verifier refuses the set."""
+    import vectorx_amd as vx
+    from vectorx_amd import eddsa_air as ea
+    from vectorx_amd import stark_chips
+    raw, eq = stark_chips.real_signatures(2)
+    state = {"raw": raw, "eq": eq}
+    bus = stark_chips.GeneratedSignatureBus(ctx, lambda job: (state["raw"], state["eq"]), [ctx], 2, sha_log_n=11, ed_log_n=17)
+    try:
+        blob = bus.prove(ctx, None)
+        descs, proofs = bus.last_bus[id(ctx)]
+        assert blob == b"".join(proofs) and len(proofs) == 4
+        sums = vx.stark_verify_bus(descs, proofs)
+        assert bus.closed(ctx) and sum(int(x) for x in sums[:, 0]) % ea.P == 0 and all(int(x) != 0 for x in sums[:, 0])
+        assert bus.last[id(ctx)][1] == [ea.decompress(sig[:32]) for _, _, sig in raw]
+        assert bus.prove(ctx, None) == blob                                       # deterministic
+        pk, msg, sig = raw[1]
+        forged = sig[:32] + ((int.from_bytes(sig[32:], "little") + 1) % ea.ELL).to_bytes(32, "little")
+        state["raw"] = [raw[0], (pk, msg, forged)]
+        state["eq"] = [eq[0], ea.equation_inputs_full(pk, msg, forged, check=False)]
+        bus.prove(ctx, None)
+        assert bus.last[id(ctx)][1][1] != ea.decompress(sig[:32])
+        assert not bus.closed(ctx)
+        descs, proofs = bus.last_bus[id(ctx)]
+        with pytest.raises(RuntimeError):
+            vx.stark_verify_bus(descs, proofs)
+    finally:
+        bus.free()

@@ -777,7 +777,6 @@ def stark_verify_bus(tables, proofs) -> np.ndarray:
 
 def stark_joint_challenges(caps, cap_heights, n: int) -> np.ndarray:
     """`vx_stark_joint_challenges`: the challenges of a cross-table argument, from every table's trace cap (table order matters)."""
-    arr = (ctypes.c_void_p * len(caps))(*[np.ascontiguousarray(c, dtype=np.uint64).ctypes.data for c in caps])
     keep = [np.ascontiguousarray(c, dtype=np.uint64) for c in caps]
     arr = (ctypes.c_void_p * len(caps))(*[k.ctypes.data for k in keep])
     hs = (ctypes.c_int32 * len(caps))(*cap_heights)

@@ -144,7 +144,7 @@ def build_per_job(ctx, lanes, kinds=("map", "reduce", "outer"), small=False, edd
         # The justification's signatures, verified THROUGH TABLES ONLY and proven as one bus (stark_chips.GeneratedSignatureBus): the SHA-512
         # table over the 300 signed messages R || A || M (117 bytes each) sends (R, A, digest); four batched EdDSA tables running the FULL
         # program (decompression, digest mod L, S < L, the group equation) send (A, S, digest, R); the link table joins them and sends what
-        # a verifier holds.  REAL Ed25519 signatures (RFC 8032 signing on the host, untimed: they are the request's input), 8 distinct
+        # a verifier holds; the sink receives it from the bytes of the keys and signatures alone.  REAL Ed25519 signatures (RFC 8032 signing on the host, untimed: they are the request's input), 8 distinct
         # ones; a job takes them in an order of its own.
         t0 = time.perf_counter()
         from . import eddsa_air
@@ -162,11 +162,12 @@ def build_per_job(ctx, lanes, kinds=("map", "reduce", "outer"), small=False, edd
             bus.take_spent(lane)
             raw, results, sums = bus.last[id(lane)]
             assert results == [eddsa_air.decompress(sig[:32]) for _, _, sig in raw], "a generated EdDSA instance does not arrive at R"
+            assert bus.closed(lane), "the signature bus does not balance"
         tables.append(bus)
-        rec["signature_bus"] = {"tables": f"SHA-512 bus variant 2^{lg} x 2012 + {bus.ntab} x EdDSA full program 2^{lg_ed} x {bus.lay.N} + link 2^{bus.link_log_n} x 41",
+        rec["signature_bus"] = {"tables": f"SHA-512 bus variant 2^{lg} x 2012 + {bus.ntab} x EdDSA full program 2^{lg_ed} x {bus.lay.N} + link 2^{bus.link_log_n} x 41 + verifier sink 2^{bus.link_log_n} x 26",
                                 "signatures": nkeys, "signatures_per_eddsa_table": bus.cap, "eddsa_tables": bus.ntab,
                                 "traces": "SHA-512 and EdDSA generated per job on the GPU; link rows written by the host",
-                                "proven_as": "one bus: joint challenges over the 6 trace caps, second rounds on the GPU",
+                                "proven_as": "one bus: joint challenges over the 7 trace caps; the closing sums add up to 0, second rounds on the GPU",
                                 "setup_incl_signing_and_one_bus_per_lane_s": round(time.perf_counter() - t0, 2)}
         rec["eddsa_outer"] = {"tables": bus.ntab, "rows_log2": lg_ed, "signatures_per_table": bus.cap}
         per_kind["outer"] = [("sha256", sha_out), ("signature_bus", bus)]

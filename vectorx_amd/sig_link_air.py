@@ -78,6 +78,9 @@ def row_of(public_key: bytes, signature: bytes, digest: bytes) -> list:
     return le(public_key) + le(signature[32:])[::-1] + le(digest) + le(signature[:32])
 
 
+NVERIFIER = len(FORMATS["verifier"][0]) + 1      # 24 words + the format tag
+
+
 def verifier_tuple(public_key: bytes, signature: bytes) -> list:
     """what the verifier's side of the bus receives: the bytes of the public key and of the signature"""
     r = row_of(public_key, signature, bytes(64))

@@ -264,11 +264,14 @@ def prove_bus_device(ctx, items, cap: int = 1 << 25):
         caps = [st.session_trace_cap(sess) for (st, _, _, _), sess in zip(items, sessions)]
         shared = vx.stark_joint_challenges(caps, [st.desc.cap_height for st, _, _, _ in items], n_shared.pop())
         proofs, sums = [], []
-        for (st, d_trace, _, d_aux), sess in zip(items, sessions):
+        for k, ((st, d_trace, _, d_aux), sess) in enumerate(zip(items, sessions)):
             vx._chk(L.vx_stark_set_aux_challenges(sess, shared.ctypes.data))
             if st.aux_program is None:
                 raise RuntimeError("prove_bus_device: a table without an AuxProgram cannot compute its second round on the GPU")
-            api = st.run_aux_gpu(ctx, d_trace, shared, d_aux)
+            try:
+                api = st.run_aux_gpu(ctx, d_trace, shared, d_aux)
+            except vx.VxError as e:
+                raise vx.VxError(e.code, f"bus table {k} of {len(items)} ({st.desc.num_columns} columns, 2^{st.desc.degree_bits} rows): {e}") from None
             out = np.empty(cap, dtype=np.uint8)
             nb = ctypes.c_size_t(cap)
             rc = L.vx_stark_finish2(sess, vp(d_aux), 1, None if api.size == 0 else api.ctypes.data, None, out.ctypes.data, ctypes.byref(nb))
@@ -368,8 +371,11 @@ class GeneratedSignatureBus:
         signature sends (A, S, digest, R) after decompressing both points, reducing the digest mod L and checking S < L;
       * the link table (40 words per signature, written by the host): joins the two on the digest, sends (A, S, R);
     all committed first, then the joint challenges, every second round on the GPU, one proof per table (prove_bus_device).  What leaves the
-    bus unbalanced is the link table's sends: the bytes of the public keys and signatures — the closing sum the job's plonky2 circuit
-    would take as the statement.  One set of buffers per lane."""
+    the verifier's sink (25 words per signature, written by the host from the bytes of the public keys and signatures alone): receives
+        exactly what the link table sends — the statement, standing where the job's plonky2 circuit would read it;
+    all committed first, then the joint challenges, every second round on the GPU, one proof per table (prove_bus_device).  The closing
+    sums of the 3 + ceil(len / capacity) tables add up to zero exactly when every signature the sink names went through all of them —
+    `last[lane]` keeps them and `closed(lane)` says so.  One set of buffers per lane."""
 
     def __init__(self, ctx, sigs_fn, lanes, nsigs: int, sha_log_n: int = 16, ed_log_n: int = 20, name="signature_bus"):
         from . import eddsa_air as ea
@@ -384,11 +390,12 @@ class GeneratedSignatureBus:
         self.sha = s5.make_stark(sha_log_n, bus=True)
         self.ed = ea.make_stark(self.lay, ed_log_n)
         self.link = link.make_stark(self.link_log_n)
+        self.sink = ea.make_sink(self.lay, [], degree_bits=self.link_log_n, ntuple=link.NVERIFIER)[0]
         self._link_mod = link
         sizes = [(2012, self.sha.desc.num_aux_columns, sha_log_n)] + [(self.lay.N, self.ed.desc.num_aux_columns, ed_log_n)] * self.ntab \
-            + [(link.N, self.link.desc.num_aux_columns, self.link_log_n)]
+            + [(link.N, self.link.desc.num_aux_columns, self.link_log_n), (link.NVERIFIER + 1, self.sink.desc.num_aux_columns, self.link_log_n)]
         self.bufs = {id(c): [(ctx.alloc(nc * (8 << lg)), ctx.alloc(max(8, na * (8 << lg)))) for nc, na, lg in sizes] for c in lanes}
-        self.spent, self.last = {}, {}
+        self.spent, self.last, self.last_bus = {}, {}, {}
 
     def prove(self, ctx=None, job=None) -> bytes:
         from . import eddsa_air as ea
@@ -404,13 +411,24 @@ class GeneratedSignatureBus:
             results += c.trace_eddsa_table(self.ed_log_n, 256, eq[t * self.cap:(t + 1) * self.cap], bufs[1 + t][0], full=True)
             items.append((self.ed, bufs[1 + t][0], nopi, bufs[1 + t][1]))
         rows = [self._link_mod.row_of(pk, sig, dg) for (pk, _, sig), dg in zip(raw, digests)]
-        c.upload(bufs[-1][0], self._link_mod.trace_of(rows, self.link_log_n))
-        items.append((self.link, bufs[-1][0], nopi, bufs[-1][1]))
+        c.upload(bufs[-2][0], self._link_mod.trace_of(rows, self.link_log_n))
+        items.append((self.link, bufs[-2][0], nopi, bufs[-2][1]))
+        sink_t = np.zeros((self._link_mod.NVERIFIER + 1, 1 << self.link_log_n), dtype=np.uint64)
+        sink_t[:-1, :len(raw)] = np.array([self._link_mod.verifier_tuple(pk, sig) for pk, _, sig in raw], dtype=np.uint64).T
+        sink_t[-1, :len(raw)] = 1
+        c.upload(bufs[-1][0], sink_t)
+        items.append((self.sink, bufs[-1][0], nopi, bufs[-1][1]))
         gen = time.perf_counter() - t0
         proofs, _, sums = prove_bus_device(c, items)
         self.spent[id(c)] = [("trace_generation", gen)]
         self.last[id(c)] = (raw, results, sums)
+        self.last_bus[id(c)] = ([(st, pi) for st, _, pi, _ in items], proofs)      # what vx.stark_verify_bus takes
         return b"".join(proofs)
+
+    def closed(self, ctx=None) -> bool:
+        """the last bus proven on this lane balances: the closing sums of all its tables add up to 0 mod p"""
+        sums = self.last[id(self.ctx if ctx is None else ctx)][2]
+        return sum(int(x) for s_ in sums for x in s_) % 0xFFFFFFFF00000001 == 0
 
     def take_spent(self, ctx=None):
         return self.spent.pop(id(self.ctx if ctx is None else ctx), None)
