@@ -11,7 +11,7 @@ import pytest
 
 import oracle_lib
 import vectorx_amd as vx
-from test_sha256_air import eval_program, violations
+from test_sha256_air import caught_near, eval_program, violations
 from vectorx_amd import eddsa_air as ea
 
 P = ea.P
@@ -85,7 +85,7 @@ def test_every_constraint_vanishes_and_a_corrupted_cell_of_every_column_class_is
         bad = t.copy()
         bad[col, row] = (int(bad[col, row]) + 1) % P
         a, cl = ea.aux_columns(lay, bad, CHAL)                           # honest second-round columns for the corrupted trace
-        assert violations(eval_program(prog, bad, a, CHAL, cl), n), (col, row)
+        assert caught_near(prog, bad, a, CHAL, cl, row, n), (col, row)
     # a carry limb outside the table with the carry itself unchanged (low limb + 2^LB, high limb - 1): every arithmetic relation still
     # holds and the helper columns are recomputed honestly — only the closing of the lookup's running sum notices
     bad = t.copy()

@@ -13,7 +13,7 @@ import pytest
 import oracle_lib
 import vectorx_amd as vx
 from test_eddsa_air import CHAL, RFC8032
-from test_sha256_air import eval_program, violations
+from test_sha256_air import caught_near, eval_program, violations
 from vectorx_amd import eddsa_air as ea
 
 P = ea.P
@@ -117,7 +117,8 @@ def test_sign_bits_and_canonical_coordinates(full):
                      (C.Z, 21), (C.Z + 1, 21), (C.Q, 17), (C.Z + 5, 25), (C.REG + C.NL * 6 + 1, 28), (C.Z, C.L - 2), (C.SW + 8, 29), (C.SW, 30)]:
         bad = t.copy()
         bad[col, row] = (int(bad[col, row]) + 1) % P
-        assert _violations(lay, prog, bad), (col, row)
+        a_, cl_ = ea.aux_columns(lay, bad, CHAL)
+        assert caught_near(prog, bad, a_, CHAL, cl_, row, bad.shape[1]), (col, row)
 
 
 def test_oracle_proves_the_full_table_and_the_bus_judges_the_bytes(oracle):

@@ -67,6 +67,22 @@ def violations(cons, n):
     return bad
 
 
+def caught_near(prog, trace, aux, chal, pis, row, n) -> bool:
+    """Is a trace that differs from a valid one around `row` only refused?  The constraints are local (a row and its successor), so
+    they are evaluated on a window around `row`, on the first rows (first-row kinds) and on the last rows (last-row kinds: where a
+    running sum has to close) instead of on all n rows — the same verdict as `violations` over the whole trace at a fraction of the
+    time.  The window's own wrap-around row is not a transition of the trace and is left out."""
+    def part(lo, hi):
+        return eval_program(prog, np.ascontiguousarray(trace[:, lo:hi]), np.ascontiguousarray(aux[:, lo:hi]), chal, pis), hi - lo
+    cons, w = part(max(0, row - 2), min(n, row + 3))
+    for kind, v in cons:
+        if (kind == vx.VX_AIR_ALL_ROWS and v.any()) or (kind == vx.VX_AIR_TRANSITION and v[:w - 1].any()):
+            return True
+    head, _ = part(0, min(n, 4))
+    tail, wt = part(max(0, n - 4), n)
+    return any(kind == vx.VX_AIR_FIRST_ROW and int(v[0]) for kind, v in head) or any(kind == vx.VX_AIR_LAST_ROW and int(v[wt - 1]) for kind, v in tail)
+
+
 @pytest.fixture(scope="module")
 def sha9():
     prog, npush = sha.build_program()
