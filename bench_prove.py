@@ -119,7 +119,7 @@ def dag_leg(ctx, local_rank, in_flight=3):
             "dag_seconds_all_passes": [[sch, round(r["seconds"], 4)] for sch, r in zip(schedules, runs)],
             "per_layer_ms": [(l["kind"], l["jobs"], round(l["ms"], 1)) for l in res["per_layer"]],
             "non_map_layers_ms": round(sum(l["ms"] for l in res["per_layer"] if l["kind"] != "map"), 1),
-            "setup_seconds_untimed": round(time.perf_counter() - t_setup - sum(r["seconds"] for r in runs), 2), "root": res["root"].hex(),
+            "setup_seconds_untimed": round(time.perf_counter() - t_setup - sum(r["seconds"] for r in runs), 2), "root": res["root"][:32].hex(),
             "what": "64 map (2^18 rows) + 63 reduce (2^16) + 1 outer (2^19) plonky2 proofs, the FIRST pass with layer barriers (per_layer_ms add up to "
                     "dag_seconds; the dependency-driven pass is listed in dag_seconds_all_passes only), synthetic stand-in circuits; witnesses "
                     "HBM-resident (4 base witnesses per circuit kind, each job's own public inputs patched in: the proving work of 128 distinct "
@@ -155,7 +155,7 @@ def dag_pool_legs(pool, with_starks=True, passes=2):
                 "per_layer_ms_is": "first start to last end of a layer's jobs; layers overlap under the dependency-driven schedule",
                 "per_layer_ms_layer_barriers": [(l["kind"], l["jobs"], round(l["ms"], 1)) for l in runs[-1]["per_layer"]],
                 "non_map_layers_ms_layer_barriers": round(sum(l["ms"] for l in runs[-1]["per_layer"] if l["kind"] != "map"), 1),
-                "jobs_by_worker": res["jobs_by_worker"], "root": res["root"].hex(), "what": what}
+                "jobs_by_worker": res["jobs_by_worker"], "root": res["root"][:32].hex(), "what": what}
 
     sizes = f"{spec.num_map} map (2^{spec.map_log_n} rows) + {spec.num_map - 1} reduce (2^{spec.reduce_log_n}) + 1 outer (2^{spec.outer_log_n}) plonky2 proofs"
     schedules = ["dependency"] * passes + ["layers"]
@@ -164,21 +164,41 @@ def dag_pool_legs(pool, with_starks=True, passes=2):
     out["dag_header_range_512"] = record(runs, sizes + ", synthetic stand-in circuits; witnesses HBM-resident (4 base witnesses per circuit kind and lane, "
                                          "each job's own public inputs patched in); NOT the contract's timed region")
     if with_starks:
+        t0 = time.perf_counter()
+        pool.load_request(b"bench request")          # the request's input (header chain, justification) in the workers' host memory
+        load_s = time.perf_counter() - t0
         runs = [pool.run(b"bench request", schedule=sch) for sch in schedules]
         assert len({r["root"] for r in runs}) == 1
         tables = next((r.get("tables") for r in ready if r.get("worker") == 0), None)
         rec = record(runs, sizes + ", EACH JOB WITH ITS STARK TABLES (own AIRs standing in for Curta's chips): map = BLAKE2b over the job's own 8 headers "
-                                  "(2240 compressions, 2^16 rows) + SHA-256 over its 14 tree nodes; reduce = SHA-256 over its 2 merge nodes; outer = SHA-256 over "
-                                  "300 keys + the 300 signatures verified THROUGH TABLES ONLY as one bus (SHA-512 over R || A || M, 4 batched EdDSA tables "
-                                  "running the full program, the link table).  Per-job tables: inputs derived from the "
-                                  "request seed and the job's position, TRACES GENERATED ON THE GPU INSIDE THE CLOCK (vx_trace_*: lane-seconds "
-                                  "`trace_generation`), the four EdDSA tables included.  The STARK proofs are part of a job's digest; "
-                                  "NOT the contract's timed region")
+                                  "(2240 compressions, 2^16 rows) + SHA-256 over the 14 nodes of their state / data root trees; reduce = SHA-256 over its "
+                                  "children's roots; outer = SHA-256 over the authority set commitment chain (300 keys) + the 300 signatures of the precommit "
+                                  "verified THROUGH TABLES ONLY as one bus (SHA-512 over R || A || M, 4 batched EdDSA tables running the full program, the link "
+                                  "table, the verifier's sink).  ONE SYNTHETIC REQUEST (vectorx_amd/header_range.py: 512 headers of 35 840 bytes chained by their "
+                                  "hashes, real Ed25519 authorities, a signed precommit), resident in host memory when the clock starts; every job hashes ITS "
+                                  "part of it and its children's statements, TRACES GENERATED ON THE GPU INSIDE THE CLOCK (vx_trace_*: lane-seconds "
+                                  "`trace_generation`), and states what the reference's circuit asserts (linked headers, merged roots, the justification) from "
+                                  "the tables' digests: the outer job's statement is the function's 96 OUTPUT BYTES (`output`), equal to the host computation "
+                                  "over the same request.  The STARK proofs and the statement are part of a job's digest; NOT the contract's timed region")
         rec["tables"] = tables
+        rec["request_load_seconds_untimed"] = round(load_s, 2)
+        rec.update(statement_record(pool.cfg, spec, b"bench request", runs[0]["root"]))
         rec["stark_proofs"] = spec.num_map * 2 + (spec.num_map - 1) + 2 + ((tables or {}).get("eddsa_outer", {}).get("tables", 0)) \
             + (2 if "signature_bus" in (tables or {}) else 0)
         out["dag_header_range_512_with_starks"] = rec
     return out
+
+
+def statement_record(cfg, spec, seed: bytes, root: bytes) -> dict:
+    """The function I/O of a DAG run with per-job tables: the request's 80 input bytes, the 96 output bytes the outer job stated (the
+    tail of the root record) and whether they equal the host computation over the same request (hashlib + avail_codec alone)."""
+    from vectorx_amd import dag_tables
+    from vectorx_amd import header_range as hr
+    if cfg.get("table_mode") != "per_job" or len(root) <= 32:
+        return {}
+    req = hr.cached_request(seed, **dag_tables.request_shape(cfg["small_tables"], spec.num_map, cfg.get("num_headers")))
+    return {"input": req.input_bytes.hex(), "output": root[32:].hex(), "output_equals_host_computation": root[32:] == hr.expected_output(req),
+            "output_is": "abi.encode(target_header_hash, state_root_commitment, data_root_commitment) — /root/reference/circuits/header_range.rs:56-58"}
 
 
 def guarded_collective_leg(dist, fn):
@@ -313,7 +333,7 @@ def dag_leg_ranks(ctx, args, local_rank, dist, device, in_flight=3, with_starks=
             "plonky2_proofs_per_sec": res["proofs"] / secs, "in_flight_per_gpu": in_flight, "schedule": "layer barriers", "scaling": "strong",
             "dag_seconds_all_passes": [round(r["seconds"], 4) for r in runs],
             "per_layer_ms": [(l["kind"], l["jobs"], round(l["ms"], 1)) for l in res["per_layer"]],
-            "setup_seconds_untimed": round(time.perf_counter() - t_setup - sum(r["seconds"] for r in runs), 2), "root": res["root"].hex(),
+            "setup_seconds_untimed": round(time.perf_counter() - t_setup - sum(r["seconds"] for r in runs), 2), "root": res["root"][:32].hex(),
             "backend": dist.get_backend(), "with_stark_tables": bool(with_starks),
             "rank0_lane_seconds_by_kind": {k: round(v, 4) for k, v in sorted(res["split"].items())} if with_starks else None,
             "what": f"{num_map} map (2^{lm} rows) + {num_map - 1} reduce (2^{lr}) + 1 outer (2^{lo}) plonky2 proofs over all ranks"
@@ -386,7 +406,7 @@ def dag_with_starks_leg(ctx, local_rank, in_flight=None, table_mode="per_job"):
             "lane_seconds_by_kind": {k: round(v, 4) for k, v in sorted(res["split"].items())},
             "per_layer_ms": [(l["kind"], l["jobs"], round(l["ms"], 1)) for l in res["per_layer"]],
             "tables": setup, "setup_seconds_untimed": round(time.perf_counter() - t_setup - sum(r["seconds"] for r in runs), 2),
-            "root": res["root"].hex(),
+            "root": res["root"][:32].hex(),
             "what": "64 map jobs = plonky2 2^18 + BLAKE2b table (2240 compressions: 2^16 rows of the byte / XOR-lookup table) + SHA-256 table 2^11; 63 reduce jobs = plonky2 2^16 + SHA-256 "
                     "table 2^9; outer = plonky2 2^19 + SHA-256 chain 2^16 + SHA-512 2^16 + 4 batched EdDSA tables 2^20 (388 signature slots for 300 "
                     "signatures); own AIRs standing in for Curta's chips, synthetic stand-in circuits; " + what_tables + "; the STARK proofs are part of a "

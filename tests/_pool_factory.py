@@ -32,6 +32,35 @@ class FakeProver:
         return self._tables(key, input_seed)
 
 
+class StatingProver(FakeProver):
+    """a prover that STATES something (mapreduce.with_statement / record_of) and reads what its children stated (`takes_children`): a
+    map job states its index, a reduce job the hash of its children's statements, the outer job its child's statement reversed"""
+    takes_children = True
+    emits_statement = True
+
+    def _statement(self, key, children):
+        import struct
+        if self.kind == "map":
+            return struct.pack("<I", key[1]) * 2
+        kids = [bytes(r)[32:] for r in children]
+        assert all(len(k) > 0 for k in kids) and len(kids) == (1 if self.kind == "outer" else 2), (self.kind, key, [len(bytes(r)) for r in children])
+        return kids[0][::-1] if self.kind == "outer" else hashlib.sha256(b"".join(kids)).digest()
+
+    def prove(self, key, public_inputs, lane=0, input_seed=b"", spent_out=None, with_tables=True, children=()):
+        proof = super().prove(key, public_inputs, lane, input_seed, spent_out, with_tables)
+        return proof + self.prove_statement(key, lane, input_seed, children) if with_tables else proof
+
+    def prove_statement(self, key, lane=0, input_seed=b"", children=(), spent_out=None):
+        from vectorx_amd import mapreduce as mr
+        return mr.with_statement(self._statement(key, children))
+
+
+def make_stating(cfg, device):
+    kinds = ("map", "reduce", "outer") if cfg["worker_index"] == 0 else ("map", "reduce")
+    seen = []
+    return {k: StatingProver(k) for k in kinds}, (lambda: None), {"fake": True, "_preload": seen.append}
+
+
 def make(cfg, device):
     kinds = ("map", "reduce", "outer") if cfg["worker_index"] == 0 else ("map", "reduce")
     return {k: FakeProver(k) for k in kinds}, (lambda: None), {"fake": True}

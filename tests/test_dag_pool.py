@@ -48,6 +48,34 @@ def test_pool_root_equals_the_one_process_root(workers, lanes, with_starks):
         pool.close()
 
 
+def test_statements_travel_from_children_to_parents_in_every_scheduler():
+    """A prover that emits statements: a job's record is its digest followed by its statement, a parent's prover receives its
+    children's records, the root record ends with the outer job's statement — the same in the pool (tables hoisted or not: the
+    statement of the outer job is made when its child is known), and in the one-process schedulers."""
+    import hashlib
+    import struct
+    spec = mr.DagSpec(4, 10, 9, 11)
+    leaves = [struct.pack("<I", j) * 2 for j in range(4)]
+    l1 = [hashlib.sha256(leaves[0] + leaves[1]).digest(), hashlib.sha256(leaves[2] + leaves[3]).digest()]
+    want = hashlib.sha256(l1[0] + l1[1]).digest()[::-1]
+    pool = DagPool(spec, workers_per_device=2, lanes=2, factory="_pool_factory:make_stating", with_starks=True).start()
+    try:
+        pool.wait_ready(timeout=120)
+        pool.load_request(b"r")                                # reaches the factory's hook on every worker; optional
+        a = pool.run(b"r")
+        b = pool.run(b"r", schedule="layers")
+        plain = pool.run(b"r", with_tables=False)
+    finally:
+        pool.close()
+    assert a["outer_tables_hoisted"] and not b["outer_tables_hoisted"]
+    assert a["root"] == b["root"] and a["root"][32:] == want and len(a["root"]) == 64
+    assert [len(r) for r in a["records"][0].values()] == [40] * 4 and len(plain["root"]) == 32
+    make = lambda kind, log_n, jobs: _pool_factory.StatingProver(kind, delay=0.0)      # noqa: E731
+    assert mr.run_dag(spec, make, None, in_flight=2, input_seed=b"r")["root"] == a["root"]
+    assert mr.run_dag(spec, make, None, in_flight=2, input_seed=b"r", barriers=False)["root"] == a["root"]
+    assert mr.run_dag(spec, make, None, in_flight=1, input_seed=b"r")["root"] == a["root"]
+
+
 def test_the_outer_job_goes_to_worker_0_and_a_worker_error_surfaces():
     spec = mr.DagSpec(4, 10, 9, 11)
     pool = DagPool(spec, workers_per_device=2, lanes=1, factory="_pool_factory:make_failing").start()

@@ -1,9 +1,13 @@
 """vectorx_amd/dag_pool.py with the real prover at tiny sizes: two worker PROCESSES of two lanes each on the one GPU, per-job STARK
 tables generated on the device — the root digest must equal the one-process scheduler's (mapreduce.run_dag) for the same request."""
+import hashlib
+
 import pytest
 
 import vectorx_amd as vx
+from vectorx_amd import avail_codec as ac
 from vectorx_amd import dag_tables
+from vectorx_amd import header_range as hr
 from vectorx_amd import mapreduce as mr
 from vectorx_amd.dag_pool import DagPool
 
@@ -17,6 +21,7 @@ def test_pool_root_equals_the_one_process_root_with_per_job_tables(ctx):
     try:
         ready = pool.wait_ready(timeout=1500)
         assert len(ready) == 2 and {r["device"] for r in ready} == {0}
+        pool.load_request(b"request 1")                       # request 2 below is derived inside its first jobs instead
         with_tables = pool.run(b"request 1")
         again = pool.run(b"request 1", schedule="layers")
         assert with_tables["outer_tables_hoisted"] and not again["outer_tables_hoisted"]
@@ -28,9 +33,22 @@ def test_pool_root_equals_the_one_process_root_with_per_job_tables(ctx):
     assert plain["root"] != with_tables["root"]
     assert with_tables["split"].get("trace_generation", 0) > 0 and "trace_generation" not in plain["split"]
     assert min(with_tables["jobs_by_worker"]) > 0
+    # what the DAG STATES: the outer job's statement — the tail of the root record — is the function's 96 output bytes, and they equal
+    # the host computation over the same synthetic request (hashlib over the headers, avail_codec's commitments); every map / reduce
+    # record carries its subchain
+    shape = dag_tables.request_shape(True, spec.num_map)
+    for seed, res in ((b"request 1", with_tables), (b"request 2", other)):
+        req = hr.cached_request(seed, **shape)
+        assert len(res["root"]) == 32 + 96 and res["root"][32:] == hr.expected_output(req)
+        top = hr.Subchain.unpack(res["records"][-2][0][32:])
+        assert (top.num_blocks, top.start_block, top.end_block) == (32, req.trusted_block + 1, req.target_block)
+        assert top.start_parent == ac.unpack_header_range_input(req.input_bytes)["trusted_header"]
+        first = hr.Subchain.unpack(res["records"][0][0][32:])
+        assert first.num_blocks == 8 and first.end_header_hash == hashlib.blake2b(req.headers[7], digest_size=32).digest()
+    assert len(plain["root"]) == 32
 
     # the same request through ONE process: run_dag with a GpuProver per kind and the same per-job tables
-    per_kind, tables, _ = dag_tables.build(ctx, small=True, mode="per_job", lanes=[ctx])
+    per_kind, tables, _ = dag_tables.build(ctx, small=True, mode="per_job", lanes=[ctx], num_map=spec.num_map)
     provers = {}
 
     def make(kind, log_n, jobs):
@@ -45,6 +63,39 @@ def test_pool_root_equals_the_one_process_root_with_per_job_tables(ctx):
         for t in tables:
             t.free()
     assert one["root"] == with_tables["root"]
+
+
+def test_a_range_shorter_than_the_capacity_and_a_broken_chain(ctx):
+    """19 of 32 headers: the third map job is enabled up to the target block, the fourth not at all (empty headers, zero leaves, an
+    inactive right subchain in the reduce above it) — the output still equals the host computation.  And a request whose header chain
+    is broken (one parent hash changed after the fact) is refused by the map job that sees it: StatementError, where the reference's
+    witness generation would fail its link check."""
+    spec = mr.DagSpec(4, 10, 9, 11)
+    shape = dag_tables.request_shape(True, spec.num_map, 19)
+    per_kind, tables, _ = dag_tables.build(ctx, small=True, mode="per_job", lanes=[ctx], num_map=spec.num_map, num_headers=19)
+    provers = {}
+
+    def make(kind, log_n, jobs):
+        provers[kind] = mr.GpuProver(ctx, kind, log_n, jobs, spec.poseidon_percent, distinct_witnesses=2, starks=per_kind[kind])
+        return provers[kind]
+
+    try:
+        res = mr.run_dag(spec, make, None, ctx.sync, in_flight=1, input_seed=b"short range")
+        req = hr.cached_request(b"short range", **shape)
+        assert req.target_block - req.trusted_block == 19 and req.headers[19:] == [b""] * 13
+        assert res["root"][32:] == hr.expected_output(req)
+        # break the chain inside batch 1 of another request and prove that batch alone
+        bad = hr.cached_request(b"broken", **shape)
+        h = bytearray(bad.headers[10])
+        h[5] ^= 1
+        bad.headers[10] = bytes(h)
+        with pytest.raises(hr.StatementError, match="not linked"):
+            provers["map"].prove((0, 1), mr.child_inputs(0, 1, {}, b"broken"), 0, input_seed=b"broken")
+    finally:
+        for p in provers.values():
+            p.free()
+        for t in tables:
+            t.free()
 
 
 def test_signature_bus_balances_only_when_every_signature_verifies(ctx):

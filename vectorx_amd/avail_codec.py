@@ -74,6 +74,33 @@ def encode_precommit(block_hash: bytes, block_number: int, rnd: int, authority_s
     return bytes([1]) + block_hash + struct.pack("<IQQ", block_number, rnd, authority_set_id)
 
 
+HASH_SIZE = 32
+DATA_ROOT_OFFSET_FROM_END = 32        # /root/reference/circuits/consts.rs:3
+
+
+def encode_header(parent_hash: bytes, block_number: int, state_root: bytes, middle: bytes, data_root: bytes) -> bytes:
+    """An Avail header as far as the circuits look at it (decode_header below): parent hash | compact block number | state root |
+    ... | data root in the last 32 bytes.  `middle` stands for everything in between (extrinsics root, digest logs, the rest of the
+    extension)."""
+    if len(parent_hash) != 32 or len(state_root) != 32 or len(data_root) != 32:
+        raise ValueError("hashes are 32 bytes")
+    return parent_hash + encode_compact_u32(block_number) + state_root + bytes(middle) + data_root
+
+
+def decode_header(header: bytes) -> dict:
+    """`decode_header` (/root/reference/circuits/builder/decoder.rs:104-158): {parent_hash, block_number, state_root, data_root}.  The
+    circuit reads a zero-padded array of MAX_HEADER_SIZE bytes and a size; an EMPTY header (size 0: the padding of a range shorter than
+    the circuit's capacity) decodes to zeros, as the all-zero array does there."""
+    if len(header) == 0:
+        return {"parent_hash": bytes(32), "block_number": 0, "state_root": bytes(32), "data_root": bytes(32)}
+    if len(header) < HASH_SIZE + 1 + HASH_SIZE + DATA_ROOT_OFFSET_FROM_END:
+        raise ValueError("header too short")
+    number, _, width = decode_compact_u32(header[HASH_SIZE:HASH_SIZE + MAX_COMPACT_UINT_BYTES])
+    start = HASH_SIZE + width
+    return {"parent_hash": header[:HASH_SIZE], "block_number": number, "state_root": header[start:start + HASH_SIZE],
+            "data_root": header[len(header) - DATA_ROOT_OFFSET_FROM_END:]}
+
+
 def authority_set_commitment(pubkeys) -> bytes:
     """H(H(...H(pk_0) || pk_1 ...) || pk_{k-1}) with H = SHA-256; the empty set hashes to the empty string."""
     h = b""

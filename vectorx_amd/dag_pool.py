@@ -41,14 +41,15 @@ _ROOT = Path(__file__).resolve().parent.parent
 
 class DagPool:
     def __init__(self, spec: mr.DagSpec, devices=(0,), workers_per_device: int = 2, lanes: int = 3, with_starks: bool = False,
-                 small_tables: bool = False, table_mode: str = "per_job", factory: str = "vectorx_amd.dag_pool:gpu_provers", distinct_witnesses: int = 4):
+                 small_tables: bool = False, table_mode: str = "per_job", factory: str = "vectorx_amd.dag_pool:gpu_provers", distinct_witnesses: int = 4,
+                 num_headers: int = None):
         """factory = "module:function" the worker imports to build its provers: function(cfg, device) -> ({kind: prover}, close, info),
         prover.prove(key, public_inputs, lane, input_seed, spent_out) -> proof bytes.  The default is the GPU library; the scheduler's
         CPU tests plug in their own (tests/_pool_factory.py)."""
         self.spec, self.devices, self.wpd, self.lanes = spec, list(devices), int(workers_per_device), int(lanes)
         self.cfg = {"spec": (spec.num_map, spec.map_log_n, spec.reduce_log_n, spec.outer_log_n, spec.poseidon_percent), "lanes": self.lanes,
                     "with_starks": bool(with_starks), "small_tables": bool(small_tables), "table_mode": table_mode, "factory": factory,
-                    "distinct_witnesses": distinct_witnesses}
+                    "distinct_witnesses": distinct_witnesses, "num_headers": num_headers}
         self.procs, self.conns, self.ready = [], [], []
         self._dir = None
         self._listener = None
@@ -113,6 +114,23 @@ class DagPool:
                 raise RuntimeError(f"DAG worker failed during setup:\n{msg[1]}")
             self.ready.append(msg[1])
         return self.ready
+
+    def load_request(self, input_seed: bytes, timeout: float = 600.0):
+        """Every worker derives (and keeps) the request of `input_seed` — the header chain; on the outer job's worker also the
+        justification and its signatures — BEFORE the clock of `run`: a request's input is in host memory when proving starts, as the
+        reference fetches it from the Avail RPC first (/root/reference/circuits/input/mod.rs).  Not required: a request that was not
+        loaded is derived inside the first job that needs it."""
+        for c in self.conns:
+            c.send(("request", bytes(input_seed)))
+        t0 = time.perf_counter()
+        for c in self.conns:
+            while not c.poll(2.0):
+                self._check_alive("while loading a request")
+                if time.perf_counter() - t0 > timeout:
+                    raise TimeoutError("a DAG worker did not load the request in time")
+            msg = c.recv()
+            if msg[0] != "loaded":
+                raise RuntimeError(f"DAG worker failed while loading a request:\n{msg[1]}")
 
     def close(self):
         for c in self.conns:
@@ -187,7 +205,8 @@ class DagPool:
                 else:
                     w = max(range(len(free)), key=lambda i: free[i])
                     free[w] -= 1
-                self.conns[w].send(("job", li, j, kind, pis.tobytes(), input_seed, with_tables, hoist and kind == "outer"))
+                self.conns[w].send(("job", li, j, kind, pis.tobytes(), input_seed, with_tables, hoist and kind == "outer",
+                                    tuple(mr.children_of(layers, li, j, prev))))
                 jobs_by_worker[w] += 1
             outstanding += 1
 
@@ -248,7 +267,7 @@ class DagPool:
         seconds = time.perf_counter() - t0
         per_layer = [{"kind": layers[li][0], "jobs": len(layers[li][1]), "ms": (span[li][1] - span[li][0]) * 1e3} for li in range(nl)]
         return {"root": digests[-1][0], "seconds": seconds, "proofs": total, "per_layer": per_layer, "split": split,
-                "jobs_by_worker": jobs_by_worker, "schedule": schedule, "outer_tables_hoisted": hoist}
+                "jobs_by_worker": jobs_by_worker, "schedule": schedule, "outer_tables_hoisted": hoist, "records": digests}
 
 
 # ---- the worker process ------------------------------------------------------------------------------------------------------------
@@ -267,9 +286,11 @@ def gpu_provers(cfg: dict, device: int):
     octx = vx.Context(device) if "outer" in kinds else None
     if cfg["with_starks"]:
         from . import dag_tables
-        per_kind, tables, table_rec = dag_tables.build(ctx, kinds=("map", "reduce"), small=cfg["small_tables"], mode=cfg["table_mode"], lanes=[ctx] + lanes)
+        shape_kw = {"num_map": num_map, "num_headers": cfg.get("num_headers")}
+        per_kind, tables, table_rec = dag_tables.build(ctx, kinds=("map", "reduce"), small=cfg["small_tables"], mode=cfg["table_mode"], lanes=[ctx] + lanes,
+                                                       **shape_kw)
         if octx is not None:
-            pk, tb, tr = dag_tables.build(octx, kinds=("outer",), small=cfg["small_tables"], mode=cfg["table_mode"], lanes=[octx])
+            pk, tb, tr = dag_tables.build(octx, kinds=("outer",), small=cfg["small_tables"], mode=cfg["table_mode"], lanes=[octx], **shape_kw)
             per_kind.update(pk)
             tables += tb
             table_rec.update(tr)
@@ -294,7 +315,12 @@ def gpu_provers(cfg: dict, device: int):
         if octx is not None:
             octx.close()
         ctx.close()
-    return provers, close, {"tables": table_rec}
+
+    def preload(seed: bytes):
+        if cfg["with_starks"] and cfg["table_mode"] == "per_job":
+            from . import dag_tables
+            dag_tables.preload_request(seed, dag_tables.request_shape(cfg["small_tables"], num_map, cfg.get("num_headers")), outer=octx is not None)
+    return provers, close, {"tables": table_rec, "_preload": preload}
 
 
 def _worker(addr: str, device: int, index: int):
@@ -312,6 +338,7 @@ def _worker(addr: str, device: int, index: int):
         mod, fn = cfg["factory"].split(":")
         provers, close, info = getattr(importlib.import_module(mod), fn)(cfg, device)
         info = dict(info or {})
+        preload = info.pop("_preload", None)          # a callable of this process, not for the coordinator
         info.update({"worker": index, "device": device, "pid": os.getpid(), "setup_seconds": round(time.perf_counter() - t0, 2)})
         conn.send(("ready", info))
         todo, todo_outer = queue.Queue(), queue.Queue()
@@ -329,13 +356,16 @@ def _worker(addr: str, device: int, index: int):
                         hoisted[bytes(seed)] = provers["outer"].prove_tables((li, j), 0, input_seed=seed, spent_out=spent)
                         reply = ("tables_done",)
                     else:
-                        _, li, j, kind, pis, seed, with_tables, tables_hoisted = item
+                        _, li, j, kind, pis, seed, with_tables, tables_hoisted, kids = item
                         own = with_tables and not tables_hoisted
-                        proof = provers[kind].prove((li, j), np.frombuffer(pis, dtype=np.uint64), 0 if kind == "outer" else lane, input_seed=seed,
-                                                    spent_out=spent, with_tables=own)
-                        if tables_hoisted:
+                        pl = 0 if kind == "outer" else lane
+                        kw = {"children": kids} if getattr(provers[kind], "takes_children", False) else {}
+                        proof = provers[kind].prove((li, j), np.frombuffer(pis, dtype=np.uint64), pl, input_seed=seed, spent_out=spent, with_tables=own, **kw)
+                        if tables_hoisted:            # plonky2 proof | the tables proven ahead | the statement, which needed the children
                             proof += hoisted.pop(bytes(seed))
-                        reply = ("done", li, j, hashlib.sha256(proof).digest())
+                            if getattr(provers[kind], "emits_statement", False):
+                                proof += provers[kind].prove_statement((li, j), pl, input_seed=seed, children=kids, spent_out=spent)
+                        reply = ("done", li, j, mr.record_of(proof, provers[kind]))
                     acc = {}
                     for label, dt in spent:
                         acc[label] = acc.get(label, 0.0) + dt
@@ -355,6 +385,12 @@ def _worker(addr: str, device: int, index: int):
             msg = conn.recv()
             if msg[0] == "stop":
                 break
+            if msg[0] == "request":
+                if preload is not None:
+                    preload(msg[1])
+                with send_lock:
+                    conn.send(("loaded",))
+                continue
             (todo_outer if msg[0] == "outer_tables" or msg[3] == "outer" else todo).put(msg)
         for _ in threads:
             todo.put(None)

@@ -96,26 +96,95 @@ HEADERS_PER_MAP = 8           # /root/reference/circuits/consts.rs:6
 
 def job_bytes(job, label: bytes, count: int, length: int) -> list:
     """`count` byte strings of `length` bytes that belong to THIS job and nobody else: SHAKE-256 of (request seed, job kind, layer,
-    index, label).  job = (kind, layer, index, input_seed) as mapreduce.prove_with_tables hands it on; None = a fixed job."""
+    index, label).  job = (kind, layer, index, input_seed, ...) as mapreduce.prove_with_tables hands it on; None = a fixed job."""
     import hashlib
-    kind, li, j, seed = job if job is not None else ("none", 0, 0, b"")
+    kind, li, j, seed = job[:4] if job is not None else ("none", 0, 0, b"")
     h = hashlib.shake_256(b"vectorx job bytes|" + bytes(seed) + b"|" + kind.encode() + b"|%d|%d|" % (li, j) + label)
     blob = h.digest(count * length)
     return [blob[i * length:(i + 1) * length] for i in range(count)]
 
 
-def build_per_job(ctx, lanes, kinds=("map", "reduce", "outer"), small=False, eddsa_log_n=20, outer_lanes=None):
-    """Every job proves tables of ITS OWN inputs, traces generated on the GPU inside the job (vx_trace_*):
-      map    : BLAKE2b over its 8 headers (280 blocks each: 2240 compressions, 2^16 rows) + SHA-256 over its 14 tree nodes (2^11 rows);
-      reduce : SHA-256 over the 2 nodes that merge its children's commitments (2^9 rows);
-      outer  : SHA-256 over the authority set (300 keys: 600 compressions, 2^16 rows) + the justification's 300 signatures verified
-               through tables only, as ONE bus: SHA-512 over R || A || M (2^16 rows), 4 batched EdDSA tables running the full program
-               (2^20 rows, 97 instances each), the link table.
+def request_shape(small: bool, num_map: int, num_headers=None) -> dict:
+    """the synthetic request the per-job tables hash (vectorx_amd/header_range.py::make_request): header_range_512's capacity, headers
+    of MAX_HEADER_SIZE bytes and 300 authorities — or the miniature of the tests"""
+    shape = {"capacity": HEADERS_PER_MAP * num_map, "header_bytes": 128 * (4 if small else MAX_HEADER_BLOCKS), "num_authorities": 8 if small else 300,
+             "distinct_keys": 2 if small else 8}
+    if num_headers is not None:
+        shape["num_headers"] = num_headers
+    return shape
+
+
+def preload_request(seed: bytes, shape: dict, outer: bool):
+    """Derive (and keep) the request of `seed` in this process BEFORE the clock: the header chain — and, where the outer job runs, the
+    justification with its signatures and the witnesses of the signature equations.  The reference fetches the same from the Avail RPC
+    before it proves (/root/reference/circuits/input/mod.rs).  A request that was not preloaded is derived inside the first job."""
+    from . import header_range as hr
+    req = hr.cached_request(seed, **shape)
+    if outer:
+        _signature_inputs(req)
+    return req
+
+
+def _signature_inputs(req):
+    """-> (raw [(pk, msg, sig)], full-program witnesses) of the validators marked as signed, kept on the request"""
+    from . import eddsa_air
+    just = req.justification()
+    with req._lock:
+        if getattr(req, "_sig_inputs", None) is None:
+            eq_by_key = {}
+            raw, eq = [], []
+            for pk, sg, signed in zip(just.pubkeys, just.signatures, just.validator_signed):
+                if not signed:
+                    continue
+                if pk not in eq_by_key:
+                    eq_by_key[pk] = eddsa_air.equation_inputs_full(pk, just.encoded_precommit, sg)
+                raw.append((pk, just.encoded_precommit, sg))
+                eq.append(eq_by_key[pk])
+            req._sig_inputs = (raw, eq)
+        return req._sig_inputs
+
+
+class JobStatement:
+    """The last "table" of a job: no proof, the job's STATEMENT — host logic (vectorx_amd/header_range.py, the mirror of the circuit's
+    assertions) over what the job's tables hashed on this lane and what its children stated — as the trailer of the job's result
+    bytes (mapreduce.with_statement), from where the scheduler hands it to the parent (mapreduce.record_of)."""
+    needs_children = True
+
+    def __init__(self, fn):
+        self.fn = fn
+
+    def prove(self, ctx=None, job=None) -> bytes:
+        from . import mapreduce as mr
+        return mr.with_statement(self.fn(ctx, job))
+
+    def free(self):
+        pass
+
+
+def build_per_job(ctx, lanes, kinds=("map", "reduce", "outer"), small=False, eddsa_log_n=20, outer_lanes=None, num_map=64, num_headers=None):
+    """Every job proves tables of ITS OWN inputs — the request's (header_range.make_request(input_seed)) and its children's
+    statements —, traces generated on the GPU inside the job (vx_trace_*), and states what the reference's circuit would
+    (/root/reference/circuits/builder/subchain_verification.rs:84-289, justification.rs:195-257), with every hash taken from the tables:
+      map    : BLAKE2b over its 8 headers (280 blocks each: 2240 compressions, 2^16 rows) + SHA-256 over the 14 nodes of the two
+               8-leaf trees of their state / data roots (2^11 rows) -> Subchain (linked headers, block numbers, the two roots);
+      reduce : SHA-256 over left root || right root of both trees (2^9 rows) -> the merged Subchain (the right one continues the left);
+      outer  : SHA-256 over the authority set commitment chain (300 keys: 599 compressions, 2^16 rows) + the justification's 300
+               signatures over the precommit message, verified through tables only as ONE bus: SHA-512 over R || A || M (2^16
+               rows), 4 batched EdDSA tables running the full program (2^20 rows, 97 instances each), the link table, the
+               verifier's sink -> the 96 output bytes (target header hash, state / data root commitments).
     -> ({kind: [(label, table)]}, [tables to free], setup record)"""
-    from . import blake2b_bytes_air, sha256_air, sha512_air, stark_chips
+    from . import blake2b_bytes_air, sha256_air, stark_chips
+    from . import header_range as hr
     lanes = list(lanes)
     rec, tables, per_kind = {"mode": "per_job", "resident_trace": []}, [], {}
-    nkeys, nhdr_blocks = (8, 4) if small else (300, MAX_HEADER_BLOCKS)
+    shape = request_shape(small, num_map, num_headers)
+    nkeys = shape["num_authorities"]
+    rec["request"] = dict(shape, what="synthetic header_range request derived from the seed: headers chained by their BLAKE2b-256 hashes, real Ed25519 "
+                                      "authorities, a signed precommit (vectorx_amd/header_range.py::make_request)")
+    WARM = b"warm-up"
+
+    def request(job):
+        return hr.cached_request(job[3] if job is not None else WARM, **shape)
 
     def gen(label, which, air, log_n, messages_fn):
         t0 = time.perf_counter()
@@ -130,33 +199,56 @@ def build_per_job(ctx, lanes, kinds=("map", "reduce", "outer"), small=False, edd
         return tab
 
     if "map" in kinds:
-        blake = gen("blake2b_map", "blake2b", blake2b_bytes_air, 16, lambda job: job_bytes(job, b"headers", HEADERS_PER_MAP, 128 * nhdr_blocks))
-        sha_map = gen("sha256_map", "sha256", sha256_air, 11, lambda job: job_bytes(job, b"tree", 14, 64))
-        per_kind["map"] = [("blake2b", blake), ("sha256", sha_map)]
+        def headers_of(job):
+            return request(job).batch(job[2] if job is not None else 0)
+
+        def tree_nodes_of(job):
+            req = request(job)
+            state, data = hr.map_leaves(req.target_block, headers_of(job))
+            return hr.tree_messages(state) + hr.tree_messages(data)
+
+        blake = gen("blake2b_map", "blake2b", blake2b_bytes_air, 16, headers_of)
+        sha_map = gen("sha256_map", "sha256", sha256_air, 11, tree_nodes_of)
+
+        def map_statement(lane, job):
+            req = request(job)
+            (hdrs, hashes), (tmsgs, tdigs) = blake.last[id(lane)], sha_map.last[id(lane)]
+            return hr.map_statement(req.trusted_block, req.target_block, job[2], hdrs, hashes, tmsgs, tdigs).pack()
+
+        per_kind["map"] = [("blake2b", blake), ("sha256", sha_map), ("statement", JobStatement(map_statement))]
     if "reduce" in kinds:
-        sha_red = gen("sha256_reduce", "sha256", sha256_air, 9, lambda job: job_bytes(job, b"merge", 2, 64))
-        per_kind["reduce"] = [("sha256", sha_red)]
+        def children_of(job):
+            if job is None or len(job) < 5 or len(job[4]) != 2:
+                raise hr.StatementError("a reduce job needs the records of its two children")
+            return [hr.Subchain.unpack(bytes(r)[32:]) for r in job[4]]
+
+        def merge_nodes_of(job):
+            if job is None:
+                return job_bytes(None, b"merge", 2, 64)
+            return hr.reduce_messages(*children_of(job))
+
+        sha_red = gen("sha256_reduce", "sha256", sha256_air, 9, merge_nodes_of)
+
+        def reduce_statement(lane, job):
+            msgs, digs = sha_red.last[id(lane)]
+            return hr.reduce_statement(*children_of(job), msgs, digs).pack()
+
+        per_kind["reduce"] = [("sha256", sha_red), ("statement", JobStatement(reduce_statement))]
     if "outer" in kinds:
         lg = 11 if small else 16
         if outer_lanes is not None:          # a scheduler that only ever proves the outer job on one lane need not hold its buffers on all
             lanes = list(outer_lanes)
-        sha_out = gen("sha256_outer", "sha256", sha256_air, lg, lambda job: job_bytes(job, b"authority set", nkeys, 64))
-        # The justification's signatures, verified THROUGH TABLES ONLY and proven as one bus (stark_chips.GeneratedSignatureBus): the SHA-512
-        # table over the 300 signed messages R || A || M (117 bytes each) sends (R, A, digest); four batched EdDSA tables running the FULL
-        # program (decompression, digest mod L, S < L, the group equation) send (A, S, digest, R); the link table joins them and sends what
-        # a verifier holds; the sink receives it from the bytes of the keys and signatures alone.  REAL Ed25519 signatures (RFC 8032 signing on the host, untimed: they are the request's input), 8 distinct
-        # ones; a job takes them in an order of its own.
         t0 = time.perf_counter()
+        preload_request(WARM, shape, outer=True)
+        sha_out = gen("sha256_outer", "sha256", sha256_air, lg, lambda job: hr.authority_chain_messages(request(job).justification().pubkeys))
+        # The justification's signatures, verified THROUGH TABLES ONLY and proven as one bus (stark_chips.GeneratedSignatureBus): the SHA-512
+        # table over the signed messages R || A || precommit (117 bytes each) sends (R, A, digest); four batched EdDSA tables running the
+        # FULL program (decompression, digest mod L, S < L, the group equation) send (A, S, digest, R); the link table joins them and
+        # sends what a verifier holds; the sink receives it from the bytes of the keys and signatures alone.  REAL Ed25519 signatures
+        # of the request's precommit (RFC 8032 signing on the host, untimed: they are the request's input), by 8 distinct authorities.
         from . import eddsa_air
         lg_ed = 17 if small else eddsa_log_n
-        base_raw, base_eq = stark_chips.real_signatures(8 if not small else 2)
-
-        def sigs_of(job):
-            k = int.from_bytes(job_bytes(job, b"signatures", 1, 2)[0], "little")
-            idx = [(k + i) % len(base_raw) for i in range(nkeys)]
-            return [base_raw[i] for i in idx], [base_eq[i] for i in idx]
-
-        bus = stark_chips.GeneratedSignatureBus(ctx, sigs_of, lanes, nkeys, sha_log_n=lg, ed_log_n=lg_ed)
+        bus = stark_chips.GeneratedSignatureBus(ctx, lambda job: _signature_inputs(request(job)), lanes, nkeys, sha_log_n=lg, ed_log_n=lg_ed)
         for lane in lanes:
             bus.prove(lane, None)
             bus.take_spent(lane)
@@ -167,14 +259,25 @@ def build_per_job(ctx, lanes, kinds=("map", "reduce", "outer"), small=False, edd
         rec["signature_bus"] = {"tables": f"SHA-512 bus variant 2^{lg} x 2012 + {bus.ntab} x EdDSA full program 2^{lg_ed} x {bus.lay.N} + link 2^{bus.link_log_n} x 41 + verifier sink 2^{bus.link_log_n} x 26",
                                 "signatures": nkeys, "signatures_per_eddsa_table": bus.cap, "eddsa_tables": bus.ntab,
                                 "traces": "SHA-512 and EdDSA generated per job on the GPU; link rows written by the host",
-                                "proven_as": "one bus: joint challenges over the 7 trace caps; the closing sums add up to 0, second rounds on the GPU",
+                                "proven_as": "one bus: joint challenges over the 7 trace caps; the closing sums add up to 0",
                                 "setup_incl_signing_and_one_bus_per_lane_s": round(time.perf_counter() - t0, 2)}
         rec["eddsa_outer"] = {"tables": bus.ntab, "rows_log2": lg_ed, "signatures_per_table": bus.cap}
-        per_kind["outer"] = [("sha256", sha_out), ("signature_bus", bus)]
+
+        def outer_statement(lane, job):
+            if job is None or len(job) < 5 or len(job[4]) != 1:
+                raise hr.StatementError("the outer job needs the record of the root reduce job")
+            req = request(job)
+            chain_msgs, chain_digs = sha_out.last[id(lane)]
+            raw = bus.last[id(lane)][0]
+            if not bus.closed(lane):
+                raise hr.StatementError("the signature bus does not balance: a signature of the justification does not verify")
+            return hr.outer_statement(req.input_bytes, hr.Subchain.unpack(bytes(job[4][0])[32:]), req.justification(), chain_msgs, chain_digs, raw)
+
+        per_kind["outer"] = [("sha256", sha_out), ("signature_bus", bus), ("statement", JobStatement(outer_statement))]
     return per_kind, tables, rec
 
 
-def build(ctx, kinds=("map", "reduce", "outer"), small=False, mode="per_job", lanes=None, outer_lanes=None):
+def build(ctx, kinds=("map", "reduce", "outer"), small=False, mode="per_job", lanes=None, outer_lanes=None, num_map=64, num_headers=None):
     """mode "per_job" (default) or "resident" (rounds 3-4: one host-generated trace per table kind)"""
     if mode == "resident":
         per_kind, tables, rec = build_resident(ctx, kinds=kinds, small=small)
@@ -186,4 +289,4 @@ def build(ctx, kinds=("map", "reduce", "outer"), small=False, mode="per_job", la
         return per_kind, tables, rec
     if mode != "per_job":
         raise ValueError(mode)
-    return build_per_job(ctx, lanes or [ctx], kinds=kinds, small=small, outer_lanes=outer_lanes)
+    return build_per_job(ctx, lanes or [ctx], kinds=kinds, small=small, outer_lanes=outer_lanes, num_map=num_map, num_headers=num_headers)

@@ -66,9 +66,40 @@ def child_inputs(layer_idx: int, job: int, prev_digests: dict, input_seed: bytes
     return digest_to_field(hashlib.sha256(prev_digests[2 * job] + prev_digests[2 * job + 1]).digest())
 
 
-def _seed_kw(prover, input_seed):
-    """provers that derive per-job table inputs from the request take `input_seed`; plain ones (the tests' stand-ins) do not"""
-    return {"input_seed": input_seed} if getattr(prover, "takes_input_seed", False) else {}
+def _seed_kw(prover, input_seed, children=()):
+    """provers that derive per-job table inputs from the request take `input_seed` — and, if they say so, the records of the job's
+    children (`takes_children`: a reduce job hashes ITS children's roots); plain ones (the tests' stand-ins) take neither"""
+    kw = {"input_seed": input_seed} if getattr(prover, "takes_input_seed", False) else {}
+    if getattr(prover, "takes_children", False):
+        kw["children"] = tuple(children)
+    return kw
+
+
+STATEMENT_MAGIC = b"VXST"
+
+
+def with_statement(statement: bytes) -> bytes:
+    """a job's statement as the trailer of its result bytes (so that the job's digest covers it): statement | u32 length | magic"""
+    return bytes(statement) + len(statement).to_bytes(4, "little") + STATEMENT_MAGIC
+
+
+def record_of(result: bytes, prover=None) -> bytes:
+    """What a job hands to its parent: SHA-256 of everything it proved — followed, when its prover emits statements
+    (`emits_statement`, the trailer of with_statement), by the statement itself: 172 bytes of a map / reduce job's subchain
+    (vectorx_amd/header_range.py::Subchain), the 96 output bytes of the outer job.  Plain provers: the 32-byte digest of rounds 1-4."""
+    dg = hashlib.sha256(result).digest()
+    if getattr(prover, "emits_statement", False) and result[-4:] == STATEMENT_MAGIC:
+        n = int.from_bytes(result[-8:-4], "little")
+        return dg + result[len(result) - 8 - n:len(result) - 8]
+    return dg
+
+
+def children_of(layers, li, j, records):
+    """the records of job (li, j)'s children, left to right (none for a map job, one for the outer job)"""
+    if li == 0:
+        return []
+    prev = records[li - 1] if isinstance(records, list) else records
+    return [prev[0]] if len(layers[li - 1][1]) == 1 else [prev[2 * j], prev[2 * j + 1]]
 
 
 def _run_dag_dependency_driven(layers, provers, in_flight, input_seed, sync):
@@ -113,8 +144,9 @@ def _run_dag_dependency_driven(layers, provers, in_flight, input_seed, sync):
                     prev = dict(digests[li - 1]) if li else {}
                     if span[li][0] is None:
                         span[li][0] = time.perf_counter()
-                proof = provers[kind].prove((li, j), child_inputs(li, j, prev, input_seed), lane, **_seed_kw(provers[kind], input_seed))
-                dg = hashlib.sha256(proof).digest()
+                proof = provers[kind].prove((li, j), child_inputs(li, j, prev, input_seed), lane,
+                                            **_seed_kw(provers[kind], input_seed, children_of(layers, li, j, prev)))
+                dg = record_of(proof, provers[kind])
                 with lock:
                     digests[li][j] = dg
                     proofs[(li, j)] = proof
@@ -197,8 +229,9 @@ def run_dag(spec: DagSpec, make_prover, dist=None, sync=lambda: None, in_flight:
                     except queue.Empty:
                         return
                     try:
-                        proof = provers[kind].prove((li, j), child_inputs(li, j, prev, input_seed), lane, **_seed_kw(provers[kind], input_seed))
-                        mine[j] = hashlib.sha256(proof).digest()
+                        proof = provers[kind].prove((li, j), child_inputs(li, j, prev, input_seed), lane,
+                                                    **_seed_kw(provers[kind], input_seed, children_of(layers, li, j, prev)))
+                        mine[j] = record_of(proof, provers[kind])
                         all_proofs[(li, j)] = proof
                     except BaseException as e:   # surfaces after the join
                         errors.append(e)
@@ -214,8 +247,8 @@ def run_dag(spec: DagSpec, make_prover, dist=None, sync=lambda: None, in_flight:
         else:
             for j in my_jobs[li]:
                 pi = child_inputs(li, j, prev, input_seed)
-                proof = provers[kind].prove((li, j), pi, **_seed_kw(provers[kind], input_seed))
-                mine[j] = hashlib.sha256(proof).digest()
+                proof = provers[kind].prove((li, j), pi, **_seed_kw(provers[kind], input_seed, children_of(layers, li, j, prev)))
+                mine[j] = record_of(proof, provers[kind])
                 all_proofs[(li, j)] = proof
         sync()
         if dist is not None:          # layer barrier: all-gather of the digests (32 B per proof)
@@ -269,6 +302,7 @@ class GpuProver:
     """One circuit kind on one GPU: circuit loaded once (constants_sigmas resident), one device-resident witness per
     job; `prove` patches the two witness rows that depend on the public inputs and calls vx_prove."""
     takes_input_seed = True
+    takes_children = True
 
     def __init__(self, ctx, kind, log_n, jobs, poseidon_percent=50, extra_lanes=(), distinct_witnesses=None, starks=(), split=None):
         """extra_lanes: more contexts on the SAME GPU; lane k proves on its own stream with its own copy of the circuit
@@ -288,6 +322,9 @@ class GpuProver:
         self.lanes = [ctx] + list(extra_lanes)
         self._lock = threading.Lock()
         self.starks, self.split = list(starks), split
+        # a table that `needs_children` is the job's STATEMENT (dag_tables.JobStatement): host logic over what the other tables hashed
+        # and what the children stated; it closes the job's result bytes
+        self.emits_statement = any(getattr(t, "needs_children", False) for _, t in self.starks)
         circuit_seed = {"map": 101, "reduce": 202, "outer": 303}[kind]
         self.sc = SynthCircuit(log_n, seed=circuit_seed, poseidon_percent=poseidon_percent, witness_seed=0)
         self.circuits = [vx.Circuit(c, self.sc.desc_ptr) for c in self.lanes]
@@ -317,7 +354,7 @@ class GpuProver:
                 sj.free()
         self.sc.release_host_buffers(witness=True, preprocessed=True)
 
-    def prove(self, key, public_inputs, lane=0, input_seed=b"", spent_out=None, with_tables=True):
+    def prove(self, key, public_inputs, lane=0, input_seed=b"", spent_out=None, with_tables=True, children=()):
         d = self.wit[key] if self.distinct is None else self.lane_wit[lane][key[1] % self.distinct]
         with self._lock:                      # the generator keeps the current public inputs: one caller at a time
             r0, r2 = self.sc.patch_public_inputs(public_inputs)
@@ -325,13 +362,21 @@ class GpuProver:
         ctx.upload_row(d, self.n, 0, r0)
         ctx.upload_row(d, self.n, 2, r2)
         return prove_with_tables(lambda: self.circuits[lane].prove(dev_ptr=d), self.starks if with_tables else (), ctx, self.split, self._lock,
-                                 job=(self.kind, key[0], key[1], input_seed), spent_out=spent_out)
+                                 job=(self.kind, key[0], key[1], input_seed, tuple(children)), spent_out=spent_out)
 
     def prove_tables(self, key, lane=0, input_seed=b"", spent_out=None) -> bytes:
         """the STARK proofs of job `key` alone, in the order `prove` appends them: for a job whose tables do not depend on its children
-        (the outer job's: vectorx_amd/dag_pool.py proves them while the reduce tree is still running)"""
-        return prove_with_tables(lambda: b"", self.starks, self.lanes[lane], self.split, self._lock, job=(self.kind, key[0], key[1], input_seed),
+        (the outer job's: vectorx_amd/dag_pool.py proves them while the reduce tree is still running) — without the job's statement,
+        which does (prove_statement)"""
+        tables = [(l, t) for l, t in self.starks if not getattr(t, "needs_children", False)]
+        return prove_with_tables(lambda: b"", tables, self.lanes[lane], self.split, self._lock, job=(self.kind, key[0], key[1], input_seed, ()),
                                  spent_out=spent_out, main_label=None)
+
+    def prove_statement(self, key, lane=0, input_seed=b"", children=(), spent_out=None) -> bytes:
+        """the statement of job `key` alone (the trailer `prove` ends with), from what the tables proven LAST on this lane hashed"""
+        tables = [(l, t) for l, t in self.starks if getattr(t, "needs_children", False)]
+        return prove_with_tables(lambda: b"", tables, self.lanes[lane], self.split, self._lock,
+                                 job=(self.kind, key[0], key[1], input_seed, tuple(children)), spent_out=spent_out, main_label=None)
 
     def free(self):
         for d in self.wit.values():
