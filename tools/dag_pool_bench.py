@@ -26,7 +26,8 @@ def main():
             pool.close()
         for name, rec in out.items():
             print(json.dumps({"leg": name, "workers": w, "lanes": k, **{x: rec[x] for x in ("dag_seconds", "dag_seconds_all_passes", "lane_seconds_by_kind",
-                              "per_layer_ms", "per_layer_ms_layer_barriers", "jobs_by_worker", "setup_seconds_untimed", "root")}}), flush=True)
+                              "per_layer_ms", "per_layer_ms_layer_barriers", "jobs_by_worker", "setup_seconds_untimed", "root", "request_load_seconds_untimed", "input", "output",
+                              "output_equals_host_computation") if x in rec}}), flush=True)
 
 
 if __name__ == "__main__":
