@@ -297,7 +297,7 @@ def dag_leg_ranks(ctx, args, local_rank, dist, device, in_flight=3, with_starks=
         kinds = ("map", "reduce", "outer") if dist.get_rank() == 0 else ("map", "reduce")
         per_kind, tables, _setup = dag_stark_tables(ctx, kinds=kinds, small=bool(getattr(args, "dag_starks_small", False)),
                                                     mode=getattr(args, "dag_table_mode", "per_job"), lanes=[ctx] + lanes,
-                                                    outer_lanes=[ctx])     # layer barriers: the outer job is alone and runs on lane 0
+                                                    outer_lanes=[ctx], num_map=num_map)     # layer barriers: the outer job is alone and runs on lane 0
 
     def make(kind, log_n, jobs):
         if kind not in provers:
@@ -335,6 +335,8 @@ def dag_leg_ranks(ctx, args, local_rank, dist, device, in_flight=3, with_starks=
             "per_layer_ms": [(l["kind"], l["jobs"], round(l["ms"], 1)) for l in res["per_layer"]],
             "setup_seconds_untimed": round(time.perf_counter() - t_setup - sum(r["seconds"] for r in runs), 2), "root": res["root"][:32].hex(),
             "backend": dist.get_backend(), "with_stark_tables": bool(with_starks),
+            **(statement_record({"table_mode": getattr(args, "dag_table_mode", "per_job"), "small_tables": bool(getattr(args, "dag_starks_small", False))},
+                                spec, b"", res["root"]) if with_starks else {}),
             "rank0_lane_seconds_by_kind": {k: round(v, 4) for k, v in sorted(res["split"].items())} if with_starks else None,
             "what": f"{num_map} map (2^{lm} rows) + {num_map - 1} reduce (2^{lr}) + 1 outer (2^{lo}) plonky2 proofs over all ranks"
                     + (", EACH WITH ITS STARK TABLES (dag_stark_tables: BLAKE2b + SHA-256 per map job, SHA-256 per reduce job, SHA-256 / SHA-512 / "
@@ -343,10 +345,14 @@ def dag_leg_ranks(ctx, args, local_rank, dist, device, in_flight=3, with_starks=
                       "HBM-resident; NOT the contract's timed region"}
 
 
-def dag_stark_tables(ctx, kinds=("map", "reduce", "outer"), small=False, mode="resident", lanes=None, outer_lanes=None):
-    """vectorx_amd.dag_tables.build (kept under this name for tools/)"""
+def dag_stark_tables(ctx, kinds=("map", "reduce", "outer"), small=False, mode="resident", lanes=None, outer_lanes=None, num_map=64, request_seed=b""):
+    """vectorx_amd.dag_tables.build (kept under this name for tools/) + the request of `request_seed` derived in this process before any
+    clock starts (per-job tables: the header chain; with the outer job also the signed justification)"""
     from vectorx_amd import dag_tables
-    return dag_tables.build(ctx, kinds=kinds, small=small, mode=mode, lanes=lanes, outer_lanes=outer_lanes)
+    out = dag_tables.build(ctx, kinds=kinds, small=small, mode=mode, lanes=lanes, outer_lanes=outer_lanes, num_map=num_map)
+    if mode == "per_job" and request_seed is not None:
+        dag_tables.preload_request(request_seed, dag_tables.request_shape(small, num_map), outer="outer" in kinds)
+    return out
 
 
 def dag_with_starks_leg(ctx, local_rank, in_flight=None, table_mode="per_job"):
@@ -406,7 +412,7 @@ def dag_with_starks_leg(ctx, local_rank, in_flight=None, table_mode="per_job"):
             "lane_seconds_by_kind": {k: round(v, 4) for k, v in sorted(res["split"].items())},
             "per_layer_ms": [(l["kind"], l["jobs"], round(l["ms"], 1)) for l in res["per_layer"]],
             "tables": setup, "setup_seconds_untimed": round(time.perf_counter() - t_setup - sum(r["seconds"] for r in runs), 2),
-            "root": res["root"][:32].hex(),
+            "root": res["root"][:32].hex(), **statement_record({"table_mode": table_mode, "small_tables": False}, spec, b"", res["root"]),
             "what": "64 map jobs = plonky2 2^18 + BLAKE2b table (2240 compressions: 2^16 rows of the byte / XOR-lookup table) + SHA-256 table 2^11; 63 reduce jobs = plonky2 2^16 + SHA-256 "
                     "table 2^9; outer = plonky2 2^19 + SHA-256 chain 2^16 + SHA-512 2^16 + 4 batched EdDSA tables 2^20 (388 signature slots for 300 "
                     "signatures); own AIRs standing in for Curta's chips, synthetic stand-in circuits; " + what_tables + "; the STARK proofs are part of a "

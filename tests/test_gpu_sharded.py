@@ -378,12 +378,14 @@ def test_bench_multi_rank_code_path_on_one_device(world):
         assert p0["plonky2_proofs"] == 8 and len(p0["jobs_by_worker"]) == world and len(p0["root"]) == 64
         if world == 2:
             assert pool["dag_header_range_512_with_starks"]["lane_seconds_by_kind"]["trace_generation"] > 0
+            assert pool["dag_header_range_512_with_starks"]["output_equals_host_computation"] is True
     if world == 2:      # the same DAG with every job's STARK tables (smallest shapes), over both ranks
         ds = line["dag_header_range_512_with_starks"]
         assert "error" not in ds, ds
         assert ds["with_stark_tables"] is True and ds["ranks"] == 2 and ds["dag_seconds"] > 0
         assert set(ds["rank0_lane_seconds_by_kind"]) >= {"plonky2", "blake2b", "sha256", "signature_bus", "trace_generation"}
         assert ds["root"] != line["dag_header_range_512"]["root"]          # the STARK proofs are part of every job's digest
+        assert ds["output_equals_host_computation"] is True and len(ds["output"]) == 192          # statements cross the ranks with the digests
 
 
 def test_bench_line_survives_multi_rank_legs_that_never_finish():
