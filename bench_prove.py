@@ -128,7 +128,7 @@ def dag_leg(ctx, local_rank, in_flight=3):
 
 def dag_pool_legs(pool, with_starks=True, passes=2):
     """The header_range_512 DAG on a pool of worker PROCESSES per GPU (vectorx_amd/dag_pool.py: started before this process's first GPU
-    call, configured here): 64 map + 63 reduce + 1 outer jobs, a job to whichever worker has a free lane, 32-byte digests back over a
+    call, configured here): 64 map + 63 reduce + 1 outer jobs, a job to whichever worker has a free lane, digest + statement records back over a
     pipe.  Two figures: the plonky2 proofs alone, and every job WITH its STARK tables (per-job inputs, traces generated on the GPU
     inside the clock).  The FIRST pass of each is the headline; all passes are listed.
     -> {"dag_header_range_512": {...}, "dag_header_range_512_with_starks": {...}}"""

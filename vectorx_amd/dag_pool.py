@@ -11,10 +11,13 @@ same DAG 13 % sooner on the same GPU).  This module is that observation built in
   * a worker connects back over a unix socket, waits for its configuration, and only THEN touches the GPU: it opens `lanes`
     contexts on its device, loads the three circuits (+ the STARK tables of every job kind) and reports ready;
   * `run()` walks the DAG layer by layer: a job goes to whichever worker has a free lane, the worker proves it and sends back
-    the 32-byte digest of the job's proofs (+ the lane-seconds it spent per kind of work); a parent's public inputs come from its
-    children's digests, so the root is the same as the one-process root whatever the placement
+    the job's record = the 32-byte digest of its proofs + what it states (mapreduce.record_of) (+ the lane-seconds it spent per
+    kind of work); a parent's public inputs come from its children's records — and its prover receives them: a reduce job hashes
+    its children's roots — so the root is the same as the one-process root whatever the placement
     (tests/test_gpu_dag_pool.py, tests/test_dag_pool.py);
-  * no collective, no shared device memory: proof-level data parallelism, 32 bytes per job over a pipe.
+  * no collective, no shared device memory: proof-level data parallelism, ~200 bytes per job over a pipe;
+  * `load_request(seed)` (optional, before the clock): every worker derives the request's input once — the header chain, the
+    justification — instead of inside its first job.
 
 Workers may sit on different devices (`devices=[0, 1, ...]`): the same coordinator then drives a whole node.
 """
