@@ -55,6 +55,7 @@ def parse():
                     help="worker PROCESSES per GPU of the DAG legs (vectorx_amd/dag_pool.py; each keeps --dag-lanes jobs in flight); 0 = the one-process scheduler of rounds 1-4")
     ap.add_argument("--dag-lanes", type=int, default=3,
                     help="jobs in flight per worker process (3 workers x 3 lanes: 3.38 s against 3.50 for 2 x 3 and 3 x 2, 3.42 for 4 x 2 on one box — profiles/r05_dag_pool.jsonl)")
+    ap.add_argument("--no-rotate-leg", action="store_true", help="skip the rotate leg (one rotate request: plonky2 2^19 + its tables; N = 1 only)")
     ap.add_argument("--no-dag-pool-leg", action="store_true",
                     help="N > 1 only: skip the leg that runs the DAG on ONE pool of worker processes spanning all N GPUs (rank 0 coordinates; vectorx_amd/dag_pool.py)")
     ap.add_argument("--dag-table-mode", default="per_job", choices=["per_job", "resident"],
@@ -433,8 +434,13 @@ def main():
             leg("dag_header_range_512", lambda: bench_prove.dag_leg(ctx, local_rank))
             if not args.no_dag_stark_leg:
                 leg("dag_header_range_512_with_starks", lambda: bench_prove.dag_with_starks_leg(ctx, local_rank, table_mode=args.dag_table_mode))
+    if single and dag_pool is not None:
+        dag_pool.close()         # the workers' HBM goes back before the legs this process proves itself
+        dag_pool = None
     if single and not args.no_chip_leg:
         leg("chip_starks", lambda: bench_prove.chip_leg(ctx))
+    if single and not args.no_rotate_leg:
+        leg("rotate", lambda: bench_prove.rotate_leg(ctx, local_rank))
 
     sharded_leg = dag_n_leg = dag_n_stark_leg = None
     if multi:

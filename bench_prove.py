@@ -419,6 +419,50 @@ def dag_with_starks_leg(ctx, local_rank, in_flight=None, table_mode="per_job"):
                     "job's digest; NOT the contract's timed region"}
 
 
+def rotate_leg(ctx, local_rank, log_n=19, small=False):
+    """The OTHER function of the hot path (/root/reference/circuits/rotate.rs:80-109, bin/rotate.rs): one rotate request = ONE plonky2
+    proof (stand-in circuit, 2^19 rows) + its tables over a synthetic request (an epoch end header announcing 300 new authorities,
+    justified by the 300 current ones): BLAKE2b over the header, SHA-256 over both authority set commitment chains, the 300 signatures
+    through the signature bus — traces generated on the GPU inside the clock — and the statement: the new authority set's hash, equal to
+    the host computation (avail_codec.rotate_output).  Outside the contract's timed region."""
+    from vectorx_amd import dag_tables
+    from vectorx_amd import header_range as hr
+    from vectorx_amd import mapreduce as mr
+    t_setup = time.perf_counter()
+    per_kind, tables, setup = dag_tables.build_rotate(ctx, [ctx], small=small)
+    prover = mr.GpuProver(ctx, "rotate", log_n, [(0, 0)], 50, distinct_witnesses=1, starks=per_kind["rotate"])
+    try:
+        seeds = [b"bench rotate 1", b"bench rotate 2"]
+        reqs = [hr.cached_request(sd, rotate=True, **dag_tables.rotate_shape(small)) for sd in seeds]
+        for r in reqs:
+            dag_tables._signature_inputs(r)          # the request's input, signatures included, in host memory before the clock
+        setup_s = time.perf_counter() - t_setup
+        runs = []
+        for sd in seeds:
+            spent = []
+            res = mr.prove_rotate(prover, sd, spent_out=spent)
+            ctx.sync()
+            split = {}
+            for k, v in spent:
+                split[k] = split.get(k, 0.0) + v
+            res["split"] = split
+            runs.append(res)
+    finally:
+        prover.free()
+        for t in tables:
+            t.free()
+    ok = [r["output"] == hr.expected_rotate_output(q) for r, q in zip(runs, reqs)]
+    res = runs[0]
+    return {"rotate_per_sec": 1.0 / res["seconds"], "seconds": round(res["seconds"], 4), "seconds_all_passes": [round(r["seconds"], 4) for r in runs],
+            "seconds_by_kind": {k: round(v, 4) for k, v in sorted(res["split"].items())}, "input": reqs[0].input_bytes.hex(), "output": res["output"].hex(),
+            "output_equals_host_computation": all(ok), "stark_proofs": 2 + 3 + setup["signature_bus"]["eddsa_tables"], "tables": setup,
+            "setup_seconds_untimed": round(setup_s, 2),
+            "what": f"ONE rotate request: plonky2 2^{log_n} (synthetic stand-in circuit) + BLAKE2b table over the epoch end header (2^16 rows) + SHA-256 table over the "
+                    "current and the new authority set commitment chains (1198 compressions, 2^17 rows) + the justification's 300 signatures as one bus "
+                    "(SHA-512 2^16 + 4 EdDSA full 2^20 + link + sink), traces generated on the GPU inside the clock, one lane; the statement = the new "
+                    "authority set hash (bytes32: /root/reference/circuits/rotate.rs:108); NOT the contract's timed region"}
+
+
 def chip_leg(ctx):
     """SURVEY §8 f-3 outside the contract's timed region: the STARK path on the four chip tables the header_range jobs prove — SHA-256,
     SHA-512, BLAKE2b (bytes + XOR lookup) and the batched EdDSA equations, own AIRs standing in for Curta's chips

@@ -98,6 +98,29 @@ def test_a_range_shorter_than_the_capacity_and_a_broken_chain(ctx):
             t.free()
 
 
+def test_rotate_states_the_new_authority_set_hash(ctx):
+    """One rotate request at miniature sizes: plonky2 proof + BLAKE2b over the epoch end header + SHA-256 over both commitment chains +
+    the signature bus -> the statement is avail_codec.rotate_output of the same request; a request whose header announces another key
+    than the witness's new set is refused."""
+    per_kind, tables, _ = dag_tables.build_rotate(ctx, [ctx], small=True)
+    prover = mr.GpuProver(ctx, "rotate", 11, [(0, 0)], 50, distinct_witnesses=1, starks=per_kind["rotate"])
+    shape = dag_tables.rotate_shape(True)
+    try:
+        for seed in (b"rotate 1", b"rotate 2"):
+            res = mr.prove_rotate(prover, seed)
+            req = hr.cached_request(seed, rotate=True, **shape)
+            assert len(res["record"]) == 64 and res["output"] == hr.expected_rotate_output(req) == ac.authority_set_commitment(req.new_pubkeys)
+        assert mr.prove_rotate(prover, b"rotate 1")["record"] != res["record"]
+        bad = hr.cached_request(b"rotate 3", rotate=True, **shape)
+        bad.new_pubkeys[3] = bytes(32)
+        with pytest.raises(hr.StatementError, match="does not announce"):
+            mr.prove_rotate(prover, b"rotate 3")
+    finally:
+        prover.free()
+        for t in tables:
+            t.free()
+
+
 def test_signature_bus_balances_only_when_every_signature_verifies(ctx):
     """The outer job's bus (SHA-512 bus variant + EdDSA full program + link + verifier sink, traces generated on the device): every proof
     verifies under the joint challenges and the closing sums add up to zero; with one signature's S replaced by S + 1 the EdDSA table

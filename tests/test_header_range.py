@@ -151,3 +151,36 @@ def test_what_the_circuit_asserts_is_refused_here():
         hr.outer_statement(req.input_bytes, top, few, chain, cd, ok)
     enough = dataclasses.replace(just, validator_signed=[True] * 6 + [False] * 2)
     assert hr.outer_statement(req.input_bytes, top, enough, chain, cd, ok[:2]) == out
+
+
+def test_rotate_statement_arrives_at_the_new_authority_set_hash_and_refuses_what_the_circuit_refuses():
+    req = hr.make_rotate_request(b"rotate", 8, 2, 8)
+    just = req.justification()
+    cm, nm = hr.authority_chain_messages(just.pubkeys), hr.authority_chain_messages(req.new_pubkeys)
+    cd, nd = [SHA(m) for m in cm], [SHA(m) for m in nm]
+    ok = [(pk, just.encoded_precommit, sg) for pk, sg in zip(just.pubkeys, just.signatures)]
+    hh = B2B(req.header)
+    args = dict(input_bytes=req.input_bytes, header=req.header, header_hash=hh, just=just, chain_msgs=cm, chain_digests=cd, verified=ok,
+                start_position=req.start_position, new_pubkeys=req.new_pubkeys, new_chain_msgs=nm, new_chain_digests=nd)
+    out = hr.rotate_statement(**args)
+    assert out == hr.expected_rotate_output(req) == ac.authority_set_commitment(req.new_pubkeys) and len(out) == 32
+    inp = ac.unpack_rotate_input(req.input_bytes)
+    assert inp["authority_set_hash"] == ac.authority_set_commitment(just.pubkeys)
+    pc = ac.decode_precommit(just.encoded_precommit)
+    assert pc["block_hash"] == hh and pc["block_number"] == ac.decode_header(req.header)["block_number"]
+
+    def refused(what, **kw):
+        with pytest.raises(hr.StatementError, match=what):
+            hr.rotate_statement(**dict(args, **kw))
+
+    refused("not the committed one", input_bytes=ac.pack_rotate_input(inp["authority_set_id"], b"\x01" * 32))
+    refused("precommit is not for", input_bytes=ac.pack_rotate_input(inp["authority_set_id"] + 1, inp["authority_set_hash"]))
+    refused("precommit is not for", header_hash=b"\x02" * 32)                       # the justification is about another header
+    refused("was not verified", verified=[])
+    other = list(req.new_pubkeys)
+    other[5] = b"\x09" * 32
+    refused("does not announce", new_pubkeys=other)                                # the header's log holds another key
+    refused("does not announce", start_position=req.start_position + 1)
+    refused("does not announce", new_pubkeys=req.new_pubkeys[:-1], new_chain_msgs=nm[:-1], new_chain_digests=nd[:-1])   # the encoded count differs
+    refused("new authority chain hashed something else", new_chain_msgs=[nm[0], nm[2], nm[1]] + nm[3:])
+    assert hr.rotate_statement(**dict(args, new_chain_digests=nd[:-1] + [b"\x07" * 32])) == b"\x07" * 32      # the output IS the table's last digest

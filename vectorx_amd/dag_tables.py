@@ -277,6 +277,66 @@ def build_per_job(ctx, lanes, kinds=("map", "reduce", "outer"), small=False, edd
     return per_kind, tables, rec
 
 
+def rotate_shape(small: bool) -> dict:
+    return {"num_authorities": 8 if small else 300, "distinct_keys": 2 if small else 8, "new_authorities": 8 if small else 300}
+
+
+def build_rotate(ctx, lanes=None, small=False, eddsa_log_n=20):
+    """The tables of ONE rotate proof (/root/reference/circuits/rotate.rs:80-109, builder/rotate.rs:278-323) over a synthetic request
+    (header_range.make_rotate_request(input_seed)): BLAKE2b over the epoch end header (2^16 rows: the XOR table's height), SHA-256 over
+    the CURRENT authority set's commitment chain and the NEW set's (2 x 599 compressions: 2^17 rows), the justification's 300
+    signatures through the signature bus — traces generated on the GPU inside the job — and the job's statement: the new authority
+    set's hash, after the checks of header_range.rotate_statement.  -> ({"rotate": [(label, table)]}, [tables to free], record)"""
+    from . import blake2b_bytes_air, eddsa_air, sha256_air, stark_chips
+    from . import header_range as hr
+    lanes = list(lanes or [ctx])
+    shape = rotate_shape(small)
+    rec, tables = {"mode": "per_job", "request": dict(shape, what="synthetic rotate request: an epoch end header announcing the new set, justified by the current one")}, []
+    WARM = b"warm-up"
+
+    def request(job):
+        return hr.cached_request(job[3] if job is not None else WARM, rotate=True, **shape)
+
+    def gen(label, which, air, log_n, messages_fn):
+        t0 = time.perf_counter()
+        stark = air.make_stark(log_n)
+        tab = stark_chips.GeneratedHashTable(ctx, which, stark, log_n, messages_fn, lanes, label)
+        for lane in lanes:
+            tab.prove(lane, None)
+            tab.take_spent(lane)
+        tables.append(tab)
+        rec[label] = {"rows_log2": log_n, "columns": f"{stark.desc.num_columns} + {stark.desc.num_aux_columns}", "messages": len(messages_fn(None)),
+                      "trace": "generated per job on the GPU", "setup_incl_one_proof_per_lane_s": round(time.perf_counter() - t0, 2)}
+        return tab
+
+    _signature_inputs(request(None))
+    blake = gen("blake2b_header", "blake2b", blake2b_bytes_air, 16, lambda job: [request(job).header])
+    sha = gen("sha256_chains", "sha256", sha256_air, 11 if small else 17,
+              lambda job: hr.authority_chain_messages(request(job).justification().pubkeys) + hr.authority_chain_messages(request(job).new_pubkeys))
+    t0 = time.perf_counter()
+    lg, lg_ed = (11, 17) if small else (16, eddsa_log_n)
+    bus = stark_chips.GeneratedSignatureBus(ctx, lambda job: _signature_inputs(request(job)), lanes, shape["num_authorities"], sha_log_n=lg, ed_log_n=lg_ed)
+    for lane in lanes:
+        bus.prove(lane, None)
+        bus.take_spent(lane)
+        assert bus.closed(lane), "the signature bus does not balance"
+    tables.append(bus)
+    rec["signature_bus"] = {"eddsa_tables": bus.ntab, "signatures": shape["num_authorities"], "setup_incl_one_bus_per_lane_s": round(time.perf_counter() - t0, 2)}
+
+    def statement(lane, job):
+        req = request(job)
+        (hdrs, hashes), (cmsgs, cdigs), raw = blake.last[id(lane)], sha.last[id(lane)], bus.last[id(lane)][0]
+        if [bytes(h) for h in hdrs] != [req.header]:
+            raise hr.StatementError("the BLAKE2b table hashed something else than the epoch end header")
+        if not bus.closed(lane):
+            raise hr.StatementError("the signature bus does not balance: a signature of the justification does not verify")
+        na = req.justification().num_authorities
+        return hr.rotate_statement(req.input_bytes, req.header, hashes[0], req.justification(), cmsgs[:na], cdigs[:na], raw, req.start_position,
+                                   req.new_pubkeys, cmsgs[na:], cdigs[na:])
+
+    return {"rotate": [("blake2b", blake), ("sha256", sha), ("signature_bus", bus), ("statement", JobStatement(statement))]}, tables, rec
+
+
 def build(ctx, kinds=("map", "reduce", "outer"), small=False, mode="per_job", lanes=None, outer_lanes=None, num_map=64, num_headers=None):
     """mode "per_job" (default) or "resident" (rounds 3-4: one host-generated trace per table kind)"""
     if mode == "resident":

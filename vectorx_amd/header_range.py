@@ -4,7 +4,9 @@
     assertions after them (:292-296): `map_statement`, `reduce_statement`, `Subchain` (= `MapReduceSubchainVariable`, :27-45);
   * `verify_simple_justification` (/root/reference/circuits/builder/justification.rs:195-257) with the chained authority set
     commitment (:127-162) and the voting threshold (:164-186): `outer_statement`;
-  * `HeaderRangeCircuit::define` (/root/reference/circuits/header_range.rs:31-58): 80 input bytes -> 96 output bytes.
+  * `HeaderRangeCircuit::define` (/root/reference/circuits/header_range.rs:31-58): 80 input bytes -> 96 output bytes;
+  * `RotateCircuit::define` / `rotate` (/root/reference/circuits/rotate.rs:80-109, builder/rotate.rs:278-323): 40 input bytes -> the new
+    authority set's hash: `rotate_statement`.
 
 Every HASH comes from outside: the DAG hands in the digests its GPU tables computed (BLAKE2b over the headers, SHA-256 over the tree
 nodes and the authority chain; the signatures through the signature bus) together with the messages those tables hashed, and the
@@ -180,14 +182,12 @@ class Justification:
         return len(self.pubkeys)
 
 
-def outer_statement(input_bytes: bytes, subchain: Subchain, just: Justification, chain_msgs, chain_digests, verified) -> bytes:
-    """`HeaderRangeCircuit::define` above the MapReduce (header_range.rs:31-58): the two assertions that tie the subchain to the input
-    (subchain_verification.rs:292-296), verify_simple_justification (justification.rs:195-257) -> the 96 output bytes.
-    chain_msgs / chain_digests: what the SHA-256 table hashed for the authority set commitment and its digests;
-    verified: the (public key, message, signature) triples the signature bus has verified (it balanced)."""
-    inp = ac.unpack_header_range_input(input_bytes)
-    _check(inp["trusted_header"] == subchain.start_parent, "the header chain does not start at the trusted header")
-    _check(inp["target_block"] == subchain.end_block, "the header chain does not end at the target block")
+def justification_checks(block_number: int, block_hash: bytes, authority_set_id: int, authority_set_hash: bytes, just: Justification,
+                         chain_msgs, chain_digests, verified):
+    """`verify_simple_justification` (/root/reference/circuits/builder/justification.rs:195-257): the authority set is the committed one
+    (chain_msgs / chain_digests: what the SHA-256 table hashed for the commitment chain, and its digests), the precommit is for this
+    block under this set, everyone marked as signed has a signature among `verified` (the (public key, message, signature) triples a
+    balanced signature bus has verified), and more than 2/3 signed."""
     # 1) the authority set commitment
     _check(just.num_authorities >= 1, "an authority set has at least one member")
     _check(len(chain_msgs) == len(chain_digests) == just.num_authorities, "the authority chain has one hash per authority")
@@ -195,18 +195,49 @@ def outer_statement(input_bytes: bytes, subchain: Subchain, just: Justification,
     for pk, m, d in zip(just.pubkeys, chain_msgs, chain_digests):
         _check(bytes(m) == prev + bytes(pk), "the authority chain hashed something else than commitment || key")
         prev = bytes(d)
-    _check(prev == inp["authority_set_hash"], "the authority set is not the committed one")
+    _check(prev == authority_set_hash, "the authority set is not the committed one")
     # 2) the precommit message
     pc = ac.decode_precommit(just.encoded_precommit)
-    _check(pc["block_number"] == inp["target_block"] and pc["authority_set_id"] == inp["authority_set_id"]
-           and pc["block_hash"] == subchain.end_header_hash, "the precommit is not for the target block under this authority set")
+    _check(pc["block_number"] == block_number and pc["authority_set_id"] == authority_set_id and pc["block_hash"] == block_hash,
+           "the precommit is not for the target block under this authority set")
     # 3) the signatures of everyone marked as signed
     have = {(bytes(pk), bytes(m), bytes(sg)) for pk, m, sg in verified}
     for pk, sg, signed in zip(just.pubkeys, just.signatures, just.validator_signed):
         _check(not signed or (bytes(pk), just.encoded_precommit, bytes(sg)) in have, "a signature marked as present was not verified")
     # 4) more than 2/3 signed
     _check(sum(1 for s in just.validator_signed if s) * 3 > just.num_authorities * 2, "not more than 2/3 of the authorities signed")
+
+
+def outer_statement(input_bytes: bytes, subchain: Subchain, just: Justification, chain_msgs, chain_digests, verified) -> bytes:
+    """`HeaderRangeCircuit::define` above the MapReduce (header_range.rs:31-58): the two assertions that tie the subchain to the input
+    (subchain_verification.rs:292-296), verify_simple_justification on the target header -> the 96 output bytes."""
+    inp = ac.unpack_header_range_input(input_bytes)
+    _check(inp["trusted_header"] == subchain.start_parent, "the header chain does not start at the trusted header")
+    _check(inp["target_block"] == subchain.end_block, "the header chain does not end at the target block")
+    justification_checks(inp["target_block"], subchain.end_header_hash, inp["authority_set_id"], inp["authority_set_hash"], just,
+                         chain_msgs, chain_digests, verified)
     return ac.pack_header_range_output(subchain.end_header_hash, subchain.state_merkle_root, subchain.data_merkle_root)
+
+
+def rotate_statement(input_bytes: bytes, header: bytes, header_hash: bytes, just: Justification, chain_msgs, chain_digests, verified,
+                     start_position: int, new_pubkeys, new_chain_msgs, new_chain_digests) -> bytes:
+    """`RotateCircuit::define` / `rotate` (/root/reference/circuits/rotate.rs:80-109, builder/rotate.rs:278-323): the epoch end header
+    hashes to `header_hash` (the BLAKE2b table's digest of exactly these bytes — the caller checks that), the CURRENT authority set
+    justifies it, the header's consensus log holds the NEW set (verify_epoch_end_header: avail_codec), and the output is the new
+    set's commitment — the last digest of the chain the SHA-256 table hashed over the new keys."""
+    inp = ac.unpack_rotate_input(input_bytes)
+    number = ac.decode_header(header)["block_number"]
+    justification_checks(number, bytes(header_hash), inp["authority_set_id"], inp["authority_set_hash"], just, chain_msgs, chain_digests, verified)
+    try:
+        ac.verify_epoch_end_header(header, start_position, len(new_pubkeys), new_pubkeys)
+    except (ValueError, IndexError) as e:
+        raise StatementError(f"the epoch end header does not announce this authority set: {e}") from None
+    _check(len(new_chain_msgs) == len(new_chain_digests) == len(new_pubkeys), "the new authority chain has one hash per authority")
+    prev = b""
+    for pk, m, d in zip(new_pubkeys, new_chain_msgs, new_chain_digests):
+        _check(bytes(m) == prev + bytes(pk), "the new authority chain hashed something else than commitment || key")
+        prev = bytes(d)
+    return prev
 
 
 # ---- synthetic requests ---------------------------------------------------------------------------------------------------------------
@@ -275,6 +306,49 @@ def make_request(seed: bytes, capacity: int = 512, header_bytes: int = MAX_HEADE
     return req
 
 
+@dataclass
+class RotateRequest:
+    input_bytes: bytes            # the 40 bytes of the function call: current authority set id, current authority set hash
+    header: bytes                 # the epoch end header
+    start_position: int           # where its consensus log starts (the byte in front of the flag)
+    new_pubkeys: list
+    keys: list
+    seed: bytes
+    _just: Justification = None
+    _lock: threading.Lock = None
+
+    def justification(self) -> Justification:
+        with self._lock:
+            if self._just is None:
+                from . import eddsa_air as ea
+                inp = ac.unpack_rotate_input(self.input_bytes)
+                number = ac.decode_header(self.header)["block_number"]
+                pc = ac.encode_precommit(hashlib.blake2b(self.header, digest_size=32).digest(), number, 1, inp["authority_set_id"])
+                sigs = [ea.sign(sk, pc)[1] for sk, _ in self.keys]
+                k, na = len(self.keys), self._num_authorities
+                self._just = Justification(pc, [self.keys[i % k][1] for i in range(na)], [sigs[i % k] for i in range(na)], [True] * na)
+            return self._just
+
+
+def make_rotate_request(seed: bytes, num_authorities: int = 300, distinct_keys: int = 8, new_authorities: int = 300, authority_set_id: int = 7) -> RotateRequest:
+    """A synthetic rotate request: an epoch end header announcing `new_authorities` keys (avail_codec.synthetic_epoch_end_header),
+    justified by the current set of `num_authorities` authorities cycling `distinct_keys` real key pairs."""
+    xof = hashlib.shake_256(b"vectorx rotate request|" + bytes(seed))
+    number = 100_000 + int.from_bytes(xof.digest(4), "little") % 1_000_000
+    header, start, new_pubkeys = ac.synthetic_epoch_end_header(bytes(seed), new_authorities, number)
+    keys = [_authority_key(i) for i in range(distinct_keys)]
+    pubkeys = [keys[i % distinct_keys][1] for i in range(num_authorities)]
+    req = RotateRequest(ac.pack_rotate_input(authority_set_id, ac.authority_set_commitment(pubkeys)), header, start, new_pubkeys, keys, bytes(seed))
+    req._lock = threading.Lock()
+    req._num_authorities = num_authorities
+    return req
+
+
+def expected_rotate_output(req: RotateRequest) -> bytes:
+    """the 32 output bytes computed WITHOUT the tables (avail_codec.rotate_output: the header checks + hashlib)"""
+    return ac.rotate_output(req.header, req.start_position, req.new_pubkeys)
+
+
 _keys, _keys_lock = {}, threading.Lock()
 
 
@@ -300,13 +374,13 @@ def expected_output(req: Request) -> bytes:
 _cache, _cache_lock = {}, threading.Lock()
 
 
-def cached_request(seed: bytes, **shape) -> Request:
-    """one Request per (seed, shape) and process: every lane of a worker reads the same header chain"""
-    key = (bytes(seed), tuple(sorted(shape.items())))
+def cached_request(seed: bytes, rotate: bool = False, **shape):
+    """one Request (RotateRequest) per (seed, shape) and process: every lane of a worker reads the same header chain"""
+    key = (bytes(seed), rotate, tuple(sorted(shape.items())))
     with _cache_lock:
         req = _cache.get(key)
         if req is None:
-            if len(_cache) >= 4:
+            if len(_cache) >= 6:
                 _cache.pop(next(iter(_cache)))
-            req = _cache[key] = make_request(seed, **shape)
+            req = _cache[key] = (make_rotate_request if rotate else make_request)(seed, **shape)
         return req

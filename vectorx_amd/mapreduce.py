@@ -298,6 +298,17 @@ def prove_with_tables(prove_main, tables, lane_ctx=None, split=None, lock=None, 
     return b"".join(parts)
 
 
+def prove_rotate(prover, input_seed: bytes = b"", spent_out=None) -> dict:
+    """ONE rotate request (/root/reference/circuits/rotate.rs:80-109 is a single proof, no MapReduce) on `prover` — a GpuProver of kind
+    "rotate" carrying dag_tables.build_rotate's tables: the plonky2 proof, the tables of the request `input_seed` names, the statement.
+    -> {"record": digest || new authority set hash, "output": the 32 output bytes, "seconds"}"""
+    t0 = time.perf_counter()
+    pis = digest_to_field(hashlib.sha256(b"rotate" + bytes(input_seed)).digest())
+    result = prover.prove((0, 0), pis, 0, input_seed=input_seed, spent_out=spent_out)
+    rec = record_of(result, prover)
+    return {"record": rec, "output": rec[32:], "seconds": time.perf_counter() - t0, "result_bytes": len(result)}
+
+
 class GpuProver:
     """One circuit kind on one GPU: circuit loaded once (constants_sigmas resident), one device-resident witness per
     job; `prove` patches the two witness rows that depend on the public inputs and calls vx_prove."""
@@ -325,7 +336,7 @@ class GpuProver:
         # a table that `needs_children` is the job's STATEMENT (dag_tables.JobStatement): host logic over what the other tables hashed
         # and what the children stated; it closes the job's result bytes
         self.emits_statement = any(getattr(t, "needs_children", False) for _, t in self.starks)
-        circuit_seed = {"map": 101, "reduce": 202, "outer": 303}[kind]
+        circuit_seed = {"map": 101, "reduce": 202, "outer": 303, "rotate": 404}[kind]
         self.sc = SynthCircuit(log_n, seed=circuit_seed, poseidon_percent=poseidon_percent, witness_seed=0)
         self.circuits = [vx.Circuit(c, self.sc.desc_ptr) for c in self.lanes]
         self.circuit = self.circuits[0]
