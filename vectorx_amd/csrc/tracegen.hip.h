@@ -18,32 +18,23 @@
 
 #define TG_THREADS 256
 
-// The lookup histogram of a BLAKE2b table takes 232 increments per row — 15 M per map job — into 65 536 bins.  Device-scope atomics
-// are performed at the fabric, not in an XCD's L2 (the eight L2s are not coherent with each other): measured 1.2 G/s, 12.9 ms per
-// table (profiles/r05_tracegen.md).  So every XCD counts into ITS OWN copy of the histogram with atomics that stay in its L2
-// (workgroup scope: no sc1 — all the CUs that touch copy x sit behind L2 x, which serialises them; HW_REG_XCC_ID names the XCD a
-// workgroup runs on and a workgroup never moves), the copies reach memory at the end of the kernel, and the kernel that writes the
-// multiplicity columns adds the eight up.  Lanes holding the same key are merged first (two leader rounds): the all-zero triples of
-// the inactive gadgets — most of a table's lookups — cost one atomic per wavefront instead of 64 on one address.
+// The lookup histograms of the BLAKE2b and EdDSA tables: 232 increments per BLAKE2b row (15 M per map job), ~92 per EdDSA row (96 M per
+// 2^20-row table, on keys as good as random), into 65 536 bins.  What was measured on the way (profiles/README.md, round 5):
+//   * device-scope atomics are performed at the fabric, not in an XCD's L2 (the eight L2s are not coherent with each other):
+//     1.2 G/s, 12.9 ms per BLAKE2b table;
+//   * one copy of the histogram PER XCD, atomics that stay in its L2 (workgroup scope: all the CUs that touch copy x sit behind L2 x;
+//     HW_REG_XCC_ID names the XCD a workgroup runs on), equal keys merged across the wavefront first: 7 - 16 G/s — 1.9 ms per BLAKE2b
+//     table, and 12.7 of the EdDSA rows kernel's 14 ms (0.3 ms were its 4.4 GB of cells; measured with either switched off);
+//   * now: a workgroup counts in LDS.  1024 threads walk `rows_per_wg` rows and increment 32-bit counters for ONE HALF of the key
+//     space (32 768 bins = 128 KB of the CU's 160 KB; blockIdx.y names the half and only half 0 stores the cells — the row arithmetic
+//     is repeated, it is the cheap part), then add their non-zero bins to their XCD's copy: 32 768 global atomics per workgroup
+//     instead of 232 / 92 per row.  0.38 ms per BLAKE2b table (1.1 TB/s of cells), 3 ms for the EdDSA rows.
+// The kernel that writes the multiplicity columns adds the eight copies up.
 #define TG_HIST_COPIES 8
 __device__ __forceinline__ unsigned tg_xcc_id() {
   unsigned v;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
   return v & (TG_HIST_COPIES - 1);
-}
-__device__ __forceinline__ void tg_hist_add(unsigned* __restrict__ hist /* this XCD's copy */, unsigned key, bool valid) {
-  unsigned long long active = __ballot(valid);
-  const int lane = (int)(threadIdx.x & 63);
-#pragma unroll 1
-  for (int round = 0; round < 2 && active; ++round) {
-    const int leader = __ffsll((long long)active) - 1;
-    const unsigned k0 = (unsigned)__shfl((int)key, leader, 64);
-    const unsigned long long same = __ballot(valid && key == k0);
-    if (lane == leader) __hip_atomic_fetch_add(&hist[k0], (unsigned)__popcll(same), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    active &= ~same;
-    if (key == k0) valid = false;
-  }
-  if (valid) __hip_atomic_fetch_add(&hist[key], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 template <class T>
@@ -88,23 +79,60 @@ __global__ __launch_bounds__(TG_THREADS) void tg_b2_expand_kernel(const tg::b2::
   if (b >= nb) return;
   tg::b2::expand(blocks[b], tg::B2_IV, tg::B2_SIGMA, exp[b]);
 }
-__global__ __launch_bounds__(TG_THREADS) void tg_b2_rows_kernel(const tg::b2::Block* __restrict__ blocks,
-                                                                const tg::b2::Expanded* __restrict__ exp, u64* __restrict__ trace, size_t n,
-                                                                unsigned* __restrict__ hist) {
-  const size_t row_raw = (size_t)blockIdx.x * TG_THREADS + threadIdx.x;
-  const bool in = row_raw < n;
-  const size_t row = in ? row_raw : n - 1;          // every lane walks the row (the histogram merge is wave-wide); only real rows store
-  const size_t b = row / tg::b2::PERIOD;
-  const int r = (int)(row % tg::b2::PERIOD);
-  const tg::b2::Block& blk = blocks[b];
-  uint64_t zero8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  const uint64_t* hn_prev = b ? exp[b - 1].hn : zero8;
-  const uint64_t* dl = blk.dsrc >= 0 ? exp[blk.dsrc].hn : zero8;
-  const bool count = in && row + 1 < n;
-  unsigned* my_hist = hist + (size_t)tg_xcc_id() * 65536;
-  tg::b2::row(blk, exp[b], hn_prev, dl, r, row, tg::B2_IV, tg::B2_SIGMA,
-              [&](int col, uint64_t v) { if (in) trace[(size_t)col * n + row] = v; },
-              [&](unsigned a, unsigned bb) { tg_hist_add(my_hist, a * 256u + bb, count); });
+#define TG_LDS_THREADS 1024
+#define TG_LDS_BINS 32768
+__global__ __launch_bounds__(TG_LDS_THREADS) void tg_b2_rows_kernel(const tg::b2::Block* __restrict__ blocks,
+                                                                    const tg::b2::Expanded* __restrict__ exp, u64* __restrict__ trace, size_t n,
+                                                                    size_t rows_per_wg, unsigned* __restrict__ hist) {
+  extern __shared__ __attribute__((aligned(16))) unsigned tg_lh[];
+  for (int b = threadIdx.x; b < TG_LDS_BINS; b += TG_LDS_THREADS) tg_lh[b] = 0;
+  __syncthreads();
+  const unsigned half = blockIdx.y;
+  const size_t base = (size_t)blockIdx.x * rows_per_wg;
+  const size_t end = base + rows_per_wg < n ? base + rows_per_wg : n;
+  for (size_t row = base + threadIdx.x; row < end; row += TG_LDS_THREADS) {
+    const size_t b = row / tg::b2::PERIOD;
+    const int r = (int)(row % tg::b2::PERIOD);
+    const tg::b2::Block& blk = blocks[b];
+    uint64_t zero8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const uint64_t* hn_prev = b ? exp[b - 1].hn : zero8;
+    const uint64_t* dl = blk.dsrc >= 0 ? exp[blk.dsrc].hn : zero8;
+    const bool count = row + 1 < n;
+    tg::b2::row(blk, exp[b], hn_prev, dl, r, row, tg::B2_IV, tg::B2_SIGMA,
+                [&](int col, uint64_t v) { if (half == 0) trace[(size_t)col * n + row] = v; },
+                [&](unsigned a, unsigned bb) {
+                  const unsigned key = a * 256u + bb;
+                  if (count && (key >> 15) == half) __hip_atomic_fetch_add(&tg_lh[key & (TG_LDS_BINS - 1)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                });
+  }
+  __syncthreads();
+  unsigned* my_hist = hist + (size_t)tg_xcc_id() * 65536 + (size_t)half * TG_LDS_BINS;
+  for (int b = threadIdx.x; b < TG_LDS_BINS; b += TG_LDS_THREADS) {
+    const unsigned v = tg_lh[b];
+    if (v) __hip_atomic_fetch_add(&my_hist[b], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+}
+// one workgroup per CU and half: up to 128 row chunks x 2 halves fill the 256 CUs of the chip in one round
+static void tg_lds_grid(size_t n, size_t* chunks_out, size_t* rows_per_wg_out) {
+  size_t chunks = (n + TG_LDS_THREADS - 1) / TG_LDS_THREADS;
+  if (chunks > 128) chunks = 128;
+  const size_t rows_per_wg = ((n + chunks - 1) / chunks + TG_LDS_THREADS - 1) / TG_LDS_THREADS * TG_LDS_THREADS;
+  *chunks_out = (n + rows_per_wg - 1) / rows_per_wg, *rows_per_wg_out = rows_per_wg;
+}
+static hipError_t tg_launch_b2_rows(hipStream_t s, const tg::b2::Block* blocks, const tg::b2::Expanded* exp, u64* trace, size_t n, unsigned* hist) {
+  static bool attr_set[16] = {};
+  int dev = 0;
+  hipGetDevice(&dev);
+  const size_t lds = (size_t)TG_LDS_BINS * sizeof(unsigned);
+  if (!attr_set[dev & 15]) {
+    hipError_t e = hipFuncSetAttribute((const void*)tg_b2_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_set[dev & 15] = true;
+  }
+  size_t chunks, rows_per_wg;
+  tg_lds_grid(n, &chunks, &rows_per_wg);
+  hipLaunchKernelGGL(tg_b2_rows_kernel, dim3((unsigned)chunks, 2), dim3(TG_LDS_THREADS), lds, s, blocks, exp, trace, n, rows_per_wg, hist);
+  return hipGetLastError();
 }
 
 // ---- C ABI ----------------------------------------------------------------------------------------------------------------------
@@ -189,13 +217,12 @@ int vx_trace_blake2b(vx_ctx* c, int degree_bits, const uint8_t* msgs, const uint
     if (e == hipSuccess) {
       hipLaunchKernelGGL(tg_b2_expand_kernel, dim3((nb + TG_THREADS - 1) / TG_THREADS), dim3(TG_THREADS), 0, c->stream,
                          (const tg::b2::Block*)d_blocks, nb, (tg::b2::Expanded*)d_exp);
-      hipLaunchKernelGGL(tg_b2_rows_kernel, dim3((unsigned)((n + TG_THREADS - 1) / TG_THREADS)), dim3(TG_THREADS), 0, c->stream,
-                         (const tg::b2::Block*)d_blocks, (const tg::b2::Expanded*)d_exp, (u64*)trace_dev, n, (unsigned*)d_hist);
+      e = tg_launch_b2_rows(c->stream, (const tg::b2::Block*)d_blocks, (const tg::b2::Expanded*)d_exp, (u64*)trace_dev, n, (unsigned*)d_hist);
       for (int k = 0; k < tg::b2::NTAB; ++k)
         hipLaunchKernelGGL(tg_patch_mult_kernel, dim3(tg::b2::TAB_ROWS / 256), dim3(256), 0, c->stream,
                            (u64*)trace_dev + (size_t)tg::b2::tabcol(k, 19) * n, (const unsigned*)d_hist + (size_t)tg::b2::TAB_ROWS * k,
                            (unsigned)tg::b2::TAB_ROWS, TG_HIST_COPIES, (size_t)65536);
-      e = hipGetLastError();
+      if (e == hipSuccess) e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) rc = vx_fail(VX_E_HIP, "vx_trace_blake2b: %s", hipGetErrorString(e));
@@ -227,16 +254,45 @@ __global__ void tg_ed_results_kernel(const tg::ed::RowVals* __restrict__ vals, i
   const int u = i >> 3, w = (i >> 2) & 1, k = i & 3;
   results[i] = vals[(size_t)u * L + xrow + w].z[k];
 }
-__global__ __launch_bounds__(TG_THREADS) void tg_ed_rows_kernel(tg::ed::Cols c, const tg::ed::RegSrc* __restrict__ rsrc, const tg::ed::RowVals* __restrict__ vals,
-                                                                const tg::ed::Sig* __restrict__ sigs, int nsig, tg::ed::Sig filler,
-                                                                u64* __restrict__ trace, size_t n, unsigned* __restrict__ hist) {
-  const size_t row_raw = (size_t)blockIdx.x * TG_THREADS + threadIdx.x;
-  const bool in = row_raw < n;
-  const size_t row = in ? row_raw : n - 1;
-  const bool count = in && row + 1 < n;
-  unsigned* my_hist = hist + (size_t)tg_xcc_id() * 65536;
-  tg::ed::row(c, *rsrc, vals, sigs, nsig, filler, row, [&](int col, uint64_t v) { if (in) trace[(size_t)col * n + row] = v; },
-              [&](unsigned limb) { tg_hist_add(my_hist, limb, count); });
+// (the LDS histogram described at the top of this file)
+__global__ __launch_bounds__(TG_LDS_THREADS) void tg_ed_rows_kernel(tg::ed::Cols c, const tg::ed::RegSrc* __restrict__ rsrc, const tg::ed::RowVals* __restrict__ vals,
+                                                                    const tg::ed::Sig* __restrict__ sigs, int nsig, tg::ed::Sig filler,
+                                                                    u64* __restrict__ trace, size_t n, size_t rows_per_wg, unsigned* __restrict__ hist) {
+  extern __shared__ __attribute__((aligned(16))) unsigned tg_lh[];
+  for (int b = threadIdx.x; b < TG_LDS_BINS; b += TG_LDS_THREADS) tg_lh[b] = 0;
+  __syncthreads();
+  const unsigned half = blockIdx.y;
+  const size_t base = (size_t)blockIdx.x * rows_per_wg;
+  const size_t end = base + rows_per_wg < n ? base + rows_per_wg : n;
+  for (size_t row = base + threadIdx.x; row < end; row += TG_LDS_THREADS) {
+    const bool count = row + 1 < n;
+    tg::ed::row(c, *rsrc, vals, sigs, nsig, filler, row, [&](int col, uint64_t v) { if (half == 0) trace[(size_t)col * n + row] = v; },
+                [&](unsigned limb) {
+                  if (count && (limb >> 15) == half) __hip_atomic_fetch_add(&tg_lh[limb & (TG_LDS_BINS - 1)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                });
+  }
+  __syncthreads();
+  unsigned* my_hist = hist + (size_t)tg_xcc_id() * 65536 + (size_t)half * TG_LDS_BINS;
+  for (int b = threadIdx.x; b < TG_LDS_BINS; b += TG_LDS_THREADS) {
+    const unsigned v = tg_lh[b];
+    if (v) __hip_atomic_fetch_add(&my_hist[b], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+}
+static hipError_t tg_launch_ed_rows(hipStream_t s, const tg::ed::Cols& cl, const tg::ed::RegSrc* rsrc, const tg::ed::RowVals* vals, const tg::ed::Sig* sigs, int nsig,
+                                    const tg::ed::Sig& filler, u64* trace, size_t n, unsigned* hist) {
+  static bool attr_set[16] = {};
+  int dev = 0;
+  hipGetDevice(&dev);
+  const size_t lds = (size_t)TG_LDS_BINS * sizeof(unsigned);
+  if (!attr_set[dev & 15]) {
+    hipError_t e = hipFuncSetAttribute((const void*)tg_ed_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_set[dev & 15] = true;
+  }
+  size_t chunks, rows_per_wg;
+  tg_lds_grid(n, &chunks, &rows_per_wg);
+  hipLaunchKernelGGL(tg_ed_rows_kernel, dim3((unsigned)chunks, 2), dim3(TG_LDS_THREADS), lds, s, cl, rsrc, vals, sigs, nsig, filler, trace, n, rows_per_wg, hist);
+  return hipGetLastError();
 }
 
 int vx_trace_eddsa(vx_ctx* c, int degree_bits, int scalar_bits, int full, const uint64_t* sigs, int num_sigs, void* trace_dev, uint64_t* results_out) {
@@ -285,12 +341,11 @@ int vx_trace_eddsa(vx_ctx* c, int degree_bits, int scalar_bits, int full, const 
     if (e == hipSuccess) {
       hipLaunchKernelGGL(tg_ed_simulate_kernel, dim3((ninst + 63) / 64), dim3(64), 0, c->stream, cl, (const tg::ed::Sig*)d_sigs, num_sigs, filler, ninst,
                          (tg::ed::RowVals*)d_vals, (int*)d_bad);
-      hipLaunchKernelGGL(tg_ed_rows_kernel, dim3((unsigned)((n + TG_THREADS - 1) / TG_THREADS)), dim3(TG_THREADS), 0, c->stream, cl,
-                         (const tg::ed::RegSrc*)d_rsrc, (const tg::ed::RowVals*)d_vals, (const tg::ed::Sig*)d_sigs, num_sigs, filler, (u64*)trace_dev, n,
-                         (unsigned*)d_hist);
+      e = tg_launch_ed_rows(c->stream, cl, (const tg::ed::RegSrc*)d_rsrc, (const tg::ed::RowVals*)d_vals, (const tg::ed::Sig*)d_sigs, num_sigs, filler,
+                            (u64*)trace_dev, n, (unsigned*)d_hist);
       hipLaunchKernelGGL(tg_patch_mult_kernel, dim3(65536 / 256), dim3(256), 0, c->stream, (u64*)trace_dev + (size_t)cl.MULT * n, (const unsigned*)d_hist,
                          65536u, TG_HIST_COPIES, (size_t)65536);
-      e = hipGetLastError();
+      if (e == hipSuccess) e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(&bad, d_bad, sizeof bad, hipMemcpyDeviceToHost, c->stream);
     // the results: affine (x, y) every given instance arrives at, gathered on the device, one copy
