@@ -369,7 +369,9 @@ def dag_with_starks_leg(ctx, local_rank, in_flight=None, table_mode="per_job"):
     lanes = [vx.Context(local_rank) for _ in range(in_flight - 1)]
     # every lane proves every table once (untimed, inside build): its pool then holds the STARK shapes too, like vx_circuit_warm does
     # for the plonky2 shapes — the first timed pass allocates nothing
-    per_kind, tables, setup = dag_stark_tables(ctx, mode=table_mode, lanes=[ctx] + lanes)
+    # (the outer job is alone in its layer and runs on lane 0: only that lane holds the signature bus's buffers — 21 GB of traces, 42 GB
+    # of sessions while it proves; on every lane they would not fit next to the circuits)
+    per_kind, tables, setup = dag_stark_tables(ctx, mode=table_mode, lanes=[ctx] + lanes, outer_lanes=[ctx])
     spec = mr.DagSpec(64, 18, 16, 19)
     provers, split = {}, {}
 
