@@ -54,7 +54,7 @@ def parse():
     ap.add_argument("--dag-workers", type=int, default=3,
                     help="worker PROCESSES per GPU of the DAG legs (vectorx_amd/dag_pool.py; each keeps --dag-lanes jobs in flight); 0 = the one-process scheduler of rounds 1-4")
     ap.add_argument("--dag-lanes", type=int, default=3,
-                    help="jobs in flight per worker process (3 workers x 3 lanes: 3.38 s against 3.50 for 2 x 3 and 3 x 2, 3.42 for 4 x 2 on one box — profiles/r05_dag_pool.jsonl)")
+                    help="jobs in flight per worker process (3 workers x 3 lanes: 3.38 s against 3.50 for 2 x 3 and 3 x 2, 3.42 for 4 x 2 on one box — profiles/r05_dag_pool.jsonl; 3 x 4 and 4 x 3 are no faster)")
     ap.add_argument("--no-rotate-leg", action="store_true", help="skip the rotate leg (one rotate request: plonky2 2^19 + its tables; N = 1 only)")
     ap.add_argument("--no-dag-pool-leg", action="store_true",
                     help="N > 1 only: skip the leg that runs the DAG on ONE pool of worker processes spanning all N GPUs (rank 0 coordinates; vectorx_amd/dag_pool.py)")
