@@ -448,8 +448,16 @@ static int build_merkle_levels(vx_ctx* c, u64* tree, size_t n_leaves, int cap_he
   ProfScope ps(c, "merkle_levels");
   size_t off = 0, n = n_leaves;
   const size_t ncap = (size_t)1 << cap_height;
+  // VX_MTOP_MAX_CHILDREN: A/B knob — from how many children on the fused top kernel takes over (default: its maximum, 32 768).  The
+  // cooperative permutation it runs costs ~5 x the issue slots of the one-thread-per-node form: a lower threshold trades a lone
+  // proof's latency (one more launch per level) for issue slots when many proofs share the chip.
+  static const size_t mtop_max = [] {
+    const char* e = getenv("VX_MTOP_MAX_CHILDREN");
+    const size_t v = e ? (size_t)strtoull(e, nullptr, 10) : (size_t)MTOP_MAX_CHILDREN;
+    return v > (size_t)MTOP_MAX_CHILDREN ? (size_t)MTOP_MAX_CHILDREN : v;
+  }();
   while (n > ncap) {
-    if (n <= MTOP_MAX_CHILDREN && ncap <= MTOP_MAX_COUNTERS) {
+    if (n <= mtop_max && ncap <= MTOP_MAX_COUNTERS) {
       // every remaining level in one launch (merkle.hip.h: merkle_top_kernel)
       int sub_log = 0;
       while (((size_t)ncap << (sub_log + 1)) <= n) ++sub_log;   // children per cap subtree = 2^sub_log
@@ -463,7 +471,7 @@ static int build_merkle_levels(vx_ctx* c, u64* tree, size_t n_leaves, int cap_he
       break;
     }
     size_t np = n >> 1;
-    if (np <= COOP_MAX_NODES)  // latency-bound level: 16 lanes per node (only reached with a cap wider than MTOP_MAX_COUNTERS)
+    if (np <= COOP_MAX_NODES && ncap > MTOP_MAX_COUNTERS)  // latency-bound level: 16 lanes per node (only with a cap wider than MTOP_MAX_COUNTERS)
       hipLaunchKernelGGL(merkle_level_coop_kernel, dim3((unsigned)((np * 16 + HASH_THREADS - 1) / HASH_THREADS)),
                          dim3(HASH_THREADS), 0, c->stream, tree + off * 4, tree + (off + n) * 4, np);
     else
