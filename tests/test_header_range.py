@@ -184,3 +184,33 @@ def test_rotate_statement_arrives_at_the_new_authority_set_hash_and_refuses_what
     refused("does not announce", new_pubkeys=req.new_pubkeys[:-1], new_chain_msgs=nm[:-1], new_chain_digests=nd[:-1])   # the encoded count differs
     refused("new authority chain hashed something else", new_chain_msgs=[nm[0], nm[2], nm[1]] + nm[3:])
     assert hr.rotate_statement(**dict(args, new_chain_digests=nd[:-1] + [b"\x07" * 32])) == b"\x07" * 32      # the output IS the table's last digest
+
+
+def test_random_ranges_and_mutations_property():
+    """hypothesis: for random capacities, range lengths and header sizes the statements arrive at the host computation; a flipped byte in
+    any enabled header is either refused (a link / position assertion) or changes the output (a root or the target hash moved) — never
+    silently accepted with the same output."""
+    from hypothesis import given, settings
+    from hypothesis import strategies as st
+
+    @settings(max_examples=15, deadline=None, derandomize=True)
+    @given(st.sampled_from([16, 32, 64]), st.data())
+    def check(capacity, data):
+        n = data.draw(st.integers(1, capacity))
+        size = data.draw(st.sampled_from([101, 128, 333, 512]))
+        shape = dict(capacity=capacity, header_bytes=size, num_authorities=4, distinct_keys=2, num_headers=n)
+        req = hr.make_request(b"prop %d %d %d" % (capacity, n, size), **shape)
+        out, top = run_statements(req)
+        assert out == hr.expected_output(req) and top.num_blocks == n
+        k = data.draw(st.integers(0, n - 1))
+        pos = data.draw(st.integers(0, size - 1))
+        h = bytearray(req.headers[k])
+        h[pos] ^= 1 << data.draw(st.integers(0, 7))
+        req.headers[k] = bytes(h)
+        try:
+            out2, _ = run_statements(req)
+        except (hr.StatementError, ValueError):
+            return
+        assert out2 != out        # (a changed hash breaks the next link, or the precommit no longer names the target header)
+
+    check()
