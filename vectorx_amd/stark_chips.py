@@ -416,8 +416,13 @@ class GeneratedSignatureBus:
         gens = [c] + self.helpers[id(c)]
         per_table = [None] * self.ntab
 
+        failed = []
+
         def generate(t):
-            per_table[t] = gens[t].trace_eddsa_table(self.ed_log_n, 256, eq[t * self.cap:(t + 1) * self.cap], bufs[1 + t][0], full=True)
+            try:
+                per_table[t] = gens[t].trace_eddsa_table(self.ed_log_n, 256, eq[t * self.cap:(t + 1) * self.cap], bufs[1 + t][0], full=True)
+            except BaseException as e:          # surfaces after the join, with the generator's own message
+                failed.append(e)
 
         if self.ntab > 1:
             c.sync()                                    # the SHA-512 trace is on the lane's stream; the helpers' streams know nothing of it
@@ -427,10 +432,10 @@ class GeneratedSignatureBus:
             generate(0)
             for th in threads:
                 th.join()
-            if any(r is None for r in per_table):
-                raise RuntimeError("an EdDSA trace generator failed on its helper stream")
         else:
             generate(0)
+        if failed:
+            raise failed[0]
         results = [r for part in per_table for r in part]     # (the call returns the instances' results: it has synchronised its stream)
         for t in range(self.ntab):
             items.append((self.ed, bufs[1 + t][0], nopi, bufs[1 + t][1]))
