@@ -64,7 +64,8 @@ def test_requests_are_self_consistent_and_differ():
     assert pc["block_hash"] == B2B(a.headers[-1]) and pc["block_number"] == a.target_block and len(just.encoded_precommit) == 53
     from vectorx_amd import eddsa_air as ea
     for pk, sg in zip(just.pubkeys[:2], just.signatures[:2]):
-        ea.equation_inputs(pk, just.encoded_precommit, sg)               # RFC 8032 verification on the host: raises if it does not verify
+        assert ea.verify(pk, just.encoded_precommit, sg)                 # RFC 8032 verification on the host
+    assert not ea.verify(just.pubkeys[0], just.encoded_precommit, just.signatures[1])
 
 
 def test_header_codec():

@@ -161,7 +161,27 @@ class JobStatement:
         pass
 
 
-def build_per_job(ctx, lanes, kinds=("map", "reduce", "outer"), small=False, eddsa_log_n=20, outer_lanes=None, num_map=64, num_headers=None):
+class GpuTables:
+    """what build_per_job makes its tables with: the GPU library's (stark_chips.GeneratedHashTable / GeneratedSignatureBus).  The
+    CPU tests hand in a factory of their own with hashlib in the tables' place (tests/_cpu_tables.py): the statements, the records and
+    the schedulers above them then run — also over gloo ranks — without a GPU."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def hash_table(self, label, which, log_n, messages_fn, lanes):
+        from . import blake2b_bytes_air, sha256_air, stark_chips
+        air = {"blake2b": blake2b_bytes_air, "sha256": sha256_air}[which]
+        stark = air.make_stark(log_n)
+        tab = stark_chips.GeneratedHashTable(self.ctx, which, stark, log_n, messages_fn, lanes, label)
+        return tab, f"{stark.desc.num_columns} + {stark.desc.num_aux_columns}"
+
+    def signature_bus(self, sigs_fn, lanes, nsigs, sha_log_n, ed_log_n):
+        from . import stark_chips
+        return stark_chips.GeneratedSignatureBus(self.ctx, sigs_fn, lanes, nsigs, sha_log_n=sha_log_n, ed_log_n=ed_log_n)
+
+
+def build_per_job(ctx, lanes, kinds=("map", "reduce", "outer"), small=False, eddsa_log_n=20, outer_lanes=None, num_map=64, num_headers=None, factory=None):
     """Every job proves tables of ITS OWN inputs — the request's (header_range.make_request(input_seed)) and its children's
     statements —, traces generated on the GPU inside the job (vx_trace_*), and states what the reference's circuit would
     (/root/reference/circuits/builder/subchain_verification.rs:84-289, justification.rs:195-257), with every hash taken from the tables:
@@ -173,9 +193,9 @@ def build_per_job(ctx, lanes, kinds=("map", "reduce", "outer"), small=False, edd
                rows), 4 batched EdDSA tables running the full program (2^20 rows, 97 instances each), the link table, the
                verifier's sink -> the 96 output bytes (target header hash, state / data root commitments).
     -> ({kind: [(label, table)]}, [tables to free], setup record)"""
-    from . import blake2b_bytes_air, sha256_air, stark_chips
     from . import header_range as hr
     lanes = list(lanes)
+    factory = GpuTables(ctx) if factory is None else factory
     rec, tables, per_kind = {"mode": "per_job", "resident_trace": []}, [], {}
     shape = request_shape(small, num_map, num_headers)
     nkeys = shape["num_authorities"]
@@ -186,15 +206,14 @@ def build_per_job(ctx, lanes, kinds=("map", "reduce", "outer"), small=False, edd
     def request(job):
         return hr.cached_request(job[3] if job is not None else WARM, **shape)
 
-    def gen(label, which, air, log_n, messages_fn):
+    def gen(label, which, log_n, messages_fn):
         t0 = time.perf_counter()
-        stark = air.make_stark(log_n)
-        tab = stark_chips.GeneratedHashTable(ctx, which, stark, log_n, messages_fn, lanes, label)
+        tab, columns = factory.hash_table(label, which, log_n, messages_fn, lanes)
         for lane in lanes:                      # warm-up per lane: loads the compiled evaluator / second-round program, fills the pool
             tab.prove(lane, None)
             tab.take_spent(lane)
         tables.append(tab)
-        rec[label] = {"rows_log2": log_n, "columns": f"{stark.desc.num_columns} + {stark.desc.num_aux_columns}", "messages": len(messages_fn(None)),
+        rec[label] = {"rows_log2": log_n, "columns": columns, "messages": len(messages_fn(None)),
                       "trace": "generated per job on the GPU", "setup_incl_one_proof_per_lane_s": round(time.perf_counter() - t0, 2)}
         return tab
 
@@ -207,8 +226,8 @@ def build_per_job(ctx, lanes, kinds=("map", "reduce", "outer"), small=False, edd
             state, data = hr.map_leaves(req.target_block, headers_of(job))
             return hr.tree_messages(state) + hr.tree_messages(data)
 
-        blake = gen("blake2b_map", "blake2b", blake2b_bytes_air, 16, headers_of)
-        sha_map = gen("sha256_map", "sha256", sha256_air, 11, tree_nodes_of)
+        blake = gen("blake2b_map", "blake2b", 16, headers_of)
+        sha_map = gen("sha256_map", "sha256", 11, tree_nodes_of)
 
         def map_statement(lane, job):
             req = request(job)
@@ -227,7 +246,7 @@ def build_per_job(ctx, lanes, kinds=("map", "reduce", "outer"), small=False, edd
                 return job_bytes(None, b"merge", 2, 64)
             return hr.reduce_messages(*children_of(job))
 
-        sha_red = gen("sha256_reduce", "sha256", sha256_air, 9, merge_nodes_of)
+        sha_red = gen("sha256_reduce", "sha256", 9, merge_nodes_of)
 
         def reduce_statement(lane, job):
             msgs, digs = sha_red.last[id(lane)]
@@ -240,7 +259,7 @@ def build_per_job(ctx, lanes, kinds=("map", "reduce", "outer"), small=False, edd
             lanes = list(outer_lanes)
         t0 = time.perf_counter()
         preload_request(WARM, shape, outer=True)
-        sha_out = gen("sha256_outer", "sha256", sha256_air, lg, lambda job: hr.authority_chain_messages(request(job).justification().pubkeys))
+        sha_out = gen("sha256_outer", "sha256", lg, lambda job: hr.authority_chain_messages(request(job).justification().pubkeys))
         # The justification's signatures, verified THROUGH TABLES ONLY and proven as one bus (stark_chips.GeneratedSignatureBus): the SHA-512
         # table over the signed messages R || A || precommit (117 bytes each) sends (R, A, digest); four batched EdDSA tables running the
         # FULL program (decompression, digest mod L, S < L, the group equation) send (A, S, digest, R); the link table joins them and
@@ -248,7 +267,7 @@ def build_per_job(ctx, lanes, kinds=("map", "reduce", "outer"), small=False, edd
         # of the request's precommit (RFC 8032 signing on the host, untimed: they are the request's input), by 8 distinct authorities.
         from . import eddsa_air
         lg_ed = 17 if small else eddsa_log_n
-        bus = stark_chips.GeneratedSignatureBus(ctx, lambda job: _signature_inputs(request(job)), lanes, nkeys, sha_log_n=lg, ed_log_n=lg_ed)
+        bus = factory.signature_bus(lambda job: _signature_inputs(request(job)), lanes, nkeys, lg, lg_ed)
         for lane in lanes:
             bus.prove(lane, None)
             bus.take_spent(lane)
@@ -256,7 +275,7 @@ def build_per_job(ctx, lanes, kinds=("map", "reduce", "outer"), small=False, edd
             assert results == [eddsa_air.decompress(sig[:32]) for _, _, sig in raw], "a generated EdDSA instance does not arrive at R"
             assert bus.closed(lane), "the signature bus does not balance"
         tables.append(bus)
-        rec["signature_bus"] = {"tables": f"SHA-512 bus variant 2^{lg} x 2012 + {bus.ntab} x EdDSA full program 2^{lg_ed} x {bus.lay.N} + link 2^{bus.link_log_n} x 41 + verifier sink 2^{bus.link_log_n} x 26",
+        rec["signature_bus"] = {"tables": bus.describe() if hasattr(bus, "describe") else f"SHA-512 bus variant 2^{lg} x 2012 + {bus.ntab} x EdDSA full program 2^{lg_ed} x {bus.lay.N} + link 2^{bus.link_log_n} x 41 + verifier sink 2^{bus.link_log_n} x 26",
                                 "signatures": nkeys, "signatures_per_eddsa_table": bus.cap, "eddsa_tables": bus.ntab,
                                 "traces": "SHA-512 and EdDSA generated per job on the GPU; link rows written by the host",
                                 "proven_as": "one bus: joint challenges over the 7 trace caps; the closing sums add up to 0",
@@ -281,15 +300,15 @@ def rotate_shape(small: bool) -> dict:
     return {"num_authorities": 8 if small else 300, "distinct_keys": 2 if small else 8, "new_authorities": 8 if small else 300}
 
 
-def build_rotate(ctx, lanes=None, small=False, eddsa_log_n=20):
+def build_rotate(ctx, lanes=None, small=False, eddsa_log_n=20, factory=None):
     """The tables of ONE rotate proof (/root/reference/circuits/rotate.rs:80-109, builder/rotate.rs:278-323) over a synthetic request
     (header_range.make_rotate_request(input_seed)): BLAKE2b over the epoch end header (2^16 rows: the XOR table's height), SHA-256 over
     the CURRENT authority set's commitment chain and the NEW set's (2 x 599 compressions: 2^17 rows), the justification's 300
     signatures through the signature bus — traces generated on the GPU inside the job — and the job's statement: the new authority
     set's hash, after the checks of header_range.rotate_statement.  -> ({"rotate": [(label, table)]}, [tables to free], record)"""
-    from . import blake2b_bytes_air, eddsa_air, sha256_air, stark_chips
     from . import header_range as hr
     lanes = list(lanes or [ctx])
+    factory = GpuTables(ctx) if factory is None else factory
     shape = rotate_shape(small)
     rec, tables = {"mode": "per_job", "request": dict(shape, what="synthetic rotate request: an epoch end header announcing the new set, justified by the current one")}, []
     WARM = b"warm-up"
@@ -297,25 +316,24 @@ def build_rotate(ctx, lanes=None, small=False, eddsa_log_n=20):
     def request(job):
         return hr.cached_request(job[3] if job is not None else WARM, rotate=True, **shape)
 
-    def gen(label, which, air, log_n, messages_fn):
+    def gen(label, which, log_n, messages_fn):
         t0 = time.perf_counter()
-        stark = air.make_stark(log_n)
-        tab = stark_chips.GeneratedHashTable(ctx, which, stark, log_n, messages_fn, lanes, label)
+        tab, columns = factory.hash_table(label, which, log_n, messages_fn, lanes)
         for lane in lanes:
             tab.prove(lane, None)
             tab.take_spent(lane)
         tables.append(tab)
-        rec[label] = {"rows_log2": log_n, "columns": f"{stark.desc.num_columns} + {stark.desc.num_aux_columns}", "messages": len(messages_fn(None)),
+        rec[label] = {"rows_log2": log_n, "columns": columns, "messages": len(messages_fn(None)),
                       "trace": "generated per job on the GPU", "setup_incl_one_proof_per_lane_s": round(time.perf_counter() - t0, 2)}
         return tab
 
     _signature_inputs(request(None))
-    blake = gen("blake2b_header", "blake2b", blake2b_bytes_air, 16, lambda job: [request(job).header])
-    sha = gen("sha256_chains", "sha256", sha256_air, 11 if small else 17,
+    blake = gen("blake2b_header", "blake2b", 16, lambda job: [request(job).header])
+    sha = gen("sha256_chains", "sha256", 11 if small else 17,
               lambda job: hr.authority_chain_messages(request(job).justification().pubkeys) + hr.authority_chain_messages(request(job).new_pubkeys))
     t0 = time.perf_counter()
     lg, lg_ed = (11, 17) if small else (16, eddsa_log_n)
-    bus = stark_chips.GeneratedSignatureBus(ctx, lambda job: _signature_inputs(request(job)), lanes, shape["num_authorities"], sha_log_n=lg, ed_log_n=lg_ed)
+    bus = factory.signature_bus(lambda job: _signature_inputs(request(job)), lanes, shape["num_authorities"], lg, lg_ed)
     for lane in lanes:
         bus.prove(lane, None)
         bus.take_spent(lane)
@@ -337,7 +355,7 @@ def build_rotate(ctx, lanes=None, small=False, eddsa_log_n=20):
     return {"rotate": [("blake2b", blake), ("sha256", sha), ("signature_bus", bus), ("statement", JobStatement(statement))]}, tables, rec
 
 
-def build(ctx, kinds=("map", "reduce", "outer"), small=False, mode="per_job", lanes=None, outer_lanes=None, num_map=64, num_headers=None):
+def build(ctx, kinds=("map", "reduce", "outer"), small=False, mode="per_job", lanes=None, outer_lanes=None, num_map=64, num_headers=None, factory=None):
     """mode "per_job" (default) or "resident" (rounds 3-4: one host-generated trace per table kind)"""
     if mode == "resident":
         per_kind, tables, rec = build_resident(ctx, kinds=kinds, small=small)
@@ -349,4 +367,4 @@ def build(ctx, kinds=("map", "reduce", "outer"), small=False, mode="per_job", la
         return per_kind, tables, rec
     if mode != "per_job":
         raise ValueError(mode)
-    return build_per_job(ctx, lanes or [ctx], kinds=kinds, small=small, outer_lanes=outer_lanes, num_map=num_map, num_headers=num_headers)
+    return build_per_job(ctx, lanes or [ctx], kinds=kinds, small=small, outer_lanes=outer_lanes, num_map=num_map, num_headers=num_headers, factory=factory)

@@ -1192,6 +1192,16 @@ def equation_inputs(public_key: bytes, message: bytes, signature: bytes):
     return a, s, h, r
 
 
+def verify(public_key: bytes, message: bytes, signature: bytes) -> bool:
+    """RFC 8032 5.1.7 on the host with the reference affine arithmetic (no cofactor multiplication, as the table's equation):
+    [S]B = R + [h]A — test infrastructure and the check the synthetic requests' signatures are held against"""
+    try:
+        a, s, h, r = equation_inputs(public_key, message, signature)
+    except ValueError:
+        return False
+    return affine_scalar_mult(s) == affine_add(r, affine_scalar_mult(h, a))
+
+
 def equation_inputs_full(public_key: bytes, message: bytes, signature: bytes, check=True):
     """what the FULL program's trace generator takes for an Ed25519 signature: ((A.x, A.y), S, h, digest) — A decompressed and h reduced
     on the host only to WRITE the witness; the table re-derives both from the encodings and the digest.  check=False skips the host-side
