@@ -262,16 +262,20 @@ static int build_zeta_table(vx_ctx* c, vxh::Ext zeta, int log_n, u64* ztab) {
     pows[2 * b + 1] = p.b;
     p = vxh::emul(p, p);
   }
-  u64* d = nullptr;
-  HIPCHK(hipMalloc(&d, pows.size() * 8));
-  HIPCHK(hipMemcpyAsync(d, pows.data(), pows.size() * 8, hipMemcpyHostToDevice, c->stream));
+  // (from the context's pool: hipMalloc / hipFree per proof cost tens of microseconds each, and hipFree waits for the WHOLE device —
+  // the other lanes of the process included)
+  void* dv = nullptr;
+  if (c->pool_alloc(&dv, pows.size() * 8) != hipSuccess) return vx_fail(VX_E_NOMEM, "build_zeta_table: out of device memory");
+  u64* d = (u64*)dv;
+  hipError_t e = hipMemcpyAsync(d, pows.data(), pows.size() * 8, hipMemcpyHostToDevice, c->stream);
   size_t n = (size_t)1 << log_n;
-  {
+  if (e == hipSuccess) {
     ProfScope ps(c, "zeta_table");
     hipLaunchKernelGGL(zeta_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, d, log_n, ztab);
   }
-  HIPCHK(hipStreamSynchronize(c->stream));
-  hipFree(d);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);   // `pows` is a stack-scoped source of the copy
+  c->pool_free(dv);
+  if (e != hipSuccess) return vx_fail(VX_E_HIP, "build_zeta_table: %s", hipGetErrorString(e));
   return VX_OK;
 }
 
@@ -319,8 +323,9 @@ __global__ __launch_bounds__(256) void eval_ext_kernel(const u64* __restrict__ c
 
 static int batch_eval_ext(vx_ctx* c, const u64* coeffs, size_t n, int log_n, size_t ncols, const u64* ztab, uint64_t* out_host) {
   (void)log_n;
-  u64* partial = nullptr;
-  HIPCHK(hipMalloc(&partial, ncols * EVAL_BLOCKS * 16));
+  void* pv = nullptr;
+  if (c->pool_alloc(&pv, ncols * EVAL_BLOCKS * 16) != hipSuccess) return vx_fail(VX_E_NOMEM, "batch_eval_ext: out of device memory");
+  u64* partial = (u64*)pv;
   {
     ProfScope ps(c, "eval_ext", 8.0 * (double)n * (double)ncols);
     hipLaunchKernelGGL(eval_ext_kernel, dim3(EVAL_BLOCKS, (unsigned)((ncols + EVAL_COLS - 1) / EVAL_COLS)), dim3(256), 0,
@@ -329,7 +334,7 @@ static int batch_eval_ext(vx_ctx* c, const u64* coeffs, size_t n, int log_n, siz
   std::vector<u64> h(ncols * EVAL_BLOCKS * 2);
   hipError_t e = hipMemcpyAsync(h.data(), partial, h.size() * 8, hipMemcpyDeviceToHost, c->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-  hipFree(partial);
+  c->pool_free(pv);
   if (e != hipSuccess) return vx_fail(VX_E_HIP, "batch_eval_ext: %s", hipGetErrorString(e));
   for (size_t col = 0; col < ncols; ++col) {
     u64 a = 0, b = 0;
