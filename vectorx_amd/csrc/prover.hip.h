@@ -1136,16 +1136,14 @@ static int prove_impl(vx_ctx* c, vx_circuit* k, const u64* wires_in, bool wires_
   std::vector<u64> ev[4], zs_next(2 * (size_t)nch), lzs_next(2 * (size_t)nlook);
   const size_t zs_pp = (size_t)nch * (1 + npp);
   {
-    u64* ztab = S.get(2 * n);
-    if (!ztab) return vx_fail(VX_E_NOMEM, "prove: out of device memory (openings)");
-    VXCHK(build_zeta_table(c, zeta, lg, ztab));
+    EvalJob jobs[6];
     for (int o = 0; o < 4; ++o) {
       ev[o].resize(2 * oracles[o]->ncols);
-      VXCHK(batch_eval_ext(c, oracles[o]->coeffs, n, lg, oracles[o]->ncols, ztab, ev[o].data()));
+      jobs[o] = EvalJob{oracles[o]->coeffs, oracles[o]->ncols, 0, ev[o].data()};
     }
-    VXCHK(build_zeta_table(c, gzeta, lg, ztab));
-    VXCHK(batch_eval_ext(c, zs_b->coeffs, n, lg, nch, ztab, zs_next.data()));
-    if (nlook) VXCHK(batch_eval_ext(c, zs_b->coeffs + zs_pp * n, n, lg, nlook, ztab, lzs_next.data()));
+    jobs[4] = EvalJob{zs_b->coeffs, (size_t)nch, 1, zs_next.data()};
+    jobs[5] = EvalJob{zs_b->coeffs + zs_pp * n, (size_t)nlook, 1, lzs_next.data()};
+    VXCHK(batch_eval_ext_many(c, zeta, gzeta, lg, jobs, 6));
   }
   // to_fri_openings: batch 0 = [constants, sigmas, wires, zs, partial products, quotient, lookup_zs], batch 1 = [zs_next,
   // lookup_zs_next] — the lookup polynomials are the TAIL of the zs_partial_products oracle but are opened after the quotient

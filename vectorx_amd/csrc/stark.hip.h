@@ -466,15 +466,12 @@ static int stark_finish_impl(vx_stark_session& s, const u64* aux_in, bool aux_on
   // ---- StarkOpeningSet: local_values, next_values [, aux local / next], quotient_polys ----
   std::vector<u64> ev_trace(2 * (size_t)ncols), ev_next(2 * (size_t)ncols), ev_aux(2 * (size_t)naux), ev_aux_next(2 * (size_t)naux), ev_quot(2 * quot_b->ncols);
   {
-    u64* ztab = S.get(2 * n);
-    if (!ztab) return vx_fail(VX_E_NOMEM, "stark: out of device memory (openings)");
-    VXCHK(build_zeta_table(c, zeta, lg, ztab));
-    VXCHK(batch_eval_ext(c, trace_b->coeffs, n, lg, ncols, ztab, ev_trace.data()));
-    if (naux) VXCHK(batch_eval_ext(c, aux_b->coeffs, n, lg, naux, ztab, ev_aux.data()));
-    VXCHK(batch_eval_ext(c, quot_b->coeffs, n, lg, quot_b->ncols, ztab, ev_quot.data()));
-    VXCHK(build_zeta_table(c, gzeta, lg, ztab));
-    VXCHK(batch_eval_ext(c, trace_b->coeffs, n, lg, ncols, ztab, ev_next.data()));
-    if (naux) VXCHK(batch_eval_ext(c, aux_b->coeffs, n, lg, naux, ztab, ev_aux_next.data()));
+    const EvalJob jobs[5] = {{trace_b->coeffs, (size_t)ncols, 0, ev_trace.data()},
+                             {naux ? aux_b->coeffs : nullptr, (size_t)naux, 0, ev_aux.data()},
+                             {quot_b->coeffs, quot_b->ncols, 0, ev_quot.data()},
+                             {trace_b->coeffs, (size_t)ncols, 1, ev_next.data()},
+                             {naux ? aux_b->coeffs : nullptr, (size_t)naux, 1, ev_aux_next.data()}};
+    VXCHK(batch_eval_ext_many(c, zeta, gzeta, lg, jobs, 5));
   }
   // to_fri_openings: zeta batch = [local_values, aux local, quotient_polys] (FRI-oracle order), zeta_next batch = [next_values, aux next]
   std::vector<Ext> batch0, batch1;
