@@ -129,18 +129,22 @@ def test_dependency_driven_schedule_with_real_proofs(oracle):
     import _mp_dag_worker as w
     from vectorx_amd import mapreduce as mr
     oracle.L.vxo_set_num_threads(1)
-    spec = mr.DagSpec(num_map=4, map_log_n=4, reduce_log_n=3, outer_log_n=4)
-    lock = threading.Lock()
+    try:
+        spec = mr.DagSpec(num_map=4, map_log_n=4, reduce_log_n=3, outer_log_n=4)
+        lock = threading.Lock()
 
-    class Locked(w.OracleProver):                      # the generator keeps the current public inputs: one caller at a time
-        def prove(self, key, pi, lane=0):
-            with lock:
-                return super().prove(key, pi)
+        class Locked(w.OracleProver):                      # the generator keeps the current public inputs: one caller at a time
+            def prove(self, key, pi, lane=0):
+                with lock:
+                    return super().prove(key, pi)
 
-    make = lambda kind, log_n, jobs: Locked(oracle, kind, log_n, jobs)               # noqa: E731
-    a = mr.run_dag(spec, make, None)
-    b = mr.run_dag(spec, make, None, in_flight=3, barriers=False)
-    assert a["root"] == b["root"] and a["my_proofs"] == b["my_proofs"] and b["proofs"] == 8
+        make = lambda kind, log_n, jobs: Locked(oracle, kind, log_n, jobs)               # noqa: E731
+        a = mr.run_dag(spec, make, None)
+        b = mr.run_dag(spec, make, None, in_flight=3, barriers=False)
+        assert a["root"] == b["root"] and a["my_proofs"] == b["my_proofs"] and b["proofs"] == 8
+    finally:
+        import os
+        oracle.L.vxo_set_num_threads(os.cpu_count() or 1)      # the library is shared by every later test of this process
 
 
 def test_dag_spec_header_range_512():
