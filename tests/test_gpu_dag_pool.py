@@ -111,6 +111,18 @@ def test_rotate_states_the_new_authority_set_hash(ctx):
             req = hr.cached_request(seed, rotate=True, **shape)
             assert len(res["record"]) == 64 and res["output"] == hr.expected_rotate_output(req) == ac.authority_set_commitment(req.new_pubkeys)
         assert mr.prove_rotate(prover, b"rotate 1")["record"] != res["record"]
+        # the bus proven AHEAD on a lane of its own: the same record as in the job's order
+        lane2 = vx.Context(0)
+        pk2, tables2, rec2 = dag_tables.build_rotate(ctx, [ctx], small=True, bus_lane=lane2)
+        prover2 = mr.GpuProver(ctx, "rotate", 11, [(0, 0)], 50, distinct_witnesses=1, starks=pk2["rotate"])
+        try:
+            assert mr.prove_rotate(prover2, b"rotate 2", ahead=rec2["ahead"])["record"] == res["record"]
+            assert mr.prove_rotate(prover2, b"rotate 2")["record"] == res["record"]          # not started ahead: proven in place, on its lane
+        finally:
+            prover2.free()
+            for t in tables2:
+                t.free()
+            lane2.close()
         bad = hr.cached_request(b"rotate 3", rotate=True, **shape)
         bad.new_pubkeys[3] = bytes(32)
         with pytest.raises(hr.StatementError, match="does not announce"):

@@ -300,12 +300,53 @@ def rotate_shape(small: bool) -> dict:
     return {"num_authorities": 8 if small else 300, "distinct_keys": 2 if small else 8, "new_authorities": 8 if small else 300}
 
 
-def build_rotate(ctx, lanes=None, small=False, eddsa_log_n=20, factory=None):
+class AheadTable:
+    """A table proven AHEAD of its place in the job, on a lane of its own: `start(job)` launches its proof on `lane` in a host thread
+    (the C calls release the GIL), `prove` — called where the table stands in the job's order — waits for it and returns the same
+    bytes as proving it there would.  The rotate request runs its signature bus (0.5 s) this way, next to its plonky2 proof and hash
+    tables (0.1 s)."""
+
+    def __init__(self, table, lane):
+        self.table, self.lane = table, lane
+        self._thread, self._out, self._err = None, None, None
+
+    def start(self, job):
+        import threading
+
+        def run():
+            try:
+                self._out = self.table.prove(self.lane, job)
+            except BaseException as e:      # surfaces in prove()
+                self._err = e
+
+        self._out, self._err = None, None
+        self._thread = threading.Thread(target=run)
+        self._thread.start()
+
+    def prove(self, ctx=None, job=None) -> bytes:
+        if self._thread is None:            # not started ahead: prove it here, on its own lane
+            return self.table.prove(self.lane, job)
+        self._thread.join()
+        self._thread = None
+        if self._err is not None:
+            raise self._err
+        return self._out
+
+    def take_spent(self, ctx=None):
+        return self.table.take_spent(self.lane)
+
+    def free(self):
+        pass
+
+
+def build_rotate(ctx, lanes=None, small=False, eddsa_log_n=20, factory=None, bus_lane=None):
     """The tables of ONE rotate proof (/root/reference/circuits/rotate.rs:80-109, builder/rotate.rs:278-323) over a synthetic request
     (header_range.make_rotate_request(input_seed)): BLAKE2b over the epoch end header (2^16 rows: the XOR table's height), SHA-256 over
     the CURRENT authority set's commitment chain and the NEW set's (2 x 599 compressions: 2^17 rows), the justification's 300
     signatures through the signature bus — traces generated on the GPU inside the job — and the job's statement: the new authority
-    set's hash, after the checks of header_range.rotate_statement.  -> ({"rotate": [(label, table)]}, [tables to free], record)"""
+    set's hash, after the checks of header_range.rotate_statement.  bus_lane: a second context on which the bus is proven AHEAD, next to
+    the plonky2 proof and the hash tables (mapreduce.prove_rotate starts it: rec["ahead"]).
+    -> ({"rotate": [(label, table)]}, [tables to free], record)"""
     from . import header_range as hr
     lanes = list(lanes or [ctx])
     factory = GpuTables(ctx) if factory is None else factory
@@ -333,26 +374,31 @@ def build_rotate(ctx, lanes=None, small=False, eddsa_log_n=20, factory=None):
               lambda job: hr.authority_chain_messages(request(job).justification().pubkeys) + hr.authority_chain_messages(request(job).new_pubkeys))
     t0 = time.perf_counter()
     lg, lg_ed = (11, 17) if small else (16, eddsa_log_n)
-    bus = factory.signature_bus(lambda job: _signature_inputs(request(job)), lanes, shape["num_authorities"], lg, lg_ed)
-    for lane in lanes:
+    bus_lanes = lanes if bus_lane is None else [bus_lane]
+    bus = factory.signature_bus(lambda job: _signature_inputs(request(job)), bus_lanes, shape["num_authorities"], lg, lg_ed)
+    for lane in bus_lanes:
         bus.prove(lane, None)
         bus.take_spent(lane)
         assert bus.closed(lane), "the signature bus does not balance"
     tables.append(bus)
-    rec["signature_bus"] = {"eddsa_tables": bus.ntab, "signatures": shape["num_authorities"], "setup_incl_one_bus_per_lane_s": round(time.perf_counter() - t0, 2)}
+    rec["signature_bus"] = {"eddsa_tables": bus.ntab, "signatures": shape["num_authorities"], "setup_incl_one_bus_per_lane_s": round(time.perf_counter() - t0, 2),
+                            "proven": "ahead, on a lane of its own, next to the plonky2 proof and the hash tables" if bus_lane is not None else "in the job's order"}
+    ahead = AheadTable(bus, bus_lane) if bus_lane is not None else None
+    rec["ahead"] = ahead
 
     def statement(lane, job):
         req = request(job)
-        (hdrs, hashes), (cmsgs, cdigs), raw = blake.last[id(lane)], sha.last[id(lane)], bus.last[id(lane)][0]
+        bl = lane if bus_lane is None else bus_lane
+        (hdrs, hashes), (cmsgs, cdigs), raw = blake.last[id(lane)], sha.last[id(lane)], bus.last[id(bl)][0]
         if [bytes(h) for h in hdrs] != [req.header]:
             raise hr.StatementError("the BLAKE2b table hashed something else than the epoch end header")
-        if not bus.closed(lane):
+        if not bus.closed(bl):
             raise hr.StatementError("the signature bus does not balance: a signature of the justification does not verify")
         na = req.justification().num_authorities
         return hr.rotate_statement(req.input_bytes, req.header, hashes[0], req.justification(), cmsgs[:na], cdigs[:na], raw, req.start_position,
                                    req.new_pubkeys, cmsgs[na:], cdigs[na:])
 
-    return {"rotate": [("blake2b", blake), ("sha256", sha), ("signature_bus", bus), ("statement", JobStatement(statement))]}, tables, rec
+    return {"rotate": [("blake2b", blake), ("sha256", sha), ("signature_bus", ahead if ahead is not None else bus), ("statement", JobStatement(statement))]}, tables, rec
 
 
 def build(ctx, kinds=("map", "reduce", "outer"), small=False, mode="per_job", lanes=None, outer_lanes=None, num_map=64, num_headers=None, factory=None):

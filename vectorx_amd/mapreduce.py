@@ -298,12 +298,16 @@ def prove_with_tables(prove_main, tables, lane_ctx=None, split=None, lock=None, 
     return b"".join(parts)
 
 
-def prove_rotate(prover, input_seed: bytes = b"", spent_out=None) -> dict:
+def prove_rotate(prover, input_seed: bytes = b"", spent_out=None, ahead=None) -> dict:
     """ONE rotate request (/root/reference/circuits/rotate.rs:80-109 is a single proof, no MapReduce) on `prover` — a GpuProver of kind
     "rotate" carrying dag_tables.build_rotate's tables: the plonky2 proof, the tables of the request `input_seed` names, the statement.
+    ahead: dag_tables.AheadTable (build_rotate(bus_lane=...)'s rec["ahead"]) — the signature bus starts NOW on its own lane and the
+    job waits for it where the bus stands in its order; same bytes, the wall time of the longer of the two.
     -> {"record": digest || new authority set hash, "output": the 32 output bytes, "seconds"}"""
     t0 = time.perf_counter()
     pis = digest_to_field(hashlib.sha256(b"rotate" + bytes(input_seed)).digest())
+    if ahead is not None:
+        ahead.start(("rotate", 0, 0, input_seed, ()))
     result = prover.prove((0, 0), pis, 0, input_seed=input_seed, spent_out=spent_out)
     rec = record_of(result, prover)
     return {"record": rec, "output": rec[32:], "seconds": time.perf_counter() - t0, "result_bytes": len(result)}
