@@ -485,13 +485,14 @@ def chip_leg(ctx):
     if "VX_JIT_CACHE_DIR" not in os.environ and cache.is_dir():
         os.environ["VX_JIT_CACHE_DIR"] = str(cache)
     out = {"what": "own AIRs, not Curta's; rate_bits 1, 84 queries, 16 PoW bits; lone proofs, trace resident in HBM, second-round columns computed "
-                   "on the GPU inside every proof; NOT the contract's timed region"}
+                   "on the GPU inside every proof, the transcript takes the tree hash of the openings computed on the device "
+                   "(VX_STARK_OPENINGS_DIGEST); NOT the contract's timed region"}
     rng = np.random.default_rng(5)
     cases = [("sha256", "sha256", sha256_air, 13, 60, 64), ("sha512", "sha512", sha512_air, 13, 48, 117),
              ("blake2b_bytes", "blake2b", blake2b_bytes_air, 16, 8, 128 * 280)]
     for name, which, air, log_n, nmsg, mlen in cases:
         msgs = [rng.integers(0, 256, size=mlen, dtype=np.uint8).tobytes() for _ in range(nmsg)]
-        stark = air.make_stark(log_n)
+        stark = air.make_stark(log_n, openings_digest=True)
         ncols = stark.desc.num_columns
         d = ctx.alloc(ncols * (1 << log_n) * 8)
         ctx.trace_hash_table(which, log_n, msgs, d)            # warm
@@ -506,7 +507,7 @@ def chip_leg(ctx):
     log_n = 17
     cap = eddsa_air.capacity(lay, log_n)
     sigs, rs = stark_chips.eddsa_signatures_full(cap, 2)
-    stark = eddsa_air.make_stark(lay, log_n)
+    stark = eddsa_air.make_stark(lay, log_n, openings_digest=True)
     d = ctx.alloc(lay.N * (1 << log_n) * 8)
     ctx.trace_eddsa_table(log_n, lay.NB, sigs, d, full=True)   # warm
     t0 = time.perf_counter()

@@ -324,7 +324,7 @@ typedef struct vx_stark_desc {
   int32_t constraint_degree;              /* quotient_degree_factor = max(1, constraint_degree - 1) */
   int32_t program_len;
   const uint64_t* program;
-  uint32_t override_flags;                /* VX_DESC_HAS_FRI_ARITIES or 0 (then ConstantArityBits(4, 5)) */
+  uint32_t override_flags;                /* VX_DESC_HAS_FRI_ARITIES (else ConstantArityBits(4, 5)) | VX_STARK_OPENINGS_DIGEST */
   int32_t num_fri_reduction_arity_bits;
   const int32_t* fri_reduction_arity_bits;
   /* A SECOND COMMITMENT ROUND (0 / 0 = none): after the trace cap the prover draws num_aux_challenges challenges and
@@ -341,6 +341,14 @@ typedef struct vx_stark_desc {
    * num_aux_public_inputs - 1 (typically in a last-row constraint  acc = closing sum). */
   int32_t num_aux_public_inputs;
 } vx_stark_desc;
+/* VX_STARK_OPENINGS_DIGEST (this library's own option, round 5): the transcript absorbs a TREE HASH of the opening set instead of the
+ * opening set — the sequence [trace(zeta), aux(zeta), quotient(zeta), trace(g zeta), aux(g zeta)] (each F_p^2 value as two elements) is
+ * zero-padded to 8 * 2^k elements (k >= 1), every 8 elements are a leaf hashed with hash_no_pad (one permutation), a two_to_one binary
+ * tree over the leaf digests gives the root, and the four elements of the root are observed.  The prover computes it on the device next
+ * to the evaluations; without the option a table of ~1000 columns costs ~1000 dependent Poseidon permutations on ONE host core at this
+ * point of every proof (1.2 ms of a 10.4 ms SHA-256 table proof, the GPU idle).  The proof's bytes do not change shape; the challenges
+ * after the openings do.  Prover and verifier must agree on the flag (it is part of the description). */
+#define VX_STARK_OPENINGS_DIGEST 8u
 #define VX_OP_LDCH 10 /* AIR programs only: r[dst] = aux challenge a */
 int vx_stark_prove(vx_ctx* ctx, const vx_stark_desc* desc, const uint64_t* trace /* [num_columns][2^degree_bits] */, int trace_on_device,
                    const uint64_t* public_inputs, const uint64_t* pow_witness_hint, uint8_t* out_buf, size_t* out_len); /* num_aux_columns = 0 */

@@ -353,6 +353,7 @@ static StarkDesc vxo_to_desc(const vxo_stark_desc* d) {
   s.program.assign(d->program, d->program + d->program_len);
   if (d->override_flags & 2) s.arity_bits.assign(d->fri_reduction_arity_bits, d->fri_reduction_arity_bits + d->num_fri_reduction_arity_bits);
   else s.default_arities();
+  s.openings_digest = (d->override_flags & 8u) != 0;      // VX_STARK_OPENINGS_DIGEST
   return s;
 }
 static std::vector<std::vector<u64>> vxo_to_trace(const vxo_stark_desc* d, const u64* trace) {

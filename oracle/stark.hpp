@@ -29,6 +29,9 @@ struct StarkDesc {
   int num_aux_public_inputs = 0;
   std::vector<u64> program;
   std::vector<int> arity_bits;
+  // the transcript takes a tree hash of the openings (openings_digest below) instead of the openings themselves — the builder's own
+  // option (include/vxprover.h VX_STARK_OPENINGS_DIGEST): a table of ~1000 columns otherwise costs ~1000 host permutations here
+  bool openings_digest = false;
   int quotient_degree_factor() const { return constraint_degree > 1 ? constraint_degree - 1 : 1; }  // Stark::quotient_degree_factor
   void default_arities() {  // ConstantArityBits(4, 5)
     arity_bits.clear();
@@ -36,6 +39,23 @@ struct StarkDesc {
     while (db > 5 && db + rate_bits - 4 >= cap_height) arity_bits.push_back(4), db -= 4;
   }
 };
+// Tree hash of a sequence of field elements: 8-element chunks (the last one zero-padded) hashed with hash_no_pad — one permutation
+// each; the SEQUENCE is zero-padded to 8 * 2^k elements (k >= 1), every chunk is a leaf, and
+// a binary two_to_one tree over the 2^k leaf digests gives the root.
+static Hash openings_digest(const std::vector<u64>& flat) {
+  size_t leaves = (flat.size() + 7) / 8, p2 = 2;
+  while (p2 < leaves) p2 <<= 1;
+  std::vector<u64> padded(flat);
+  padded.resize(8 * p2, 0);
+  std::vector<Hash> level(p2);
+  for (size_t i = 0; i < p2; ++i) level[i] = hash_no_pad(padded.data() + 8 * i, 8);
+  while (level.size() > 1) {
+    std::vector<Hash> next(level.size() / 2);
+    for (size_t i = 0; i < next.size(); ++i) next[i] = two_to_one(level[2 * i], level[2 * i + 1]);
+    level.swap(next);
+  }
+  return level[0];
+}
 struct StarkProof {
   std::vector<Hash> trace_cap, aux_cap, quotient_cap;
   std::vector<Ext> local_values, next_values, aux_local_values, aux_next_values, quotient_polys;
@@ -320,10 +340,18 @@ static StarkProof stark_prove(const StarkDesc& d, const std::vector<std::vector<
   }
   proof.quotient_polys = eval_batch(quot_b, zeta);
   // zeta batch = [trace, aux, quotient] in FRI-oracle order, zeta_next batch = [trace, aux]
-  for (auto* v : {&proof.local_values, &proof.aux_local_values, &proof.quotient_polys})
-    for (Ext e : *v) ch.observe_ext(e);
-  for (auto* v : {&proof.next_values, &proof.aux_next_values})
-    for (Ext e : *v) ch.observe_ext(e);
+  if (d.openings_digest) {
+    std::vector<u64> flat;
+    for (auto* v : {&proof.local_values, &proof.aux_local_values, &proof.quotient_polys, &proof.next_values, &proof.aux_next_values})
+      for (Ext e : *v) flat.push_back(e.a), flat.push_back(e.b);
+    const Hash dg = openings_digest(flat);
+    ch.observe_elements(dg.e, 4);
+  } else {
+    for (auto* v : {&proof.local_values, &proof.aux_local_values, &proof.quotient_polys})
+      for (Ext e : *v) ch.observe_ext(e);
+    for (auto* v : {&proof.next_values, &proof.aux_next_values})
+      for (Ext e : *v) ch.observe_ext(e);
+  }
   proof.trace_cap = trace_b.tree.cap();
   if (naux > 0) proof.aux_cap = aux_b.tree.cap();
   proof.quotient_cap = quot_b.tree.cap();

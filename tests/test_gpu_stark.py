@@ -150,6 +150,34 @@ def test_sha256_air_proof_bytes_identical_to_oracle(ctx, oracle, degree_bits, cf
             stark.verify(pis, bp)
 
 
+@pytest.mark.parametrize("which,degree_bits,cfg", [("sha256", 7, {}), ("sha256", 11, dict(num_query_rounds=40)), ("sha512", 9, dict(rate_bits=2))])
+def test_openings_digest_on_the_device_equals_the_oracles(ctx, oracle, which, degree_bits, cfg):
+    """VX_STARK_OPENINGS_DIGEST: the tree hash of the opening set computed ON THE DEVICE next to the evaluations (one leaf-hash launch +
+    the fused tree top inside the openings' one submission) gives the oracle's transcript: byte-identical proofs for narrow and wide
+    tables (258 ... 1004 leaves of 8 elements), stage `openings_digest` on the clock; the product verifier accepts, and refuses the same table's
+    proof made without the option."""
+    import importlib
+    air = importlib.import_module("vectorx_amd." + which + "_air")
+    cfg = dict(dict(pow_bits=6, num_query_rounds=16), **cfg)
+    msgs = [b"abc", b"", b"y" * 200]
+    stark, plain = air.make_stark(degree_bits, openings_digest=True, **cfg), air.make_stark(degree_bits, **cfg)
+    trace, pis, _ = air.generate_trace(degree_bits, msgs)
+    ctx.prof_enable(True)
+    ctx.prof_reset()
+    gp = stark.prove(ctx, trace, pis)
+    stages = ctx.prof()
+    ctx.prof_enable(False)
+    assert "openings_digest" in stages and stages["eval_ext"]["calls"] == 1, sorted(stages)
+    assert gp == oracle_lib.stark_prove(oracle, stark, trace, pis)
+    stark.verify(pis, gp)
+    p0 = plain.prove(ctx, trace, pis)
+    assert p0 != gp and len(p0) == len(gp)
+    with pytest.raises(vx.VxError):
+        stark.verify(pis, p0)
+    with pytest.raises(vx.VxError):
+        plain.verify(pis, gp)
+
+
 def test_sha256_air_interpreted_equals_compiled(ctx, oracle):
     import os
     from vectorx_amd import sha256_air as sha

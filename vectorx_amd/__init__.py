@@ -460,6 +460,9 @@ def verify_standalone(desc_ptr, constants_sigmas_cap, proof: bytes) -> None:
     _chk(lib().vx_verify_standalone(ctypes.cast(desc_ptr, _vp), cap.ctypes.data, buf.ctypes.data, len(proof)))
 
 
+VX_STARK_OPENINGS_DIGEST = 8
+
+
 class StarkDesc(ctypes.Structure):
     """ctypes mirror of `vx_stark_desc` (include/vxprover.h)."""
     _fields_ = [("degree_bits", ctypes.c_int32), ("num_columns", ctypes.c_int32), ("num_public_inputs", ctypes.c_int32),
@@ -556,8 +559,10 @@ class Stark:
 
     def __init__(self, degree_bits, num_columns, num_public_inputs, program, constraint_degree, rate_bits=1, cap_height=4, pow_bits=16,
                  num_query_rounds=84, num_challenges=2, fri_arities=None, num_aux_columns=0, num_aux_challenges=0, aux_fn=None,
-                 num_aux_public_inputs=0, aux_reps=None):
-        """`num_aux_columns` / `num_aux_challenges` / `aux_fn`: a second commitment round — `aux_fn(trace, challenges)` returns the
+                 num_aux_public_inputs=0, aux_reps=None, openings_digest=False):
+        """`openings_digest`: the transcript absorbs a tree hash of the opening set, computed on the device, instead of the opening set
+        (`VX_STARK_OPENINGS_DIGEST`, include/vxprover.h) — for wide tables; prover and verifier must both set it.
+        `num_aux_columns` / `num_aux_challenges` / `aux_fn`: a second commitment round — `aux_fn(trace, challenges)` returns the
         [num_aux_columns][n] columns the caller computes between `vx_stark_begin` and `vx_stark_finish`; with
         `num_aux_public_inputs` > 0 (closing sums of a bus / lookup accumulator) it returns `(columns, aux_public_inputs)`.
         These counts, the program and `aux_fn` describe ONE challenge set; the second round is repeated `aux_reps` times
@@ -579,6 +584,8 @@ class Stark:
             self.desc.override_flags = 2
             self.desc.num_fri_reduction_arity_bits = len(fri_arities)
             self.desc.fri_reduction_arity_bits = ctypes.cast(self._ar, ctypes.c_void_p).value
+        if openings_digest:
+            self.desc.override_flags |= VX_STARK_OPENINGS_DIGEST
         self.desc_ptr = ctypes.pointer(self.desc)
 
     def precompile(self) -> tuple:

@@ -341,7 +341,10 @@ struct EvalJob {
   int point;           // 0: zeta, 1: g * zeta
   uint64_t* out_host;  // [ncols][2]
 };
-static int batch_eval_ext_many(vx_ctx* c, vxh::Ext z0, vxh::Ext z1, int log_n, const EvalJob* jobs, int njobs) {
+// digest_out (optional): the tree hash of all the values in job order (include/vxprover.h VX_STARK_OPENINGS_DIGEST), computed on the
+// device from the buffer the evaluations land in: one leaf-hash launch + the fused tree top, inside the same submission.
+static int build_merkle_levels(vx_ctx* c, u64* tree, size_t n_leaves, int cap_height, size_t* cap_offset_digests);
+static int batch_eval_ext_many(vx_ctx* c, vxh::Ext z0, vxh::Ext z1, int log_n, const EvalJob* jobs, int njobs, uint64_t* digest_out = nullptr) {
   const size_t n = (size_t)1 << log_n;
   const int lp = log_n > 0 ? log_n : 1;
   std::vector<u64> pows(4 * (size_t)lp);
@@ -361,10 +364,14 @@ static int batch_eval_ext_many(vx_ctx* c, vxh::Ext z0, vxh::Ext z1, int log_n, c
     if (jobs[j].ncols) need[jobs[j].point & 1] = true;
   }
   if (!total) return VX_OK;
-  void *d_pows = nullptr, *ztab[2] = {nullptr, nullptr}, *partial = nullptr, *d_out = nullptr;
-  auto release = [&] { c->pool_free(d_pows), c->pool_free(ztab[0]), c->pool_free(ztab[1]), c->pool_free(partial), c->pool_free(d_out); };
+  void *d_pows = nullptr, *ztab[2] = {nullptr, nullptr}, *partial = nullptr, *d_out = nullptr, *d_tree = nullptr;
+  auto release = [&] { c->pool_free(d_pows), c->pool_free(ztab[0]), c->pool_free(ztab[1]), c->pool_free(partial), c->pool_free(d_out), c->pool_free(d_tree); };
+  size_t leaves = 2;                                   // digest: the values, zero-padded to 8 * leaves elements
+  while (leaves * 8 < total * 2) leaves <<= 1;
+  const size_t out_words = digest_out ? leaves * 8 : total * 2;
   bool ok = c->pool_alloc(&d_pows, pows.size() * 8) == hipSuccess && c->pool_alloc(&partial, total * EVAL_BLOCKS * 16) == hipSuccess &&
-            c->pool_alloc(&d_out, total * 16) == hipSuccess;
+            c->pool_alloc(&d_out, out_words * 8) == hipSuccess;
+  if (ok && digest_out) ok = c->pool_alloc(&d_tree, (2 * leaves) * 32) == hipSuccess;
   for (int q = 0; q < 2 && ok; ++q)
     if (need[q]) ok = c->pool_alloc(&ztab[q], n * 16) == hipSuccess;
   if (!ok) {
@@ -391,9 +398,19 @@ static int batch_eval_ext_many(vx_ctx* c, vxh::Ext z0, vxh::Ext z1, int log_n, c
                          jobs[j].ncols, (const u64*)ztab[jobs[j].point & 1], (u64*)partial + off * EVAL_BLOCKS * 2);
       off += jobs[j].ncols;
     }
+    if (digest_out) (void)hipMemsetAsync((u64*)d_out + total * 2, 0, (out_words - total * 2) * 8, c->stream);
     hipLaunchKernelGGL(eval_ext_reduce_kernel, dim3((unsigned)((2 * total + 255) / 256)), dim3(256), 0, c->stream, (const u64*)partial, total, (u64*)d_out);
     e = hipGetLastError();
   }
+  size_t root_off = 0;
+  if (e == hipSuccess && digest_out) {
+    ProfScope ps(c, "openings_digest", 8.0 * (double)out_words);
+    hipLaunchKernelGGL(hash_leaves_rowmajor_kernel, dim3((unsigned)((leaves + HASH_THREADS - 1) / HASH_THREADS)), dim3(HASH_THREADS), 0, c->stream,
+                       (const u64*)d_out, leaves, 8, (u64*)d_tree);
+    ps.end();
+    if (build_merkle_levels(c, (u64*)d_tree, leaves, 0, &root_off) != VX_OK) e = hipErrorUnknown;
+  }
+  if (e == hipSuccess && digest_out) e = hipMemcpyAsync(digest_out, (u64*)d_tree + root_off * 4, 32, hipMemcpyDeviceToHost, c->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(h.data(), d_out, h.size() * 8, hipMemcpyDeviceToHost, c->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);   // `pows` and `h` are stack-scoped ends of the copies
   release();

@@ -158,7 +158,7 @@ static std::string stark_check(const vx_stark_desc* d, StarkShape* out) {
     if (op != VX_OP_PUSH) defined |= (uint64_t)1 << dst;
   }
   if (!ended) return "stark: unterminated AIR program";
-  if (d->override_flags & ~(uint32_t)VX_DESC_HAS_FRI_ARITIES) return bad("unknown override_flags bits", d->override_flags);
+  if (d->override_flags & ~(uint32_t)(VX_DESC_HAS_FRI_ARITIES | VX_STARK_OPENINGS_DIGEST)) return bad("unknown override_flags bits", d->override_flags);
   if (d->override_flags & VX_DESC_HAS_FRI_ARITIES) {
     if (d->num_fri_reduction_arity_bits < 0 || d->num_fri_reduction_arity_bits > 32 || (d->num_fri_reduction_arity_bits && !d->fri_reduction_arity_bits))
       return bad("bad fri_reduction_arity_bits list", d->num_fri_reduction_arity_bits);
@@ -465,13 +465,14 @@ static int stark_finish_impl(vx_stark_session& s, const u64* aux_in, bool aux_on
   const Ext gzeta{mul(zeta.a, g), mul(zeta.b, g)};
   // ---- StarkOpeningSet: local_values, next_values [, aux local / next], quotient_polys ----
   std::vector<u64> ev_trace(2 * (size_t)ncols), ev_next(2 * (size_t)ncols), ev_aux(2 * (size_t)naux), ev_aux_next(2 * (size_t)naux), ev_quot(2 * quot_b->ncols);
+  uint64_t openings_root[4] = {0, 0, 0, 0};            // VX_STARK_OPENINGS_DIGEST: the tree hash of the openings, from the device
   {
     const EvalJob jobs[5] = {{trace_b->coeffs, (size_t)ncols, 0, ev_trace.data()},
                              {naux ? aux_b->coeffs : nullptr, (size_t)naux, 0, ev_aux.data()},
                              {quot_b->coeffs, quot_b->ncols, 0, ev_quot.data()},
                              {trace_b->coeffs, (size_t)ncols, 1, ev_next.data()},
                              {naux ? aux_b->coeffs : nullptr, (size_t)naux, 1, ev_aux_next.data()}};
-    VXCHK(batch_eval_ext_many(c, zeta, gzeta, lg, jobs, 5));
+    VXCHK(batch_eval_ext_many(c, zeta, gzeta, lg, jobs, 5, (d->override_flags & VX_STARK_OPENINGS_DIGEST) ? openings_root : nullptr));
   }
   // to_fri_openings: zeta batch = [local_values, aux local, quotient_polys] (FRI-oracle order), zeta_next batch = [next_values, aux next]
   std::vector<Ext> batch0, batch1;
@@ -480,8 +481,12 @@ static int stark_finish_impl(vx_stark_session& s, const u64* aux_in, bool aux_on
   for (size_t i = 0; i < quot_b->ncols; ++i) batch0.push_back(Ext{ev_quot[2 * i], ev_quot[2 * i + 1]});
   for (int i = 0; i < ncols; ++i) batch1.push_back(Ext{ev_next[2 * i], ev_next[2 * i + 1]});
   for (int i = 0; i < naux; ++i) batch1.push_back(Ext{ev_aux_next[2 * i], ev_aux_next[2 * i + 1]});
-  for (Ext e : batch0) ch.observe_ext(e);
-  for (Ext e : batch1) ch.observe_ext(e);
+  if (d->override_flags & VX_STARK_OPENINGS_DIGEST) {
+    ch.observe_elements(openings_root, 4);
+  } else {
+    for (Ext e : batch0) ch.observe_ext(e);
+    for (Ext e : batch1) ch.observe_ext(e);
+  }
   // ---- opening proof: the same FRI prover as vx_prove ----
   FriProverParams fp;
   fp.degree_bits = lg, fp.rate_bits = rb, fp.cap_height = d->cap_height, fp.pow_bits = d->pow_bits, fp.num_queries = d->num_query_rounds;
@@ -640,10 +645,27 @@ static std::string verify(const vx_stark_desc* d, const StarkShape& sh, const u6
   for (auto& v : alphas) v = ch.get_challenge();
   ch.observe_elements(quot_cap.data(), quot_cap.size());
   const E zeta = ch.get_extension_challenge();
-  for (auto* v : {&o_local, &o_aux, &o_quot})
-    for (E e : *v) ch.observe_ext(e.x());
-  for (auto* v : {&o_next, &o_aux_next})
-    for (E e : *v) ch.observe_ext(e.x());
+  if (d->override_flags & VX_STARK_OPENINGS_DIGEST) {     // the tree hash of the openings (include/vxprover.h), here on the host
+    std::vector<u64> flat;
+    for (auto* v : {&o_local, &o_aux, &o_quot, &o_next, &o_aux_next})
+      for (E e : *v) flat.push_back(e.a), flat.push_back(e.b);
+    size_t leaves = 2;
+    while (leaves * 8 < flat.size()) leaves <<= 1;
+    flat.resize(leaves * 8, 0);
+    std::vector<vxh::Hash4> level(leaves);
+    for (size_t i = 0; i < leaves; ++i) level[i] = vxh::hash_no_pad(flat.data() + 8 * i, 8);
+    while (level.size() > 1) {
+      std::vector<vxh::Hash4> next(level.size() / 2);
+      for (size_t i = 0; i < next.size(); ++i) next[i] = vxv::two_to_one(level[2 * i], level[2 * i + 1]);
+      level.swap(next);
+    }
+    ch.observe_elements(level[0].e, 4);
+  } else {
+    for (auto* v : {&o_local, &o_aux, &o_quot})
+      for (E e : *v) ch.observe_ext(e.x());
+    for (auto* v : {&o_next, &o_aux_next})
+      for (E e : *v) ch.observe_ext(e.x());
+  }
   const E fri_alpha = ch.get_extension_challenge();
   std::vector<E> fri_betas;
   for (auto& cp : commit_caps) {
