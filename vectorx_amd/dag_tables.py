@@ -10,6 +10,7 @@ Curta's chips, sized from the reference's constants.  Two modes:
 """
 from __future__ import annotations
 
+import os
 import time
 
 import numpy as np
@@ -174,7 +175,7 @@ class GpuTables:
         air = {"blake2b": blake2b_bytes_air, "sha256": sha256_air}[which]
         # these tables are ~1000 columns wide: their transcripts take the tree hash of the openings, computed on the device
         # (VX_STARK_OPENINGS_DIGEST), not 1000 host permutations per proof
-        stark = air.make_stark(log_n, openings_digest=True)
+        stark = air.make_stark(log_n, openings_digest=not os.environ.get("VX_NO_OPENINGS_DIGEST"))      # (the variable: an A/B knob)
         tab = stark_chips.GeneratedHashTable(self.ctx, which, stark, log_n, messages_fn, lanes, label)
         return tab, f"{stark.desc.num_columns} + {stark.desc.num_aux_columns}"
 

@@ -389,10 +389,11 @@ class GeneratedSignatureBus:
         self.cap = ea.capacity(self.lay, ed_log_n)
         self.ntab = max(1, -(-nsigs // self.cap))
         # (every table's transcript takes the tree hash of its openings, computed on the device: VX_STARK_OPENINGS_DIGEST)
-        self.sha = s5.make_stark(sha_log_n, bus=True, openings_digest=True)
-        self.ed = ea.make_stark(self.lay, ed_log_n, openings_digest=True)
-        self.link = link.make_stark(self.link_log_n, openings_digest=True)
-        self.sink = ea.make_sink(self.lay, [], degree_bits=self.link_log_n, ntuple=link.NVERIFIER, openings_digest=True)[0]
+        od = not os.environ.get("VX_NO_OPENINGS_DIGEST")           # (the variable: an A/B knob)
+        self.sha = s5.make_stark(sha_log_n, bus=True, openings_digest=od)
+        self.ed = ea.make_stark(self.lay, ed_log_n, openings_digest=od)
+        self.link = link.make_stark(self.link_log_n, openings_digest=od)
+        self.sink = ea.make_sink(self.lay, [], degree_bits=self.link_log_n, ntuple=link.NVERIFIER, openings_digest=od)[0]
         self._link_mod = link
         sizes = [(2012, self.sha.desc.num_aux_columns, sha_log_n)] + [(self.lay.N, self.ed.desc.num_aux_columns, ed_log_n)] * self.ntab \
             + [(link.N, self.link.desc.num_aux_columns, self.link_log_n), (link.NVERIFIER + 1, self.sink.desc.num_aux_columns, self.link_log_n)]
