@@ -45,6 +45,8 @@ while time.time() < t_end:
     if kind in ("sha256", "blake2b", "ed25519", "eddsa"):      # one compiled program shape (2 challenges); the rest of the configuration varies
         cfg["num_challenges"] = 2
         cfg["rate_bits"] = rate_bits = int(rng.choice([1, 2]))
+    if rng.random() < 0.4:                       # round 5: the transcript over a tree hash of the openings (VX_STARK_OPENINGS_DIGEST)
+        cfg["openings_digest"] = True
     if rng.random() < 0.3:
         ar, left = [], lg
         while left > 0 and len(ar) < 5 and rng.random() < 0.8:
@@ -104,7 +106,7 @@ while time.time() < t_end:
     except vx.VxError:
         pass
     faulthandler.cancel_dump_traceback_later()
-    key = f"{kind}/rate{rate_bits}" + ("" if jit else "/interpreted") + ("/A" if "fri_arities" in cfg else "")
+    key = f"{kind}/rate{rate_bits}" + ("" if jit else "/interpreted") + ("/A" if "fri_arities" in cfg else "") + ("/D" if cfg.get("openings_digest") else "")
     by_kind[key] = by_kind.get(key, 0) + 1
     if ok:
         n_ok += 1
