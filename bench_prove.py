@@ -92,7 +92,7 @@ def dag_leg(ctx, local_rank, in_flight=3):
 
     def make(kind, log_n, jobs):        # one prover per circuit kind, kept across the two passes
         if kind not in provers:
-            provers[kind] = mr.GpuProver(ctx, kind, log_n, jobs, spec.poseidon_percent, extra_lanes=lanes, distinct_witnesses=4)
+            provers[kind] = mr.GpuProver(ctx, kind, log_n, jobs, spec.poseidon_percent, extra_lanes=lanes, distinct_witnesses=4, recursion=spec.recursion, recursion=spec.recursion)
         return provers[kind]
 
     def sync():
@@ -301,7 +301,7 @@ def dag_leg_ranks(ctx, args, local_rank, dist, device, in_flight=3, with_starks=
 
     def make(kind, log_n, jobs):
         if kind not in provers:
-            provers[kind] = mr.GpuProver(ctx, kind, log_n, jobs, spec.poseidon_percent, extra_lanes=lanes, distinct_witnesses=4,
+            provers[kind] = mr.GpuProver(ctx, kind, log_n, jobs, spec.poseidon_percent, extra_lanes=lanes, distinct_witnesses=4, recursion=spec.recursion,
                                          starks=per_kind.get(kind, ()), split=split)
         return provers[kind]
 
@@ -377,7 +377,7 @@ def dag_with_starks_leg(ctx, local_rank, in_flight=None, table_mode="per_job"):
 
     def make(kind, log_n, jobs):
         if kind not in provers:
-            provers[kind] = mr.GpuProver(ctx, kind, log_n, jobs, spec.poseidon_percent, extra_lanes=lanes, distinct_witnesses=4,
+            provers[kind] = mr.GpuProver(ctx, kind, log_n, jobs, spec.poseidon_percent, extra_lanes=lanes, distinct_witnesses=4, recursion=spec.recursion,
                                          starks=per_kind[kind], split=split)
         return provers[kind]
 

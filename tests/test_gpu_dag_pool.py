@@ -52,7 +52,7 @@ def test_pool_root_equals_the_one_process_root_with_per_job_tables(ctx):
     provers = {}
 
     def make(kind, log_n, jobs):
-        provers[kind] = mr.GpuProver(ctx, kind, log_n, jobs, spec.poseidon_percent, distinct_witnesses=4, starks=per_kind[kind])
+        provers[kind] = mr.GpuProver(ctx, kind, log_n, jobs, spec.poseidon_percent, recursion=spec.recursion, distinct_witnesses=4, starks=per_kind[kind])
         return provers[kind]
 
     try:
@@ -76,7 +76,7 @@ def test_a_range_shorter_than_the_capacity_and_a_broken_chain(ctx):
     provers = {}
 
     def make(kind, log_n, jobs):
-        provers[kind] = mr.GpuProver(ctx, kind, log_n, jobs, spec.poseidon_percent, distinct_witnesses=2, starks=per_kind[kind])
+        provers[kind] = mr.GpuProver(ctx, kind, log_n, jobs, spec.poseidon_percent, recursion=spec.recursion, distinct_witnesses=2, starks=per_kind[kind])
         return provers[kind]
 
     try:

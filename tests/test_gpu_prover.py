@@ -521,3 +521,30 @@ def test_quotient_degree_factor_below_the_blowup(ctx, oracle, degree_bits, flags
     assert g2.prove(w) == gp
     g2.free()
     gc.free()
+
+
+@pytest.mark.parametrize("degree_bits", [5, 9, 12, 16])
+def test_recursion_mix_proof_bytes_identical_to_oracle(ctx, oracle, degree_bits):
+    """The DAG's reduce / outer / map stand-ins since round 6: the recursive verifier's gate set in its declared row mix
+    (vectorx_amd/synth.py RECURSIVE_VERIFIER_MIX with RECURSION_FLAGS — what mapreduce.circuit_shape() hands every GpuProver;
+    /root/reference/circuits/builder/subchain_verification.rs:78, 233-289: a reduce job verifies its two children in-circuit).
+    Byte-identical to the oracle at the reduce size (2^16 rows) with exactly that flag set, compiled gate programs."""
+    from vectorx_amd.mapreduce import circuit_shape
+    from vectorx_amd.synth import RECURSION_FLAGS, RECURSIVE_VERIFIER_MIX
+    shape = circuit_shape(True)
+    assert shape == {"flags": RECURSION_FLAGS, "mix": RECURSIVE_VERIFIER_MIX}
+    sc = SynthCircuit(degree_bits, seed=202, witness_seed=3, **shape)
+    rows = sc.gate_rows()
+    for g in ("PoseidonGate", "ArithmeticExtensionGate", "BaseSumGate", "ExponentiationGate", "RandomAccessGate", "MulExtensionGate", "ReducingGate",
+              "ReducingExtensionGate", "PoseidonMdsGate", "CosetInterpolationGate", "LookupGate", "LookupTableGate"):
+        assert rows.get(g, 0) >= 1
+    oc = oracle_lib.OracleCircuit(oracle, sc.desc_ptr)
+    gc = vx.Circuit(ctx, sc.desc_ptr)
+    total, compiled, note = gc.program_gates()
+    assert total == 9 and compiled == total, note
+    assert (gc.digest() == oc.digest()).all()
+    gp = gc.prove(sc.witness())
+    op = oc.prove(sc.witness())
+    assert gp == op
+    assert oc.verify(gp) == ""
+    gc.free()

@@ -224,3 +224,38 @@ def test_recursion_gate_set_as_programs(oracle):
         acc = ((acc[0] + t[0] * dinv) % P, (acc[1] + t[1] * dinv) % P)
     assert acc == (int(w[35, r]), int(w[36, r]))
     assert FLAG_RECURSION_GATES == 8 and einv((3, 5)) == einv((3, 5))
+
+
+def test_recursive_verifier_mix_is_what_is_declared_and_proves(oracle):
+    """The DAG's stand-in circuits (round 6): the recursive verifier's gate set in the DECLARED row mix.  At 2^12 rows the counts are the
+    derivation written next to RECURSIVE_VERIFIER_MIX (28 queries x 95 PoseidonGate rows + the challenger, 196 ReducingGate rows, ...);
+    the oracle proves and verifies the circuit, and a witness that breaks one recursion gate's relation is refused."""
+    from vectorx_amd.mapreduce import circuit_shape
+    from vectorx_amd.synth import MIX_KEYS, RECURSION_FLAGS, RECURSIVE_VERIFIER_MIX
+    assert set(RECURSIVE_VERIFIER_MIX) <= set(MIX_KEYS) and sum(RECURSIVE_VERIFIER_MIX.values()) == 912
+    assert circuit_shape(False) == {} and circuit_shape(True)["flags"] == RECURSION_FLAGS == 29
+    sc = SynthCircuit(12, seed=5, witness_seed=6, **circuit_shape(True))
+    rows = sc.gate_rows()
+    assert sum(rows.values()) == 4096
+    assert rows["PoseidonGate"] == 2776 and rows["ReducingGate"] == 196 and rows["ArithmeticExtensionGate"] == 282
+    assert rows["RandomAccessGate"] == 167 and rows["CosetInterpolationGate"] == 57 and rows["ExponentiationGate"] == 28
+    assert 300 <= rows["NoopGate"] <= 420                                             # the padding a 2^12-row verifier circuit carries
+    assert len(sc.gate_names()) == sc.desc.num_gates == 16 and sc.desc.num_luts == 1
+    oc = oracle_lib.OracleCircuit(oracle, sc.desc_ptr)
+    w = sc.witness()
+    proof = oc.prove(w)
+    assert oc.verify(proof) == ""
+    # same circuit, other witness values: another proof, same verdict
+    sc2 = SynthCircuit(12, seed=5, witness_seed=7, **circuit_shape(True))
+    p2 = oc.prove(sc2.witness())
+    assert p2 != proof and oc.verify(p2) == ""
+    # a family the flags do not enable cannot be in the mix; shares above 1000 are refused
+    with pytest.raises(ValueError):
+        SynthCircuit(8, seed=1, flags=0, mix={"reducing": 10})
+    with pytest.raises(ValueError):
+        SynthCircuit(8, seed=1, flags=RECURSION_FLAGS, mix={"poseidon": 1001})
+    with pytest.raises(ValueError):
+        SynthCircuit(8, seed=1, flags=RECURSION_FLAGS, mix={"no_such_gate": 1})
+    # tiny traces still hold every family (one row each)
+    tiny = SynthCircuit(5, seed=1, **circuit_shape(True))
+    assert min(tiny.gate_rows().get(g, 0) for g in ("CosetInterpolationGate", "PoseidonMdsGate", "LookupGate", "ReducingExtensionGate")) == 1

@@ -40,7 +40,7 @@ def main():
     provers = []
 
     def make(kind, log_n, jobs):
-        p = mr.GpuProver(ctx, kind, log_n, jobs, spec.poseidon_percent, extra_lanes=lanes)
+        p = mr.GpuProver(ctx, kind, log_n, jobs, spec.poseidon_percent, extra_lanes=lanes, recursion=spec.recursion)
         provers.append(p)
         return p
 

@@ -155,6 +155,31 @@ GLD u64 gl_sqr(u64 a) { return gl_mul(a, a); }
 GLD u64 gl_mad_nc(u64 a, u64 b, u64 c) { return gl_mulmad_t<true, false>(a, b, c); }
 // a*b + c, canonical result
 GLD u64 gl_mad(u64 a, u64 b, u64 c) { return gl_mulmad_t<true, true>(a, b, c); }
+// x * c for a SMALL constant c < 2^31 (the 7 of every F_p^2 product, the MDS coefficients, the base of a BaseSumGate: a third of the
+// multiplications of a recursion circuit's gate programs) -> some representative.  x c = p1 2^32 + lo32(p0) with p1 < 2^63:
+// lo64 + h 2^64 = lo64 + h EPS, one carry fix: 5-6 VALU instead of the 16 of a general multiply-reduce.
+GLD u64 gl_mulc_tail(u64 lo, u32 h) {
+  u64 T, cT;
+  const u32 eps = 0xFFFFFFFFu;
+  asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(T), "=s"(cT) : "v"(h), "v"(eps), "v"(lo));
+  u32 d0;
+  asm("v_cndmask_b32_e64 %0, 0, -1, %1" : "=v"(d0) : "s"(cT));
+  return gl_add32(T, d0);   // a carry is worth 2^64 = EPS; T_wrapped < h EPS <= 2^63, so adding EPS cannot carry again
+}
+GLD u64 gl_mulc_nc(u64 x, u32 c) {
+  const u64 p0 = (u64)(u32)x * c;
+  const u64 p1 = (u64)(u32)(x >> 32) * c + (p0 >> 32);
+  return gl_mulc_tail(gl_pack((u32)p0, (u32)p1), (u32)(p1 >> 32));
+}
+// x * c + a (a: any representative) for c < 2^31 -> some representative
+GLD u64 gl_madc_nc(u64 x, u32 c, u64 a) {
+  u64 p0, c0, cz;
+  asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(p0), "=s"(c0) : "v"((u32)x), "v"(c), "v"(a));   // the carry is worth 2^64: one more unit of h
+  const u64 p1 = (u64)(u32)(x >> 32) * c + (p0 >> 32);
+  u32 h;
+  asm("v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(h), "=s"(cz) : "v"((u32)(p1 >> 32)), "s"(c0));   // h <= 2^31 - 1 + 1: no overflow
+  return gl_mulc_tail(gl_pack((u32)p0, (u32)p1), h);
+}
 GLD u64 gl_pow(u64 b, u64 e) {
   u64 r = 1;
   while (e) {

@@ -18,6 +18,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 #include <hip/hiprtc.h>
+#include <algorithm>
 #include <map>
 #include <mutex>
 #include <atomic>
@@ -126,6 +127,7 @@ struct JitAuxMode {
   int nfrac = 0;
 };
 static thread_local JitAuxMode g_jit_aux;
+static thread_local bool g_jit_lds_wires = false;   // fused gate kernel: LDW reads the row's wires from the workgroup's LDS tile (already canonical)
 static void jit_emit_code(std::ostringstream& s, std::vector<JitIns> code, int nch, bool air, int air_ncols);
 static void jit_emit_program(std::ostringstream& s, const uint64_t* prog, int nch, bool air, int air_ncols = 0) {
   jit_emit_code(s, jit_decode(prog), nch, air, air_ncols);
@@ -181,6 +183,13 @@ static void jit_emit_code(std::ostringstream& s, std::vector<JitIns> code, int n
   }
   bool canon_reg[VX_PROGRAM_REGS];
   for (bool& c : canon_reg) c = true;
+  // registers known to hold a small immediate (LDI of a value < 2^31, not overwritten since): a multiplication by one of them is
+  // gl_mulc_nc / gl_madc_nc — 5-6 instructions instead of 16-18 (the 7 of every F_p^2 product, the MDS rows, the 2 of a base sum)
+  bool imm_known[VX_PROGRAM_REGS];
+  uint64_t imm_val[VX_PROGRAM_REGS];
+  for (bool& c : imm_known) c = false;
+  const bool small_consts = !getenv("VX_JIT_NO_SMALL_CONSTS");
+  auto small = [&](int r) { return small_consts && imm_known[r] && imm_val[r] < (1ull << 31); };
   auto need_canon = [&](int r) {
     if (!canon_reg[r]) {
       s << "  R[" << r << "] = gl_canon(R[" << r << "]);\n";
@@ -190,15 +199,26 @@ static void jit_emit_code(std::ostringstream& s, std::vector<JitIns> code, int n
   int k = 0;
   for (const Ins& I : code) {
     if (I.skip) continue;
+    if (I.op != VX_OP_PUSH && I.op != VX_OP_LDI) imm_known[I.dst] = false;
     switch (I.op) {
-      case VX_OP_LDW: s << "  R[" << I.dst << "] = gl_canon(" << col(I.a) << "il]);\n"; canon_reg[I.dst] = true; break;
+      case VX_OP_LDW:
+        if (g_jit_lds_wires && !air) s << "  R[" << I.dst << "] = LW[" << I.a << " * 64 + lane];\n";
+        else s << "  R[" << I.dst << "] = gl_canon(" << col(I.a) << "il]);\n";
+        canon_reg[I.dst] = true;
+        break;
       case VX_OP_LDN: s << "  R[" << I.dst << "] = gl_canon(" << col(I.a) << "il_next]);\n"; canon_reg[I.dst] = true; break;
       case VX_OP_LDCH: s << "  R[" << I.dst << "] = p.chal[" << I.a << "];\n"; canon_reg[I.dst] = true; break;
       case VX_OP_LDC: s << "  R[" << I.dst << "] = CS[(size_t)(cbase + " << I.a << ") * N + i];\n"; canon_reg[I.dst] = true; break;
-      case VX_OP_LDI: s << "  R[" << I.dst << "] = " << I.imm << "ULL;\n"; canon_reg[I.dst] = true; break;
+      case VX_OP_LDI:
+        s << "  R[" << I.dst << "] = " << I.imm << "ULL;\n";
+        canon_reg[I.dst] = true;
+        imm_known[I.dst] = true, imm_val[I.dst] = I.imm;
+        break;
       case VX_OP_ADD:
         if (I.fa >= 0) {  // fused multiply-add: any representatives in, one out
-          s << "  R[" << I.dst << "] = gl_mad_nc(R[" << I.fa << "], R[" << I.fb << "], R[" << I.a << "]);\n";
+          if (small(I.fb)) s << "  R[" << I.dst << "] = gl_madc_nc(R[" << I.fa << "], " << imm_val[I.fb] << "u, R[" << I.a << "]);\n";
+          else if (small(I.fa)) s << "  R[" << I.dst << "] = gl_madc_nc(R[" << I.fb << "], " << imm_val[I.fa] << "u, R[" << I.a << "]);\n";
+          else s << "  R[" << I.dst << "] = gl_mad_nc(R[" << I.fa << "], R[" << I.fb << "], R[" << I.a << "]);\n";
           canon_reg[I.dst] = false;
         } else {
           need_canon(I.a);
@@ -213,7 +233,12 @@ static void jit_emit_code(std::ostringstream& s, std::vector<JitIns> code, int n
         s << "  R[" << I.dst << "] = gl_sub(R[" << I.a << "], R[" << I.b << "]);\n";
         canon_reg[I.dst] = true;
         break;
-      case VX_OP_MUL: s << "  R[" << I.dst << "] = gl_mul_nc(R[" << I.a << "], R[" << I.b << "]);\n"; canon_reg[I.dst] = false; break;
+      case VX_OP_MUL:
+        if (small(I.b)) s << "  R[" << I.dst << "] = gl_mulc_nc(R[" << I.a << "], " << imm_val[I.b] << "u);\n";
+        else if (small(I.a)) s << "  R[" << I.dst << "] = gl_mulc_nc(R[" << I.b << "], " << imm_val[I.a] << "u);\n";
+        else s << "  R[" << I.dst << "] = gl_mul_nc(R[" << I.a << "], R[" << I.b << "]);\n";
+        canon_reg[I.dst] = false;
+        break;
       case VX_OP_PUSH:
         if (g_jit_aux.on) {
           // fraction f = k / 2: numerator (any representative) then denominator (canonical: tested against zero); after every
@@ -365,6 +390,171 @@ static std::vector<std::vector<size_t>> jit_gate_groups(const std::vector<const 
     cur += len;
   }
   return groups;
+}
+
+// ---- ALL program gates of a circuit in ONE kernel that reads the wires ONCE (round 6) ---------------------------------------------
+// One kernel per gate is bound by re-reading the wire columns: with the recursive verifier's nine program gates the wires LDE
+// (135 columns x 8n rows) is read 813 columns' worth per proof, six of the nine kernels run at 4.2 - 4.7 TB/s of HBM, and the
+// register-fused kernel of rounds 1-3 lost more to spills than it saved.  Here a workgroup owns 64 consecutive LDE rows and is W
+// wavefronts wide: all waves stage the rows' wires into LDS once (column-major [column][64 rows]: a wave's 64 lanes write and read 512
+// contiguous bytes, conflict-free; canonicalised on the way in), then every WAVE evaluates its own share of the gates on the same 64
+// rows — a wave-uniform branch, so each gate's straight-line block keeps the register file to itself — reading wires from LDS at the
+// point of use, and the waves' filtered sums meet in LDS for one read-modify-write of the quotient values.  Gates are dealt to waves
+// by estimated instruction count (longest first).  HBM traffic of the program gates: the wires once.
+#define VX_JIT_FUSED_MAX 24    /* program gates per fused kernel (JitFusedParams::g) */
+#define VX_JIT_FUSED_WAVES 8   /* waves per workgroup: 8 x 64 threads, 2 workgroups per CU at 69 KB of LDS each = 4 waves per SIMD, 128 VGPRs */
+struct JitFusedParams {  // mirrored textually in jit_fused_source()
+  const u64 *cs, *wires;
+  const Limbs3x2* alpha_limbs;
+  u64* out;
+  size_t N, rows, row_base, stride_w;
+  int log_n, rate_bits, num_selectors, nch;
+  int base_idx, ngates;
+  int const_base, pad_;
+  u64 pih[4];
+  u64 zh_inv[VX_MAX_RATE];
+  JitGateRt g[VX_JIT_FUSED_MAX];
+};
+struct JitFusedPlan {
+  int waves = 0, max_col = 0;
+  std::vector<std::vector<size_t>> of_wave;   // program indices per wave
+  std::vector<size_t> cost;                   // estimated VALU instructions per program
+};
+static JitFusedPlan jit_fused_plan(const std::vector<const uint64_t*>& progs, int nch) {
+  JitFusedPlan P;
+  for (const uint64_t* prog : progs) {
+    size_t c = 0;
+    for (const JitIns& I : jit_decode(prog)) {
+      switch (I.op) {
+        case VX_OP_MUL: c += 14; break;
+        case VX_OP_ADD: case VX_OP_SUB: c += 5; break;
+        case VX_OP_PUSH: c += 7 * (size_t)nch; break;
+        case VX_OP_LDW: P.max_col = std::max(P.max_col, I.a + 1), c += 1; break;
+        default: c += 1; break;
+      }
+    }
+    P.cost.push_back(c + 150);   // + the selector filter
+  }
+  const char* we = getenv("VX_JIT_FUSED_WAVES");
+  P.waves = std::max(1, std::min<int>({we && atoi(we) > 0 ? atoi(we) : VX_JIT_FUSED_WAVES, 16, (int)progs.size()}));
+  P.of_wave.resize(P.waves);
+  std::vector<size_t> order(progs.size()), load(P.waves, 0);
+  for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return P.cost[a] > P.cost[b]; });
+  for (size_t q : order) {
+    const size_t w = std::min_element(load.begin(), load.end()) - load.begin();
+    P.of_wave[w].push_back(q);
+    load[w] += P.cost[q];
+  }
+  return P;
+}
+// can this gate set run as one fused kernel?  (at least two gates, no more than the parameter block holds, a wire tile that leaves room
+// for two workgroups per CU)
+static bool jit_fused_applicable(const std::vector<const uint64_t*>& progs, int nch) {
+  const char* e = getenv("VX_JIT_FUSED");
+  if (e && atoi(e) == 0) return false;
+  if (progs.size() < 2 || progs.size() > VX_JIT_FUSED_MAX) return false;
+  const JitFusedPlan P = jit_fused_plan(progs, nch);
+  return P.max_col >= 1 && (size_t)P.max_col * 512 + (size_t)P.waves * 1024 <= 80 * 1024;
+}
+static std::string jit_fused_source(const std::vector<const uint64_t*>& progs, int nch) {
+  const JitFusedPlan P = jit_fused_plan(progs, nch);
+  const int W = P.waves;
+  const size_t lds = (size_t)P.max_col * 512 + (size_t)W * 1024;
+  const int blocks_per_cu = (int)std::max<size_t>(1, std::min<size_t>(160 * 1024 / lds, 2));
+  const int waves_per_simd = std::max(1, std::min(8, blocks_per_cu * W / 4));
+  std::ostringstream s;
+  s << "typedef unsigned long long uint64_t;\ntypedef unsigned int uint32_t;\n"
+    << "#define VX_ALPHA_POWS " << VX_ALPHA_POWS << "\n#define VX_JIT_FUSED_MAX " << VX_JIT_FUSED_MAX << "\n#define FW " << W << "\n#define FCOLS " << P.max_col
+    << "\n#define FLOADS " << (P.max_col + W - 1) / W << "\n#define FWPS " << waves_per_simd << "\n"
+    << jit_limits_defines() << JIT_PRELUDE << JIT_DOT3 << R"VXJIT(
+struct JitGateRt {
+  int gate_index, selector_index, group_start, group_end;
+};
+struct JitFusedParams {
+  const u64 *cs, *wires;
+  const Limbs3x2* alpha_limbs;
+  u64* out;
+  size_t N, rows, row_base, stride_w;
+  int log_n, rate_bits, num_selectors, nch;
+  int base_idx, ngates;
+  int const_base, pad_;
+  u64 pih[4];
+  u64 zh_inv[VX_MAX_RATE];
+  JitGateRt g[VX_JIT_FUSED_MAX];
+};
+extern "C" __global__ __launch_bounds__(64 * FW, FWPS) void vx_program_gates_fused(JitFusedParams p) {
+  __shared__ u64 LW[FCOLS * 64];
+  __shared__ u64 LT[FW * 2 * 64];
+  const u32 lane0 = threadIdx.x & 63u, lane = lane0;
+  const u32 wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const size_t il_raw = (size_t)blockIdx.x * 64 + lane;
+  const bool live = il_raw < p.rows;
+  const size_t il = live ? il_raw : p.rows - 1;
+  const size_t N = p.N, SW = p.stride_w, i = il + p.row_base;
+  const u64* __restrict__ CS = p.cs;
+  const u64* __restrict__ W = p.wires;
+  const Limbs3x2* AL0 = p.alpha_limbs + p.base_idx;
+  const int nsel = p.num_selectors, cbase = p.const_base;
+  {
+    u64 v[FLOADS];
+#pragma unroll
+    for (int k = 0; k < FLOADS; ++k) {
+      const u32 col = wid + (u32)k * FW;
+      v[k] = col < FCOLS ? W[(size_t)col * SW + il] : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < FLOADS; ++k) {
+      const u32 col = wid + (u32)k * FW;
+      if (col < FCOLS) LW[col * 64 + lane] = gl_canon(v[k]);
+    }
+  }
+  __syncthreads();
+  u64 t0 = 0, t1 = 0;
+)VXJIT";
+  for (int w = 0; w < W; ++w) {
+    s << (w ? "  else if" : "  if") << " (wid == " << w << "u) {\n";
+    for (size_t q : P.of_wave[w]) {
+      s << "  {  // program gate, slot " << q << " (estimated " << P.cost[q] << " instructions)\n"
+           "    const JitGateRt G = p.g[" << q << "];\n"
+           "    const u64 s = CS[(size_t)G.selector_index * N + i];\n"
+           "    u64 filter = 1;\n"
+           "    for (int q = G.group_start; q < G.group_end; ++q)\n"
+           "      if (q != G.gate_index) filter = gl_mul(filter, gl_sub((u64)q, s));\n"
+           "    if (nsel > 1) filter = gl_mul(filter, gl_sub(0xFFFFFFFFULL, s));\n"
+           "    dot3 A0 = {0, 0, 0}, A1 = {0, 0, 0};\n"
+           "    u64 R[VX_PROGRAM_REGS];\n"
+           // the same alpha-power limbs / the same wire cells are read by the blocks of different waves: laundering the two bases per
+           // block keeps the compiler from hoisting those loads above the wave branch (it did: 248 SGPR and 285 VGPR spills)
+           "    const Limbs3x2* AL_ = AL0; asm volatile(\"\" : \"+s\"(AL_)); const Limbs3x2* __restrict__ AL = AL_;\n"
+           "    u32 lane = lane0; asm volatile(\"\" : \"+v\"(lane));\n";
+      g_jit_lds_wires = true;
+      jit_emit_program(s, progs[q], nch, false);
+      g_jit_lds_wires = false;
+      s << "    t0 = gl_mad(filter, dot3_reduce_nc(A0), t0);\n";
+      if (nch > 1) s << "    t1 = gl_mad(filter, dot3_reduce_nc(A1), t1);\n";
+      s << "    (void)A1;\n  }\n";
+    }
+    s << "  }\n";
+  }
+  s << R"VXJIT(
+  LT[(wid * 2 + 0) * 64 + lane] = t0;
+  LT[(wid * 2 + 1) * 64 + lane] = t1;
+  __syncthreads();
+  if (wid == 0u && live) {
+    const u32 z = (u32)(i >> p.log_n);
+    const u32 r = p.rate_bits ? (__brev(z) >> (32 - p.rate_bits)) : 0u;
+    const u64 zi = p.zh_inv[r];
+    u64 a0 = LT[lane];
+#pragma unroll
+    for (int w = 1; w < FW; ++w) a0 = gl_add(a0, LT[(w * 2 + 0) * 64 + lane]);
+    { u64* o = p.out + il; *o = gl_add(*o, gl_mul(a0, zi)); }
+)VXJIT";
+  if (nch > 1)
+    s << "    u64 a1 = LT[64 + lane];\n#pragma unroll\n    for (int w = 1; w < FW; ++w) a1 = gl_add(a1, LT[(w * 2 + 1) * 64 + lane]);\n"
+         "    { u64* o = p.out + SW + il; *o = gl_add(*o, gl_mul(a1, zi)); }\n";
+  s << "  }\n  (void)cbase; (void)W;\n}\n";
+  return s.str();
 }
 
 // ---- AIR programs are compiled in CHUNKS (round 3) --------------------------------------------------------------------------
@@ -556,6 +746,9 @@ static bool jit_cache_dir_ok(const char* dir) {
 static hipFunction_t jit_get_kernel(const std::string& src, const char* kernel_name, int device, std::string* why);
 static hipFunction_t jit_get_gates(const std::vector<const uint64_t*>& progs, int nch, int device, std::string* why) {
   return jit_get_kernel(jit_gate_source(progs, nch), "vx_program_gate", device, why);
+}
+static hipFunction_t jit_get_fused_gates(const std::vector<const uint64_t*>& progs, int nch, int device, std::string* why) {
+  return jit_get_kernel(jit_fused_source(progs, nch), "vx_program_gates_fused", device, why);
 }
 // compile (or find in the caches) every chunk WITHOUT loading it: needs no GPU — the `build` step of a host that proves later
 static int jit_air_precompile(const uint64_t* prog, int nch, int ncols, int* nchunks, std::string* why);
@@ -781,10 +974,14 @@ static int jit_air_precompile(const uint64_t* prog, int nch, int ncols, int* nch
 // the gate programs of a circuit description (vx_circuit_precompile): one source per program gate
 static int jit_gates_precompile(const std::vector<const uint64_t*>& progs, int nch, std::string* why) {
   std::vector<std::string> keep;
-  for (const std::vector<size_t>& grp : jit_gate_groups(progs)) {
-    std::vector<const uint64_t*> sub;
-    for (size_t q : grp) sub.push_back(progs[q]);
-    keep.push_back(jit_gate_source(sub, nch));
+  if (jit_fused_applicable(progs, nch)) {   // what vx_circuit_create will ask for
+    keep.push_back(jit_fused_source(progs, nch));
+  } else {
+    for (const std::vector<size_t>& grp : jit_gate_groups(progs)) {
+      std::vector<const uint64_t*> sub;
+      for (size_t q : grp) sub.push_back(progs[q]);
+      keep.push_back(jit_gate_source(sub, nch));
+    }
   }
   std::vector<const std::string*> srcs;
   for (const std::string& k : keep) srcs.push_back(&k);

@@ -24,6 +24,8 @@ struct vx_circuit {
   std::vector<hipFunction_t> jit_fns;  // native kernels (jit.hip.h), one per GROUP of program gates; empty -> interpreter
   std::vector<std::vector<size_t>> jit_groups;  // jit_fns[i] evaluates the gates jit_gates[jit_groups[i][..]]
   std::vector<int> jit_gates;         // gate index of each block of that kernel, in order
+  hipFunction_t jit_fused_fn = nullptr;  // ALL program gates in one kernel that stages the wires through LDS once (jit.hip.h, round 6); then jit_fns is empty
+  std::vector<std::string> jit_stage;  // profile stage of each launch: "qgate_<gate index>[+<gate index>...]" (vx_prof_get; the caller knows its gate order)
   std::vector<uint64_t> programs_host;  // host copy of the programs (vx_verify evaluates gates at zeta on the host)
   std::vector<u64> cs_cap_host;         // constants_sigmas cap (verifier data)
   std::string jit_note;               // why the program gates stayed on the interpreter (diagnostics)
@@ -151,18 +153,28 @@ static int circuit_create(vx_ctx* c, const vx_circuit_desc* d, vx_circuit** out)
         progs.push_back(prog);
         k->jit_gates.push_back(g);
       }
-      if (why.empty()) k->jit_groups = jit_gate_groups(progs);
+      if (why.empty() && jit_fused_applicable(progs, d->num_challenges)) {
+        std::string fwhy;   // a failure here is not fatal: the gates fall back to one kernel each
+        k->jit_fused_fn = jit_get_fused_gates(progs, d->num_challenges, c->device, &fwhy);
+      }
+      if (why.empty() && !k->jit_fused_fn) k->jit_groups = jit_gate_groups(progs);
       for (size_t gi = 0; gi < k->jit_groups.size() && why.empty(); ++gi) {
         std::vector<const uint64_t*> sub;
         for (size_t q : k->jit_groups[gi]) sub.push_back(progs[q]);
         hipFunction_t fn = jit_get_gates(sub, d->num_challenges, c->device, &why);
         if (fn) k->jit_fns.push_back(fn);
+        std::string nm = "qgate";
+        for (size_t q : k->jit_groups[gi]) nm += (nm.size() == 5 ? "_" : "+") + std::to_string(k->jit_gates[q]);
+        k->jit_stage.push_back(nm);
       }
-      if (!why.empty() || k->jit_fns.size() != k->jit_groups.size() || k->jit_fns.empty()) {   // all or nothing: the interpreter takes every program gate
+      if (k->jit_fused_fn) {
+        // nothing else to compile
+      } else if (!why.empty() || k->jit_fns.size() != k->jit_groups.size() || k->jit_fns.empty()) {   // all or nothing: the interpreter takes every program gate
         k->jit_note = why;
         k->jit_gates.clear();
         k->jit_fns.clear();
         k->jit_groups.clear();
+        k->jit_stage.clear();
       }
     }
   }
@@ -1026,7 +1038,27 @@ static int prove_impl(vx_ctx* c, vx_circuit* k, const u64* wires_in, bool wires_
           jp.base_idx = (int)nterms_before;
           for (int i = 0; i < 4; ++i) jp.pih[i] = pih.e[i];
           for (int r = 0; r < rate; ++r) jp.zh_inv[r] = qp.zh_inv[r];
-          if (!k->jit_fns.empty()) {
+          if (k->jit_fused_fn) {
+            JitFusedParams fp;
+            memset(&fp, 0, sizeof fp);
+            fp.cs = jp.cs, fp.wires = jp.wires, fp.alpha_limbs = jp.alpha_limbs, fp.out = jp.out;
+            fp.N = jp.N, fp.rows = jp.rows, fp.row_base = jp.row_base, fp.stride_w = jp.stride_w;
+            fp.log_n = jp.log_n, fp.rate_bits = jp.rate_bits, fp.num_selectors = jp.num_selectors, fp.nch = jp.nch;
+            fp.base_idx = jp.base_idx, fp.const_base = jp.const_base;
+            for (int i = 0; i < 4; ++i) fp.pih[i] = jp.pih[i];
+            for (int r = 0; r < rate; ++r) fp.zh_inv[r] = jp.zh_inv[r];
+            fp.ngates = (int)k->jit_gates.size();
+            for (int q = 0; q < fp.ngates; ++q) {
+              const int g = k->jit_gates[q];
+              fp.g[q] = JitGateRt{g, k->gates[g].selector_index, k->gates[g].group_start, k->gates[g].group_end};
+            }
+            std::vector<const uint64_t*> progs_h;   // the plan (waves per workgroup) is a function of the programs alone
+            for (int g : k->jit_gates) progs_h.push_back(k->programs_host.data() + k->prog_off[g]);
+            const int waves = jit_fused_plan(progs_h, nch).waves;
+            void* args[] = {&fp};
+            ProfScope psj(c, "quotient_program_gates_jit");
+            HIPCHK(hipModuleLaunchKernel(k->jit_fused_fn, (unsigned)((Nl + 63) / 64), 1, 1, 64 * waves, 1, 1, 0, c->stream, args, nullptr));
+          } else if (!k->jit_fns.empty()) {
             ProfScope psj(c, "quotient_program_gates_jit");
             for (size_t gi = 0; gi < k->jit_fns.size(); ++gi) {   // one launch per group of program gates, each adds its share
               jp.ngates = (int)k->jit_groups[gi].size();
@@ -1035,6 +1067,7 @@ static int prove_impl(vx_ctx* c, vx_circuit* k, const u64* wires_in, bool wires_
                 jp.g[q] = JitGateRt{g, k->gates[g].selector_index, k->gates[g].group_start, k->gates[g].group_end};
               }
               void* args[] = {&jp};
+              ProfScope psg(c, k->jit_stage[gi].c_str());
               HIPCHK(hipModuleLaunchKernel(k->jit_fns[gi], (unsigned)((Nl + 255) / 256), 1, 1, 256, 1, 1, 0, c->stream, args, nullptr));
             }
           }
@@ -1054,7 +1087,7 @@ static int prove_impl(vx_ctx* c, vx_circuit* k, const u64* wires_in, bool wires_
         pg.const_base = k->const_base();
         pg.nch = nch;
         for (size_t g = 0; g < k->gates.size(); ++g)
-          if (k->prog_off[g] >= 0 && k->jit_fns.empty())  // not compiled: interpreter
+          if (k->prog_off[g] >= 0 && k->jit_fns.empty() && !k->jit_fused_fn)  // not compiled: interpreter
             pg.gates[pg.num_gates++] = ProgramGateDev{(int)g, k->gates[g].selector_index, k->gates[g].group_start, k->gates[g].group_end, k->prog_off[g]};
         for (int i = 0; i < VX_MAX_CHALLENGES; ++i) pg.alphas[i] = alphas[i], pg.base_pw[i] = pow(alphas[i], nterms_before);
         for (int i = 0; i < 4; ++i) pg.pih[i] = pih.e[i];

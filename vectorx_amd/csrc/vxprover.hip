@@ -733,7 +733,7 @@ int vx_circuit_program_gates(vx_circuit* k, int* total_out, int* compiled_out, c
   for (size_t g = 0; g < k->prog_off.size(); ++g)
     if (k->prog_off[g] >= 0) {
       ++total;
-      compiled += !k->jit_fns.empty();
+      compiled += !k->jit_fns.empty() || k->jit_fused_fn != nullptr;
     }
   if (total_out) *total_out = total;
   if (compiled_out) *compiled_out = compiled;

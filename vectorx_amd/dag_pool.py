@@ -50,7 +50,7 @@ class DagPool:
         prover.prove(key, public_inputs, lane, input_seed, spent_out) -> proof bytes.  The default is the GPU library; the scheduler's
         CPU tests plug in their own (tests/_pool_factory.py)."""
         self.spec, self.devices, self.wpd, self.lanes = spec, list(devices), int(workers_per_device), int(lanes)
-        self.cfg = {"spec": (spec.num_map, spec.map_log_n, spec.reduce_log_n, spec.outer_log_n, spec.poseidon_percent), "lanes": self.lanes,
+        self.cfg = {"spec": (spec.num_map, spec.map_log_n, spec.reduce_log_n, spec.outer_log_n, spec.poseidon_percent, spec.recursion), "lanes": self.lanes,
                     "with_starks": bool(with_starks), "small_tables": bool(small_tables), "table_mode": table_mode, "factory": factory,
                     "distinct_witnesses": distinct_witnesses, "num_headers": num_headers}
         self.procs, self.conns, self.ready = [], [], []
@@ -281,8 +281,8 @@ class DagPool:
 def gpu_provers(cfg: dict, device: int):
     """the default factory: `lanes` contexts on `device`, the three circuits (+ the STARK tables of every job kind) loaded on each"""
     import vectorx_amd as vx
-    num_map, lm, lr, lo, pp = cfg["spec"]
-    spec = mr.DagSpec(num_map, lm, lr, lo, pp)
+    num_map, lm, lr, lo, pp, rec = cfg["spec"]
+    spec = mr.DagSpec(num_map, lm, lr, lo, pp, rec)
     ctx = vx.Context(device)
     lanes = [vx.Context(device) for _ in range(cfg["lanes"] - 1)]
     per_kind, tables, table_rec = {}, [], {}
@@ -307,10 +307,11 @@ def gpu_provers(cfg: dict, device: int):
         # the job list only sizes the set of base witnesses (min(distinct_witnesses, jobs of this kind)): the same as one process would build
         jobs = [(li, j) for li, (k, js) in enumerate(layers) if k == kind for j in js]
         if kind == "outer":
-            provers[kind] = mr.GpuProver(octx, kind, spec.log_n(kind), jobs, pp, distinct_witnesses=cfg["distinct_witnesses"], starks=per_kind.get(kind, ()))
+            provers[kind] = mr.GpuProver(octx, kind, spec.log_n(kind), jobs, pp, distinct_witnesses=cfg["distinct_witnesses"], starks=per_kind.get(kind, ()),
+                                         recursion=rec)
         else:
             provers[kind] = mr.GpuProver(ctx, kind, spec.log_n(kind), jobs, pp, extra_lanes=lanes, distinct_witnesses=cfg["distinct_witnesses"],
-                                         starks=per_kind.get(kind, ()))
+                                         starks=per_kind.get(kind, ()), recursion=rec)
 
     def close():
         for p in provers.values():

@@ -32,7 +32,13 @@ class DagSpec:
     map_log_n: int = 18
     reduce_log_n: int = 16
     outer_log_n: int = 19
-    poseidon_percent: int = 50
+    poseidon_percent: int = 50     # only without `recursion`: the PoseidonGate / ArithmeticGate split of rounds 1-5
+    recursion: bool = True         # the circuits carry the recursive verifier's gate set in its declared row mix
+                                   # (vectorx_amd/synth.py RECURSIVE_VERIFIER_MIX): a reduce job verifies two proofs in-circuit, a map /
+                                   # outer job its STARKs (/root/reference/circuits/builder/subchain_verification.rs:78, 233-289)
+
+    def circuit_kw(self):
+        return circuit_shape(self.recursion)
 
     def layers(self):
         """[(kind, [job ids])...]: map layer, reduce layers (binary tree), outer."""
@@ -50,6 +56,14 @@ class DagSpec:
 
     def log_n(self, kind):
         return {"map": self.map_log_n, "reduce": self.reduce_log_n, "outer": self.outer_log_n}[kind]
+
+
+def circuit_shape(recursion: bool = True) -> dict:
+    """SynthCircuit keywords of the DAG's stand-in circuits: with `recursion` PoseidonGate (Merkle paths, challenger), ArithmeticGate,
+    ArithmeticExtension, BaseSum, Exponentiation, RandomAccess, MulExtension, Reducing, ReducingExtension, PoseidonMds,
+    CosetInterpolation{4 bits, degree 8} and a lookup table in the declared mix; without, the two-gate stand-in of rounds 1-5"""
+    from vectorx_amd.synth import RECURSION_FLAGS, RECURSIVE_VERIFIER_MIX
+    return {"flags": RECURSION_FLAGS, "mix": RECURSIVE_VERIFIER_MIX} if recursion else {}
 
 
 def digest_to_field(d: bytes) -> np.ndarray:
@@ -319,7 +333,8 @@ class GpuProver:
     takes_input_seed = True
     takes_children = True
 
-    def __init__(self, ctx, kind, log_n, jobs, poseidon_percent=50, extra_lanes=(), distinct_witnesses=None, starks=(), split=None):
+    def __init__(self, ctx, kind, log_n, jobs, poseidon_percent=50, extra_lanes=(), distinct_witnesses=None, starks=(), split=None,
+                 recursion=True):
         """extra_lanes: more contexts on the SAME GPU; lane k proves on its own stream with its own copy of the circuit
         (run_dag(in_flight=...)).  distinct_witnesses = None: every job has its own generated witness (device-global, shared by
         the lanes).  distinct_witnesses = k: only k base witnesses are generated per circuit kind and job j proves base witness
@@ -341,7 +356,9 @@ class GpuProver:
         # and what the children stated; it closes the job's result bytes
         self.emits_statement = any(getattr(t, "needs_children", False) for _, t in self.starks)
         circuit_seed = {"map": 101, "reduce": 202, "outer": 303, "rotate": 404}[kind]
-        self.sc = SynthCircuit(log_n, seed=circuit_seed, poseidon_percent=poseidon_percent, witness_seed=0)
+        shape = circuit_shape(recursion)
+        self.recursion = bool(recursion)
+        self.sc = SynthCircuit(log_n, seed=circuit_seed, poseidon_percent=poseidon_percent, witness_seed=0, **shape)
         self.circuits = [vx.Circuit(c, self.sc.desc_ptr) for c in self.lanes]
         self.circuit = self.circuits[0]
         self.wit = {}
@@ -349,7 +366,7 @@ class GpuProver:
         self.lane_wit = []
         if distinct_witnesses is None:
             for (li, j) in jobs:
-                sj = SynthCircuit(log_n, seed=circuit_seed, poseidon_percent=poseidon_percent, witness_seed=1000 * li + j + 1)
+                sj = SynthCircuit(log_n, seed=circuit_seed, poseidon_percent=poseidon_percent, witness_seed=1000 * li + j + 1, **shape)
                 w = sj.witness()
                 d = ctx.alloc(w.nbytes)
                 ctx.upload(d, w)
@@ -360,7 +377,7 @@ class GpuProver:
             self.distinct = k
             self.lane_wit = [[] for _ in self.lanes]
             for b in range(k):
-                sj = SynthCircuit(log_n, seed=circuit_seed, poseidon_percent=poseidon_percent, witness_seed=7000 + b)
+                sj = SynthCircuit(log_n, seed=circuit_seed, poseidon_percent=poseidon_percent, witness_seed=7000 + b, **shape)
                 w = sj.witness()
                 for li_, c in enumerate(self.lanes):
                     d = ctx.alloc(w.nbytes)

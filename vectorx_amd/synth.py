@@ -48,6 +48,26 @@ FLAG_LOOKUP = 16             # + one lookup table (LookupTableGate rows) and Loo
 FLAG_U32_GATES = 32          # + plonky2-u32's U32Arithmetic / U32AddMany / U32Subtraction / U32RangeCheck / Comparison gates as programs (a voting-threshold block)
 FLAG_RECURSION_GATES = 8     # + MulExtension, Reducing, ReducingExtension, PoseidonMds, CosetInterpolation{4 bits, degree 8} as programs
 
+# ---- the declared row mix of a recursive verifier -------------------------------------------------------------------------------
+# In the reference a reduce job verifies its two children's proofs in-circuit and a map / outer job verifies its Curta STARKs in-circuit
+# (/root/reference/circuits/builder/subchain_verification.rs:78, 233-289; builder/header.rs:14-19; justification.rs:236-243), so most
+# rows of those circuits are the gates of plonky2's `verify_proof`.  The mix below is a RECOLLECTION-BASED COUNT (no Rust here to print
+# `builder.print_gate_counts`) of one `verify_proof` under standard_recursion_config for an inner proof of 2^12 rows — which lands, as
+# upstream's does, just under 2^12 rows itself.  Per FRI query (28 of them): leaf hashing of the four initial oracles
+# ceil(84/8) + ceil(135/8) + ceil(20/8) + ceil(16/8) = 33 PoseidonGate rows, four Merkle paths of 12 + 3 - 4 = 11 levels = 44, two FRI
+# layers (32 base elements per leaf = 4 permutations, paths of 7 and 3 levels) = 18  ->  95 PoseidonGate rows; reducing 255 + 2
+# openings with ReducingGate{43} = 7 rows; 2 CosetInterpolationGate rows; the cap / evaluation selections = 6 RandomAccessGate{4 bits}
+# rows; 2 BaseSumGate rows (index bits), 1 ExponentiationGate row, ~3 ArithmeticExtensionGate and ~2 ArithmeticGate rows.  Once per
+# proof: the challenger (~900 observed elements = ~115 PoseidonGate rows), the gate constraints at zeta (~200 ArithmeticExtensionGate,
+# ~30 PoseidonMdsGate, ~20 MulExtensionGate, ~12 ReducingExtensionGate rows), the permutation checks (~24 ArithmeticGate rows).
+# Total ~3 730 of 4 096 rows.  plonky2x circuits also carry a lookup table (byte range checks): 4 rows per thousand, declared.
+MIX_KEYS = ("poseidon", "arithmetic", "arithmetic_extension", "base_sum", "exponentiation", "random_access", "mul_extension", "reducing",
+            "reducing_extension", "poseidon_mds", "coset_interpolation", "lookup")          # the order of vxs_build5's mix_permille
+RECURSIVE_VERIFIER_MIX = {"poseidon": 678, "arithmetic_extension": 69, "reducing": 48, "random_access": 41, "arithmetic": 20, "base_sum": 16,
+                          "coset_interpolation": 14, "exponentiation": 7, "poseidon_mds": 7, "mul_extension": 5, "reducing_extension": 3,
+                          "lookup": 4}                                                     # rows per 1000; the remaining 88 are NoopGate padding
+RECURSION_FLAGS = FLAG_PROGRAM_GATES | FLAG_MORE_PROGRAM_GATES | FLAG_RECURSION_GATES | FLAG_LOOKUP   # = 29: the gate families the mix needs
+
 
 def build() -> Path:
     r = subprocess.run(["make", "-C", str(_PKG / "synth")], capture_output=True, text=True)
@@ -73,6 +93,14 @@ def _load():
         L.vxs_build3.argtypes = [ctypes.c_int, ctypes.c_uint64, ctypes.c_int, ctypes.c_uint64, ctypes.c_int]
         L.vxs_build4.restype = ctypes.c_void_p
         L.vxs_build4.argtypes = [ctypes.c_int, ctypes.c_uint64, ctypes.c_int, ctypes.c_uint64, ctypes.c_int, ctypes.c_int]
+        L.vxs_build5.restype = ctypes.c_void_p
+        L.vxs_build5.argtypes = [ctypes.c_int, ctypes.c_uint64, ctypes.c_int, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+        L.vxs_gate_rows.restype = ctypes.c_int
+        L.vxs_gate_rows.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        L.vxs_gate_keys.restype = ctypes.c_int
+        L.vxs_gate_keys.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        L.vxs_gate_key_name.restype = ctypes.c_char_p
+        L.vxs_gate_key_name.argtypes = [ctypes.c_int]
         L.vxs_row_counts_ext.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         L.vxs_recursion_rows.restype = ctypes.c_uint64
         L.vxs_recursion_rows.argtypes = [ctypes.c_void_p]
@@ -96,12 +124,22 @@ class SynthCircuit:
     """A synthetic standard_recursion_config circuit with a satisfying witness."""
 
     def __init__(self, degree_bits: int, seed: int = 0, poseidon_percent: int = 50, witness_seed: int | None = None,
-                 flags: int = 0, quotient_degree_factor: int = 8):
+                 flags: int = 0, quotient_degree_factor: int = 8, mix: dict | None = None):
         """`seed` fixes the circuit; `witness_seed` (default = seed) only the witness values; `flags`: FLAG_*;
-        `quotient_degree_factor` (CircuitConfig::max_quotient_degree_factor, 3..8): below 7 the circuit has no PoseidonGate."""
+        `quotient_degree_factor` (CircuitConfig::max_quotient_degree_factor, 3..8): below 7 the circuit has no PoseidonGate;
+        `mix`: a declared row mix {MIX_KEYS name: rows per thousand} (e.g. RECURSIVE_VERIFIER_MIX with flags=RECURSION_FLAGS) instead of
+        the fixed fractions; every family it names must be enabled in `flags`, the rest of the trace is NoopGate padding."""
         L = _load()
-        self._h = L.vxs_build4(degree_bits, seed, poseidon_percent, seed if witness_seed is None else witness_seed, flags,
-                               quotient_degree_factor)
+        mixbuf = None
+        if mix is not None:
+            unknown = set(mix) - set(MIX_KEYS)
+            if unknown:
+                raise ValueError(f"unknown gate families in the mix: {sorted(unknown)}")
+            mixbuf = (ctypes.c_int32 * len(MIX_KEYS))(*[int(mix.get(k, 0)) for k in MIX_KEYS])
+        self.mix = dict(mix) if mix is not None else None
+        self.flags = flags
+        self._h = L.vxs_build5(degree_bits, seed, poseidon_percent, seed if witness_seed is None else witness_seed, flags,
+                               quotient_degree_factor, ctypes.cast(mixbuf, ctypes.c_void_p) if mixbuf is not None else None)
         if not self._h:
             raise ValueError("vxs_build rejected the parameters")
         self.degree_bits = degree_bits
@@ -146,6 +184,20 @@ class SynthCircuit:
         if rec:
             d["recursion_each"] = rec   # rows of EACH of MulExtension / Reducing / ReducingExtension / PoseidonMds / CosetInterpolation
         return d
+
+    def gate_rows(self) -> dict:
+        """{gate name: rows} for every gate that has rows (counted where the selector columns are written)"""
+        L = _load()
+        out = (ctypes.c_uint64 * 64)()
+        k = L.vxs_gate_rows(self._h, out, 64)
+        return {L.vxs_gate_key_name(i).decode(): int(out[i]) for i in range(k) if out[i]}
+
+    def gate_names(self) -> list:
+        """the gate's name for every gate index of the description (the order the prover's per-gate stages are numbered in)"""
+        L = _load()
+        out = (ctypes.c_int32 * 64)()
+        k = L.vxs_gate_keys(self._h, out, 64)
+        return [L.vxs_gate_key_name(out[i]).decode() for i in range(k)]
 
     # ---- overrides: what a plonky2 caller takes from CommonCircuitData / VerifierOnlyCircuitData (vxprover.h VX_DESC_HAS_*)
     def set_circuit_digest(self, digest) -> None:

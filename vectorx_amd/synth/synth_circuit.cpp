@@ -38,6 +38,10 @@ using namespace vxh;
 #define VXS_FLAG_RECURSION_GATES 8    /* + the rest of the recursive verifier's gate set as programs: MulExtensionGate, ReducingGate,
                                          ReducingExtensionGate, PoseidonMdsGate, CosetInterpolationGate{4 bits, degree 8} */
 
+/* vxs_build5's mix_permille entries (rows of a gate per thousand rows of the trace) */
+enum { VXS_MIX_POSEIDON, VXS_MIX_ARITHMETIC, VXS_MIX_ARITHMETIC_EXTENSION, VXS_MIX_BASE_SUM, VXS_MIX_EXPONENTIATION, VXS_MIX_RANDOM_ACCESS,
+       VXS_MIX_MUL_EXTENSION, VXS_MIX_REDUCING, VXS_MIX_REDUCING_EXTENSION, VXS_MIX_POSEIDON_MDS, VXS_MIX_COSET_INTERPOLATION, VXS_MIX_LOOKUP,
+       VXS_MIX_COUNT };
 #define VXS_FLAG_U32_GATES 32         /* + plonky2-u32's gates as programs (what plonky2x's U32Variable add / mul / sub / gt and its range checks
                                          instantiate — /root/reference/circuits/builder/justification.rs:164-186, decoder.rs:39-92):
                                          U32ArithmeticGate{3 ops}, U32AddManyGate{3 addends, 5 ops}, U32SubtractionGate{6 ops},
@@ -80,8 +84,10 @@ struct Synth {
   std::vector<u64> public_inputs;
   size_t n_poseidon = 0, n_arith = 0, n_noop = 0, n_arithext = 0, n_basesum = 0, n_exp = 0, n_randacc = 0, n_recursion = 0;
   size_t n_lookup = 0, n_lookup_table = 0, n_u32 = 0;
+  size_t rows_by_key[K_COUNT] = {0};   // rows carrying each gate (counted where the selectors are written)
   std::vector<int32_t> lut_lens, lookup_rows;
   std::vector<uint16_t> lut_inputs, lut_outputs;
+  std::vector<int32_t> key_of_gate;   // desc gate index -> Key
   vx_circuit_desc desc;
 };
 
@@ -687,6 +693,8 @@ extern "C" {
 typedef struct vxs_circuit vxs_circuit;
 
 vxs_circuit* vxs_build4(int degree_bits, uint64_t seed, int poseidon_percent, uint64_t witness_seed, int flags, int quotient_degree_factor);
+vxs_circuit* vxs_build5(int degree_bits, uint64_t seed, int poseidon_percent, uint64_t witness_seed, int flags, int quotient_degree_factor,
+                        const int32_t* mix_permille);
 vxs_circuit* vxs_build3(int degree_bits, uint64_t seed, int poseidon_percent, uint64_t witness_seed, int flags) {
   return vxs_build4(degree_bits, seed, poseidon_percent, witness_seed, flags, 8);
 }
@@ -703,6 +711,13 @@ vxs_circuit* vxs_build(int degree_bits, uint64_t seed, int poseidon_percent) {
 // PoseidonGate (degree 7): below 7 the circuit is built without it (row 2, which hashes the public inputs in a real
 // circuit, becomes a NoopGate row that merely carries the hash).
 vxs_circuit* vxs_build4(int degree_bits, uint64_t seed, int poseidon_percent, uint64_t witness_seed, int flags, int qdf) {
+  return vxs_build5(degree_bits, seed, poseidon_percent, witness_seed, flags, qdf, nullptr);
+}
+// mix_permille (VXS_MIX_COUNT entries, or NULL = the fixed fractions of rounds 1-5): a DECLARED row mix — rows of each gate as
+// parts per thousand of the trace, in the order of VXS_MIX_*; what is left is NoopGate padding (a real circuit is padded to a power
+// of two the same way).  Every family with a non-zero entry must be enabled in `flags`; poseidon_percent is ignored.
+vxs_circuit* vxs_build5(int degree_bits, uint64_t seed, int poseidon_percent, uint64_t witness_seed, int flags, int qdf,
+                        const int32_t* mix) {
   if (degree_bits < 3 || degree_bits > 24 || poseidon_percent < 0 || poseidon_percent > 100 || qdf < 3 || qdf > 8) return nullptr;
   const bool has_poseidon = qdf >= 7;
   if (!has_poseidon) poseidon_percent = 0;
@@ -763,6 +778,7 @@ vxs_circuit* vxs_build4(int degree_bits, uint64_t seed, int poseidon_percent, ui
   int idx_of[K_COUNT];
   for (int k = 0; k < K_COUNT; ++k) idx_of[k] = -1;
   for (int g = 0; g < ng; ++g) idx_of[gates[g].key] = g;
+  for (int g = 0; g < ng; ++g) S->key_of_gate.push_back(gates[g].key);
   // gates/selectors.rs::selector_polynomials, max_degree = quotient_degree_factor + 1 (9 in the standard configuration)
   const int max_degree = qdf + 1;
   std::vector<std::pair<int, int>> groups;
@@ -829,31 +845,62 @@ vxs_circuit* vxs_build4(int degree_bits, uint64_t seed, int poseidon_percent, ui
   size_t n_ext = with_prog ? std::max<size_t>(1, body / 16) : 0, n_bs = with_prog ? std::max<size_t>(1, body / 16) : 0;
   size_t n_exp = more_prog ? std::max<size_t>(1, body / 32) : 0, n_ra = more_prog ? std::max<size_t>(1, body / 32) : 0;
   size_t n_rec = rec_prog ? std::max<size_t>(1, body / 64) : 0;   // rows of EACH of the five recursion gates
+  size_t n_recs[5] = {n_rec, n_rec, n_rec, n_rec, n_rec};         // MulExtension, Reducing, ReducingExtension, PoseidonMds, CosetInterpolation
   // lookup argument: a table of L (input, output) pairs in ceil(L / 26) LookupTableGate rows, n_lu LookupGate rows, and the
   // all-zero NoopGate row that must follow the table (circuit_builder.rs::add_all_lookups)
   const size_t lut_len = with_lookup ? std::min<size_t>(200, 26 * std::max<size_t>(1, body / 32)) : 0;
-  const size_t n_lut = with_lookup ? (lut_len + 25) / 26 : 0, n_lu = with_lookup ? std::max<size_t>(1, body / 32) : 0;
+  size_t n_lut = with_lookup ? (lut_len + 25) / 26 : 0, n_lu = with_lookup ? std::max<size_t>(1, body / 32) : 0;
   // the U32 "voting threshold" block: n_u32 chained U32ArithmeticGate rows + 1 threshold row, and n_u32 rows of each of the
   // other four gates
   size_t n_u32 = u32_prog ? std::max<size_t>(1, body / 64) : 0;
-  const size_t lookup_total = (with_lookup ? n_lu + n_lut + 1 : 0);
   auto u32_total = [&]() { return n_u32 ? 5 * n_u32 + 1 : (size_t)0; };
-  while (n_noop + n_ext + n_bs + n_exp + n_ra + 5 * n_rec + lookup_total + u32_total() > body && n_ext + n_exp + (n_rec > 1) + (n_u32 > 1) > 0) {
-    if (n_ext) --n_ext, --n_bs;
-    if (n_exp) --n_exp, --n_ra;
-    if (n_rec > 1) --n_rec;
-    if (n_u32 > 1) --n_u32;
+  size_t n_pos = 0, n_arith = 0;
+  if (mix) {
+    // the declared mix: every enabled family gets its share of the trace (at least one row), the rest is padding
+    for (int i = 0; i < VXS_MIX_COUNT; ++i)
+      if (mix[i] < 0 || mix[i] > 1000) { delete S; return nullptr; }
+    auto share = [&](int i, bool enabled) -> size_t {
+      if (!enabled) return 0;
+      return std::max<size_t>(1, (size_t)((unsigned __int128)body * (unsigned)mix[i] / 1000));
+    };
+    if ((!with_prog && (mix[VXS_MIX_ARITHMETIC_EXTENSION] || mix[VXS_MIX_BASE_SUM])) || (!more_prog && (mix[VXS_MIX_EXPONENTIATION] || mix[VXS_MIX_RANDOM_ACCESS])) ||
+        (!rec_prog && (mix[VXS_MIX_MUL_EXTENSION] || mix[VXS_MIX_REDUCING] || mix[VXS_MIX_REDUCING_EXTENSION] || mix[VXS_MIX_POSEIDON_MDS] || mix[VXS_MIX_COSET_INTERPOLATION])) ||
+        (!with_lookup && mix[VXS_MIX_LOOKUP]) || (!has_poseidon && mix[VXS_MIX_POSEIDON])) { delete S; return nullptr; }
+    n_noop = 0;
+    n_ext = share(VXS_MIX_ARITHMETIC_EXTENSION, with_prog), n_bs = share(VXS_MIX_BASE_SUM, with_prog);
+    n_exp = share(VXS_MIX_EXPONENTIATION, more_prog), n_ra = share(VXS_MIX_RANDOM_ACCESS, more_prog);
+    for (int q = 0; q < 5; ++q) n_recs[q] = share(VXS_MIX_MUL_EXTENSION + q, rec_prog);
+    n_lu = share(VXS_MIX_LOOKUP, with_lookup);
+    n_pos = has_poseidon ? (size_t)((unsigned __int128)body * (unsigned)mix[VXS_MIX_POSEIDON] / 1000) : 0;
+    n_arith = (size_t)((unsigned __int128)body * (unsigned)mix[VXS_MIX_ARITHMETIC] / 1000);
   }
-  if (n_noop + n_ext + n_bs + n_exp + n_ra + 5 * n_rec + lookup_total + u32_total() > body) { delete S; return nullptr; }
+  auto rec_total = [&]() { return n_recs[0] + n_recs[1] + n_recs[2] + n_recs[3] + n_recs[4]; };
+  const size_t lookup_total = (with_lookup ? n_lu + n_lut + 1 : 0);
+  if (!mix)
+    while (n_noop + n_ext + n_bs + n_exp + n_ra + rec_total() + lookup_total + u32_total() > body && n_ext + n_exp + (n_recs[0] > 1) + (n_u32 > 1) > 0) {
+      if (n_ext) --n_ext, --n_bs;
+      if (n_exp) --n_exp, --n_ra;
+      if (n_recs[0] > 1) for (size_t& r : n_recs) --r;
+      if (n_u32 > 1) --n_u32;
+    }
+  if (mix) {   // a tiny trace: the one-row minimum of every family comes out of the arithmetic rows first, then out of the Poseidon rows
+    const size_t fixed = n_ext + n_bs + n_exp + n_ra + rec_total() + lookup_total + u32_total();
+    if (fixed > body) { delete S; return nullptr; }
+    if (fixed + n_pos > body) n_pos = body - fixed;
+    if (fixed + n_pos + n_arith > body) n_arith = body - fixed - n_pos;
+  }
+  if (n_noop + n_ext + n_bs + n_exp + n_ra + rec_total() + lookup_total + u32_total() + n_pos + n_arith > body) { delete S; return nullptr; }
   S->n_u32 = n_u32;
-  S->n_recursion = n_rec;
+  S->n_recursion = n_recs[0];
   S->n_lookup = n_lu;
   S->n_lookup_table = n_lut;
-  size_t rest = body - n_noop - n_ext - n_bs - n_exp - n_ra - 5 * n_rec - lookup_total - u32_total();
+  size_t rest = body - n_noop - n_ext - n_bs - n_exp - n_ra - rec_total() - lookup_total - u32_total();
   S->n_exp = n_exp;
   S->n_randacc = n_ra;
-  size_t n_pos = rest * (size_t)poseidon_percent / 100;
-  size_t n_arith = rest - n_pos;
+  if (!mix) {
+    n_pos = rest * (size_t)poseidon_percent / 100;
+    n_arith = rest - n_pos;
+  }
   S->n_poseidon = has_poseidon ? n_pos + 1 : 0;
   S->n_arith = n_arith;
   S->n_noop = n_noop;
@@ -868,6 +915,7 @@ vxs_circuit* vxs_build4(int degree_bits, uint64_t seed, int poseidon_percent, ui
   const u64 UNUSED = 0xFFFFFFFFULL;
   auto set_gate = [&](size_t row, int key) {
     const int g = idx_of[key];
+    ++S->rows_by_key[key];
     for (int q = 0; q < NSEL; ++q) S->constants_sigmas[(size_t)q * n + row] = group_of[g] == q ? (u64)g : UNUSED;
   };
   DSU dsu((size_t)NR * n);
@@ -1009,7 +1057,7 @@ vxs_circuit* vxs_build4(int degree_bits, uint64_t seed, int poseidon_percent, ui
     auto rext = [&]() { return Ext{wrng.field(), wrng.field()}; };
     auto put = [&](int col, size_t r, Ext e) { W(col, r) = e.a, W(col + 1, r) = e.b; };
     // MulExtensionGate rows
-    for (size_t e = 0; e < n_rec; ++e, ++row) {
+    for (size_t e = 0; e < n_recs[0]; ++e, ++row) {
       set_gate(row, K_MULEXT);
       const u64 k0 = rng.field();
       c0[row] = k0;
@@ -1022,7 +1070,7 @@ vxs_circuit* vxs_build4(int degree_bits, uint64_t seed, int poseidon_percent, ui
     }
     // ReducingGate / ReducingExtensionGate rows: Horner accumulation of the coefficients at alpha
     for (int kind = 0; kind < 2; ++kind)
-      for (size_t e = 0; e < n_rec; ++e, ++row) {
+      for (size_t e = 0; e < n_recs[1 + kind]; ++e, ++row) {
         set_gate(row, kind ? K_REDUCINGEXT : K_REDUCING);
         const int nc = kind ? 32 : 43, cw = kind ? 2 : 1, start_accs = 6 + cw * nc;
         Ext alpha = rext(), acc = rext();
@@ -1037,7 +1085,7 @@ vxs_circuit* vxs_build4(int degree_bits, uint64_t seed, int poseidon_percent, ui
         }
       }
     // PoseidonMdsGate rows
-    for (size_t e = 0; e < n_rec; ++e, ++row) {
+    for (size_t e = 0; e < n_recs[3]; ++e, ++row) {
       set_gate(row, K_POSEIDONMDS);
       static const u64 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
       Ext in[12];
@@ -1054,7 +1102,7 @@ vxs_circuit* vxs_build4(int degree_bits, uint64_t seed, int poseidon_percent, ui
     }
     // CosetInterpolationGate rows
     CosetInterp G;
-    for (size_t e = 0; e < n_rec; ++e, ++row) {
+    for (size_t e = 0; e < n_recs[4]; ++e, ++row) {
       set_gate(row, K_COSETINTERP);
       u64 shift = wrng.field();
       if (shift == 0) shift = 7;
@@ -1230,6 +1278,7 @@ vxs_circuit* vxs_build4(int degree_bits, uint64_t seed, int poseidon_percent, ui
     set_gate(row++, K_NOOP);
   }
   for (; row < n; ++row) set_gate(row, K_NOOP);
+  S->n_noop = S->rows_by_key[K_NOOP];
 
   // k_is = 7^j (plonk_common / circuit_builder: get_unique_coset_shifts)
   S->k_is.resize(NR);
@@ -1334,6 +1383,24 @@ void vxs_row_counts(vxs_circuit* c, uint64_t out[3]) {
   out[0] = S->n_poseidon;
   out[1] = S->n_arith;
   out[2] = S->n_noop;
+}
+/* Rows per gate: out[key] for the VXS gate keys (vxs_gate_key_name), and the key of every gate of the description in its order. */
+int vxs_gate_rows(vxs_circuit* c, uint64_t* out, int cap) {
+  Synth* S = reinterpret_cast<Synth*>(c);
+  for (int k = 0; k < K_COUNT && k < cap; ++k) out[k] = S->rows_by_key[k];
+  return K_COUNT;
+}
+int vxs_gate_keys(vxs_circuit* c, int32_t* out, int cap) {
+  Synth* S = reinterpret_cast<Synth*>(c);
+  for (size_t g = 0; g < S->key_of_gate.size() && (int)g < cap; ++g) out[g] = S->key_of_gate[g];
+  return (int)S->key_of_gate.size();
+}
+const char* vxs_gate_key_name(int key) {
+  static const char* names[K_COUNT] = {"NoopGate", "ConstantGate", "PublicInputGate", "ArithmeticGate", "PoseidonGate", "ArithmeticExtensionGate",
+                                       "BaseSumGate", "ExponentiationGate", "RandomAccessGate", "MulExtensionGate", "ReducingGate",
+                                       "ReducingExtensionGate", "PoseidonMdsGate", "CosetInterpolationGate", "LookupGate", "LookupTableGate",
+                                       "U32ArithmeticGate", "U32AddManyGate", "U32SubtractionGate", "U32RangeCheckGate", "ComparisonGate"};
+  return key >= 0 && key < K_COUNT ? names[key] : "";
 }
 uint64_t vxs_recursion_rows(vxs_circuit* c) { return reinterpret_cast<Synth*>(c)->n_recursion; }
 uint64_t vxs_u32_rows(vxs_circuit* c) { return reinterpret_cast<Synth*>(c)->n_u32; }
