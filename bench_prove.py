@@ -92,7 +92,7 @@ def dag_leg(ctx, local_rank, in_flight=3):
 
     def make(kind, log_n, jobs):        # one prover per circuit kind, kept across the two passes
         if kind not in provers:
-            provers[kind] = mr.GpuProver(ctx, kind, log_n, jobs, spec.poseidon_percent, extra_lanes=lanes, distinct_witnesses=4, recursion=spec.recursion, recursion=spec.recursion)
+            provers[kind] = mr.GpuProver(ctx, kind, log_n, jobs, spec.poseidon_percent, extra_lanes=lanes, distinct_witnesses=4, recursion=spec.recursion)
         return provers[kind]
 
     def sync():

@@ -841,6 +841,233 @@ __global__ __launch_bounds__(256, 4) void lookup_terms_kernel(LookupParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// The same terms for the shape of standard_recursion_config (80 routed wires, quotient_degree_factor 8: 26 table slots in groups of
+// 5, 40 looking slots in groups of 7, 6 partial sums), re-formulated for instruction count (round 6: 18.8 k -> ~11 k VALU instructions
+// per row; the kernel is issue-bound like every Goldilocks kernel here):
+//   * a group's wires are loaded ONCE and serve both challenges (the walk is group-major, the terms' alpha powers are addressed
+//     explicitly: term t of challenge c sits at base_idx + c T + t);
+//   * prod (alpha - v_j) and sum_i w_i prod_{j != i} (alpha - v_j) come from a PRODUCT TREE over (P, S) pairs — merge
+//     (P_a P_b, S_a P_b + P_a S_b), leaves (f_i, w_i) — 11 multiplications for seven unweighted members and 12 for five weighted ones
+//     instead of 28 + 20 with prefix / suffix products;
+//   * the RE row transition  RE(next) delta^26 + sum_s (in_s + b out_s) delta^(25 - s)  is a dot product with constants the host
+//     knows (delta^k, b delta^k as pre-split limbs in the parameter block): carry-free accumulation, 6 multiply-adds per wire, one
+//     reduction, instead of a 26-step Horner chain of full multiply-reduces;
+//   * terms that share a selector are accumulated against their alpha powers FIRST and multiplied by the selector once;
+//   * every alpha-power multiply is the carry-free dot3 form against the pre-split powers (as in the gate kernels).
+// ------------------------------------------------------------------------------------------------
+struct LookupStaticExtra {
+  const Limbs3x2* alpha_limbs;                  // [VX_MAX_CHALLENGES][VX_ALPHA_POWS]
+  Limbs3x2 re_in[VX_MAX_CHALLENGES][26];        // delta^(25 - s)
+  Limbs3x2 re_out[VX_MAX_CHALLENGES][26];       // b delta^(25 - s)
+  u64 delta26[VX_MAX_CHALLENGES];
+};
+struct PSnode {
+  u64 P, S;
+};
+GLD PSnode ps_merge(PSnode a, PSnode b) { return PSnode{gl_mul_nc(a.P, b.P), gl_mad_nc(a.S, b.P, gl_mul_nc(a.P, b.S))}; }
+template <int WPS>
+__global__ __launch_bounds__(256, WPS) void lookup_terms_static_kernel(LookupParams p, LookupStaticExtra x) {
+  const size_t il = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (il >= p.rows) return;
+  const size_t N = p.N, SW = p.stride_w, i = il + p.row_base;
+  const int log_n = p.log_n;
+  const u32 nmask = (1u << log_n) - 1;
+  const u32 z = (u32)(i >> log_n);
+  const u32 r = bitrev32(z, p.rate_bits);
+  const u32 k = bitrev32((u32)i & nmask, log_n);
+  const size_t il_next = (((size_t)z << log_n) | bitrev32((k + 1) & nmask, log_n)) - p.row_base;
+  constexpr int NSL = 6;
+  const int T = 4 + p.num_luts + 2 * NSL;          // terms per challenge
+  const u64* __restrict__ wires = p.wires;
+  const Limbs3x2* __restrict__ AL = x.alpha_limbs;
+  // accumulators: [selector class][alpha challenge]; class 0 = TransSre terms, 1 = TransLdc terms, 2 = everything else (already multiplied)
+  dot3 acc[3][VX_MAX_CHALLENGES];
+#pragma unroll
+  for (int q = 0; q < 3; ++q)
+#pragma unroll
+    for (int c = 0; c < VX_MAX_CHALLENGES; ++c) acc[q][c] = dot3{0, 0, 0};
+  auto push = [&](int cls, u64 term, int idx) {
+#pragma unroll
+    for (int c = 0; c < VX_MAX_CHALLENGES; ++c) dot3_mac(acc[cls][c], term, AL[c * VX_ALPHA_POWS + idx]);
+  };
+  dot3 re_acc[VX_MAX_CHALLENGES];
+#pragma unroll
+  for (int c = 0; c < VX_MAX_CHALLENGES; ++c) re_acc[c] = dot3{0, 0, 0};
+  const u64* zl0 = p.zs + (size_t)p.zs_base * SW;
+  const size_t zstride = (size_t)p.nlp * SW;      // challenge stride inside the zs batch
+#pragma unroll 1
+  for (int poly = 0; poly < NSL; ++poly) {
+    u64 in5[5], out5[5], mu5[5], in7[7], out7[7];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+      const int s2 = poly * 5 + q;
+      const int col = s2 < 26 ? 3 * s2 : 0;
+      in5[q] = gl_canon(wires[(size_t)col * SW + il]);
+      out5[q] = gl_canon(wires[(size_t)(col + 1) * SW + il]);
+      mu5[q] = gl_canon(wires[(size_t)(col + 2) * SW + il]);
+    }
+#pragma unroll
+    for (int q = 0; q < 7; ++q) {
+      const int s2 = poly * 7 + q;
+      const int col = s2 < 40 ? 2 * s2 : 0;
+      in7[q] = gl_canon(wires[(size_t)col * SW + il]);
+      out7[q] = gl_canon(wires[(size_t)(col + 1) * SW + il]);
+    }
+#pragma unroll
+    for (int ch = 0; ch < VX_MAX_CHALLENGES; ++ch) {
+      if (ch >= p.nch) break;
+      const u64 da = p.deltas[ch][0], dalpha = p.deltas[ch][2];
+      const u64* zl = zl0 + (size_t)ch * zstride;
+      PSnode L5[5], L7[7];
+#pragma unroll
+      for (int q = 0; q < 5; ++q) {
+        const bool on = poly * 5 + q < 26;
+        L5[q].P = on ? gl_sub(dalpha, gl_canon(gl_mad_nc(da, out5[q], in5[q]))) : 1;
+        L5[q].S = on ? mu5[q] : 0;
+        if (on) {   // the RE row transition's dot product rides on the same loads
+          dot3_mac(re_acc[ch], in5[q], x.re_in[ch][poly * 5 + q]);
+          dot3_mac(re_acc[ch], out5[q], x.re_out[ch][poly * 5 + q]);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 7; ++q) {
+        const bool on = poly * 7 + q < 40;
+        L7[q].P = on ? gl_sub(dalpha, gl_canon(gl_mad_nc(da, out7[q], in7[q]))) : 1;
+        L7[q].S = on ? 1 : 0;
+      }
+      const PSnode t5 = ps_merge(ps_merge(ps_merge(L5[0], L5[1]), ps_merge(L5[2], L5[3])), L5[4]);
+      // unweighted leaves: (f1, w1) + (f2, w2) = (f1 f2, w1 f2 + w2 f1) with w in {0, 1} — the looking slots' "off" members only occur
+      // in the last group, so the general merge is used there as well (neutral members cost what real ones do)
+      const PSnode a = ps_merge(L7[0], L7[1]), b = ps_merge(L7[2], L7[3]), cc = ps_merge(L7[4], L7[5]);
+      const PSnode t7 = ps_merge(ps_merge(a, b), ps_merge(cc, L7[6]));
+      const u64 prev = poly == 0 ? zl[(size_t)NSL * SW + il_next] : zl[(size_t)poly * SW + il];
+      const u64 d = gl_sub(gl_canon(zl[(size_t)(poly + 1) * SW + il]), gl_canon(prev));
+      const int idx = p.base_idx + ch * T + 4 + p.num_luts + 2 * poly;
+      push(0, gl_sub(gl_canon(gl_mul_nc(t5.P, d)), gl_canon(t5.S)), idx);          // Sum transition  (x TransSre)
+      push(1, gl_add(gl_canon(gl_mul_nc(t7.P, d)), gl_canon(t7.S)), idx + 1);      // LDC transition  (x TransLdc)
+    }
+  }
+  u64 sel[4 + VX_MAX_LUTS];
+  for (int q = 0; q < 4 + p.num_luts; ++q) sel[q] = p.cs[(size_t)(p.sel_base + q) * N + i];
+#pragma unroll
+  for (int ch = 0; ch < VX_MAX_CHALLENGES; ++ch) {
+    if (ch >= p.nch) break;
+    const u64* zl = zl0 + (size_t)ch * zstride;
+    const u64 z_re = gl_canon(zl[il]);
+    const int idx = p.base_idx + ch * T;
+    push(2, gl_mul_nc(sel[3], zl[(size_t)NSL * SW + il]), idx);          // LastLdc * SLDC_{last}
+    push(2, gl_mul_nc(sel[2], zl[(size_t)1 * SW + il]), idx + 1);        // InitSre * SLDC_0
+    push(2, gl_mul_nc(sel[2], z_re), idx + 2);                           // InitSre * RE
+    for (int t = 0; t < p.num_luts; ++t) push(2, gl_mul_nc(sel[4 + t], gl_sub(z_re, p.lut_poly[ch][t])), idx + 3 + t);
+    const u64 cur = gl_canon(gl_mad_nc(zl[il_next], x.delta26[ch], dot3_reduce_nc(re_acc[ch])));
+    push(0, gl_sub(z_re, cur), idx + 3 + p.num_luts);                    // RE row transition (x TransSre)
+  }
+  const u64 zi = p.zh_inv[r];
+#pragma unroll
+  for (int c = 0; c < VX_MAX_CHALLENGES; ++c) {
+    if (c >= p.nch) break;
+    u64 tot = gl_mad_nc(sel[0], dot3_reduce_nc(acc[0][c]), dot3_reduce_nc(acc[2][c]));
+    tot = gl_mad(sel[1], dot3_reduce_nc(acc[1][c]), tot);
+    u64* o = p.out + (size_t)c * SW + il;
+    *o = gl_add(*o, gl_mul(tot, zi));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The lookup polynomials themselves (prover.rs::compute_lookup_polys), on the device since round 6.  For every challenge the
+// columns [RE, SLDC_0 .. SLDC_{k-1}] are zero outside the rows [last_lu_row, first_lut_row] of the table and, inside them,
+// recurrences that walk the rows DOWNWARDS:
+//   table rows    RE(row) = RE(row + 1) delta^slots + Horner_delta(input_s + b output_s),
+//                 SLDC_j(row) = S(row + 1) + sum_{groups <= j} sum_{s in group} multiplicity_s / (alpha - input_s - a output_s)
+//   looking rows  SLDC_j(row) = S(row + 1) - sum_{groups <= j} sum_{s in group} 1 / (alpha - input_s - a output_s)
+// with S(row) = SLDC_{k-1}(row), S(first_lut_row + 1) = 0.  The per-row parts (one batch inversion of the row's denominators,
+// the group sums, the row's Horner value) are independent: one thread per (row, challenge); the two recurrences across rows are a
+// suffix sum of the rows' totals (one workgroup: chunk sums, a scan of 1024 partials in LDS, the walk back) and an affine chain
+// over the table rows (one lane: a table has a handful of rows).  Rounds 3-5 gathered the rows to the host and ran all of this
+// there, with two stream synchronisations in the middle of every proof (2.6 ms at 2^19 rows).  A zero denominator
+// (probability 2^-64 per slot) contributes zero, as the host version's batch inversion did.
+// ------------------------------------------------------------------------------------------------
+struct LookupPolyParams {
+  const u64* wires;    // [nr][n] witness, natural rows
+  u64* dst;            // [nch * nlp][n]: the lookup columns of the zs batch (zeroed by the caller)
+  u64* gc;             // [nch][nsl][R] scratch: prefix sums of the group terms inside a row
+  u64* hrow;           // [nch][R] scratch: the row's Horner value (table rows)
+  size_t n;
+  int last_lu, last_lut, first_lut, R;
+  int nch, nsl, lu_slots, lut_slots, lu_deg, lut_deg;
+  u64 deltas[VX_MAX_CHALLENGES][4];
+  u64 delta_pow_slots[VX_MAX_CHALLENGES];   // delta^lut_slots
+};
+#define VX_LOOKUP_SLOTS_MAX 64
+__global__ __launch_bounds__(64) void lookup_poly_rows_kernel(LookupPolyParams p) {
+  const int t = blockIdx.x * 64 + threadIdx.x;
+  if (t >= p.R * p.nch) return;
+  const int ch = t / p.R, rr = t % p.R;
+  const size_t row = (size_t)p.last_lu + rr;
+  const bool table = (int)row >= p.last_lut;
+  const u64 da = p.deltas[ch][0], db = p.deltas[ch][1], dalpha = p.deltas[ch][2], ddelta = p.deltas[ch][3];
+  const int slots = table ? p.lut_slots : p.lu_slots, step = table ? 3 : 2, deg = table ? p.lut_deg : p.lu_deg;
+  auto Wv = [&](int col) { return gl_canon(p.wires[(size_t)col * p.n + row]); };
+  u64 den[VX_LOOKUP_SLOTS_MAX], pre[VX_LOOKUP_SLOTS_MAX];
+  u64 h = 0, acc = 1;
+  for (int s2 = 0; s2 < slots; ++s2) {
+    const u64 inp = Wv(step * s2), outp = Wv(step * s2 + 1);
+    den[s2] = gl_sub(dalpha, gl_mad(da, outp, inp));
+    if (table) h = gl_add(gl_mul(h, ddelta), gl_mad(db, outp, inp));
+    pre[s2] = acc;
+    if (den[s2]) acc = gl_mul(acc, den[s2]);
+  }
+  acc = gl_inv(acc);
+  for (int s2 = slots - 1; s2 >= 0; --s2) {   // Montgomery's trick backwards: den[s2] <- 1 / den[s2]
+    if (!den[s2]) continue;
+    const u64 inv = gl_mul(acc, pre[s2]);
+    acc = gl_mul(acc, den[s2]);
+    den[s2] = inv;
+  }
+  u64 run = 0;
+  for (int slot = 0; slot < p.nsl; ++slot) {
+    u64 g = 0;
+    for (int s2 = slot * deg; s2 < min((slot + 1) * deg, slots); ++s2) g = gl_add(g, table ? gl_mul(Wv(3 * s2 + 2), den[s2]) : den[s2]);
+    run = table ? gl_add(run, g) : gl_sub(run, g);
+    p.gc[((size_t)ch * p.nsl + slot) * p.R + rr] = run;
+  }
+  p.hrow[(size_t)ch * p.R + rr] = h;
+}
+__global__ __launch_bounds__(1024) void lookup_poly_scan_kernel(LookupPolyParams p) {
+  __shared__ u64 part[1024];
+  const int tid = threadIdx.x, ch = blockIdx.x;
+  const int nlp = p.nsl + 1, R = p.R;
+  const int chunk = (R + 1023) / 1024;
+  // rows are walked from the TOP (first_lut_row) down: position q = R - 1 - rr, thread tid owns q in [tid chunk, (tid + 1) chunk)
+  const u64* total = p.gc + ((size_t)ch * p.nsl + (p.nsl - 1)) * R;
+  u64 sum = 0;
+  for (int q = tid * chunk; q < min((tid + 1) * chunk, R); ++q) sum = gl_add(sum, total[R - 1 - q]);
+  part[tid] = sum;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {   // inclusive scan of the chunk sums
+    const u64 v = tid >= off ? part[tid - off] : 0;
+    __syncthreads();
+    part[tid] = gl_add(part[tid], v);
+    __syncthreads();
+  }
+  u64 carry = tid ? part[tid - 1] : 0;         // S(row + 1) of this thread's first row
+  for (int q = tid * chunk; q < min((tid + 1) * chunk, R); ++q) {
+    const int rr = R - 1 - q;
+    const size_t row = (size_t)p.last_lu + rr;
+    for (int slot = 0; slot < p.nsl; ++slot)
+      p.dst[((size_t)ch * nlp + slot + 1) * p.n + row] = gl_add(carry, p.gc[((size_t)ch * p.nsl + slot) * R + rr]);
+    carry = gl_add(carry, total[rr]);
+  }
+  if (tid == 0) {                              // RE down the table rows
+    u64 re = 0;
+    for (int row = p.first_lut; row >= p.last_lut; --row) {
+      re = gl_add(gl_mul(re, p.delta_pow_slots[ch]), p.hrow[(size_t)ch * R + (row - p.last_lu)]);
+      p.dst[((size_t)ch * nlp) * p.n + row] = re;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Constraint programs (include/vxprover.h VX_OP_*): gates outside the native set arrive as straight-line
 // programs over the row's wires / constants.  One thread per LDE row interprets the program — every lane
 // executes the same instruction, so fetch and decode are wave-uniform — and ADDS

@@ -720,7 +720,39 @@ static inline void batch_inverse(vxh::u64* v, size_t count, std::vector<vxh::u64
     v[i] = t;
   }
 }
-static int lookup_polys_to_device(vx_ctx* c, const vx_circuit* k, const u64* d_wires, const std::vector<u64>& deltas, u64* dst) {
+// the device version (plonk_kernels.hip.h lookup_poly_*_kernel): no copy to the host, no synchronisation; VX_LOOKUP_POLYS_HOST=1 keeps the
+// host recurrences of rounds 3-5 (cross-check, A/B)
+static int lookup_polys_host(vx_ctx* c, const vx_circuit* k, const u64* d_wires, const std::vector<u64>& deltas, u64* dst);
+static int lookup_polys_to_device(vx_ctx* c, const vx_circuit* k, const u64* d_wires, const std::vector<u64>& deltas, u64* dst, Scratch& S) {
+  using namespace vxh;
+  const size_t n = k->n();
+  const int nch = k->nch, nlp = k->nlp(), nsl = nlp - 1;
+  const int lu_slots = k->nr / 2, lut_slots = k->nr / 3, lu_deg = k->qdf - 1, lut_deg = (lut_slots + nsl - 1) / nsl;
+  static const bool on_host = getenv("VX_LOOKUP_POLYS_HOST") != nullptr;
+  if (on_host || lu_slots > VX_LOOKUP_SLOTS_MAX || lut_slots > VX_LOOKUP_SLOTS_MAX) return lookup_polys_host(c, k, d_wires, deltas, dst);
+  HIPCHK(hipMemsetAsync(dst, 0, (size_t)nch * nlp * n * 8, c->stream));
+  ProfScope ps(c, "lookup_polys");
+  for (int t = 0; t < k->num_luts; ++t) {
+    LookupPolyParams lp;
+    memset(&lp, 0, sizeof lp);
+    lp.wires = d_wires, lp.dst = dst, lp.n = n;
+    lp.last_lu = k->lookup_rows[3 * t], lp.last_lut = k->lookup_rows[3 * t + 1], lp.first_lut = k->lookup_rows[3 * t + 2];
+    lp.R = lp.first_lut - lp.last_lu + 1;
+    lp.nch = nch, lp.nsl = nsl, lp.lu_slots = lu_slots, lp.lut_slots = lut_slots, lp.lu_deg = lu_deg, lp.lut_deg = lut_deg;
+    for (int cI = 0; cI < nch; ++cI) {
+      for (int q = 0; q < 4; ++q) lp.deltas[cI][q] = deltas[4 * cI + q];
+      lp.delta_pow_slots[cI] = pow(deltas[4 * cI + 3], (u64)lut_slots);
+    }
+    lp.gc = S.get((size_t)nch * nsl * lp.R);
+    lp.hrow = S.get((size_t)nch * lp.R);
+    if (!lp.gc || !lp.hrow) return vx_fail(VX_E_NOMEM, "prove: out of device memory (lookup polynomials)");
+    hipLaunchKernelGGL(lookup_poly_rows_kernel, dim3((unsigned)(((size_t)lp.R * nch + 63) / 64)), dim3(64), 0, c->stream, lp);
+    hipLaunchKernelGGL(lookup_poly_scan_kernel, dim3((unsigned)nch), dim3(1024), 0, c->stream, lp);
+    HIPCHK(hipGetLastError());
+  }
+  return VX_OK;
+}
+static int lookup_polys_host(vx_ctx* c, const vx_circuit* k, const u64* d_wires, const std::vector<u64>& deltas, u64* dst) {
   using namespace vxh;
   std::vector<u64> inv_scratch;
   const size_t n = k->n();
@@ -889,7 +921,7 @@ static int prove_impl(vx_ctx* c, vx_circuit* k, const u64* wires_in, bool wires_
       hipLaunchKernelGGL(perm_write_kernel, dim3((unsigned)nblocks, nch), dim3(256), 0, c->stream, cp, n, nchunks, nch, bp, zs_vals);
       HIPCHK(hipGetLastError());
     }
-    if (k->num_luts > 0) VXCHK(lookup_polys_to_device(c, k, d_wires, deltas, zs_vals + (size_t)nch * (1 + npp) * n));
+    if (k->num_luts > 0) VXCHK(lookup_polys_to_device(c, k, d_wires, deltas, zs_vals + (size_t)nch * (1 + npp) * n, S));
     VXCHK(batch_alloc(c, lg, (size_t)nch * (1 + npp) + nlook, rb, k->cap_height, &zs_b, sh.rank, sh.lg));
     VXCHK(batch_commit_device(c, zs_b, zs_vals, n, false));
   }
@@ -1010,7 +1042,32 @@ static int prove_impl(vx_ctx* c, vx_circuit* k, const u64* wires_in, bool wires_
         }
         for (int r = 0; r < rate; ++r) lp.zh_inv[r] = qp.zh_inv[r];
         ProfScope psl(c, "quotient_lookup_terms");
-        if (lp.nlp == 7 && lp.lut_slots == 26 && lp.lu_slots == 40 && lp.lut_deg == 5 && lp.lu_deg == 7)   // standard_recursion_config
+        static const bool terms_v1 = getenv("VX_LOOKUP_TERMS_V1") != nullptr;   // rounds 3-5's form of the static kernel (A/B, cross-check)
+        if (lp.nlp == 7 && lp.lut_slots == 26 && lp.lu_slots == 40 && lp.lut_deg == 5 && lp.lu_deg == 7 && !terms_v1) {   // standard_recursion_config
+          LookupStaticExtra lx;
+          memset(&lx, 0, sizeof lx);
+          lx.alpha_limbs = qp.alpha_limbs;
+          auto limbs_of = [](u64 bb) {
+            Limbs3x2 t;
+            const u64 bh = mul(bb, (u64)1 << 32);
+            t.lo[0] = (u32)(bb & 0x3FFFFFu), t.lo[1] = (u32)((bb >> 22) & 0x3FFFFFu), t.lo[2] = (u32)(bb >> 44);
+            t.hi[0] = (u32)(bh & 0x3FFFFFu), t.hi[1] = (u32)((bh >> 22) & 0x3FFFFFu), t.hi[2] = (u32)(bh >> 44);
+            return t;
+          };
+          for (int cI = 0; cI < nch; ++cI) {
+            const u64 db = deltas[4 * cI + 1], dd = deltas[4 * cI + 3];
+            u64 pw = 1;
+            for (int sl = 25; sl >= 0; --sl) {   // slot sl meets delta^(25 - sl)
+              lx.re_in[cI][sl] = limbs_of(pw);
+              lx.re_out[cI][sl] = limbs_of(mul(db, pw));
+              pw = mul(pw, dd);
+            }
+            lx.delta26[cI] = pw;
+          }
+          static const int wps = getenv("VX_LOOKUP_WPS") ? atoi(getenv("VX_LOOKUP_WPS")) : 3;   // waves per SIMD the kernel is compiled for: 3 = 168 VGPRs, no spills (0.87 ms at 2^18 rows); 4 = 128 VGPRs, 44 spills (1.08 ms)
+          if (wps != 4) hipLaunchKernelGGL(lookup_terms_static_kernel<3>, dim3((unsigned)((Nl + 255) / 256)), dim3(256), 0, c->stream, lp, lx);
+          else hipLaunchKernelGGL(lookup_terms_static_kernel<4>, dim3((unsigned)((Nl + 255) / 256)), dim3(256), 0, c->stream, lp, lx);
+        } else if (lp.nlp == 7 && lp.lut_slots == 26 && lp.lu_slots == 40 && lp.lut_deg == 5 && lp.lu_deg == 7)
           hipLaunchKernelGGL(lookup_terms_kernel<true>, dim3((unsigned)((Nl + 255) / 256)), dim3(256), 0, c->stream, lp);
         else
           hipLaunchKernelGGL(lookup_terms_kernel<false>, dim3((unsigned)((Nl + 255) / 256)), dim3(256), 0, c->stream, lp);

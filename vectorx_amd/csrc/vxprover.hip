@@ -8,6 +8,9 @@
 #include <mutex>
 #include <fcntl.h>
 #include <sys/file.h>
+#include <sys/stat.h>
+#include <errno.h>
+#include <thread>
 #include <unistd.h>
 #include "plonk_kernels.hip.h"
 #include "aux.hip.h"
@@ -570,27 +573,43 @@ int vx_hash_rows_dev(vx_ctx* c, const uint64_t* cols, size_t col_stride, size_t 
 // One rehearsal proof of an all-zero witness (discarded; the two "witness does not satisfy the circuit" checks are off): every device
 // buffer shape a proof of this circuit asks the pool for is allocated once and cached, the circuit's program-gate kernels are loaded,
 // the twiddle / scale tables of its sizes exist — so that the FIRST real proof costs what every later one does (round 3 measured 250 ms
-// instead of 57 for the first 2^19-row proof on some boxes: first-use hipMallocs).  Circuits with lookup tables are skipped (their host
-// recurrences divide by witness-dependent values).
+// instead of 57 for the first 2^19-row proof on some boxes: first-use hipMallocs).  Circuits with lookup tables are rehearsed too since
+// round 6 (the lookup polynomials are computed on the device and a zero denominator contributes zero; rounds 3-5 skipped them, which
+// left the first pass of a DAG of recursion-shaped circuits 1.2 s slower than the later ones).
 int vx_circuit_warm(vx_ctx* c, vx_circuit* k) {
   if (!c || !k) return vx_fail(VX_E_INVALID, "vx_circuit_warm: NULL argument");
   if (k->ctx != c) return vx_fail(VX_E_INVALID, "vx_circuit_warm: circuit belongs to a different context");
-  if (k->num_luts > 0) return VX_OK;
   HIPCHK(hipSetDevice(c->device));
   // Several processes (the DAG's worker pool, ranks emulated on one device) and several contexts of one process load circuits on the same
   // device at the same time; each would see the same free memory below and then all allocate.  One rehearsal at a time per device: an
   // advisory file lock for the other processes, a mutex for this one's threads (both best effort: a rehearsal is an optimisation).
-  static std::mutex warm_mutex;
-  std::lock_guard<std::mutex> in_process(warm_mutex);
+  // Both waits are BOUNDED (VX_WARM_LOCK_TIMEOUT_S, default 120 s): a worker that hangs inside its rehearsal must not block every other
+  // process's vx_circuit_create on that device for ever — after the wait the rehearsal is skipped, which costs the first proof some
+  // hipMallocs and nothing else.  The mutex is per device; the lock file lives in a directory of this user (mode 0700, no symlink followed).
+  const char* te = getenv("VX_WARM_LOCK_TIMEOUT_S");
+  const double wait_s = te && atof(te) >= 0 ? atof(te) : 120.0;
+  const auto deadline = std::chrono::steady_clock::now() + std::chrono::duration_cast<std::chrono::steady_clock::duration>(std::chrono::duration<double>(wait_s));
+  static std::timed_mutex warm_mutex[16];
+  std::unique_lock<std::timed_mutex> in_process(warm_mutex[(unsigned)c->device % 16], std::defer_lock);
+  if (!in_process.try_lock_until(deadline)) return VX_OK;
   struct FileLock {
     int fd = -1;
-    explicit FileLock(int device) {
-      char path[64];
-      snprintf(path, sizeof path, "/tmp/vxprover_warm_dev%d.lock", device);
-      fd = open(path, O_CREAT | O_RDWR, 0666);
-      if (fd >= 0 && flock(fd, LOCK_EX) != 0) {
-        close(fd);
-        fd = -1;
+    bool timed_out = false;
+    FileLock(int device, std::chrono::steady_clock::time_point until) {
+      char dir[256], path[320];
+      const char* rt = getenv("XDG_RUNTIME_DIR");
+      if (rt && *rt) snprintf(dir, sizeof dir, "%s/vxprover", rt);
+      else snprintf(dir, sizeof dir, "/tmp/vxprover-%u", (unsigned)geteuid());
+      struct stat st;
+      if (mkdir(dir, 0700) != 0 && errno != EEXIST) return;                      // no lock directory: rehearse unlocked (best effort)
+      if (lstat(dir, &st) != 0 || !S_ISDIR(st.st_mode) || st.st_uid != geteuid() || (st.st_mode & 0077)) return;
+      snprintf(path, sizeof path, "%s/warm_dev%d.lock", dir, device);
+      fd = open(path, O_CREAT | O_RDWR | O_NOFOLLOW | O_CLOEXEC, 0600);
+      if (fd < 0) return;
+      while (flock(fd, LOCK_EX | LOCK_NB) != 0) {
+        if (errno != EWOULDBLOCK && errno != EINTR) { close(fd); fd = -1; return; }
+        if (std::chrono::steady_clock::now() >= until) { close(fd); fd = -1; timed_out = true; return; }
+        std::this_thread::sleep_for(std::chrono::milliseconds(20));
       }
     }
     ~FileLock() {
@@ -599,7 +618,8 @@ int vx_circuit_warm(vx_ctx* c, vx_circuit* k) {
         close(fd);
       }
     }
-  } across_processes(c->device);
+  } across_processes(c->device, deadline);
+  if (across_processes.timed_out) return VX_OK;
   {
     // a proof's working set is about 8 N (wires + Z / partial products + quotient chunks) for the LDEs plus trees, coefficients and
     // scratch: rehearse only when twice a generous estimate is free — a host that packs many contexts onto one device (the

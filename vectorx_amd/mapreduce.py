@@ -358,8 +358,16 @@ class GpuProver:
         circuit_seed = {"map": 101, "reduce": 202, "outer": 303, "rotate": 404}[kind]
         shape = circuit_shape(recursion)
         self.recursion = bool(recursion)
+        import os
+        trace = os.environ.get("VX_POOL_TRACE")
+        t_ = time.perf_counter()
         self.sc = SynthCircuit(log_n, seed=circuit_seed, poseidon_percent=poseidon_percent, witness_seed=0, **shape)
+        t1_ = time.perf_counter()
         self.circuits = [vx.Circuit(c, self.sc.desc_ptr) for c in self.lanes]
+        if trace:
+            import sys
+            print(f"[vx pool {os.getpid()}] {kind}: circuit generated in {t1_ - t_:.2f} s, loaded on {len(self.lanes)} lanes in {time.perf_counter() - t1_:.2f} s",
+                  file=sys.stderr, flush=True)
         self.circuit = self.circuits[0]
         self.wit = {}
         self.distinct = distinct_witnesses
@@ -385,6 +393,8 @@ class GpuProver:
                     self.lane_wit[li_].append(d)
                 sj.free()
         self.sc.release_host_buffers(witness=True, preprocessed=True)
+        if trace:
+            print(f"[vx pool {os.getpid()}] {kind}: witnesses ready {time.perf_counter() - t_:.2f} s after the start", file=sys.stderr, flush=True)
 
     def prove(self, key, public_inputs, lane=0, input_seed=b"", spent_out=None, with_tables=True, children=()):
         d = self.wit[key] if self.distinct is None else self.lane_wit[lane][key[1] % self.distinct]
