@@ -62,8 +62,10 @@ def parse():
                     help="STARK tables of the DAG: per_job = every job's own inputs, traces generated on the GPU inside the clock; resident = one host-generated trace per table kind (rounds 3-4)")
     ap.add_argument("--extra-legs-deadline", type=float, default=1500.0,
                     help="seconds the legs AFTER the contract's line may take at N = 1 before the process prints what it has and exits")
-    ap.add_argument("--cpu-baseline-full", action="store_true",
-                    help="cpu_baseline: ALSO prove the full-size circuit once with the oracle (minutes of CPU) and record it (profiles/r05_cpu_full_size.json holds such a run)")
+    ap.add_argument("--cpu-baseline-full", action="store_true", help="(default since round 6; kept so that older command lines still parse)")
+    ap.add_argument("--no-cpu-baseline-full", action="store_true",
+                    help="cpu_baseline: only the bounded sample (2^18 rows, scaled); by default the N = 1 run ALSO proves the bench circuit itself once "
+                         "with the oracle — ~4 min of host cores after every GPU leg — and `cpu_baseline.value` is that measured figure")
     ap.add_argument("--no-chip-leg", action="store_true",
                     help="skip the extra leg that proves the three chip-sized STARK tables (SHA-256, BLAKE2b, Ed25519 scalar multiplication; SURVEY §8 f-3)")
     ap.add_argument("--circuit-flags", type=int, default=0,
@@ -381,12 +383,27 @@ def main():
     state = {"printed": False}
 
     def emit_line(extra=None):
+        """ONE line on stdout: the compact form (every number, no prose — the driver's record keeps the last 8 KB of stdout; the
+        descriptions of the fields are in profiles/bench_line_glossary.md).  The complete line of the same run, prose included, goes to
+        bench_line_full.json (in gpurun_out/ when that exists)."""
         with line_lock:
             if rank == 0 and not state["printed"]:
                 d = dict(out)
+                try:
+                    d.update(dict(legs))      # whatever legs are complete by now (the watchdog / SIGTERM paths print before the merge below)
+                except NameError:
+                    pass
                 if extra:
                     d.update(extra)
-                print(json.dumps(d), flush=True)
+                try:
+                    import bench_prove as bp
+                    side = Path("gpurun_out") if Path("gpurun_out").is_dir() else Path(".")
+                    (side / "bench_line_full.json").write_text(json.dumps(d))
+                    line = json.dumps(bp.compact_line(d))
+                except Exception as e:   # noqa: BLE001 — the line goes out whatever happens to its short form
+                    d["compact_line_error"] = repr(e)
+                    line = json.dumps(d)
+                print(line, flush=True)
             state["printed"] = True
 
     def give_up(why):
@@ -415,7 +432,12 @@ def main():
     sig_thread.start()
 
     legs = {}
+    t_legs = time.perf_counter()
     single = args.workload == "prove" and world == 1 and args.log_n >= 20 and not args.circuit_flags
+    mr_spec = None
+    if single and not args.no_dag_leg:
+        from vectorx_amd import mapreduce as _mr
+        mr_spec = _mr.DagSpec(*(int(x) for x in args.dag_spec.split(",")))
 
     def leg(name, fn):
         try:
@@ -441,6 +463,24 @@ def main():
         leg("chip_starks", lambda: bench_prove.chip_leg(ctx))
     if single and not args.no_rotate_leg:
         leg("rotate", lambda: bench_prove.rotate_leg(ctx, local_rank))
+    if single and not args.no_dag_leg:
+        # the DAG's three circuit sizes proven alone, recursion-shaped gate mix: ms per proof and the quotient by kernel / by gate
+        leg("recursion_circuits_alone", lambda: bench_prove.recursion_profile_leg(ctx, mr_spec))
+    if single and not args.no_cpu_baseline and not args.no_cpu_baseline_full and "cpu_baseline" in out:
+        # LAST: the CPU baseline measured at the bench size, no scaling (~4 min of host cores; the GPU idles).  A child process: whatever
+        # happens to it, the line goes out — with the bounded sample's figure if this one is missing.
+        try:
+            left = max(60.0, deadline - (time.perf_counter() - t_legs) - 30.0)
+            full = bench_prove.cpu_baseline_full(args, timeout_s=left)
+            cb = out["cpu_baseline"]
+            sampled = {k: cb[k] for k in ("value", "seconds", "log_n", "stages_s") if k in cb}
+            sampled["scaled_by"] = 1 << (args.log_n - cb.get("log_n", args.log_n))
+            cb.update({"value": full["value"], "seconds": full["seconds"], "log_n": full["log_n"], "stages_s": full["stages_s"],
+                       "cores": full["cores"], "proof_sha256": full["proof_sha256"], "sample": "measured in this run, no scaling",
+                       "measured_in_this_run": True, "sampled": sampled})
+        except Exception as e:   # noqa: BLE001
+            out["cpu_baseline"]["full_size_error"] = repr(e)[:200]
+            out["cpu_baseline"]["measured_in_this_run"] = False
 
     sharded_leg = dag_n_leg = dag_n_stark_leg = None
     if multi:

@@ -1,8 +1,13 @@
 """Whole-proof workload for bench.py: one step = one vx_prove of a header_range_512-shaped synthetic circuit
 (BASELINE.json configs[2]: 2^21 rows, 135 wires, blow-up 8, full FRI) with the witness already in HBM."""
+import sys
 import time
+from pathlib import Path
 
 import numpy as np
+
+if str(Path(__file__).resolve().parent) not in sys.path:      # run as a script (the CPU baseline's child process)
+    sys.path.insert(0, str(Path(__file__).resolve().parent))
 
 
 def make_step(ctx, args, rank, dist=None, device=None):
@@ -41,10 +46,10 @@ def make_step(ctx, args, rank, dist=None, device=None):
     _LEG["circuit"], _LEG["d_w"] = circuit, d_w
     metric = "header_range_512 proofs/sec"
     unit = "proofs/sec"
-    wl = (f"header_range_512 stand-in: one plonky2 proof of a synthetic standard_recursion_config circuit, n=2^{args.log_n} rows x 135 wires "
-          f"(80 routed), blowup 8, cap_height 4, FRI arity 16 / 28 queries / 16 PoW bits; gate rows: {counts['poseidon']} PoseidonGate, "
-          f"{counts['arithmetic']} ArithmeticGate(20 ops), {counts['noop']} NoopGate, 1 PublicInputGate, 1 ConstantGate "
-          f"(the real 64 map + 63 reduce + 1 outer proof DAG and its gate mix need the Rust circuit builder: SURVEY.md §0.7)")
+    pct = lambda k: round(100.0 * counts[k] / (1 << args.log_n))   # noqa: E731
+    wl = (f"header_range_512 stand-in (BASELINE configs[2]): one plonky2 proof, n=2^{args.log_n} rows x 135 wires, blow-up 8, cap height 4, "
+          f"FRI arity 16 / 28 queries / 16 PoW bits; synthetic circuit {pct('poseidon')}% PoseidonGate / {pct('arithmetic')}% ArithmeticGate rows"
+          + (f", circuit flags {args.circuit_flags}" if getattr(args, "circuit_flags", 0) else ""))
     def cleanup():
         circuit.free()
         ctx.free(d_w)
@@ -485,14 +490,15 @@ def chip_leg(ctx):
     if "VX_JIT_CACHE_DIR" not in os.environ and cache.is_dir():
         os.environ["VX_JIT_CACHE_DIR"] = str(cache)
     out = {"what": "own AIRs, not Curta's; rate_bits 1, 84 queries, 16 PoW bits; lone proofs, trace resident in HBM, second-round columns computed "
-                   "on the GPU inside every proof, the transcript takes the tree hash of the openings computed on the device "
-                   "(VX_STARK_OPENINGS_DIGEST); NOT the contract's timed region"}
+                   "on the GPU inside every proof, starky's transcript order (the opening set absorbed element by element; "
+                   "`ms_per_proof_openings_digest` = the same table under this library's tree-hash variant VX_STARK_OPENINGS_DIGEST); NOT the contract's timed region",
+           "openings_digest": 0}
     rng = np.random.default_rng(5)
     cases = [("sha256", "sha256", sha256_air, 13, 60, 64), ("sha512", "sha512", sha512_air, 13, 48, 117),
              ("blake2b_bytes", "blake2b", blake2b_bytes_air, 16, 8, 128 * 280)]
     for name, which, air, log_n, nmsg, mlen in cases:
         msgs = [rng.integers(0, 256, size=mlen, dtype=np.uint8).tobytes() for _ in range(nmsg)]
-        stark = air.make_stark(log_n, openings_digest=True)
+        stark = air.make_stark(log_n)
         ncols = stark.desc.num_columns
         d = ctx.alloc(ncols * (1 << log_n) * 8)
         ctx.trace_hash_table(which, log_n, msgs, d)            # warm
@@ -503,11 +509,15 @@ def chip_leg(ctx):
         out[name] = {"ms_per_proof": round(r["ms_per_proof"], 3), "rows_log2": log_n, "columns": r["columns"], "messages": nmsg,
                      "trace_generation_ms_gpu": round(gen_ms, 3), "trace_GB": round(ncols * (1 << log_n) * 8 / 1e9, 3),
                      "stage_ms_per_proof": r["stage_ms_per_proof"], "proof_bytes": r["proof_bytes"], "evaluator": r["evaluator"]}
+        d2 = ctx.alloc(ncols * (1 << log_n) * 8)               # (a ResidentTable owns and frees the trace it is given)
+        ctx.trace_hash_table(which, log_n, msgs, d2)
+        rd = stark_chips.bench_table(ctx, air.make_stark(log_n, openings_digest=True), None, pis, name, steps=3, warmup=1, d_trace=d2)
+        out[name]["ms_per_proof_openings_digest"] = round(rd["ms_per_proof"], 3)
     lay = eddsa_air.Layout(full=True)                          # signatures from their bytes: decompression, digest mod L, S < L in the table
     log_n = 17
     cap = eddsa_air.capacity(lay, log_n)
     sigs, rs = stark_chips.eddsa_signatures_full(cap, 2)
-    stark = eddsa_air.make_stark(lay, log_n, openings_digest=True)
+    stark = eddsa_air.make_stark(lay, log_n)
     d = ctx.alloc(lay.N * (1 << log_n) * 8)
     ctx.trace_eddsa_table(log_n, lay.NB, sigs, d, full=True)   # warm
     t0 = time.perf_counter()
@@ -518,6 +528,10 @@ def chip_leg(ctx):
     out["eddsa"] = {"ms_per_proof": round(r["ms_per_proof"], 3), "rows_log2": log_n, "columns": r["columns"], "signatures": cap, "program": "full (encodings, S, digest in; decompression, digest mod L, S < L inside the table)",
                     "trace_generation_ms_gpu": round(gen_ms, 3), "trace_GB": round(lay.N * (1 << log_n) * 8 / 1e9, 3),
                     "stage_ms_per_proof": r["stage_ms_per_proof"], "proof_bytes": r["proof_bytes"], "evaluator": r["evaluator"]}
+    d2 = ctx.alloc(lay.N * (1 << log_n) * 8)
+    ctx.trace_eddsa_table(log_n, lay.NB, sigs, d2, full=True)
+    rd = stark_chips.bench_table(ctx, eddsa_air.make_stark(lay, log_n, openings_digest=True), None, np.zeros(0, dtype=np.uint64), "eddsa", steps=3, warmup=1, d_trace=d2)
+    out["eddsa"]["ms_per_proof_openings_digest"] = round(rd["ms_per_proof"], 3)
     return out
 
 
@@ -555,40 +569,189 @@ def cpu_baseline(args):
     scale = float(1 << (args.log_n - s_log))
     out = {
         "value": 1.0 / (dt * scale), "unit": "proofs/sec", "cores": cores, "kind": "port",
-        "sample": (f"oracle prove() of the same synthetic circuit family at 2^{s_log} rows took {dt:.2f} s on {cores} OpenMP threads "
-                   f"(stages s: {', '.join(f'{k}={v:.2f}' for k, v in tm.items())}); scaled x{int(scale)} (linear in rows) to 2^{args.log_n}"),
+        "sample": f"oracle prove() at 2^{s_log} rows in {dt:.2f} s, scaled x{int(scale)} (linear in rows) to 2^{args.log_n}",
     }
     sc.free()
-    # The full-size figure, MEASURED (no scaling): run here with --cpu-baseline-full (minutes of CPU), else quoted from the record of such a
-    # run on a GPU box of this pool (profiles/r05_cpu_full_size.json, written by this very code path) — clearly marked as a citation.
-    import json
-    from pathlib import Path
-    rec_path = Path(__file__).resolve().parent / "profiles" / "r05_cpu_full_size.json"
-    if getattr(args, "cpu_baseline_full", False):
-        scf = SynthCircuit(args.log_n, seed=0x5EED0000, poseidon_percent=args.poseidon_percent)
-        ocf = oracle_lib.OracleCircuit(oracle, scf.desc_ptr)
-        t0 = time.perf_counter()
-        proof, tmf = ocf.prove(scf.witness(), want_timings=True)
-        dtf = time.perf_counter() - t0
-        full = {"value": 1.0 / dtf, "unit": "proofs/sec", "seconds": round(dtf, 2), "cores": cores, "kind": "port", "log_n": args.log_n,
-                "stages_s": {k: round(v, 2) for k, v in tmf.items()}, "measured": "in this run", "proof_sha256": __import__("hashlib").sha256(proof).hexdigest()}
-        out["full_size_measured"] = full
-        out["value_bounded_sample_scaled"] = out["value"]
-        out["value"] = full["value"]
-        out["sample"] = f"oracle prove() of the bench circuit itself at 2^{args.log_n} rows: {dtf:.1f} s on {cores} OpenMP threads, measured in this run (no scaling); " + out["sample"]
-        try:
-            import os
-            os.makedirs("gpurun_out", exist_ok=True)
-            Path("gpurun_out/cpu_full_size.json").write_text(json.dumps(full))
-        except Exception:
-            pass
-        scf.free()
-    elif rec_path.exists():
-        try:
-            full = json.loads(rec_path.read_text())
-            if full.get("log_n") == args.log_n:
-                full["measured"] = "earlier run on a GPU box of this pool (profiles/r05_cpu_full_size.json): a citation, not this run's clock"
-                out["full_size_measured"] = full
-        except Exception:
-            pass
+    out["seconds"] = round(dt, 2)
+    out["log_n"] = s_log
+    out["stages_s"] = {k: round(v, 2) for k, v in tm.items()}
     return out
+
+
+QUOTIENT_NESTED = ("quotient_l0_permutation", "quotient_small_native_gates", "quotient_poseidon_gate", "quotient_lookup_terms",
+                   "quotient_program_gates_jit", "quotient_program_gates")     # stages bracketed INSIDE quotient_eval
+
+
+def lone_proof_profile(ctx, log_n: int, recursion: bool, steps: int = 10, per_gate: bool = False) -> dict:
+    """One circuit of the DAG's family at 2^log_n rows proven `steps` times on its own: wall ms per proof and the HIP-event stage times, the
+    quotient split by kernel (`quotient_by_kernel_ms`); per_gate: the program gates as one kernel each (VX_JIT_FUSED=0 for this circuit
+    only) so that every gate has its own time (`quotient_by_gate_ms`, by gate name)."""
+    import os
+    import vectorx_amd as vx
+    from vectorx_amd.mapreduce import circuit_shape
+    from vectorx_amd.synth import SynthCircuit
+    sc = SynthCircuit(log_n, seed=202, poseidon_percent=50, witness_seed=1, **circuit_shape(recursion))
+    old = os.environ.get("VX_JIT_FUSED")
+    if per_gate:
+        os.environ["VX_JIT_FUSED"] = "0"
+    try:
+        circuit = vx.Circuit(ctx, sc.desc_ptr)
+    finally:
+        if per_gate:
+            if old is None:
+                os.environ.pop("VX_JIT_FUSED", None)
+            else:
+                os.environ["VX_JIT_FUSED"] = old
+    w = sc.witness()
+    d_w = ctx.alloc(w.nbytes)
+    ctx.upload(d_w, w)
+    for _ in range(2):
+        circuit.prove(dev_ptr=d_w)
+    ctx.prof_enable(True)
+    ctx.prof_reset()
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        circuit.prove(dev_ptr=d_w)
+    ctx.sync()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    prof = ctx.prof()
+    ctx.prof_enable(False)
+    stages = {k: round(v["ms"] / steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
+    names = sc.gate_names()
+    by_gate = {"+".join(names[int(g)] for g in k[6:].split("+")): v for k, v in stages.items() if k.startswith("qgate_")}
+    top = {k: v for k, v in stages.items() if not k.startswith("qgate_") and k not in QUOTIENT_NESTED}
+    rec = {"log_n": log_n, "recursion_mix": bool(recursion), "ms_per_proof": round(ms, 3), "kernel_ms": round(sum(top.values()), 3),
+           "quotient_eval_ms": stages.get("quotient_eval"),
+           "quotient_by_kernel_ms": {k[len("quotient_"):]: stages[k] for k in QUOTIENT_NESTED if k in stages},
+           "stage_ms": top}
+    if by_gate:
+        rec["quotient_by_gate_ms"] = by_gate
+    if recursion:
+        rec["gate_rows"] = sc.gate_rows()
+    circuit.free()
+    ctx.free(d_w)
+    sc.free()
+    return rec
+
+
+def recursion_profile_leg(ctx, spec=None) -> dict:
+    """The DAG's three circuit sizes proven alone with the recursion-shaped gate mix: what a job costs outside the saturated pool, and where
+    the quotient's time goes kernel by kernel (VERDICT r5 #1: `quotient_eval` by kernel; per gate at the map size)."""
+    from vectorx_amd import mapreduce as mr
+    spec = spec or mr.DagSpec()
+    out = {}
+    for kind in ("reduce", "map", "outer"):
+        r = lone_proof_profile(ctx, spec.log_n(kind), True, steps=10)
+        out[kind] = {"log_n": r["log_n"], "ms_per_proof": r["ms_per_proof"], "quotient_eval_ms": r["quotient_eval_ms"],
+                     "quotient_by_kernel_ms": r["quotient_by_kernel_ms"], "hash_leaves_ms": r["stage_ms"].get("hash_leaves"),
+                     "lde_ms": r["stage_ms"].get("lde"), "merkle_levels_ms": r["stage_ms"].get("merkle_levels")}
+        base = lone_proof_profile(ctx, spec.log_n(kind), False, steps=10)
+        out[kind]["ms_per_proof_two_gate_stand_in"] = base["ms_per_proof"]
+    g = lone_proof_profile(ctx, spec.map_log_n, True, steps=5, per_gate=True)
+    out["map_quotient_by_gate_ms_one_kernel_per_gate"] = g.get("quotient_by_gate_ms")
+    out["gate_rows_map"] = g.get("gate_rows")
+    return out
+
+
+def cpu_baseline_full(args, timeout_s: float = 900.0) -> dict:
+    """The CPU baseline MEASURED at the bench size, no scaling (VERDICT r5 #2): the oracle proves the bench circuit itself — same generator
+    seed, 2^log_n rows — once, on all host cores, in a CHILD process (an out-of-memory kill or a hang there costs this record, never the
+    bench line) while the GPU idles.  -> {"value", "seconds", "cores", "log_n", "stages_s", "proof_sha256"}"""
+    import json
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, str(Path(__file__).resolve()), "--cpu-full-child", str(args.log_n), str(args.poseidon_percent)],
+                       capture_output=True, text=True, timeout=timeout_s)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not lines:
+        raise RuntimeError(f"the CPU child ended with code {r.returncode}: {r.stderr[-300:]}")
+    return json.loads(lines[-1])
+
+
+def _cpu_full_child(log_n: int, pct: int) -> None:
+    import hashlib
+    import json
+    sys.path.insert(0, str(Path(__file__).resolve().parent / "tests"))
+    import oracle_lib
+    from vectorx_amd.synth import SynthCircuit
+    oracle = oracle_lib.load()
+    cores = usable_cores()
+    oracle.L.vxo_set_num_threads(cores)
+    sc = SynthCircuit(log_n, seed=0x5EED0000, poseidon_percent=pct)
+    oc = oracle_lib.OracleCircuit(oracle, sc.desc_ptr)
+    t0 = time.perf_counter()
+    proof, tm = oc.prove(sc.witness(), want_timings=True)
+    dt = time.perf_counter() - t0
+    print(json.dumps({"value": 1.0 / dt, "unit": "proofs/sec", "seconds": round(dt, 2), "cores": cores, "kind": "port", "log_n": log_n,
+                      "stages_s": {k: round(v, 2) for k, v in tm.items()}, "proof_sha256": hashlib.sha256(proof).hexdigest()}), flush=True)
+
+
+# ---- the line the driver keeps (VERDICT r5 #2b) -------------------------------------------------------------------------------------
+# The driver's record holds the last 8 KB of stdout: a 16 KB line of mostly prose loses its numbers.  `compact_line` keeps every NUMBER
+# and drops the descriptions, which live — keyed by field name — in profiles/bench_line_glossary.md; the complete line of the same run
+# (prose included) goes to a side file.
+_KEEP_TEXT = {"metric", "unit", "dtype", "data", "scaling", "workload", "parallelism", "kind", "bound", "dist_backend", "error", "evaluator", "backend"}
+_HEX_KEYS = {"root", "input", "output", "proof_sha256", "record"}
+
+
+def compact_line(d, limit: int = 5900):
+    """-> a copy of the bench line that serialises to fewer than `limit` bytes: strings longer than 48 characters are dropped unless
+    their key is one of the contract's (metric, config.workload ...), hex fields are cut to 16 characters, floats to 6 significant
+    digits; if that is not enough, the least important detail tables go (listed in `dropped_for_size`), never a headline number."""
+    import json
+
+    def walk(o, key=None):
+        if isinstance(o, dict):
+            out = {}
+            for k, v in o.items():
+                w = walk(v, k)
+                if w is not None or v is None:
+                    out[k] = w
+            return out
+        if isinstance(o, (list, tuple)):
+            return [walk(v, key) for v in o]
+        if isinstance(o, float):
+            return float(f"{o:.6g}")
+        if isinstance(o, str):
+            if key in _HEX_KEYS:
+                return o[:16]
+            if key in _KEEP_TEXT or len(o) <= 48:
+                return o
+            return None
+        return o
+
+    c = walk(d)
+    c["glossary"] = "profiles/bench_line_glossary.md"
+    order = [("chip_starks", "stage_ms_per_proof"), ("rotate", "tables"), ("dag_header_range_512_with_starks", "tables"),
+             ("dag_header_range_512_with_starks", "per_layer_ms_layer_barriers"), ("dag_header_range_512", "per_layer_ms_layer_barriers"),
+             ("alu_bound_dominant_kernel", "ubench_cycles_per_inst"), ("stage_alg_GBps",), ("rank_devices",),
+             ("dag_header_range_512_with_starks", "per_layer_ms"), ("dag_header_range_512", "per_layer_ms"), ("chip_starks",), ("rotate",)]
+    dropped = []
+
+    def drop(path):
+        if len(path) == 1:
+            return c.pop(path[0], None) is not None
+        hit = False
+        node = c.get(path[0])
+        stack = [node] if isinstance(node, dict) else []
+        while stack:                                   # the key at any depth below path[0]
+            n = stack.pop()
+            if path[1] in n:
+                del n[path[1]]
+                hit = True
+            stack.extend(v for v in n.values() if isinstance(v, dict))
+        return hit
+
+    for path in order:
+        if len(json.dumps(c)) < limit:
+            break
+        if drop(path):
+            dropped.append("/".join(path))
+            c["dropped_for_size"] = dropped
+    return c
+
+
+if __name__ == "__main__":
+    if len(sys.argv) == 4 and sys.argv[1] == "--cpu-full-child":
+        _cpu_full_child(int(sys.argv[2]), int(sys.argv[3]))

@@ -15,13 +15,16 @@ from vectorx_amd.synth import SynthCircuit  # noqa: E402
 
 
 class OracleProver:
-    def __init__(self, oracle, kind, log_n, jobs):
+    def __init__(self, oracle, kind, log_n, jobs, recursion=False):
+        """recursion: the circuits of mapreduce.GpuProver's default (the recursive verifier's gate set, >= 2^5 rows); the gloo tests'
+        2^3 / 2^4-row circuits keep the two-gate stand-in"""
         seed = {"map": 101, "reduce": 202, "outer": 303}[kind]
-        self.sc = SynthCircuit(log_n, seed=seed, poseidon_percent=50, witness_seed=0)
+        shape = mr.circuit_shape(recursion)
+        self.sc = SynthCircuit(log_n, seed=seed, poseidon_percent=50, witness_seed=0, **shape)
         self.oc = oracle_lib.OracleCircuit(oracle, self.sc.desc_ptr)
         self.wit = {}
         for (li, j) in jobs:
-            sj = SynthCircuit(log_n, seed=seed, poseidon_percent=50, witness_seed=1000 * li + j + 1)
+            sj = SynthCircuit(log_n, seed=seed, poseidon_percent=50, witness_seed=1000 * li + j + 1, **shape)
             self.wit[(li, j)] = sj.witness().copy()
             sj.free()
 

@@ -83,6 +83,34 @@ def test_the_outer_job_goes_to_worker_0_and_a_worker_error_surfaces():
         pool.wait_ready(timeout=120)
         with pytest.raises(RuntimeError, match="boom in reduce job 1"):
             pool.run(b"")
+        # replies of the failed run may still be queued on the other connections: the pool says so instead of reading them as its next results
+        with pytest.raises(RuntimeError, match="unusable after a failed run"):
+            pool.run(b"")
+    finally:
+        pool.close()
+
+
+def test_a_peer_that_connects_and_says_nothing_does_not_hang_the_coordinator():
+    """Listener.accept() + a blocking recv() of the hello message let any local process that found the socket hang wait_ready"""
+    import threading
+    import time
+    from multiprocessing.connection import Client
+    spec = mr.DagSpec(4, 10, 9, 11)
+    pool = DagPool(spec, workers_per_device=1, lanes=1, factory="_pool_factory:make").start()
+    try:
+        addr, key = pool._listener.address, pool._authkey
+        def mute():
+            try:
+                c = Client(addr, family="AF_UNIX", authkey=key)      # knows the key, never says hello
+                time.sleep(60)
+                c.close()
+            except Exception:
+                pass
+        threading.Thread(target=mute, daemon=True).start()
+        t0 = time.perf_counter()
+        ready = pool.wait_ready(timeout=120)
+        assert len(ready) == 1 and time.perf_counter() - t0 < 100
+        assert pool.run(b"q")["root"] == one_process_root(spec, b"q")
     finally:
         pool.close()
 

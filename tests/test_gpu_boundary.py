@@ -77,13 +77,14 @@ def test_two_contexts_from_two_threads(ctx):
 
 
 def test_mapreduce_dag_on_one_gpu_matches_the_oracle_dag(ctx, oracle):
-    """The proof DAG (4 map + 3 reduce + 1 outer, tiny circuits) proven on the GPU gives the same root digest as the
-    same DAG proven by the oracle: every one of the 8 proofs is byte-identical, dependencies included."""
+    """The proof DAG (4 map + 3 reduce + 1 outer, tiny circuits — since round 6 with the recursive verifier's gate set, GpuProver's
+    default) proven on the GPU gives the same root digest as the same DAG proven by the oracle: every one of the 8 proofs is
+    byte-identical, dependencies included."""
     import hashlib
     import oracle_lib
     from vectorx_amd import mapreduce as mr
     from _mp_dag_worker import OracleProver
-    spec = mr.DagSpec(num_map=4, map_log_n=5, reduce_log_n=4, outer_log_n=5)
+    spec = mr.DagSpec(num_map=4, map_log_n=6, reduce_log_n=5, outer_log_n=6)
     gp = []
 
     def make_gpu(kind, log_n, jobs):
@@ -91,7 +92,8 @@ def test_mapreduce_dag_on_one_gpu_matches_the_oracle_dag(ctx, oracle):
         gp.append(p)
         return p
     g = mr.run_dag(spec, make_gpu, None, ctx.sync)
-    o = mr.run_dag(spec, lambda kind, log_n, jobs: OracleProver(oracle, kind, log_n, jobs), None)
+    assert spec.recursion
+    o = mr.run_dag(spec, lambda kind, log_n, jobs: OracleProver(oracle, kind, log_n, jobs, recursion=True), None)
     assert g["proofs"] == o["proofs"] == 8
     assert g["root"] == o["root"]
     assert g["my_proofs"].keys() == o["my_proofs"].keys()

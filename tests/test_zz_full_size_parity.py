@@ -1,7 +1,9 @@
 """BASELINE.json configs[2] byte for byte, in the driver-run suite: the GPU proof of the header_range_512 stand-in
 (n = 2^21 rows x 135 wires — the circuit and witness bench.py times) equals the ORACLE's proof of the same circuit and witness.  The
 oracle needs about four minutes for it on the GPU box's 16 host cores (61 s to commit the preprocessed polynomials, ~180 s to prove),
-so the file is named to run LAST: under `pytest -x` every faster test has had its say before this one starts.
+so the file is named to run LAST: under `pytest -x` every faster test has had its say before this one starts — and since round 6 the
+oracle's proof is computed in the BACKGROUND of the whole GPU run (tests/conftest.py, tests/_bg_oracle.py: same generator parameters,
+same oracle), so that the suite no longer waits four minutes with the GPU idle; run on its own, the test asks the oracle itself.
 (tools/full_size_parity.py is the same check as a command-line tool; profiles/r0N_full_size_parity.jsonl hold its earlier records.)"""
 import hashlib
 
@@ -16,7 +18,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.timeout(1500)
-def test_header_range_512_sized_proof_bytes_identical_to_oracle(ctx, oracle):
+def test_header_range_512_sized_proof_bytes_identical_to_oracle(ctx, oracle, background_oracle_proof):
     log_n = 21
     oracle.L.vxo_set_num_threads(bench_prove.usable_cores())
     sc = SynthCircuit(log_n, seed=0x5EED0000, poseidon_percent=50)          # bench.py's circuit and (rank 0) witness

@@ -717,11 +717,9 @@ struct LookupParams {
 GLD void lookup_group(const u64* f, const u64* w, int k, u64& prod, u64& sum) {
   u64 pre[VX_LOOKUP_GROUP_MAX + 1];
   pre[0] = 1;
-#pragma unroll
   for (int j = 0; j < k; ++j) pre[j + 1] = gl_mul(pre[j], f[j]);
   prod = pre[k];
   u64 suf = 1, acc = 0;
-#pragma unroll
   for (int j = k - 1; j >= 0; --j) {
     const u64 lo = gl_mul(pre[j], suf);
     acc = gl_add(acc, w ? gl_mul(w[j], lo) : lo);
@@ -729,27 +727,9 @@ GLD void lookup_group(const u64* f, const u64* w, int k, u64& prod, u64& sum) {
   }
   sum = acc;
 }
-// the same with a compile-time group size: everything in registers (neutral members: f = 1, w = 0)
-template <int K>
-GLD void lookup_group_k(const u64 (&f)[K], const u64 (&w)[K], u64& prod, u64& sum) {
-  u64 pre[K + 1];
-  pre[0] = 1;
-#pragma unroll
-  for (int j = 0; j < K; ++j) pre[j + 1] = gl_mul(pre[j], f[j]);
-  prod = pre[K];
-  u64 suf = 1, acc = 0;
-#pragma unroll
-  for (int j = K - 1; j >= 0; --j) {
-    acc = gl_mad(w[j], gl_mul(pre[j], suf), acc);
-    suf = gl_mul(suf, f[j]);
-  }
-  sum = acc;
-}
-// STATIC = true: the shape of standard_recursion_config (80 routed wires, quotient_degree_factor 8: 26 table slots in groups of 5,
-// 40 looking slots in groups of 7, 6 partial sums) as compile-time constants — every loop unrolls, the group buffers live in
-// registers and the wire loads of a group are issued together; the generic form (any shape desc_check admits) walks dynamic
-// loops over scratch arrays at 10 cycles per instruction (profiles/r03_pmc_sq_prove_flags.md).
-template <bool STATIC>
+// The GENERIC form: any shape desc_check admits, dynamic loops over scratch arrays (~10 cycles per instruction).  The shape of
+// standard_recursion_config has its own kernel below (lookup_terms_static_kernel); VX_LOOKUP_TERMS_GENERIC=1 sends that shape here
+// too, which is how the two are cross-checked (same proof bytes: tests/test_gpu_prover.py).
 __global__ __launch_bounds__(256, 4) void lookup_terms_kernel(LookupParams p) {
   const size_t il = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (il >= p.rows) return;
@@ -761,8 +741,8 @@ __global__ __launch_bounds__(256, 4) void lookup_terms_kernel(LookupParams p) {
   const u32 k = bitrev32((u32)i & nmask, log_n);
   const size_t il_next = (((size_t)z << log_n) | bitrev32((k + 1) & nmask, log_n)) - p.row_base;
 #define LW(c) gl_canon(p.wires[(size_t)(c) * SW + il])
-  const int nsl = STATIC ? 6 : p.nlp - 1;
-  const int lut_slots = STATIC ? 26 : p.lut_slots, lu_slots = STATIC ? 40 : p.lu_slots, lut_deg = STATIC ? 5 : p.lut_deg, lu_deg = STATIC ? 7 : p.lu_deg;
+  const int nsl = p.nlp - 1;
+  const int lut_slots = p.lut_slots, lu_slots = p.lu_slots, lut_deg = p.lut_deg, lu_deg = p.lu_deg;
   u64 sel[4 + VX_MAX_LUTS];
   for (int q = 0; q < 4 + p.num_luts; ++q) sel[q] = p.cs[(size_t)(p.sel_base + q) * N + i];
   u64 total[VX_MAX_CHALLENGES] = {0, 0};
@@ -784,7 +764,6 @@ __global__ __launch_bounds__(256, 4) void lookup_terms_kernel(LookupParams p) {
     for (int t = 0; t < p.num_luts; ++t) push(gl_mul(sel[4 + t], gl_sub(z_re, p.lut_poly[ch][t])));
     {
       u64 cur = ZN(0);                 // RE row transition: Horner over the looked combos with challenge b
-      #pragma unroll 2
       for (int s2 = 0; s2 < lut_slots; ++s2) cur = gl_add(gl_mul(cur, ddelta), gl_mad(db, LW(3 * s2 + 1), LW(3 * s2)));
       push(gl_mul(sel[0], gl_sub(z_re, cur)));
     }
@@ -794,29 +773,6 @@ __global__ __launch_bounds__(256, 4) void lookup_terms_kernel(LookupParams p) {
       const int u0 = poly * lu_deg, u1 = min((poly + 1) * lu_deg, lu_slots);
       (void)t0, (void)t1, (void)u0, (void)u1;
       u64 lut_prod, lut_sum, lu_prod, lu_sum;
-      if constexpr (STATIC) {
-        u64 f5[5], w5[5], f7[7], w7[7];
-#pragma unroll
-        for (int q = 0; q < 5; ++q) {
-          const int s2 = poly * 5 + q;
-          const bool on = s2 < 26;
-          const int col = on ? 3 * s2 : 0;
-          const u64 inp = LW(col), outp = LW(col + 1), mult = LW(col + 2);
-          f5[q] = on ? gl_sub(dalpha, gl_mad(da, outp, inp)) : 1;
-          w5[q] = on ? mult : 0;
-        }
-        lookup_group_k<5>(f5, w5, lut_prod, lut_sum);
-#pragma unroll
-        for (int q = 0; q < 7; ++q) {
-          const int s2 = poly * 7 + q;
-          const bool on = s2 < 40;
-          const int col = on ? 2 * s2 : 0;
-          const u64 inp = LW(col), outp = LW(col + 1);
-          f7[q] = on ? gl_sub(dalpha, gl_mad(da, outp, inp)) : 1;
-          w7[q] = on ? 1 : 0;
-        }
-        lookup_group_k<7>(f7, w7, lu_prod, lu_sum);
-      } else {
       u64 f[VX_LOOKUP_GROUP_MAX], w[VX_LOOKUP_GROUP_MAX];
       for (int s2 = t0; s2 < t1; ++s2) {
         f[s2 - t0] = gl_sub(dalpha, gl_mad(da, LW(3 * s2 + 1), LW(3 * s2)));
@@ -825,7 +781,6 @@ __global__ __launch_bounds__(256, 4) void lookup_terms_kernel(LookupParams p) {
       lookup_group(f, w, max(t1 - t0, 0), lut_prod, lut_sum);   // a polynomial past the last table slot has an empty group: product 1, sum 0
       for (int s2 = u0; s2 < u1; ++s2) f[s2 - u0] = gl_sub(dalpha, gl_mad(da, LW(2 * s2 + 1), LW(2 * s2)));
       lookup_group(f, nullptr, max(u1 - u0, 0), lu_prod, lu_sum);
-      }
       const u64 prev = poly == 0 ? ZN(nsl) : Z(poly);
       const u64 d = gl_sub(Z(poly + 1), prev);
       push(gl_mul(sel[0], gl_sub(gl_mul(lut_prod, d), lut_sum)));   // Sum transition

@@ -1002,14 +1002,24 @@ static int prove_impl(vx_ctx* c, vx_circuit* k, const u64* wires_in, bool wires_
       qp.out = qv;
       size_t bytes_read = 8ull * Nl * ((size_t)k->num_constants + k->nr + k->num_wires + (size_t)nch * (2 + npp));
       ProfScope ps(c, "quotient_eval", (double)bytes_read);
-      hipLaunchKernelGGL(quotient_kernel<0>, dim3((unsigned)((Nl + 255) / 256)), dim3(256), 0, c->stream, qp);   // out = (L_0 + permutation terms) / Z_H
+      // every kernel of the quotient is its own profile stage INSIDE quotient_eval (round 6: "quotient_eval by kernel")
+      {
+        ProfScope pk(c, "quotient_l0_permutation");
+        hipLaunchKernelGGL(quotient_kernel<0>, dim3((unsigned)((Nl + 255) / 256)), dim3(256), 0, c->stream, qp);   // out = (L_0 + permutation terms) / Z_H
+      }
       bool small_gates = false, poseidon_gate = false;
       for (const GateDev& gd : k->gates) {
         small_gates |= gd.type >= 1 && gd.type <= 3;
         poseidon_gate |= gd.type == 4;
       }
-      if (small_gates) hipLaunchKernelGGL(quotient_kernel<1>, dim3((unsigned)((Nl + 255) / 256)), dim3(256), 0, c->stream, qp);   // out += Constant / PublicInput / Arithmetic gate terms / Z_H
-      if (poseidon_gate) hipLaunchKernelGGL(quotient_kernel<2>, dim3((unsigned)((Nl + 255) / 256)), dim3(256), 0, c->stream, qp);  // out += PoseidonGate terms / Z_H
+      if (small_gates) {
+        ProfScope pk(c, "quotient_small_native_gates");
+        hipLaunchKernelGGL(quotient_kernel<1>, dim3((unsigned)((Nl + 255) / 256)), dim3(256), 0, c->stream, qp);   // out += Constant / PublicInput / Arithmetic gate terms / Z_H
+      }
+      if (poseidon_gate) {
+        ProfScope pk(c, "quotient_poseidon_gate");
+        hipLaunchKernelGGL(quotient_kernel<2>, dim3((unsigned)((Nl + 255) / 256)), dim3(256), 0, c->stream, qp);  // out += PoseidonGate terms / Z_H
+      }
       HIPCHK(hipGetLastError());
       if (k->num_luts > 0) {  // the lookup argument's terms sit between the partial-product checks and the gate constraints
         LookupParams lp;
@@ -1042,8 +1052,8 @@ static int prove_impl(vx_ctx* c, vx_circuit* k, const u64* wires_in, bool wires_
         }
         for (int r = 0; r < rate; ++r) lp.zh_inv[r] = qp.zh_inv[r];
         ProfScope psl(c, "quotient_lookup_terms");
-        static const bool terms_v1 = getenv("VX_LOOKUP_TERMS_V1") != nullptr;   // rounds 3-5's form of the static kernel (A/B, cross-check)
-        if (lp.nlp == 7 && lp.lut_slots == 26 && lp.lu_slots == 40 && lp.lut_deg == 5 && lp.lu_deg == 7 && !terms_v1) {   // standard_recursion_config
+        static const bool terms_generic = getenv("VX_LOOKUP_TERMS_GENERIC") != nullptr;   // cross-check: the generic kernel for every shape
+        if (lp.nlp == 7 && lp.lut_slots == 26 && lp.lu_slots == 40 && lp.lut_deg == 5 && lp.lu_deg == 7 && !terms_generic) {   // standard_recursion_config
           LookupStaticExtra lx;
           memset(&lx, 0, sizeof lx);
           lx.alpha_limbs = qp.alpha_limbs;
@@ -1067,10 +1077,9 @@ static int prove_impl(vx_ctx* c, vx_circuit* k, const u64* wires_in, bool wires_
           static const int wps = getenv("VX_LOOKUP_WPS") ? atoi(getenv("VX_LOOKUP_WPS")) : 3;   // waves per SIMD the kernel is compiled for: 3 = 168 VGPRs, no spills (0.87 ms at 2^18 rows); 4 = 128 VGPRs, 44 spills (1.08 ms)
           if (wps != 4) hipLaunchKernelGGL(lookup_terms_static_kernel<3>, dim3((unsigned)((Nl + 255) / 256)), dim3(256), 0, c->stream, lp, lx);
           else hipLaunchKernelGGL(lookup_terms_static_kernel<4>, dim3((unsigned)((Nl + 255) / 256)), dim3(256), 0, c->stream, lp, lx);
-        } else if (lp.nlp == 7 && lp.lut_slots == 26 && lp.lu_slots == 40 && lp.lut_deg == 5 && lp.lu_deg == 7)
-          hipLaunchKernelGGL(lookup_terms_kernel<true>, dim3((unsigned)((Nl + 255) / 256)), dim3(256), 0, c->stream, lp);
-        else
-          hipLaunchKernelGGL(lookup_terms_kernel<false>, dim3((unsigned)((Nl + 255) / 256)), dim3(256), 0, c->stream, lp);
+        } else {
+          hipLaunchKernelGGL(lookup_terms_kernel, dim3((unsigned)((Nl + 255) / 256)), dim3(256), 0, c->stream, lp);
+        }
         HIPCHK(hipGetLastError());
       }
       if (k->programs) {  // gates supplied as constraint programs add their share to the same quotient values

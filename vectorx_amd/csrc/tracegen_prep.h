@@ -65,6 +65,8 @@ int sha2_prepare(int degree_bits, const uint8_t* msgs, const uint64_t* off, int 
     b.first = first_of_message;
     for (int j = 0; j < 16; ++j) b.lw[j] = latched[j];
   };
+  for (int mi = 0; mi < nmsg; ++mi)
+    if (off[mi + 1] < off[mi]) return PREP_BAD_ARGS;       // offsets must not decrease (a wrapped length would ask for exabytes)
   for (int mi = 0; mi < nmsg; ++mi) {
     const size_t ml = (size_t)(off[mi + 1] - off[mi]);
     const size_t total = ((ml + 1 + LB + BB - 1) / BB) * BB;
@@ -151,6 +153,8 @@ inline int b2_prepare(int degree_bits, const uint8_t* msgs, const uint64_t* off,
     }
     return false;
   };
+  for (int mi = 0; mi < nmsg; ++mi)
+    if (off[mi + 1] < off[mi]) return PREP_BAD_ARGS;       // offsets must not decrease
   for (int mi = 0; mi < nmsg; ++mi) {
     const size_t ml = (size_t)(off[mi + 1] - off[mi]);
     const size_t nblk = ml ? (ml + 127) / 128 : 1;

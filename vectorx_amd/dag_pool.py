@@ -101,7 +101,21 @@ class DagPool:
                 if time.perf_counter() - t0 > timeout:
                     raise TimeoutError("the DAG workers did not connect in time")
                 continue
-            hello = c.recv()                   # ("hello", worker index): connections arrive in any order
+            # ("hello", worker index): connections arrive in any order.  A peer that connects and then says nothing (a stalled worker, any
+            # local process that found the socket) must not hang the coordinator: bounded wait, then the connection is dropped
+            if not c.poll(30.0):
+                c.close()
+                self._check_alive("after connecting without a hello")
+                continue
+            try:
+                hello = c.recv()
+            except (EOFError, OSError):
+                c.close()
+                continue
+            if not (isinstance(hello, tuple) and len(hello) == 2 and hello[0] == "hello" and isinstance(hello[1], int)
+                    and 0 <= hello[1] < len(self.procs) and hello[1] not in byindex):
+                c.close()
+                continue
             byindex[hello[1]] = c
         self.conns = [byindex[i] for i in range(len(self.procs))]
         for c in self.conns:
@@ -167,6 +181,16 @@ class DagPool:
         one more task, queued behind the map jobs, that worker 0's outer lane proves while the tree is still being reduced; the outer
         plonky2 proof then only waits for the root reduce proof.  schedule = "layers": strict layer barriers, nothing hoisted (rounds 1-4).
         Same proofs, same digests, same root either way."""
+        if getattr(self, "_broken", None):
+            raise RuntimeError(f"this pool is unusable after a failed run ({self._broken}): replies of that run may still be queued on its "
+                               "connections; close() it and start another")
+        try:
+            return self._run(input_seed, with_tables, schedule)
+        except BaseException as e:   # noqa: BLE001 — whatever ended the run, the other workers' outstanding replies make the pool unusable
+            self._broken = repr(e)[:200]
+            raise
+
+    def _run(self, input_seed: bytes, with_tables: bool, schedule: str) -> dict:
         layers = self.spec.layers()
         nl = len(layers)
         hoist = schedule == "dependency" and with_tables and self.cfg["with_starks"]

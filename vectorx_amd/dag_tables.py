@@ -173,9 +173,8 @@ class GpuTables:
     def hash_table(self, label, which, log_n, messages_fn, lanes):
         from . import blake2b_bytes_air, sha256_air, stark_chips
         air = {"blake2b": blake2b_bytes_air, "sha256": sha256_air}[which]
-        # these tables are ~1000 columns wide: their transcripts take the tree hash of the openings, computed on the device
-        # (VX_STARK_OPENINGS_DIGEST), not 1000 host permutations per proof
-        stark = air.make_stark(log_n, openings_digest=not os.environ.get("VX_NO_OPENINGS_DIGEST"))      # (the variable: an A/B knob)
+        # starky's transcript order (the opening set absorbed element by element) unless VX_OPENINGS_DIGEST=1 asks for the tree-hash variant
+        stark = air.make_stark(log_n, openings_digest=stark_chips.openings_digest_default())
         tab = stark_chips.GeneratedHashTable(self.ctx, which, stark, log_n, messages_fn, lanes, label)
         return tab, f"{stark.desc.num_columns} + {stark.desc.num_aux_columns}"
 

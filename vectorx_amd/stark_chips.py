@@ -10,6 +10,14 @@ import time
 
 import numpy as np
 
+
+def openings_digest_default() -> bool:
+    """Does the transcript of the DAG's / the bench's chip tables take the tree hash of the opening set (`VX_STARK_OPENINGS_DIGEST`, this
+    library's own variant: saves 0.2 - 1.1 ms of dependent host permutations per lone wide table, nothing in the saturated DAG) instead of
+    the opening set itself in starky's order?  Off unless VX_OPENINGS_DIGEST=1: figures are quoted under the starky-order transcript."""
+    return os.environ.get("VX_OPENINGS_DIGEST", "0") not in ("", "0")
+
+
 CHIPS = ("sha256", "blake2b", "ed25519")
 
 
@@ -388,8 +396,9 @@ class GeneratedSignatureBus:
         self.link_log_n = max(4, (nsigs + 1).bit_length())
         self.cap = ea.capacity(self.lay, ed_log_n)
         self.ntab = max(1, -(-nsigs // self.cap))
-        # (every table's transcript takes the tree hash of its openings, computed on the device: VX_STARK_OPENINGS_DIGEST)
-        od = not os.environ.get("VX_NO_OPENINGS_DIGEST")           # (the variable: an A/B knob)
+        # starky's transcript order by default since round 6 (the opening set is absorbed element by element, as an in-circuit verifier
+        # of the reference would follow it); VX_OPENINGS_DIGEST=1 = this library's own variant, a tree hash of the openings made on the device
+        od = openings_digest_default()
         self.sha = s5.make_stark(sha_log_n, bus=True, openings_digest=od)
         self.ed = ea.make_stark(self.lay, ed_log_n, openings_digest=od)
         self.link = link.make_stark(self.link_log_n, openings_digest=od)
@@ -457,9 +466,14 @@ class GeneratedSignatureBus:
         return b"".join(proofs)
 
     def closed(self, ctx=None) -> bool:
-        """the last bus proven on this lane balances: the closing sums of all its tables add up to 0 mod p"""
+        """the last bus proven on this lane balances: for EVERY challenge set on its own (a table carries one closing sum per set) the
+        tables' closing sums add up to 0 mod p — index by index, as vx_stark_verify_bus checks them; adding the sets together would
+        accept X + Y = 0 with X != 0 (single-set soundness)"""
         sums = self.last[id(self.ctx if ctx is None else ctx)][2]
-        return sum(int(x) for s_ in sums for x in s_) % 0xFFFFFFFF00000001 == 0
+        width = len(sums[0])
+        if any(len(s_) != width for s_ in sums):
+            return False
+        return all(sum(int(s_[i]) for s_ in sums) % 0xFFFFFFFF00000001 == 0 for i in range(width))
 
     def take_spent(self, ctx=None):
         return self.spent.pop(id(self.ctx if ctx is None else ctx), None)
