@@ -63,6 +63,9 @@ def parse():
     ap.add_argument("--extra-legs-deadline", type=float, default=1500.0,
                     help="seconds the legs AFTER the contract's line may take at N = 1 before the process prints what it has and exits")
     ap.add_argument("--cpu-baseline-full", action="store_true", help="(default since round 6; kept so that older command lines still parse)")
+    ap.add_argument("--full-line", action="store_true",
+                    help="print the COMPLETE line (descriptions, whole digests: 12-16 KB) instead of the compact form (< 6 KB: every number, no prose; "
+                         "profiles/bench_line_glossary.md describes the fields).  The complete line is always written to bench_line_full.json")
     ap.add_argument("--no-cpu-baseline-full", action="store_true",
                     help="cpu_baseline: only the bounded sample (2^18 rows, scaled); by default the N = 1 run ALSO proves the bench circuit itself once "
                          "with the oracle — ~4 min of host cores after every GPU leg — and `cpu_baseline.value` is that measured figure")
@@ -399,7 +402,7 @@ def main():
                     import bench_prove as bp
                     side = Path("gpurun_out") if Path("gpurun_out").is_dir() else Path(".")
                     (side / "bench_line_full.json").write_text(json.dumps(d))
-                    line = json.dumps(bp.compact_line(d))
+                    line = json.dumps(d if args.full_line else bp.compact_line(d))
                 except Exception as e:   # noqa: BLE001 — the line goes out whatever happens to its short form
                     d["compact_line_error"] = repr(e)
                     line = json.dumps(d)

@@ -693,6 +693,7 @@ def _cpu_full_child(log_n: int, pct: int) -> None:
 # (prose included) goes to a side file.
 _KEEP_TEXT = {"metric", "unit", "dtype", "data", "scaling", "workload", "parallelism", "kind", "bound", "dist_backend", "error", "evaluator", "backend"}
 _HEX_KEYS = {"root", "input", "output", "proof_sha256", "record"}
+_FLAG_TEXT = {"emulated_ranks_on_one_device"}     # a label whose PRESENCE is the information: kept as `true`
 
 
 def compact_line(d, limit: int = 5900):
@@ -716,6 +717,8 @@ def compact_line(d, limit: int = 5900):
         if isinstance(o, str):
             if key in _HEX_KEYS:
                 return o[:16]
+            if key in _FLAG_TEXT:
+                return True
             if key in _KEEP_TEXT or len(o) <= 48:
                 return o
             return None
@@ -724,9 +727,13 @@ def compact_line(d, limit: int = 5900):
     c = walk(d)
     c["glossary"] = "profiles/bench_line_glossary.md"
     order = [("chip_starks", "stage_ms_per_proof"), ("rotate", "tables"), ("dag_header_range_512_with_starks", "tables"),
+             ("dag_on_one_pool_over_all_gpus", "tables"),
              ("dag_header_range_512_with_starks", "per_layer_ms_layer_barriers"), ("dag_header_range_512", "per_layer_ms_layer_barriers"),
-             ("alu_bound_dominant_kernel", "ubench_cycles_per_inst"), ("stage_alg_GBps",), ("rank_devices",),
-             ("dag_header_range_512_with_starks", "per_layer_ms"), ("dag_header_range_512", "per_layer_ms"), ("chip_starks",), ("rotate",)]
+             ("dag_on_one_pool_over_all_gpus", "per_layer_ms_layer_barriers"),
+             ("alu_bound_dominant_kernel", "ubench_cycles_per_inst"), ("stage_alg_GBps",), ("sharded_one_proof", "rank0_stage_ms"),
+             ("dag_on_one_pool_over_all_gpus", "per_layer_ms"), ("dag_on_one_pool_over_all_gpus", "setup_seconds_by_worker"),
+             ("dag_header_range_512_with_starks", "per_layer_ms"), ("dag_header_range_512", "per_layer_ms"), ("rank_devices",),
+             ("recursion_circuits_alone", "gate_rows_map"), ("chip_starks",), ("rotate",)]
     dropped = []
 
     def drop(path):

@@ -124,7 +124,8 @@ def test_prove_argument_errors(ctx):
     gc.free()
 
 
-@pytest.mark.parametrize("degree_bits", [16, 20, 21])
+@pytest.mark.parametrize("degree_bits", [16])   # (round 6: the 2^20 / 2^21 cases went — the two full-size byte-identity tests prove and
+                                                #  verify those sizes; tools/full_size_parity.py still runs this check at any size)
 def test_large_proof_is_accepted_by_the_restated_verifier(ctx, oracle, degree_bits):
     """2^16 (full oracle cross-check of the preprocessed commitment), header_range_256 stand-in (2^20 rows,
     BASELINE.json configs[1]) and header_range_512 stand-in (2^21 rows, configs[2]): the oracle cannot PROVE
@@ -173,7 +174,7 @@ def test_randomized_differential_sweep(ctx, oracle):
     """Many small circuits with different seeds / sizes / gate mixes: GPU proof bytes == oracle proof bytes.
     (PoW bits lowered so the oracle's scalar grinding does not dominate the run time.)"""
     rng = np.random.default_rng(2026)
-    for trial in range(100):
+    for trial in range(30):        # (100 until round 5; the long sweeps are tools/soak_differential.py: profiles/r0N_soak_differential.jsonl)
         db = int(rng.integers(3, 10))
         pct = int(rng.integers(0, 101))
         sc = SynthCircuit(db, seed=int(rng.integers(1, 1 << 62)), poseidon_percent=pct, witness_seed=int(rng.integers(1, 1 << 62)))

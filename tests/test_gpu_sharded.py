@@ -308,7 +308,8 @@ def test_bench_two_gpus_under_torchrun(mode):
 def _plain_bench(*extra):
     """`python bench.py --gpus N ...` run PLAINLY — no launcher in front: bench.py starts its own ranks as child processes"""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    return subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "2", "--warmup", "1", "--log-n", "16", "--no-cpu-baseline", *extra],
+    # --full-line: the complete line (whole digests, the descriptions) instead of the compact form the driver's record keeps
+    return subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "2", "--warmup", "1", "--log-n", "16", "--no-cpu-baseline", "--full-line", *extra],
                           capture_output=True, text=True, timeout=900, cwd=str(ROOT), env=env)
 
 
@@ -324,15 +325,16 @@ def test_bench_gpus_2_run_plainly_launches_two_ranks(mode):
     assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["value"] > 0
     assert len({d["local_rank"] for d in line["rank_devices"]}) == 2
     if mode == "sharded":
-        # bench.py hands vx_prove_sharded a DEVICE-resident witness: no witness all-gather, so 7 exchanges per proof (3 + 1 caps, quotient
-        # coset coefficients, first FRI layer, ONE batched query-opening exchange); a host witness adds the column all-gather = 8
+        # bench.py hands vx_prove_sharded a DEVICE-resident witness: no witness all-gather, so 8 exchanges per proof (3 + 1 caps, quotient
+        # coset coefficients, the openings, first FRI layer, ONE batched query-opening exchange); a host witness adds the column all-gather = 9
         assert line["exchange"]["allgather_calls_per_proof"] == EXCHANGES_PER_PROOF["device"]
         assert line["exchange"]["inbound_bytes_per_rank_per_proof"] > 0
     _check_multi_rank_legs(line, 2, "nccl")
 
 
 # exchanges vx_prove_sharded asks its host for, by where the witness is (prover.hip.h: the witness-column all-gather exists only for a host witness)
-EXCHANGES_PER_PROOF = {"device": 7, "host": 8}
+# round 6: + the openings (the ~260 evaluations at zeta / g zeta shard by column range, 2 words per polynomial come back)
+EXCHANGES_PER_PROOF = {"device": 8, "host": 9}
 
 
 def _check_multi_rank_legs(line, world, backend):
@@ -367,6 +369,10 @@ def test_bench_multi_rank_code_path_on_one_device(world):
     line = json.loads(lines[0])
     assert line["n_gpus"] == world and line["rccl_ranks"] == world and line["dist_backend"] == "gloo" and line["value"] > 0
     assert line["scaling"] == "weak" and "emulated_ranks_on_one_device" in line
+    import bench_prove
+    short = bench_prove.compact_line(line)                       # what the same run prints without --full-line
+    assert len(json.dumps(short)) < 6144 and short["value"] > 0 and short["emulated_ranks_on_one_device"] is True
+    assert short["sharded_one_proof"]["allgather_calls_per_proof"] == EXCHANGES_PER_PROOF["device"] and short["dag_header_range_512"]["dag_seconds"] > 0
     assert [d["rank"] for d in line["rank_devices"]] == list(range(world))
     _check_multi_rank_legs(line, world, "gloo")
     assert line["dag_header_range_512"]["plonky2_proofs"] == (4 + 3 + 1 if world < 8 else 8 + 7 + 1)

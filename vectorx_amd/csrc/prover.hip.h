@@ -1242,7 +1242,50 @@ static int prove_impl(vx_ctx* c, vx_circuit* k, const u64* wires_in, bool wires_
     }
     jobs[4] = EvalJob{zs_b->coeffs, (size_t)nch, 1, zs_next.data()};
     jobs[5] = EvalJob{zs_b->coeffs + zs_pp * n, (size_t)nlook, 1, lzs_next.data()};
-    VXCHK(batch_eval_ext_many(c, zeta, gzeta, lg, jobs, 6));
+    static const bool replicate = getenv("VX_SHARD_REPLICATE_OPENINGS") != nullptr;   // rounds 2-5: every rank evaluated every polynomial (A/B)
+    if (sh.world == 1 || replicate) {
+      VXCHK(batch_eval_ext_many(c, zeta, gzeta, lg, jobs, 6));
+    } else {
+      // One proof over G ranks (round 6): the coefficients are replicated, so the ~260 evaluations at zeta / g zeta shard by COLUMN RANGE
+      // for free — rank r takes ceil(ncols / G) columns of every job — and one more small in-place all-gather (2 words per polynomial:
+      // ~4 KB per proof) puts every value on every rank.  1.7 ms of 38.5 per rank were this stage at G = 8 (single-device emulation).
+      const size_t G = (size_t)sh.world;
+      EvalJob sub[6];
+      std::vector<u64> mine_vals[6];
+      size_t per[6], slot = 0;
+      for (int j = 0; j < 6; ++j) {
+        per[j] = (jobs[j].ncols + G - 1) / G;
+        const size_t c0 = std::min(jobs[j].ncols, per[j] * (size_t)sh.rank), c1 = std::min(jobs[j].ncols, c0 + per[j]);
+        mine_vals[j].assign(2 * per[j] + 2, 0);
+        sub[j] = EvalJob{jobs[j].coeffs + c0 * n, c1 - c0, jobs[j].point, mine_vals[j].data()};
+        slot += 2 * per[j];
+      }
+      VXCHK(batch_eval_ext_many(c, zeta, gzeta, lg, sub, 6));
+      std::vector<u64> all(slot * G, 0);
+      {
+        size_t off = 0;
+        for (int j = 0; j < 6; ++j) {
+          memcpy(all.data() + slot * sh.rank + off, mine_vals[j].data(), 2 * per[j] * 8);
+          off += 2 * per[j];
+        }
+      }
+      u64* d_x = slot ? S.get(slot * G) : nullptr;
+      if (slot && !d_x) return vx_fail(VX_E_NOMEM, "prove: out of device memory (openings exchange)");
+      if (slot) {
+        HIPCHK(hipMemcpyAsync(d_x + slot * sh.rank, all.data() + slot * sh.rank, slot * 8, hipMemcpyHostToDevice, c->stream));
+        VXCHK(shard_allgather(c, sh, d_x, slot * 8, "openings at zeta and g zeta"));
+        HIPCHK(hipMemcpyAsync(all.data(), d_x, slot * G * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+      }
+      for (size_t r2 = 0; r2 < G; ++r2) {
+        size_t off = 0;
+        for (int j = 0; j < 6; ++j) {
+          const size_t c0 = std::min(jobs[j].ncols, per[j] * r2), c1 = std::min(jobs[j].ncols, c0 + per[j]);
+          if (c1 > c0) memcpy(jobs[j].out_host + 2 * c0, all.data() + slot * r2 + off, 2 * (c1 - c0) * 8);
+          off += 2 * per[j];
+        }
+      }
+    }
   }
   // to_fri_openings: batch 0 = [constants, sigmas, wires, zs, partial products, quotient, lookup_zs], batch 1 = [zs_next,
   // lookup_zs_next] — the lookup polynomials are the TAIL of the zs_partial_products oracle but are opened after the quotient
