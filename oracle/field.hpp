@@ -30,13 +30,14 @@ static const int TWO_ADICITY = 32;
 
 // All values are kept CANONICAL (< p) in the oracle; plonky2 allows non-canonical u64 internally
 // but canonicalises on serialisation, so canonical-everywhere is output-equivalent.
-// (branch-free forms: on random data the carry / borrow branches of the textbook forms mispredict every other time, which made a
-//  field multiplication cost ~7 ns and the oracle a 4x slower CPU baseline than the same algorithm deserves — round 6)
-static inline u64 canon(u64 x) { return x - (P & (0 - (u64)(x >= P))); }
+// (round 6: a carry / borrow that happens every other time on random data is a MASK — as a branch it mispredicted half the time and made
+//  a field multiplication cost ~7 ns; one that happens with probability 2^-32 stays a branch, which the predictor gets right for free.
+//  The textbook forms made the oracle a 1.5x slower CPU baseline than the same algorithm deserves.)
+static inline u64 canon(u64 x) { return __builtin_expect(x >= P, 0) ? x - P : x; }
 static inline u64 add(u64 a, u64 b) {
   u64 s;
   const u64 c = __builtin_add_overflow(a, b, &s);
-  s += EPS & (0 - c);  // + 2^64 mod p; cannot overflow again because a,b < p
+  s += EPS & (0 - c);  // + 2^64 mod p: a + b - p < p, canonical; without a carry s < 2^64 can still reach p (rarely)
   return canon(s);
 }
 static inline u64 sub(u64 a, u64 b) {
@@ -49,10 +50,9 @@ static inline u64 neg(u64 a) { return a ? P - a : 0; }
 static inline u64 reduce128(u128 x) {
   u64 lo = (u64)x, hi = (u64)(x >> 64);
   u64 hh = hi >> 32, hl = hi & EPS;
-  u64 t;
-  const u64 bw = __builtin_sub_overflow(lo, hh, &t);
-  t -= EPS & (0 - bw);    // borrow: subtract 2^64 mod p
-  u64 m = hl * EPS;       // < 2^64
+  u64 t = lo - hh;
+  if (__builtin_expect(lo < hh, 0)) t -= EPS;  // borrow (lo < 2^32: once in 2^32): subtract 2^64 mod p
+  u64 m = hl * EPS;                            // < 2^64
   u64 r;
   const u64 c = __builtin_add_overflow(t, m, &r);
   r += EPS & (0 - c);

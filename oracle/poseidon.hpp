@@ -107,6 +107,43 @@ static inline void permute(State& s) {
   }
 }
 
+// B independent permutations side by side (round 6): the partial rounds are one dependency chain per state — S-box of lane 0, dot
+// product, next round — so a lone permutation leaves most of the core idle; interleaving the chains of B states lets the out-of-order
+// core overlap them (1.4x at B = 4 on the build machine).  Same arithmetic per state as `permute`, step by step.
+template <int B>
+static inline void permute_batch(State* s) {
+  int rc = 0;
+  for (int r = 0; r < HALF_N_FULL_ROUNDS; ++r) {
+    for (int b = 0; b < B; ++b)
+      for (int i = 0; i < 12; ++i) s[b][i] = sbox(add(s[b][i], ROUND_CONSTANTS[rc + i]));
+    rc += 12;
+    for (int b = 0; b < B; ++b) mds_layer(s[b]);
+  }
+  for (int b = 0; b < B; ++b)
+    for (int i = 0; i < 12; ++i) s[b][i] = add(s[b][i], FAST_FIRST[i]);
+  for (int b = 0; b < B; ++b) {
+    u64 t[11];
+    for (int r = 0; r < 11; ++r) t[r] = dot_reduce(&s[b][1], FAST_INIT[r], 11);
+    for (int r = 0; r < 11; ++r) s[b][1 + r] = t[r];
+  }
+  for (int r = 0; r < N_PARTIAL_ROUNDS; ++r) {
+    u64 s0[B];
+    for (int b = 0; b < B; ++b) s0[b] = add(sbox(s[b][0]), FAST_K[r]);
+    for (int b = 0; b < B; ++b) {
+      u64 d = dot_reduce(&s[b][1], FAST_W_HATS[r], 11, s0[b], MDS_CIRC[0] + MDS_DIAG[0]);
+      for (int i = 0; i < 11; ++i) s[b][1 + i] = reduce128((u128)s0[b] * FAST_VS[r][i] + s[b][1 + i]);
+      s[b][0] = d;
+    }
+  }
+  rc = 12 * (HALF_N_FULL_ROUNDS + N_PARTIAL_ROUNDS);
+  for (int r = 0; r < HALF_N_FULL_ROUNDS; ++r) {
+    for (int b = 0; b < B; ++b)
+      for (int i = 0; i < 12; ++i) s[b][i] = sbox(add(s[b][i], ROUND_CONSTANTS[rc + i]));
+    rc += 12;
+    for (int b = 0; b < B; ++b) mds_layer(s[b]);
+  }
+}
+
 struct Hash {
   u64 e[4];
   bool operator==(const Hash& o) const { return !memcmp(e, o.e, sizeof e); }
@@ -163,6 +200,35 @@ static inline Hash two_to_one(const Hash& l, const Hash& r) {
   return h;
 }
 
+// hash_or_noop of PB leaves of the same width, and two_to_one of PB node pairs, PB permutations at a time (same outputs as the scalar forms)
+static const int PB = 4;
+static inline void hash_or_noop_batch(const u64* in, size_t w, Hash* out) {   // leaves in + k w, k < PB
+  if (w <= 4) {
+    for (int k = 0; k < PB; ++k) out[k] = hash_or_noop(in + (size_t)k * w, w);
+    return;
+  }
+  State s[PB];
+  for (int k = 0; k < PB; ++k) s[k] = State{};
+  for (size_t off = 0; off < w; off += SPONGE_RATE) {
+    size_t len = w - off < (size_t)SPONGE_RATE ? w - off : SPONGE_RATE;
+    for (int k = 0; k < PB; ++k)
+      for (size_t i = 0; i < len; ++i) s[k][i] = in[(size_t)k * w + off + i];
+    permute_batch<PB>(s);
+  }
+  for (int k = 0; k < PB; ++k)
+    for (int i = 0; i < 4; ++i) out[k].e[i] = s[k][i];
+}
+static inline void two_to_one_batch(const Hash* children, Hash* out) {       // out[k] = two_to_one(children[2k], children[2k + 1]), k < PB
+  State s[PB];
+  for (int k = 0; k < PB; ++k) {
+    s[k] = State{};
+    for (int i = 0; i < 4; ++i) s[k][i] = children[2 * k].e[i], s[k][4 + i] = children[2 * k + 1].e[i];
+  }
+  permute_batch<PB>(s);
+  for (int k = 0; k < PB; ++k)
+    for (int i = 0; i < 4; ++i) out[k].e[i] = s[k][i];
+}
+
 // ---------------------------------------------------------------------------------------------
 // merkle_tree.rs::MerkleTree (outputs only: cap + proofs; upstream's interleaved digest buffer is
 // an internal layout that does not affect either).  Leaves are row-major: leaf i = leaves[i*width..].
@@ -187,15 +253,25 @@ struct MerkleTree {
     {
       std::vector<Hash>& d = layers[0];
       long long nl = (long long)n_leaves;
+      if (nl % PB == 0) {
 #pragma omp parallel for schedule(static)
-      for (long long i = 0; i < nl; ++i) d[i] = hash_or_noop(&leaves[(size_t)i * w], w);
+        for (long long i = 0; i < nl; i += PB) hash_or_noop_batch(&leaves[(size_t)i * w], w, &d[i]);
+      } else {
+#pragma omp parallel for schedule(static)
+        for (long long i = 0; i < nl; ++i) d[i] = hash_or_noop(&leaves[(size_t)i * w], w);
+      }
     }
     for (int lvl = lg; lvl > cap_h; --lvl) {
       const std::vector<Hash>& prev = layers.back();
       std::vector<Hash> next(prev.size() / 2);
       long long nn = (long long)next.size();
+      if (nn % PB == 0) {
 #pragma omp parallel for schedule(static)
-      for (long long i = 0; i < nn; ++i) next[i] = two_to_one(prev[2 * i], prev[2 * i + 1]);
+        for (long long i = 0; i < nn; i += PB) two_to_one_batch(&prev[2 * i], &next[i]);
+      } else {
+#pragma omp parallel for schedule(static)
+        for (long long i = 0; i < nn; ++i) next[i] = two_to_one(prev[2 * i], prev[2 * i + 1]);
+      }
       layers.push_back(std::move(next));
     }
   }
