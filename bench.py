@@ -74,6 +74,9 @@ def parse():
     ap.add_argument("--circuit-flags", type=int, default=0,
                     help="vectorx_amd.synth FLAG_* bits of the synthetic circuit (1|4|8: constraint-program gates, 16: a lookup table); the "
                          "default 0 is the headline gate mix — other values are for profiling the prove-only kernels")
+    ap.add_argument("--recursion-mix", action="store_true",
+                    help="profiling: the workload circuit carries the recursive verifier's gate set in its declared row mix (the DAG legs' circuit family, "
+                         "vectorx_amd/synth.py RECURSIVE_VERIFIER_MIX) instead of the headline two-gate mix; implies no extra legs, like --circuit-flags")
     ap.add_argument("--no-host-witness-leg", action="store_true",
                     help="skip the extra (untimed-by-the-contract) leg that proves from a pinned HOST witness (PCIe-inclusive rate)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -167,6 +170,8 @@ def launch_ranks(args) -> int:
 
 def main():
     args = parse()
+    if args.recursion_mix:
+        args.circuit_flags = args.circuit_flags or 29      # (the flag set the mix needs; also switches the extra legs off)
     if args.gpus < 1:
         sys.exit("bench.py: --gpus must be >= 1")
     if "WORLD_SIZE" not in os.environ:

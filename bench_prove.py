@@ -18,8 +18,12 @@ def make_step(ctx, args, rank, dist=None, device=None):
     # throughput mode: every rank proves its OWN witness; sharded mode: all ranks work on the SAME proof
     # ONE circuit on every rank (so that the sharded leg after a throughput run can put all ranks on one proof); in throughput
     # mode each rank proves its own witness of it (rank 0: witness seed = circuit seed, the N = 1 workload)
+    shape = {"flags": getattr(args, "circuit_flags", 0)}
+    if getattr(args, "recursion_mix", False):         # profiling runs: the DAG's circuit family (recursive verifier's gate set, declared mix) as THE workload
+        from vectorx_amd.mapreduce import circuit_shape
+        shape = circuit_shape(True)
     sc = SynthCircuit(args.log_n, seed=0x5EED0000, poseidon_percent=args.poseidon_percent,
-                      witness_seed=0x5EED0000 + (0 if sharded_mode else rank), flags=getattr(args, "circuit_flags", 0))
+                      witness_seed=0x5EED0000 + (0 if sharded_mode else rank), **shape)
     counts = sc.row_counts()
     circuit = vx.Circuit(ctx, sc.desc_ptr)   # constants_sigmas commitment stays resident (per-circuit, not per-proof)
     w = sc.witness()
@@ -49,7 +53,8 @@ def make_step(ctx, args, rank, dist=None, device=None):
     pct = lambda k: round(100.0 * counts[k] / (1 << args.log_n))   # noqa: E731
     wl = (f"header_range_512 stand-in (BASELINE configs[2]): one plonky2 proof, n=2^{args.log_n} rows x 135 wires, blow-up 8, cap height 4, "
           f"FRI arity 16 / 28 queries / 16 PoW bits; synthetic circuit {pct('poseidon')}% PoseidonGate / {pct('arithmetic')}% ArithmeticGate rows"
-          + (f", circuit flags {args.circuit_flags}" if getattr(args, "circuit_flags", 0) else ""))
+          + (f", circuit flags {args.circuit_flags}" if getattr(args, "circuit_flags", 0) else "")
+          + (" — NOT the headline mix: the recursive verifier's gate set in its declared row mix (--recursion-mix)" if getattr(args, "recursion_mix", False) else ""))
     def cleanup():
         circuit.free()
         ctx.free(d_w)
@@ -726,14 +731,40 @@ def compact_line(d, limit: int = 5900):
 
     c = walk(d)
     c["glossary"] = "profiles/bench_line_glossary.md"
-    order = [("chip_starks", "stage_ms_per_proof"), ("rotate", "tables"), ("dag_header_range_512_with_starks", "tables"),
-             ("dag_on_one_pool_over_all_gpus", "tables"),
-             ("dag_header_range_512_with_starks", "per_layer_ms_layer_barriers"), ("dag_header_range_512", "per_layer_ms_layer_barriers"),
-             ("dag_on_one_pool_over_all_gpus", "per_layer_ms_layer_barriers"),
-             ("alu_bound_dominant_kernel", "ubench_cycles_per_inst"), ("stage_alg_GBps",), ("sharded_one_proof", "rank0_stage_ms"),
-             ("dag_on_one_pool_over_all_gpus", "per_layer_ms"), ("dag_on_one_pool_over_all_gpus", "setup_seconds_by_worker"),
-             ("dag_header_range_512_with_starks", "per_layer_ms"), ("dag_header_range_512", "per_layer_ms"), ("rank_devices",),
-             ("recursion_circuits_alone", "gate_rows_map"), ("chip_starks",), ("rotate",)]
+    # the legs keep their headline numbers; detail tables (per-layer times, per-table shapes, stage splits of the chip proofs ...) are in
+    # the complete line only
+    keep = {
+        "dag": ("dag_seconds", "dag_seconds_all_passes", "lane_seconds_by_kind", "rank0_lane_seconds_by_kind", "jobs_by_worker", "workers_per_gpu",
+                "lanes_per_worker", "non_map_layers_ms_layer_barriers", "setup_seconds_untimed", "root", "output", "output_equals_host_computation",
+                "stark_proofs", "plonky2_proofs", "ranks", "with_stark_tables", "devices", "error", "backend", "seconds"),
+        "chip": ("ms_per_proof", "ms_per_proof_openings_digest", "rows_log2", "proof_bytes", "trace_generation_ms_gpu"),
+        "rotate": ("seconds", "seconds_all_passes", "seconds_by_kind", "output", "output_equals_host_computation", "stark_proofs", "setup_seconds_untimed", "error"),
+        "alone": ("log_n", "ms_per_proof", "ms_per_proof_two_gate_stand_in", "quotient_eval_ms", "quotient_by_kernel_ms"),
+    }
+
+    def slim(node, names):
+        return {k: v for k, v in node.items() if k in names} if isinstance(node, dict) else node
+
+    for leg in ("dag_header_range_512", "dag_header_range_512_with_starks"):
+        if isinstance(c.get(leg), dict):
+            c[leg] = slim(c[leg], keep["dag"])
+    pool = c.get("dag_on_one_pool_over_all_gpus")
+    if isinstance(pool, dict):
+        c["dag_on_one_pool_over_all_gpus"] = {k: (slim(v, keep["dag"]) if isinstance(v, dict) else v) for k, v in pool.items()}
+    if isinstance(c.get("chip_starks"), dict):
+        c["chip_starks"] = {k: (slim(v, keep["chip"]) if isinstance(v, dict) else v) for k, v in c["chip_starks"].items()}
+    if isinstance(c.get("rotate"), dict):
+        c["rotate"] = slim(c["rotate"], keep["rotate"])
+    alone = c.get("recursion_circuits_alone")
+    if isinstance(alone, dict):
+        c["recursion_circuits_alone"] = {k: (slim(v, keep["alone"]) if k in ("map", "reduce", "outer") else v) for k, v in alone.items() if k != "gate_rows_map"}
+    cb = c.get("cpu_baseline")
+    if isinstance(cb, dict) and isinstance(cb.get("sampled"), dict):
+        cb["sampled"].pop("stages_s", None)
+    order = [("alu_bound_dominant_kernel", "ubench_cycles_per_inst"), ("stage_alg_GBps",), ("sharded_one_proof", "rank0_stage_ms"),
+             ("dag_on_one_pool_over_all_gpus", "jobs_by_worker"), ("recursion_circuits_alone", "map_quotient_by_gate_ms_one_kernel_per_gate"),
+             ("alu_bound_dominant_kernel", "frac_at_pmc_run_clock"), ("alu_bound_dominant_kernel", "frac_quad_issue_model"),
+             ("rank_devices",), ("chip_starks",), ("rotate",)]
     dropped = []
 
     def drop(path):
