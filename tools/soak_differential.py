@@ -43,8 +43,12 @@ while time.time() < t_end:
             flags &= ~8                  # CosetInterpolationGate has degree 8
         if qdf < 5:
             flags &= ~(4 | 32)           # RandomAccess (degree 5) / Exponentiation (4) family; the U32 gates (degree 4) need qdf >= 5
+    mix = None
+    if qdf == 8 and rng.random() < 0.15:     # round 6: the DAG's circuit family — the recursive verifier's gate set in its declared row mix
+        from vectorx_amd.synth import RECURSION_FLAGS, RECURSIVE_VERIFIER_MIX
+        flags, mix, db = RECURSION_FLAGS, RECURSIVE_VERIFIER_MIX, max(db, 5)
     sc = SynthCircuit(db, seed=int(rng.integers(1, 1 << 30)), poseidon_percent=pct, witness_seed=int(rng.integers(1, 1 << 30)), flags=flags,
-                      quotient_degree_factor=qdf)
+                      quotient_degree_factor=qdf, mix=mix)
     sc.desc.pow_bits = int(rng.choice([0, 3, 8, 12]))
     if rng.random() < 0.3:
         sc.desc.num_challenges = 1
@@ -74,7 +78,7 @@ while time.time() < t_end:
     if world > (1 << sc.desc.cap_height):
         world = 1 << sc.desc.cap_height
     # progress on stderr + a watchdog: a case that stalls dumps every thread's Python stack and ends the run (rc != 0)
-    print(json.dumps({"case": n_ok + n_bad, "degree_bits": db, "flags": flags, "pct": pct, "qdf": qdf, "world": world, "overrides": overrides,
+    print(json.dumps({"case": n_ok + n_bad, "degree_bits": db, "flags": flags, "recursion_mix": mix is not None, "pct": pct, "qdf": qdf, "world": world, "overrides": overrides,
                       "pow_bits": int(sc.desc.pow_bits), "nch": int(sc.desc.num_challenges), "cap_height": int(sc.desc.cap_height),
                       "queries": int(sc.desc.num_query_rounds)}), file=sys.stderr, flush=True)
     faulthandler.dump_traceback_later(300 if db_max > 13 else 120, exit=True)
@@ -95,7 +99,7 @@ while time.time() < t_end:
         ok = False
     except vx.VxError:
         pass
-    key = f"flags{flags}/world{world}" + (f"/qdf{qdf}" if qdf != 8 else "") + (f"/{overrides}" if overrides else "")
+    key = f"flags{flags}" + ("mix" if mix is not None else "") + f"/world{world}" + (f"/qdf{qdf}" if qdf != 8 else "") + (f"/{overrides}" if overrides else "")
     by_kind[key] = by_kind.get(key, 0) + 1
     if ok:
         n_ok += 1

@@ -195,14 +195,18 @@ TG_HD int row_type(int rho, int NB, int np = NP) {
 // the full program does not hold (cannot happen for honest inputs).
 // `regs` = the instance's register file, NREG x 4 words (the device keeps it in LDS: indexed by the row's op, it would otherwise live in
 // scratch memory, whose latency every one of the 10 772 dependent rows would pay several times)
-TG_HD int simulate_instance(const Cols& c, const Sig& sg, RowVals* out, uint64_t (*regs)[4]) {
-  for (int r = 0; r < NREG; ++r)
-    for (int k = 0; k < 4; ++k) regs[r][k] = 0;
-  const int NB = c.NB, L = c.L;
-  int bad = 0;
-  for (int rho = 0; rho < L; ++rho) {
-    const Op& op = op_at(c, row_type(rho, NB, c.NP));
-    const int step = rho < c.NP ? 0 : (rho - c.NP) / NLOOP;
+// one row of the program: `op` is the row's operation, `step` the ladder step it belongs to.  Force-inlined: called with a COMPILE-TIME op
+// for the 42 rows of a ladder step (simulate_instance), the operation's fields fold into the code — no table fetch, no dispatch on the
+// kind of row, register-file addresses as constants; the diagnostic of profiles/r06_eddsa_simulate_analysis.md put that bookkeeping at
+// 13 of the kernel's 24 ms.
+#if defined(__HIPCC__) || defined(__clang__) || defined(__GNUC__)
+#define TG_ALWAYS_INLINE __attribute__((always_inline))
+#else
+#define TG_ALWAYS_INLINE
+#endif
+TG_HD TG_ALWAYS_INLINE void simulate_row(const Cols& c, const Sig& sg, RowVals* out, uint64_t (*regs)[4], const Op& op, int rho, int step, int& bad) {
+  const int NB = c.NB;
+  {
     RowVals& rv = out[rho];
     uint64_t x[4] = {0, 0, 0, 0}, y[4] = {0, 0, 0, 0}, e[4] = {0, 0, 0, 0}, z[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
     if (op.free_) {
@@ -258,6 +262,26 @@ TG_HD int simulate_instance(const Cols& c, const Sig& sg, RowVals* out, uint64_t
     if (op.one && !(z[0] == 1 && z[1] == 0 && z[2] == 0 && z[3] == 0)) bad = bad ? bad : 1;
     for (int k = 0; k < 4; ++k) regs[op.dst][k] = z[k], rv.x[k] = x[k], rv.y[k] = y[k], rv.z[k] = z[k], rv.q[k] = q[k];
   }
+}
+template <int I>
+struct LoopRows {   // rows I .. NLOOP - 1 of a ladder step, each with its operation as a constant
+  static TG_HD TG_ALWAYS_INLINE void run(const Cols& c, const Sig& sg, RowVals* out, uint64_t (*regs)[4], int rho0, int step, int& bad) {
+    simulate_row(c, sg, out, regs, OPS[NP + I], rho0 + I, step, bad);   // the base and the full program share the loop (checked in simulate_instance's test)
+    LoopRows<I + 1>::run(c, sg, out, regs, rho0, step, bad);
+  }
+};
+template <>
+struct LoopRows<NLOOP> {
+  static TG_HD TG_ALWAYS_INLINE void run(const Cols&, const Sig&, RowVals*, uint64_t (*)[4], int, int, int&) {}
+};
+TG_HD int simulate_instance(const Cols& c, const Sig& sg, RowVals* out, uint64_t (*regs)[4]) {
+  for (int r = 0; r < NREG; ++r)
+    for (int k = 0; k < 4; ++k) regs[r][k] = 0;
+  const int NB = c.NB;
+  int bad = 0;
+  for (int rho = 0; rho < c.NP; ++rho) simulate_row(c, sg, out, regs, op_at(c, rho), rho, 0, bad);
+  for (int step = 0; step < NB; ++step) LoopRows<0>::run(c, sg, out, regs, c.NP + NLOOP * step, step, bad);
+  for (int t = 0; t < c.NE; ++t) simulate_row(c, sg, out, regs, op_at(c, c.NP + NLOOP + t), c.NP + NLOOP * NB + t, 0, bad);
   return bad;
 }
 
