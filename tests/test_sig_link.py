@@ -102,3 +102,19 @@ def test_signatures_verify_through_tables_only_and_forgeries_unbalance_the_bus(o
     sink4, sink4_t, _ = ea.make_sink(lay, [link.verifier_tuple(pk, sig_flip)], ntuple=25, **CFG)
     _, lk4_t, _ = link.make_link([link.row_of(pk, sig_flip, dig)], **CFG)
     assert (sha_cl + ed_cl + closing(link.aux_columns, lk4_t) + closing(sink4.aux_fn, sink4_t)) % P != 0
+
+
+def test_a_bus_closes_only_when_every_challenge_set_closes_on_its_own():
+    """`GeneratedSignatureBus.closed()` added up the closing sums of ALL challenge sets; X + Y = 0 with X != 0 passed although
+    `vx_stark_verify_bus` checks every set by itself (single-set soundness).  Now index by index."""
+    from vectorx_amd import stark_chips
+    P = 0xFFFFFFFF00000001
+    bus = object.__new__(stark_chips.GeneratedSignatureBus)
+    bus.ctx = object()
+    key = id(bus.ctx)
+    bus.last = {key: (None, None, [[5, 9], [P - 5, P - 9]])}               # both sets close
+    assert bus.closed()
+    bus.last = {key: (None, None, [[5, 9], [P - 4, P - 10]])}              # set 0 is off by one, set 1 by minus one: the grand total is 0
+    assert (5 + 9 + P - 4 + P - 10) % P == 0 and not bus.closed()
+    bus.last = {key: (None, None, [[5, 9], [P - 5]])}                       # tables disagree on the number of sets
+    assert not bus.closed()
