@@ -46,36 +46,68 @@ struct RowVals {
 };
 
 typedef unsigned __int128 u128;
-// z = (x y + e) mod p canonical, quo = (x y + e - z) / p, for p = 2^255 - 19 and x, y, e < 2^255
+// add / subtract with carry: clang's builtins hand the device compiler the carry chain (v_addc_co_u32) instead of compare-and-select
+// sequences; g++ builds the TEST-ONLY host copy of this file
+#if defined(__clang__)
+#define TG_ADDC(a, b, cin, cout) __builtin_addcll((a), (b), (cin), (cout))
+#define TG_SUBC(a, b, cin, cout) __builtin_subcll((a), (b), (cin), (cout))
+#else
+static inline unsigned long long tg_addc(unsigned long long a, unsigned long long b, unsigned long long cin, unsigned long long* cout) {
+  const unsigned long long s1 = a + b, s2 = s1 + cin;
+  *cout = (unsigned long long)(s1 < a) | (unsigned long long)(s2 < s1);
+  return s2;
+}
+static inline unsigned long long tg_subc(unsigned long long a, unsigned long long b, unsigned long long cin, unsigned long long* cout) {
+  const unsigned long long t1 = a - b, t2 = t1 - cin;
+  *cout = (unsigned long long)(a < b) | (unsigned long long)(t1 < cin);
+  return t2;
+}
+#define TG_ADDC(a, b, cin, cout) tg_addc((a), (b), (cin), (cout))
+#define TG_SUBC(a, b, cin, cout) tg_subc((a), (b), (cin), (cout))
+#endif
+#if defined(__HIPCC__) || defined(__clang__)
+#define TG_UNROLL _Pragma("unroll")
+#else
+#define TG_UNROLL
+#endif
+// z = (x y + e) mod p canonical, quo = (x y + e - z) / p, for p = 2^255 - 19 and x, y, e < 2^255.
+// Round 6: every loop has a constant trip count and is unrolled, carries ride add-with-carry chains and the two "if it overflows"
+// steps are masks — the round-5 form had data-dependent loop bounds (`k < 4 && carry`), which put its arrays behind dynamic register
+// indexing (694 s_set_gpr_idx pairs and 1 800 s_nop in the kernel) on the one lane per signature that walks 10 772 dependent rows.
 TG_HD void mul_add_divmod(const uint64_t* x, const uint64_t* y, const uint64_t* e, uint64_t* z, uint64_t* quo) {
-  uint64_t v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (int i = 0; i < 4; ++i) {
-    uint64_t carry = 0;
-    for (int j = 0; j < 4; ++j) {
-      const u128 t = (u128)x[i] * y[j] + v[i + j] + carry;
-      v[i + j] = (uint64_t)t;
+  uint64_t v[8];
+  {  // the 512-bit product, row by row: v += x[i] * y << 64 i
+    unsigned long long carry = 0;
+    TG_UNROLL for (int j = 0; j < 4; ++j) {
+      const u128 t = (u128)x[0] * y[j] + carry;
+      v[j] = (uint64_t)t;
       carry = (uint64_t)(t >> 64);
     }
-    v[i + 4] = carry;
+    v[4] = carry;
+    TG_UNROLL for (int i = 1; i < 4; ++i) {
+      carry = 0;
+      TG_UNROLL for (int j = 0; j < 4; ++j) {
+        const u128 t = (u128)x[i] * y[j] + v[i + j] + carry;      // < 2^128: (2^64 - 1)^2 + 2 (2^64 - 1)
+        v[i + j] = (uint64_t)t;
+        carry = (uint64_t)(t >> 64);
+      }
+      v[i + 4] = carry;
+    }
   }
   {
-    uint64_t carry = 0;
-    for (int k = 0; k < 8; ++k) {
-      const u128 t = (u128)v[k] + (k < 4 ? e[k] : 0) + carry;
-      v[k] = (uint64_t)t;
-      carry = (uint64_t)(t >> 64);
-    }
+    unsigned long long c = 0;
+    TG_UNROLL for (int k = 0; k < 4; ++k) v[k] = TG_ADDC(v[k], e[k], c, &c);
+    TG_UNROLL for (int k = 4; k < 8; ++k) v[k] = TG_ADDC(v[k], 0ull, c, &c);
   }
   // V = H 2^255 + Lo = H p + (19 H + Lo)
   uint64_t H[4], lo[4];
-  for (int k = 0; k < 4; ++k) H[k] = (v[k + 3] >> 63) | ((k + 4 < 8 ? v[k + 4] : 0) << 1);
-  for (int k = 0; k < 4; ++k) lo[k] = v[k];
+  TG_UNROLL for (int k = 0; k < 4; ++k) H[k] = (v[k + 3] >> 63) | ((k + 4 < 8 ? v[k + 4] : 0) << 1);
+  TG_UNROLL for (int k = 0; k < 4; ++k) lo[k] = v[k];
   lo[3] &= 0x7FFFFFFFFFFFFFFFull;
-  for (int k = 0; k < 4; ++k) quo[k] = H[k];
   uint64_t v1[5];
   {
     uint64_t carry = 0;
-    for (int k = 0; k < 4; ++k) {
+    TG_UNROLL for (int k = 0; k < 4; ++k) {
       const u128 t = (u128)H[k] * 19 + lo[k] + carry;
       v1[k] = (uint64_t)t;
       carry = (uint64_t)(t >> 64);
@@ -85,38 +117,29 @@ TG_HD void mul_add_divmod(const uint64_t* x, const uint64_t* y, const uint64_t* 
   const uint64_t H1 = (v1[3] >> 63) | (v1[4] << 1);     // < 2^6
   v1[3] &= 0x7FFFFFFFFFFFFFFFull;
   {
-    uint64_t carry = H1;
-    for (int k = 0; k < 4 && carry; ++k) {
-      const uint64_t s = quo[k] + carry;
-      carry = s < quo[k];
-      quo[k] = s;
-    }
+    unsigned long long c = 0;                            // quo = H + H1
+    quo[0] = TG_ADDC(H[0], H1, c, &c);
+    TG_UNROLL for (int k = 1; k < 4; ++k) quo[k] = TG_ADDC(H[k], 0ull, c, &c);
   }
   {
-    uint64_t carry = 19 * H1;
-    for (int k = 0; k < 4; ++k) {
-      const uint64_t s = v1[k] + carry;
-      carry = s < v1[k];
-      z[k] = s;
-    }
+    unsigned long long c = 0;                            // z = v1 + 19 H1
+    z[0] = TG_ADDC(v1[0], 19 * H1, c, &c);
+    TG_UNROLL for (int k = 1; k < 4; ++k) z[k] = TG_ADDC(v1[k], 0ull, c, &c);
   }
-  // z < 2^255 + 2^11: at most one more p
-  const bool ge = z[3] > 0x7FFFFFFFFFFFFFFFull ||
-                  (z[3] == 0x7FFFFFFFFFFFFFFFull && z[2] == ~0ull && z[1] == ~0ull && z[0] >= 0xFFFFFFFFFFFFFFEDull);
-  if (ge) {
-    // z -= p  <=>  z += 19, then drop bit 255
-    uint64_t carry = 19;
-    for (int k = 0; k < 4; ++k) {
-      const uint64_t s = z[k] + carry;
-      carry = s < z[k];
-      z[k] = s;
-    }
-    z[3] &= 0x7FFFFFFFFFFFFFFFull;
-    uint64_t c1 = 1;
-    for (int k = 0; k < 4 && c1; ++k) {
-      quo[k] += 1;
-      c1 = quo[k] == 0;
-    }
+  // z < 2^255 + 2^11: at most one more p.  z >= p  <=>  z + 19 reaches 2^255; then z - p = (z + 19) mod 2^255 and quo += 1
+  uint64_t w[4];
+  {
+    unsigned long long c = 0;
+    w[0] = TG_ADDC(z[0], 19ull, c, &c);
+    TG_UNROLL for (int k = 1; k < 4; ++k) w[k] = TG_ADDC(z[k], 0ull, c, &c);
+  }
+  const uint64_t ge = 0 - (w[3] >> 63);                  // all ones when z >= p
+  w[3] &= 0x7FFFFFFFFFFFFFFFull;
+  TG_UNROLL for (int k = 0; k < 4; ++k) z[k] = (w[k] & ge) | (z[k] & ~ge);
+  {
+    unsigned long long c = 0;
+    quo[0] = TG_ADDC(quo[0], ge & 1, c, &c);
+    TG_UNROLL for (int k = 1; k < 4; ++k) quo[k] = TG_ADDC(quo[k], 0ull, c, &c);
   }
 }
 // the same for the modulus L (the group order), for the FULL program's two reduction rows: plain shift-and-subtract long division of the
@@ -164,6 +187,63 @@ TG_HD void mul_add_divmod_l(const uint64_t* x, const uint64_t* y, const uint64_t
   }
   for (int k = 0; k < 4; ++k) z[k] = r[k], quo[k] = q[k];     // the quotient fits 256 bits for the operands the program feeds (x y < 2^384)
 }
+// ---- the LINEAR rows -----------------------------------------------------------------------------------------------------------------
+// 20 of the 42 rows of a ladder step are not multiplications: the Y slot holds the CONSTANT 1, 2, p - 1 or p - 2 (additions, doublings,
+// subtractions written as x (p - 1) + e).  For canonical x, e (< p) the same z = (x y + e) mod p and quo = (x y + e - z) / p follow from
+// one or two additions / subtractions of p:
+//   y = c in {0, 1, 2}:      V = c x + e < 3 p:           subtract p while V >= p, quo = how often;
+//   y = p - c, c in {1, 2}:  V = x p - (c x - e):          z = e - c x + k p with the smallest k >= 0 (k <= c), quo = x - k.
+// Taken only where the row's operation says so at COMPILE time (simulate_row is specialised per row of the ladder step): as a run-time
+// test on y it cost more than it saved (profiles/r06_eddsa_simulate_analysis.md).  Branch-free: every lane walks its own signature.
+TG_HD constexpr int linear_kind(const uint64_t* y) {   // 0: not linear; 1 + c for y = c (c = 0, 1, 2); 4 + c for y = p - c (c = 1, 2)
+  return ((y[1] | y[2] | y[3]) == 0 && y[0] <= 2) ? 1 + (int)y[0]
+       : (y[3] == 0x7FFFFFFFFFFFFFFFull && y[2] == ~0ull && y[1] == ~0ull && (y[0] == 0xFFFFFFFFFFFFFFECull || y[0] == 0xFFFFFFFFFFFFFFEBull))
+             ? 4 + (int)(0xFFFFFFFFFFFFFFEDull - y[0]) : 0;
+}
+TG_HD bool below_p(const uint64_t* a) {
+  return a[3] < 0x7FFFFFFFFFFFFFFFull || (a[3] == 0x7FFFFFFFFFFFFFFFull && !(a[2] == ~0ull && a[1] == ~0ull && a[0] >= 0xFFFFFFFFFFFFFFEDull));
+}
+TG_HD void linear_row(int kind, const uint64_t* x, const uint64_t* e, uint64_t* z, uint64_t* quo) {
+  const uint64_t P5[5] = {0xFFFFFFFFFFFFFFEDull, ~0ull, ~0ull, 0x7FFFFFFFFFFFFFFFull, 0};
+  const int c = kind <= 3 ? kind - 1 : kind - 4;             // the small factor
+  uint64_t cx[5] = {0, 0, 0, 0, 0}, w[5] = {e[0], e[1], e[2], e[3], 0};
+  if (c == 1) {
+    TG_UNROLL for (int k = 0; k < 4; ++k) cx[k] = x[k];
+  } else if (c == 2) {
+    TG_UNROLL for (int k = 0; k < 4; ++k) cx[k] = (x[k] << 1) | (k ? x[k - 1] >> 63 : 0);
+    cx[4] = x[3] >> 63;
+  }
+  if (kind <= 3) {                                           // V = c x + e < 3 p: take p away while it fits
+    unsigned long long cy = 0;
+    TG_UNROLL for (int k = 0; k < 5; ++k) w[k] = TG_ADDC(w[k], cx[k], cy, &cy);
+    uint64_t cnt = 0;
+    TG_UNROLL for (int t = 0; t < 2; ++t) {
+      uint64_t d[5];
+      unsigned long long bw = 0;
+      TG_UNROLL for (int k = 0; k < 5; ++k) d[k] = TG_SUBC(w[k], P5[k], bw, &bw);
+      const uint64_t keep = bw - 1;                          // all ones when w >= p (no borrow)
+      TG_UNROLL for (int k = 0; k < 5; ++k) w[k] = (d[k] & keep) | (w[k] & ~keep);
+      cnt += keep & 1;
+    }
+    TG_UNROLL for (int k = 0; k < 4; ++k) z[k] = w[k];
+    quo[0] = cnt, quo[1] = quo[2] = quo[3] = 0;
+  } else {                                                   // z = e - c x + k p with the smallest k >= 0, quo = x - k
+    uint64_t d[5];
+    unsigned long long bw = 0;
+    TG_UNROLL for (int k = 0; k < 5; ++k) d[k] = TG_SUBC(w[k], cx[k], bw, &bw);     // two's complement, > -2^257
+    uint64_t kk = 0;
+    TG_UNROLL for (int t = 0; t < 2; ++t) {
+      const uint64_t neg = 0 - (d[4] >> 63);                 // all ones while the value is negative
+      unsigned long long cy = 0;
+      TG_UNROLL for (int k = 0; k < 5; ++k) d[k] = TG_ADDC(d[k], P5[k] & neg, cy, &cy);
+      kk += neg & 1;
+    }
+    TG_UNROLL for (int k = 0; k < 4; ++k) z[k] = d[k];
+    unsigned long long b2 = 0;                               // quo = x - k
+    quo[0] = TG_SUBC(x[0], kk, b2, &b2);
+    TG_UNROLL for (int k = 1; k < 4; ++k) quo[k] = TG_SUBC(x[k], 0ull, b2, &b2);
+  }
+}
 TG_HD void mulmod(const uint64_t* x, const uint64_t* y, uint64_t* z) {
   const uint64_t zero[4] = {0, 0, 0, 0};
   uint64_t q[4], t[4];
@@ -204,8 +284,7 @@ TG_HD int row_type(int rho, int NB, int np = NP) {
 #else
 #define TG_ALWAYS_INLINE
 #endif
-TG_HD TG_ALWAYS_INLINE void simulate_row(const Cols& c, const Sig& sg, RowVals* out, uint64_t (*regs)[4], const Op& op, int rho, int step, int& bad) {
-  const int NB = c.NB;
+TG_HD TG_ALWAYS_INLINE void simulate_row(const Cols& c, const Sig& sg, RowVals* out, uint64_t (*regs)[4], const Op& op, int rho, int sbit, int hbit, int& bad) {
   {
     RowVals& rv = out[rho];
     uint64_t x[4] = {0, 0, 0, 0}, y[4] = {0, 0, 0, 0}, e[4] = {0, 0, 0, 0}, z[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
@@ -234,8 +313,8 @@ TG_HD TG_ALWAYS_INLINE void simulate_row(const Cols& c, const Sig& sg, RowVals* 
     } else {
       for (int k = 0; k < 4; ++k) x[k] = regs[op.x][k];
       bool from_reg = op.ykind == 0, on = true;
-      if (op.ykind == 2) on = scalar_bit(sg.s, NB, step) != 0;
-      if (op.ykind == 3) on = scalar_bit(sg.h, NB, step) != 0, from_reg = on;
+      if (op.ykind == 2) on = sbit != 0;
+      if (op.ykind == 3) on = hbit != 0, from_reg = on;
       for (int k = 0; k < 4; ++k) y[k] = from_reg ? regs[op.yreg][k] : (op.ykind == 1 || (op.ykind == 2 && on) ? op.con[k] : op.coff[k]);
       if (op.e >= 0) for (int k = 0; k < 4; ++k) e[k] = regs[op.e][k];
       if (op.qzero) {                                   // an integer identity: Z is what the row requires, x y + e must BE it
@@ -256,7 +335,10 @@ TG_HD TG_ALWAYS_INLINE void simulate_row(const Cols& c, const Sig& sg, RowVals* 
       } else if (op.modl) {
         mul_add_divmod_l(x, y, e, z, q);
       } else {
-        mul_add_divmod(x, y, e, z, q);
+        // a row whose Y slot is a small / negated-small CONSTANT (known when `op` is a compile-time constant: the ladder rows)
+        const int lk = op.ykind == 1 ? linear_kind(op.con) : 0;
+        if (lk && below_p(x) && below_p(e)) linear_row(lk, x, e, z, q);
+        else mul_add_divmod(x, y, e, z, q);
       }
     }
     if (op.one && !(z[0] == 1 && z[1] == 0 && z[2] == 0 && z[3] == 0)) bad = bad ? bad : 1;
@@ -265,23 +347,31 @@ TG_HD TG_ALWAYS_INLINE void simulate_row(const Cols& c, const Sig& sg, RowVals* 
 }
 template <int I>
 struct LoopRows {   // rows I .. NLOOP - 1 of a ladder step, each with its operation as a constant
-  static TG_HD TG_ALWAYS_INLINE void run(const Cols& c, const Sig& sg, RowVals* out, uint64_t (*regs)[4], int rho0, int step, int& bad) {
-    simulate_row(c, sg, out, regs, OPS[NP + I], rho0 + I, step, bad);   // the base and the full program share the loop (checked in simulate_instance's test)
-    LoopRows<I + 1>::run(c, sg, out, regs, rho0, step, bad);
+  static TG_HD TG_ALWAYS_INLINE void run(const Cols& c, const Sig& sg, RowVals* out, uint64_t (*regs)[4], int rho0, int sbit, int hbit, int& bad) {
+    simulate_row(c, sg, out, regs, OPS[NP + I], rho0 + I, sbit, hbit, bad);   // the base and the full program share the loop (the cell-by-cell tests cover both)
+    LoopRows<I + 1>::run(c, sg, out, regs, rho0, sbit, hbit, bad);
   }
 };
 template <>
 struct LoopRows<NLOOP> {
-  static TG_HD TG_ALWAYS_INLINE void run(const Cols&, const Sig&, RowVals*, uint64_t (*)[4], int, int, int&) {}
+  static TG_HD TG_ALWAYS_INLINE void run(const Cols&, const Sig&, RowVals*, uint64_t (*)[4], int, int, int, int&) {}
 };
 TG_HD int simulate_instance(const Cols& c, const Sig& sg, RowVals* out, uint64_t (*regs)[4]) {
   for (int r = 0; r < NREG; ++r)
     for (int k = 0; k < 4; ++k) regs[r][k] = 0;
   const int NB = c.NB;
   int bad = 0;
-  for (int rho = 0; rho < c.NP; ++rho) simulate_row(c, sg, out, regs, op_at(c, rho), rho, 0, bad);
-  for (int step = 0; step < NB; ++step) LoopRows<0>::run(c, sg, out, regs, c.NP + NLOOP * step, step, bad);
-  for (int t = 0; t < c.NE; ++t) simulate_row(c, sg, out, regs, op_at(c, c.NP + NLOOP + t), c.NP + NLOOP * NB + t, 0, bad);
+  // the scalars' bits: a 64-bit word of S and of h is fetched once per 64 ladder steps (the rows used to read the signature from global
+  // memory on every bit-dependent row: six dependent loads per step for the one wavefront there is)
+  const int s0 = scalar_bit(sg.s, NB, 0), h0 = scalar_bit(sg.h, NB, 0);
+  for (int rho = 0; rho < c.NP; ++rho) simulate_row(c, sg, out, regs, op_at(c, rho), rho, s0, h0, bad);
+  uint64_t sw = 0, hw = 0;
+  for (int step = 0; step < NB; ++step) {
+    const int b = NB - 1 - step;
+    if (step == 0 || (b & 63) == 63) sw = sg.s[b >> 6], hw = sg.h[b >> 6];
+    LoopRows<0>::run(c, sg, out, regs, c.NP + NLOOP * step, (int)((sw >> (b & 63)) & 1), (int)((hw >> (b & 63)) & 1), bad);
+  }
+  for (int t = 0; t < c.NE; ++t) simulate_row(c, sg, out, regs, op_at(c, c.NP + NLOOP + t), c.NP + NLOOP * NB + t, s0, h0, bad);
   return bad;
 }
 
