@@ -12,22 +12,32 @@ typedef unsigned __int128 u128;
 static const u64 P = 0xFFFFFFFF00000001ULL;
 static const u64 EPS = 0xFFFFFFFFULL;
 
-static inline u64 canon(u64 x) { return x >= P ? x - P : x; }
+// The challenger is ~130 DEPENDENT permutations per plonky2 proof and ~1 000 per wide STARK table on one host core, inside every
+// proof's wall time.  A carry that happens every other time on random data (the sum of two field elements, the low word plus hl * EPS)
+// is a MASK — as a branch it mispredicted half the time —, one that happens once in 2^32 (the borrow of lo - hh, a result >= p) stays a
+// predicted branch: 6.7 -> 3.3 us per permutation on the build machine (round 6).
+static inline u64 canon(u64 x) { return __builtin_expect(x >= P, 0) ? x - P : x; }
 static inline u64 add(u64 a, u64 b) {
-  u64 s = a + b;
-  if (s < a) s += EPS;
+  u64 s;
+  const u64 c = __builtin_add_overflow(a, b, &s);
+  s += EPS & (0 - c);
   return canon(s);
 }
-static inline u64 sub(u64 a, u64 b) { return a >= b ? a - b : a + (P - b); }
+static inline u64 sub(u64 a, u64 b) {
+  u64 d;
+  const u64 bw = __builtin_sub_overflow(a, b, &d);
+  return d + (P & (0 - bw));
+}
 static inline u64 neg(u64 a) { return a ? P - a : 0; }
 static inline u64 reduce128(u128 x) {
   u64 lo = (u64)x, hi = (u64)(x >> 64);
   u64 hh = hi >> 32, hl = hi & EPS;
   u64 t = lo - hh;
-  if (lo < hh) t -= EPS;
+  if (__builtin_expect(lo < hh, 0)) t -= EPS;
   u64 m = hl * EPS;
-  u64 r = t + m;
-  if (r < m) r += EPS;
+  u64 r;
+  const u64 c = __builtin_add_overflow(t, m, &r);
+  r += EPS & (0 - c);
   return canon(r);
 }
 static inline u64 mul(u64 a, u64 b) { return reduce128((u128)a * b); }
