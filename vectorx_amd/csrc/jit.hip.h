@@ -128,12 +128,13 @@ struct JitAuxMode {
 };
 static thread_local JitAuxMode g_jit_aux;
 static thread_local bool g_jit_lds_wires = false;   // fused gate kernel: LDW reads the row's wires from the workgroup's LDS tile (already canonical)
-static void jit_emit_code(std::ostringstream& s, std::vector<JitIns> code, int nch, bool air, int air_ncols);
+static void jit_emit_code(std::ostringstream& s, std::vector<JitIns> code, int nch, bool air, int air_ncols, int k0 = 0);
 static void jit_emit_program(std::ostringstream& s, const uint64_t* prog, int nch, bool air, int air_ncols = 0) {
   jit_emit_code(s, jit_decode(prog), nch, air, air_ncols);
 }
 // `code`: a self-contained straight-line sequence (every register is written before it is read)
-static void jit_emit_code(std::ostringstream& s, std::vector<JitIns> code, int nch, bool air, int air_ncols) {
+// `k0`: position (among its gate's constraints) of the first constraint `code` pushes — a CHUNK of a gate's program (jit_fused_plan)
+static void jit_emit_code(std::ostringstream& s, std::vector<JitIns> code, int nch, bool air, int air_ncols, int k0) {
   typedef JitIns Ins;
   // AIR: columns >= air_ncols are second-round (aux) columns, held in their own LDE with the same row stride
   auto col = [&](int a) {
@@ -196,7 +197,7 @@ static void jit_emit_code(std::ostringstream& s, std::vector<JitIns> code, int n
       canon_reg[r] = true;
     }
   };
-  int k = 0;
+  int k = k0;
   for (const Ins& I : code) {
     if (I.skip) continue;
     if (I.op != VX_OP_PUSH && I.op != VX_OP_LDI) imm_known[I.dst] = false;
@@ -415,37 +416,135 @@ struct JitFusedParams {  // mirrored textually in jit_fused_source()
   u64 zh_inv[VX_MAX_RATE];
   JitGateRt g[VX_JIT_FUSED_MAX];
 };
+struct JitFusedItem {   // a run of consecutive constraints of ONE gate: the code that computes them (backward slice of what came before + the run)
+  size_t gate;          // index into `progs`
+  int push_begin;       // position of its first constraint among the gate's constraints
+  size_t cost;          // estimated VALU instructions
+  std::vector<JitIns> code;
+};
 struct JitFusedPlan {
   int waves = 0, max_col = 0;
-  std::vector<std::vector<size_t>> of_wave;   // program indices per wave
-  std::vector<size_t> cost;                   // estimated VALU instructions per program
+  std::vector<JitFusedItem> items;
+  std::vector<std::vector<size_t>> of_wave;   // item indices per wave, grouped by gate
 };
+static size_t jit_cost_of(const std::vector<JitIns>& code, int nch) {
+  size_t c = 0;
+  for (const JitIns& I : code) {
+    switch (I.op) {
+      case VX_OP_MUL: c += 14; break;
+      case VX_OP_ADD: case VX_OP_SUB: c += 5; break;
+      case VX_OP_PUSH: c += 7 * (size_t)nch; break;
+      default: c += 1; break;
+    }
+  }
+  return c;
+}
+// instructions [begin, end) of a straight-line program preceded by the backward slice of everything they read but do not write
+static std::vector<JitIns> jit_slice(const std::vector<JitIns>& code, size_t begin, size_t end) {
+  auto srcs = [](const JitIns& I, int out[2]) {
+    int k = 0;
+    if (I.op == VX_OP_ADD || I.op == VX_OP_SUB || I.op == VX_OP_MUL) out[k++] = I.a, out[k++] = I.b;
+    else if (I.op == VX_OP_PUSH) out[k++] = I.a;
+    return k;
+  };
+  bool written[VX_PROGRAM_REGS] = {false}, need[VX_PROGRAM_REGS] = {false};
+  for (size_t i = begin; i < end; ++i) {
+    int sr[2];
+    const int k = srcs(code[i], sr);
+    for (int q = 0; q < k; ++q)
+      if (!written[sr[q]]) need[sr[q]] = true;
+    if (code[i].op != VX_OP_PUSH) written[code[i].dst] = true;
+  }
+  std::vector<char> take(begin, 0);
+  for (size_t i = begin; i-- > 0;) {
+    const JitIns& I = code[i];
+    if (I.op == VX_OP_PUSH || !need[I.dst]) continue;
+    take[i] = 1;
+    need[I.dst] = false;
+    int sr[2];
+    const int k = srcs(I, sr);
+    for (int q = 0; q < k; ++q) need[sr[q]] = true;
+  }
+  std::vector<JitIns> sub;
+  for (size_t i = 0; i < begin; ++i)
+    if (take[i]) sub.push_back(code[i]);
+  sub.insert(sub.end(), code.begin() + begin, code.begin() + end);
+  return sub;
+}
+// Work items = runs of constraints.  Nine gates do not balance on eight waves (the workgroup lasts as long as its longest wave: 5.5
+// cycles per instruction against the issue floor's 4, profiles/r06_pmc_sq_prove_recursion.md), so a gate's program is cut at constraint
+// boundaries into chunks of about two thirds of a wave's fair share; a chunk re-creates the registers it reads with the backward slice of
+// the earlier code (the gates' chains — Reducing, Exponentiation, CosetInterpolation — restart from WIRES every step, so slices are a few
+// loads), pushes against its own alpha powers (k0), and the chunks are dealt longest first.  A sum of filtered partial sums is the same
+// field element as the filtered sum: byte-identical proofs (tests/test_gpu_prover.py).
 static JitFusedPlan jit_fused_plan(const std::vector<const uint64_t*>& progs, int nch) {
   JitFusedPlan P;
-  for (const uint64_t* prog : progs) {
-    size_t c = 0;
-    for (const JitIns& I : jit_decode(prog)) {
-      switch (I.op) {
-        case VX_OP_MUL: c += 14; break;
-        case VX_OP_ADD: case VX_OP_SUB: c += 5; break;
-        case VX_OP_PUSH: c += 7 * (size_t)nch; break;
-        case VX_OP_LDW: P.max_col = std::max(P.max_col, I.a + 1), c += 1; break;
-        default: c += 1; break;
-      }
-    }
-    P.cost.push_back(c + 150);   // + the selector filter
-  }
   const char* we = getenv("VX_JIT_FUSED_WAVES");
   P.waves = std::max(1, std::min<int>({we && atoi(we) > 0 ? atoi(we) : VX_JIT_FUSED_WAVES, 16, (int)progs.size()}));
-  P.of_wave.resize(P.waves);
-  std::vector<size_t> order(progs.size()), load(P.waves, 0);
-  for (size_t i = 0; i < order.size(); ++i) order[i] = i;
-  std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return P.cost[a] > P.cost[b]; });
-  for (size_t q : order) {
-    const size_t w = std::min_element(load.begin(), load.end()) - load.begin();
-    P.of_wave[w].push_back(q);
-    load[w] += P.cost[q];
+  std::vector<std::vector<JitIns>> codes;
+  size_t total = 0;
+  for (const uint64_t* prog : progs) {
+    codes.push_back(jit_decode(prog));
+    for (const JitIns& I : codes.back())
+      if (I.op == VX_OP_LDW) P.max_col = std::max(P.max_col, I.a + 1);
+    total += jit_cost_of(codes.back(), nch);
   }
+  // VX_JIT_FUSED_CHUNK: 0 = whole gates; default = two thirds of a wave's fair share.  Measured at 2^18 rows, nine recursion gates, same
+  // box: whole gates 2.59 ms (38 spilled VGPRs: the longest gate's block), a third of a share 2.80 (24 chunks: their slices and filters
+  // cost more than the balance returns), two thirds 2.53 (no spills), a whole share 2.74 — balance is NOT what holds this kernel at 5.5
+  // cycles per instruction; the chunks stay for the spills they remove.
+  const char* ce = getenv("VX_JIT_FUSED_CHUNK");
+  const size_t limit = ce ? (size_t)atoi(ce) : std::max<size_t>(400, 2 * total / ((size_t)P.waves * 3));
+  for (size_t g = 0; g < codes.size(); ++g) {
+    const std::vector<JitIns>& code = codes[g];
+    size_t begin = 0;
+    int pushes = 0;
+    while (begin < code.size()) {
+      size_t end = begin, cost = 0;
+      int np = 0;
+      while (end < code.size()) {
+        const bool push = code[end].op == VX_OP_PUSH;
+        cost += code[end].op == VX_OP_MUL ? 14 : (code[end].op == VX_OP_ADD || code[end].op == VX_OP_SUB) ? 5 : push ? 7 * (size_t)nch : 1;
+        ++end;
+        if (push) {
+          ++np;
+          if (limit && cost >= limit) break;
+        }
+      }
+      if (end < code.size()) {   // never leave a tail without constraints
+        bool more = false;
+        for (size_t i = end; i < code.size(); ++i) more = more || code[i].op == VX_OP_PUSH;
+        if (!more) end = code.size();
+      }
+      JitFusedItem it;
+      it.gate = g, it.push_begin = pushes;
+      it.code = jit_slice(code, begin, end);
+      it.cost = jit_cost_of(it.code, nch);
+      P.items.push_back(std::move(it));
+      pushes += np;
+      begin = end;
+    }
+  }
+  P.of_wave.resize(P.waves);
+  std::vector<size_t> order(P.items.size()), load(P.waves, 0);
+  for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return P.items[a].cost > P.items[b].cost; });
+  std::vector<std::vector<char>> has(P.waves, std::vector<char>(progs.size(), 0));
+  for (size_t q : order) {
+    // the least loaded wave; a wave that already holds a chunk of this gate saves the selector filter (150): prefer it on a near tie
+    size_t best = 0, best_load = (size_t)-1;
+    for (int w = 0; w < P.waves; ++w) {
+      const size_t eff = load[w] + (has[w][P.items[q].gate] ? 0 : 150);
+      if (eff < best_load) best_load = eff, best = (size_t)w;
+    }
+    P.of_wave[best].push_back(q);
+    load[best] = best_load + P.items[q].cost;
+    has[best][P.items[q].gate] = 1;
+  }
+  for (auto& v : P.of_wave)   // chunks of one gate next to each other, in program order: one filter, one pair of accumulators per gate and wave
+    std::stable_sort(v.begin(), v.end(), [&](size_t a, size_t b) {
+      return P.items[a].gate != P.items[b].gate ? P.items[a].gate < P.items[b].gate : P.items[a].push_begin < P.items[b].push_begin;
+    });
   return P;
 }
 // can this gate set run as one fused kernel?  (at least two gates, no more than the parameter block holds, a wire tile that leaves room
@@ -514,23 +613,30 @@ extern "C" __global__ __launch_bounds__(64 * FW, FWPS) void vx_program_gates_fus
 )VXJIT";
   for (int w = 0; w < W; ++w) {
     s << (w ? "  else if" : "  if") << " (wid == " << w << "u) {\n";
-    for (size_t q : P.of_wave[w]) {
-      s << "  {  // program gate, slot " << q << " (estimated " << P.cost[q] << " instructions)\n"
+    const std::vector<size_t>& mine = P.of_wave[w];
+    for (size_t at = 0; at < mine.size();) {
+      const size_t q = P.items[mine[at]].gate;
+      s << "  {  // program gate, slot " << q << "\n"
            "    const JitGateRt G = p.g[" << q << "];\n"
            "    const u64 s = CS[(size_t)G.selector_index * N + i];\n"
            "    u64 filter = 1;\n"
            "    for (int q = G.group_start; q < G.group_end; ++q)\n"
            "      if (q != G.gate_index) filter = gl_mul(filter, gl_sub((u64)q, s));\n"
            "    if (nsel > 1) filter = gl_mul(filter, gl_sub(0xFFFFFFFFULL, s));\n"
-           "    dot3 A0 = {0, 0, 0}, A1 = {0, 0, 0};\n"
-           "    u64 R[VX_PROGRAM_REGS];\n"
-           // the same alpha-power limbs / the same wire cells are read by the blocks of different waves: laundering the two bases per
-           // block keeps the compiler from hoisting those loads above the wave branch (it did: 248 SGPR and 285 VGPR spills)
-           "    const Limbs3x2* AL_ = AL0; asm volatile(\"\" : \"+s\"(AL_)); const Limbs3x2* __restrict__ AL = AL_;\n"
-           "    u32 lane = lane0; asm volatile(\"\" : \"+v\"(lane));\n";
-      g_jit_lds_wires = true;
-      jit_emit_program(s, progs[q], nch, false);
-      g_jit_lds_wires = false;
+           "    dot3 A0 = {0, 0, 0}, A1 = {0, 0, 0};\n";
+      for (; at < mine.size() && P.items[mine[at]].gate == q; ++at) {
+        const JitFusedItem& it = P.items[mine[at]];
+        s << "    {  // constraints from " << it.push_begin << " on (estimated " << it.cost << " instructions)\n"
+             "    u64 R[VX_PROGRAM_REGS];\n"
+             // the same alpha-power limbs / the same wire cells are read by the blocks of different waves: laundering the two bases per
+             // block keeps the compiler from hoisting those loads above the wave branch (it did: 248 SGPR and 285 VGPR spills)
+             "    const Limbs3x2* AL_ = AL0; asm volatile(\"\" : \"+s\"(AL_)); const Limbs3x2* __restrict__ AL = AL_;\n"
+             "    u32 lane = lane0; asm volatile(\"\" : \"+v\"(lane));\n";
+        g_jit_lds_wires = true;
+        jit_emit_code(s, it.code, nch, false, 0, it.push_begin);
+        g_jit_lds_wires = false;
+        s << "    }\n";
+      }
       s << "    t0 = gl_mad(filter, dot3_reduce_nc(A0), t0);\n";
       if (nch > 1) s << "    t1 = gl_mad(filter, dot3_reduce_nc(A1), t1);\n";
       s << "    (void)A1;\n  }\n";

@@ -24,6 +24,7 @@ struct vx_circuit {
   std::vector<hipFunction_t> jit_fns;  // native kernels (jit.hip.h), one per GROUP of program gates; empty -> interpreter
   std::vector<std::vector<size_t>> jit_groups;  // jit_fns[i] evaluates the gates jit_gates[jit_groups[i][..]]
   std::vector<int> jit_gates;         // gate index of each block of that kernel, in order
+  int jit_fused_waves = 0;               // wavefronts per workgroup of that kernel (a function of the gate set: jit_fused_plan)
   hipFunction_t jit_fused_fn = nullptr;  // ALL program gates in one kernel that stages the wires through LDS once (jit.hip.h, round 6); then jit_fns is empty
   std::vector<std::string> jit_stage;  // profile stage of each launch: "qgate_<gate index>[+<gate index>...]" (vx_prof_get; the caller knows its gate order)
   std::vector<uint64_t> programs_host;  // host copy of the programs (vx_verify evaluates gates at zeta on the host)
@@ -156,6 +157,7 @@ static int circuit_create(vx_ctx* c, const vx_circuit_desc* d, vx_circuit** out)
       if (why.empty() && jit_fused_applicable(progs, d->num_challenges)) {
         std::string fwhy;   // a failure here is not fatal: the gates fall back to one kernel each
         k->jit_fused_fn = jit_get_fused_gates(progs, d->num_challenges, c->device, &fwhy);
+        if (k->jit_fused_fn) k->jit_fused_waves = jit_fused_plan(progs, d->num_challenges).waves;
       }
       if (why.empty() && !k->jit_fused_fn) k->jit_groups = jit_gate_groups(progs);
       for (size_t gi = 0; gi < k->jit_groups.size() && why.empty(); ++gi) {
@@ -1118,9 +1120,7 @@ static int prove_impl(vx_ctx* c, vx_circuit* k, const u64* wires_in, bool wires_
               const int g = k->jit_gates[q];
               fp.g[q] = JitGateRt{g, k->gates[g].selector_index, k->gates[g].group_start, k->gates[g].group_end};
             }
-            std::vector<const uint64_t*> progs_h;   // the plan (waves per workgroup) is a function of the programs alone
-            for (int g : k->jit_gates) progs_h.push_back(k->programs_host.data() + k->prog_off[g]);
-            const int waves = jit_fused_plan(progs_h, nch).waves;
+            const int waves = k->jit_fused_waves;
             void* args[] = {&fp};
             ProfScope psj(c, "quotient_program_gates_jit");
             HIPCHK(hipModuleLaunchKernel(k->jit_fused_fn, (unsigned)((Nl + 63) / 64), 1, 1, 64 * waves, 1, 1, 0, c->stream, args, nullptr));
