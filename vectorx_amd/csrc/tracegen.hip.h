@@ -274,6 +274,105 @@ __global__ __launch_bounds__(64) void tg_ed_simulate_kernel(tg::ed::Cols c, cons
   const int why = tg::ed::simulate_instance(c, u < nsig ? sigs[u] : filler, vals + (size_t)u * c.L, regs[threadIdx.x]);
   if (why && u < nsig) atomicExch(bad, (why << 24) | (u + 1));
 }
+// ---- the same simulation with FOUR LANES PER SIGNATURE (round 6) --------------------------------------------------------------------
+// One lane per signature walks 10 772 dependent rows and leaves all but two wavefronts of the chip idle; nothing hides its instruction
+// latency.  But the 42 rows of a ladder step are 13 LEVELS of up to four mutually independent rows of one kind — three or four
+// multiplications of a doubling / a mixed addition, three or four additions and subtractions (tools/gen_tracegen_consts.py levelise ->
+// LEVELS in tracegen_eddsa_ops.h) — so four adjacent lanes take a level at a time: every lane reads its row's operands from the
+// signature's register file in LDS (all reads of a level precede its writes: lockstep lanes of one wavefront), runs the level's kind
+// of row (mul_add_divmod or linear_row: the same functions the one-lane walk and the host test build use), writes its destination
+// register and its row's x / y / z / q.  13 row-times per step instead of 42.  The prologue and the epilogue (20 - 43 rows of 10 772, the
+// inversions among them) stay with lane 0 of the group.  Same cells as the one-lane kernel (tests/test_gpu_tracegen.py compares the
+// trace with the numpy generator cell by cell); VX_TRACE_EDDSA_ONE_LANE=1 keeps the one-lane kernel.
+template <int LV>
+__device__ __forceinline__ void tg_ed_level(tg::ed::RowVals* __restrict__ out, uint64_t (*regs)[4], const uint64_t (*ycon)[4][4], const uint64_t (*ycoff)[4][4],
+                                            int j, bool active, int rho0, int sbit, int hbit) {
+  using namespace tg::ed;
+  constexpr LvRow r0 = LEVELS[LV][0], r1 = LEVELS[LV][1], r2 = LEVELS[LV][2], r3 = LEVELS[LV][3];
+  auto sel = [&](int a0, int a1, int a2, int a3) { return j == 0 ? a0 : j == 1 ? a1 : j == 2 ? a2 : a3; };
+  const int row = sel(r0.row, r1.row, r2.row, r3.row), xi = sel(r0.x, r1.x, r2.x, r3.x), ei = sel(r0.e, r1.e, r2.e, r3.e), dst = sel(r0.dst, r1.dst, r2.dst, r3.dst);
+  uint64_t x[4], y[4], e[4], z[4], q[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) x[k] = regs[xi][k];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) e[k] = regs[ei < 0 ? 0 : ei][k] & (ei < 0 ? 0ull : ~0ull);
+  if constexpr (LEVEL_LIN[LV] == 0) {
+    const int yk = sel(r0.ykind, r1.ykind, r2.ykind, r3.ykind), yreg = sel(r0.yreg, r1.yreg, r2.yreg, r3.yreg);
+    const bool on = yk == 2 ? sbit != 0 : hbit != 0;
+    const bool from_reg = yk == 0 || (yk == 3 && on), from_con = yk == 1 || (yk == 2 && on);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint64_t yr = regs[yreg][k], yc = ycon[LV][j][k], yo = ycoff[LV][j][k];
+      y[k] = from_reg ? yr : (from_con ? yc : yo);
+    }
+    mul_add_divmod(x, y, e, z, q);
+  } else {
+    const int lin = sel(r0.lin, r1.lin, r2.lin, r3.lin);          // linear_kind's code: 1 + c for Y = c, 4 + c for Y = p - c
+    const uint64_t cc = (uint64_t)(lin <= 3 ? lin - 1 : lin - 4);
+    const uint64_t neg = lin <= 3 ? 0ull : ~0ull;                  // Y = p - c: the words of p with c taken off the lowest
+    y[0] = neg ? 0xFFFFFFFFFFFFFFEDull - cc : cc, y[1] = neg, y[2] = neg, y[3] = neg & 0x7FFFFFFFFFFFFFFFull;
+    if (below_p(x) && below_p(e)) linear_row(lin, x, e, z, q);
+    else mul_add_divmod(x, y, e, z, q);                            // (a non-canonical register cannot occur in the ladder; exactness first)
+  }
+  if (row >= 0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) regs[dst][k] = z[k];
+    if (active) {
+      RowVals& rv = out[rho0 + row];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) rv.x[k] = x[k], rv.y[k] = y[k], rv.z[k] = z[k], rv.q[k] = q[k];
+    }
+  }
+  __syncthreads();   // one wavefront per block: orders the level's LDS writes before the next level's reads, for the compiler too
+}
+template <int LV>
+struct TgEdLevels {
+  static __device__ __forceinline__ void run(tg::ed::RowVals* __restrict__ out, uint64_t (*regs)[4], const uint64_t (*ycon)[4][4], const uint64_t (*ycoff)[4][4], int j,
+                                             bool active, int rho0, int sbit, int hbit) {
+    tg_ed_level<LV>(out, regs, ycon, ycoff, j, active, rho0, sbit, hbit);
+    TgEdLevels<LV + 1>::run(out, regs, ycon, ycoff, j, active, rho0, sbit, hbit);
+  }
+};
+template <>
+struct TgEdLevels<tg::ed::NLEV> {
+  static __device__ __forceinline__ void run(tg::ed::RowVals*, uint64_t (*)[4], const uint64_t (*)[4][4], const uint64_t (*)[4][4], int, bool, int, int, int) {}
+};
+__global__ __launch_bounds__(64) void tg_ed_simulate4_kernel(tg::ed::Cols c, const tg::ed::Sig* __restrict__ sigs, int nsig, tg::ed::Sig filler, int ninst,
+                                                             tg::ed::RowVals* __restrict__ vals, int* __restrict__ bad) {
+  using namespace tg::ed;
+  __shared__ uint64_t regs[16][NREG][4];
+  __shared__ uint64_t ycon[NLEV][4][4], ycoff[NLEV][4][4];
+  for (int t = threadIdx.x; t < NLEV * 16; t += 64) {
+    (&ycon[0][0][0])[t] = (&LEVEL_CON[0][0][0])[t];
+    (&ycoff[0][0][0])[t] = (&LEVEL_COFF[0][0][0])[t];
+  }
+  const int grp = threadIdx.x >> 2, j = threadIdx.x & 3;
+  const int u = blockIdx.x * 16 + grp;
+  const bool active = u < ninst;
+  const Sig& sg = active && u < nsig ? sigs[u] : filler;
+  RowVals* out = vals + (size_t)(active ? u : 0) * c.L;
+  uint64_t (*rg)[4] = regs[grp];
+  const int NB = c.NB;
+  int why = 0;
+  const int s0 = scalar_bit(sg.s, NB, 0), h0 = scalar_bit(sg.h, NB, 0);
+  if (j == 0) {
+    for (int r = 0; r < NREG; ++r)
+      for (int k = 0; k < 4; ++k) rg[r][k] = 0;
+    if (active)
+      for (int rho = 0; rho < c.NP; ++rho) simulate_row(c, sg, out, rg, op_at(c, rho), rho, s0, h0, why);
+  }
+  __syncthreads();
+  uint64_t sw = 0, hw = 0;
+  for (int step = 0; step < NB; ++step) {
+    const int b = NB - 1 - step;
+    if (step == 0 || (b & 63) == 63) sw = sg.s[b >> 6], hw = sg.h[b >> 6];
+    TgEdLevels<0>::run(out, rg, ycon, ycoff, j, active, c.NP + NLOOP * step, (int)((sw >> (b & 63)) & 1), (int)((hw >> (b & 63)) & 1));
+  }
+  if (j == 0 && active) {
+    for (int t = 0; t < c.NE; ++t) simulate_row(c, sg, out, rg, op_at(c, c.NP + NLOOP + t), c.NP + NLOOP * NB + t, s0, h0, why);
+    if (why && u < nsig) atomicExch(bad, (why << 24) | (u + 1));
+  }
+}
 // results[u][w] = z of rows XROW / YROW of instance u (the affine x, y the instance arrives at)
 __global__ void tg_ed_results_kernel(const tg::ed::RowVals* __restrict__ vals, int nsig, int L, int xrow, u64* __restrict__ results) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -370,8 +469,13 @@ static int tg_trace_eddsa(vx_ctx* c, int degree_bits, int scalar_bits, int full,
     if (e == hipSuccess) e = hipMemsetAsync(d_bad, 0, 256, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_rsrc, &rsrc, sizeof rsrc, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) {
-      hipLaunchKernelGGL(tg_ed_simulate_kernel, dim3((ninst + 63) / 64), dim3(64), 0, c->stream, cl, (const tg::ed::Sig*)d_sigs, num_sigs, filler, ninst,
-                         (tg::ed::RowVals*)d_vals, (int*)d_bad);
+      static const bool one_lane = getenv("VX_TRACE_EDDSA_ONE_LANE") != nullptr;   // the one-lane-per-signature kernel of rounds 5-6 (A/B, cross-check)
+      if (one_lane)
+        hipLaunchKernelGGL(tg_ed_simulate_kernel, dim3((ninst + 63) / 64), dim3(64), 0, c->stream, cl, (const tg::ed::Sig*)d_sigs, num_sigs, filler, ninst,
+                           (tg::ed::RowVals*)d_vals, (int*)d_bad);
+      else
+        hipLaunchKernelGGL(tg_ed_simulate4_kernel, dim3((ninst + 15) / 16), dim3(64), 0, c->stream, cl, (const tg::ed::Sig*)d_sigs, num_sigs, filler, ninst,
+                           (tg::ed::RowVals*)d_vals, (int*)d_bad);
       e = tg_launch_ed_rows(c->stream, cl, (const tg::ed::RegSrc*)d_rsrc, (const tg::ed::RowVals*)d_vals, (const tg::ed::Sig*)d_sigs, num_sigs, filler,
                             (u64*)trace_dev, n, (unsigned*)d_hist);
       hipLaunchKernelGGL(tg_patch_mult_kernel, dim3(65536 / 256), dim3(256), 0, c->stream, (u64*)trace_dev + (size_t)cl.MULT * n, (const unsigned*)d_hist,
