@@ -161,3 +161,39 @@ def test_eddsa_table_proves_from_the_device_generated_trace_and_refuses_a_point_
     finally:
         tabs.free()
         res.free()
+
+
+def test_the_one_lane_and_the_four_lane_simulation_write_the_same_trace(ctx):
+    """Round 6: `tg_ed_simulate4_kernel` (four lanes per signature, the ladder step's 13 levels of independent rows) replaced the
+    one-lane-per-signature walk, which stays behind VX_TRACE_EDDSA_ONE_LANE=1: same cells (the full program, 20 instances so that the
+    last group of a block is only partly filled), same results."""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    from vectorx_amd import eddsa_air as ea
+    root = Path(__file__).resolve().parent.parent
+    log_n = 18
+    lay = ea.Layout(16, 256, full=True)
+    sigs, rs = stark_chips.eddsa_signatures_full(20, 4)
+    n = 1 << log_n
+    d = ctx.alloc(lay.N * n * 8)
+    try:
+        assert ctx.trace_eddsa_table(log_n, lay.NB, sigs, d, full=True) == rs
+        mine = hashlib.sha256(ctx.download(d, lay.N * n * 8).tobytes()).hexdigest()
+    finally:
+        ctx.free(d)
+    code = (
+        "import sys, hashlib; sys.path.insert(0, %r)\n"
+        "import vectorx_amd as vx\n"
+        "from vectorx_amd import eddsa_air as ea, stark_chips\n"
+        "ctx = vx.Context(0); lay = ea.Layout(16, 256, full=True)\n"
+        "sigs, rs = stark_chips.eddsa_signatures_full(20, 4)\n"
+        "d = ctx.alloc(lay.N * (1 << 18) * 8)\n"
+        "assert ctx.trace_eddsa_table(18, lay.NB, sigs, d, full=True) == rs\n"
+        "print(hashlib.sha256(ctx.download(d, lay.N * (1 << 18) * 8).tobytes()).hexdigest())\n"
+    ) % str(root)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env={**os.environ, "VX_TRACE_EDDSA_ONE_LANE": "1"})
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-2000:]
+    assert r.stdout.strip().splitlines()[-1] == mine
