@@ -173,6 +173,17 @@ def dag_pool_legs(pool, with_starks=True, passes=2):
     assert len({r["root"] for r in runs}) == 1
     out["dag_header_range_512"] = record(runs, sizes + ", synthetic stand-in circuits; witnesses HBM-resident (4 base witnesses per circuit kind and lane, "
                                          "each job's own public inputs patched in); NOT the contract's timed region")
+    try:   # one more pass with HIP-event profiling on every lane: where the 128 proofs' GPU time goes, the quotient by kernel (not a timed pass)
+        pool.profile(True)
+        pr = pool.run(b"bench request", with_tables=False, schedule="dependency")
+        stages = pool.profile_get()
+        pool.profile(False)
+        top = {k: round(v, 1) for k, v in sorted(stages.items(), key=lambda kv: -kv[1]) if not k.startswith("qgate_") and k not in QUOTIENT_NESTED and v >= 1.0}
+        out["dag_header_range_512"]["stage_ms_per_dag"] = dict(list(top.items())[:8])
+        out["dag_header_range_512"]["quotient_by_kernel_ms_per_dag"] = {k[len("quotient_"):]: round(stages[k], 1) for k in QUOTIENT_NESTED if k in stages}
+        out["dag_header_range_512"]["profiled_pass_seconds"] = round(pr["seconds"], 4)
+    except Exception as e:   # noqa: BLE001 — a diagnostic, never the leg
+        out["dag_header_range_512"]["stage_profile_error"] = repr(e)[:160]
     if with_starks:
         t0 = time.perf_counter()
         pool.load_request(b"bench request")          # the request's input (header chain, justification) in the workers' host memory
@@ -701,10 +712,10 @@ _HEX_KEYS = {"root", "input", "output", "proof_sha256", "record"}
 _FLAG_TEXT = {"emulated_ranks_on_one_device"}     # a label whose PRESENCE is the information: kept as `true`
 
 
-def compact_line(d, limit: int = 5900):
+def compact_line(d, limit: int = 6000):
     """-> a copy of the bench line that serialises to fewer than `limit` bytes: strings longer than 48 characters are dropped unless
     their key is one of the contract's (metric, config.workload ...), hex fields are cut to 16 characters, floats to 6 significant
-    digits; if that is not enough, the least important detail tables go (listed in `dropped_for_size`), never a headline number."""
+    digits; if that is not enough, the least important detail tables go (`dropped_for_size` counts them), never a headline number."""
     import json
 
     def walk(o, key=None):
@@ -736,7 +747,8 @@ def compact_line(d, limit: int = 5900):
     keep = {
         "dag": ("dag_seconds", "dag_seconds_all_passes", "lane_seconds_by_kind", "rank0_lane_seconds_by_kind", "jobs_by_worker", "workers_per_gpu",
                 "lanes_per_worker", "non_map_layers_ms_layer_barriers", "setup_seconds_untimed", "root", "output", "output_equals_host_computation",
-                "stark_proofs", "plonky2_proofs", "ranks", "with_stark_tables", "devices", "error", "backend", "seconds"),
+                "stark_proofs", "plonky2_proofs", "ranks", "with_stark_tables", "devices", "error", "backend", "seconds", "stage_ms_per_dag",
+                "quotient_by_kernel_ms_per_dag", "profiled_pass_seconds"),
         "chip": ("ms_per_proof", "ms_per_proof_openings_digest", "rows_log2", "proof_bytes", "trace_generation_ms_gpu"),
         "rotate": ("seconds", "seconds_all_passes", "seconds_by_kind", "output", "output_equals_host_computation", "stark_proofs", "setup_seconds_untimed", "error"),
         "alone": ("log_n", "ms_per_proof", "ms_per_proof_two_gate_stand_in", "quotient_eval_ms", "quotient_by_kernel_ms"),
@@ -761,10 +773,13 @@ def compact_line(d, limit: int = 5900):
     cb = c.get("cpu_baseline")
     if isinstance(cb, dict) and isinstance(cb.get("sampled"), dict):
         cb["sampled"].pop("stages_s", None)
-    order = [("alu_bound_dominant_kernel", "ubench_cycles_per_inst"), ("stage_alg_GBps",), ("sharded_one_proof", "rank0_stage_ms"),
-             ("dag_on_one_pool_over_all_gpus", "jobs_by_worker"), ("recursion_circuits_alone", "map_quotient_by_gate_ms_one_kernel_per_gate"),
+    order = [("alu_bound_dominant_kernel", "ubench_cycles_per_inst"), ("stage_alg_GBps",), ("value_from_host_witness",),
              ("alu_bound_dominant_kernel", "frac_at_pmc_run_clock"), ("alu_bound_dominant_kernel", "frac_quad_issue_model"),
-             ("rank_devices",), ("chip_starks",), ("rotate",)]
+             ("dag_header_range_512", "jobs_by_worker"), ("dag_header_range_512_with_starks", "jobs_by_worker"),
+             ("dag_on_one_pool_over_all_gpus", "jobs_by_worker"), ("dag_on_one_pool_over_all_gpus", "stage_ms_per_dag"),
+             ("sharded_one_proof", "rank0_stage_ms"), ("cpu_baseline", "sampled"),
+             ("recursion_circuits_alone", "map_quotient_by_gate_ms_one_kernel_per_gate"),
+             ("dag_header_range_512", "stage_ms_per_dag"), ("rank_devices",), ("chip_starks",), ("rotate",)]
     dropped = []
 
     def drop(path):
@@ -786,7 +801,7 @@ def compact_line(d, limit: int = 5900):
             break
         if drop(path):
             dropped.append("/".join(path))
-            c["dropped_for_size"] = dropped
+            c["dropped_for_size"] = len(dropped)      # how many detail tables went (their names would cost what they save; the complete line has them)
     return c
 
 

@@ -97,7 +97,7 @@ def test_the_line_the_driver_keeps_is_under_6_kb_and_holds_every_headline_number
                 yield from strings(v, key)
         elif isinstance(o, str):
             yield key, o
-    assert all(len(v) <= 48 or k in bench_prove._KEEP_TEXT or k == "dropped_for_size" for k, v in strings(c))
+    assert all(len(v) <= 48 or k in bench_prove._KEEP_TEXT for k, v in strings(c))
     assert (ROOT / c["glossary"]).exists()
     # a line that is already small is left alone (apart from the rounding)
     small = {"metric": "m", "value": 1.23456789, "cpu_baseline": {"value": 0.5, "sample": "x" * 100}}

@@ -38,7 +38,10 @@ STATIC = {
                    "(`openings_digest` 0); `ms_per_proof_openings_digest` = the same table under this library's tree-hash variant (VX_STARK_OPENINGS_DIGEST)",
     "rotate": "one rotate request end to end on the GPU: plonky2 2^19 + BLAKE2b + two SHA-256 commitment chains + the 300 signatures through the signature bus; `output` = the 32 output bytes",
     "glossary": "this file",
-    "dropped_for_size": "detail tables left out of the compact line to stay under 6 KB (they are in bench_line_full.json of the same run)",
+    "dropped_for_size": "how many detail tables were left out of the compact line to stay under 6 KB, in the order of bench_prove.compact_line's `order` "
+                        "(unit-test cycle counts, per-stage GB/s, the duplicate host-witness block, ...): they are in bench_line_full.json of the same run",
+    "dag_header_range_512/stage_ms_per_dag": "HIP-event stage times summed over the 128 proofs of ONE MORE pass of the DAG with profiling on every lane "
+                                             "(`profiled_pass_seconds`; not one of the timed passes); `quotient_by_kernel_ms_per_dag` = the quotient's kernels, nested in quotient_eval",
 }
 
 

@@ -136,6 +136,33 @@ class DagPool:
             self.ready.append(msg[1])
         return self.ready
 
+    def profile(self, on: bool, timeout: float = 60.0):
+        """HIP-event stage profiling on every context of every worker, between runs (the DAG's `quotient_eval` by kernel: VERDICT r5 #1).
+        Profiled passes are not the ones whose seconds are quoted: the events cost a little."""
+        for c in self.conns:
+            c.send(("prof", bool(on)))
+        for c in self.conns:
+            if not c.poll(timeout):
+                raise TimeoutError("a DAG worker did not answer the profiling switch")
+            msg = c.recv()
+            if msg[0] != "prof_ok":
+                raise RuntimeError(f"DAG worker: {msg}")
+
+    def profile_get(self, timeout: float = 60.0) -> dict:
+        """-> {stage: ms summed over every context of every worker since profile(True)}"""
+        for c in self.conns:
+            c.send(("prof_get",))
+        total = {}
+        for c in self.conns:
+            if not c.poll(timeout):
+                raise TimeoutError("a DAG worker did not return its stage times")
+            msg = c.recv()
+            if msg[0] != "prof":
+                raise RuntimeError(f"DAG worker: {msg}")
+            for k, v in msg[1].items():
+                total[k] = total.get(k, 0.0) + v
+        return total
+
     def load_request(self, input_seed: bytes, timeout: float = 600.0):
         """Every worker derives (and keeps) the request of `input_seed` — the header chain; on the outer job's worker also the
         justification and its signatures — BEFORE the clock of `run`: a request's input is in host memory when proving starts, as the
@@ -422,6 +449,24 @@ def _worker(addr: str, device: int, index: int):
                     preload(msg[1])
                 with send_lock:
                     conn.send(("loaded",))
+                continue
+            if msg[0] in ("prof", "prof_get"):          # HIP-event stage times of every context of this worker (between runs only)
+                ctxs = {id(c): c for p in provers.values() for c in getattr(p, "lanes", ())}
+                if msg[0] == "prof":
+                    for c in ctxs.values():
+                        c.prof_enable(bool(msg[1]))
+                        if msg[1]:
+                            c.prof_reset()
+                    reply = ("prof_ok",)
+                else:
+                    acc = {}
+                    for c in ctxs.values():
+                        c.sync()
+                        for k, v in c.prof().items():
+                            acc[k] = acc.get(k, 0.0) + v["ms"]
+                    reply = ("prof", acc)
+                with send_lock:
+                    conn.send(reply)
                 continue
             (todo_outer if msg[0] == "outer_tables" or msg[3] == "outer" else todo).put(msg)
         for _ in threads:
