@@ -179,8 +179,8 @@ def dag_pool_legs(pool, with_starks=True, passes=2):
         stages = pool.profile_get()
         pool.profile(False)
         top = {k: round(v, 1) for k, v in sorted(stages.items(), key=lambda kv: -kv[1]) if not k.startswith("qgate_") and k not in QUOTIENT_NESTED and v >= 1.0}
-        out["dag_header_range_512"]["stage_ms_per_dag"] = dict(list(top.items())[:8])
-        out["dag_header_range_512"]["quotient_by_kernel_ms_per_dag"] = {k[len("quotient_"):]: round(stages[k], 1) for k in QUOTIENT_NESTED if k in stages}
+        out["dag_header_range_512"]["stage_elapsed_ms_per_dag"] = dict(list(top.items())[:8])
+        out["dag_header_range_512"]["quotient_elapsed_by_kernel_ms_per_dag"] = {k[len("quotient_"):]: round(stages[k], 1) for k in QUOTIENT_NESTED if k in stages}
         out["dag_header_range_512"]["profiled_pass_seconds"] = round(pr["seconds"], 4)
     except Exception as e:   # noqa: BLE001 — a diagnostic, never the leg
         out["dag_header_range_512"]["stage_profile_error"] = repr(e)[:160]
@@ -747,8 +747,8 @@ def compact_line(d, limit: int = 6000):
     keep = {
         "dag": ("dag_seconds", "dag_seconds_all_passes", "lane_seconds_by_kind", "rank0_lane_seconds_by_kind", "jobs_by_worker", "workers_per_gpu",
                 "lanes_per_worker", "non_map_layers_ms_layer_barriers", "setup_seconds_untimed", "root", "output", "output_equals_host_computation",
-                "stark_proofs", "plonky2_proofs", "ranks", "with_stark_tables", "devices", "error", "backend", "seconds", "stage_ms_per_dag",
-                "quotient_by_kernel_ms_per_dag", "profiled_pass_seconds"),
+                "stark_proofs", "plonky2_proofs", "ranks", "with_stark_tables", "devices", "error", "backend", "seconds", "stage_elapsed_ms_per_dag",
+                "quotient_elapsed_by_kernel_ms_per_dag", "profiled_pass_seconds"),
         "chip": ("ms_per_proof", "ms_per_proof_openings_digest", "rows_log2", "proof_bytes", "trace_generation_ms_gpu"),
         "rotate": ("seconds", "seconds_all_passes", "seconds_by_kind", "output", "output_equals_host_computation", "stark_proofs", "setup_seconds_untimed", "error"),
         "alone": ("log_n", "ms_per_proof", "ms_per_proof_two_gate_stand_in", "quotient_eval_ms", "quotient_by_kernel_ms"),
@@ -776,10 +776,10 @@ def compact_line(d, limit: int = 6000):
     order = [("alu_bound_dominant_kernel", "ubench_cycles_per_inst"), ("stage_alg_GBps",), ("value_from_host_witness",),
              ("alu_bound_dominant_kernel", "frac_at_pmc_run_clock"), ("alu_bound_dominant_kernel", "frac_quad_issue_model"),
              ("dag_header_range_512", "jobs_by_worker"), ("dag_header_range_512_with_starks", "jobs_by_worker"),
-             ("dag_on_one_pool_over_all_gpus", "jobs_by_worker"), ("dag_on_one_pool_over_all_gpus", "stage_ms_per_dag"),
+             ("dag_on_one_pool_over_all_gpus", "jobs_by_worker"), ("dag_on_one_pool_over_all_gpus", "stage_elapsed_ms_per_dag"),
              ("sharded_one_proof", "rank0_stage_ms"), ("cpu_baseline", "sampled"),
              ("recursion_circuits_alone", "map_quotient_by_gate_ms_one_kernel_per_gate"),
-             ("dag_header_range_512", "stage_ms_per_dag"), ("rank_devices",), ("chip_starks",), ("rotate",)]
+             ("dag_header_range_512", "stage_elapsed_ms_per_dag"), ("rank_devices",), ("chip_starks",), ("rotate",)]
     dropped = []
 
     def drop(path):

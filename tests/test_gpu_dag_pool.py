@@ -27,8 +27,15 @@ def test_pool_root_equals_the_one_process_root_with_per_job_tables(ctx):
         assert with_tables["outer_tables_hoisted"] and not again["outer_tables_hoisted"]
         other = pool.run(b"request 2")
         plain = pool.run(b"request 1", with_tables=False)
+        # one more plonky2-only pass with HIP-event profiling on every lane of every worker (bench.py: `stage_ms_per_dag`)
+        pool.profile(True)
+        profiled = pool.run(b"request 1", with_tables=False)
+        stages = pool.profile_get()
+        pool.profile(False)
     finally:
         pool.close()
+    assert profiled["root"] == plain["root"]
+    assert stages["hash_leaves"] > 0 and stages["quotient_eval"] >= stages["quotient_program_gates_jit"] > 0 and stages["quotient_lookup_terms"] > 0
     assert with_tables["root"] == again["root"] != other["root"]
     assert plain["root"] != with_tables["root"]
     assert with_tables["split"].get("trace_generation", 0) > 0 and "trace_generation" not in plain["split"]

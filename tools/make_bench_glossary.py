@@ -40,8 +40,12 @@ STATIC = {
     "glossary": "this file",
     "dropped_for_size": "how many detail tables were left out of the compact line to stay under 6 KB, in the order of bench_prove.compact_line's `order` "
                         "(unit-test cycle counts, per-stage GB/s, the duplicate host-witness block, ...): they are in bench_line_full.json of the same run",
-    "dag_header_range_512/stage_ms_per_dag": "HIP-event stage times summed over the 128 proofs of ONE MORE pass of the DAG with profiling on every lane "
-                                             "(`profiled_pass_seconds`; not one of the timed passes); `quotient_by_kernel_ms_per_dag` = the quotient's kernels, nested in quotient_eval",
+    "dag_header_range_512/stage_elapsed_ms_per_dag": "HIP-event ELAPSED time per stage, summed over the 128 proofs of ONE MORE pass of the DAG with profiling on every "
+                                             "lane (`profiled_pass_seconds`; not one of the timed passes).  Nine lanes share the GPU, so a stage's bracket also contains "
+                                             "other lanes' kernels: the sums are lane-seconds of waiting + work (they add up to ~ lanes x wall), NOT kernel time — a "
+                                             "kernel that needs much LDS (the fused gate kernel: 77 KB per workgroup) waits longest for a CU; "
+                                             "`quotient_elapsed_by_kernel_ms_per_dag` = the quotient's kernels the same way (nested in quotient_eval); kernel times "
+                                             "proper: `recursion_circuits_alone`",
 }
 
 
