@@ -475,8 +475,8 @@ TG_HD void row(const Cols& c, const RegSrc& rsrc, const RowVals* vals, const Sig
       for (int k = 0; k < 4; ++k) ev[k] = v[k];
   }
   // X Y Z Q limbs and the carries of  X(t) Y(t) + E(t) - Z(t) - Q(t) P(t) = (t - 2^16) W(t);  P = p, or L on the full program's reduction rows
-  long long d[2 * NL - 1];
-  for (int k = 0; k < 2 * NL - 1; ++k) d[k] = 0;
+  // (round 6: the coefficient d_k is formed COLUMN BY COLUMN on the way down the carry chain — the 31 accumulators of the row-by-row form
+  //  were 62 registers that the 1024-thread kernel does not have: 400 B of scratch per lane)
   unsigned xl[NL], yl[NL], zl[NL], ql[NL];
   for (int i = 0; i < NL; ++i) {
     xl[i] = limb16(rv.x, i), yl[i] = limb16(rv.y, i), zl[i] = limb16(rv.z, i), ql[i] = limb16(rv.q, i);
@@ -484,17 +484,19 @@ TG_HD void row(const Cols& c, const RegSrc& rsrc, const RowVals* vals, const Sig
     look(zl[i]);
   }
   for (int i = 0; i < NL; ++i) look(ql[i]);
-  if (!op.free_) {
-    for (int i = 0; i < NL; ++i)
-      for (int j = 0; j < NL; ++j) {
-        const long long pj = op.modl ? (long long)limb16(ELL, j) : (j == 0 ? 0xFFED : (j == NL - 1 ? 0x7FFF : 0xFFFF));
-        d[i + j] += (long long)xl[i] * yl[j] - (long long)ql[i] * pj;
-      }
-    for (int i = 0; i < NL; ++i) d[i] += (long long)limb16(ev, i) - (long long)zl[i];
-  }
   long long prev = 0;
-  for (int k = 0; k < 2 * NL - 1; ++k) {
-    const long long t = prev - d[k];
+  TG_UNROLL for (int k = 0; k < 2 * NL - 1; ++k) {
+    long long dk = 0;
+    if (!op.free_) {
+      const int i0 = k < NL ? 0 : k - NL + 1, i1 = k < NL ? k : NL - 1;
+      TG_UNROLL for (int i = i0; i <= i1; ++i) {
+        const int j = k - i;
+        const long long pj = op.modl ? (long long)limb16(ELL, j) : (j == 0 ? 0xFFED : (j == NL - 1 ? 0x7FFF : 0xFFFF));
+        dk += (long long)xl[i] * yl[j] - (long long)ql[i] * pj;
+      }
+      if (k < NL) dk += (long long)limb16(ev, k) - (long long)zl[k];
+    }
+    const long long t = prev - dk;
     prev = t >> LB;                                      // exact: the low 16 bits of t are zero when the relation holds
     if (k <= 2 * NL - 3) {
       const long long off = prev + (1ll << (2 * LB - 1));
