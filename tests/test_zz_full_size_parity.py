@@ -28,11 +28,18 @@ def test_header_range_512_sized_proof_bytes_identical_to_oracle(ctx, oracle, bac
     gc.verify(gp)
     gpu_digest, cap = gc.digest().copy(), gc.constants_sigmas_cap().copy()
     gc.free()                                                                 # 11 GB of HBM back before the CPU takes over
-    oc = oracle_lib.OracleCircuit(oracle, sc.desc_ptr)
-    assert (oc.digest() == gpu_digest).all() and (oc.cap() == cap).all()
-    op = oc.prove(w)
-    assert len(gp) == len(op) and hashlib.sha256(gp).hexdigest() == hashlib.sha256(op).hexdigest()
-    assert gp == op
-    assert oc.verify(gp) == ""
-    oc.free()
+    bg = background_oracle_proof(log_n, 0x5EED0000)     # made by tests/_bg_oracle.py while the earlier tests ran (same circuit, same witness)
+    if bg is not None:
+        op, rec = bg
+        assert rec["digest"] == [int(x) for x in gpu_digest] and rec["cap_sha256"] == hashlib.sha256(cap.tobytes()).hexdigest()
+        assert len(gp) == len(op) and hashlib.sha256(gp).hexdigest() == hashlib.sha256(op).hexdigest() == rec["proof_sha256"]
+        assert gp == op
+    else:
+        oc = oracle_lib.OracleCircuit(oracle, sc.desc_ptr)
+        assert (oc.digest() == gpu_digest).all() and (oc.cap() == cap).all()
+        op = oc.prove(w)
+        assert len(gp) == len(op) and hashlib.sha256(gp).hexdigest() == hashlib.sha256(op).hexdigest()
+        assert gp == op
+        assert oc.verify(gp) == ""
+        oc.free()
     sc.free()

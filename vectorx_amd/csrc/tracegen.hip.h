@@ -93,6 +93,7 @@ __global__ __launch_bounds__(TG_THREADS) void tg_b2_expand_kernel(const tg::b2::
 }
 #define TG_LDS_THREADS 1024
 #define TG_LDS_BINS 32768
+static __device__ const uint64_t tg_zero8[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // the hand-over of "no block before" (in memory once, not in every lane's scratch)
 __global__ __launch_bounds__(TG_LDS_THREADS) void tg_b2_rows_kernel(const tg::b2::Block* __restrict__ blocks,
                                                                     const tg::b2::Expanded* __restrict__ exp, u64* __restrict__ trace, size_t n,
                                                                     size_t rows_per_wg, unsigned* __restrict__ hist) {
@@ -106,12 +107,13 @@ __global__ __launch_bounds__(TG_LDS_THREADS) void tg_b2_rows_kernel(const tg::b2
     const size_t b = row / tg::b2::PERIOD;
     const int r = (int)(row % tg::b2::PERIOD);
     const tg::b2::Block& blk = blocks[b];
-    uint64_t zero8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const uint64_t* hn_prev = b ? exp[b - 1].hn : zero8;
-    const uint64_t* dl = blk.dsrc >= 0 ? exp[blk.dsrc].hn : zero8;
+    const uint64_t* hn_prev = b ? exp[b - 1].hn : tg_zero8;
+    const uint64_t* dl = blk.dsrc >= 0 ? exp[blk.dsrc].hn : tg_zero8;
     const bool count = row + 1 < n;
+    size_t nn = n;
+    asm volatile("" : "+s"(nn));   // 775 column bases hoisted out of this loop were 957 spilled SGPRs; col * nn is two scalar multiplies
     tg::b2::row(blk, exp[b], hn_prev, dl, r, row, tg::B2_IV, tg::B2_SIGMA,
-                [&](int col, uint64_t v) { if (half == 0) trace[(size_t)col * n + row] = v; },
+                [&](int col, uint64_t v) { if (half == 0) trace[(size_t)col * nn + row] = v; },
                 [&](unsigned a, unsigned bb) {
                   const unsigned key = a * 256u + bb;
                   if (count && (key >> 15) == half) __hip_atomic_fetch_add(&tg_lh[key & (TG_LDS_BINS - 1)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -380,17 +382,19 @@ __global__ void tg_ed_results_kernel(const tg::ed::RowVals* __restrict__ vals, i
   const int u = i >> 3, w = (i >> 2) & 1, k = i & 3;
   results[i] = vals[(size_t)u * L + xrow + w].z[k];
 }
-// (the LDS histogram described at the top of this file)
-__global__ __launch_bounds__(TG_LDS_THREADS) void tg_ed_rows_kernel(tg::ed::Cols c, const tg::ed::RegSrc* __restrict__ rsrc, const tg::ed::RowVals* __restrict__ vals,
+// (the LDS histogram described at the top of this file; 512 lanes per workgroup — one workgroup per CU either way, the histogram is 128 KB —
+// so that a lane may hold the row's four 16-limb operands in registers: at 1024 lanes, 128 VGPRs, 53 of them spilled)
+#define TG_ED_ROWS_THREADS 512
+__global__ __launch_bounds__(TG_ED_ROWS_THREADS) void tg_ed_rows_kernel(tg::ed::Cols c, const tg::ed::RegSrc* __restrict__ rsrc, const tg::ed::RowVals* __restrict__ vals,
                                                                     const tg::ed::Sig* __restrict__ sigs, int nsig, tg::ed::Sig filler,
                                                                     u64* __restrict__ trace, size_t n, size_t rows_per_wg, unsigned* __restrict__ hist) {
   extern __shared__ __attribute__((aligned(16))) unsigned tg_lh[];
-  for (int b = threadIdx.x; b < TG_LDS_BINS; b += TG_LDS_THREADS) tg_lh[b] = 0;
+  for (int b = threadIdx.x; b < TG_LDS_BINS; b += TG_ED_ROWS_THREADS) tg_lh[b] = 0;
   __syncthreads();
   const unsigned half = blockIdx.y;
   const size_t base = (size_t)blockIdx.x * rows_per_wg;
   const size_t end = base + rows_per_wg < n ? base + rows_per_wg : n;
-  for (size_t row = base + threadIdx.x; row < end; row += TG_LDS_THREADS) {
+  for (size_t row = base + threadIdx.x; row < end; row += TG_ED_ROWS_THREADS) {
     const bool count = row + 1 < n;
     tg::ed::row(c, *rsrc, vals, sigs, nsig, filler, row, [&](int col, uint64_t v) { if (half == 0) trace[(size_t)col * n + row] = v; },
                 [&](unsigned limb) {
@@ -399,7 +403,7 @@ __global__ __launch_bounds__(TG_LDS_THREADS) void tg_ed_rows_kernel(tg::ed::Cols
   }
   __syncthreads();
   unsigned* my_hist = hist + (size_t)tg_xcc_id() * 65536 + (size_t)half * TG_LDS_BINS;
-  for (int b = threadIdx.x; b < TG_LDS_BINS; b += TG_LDS_THREADS) {
+  for (int b = threadIdx.x; b < TG_LDS_BINS; b += TG_ED_ROWS_THREADS) {
     const unsigned v = tg_lh[b];
     if (v) __hip_atomic_fetch_add(&my_hist[b], v, __ATOMIC_RELAXED, TG_XCD_COPY_SCOPE);
   }
@@ -417,7 +421,7 @@ static hipError_t tg_launch_ed_rows(hipStream_t s, const tg::ed::Cols& cl, const
   }
   size_t chunks, rows_per_wg;
   tg_lds_grid(n, &chunks, &rows_per_wg);
-  hipLaunchKernelGGL(tg_ed_rows_kernel, dim3((unsigned)chunks, 2), dim3(TG_LDS_THREADS), lds, s, cl, rsrc, vals, sigs, nsig, filler, trace, n, rows_per_wg, hist);
+  hipLaunchKernelGGL(tg_ed_rows_kernel, dim3((unsigned)chunks, 2), dim3(TG_ED_ROWS_THREADS), lds, s, cl, rsrc, vals, sigs, nsig, filler, trace, n, rows_per_wg, hist);
   return hipGetLastError();
 }
 

@@ -274,26 +274,21 @@ struct GOut {
   unsigned k[8];
   uint64_t a2, b2, c2, d2;
 };
-TG_HD uint64_t add_k(const uint64_t* terms, int n, unsigned* k) {
-  uint64_t lo = 0, hi = 0;
-  for (int i = 0; i < n; ++i) lo += terms[i] & 0xFFFFFFFFu, hi += terms[i] >> 32;
-  k[0] = (unsigned)(lo >> 32);
-  hi += k[0];
-  k[1] = (unsigned)(hi >> 32);
+TG_HD uint64_t add_k(uint64_t t0, uint64_t t1, uint64_t t2, unsigned& k0, unsigned& k1) {   // t0 + t1 + t2 by 32-bit halves, carries out
+  const uint64_t lo = (t0 & 0xFFFFFFFFu) + (t1 & 0xFFFFFFFFu) + (t2 & 0xFFFFFFFFu);
+  k0 = (unsigned)(lo >> 32);
+  const uint64_t hi = (t0 >> 32) + (t1 >> 32) + (t2 >> 32) + k0;
+  k1 = (unsigned)(hi >> 32);
   return (lo & 0xFFFFFFFFu) | ((hi & 0xFFFFFFFFu) << 32);
 }
 TG_HD void g_full(uint64_t a, uint64_t b, uint64_t c, uint64_t d, uint64_t x, uint64_t y, GOut& o) {
-  const uint64_t t1[3] = {a, b, x};
-  const uint64_t a1 = add_k(t1, 3, o.k + 0);
+  const uint64_t a1 = add_k(a, b, x, o.k[0], o.k[1]);
   const uint64_t e1 = d ^ a1, d1 = rotr64(e1, 32);
-  const uint64_t t2[2] = {c, d1};
-  const uint64_t c1 = add_k(t2, 2, o.k + 2);
+  const uint64_t c1 = add_k(c, d1, 0, o.k[2], o.k[3]);
   const uint64_t f1 = b ^ c1, b1 = rotr64(f1, 24);
-  const uint64_t t3[3] = {a1, b1, y};
-  const uint64_t a2 = add_k(t3, 3, o.k + 4);
+  const uint64_t a2 = add_k(a1, b1, y, o.k[4], o.k[5]);
   const uint64_t e2 = d1 ^ a2, d2 = rotr64(e2, 16);
-  const uint64_t t4[2] = {c1, d2};
-  const uint64_t c2 = add_k(t4, 2, o.k + 6);
+  const uint64_t c2 = add_k(c1, d2, 0, o.k[6], o.k[7]);
   const uint64_t f2 = b1 ^ c2, b2v = rotr64(f2, 63);
   const uint64_t top = (f2 >> 7) & 0x0101010101010101ull;        // TOP byte j = bit 7 of f2's byte j
   o.f[BIN] = b, o.f[DIN] = d, o.f[A1] = a1, o.f[E1] = e1, o.f[C1] = c1, o.f[F1] = f1, o.f[A2] = a2, o.f[E2] = e2, o.f[C2] = c2, o.f[F2] = f2;
@@ -331,8 +326,9 @@ TG_HD void compress(uint64_t (&h)[8], const Block& b, const uint64_t* IV, const 
 }
 
 // Row `r` of block `blk`.  hn_prev = the HN the block before handed over (zeros for the first block), dlatch = the 4 words latched in
-// D.  look(a, b) is called once per looked-up triple of the row with its (a, b) bytes, in blake2b_bytes_air.tuples() order (the
-// caller counts multiplicities; rows it must not count are its business).  The table columns' MULT is written as 0.
+// D.  look(a, b) is called once per looked-up triple of the row with its (a, b) bytes — the triples of blake2b_bytes_air.tuples(),
+// each as soon as its words exist (the callers count multiplicities, so the order is free, and nothing is held in arrays across the
+// row: that was 592 B of scratch per lane; rows a caller must not count are its business).  The table columns' MULT is written as 0.
 template <class Put, class Look>
 TG_HD void row(const Block& blk, const Expanded& e, const uint64_t* hn_prev, const uint64_t* dlatch, int r, size_t rowi,
                const uint64_t* IV, const uint8_t (*SIGMA)[16], Put put, Look look) {
@@ -355,16 +351,17 @@ TG_HD void row(const Block& blk, const Expanded& e, const uint64_t* hn_prev, con
     put(V + 2 * k, w & 0xFFFFFFFFu), put(V + 2 * k + 1, w >> 32);
   }
   // slots
-  uint64_t sf[NSLOT][NFIELD];
+#define TG_BYTE(w, j) ((unsigned)(((w) >> (8 * (j))) & 255))
   for (int g = 0; g < NSLOT; ++g) {
     GOut o;
     for (int q = 0; q < NFIELD; ++q) o.f[q] = 0;
     o.al = o.cl = 0;
     for (int q = 0; q < 8; ++q) o.k[q] = 0;
     if (r == 0) {
-      uint64_t v[16];
-      init_v(blk, IV, v);
-      const uint64_t a2 = v[g], b2v = v[4 + (g + 1) % 4], c2 = v[8 + (g + 2) % 4], d2 = v[12 + (g + 3) % 4];
+      // init_v's v[g], v[4 + (g + 1) % 4], v[8 + (g + 2) % 4], v[12 + (g + 3) % 4], read where they come from (no local vector)
+      const int dk = (g + 3) % 4;
+      const uint64_t a2 = blk.h_in[g], b2v = blk.h_in[4 + (g + 1) % 4], c2 = IV[(g + 2) % 4],
+                     d2 = IV[4 + dk] ^ (dk == 0 ? blk.t : (dk == 2 && blk.fin ? ~(uint64_t)0 : 0));
       const uint64_t e2 = rotr64(d2, 48), e1 = rotr64(e2 ^ a2, 32);
       o.f[A2] = a2, o.f[B2] = b2v, o.f[C2] = c2, o.f[E2] = e2, o.f[E1] = e1, o.f[A1] = e1, o.f[F2] = c2;
     } else if (r >= ROW_G0 && r <= ROW_GLAST) {
@@ -375,16 +372,20 @@ TG_HD void row(const Block& blk, const Expanded& e, const uint64_t* hn_prev, con
       const uint64_t x = blk.m[SIGMA[rr % 10][2 * (4 * half + g)]], y = blk.m[SIGMA[rr % 10][2 * (4 * half + g) + 1]];
       g_full(v[idx[0]], v[idx[1]], v[idx[2]], v[idx[3]], x, y, o);
     }
-    for (int q = 0; q < NFIELD; ++q) {
-      sf[g][q] = o.f[q];
+    for (int q = 0; q < NFIELD; ++q)
       for (int j = 0; j < 8; ++j) put(fcol(g, q, j), (o.f[q] >> (8 * j)) & 255);
+    for (int j = 0; j < 8; ++j) {
+      look(TG_BYTE(o.f[DIN], j), TG_BYTE(o.f[A1], j));
+      look(TG_BYTE(o.f[BIN], j), TG_BYTE(o.f[C1], j));
+      look(TG_BYTE(o.f[E1], (j + 4) % 8), TG_BYTE(o.f[A2], j));
+      look(TG_BYTE(o.f[F1], (j + 3) % 8), TG_BYTE(o.f[C2], j));
+      look(TG_BYTE(o.f[B2], j), 0u);
     }
     const int base = SLOT + g * SLOT_W + 8 * NFIELD;
     put(base + 0, o.al & 0xFFFFFFFFu), put(base + 1, o.al >> 32), put(base + 2, o.cl & 0xFFFFFFFFu), put(base + 3, o.cl >> 32);
     for (int q = 0; q < 8; ++q) put(base + 4 + q, (uint64_t)o.k[q]);
   }
   // finalisation groups: FA FB FE FH FO
-  uint64_t ff[NFING][5];
   for (int g = 0; g < NFING; ++g) {
     uint64_t fa = 0, fb = 0, fe = 0, fh = 0, fo = 0;
     if (r == 0 && g == 0) {
@@ -393,9 +394,12 @@ TG_HD void row(const Block& blk, const Expanded& e, const uint64_t* hn_prev, con
       const int k = 4 * (r - ROW_FIN0) + g;
       fa = e.v[24][k], fb = e.v[24][k + 8], fe = fa ^ fb, fh = blk.h_in[k], fo = fe ^ fh;
     }
-    ff[g][0] = fa, ff[g][1] = fb, ff[g][2] = fe, ff[g][3] = fh, ff[g][4] = fo;
-    for (int q = 0; q < 5; ++q)
-      for (int j = 0; j < 8; ++j) put(fincol(g, q, j), (ff[g][q] >> (8 * j)) & 255);
+    for (int j = 0; j < 8; ++j) {
+      put(fincol(g, 0, j), (uint64_t)TG_BYTE(fa, j)), put(fincol(g, 1, j), (uint64_t)TG_BYTE(fb, j)), put(fincol(g, 2, j), (uint64_t)TG_BYTE(fe, j));
+      put(fincol(g, 3, j), (uint64_t)TG_BYTE(fh, j)), put(fincol(g, 4, j), (uint64_t)TG_BYTE(fo, j));
+      look(TG_BYTE(fa, j), TG_BYTE(fb, j));
+      look(TG_BYTE(fe, j), TG_BYTE(fh, j));
+    }
   }
   const uint64_t by = (r >= 1 && r <= 16) ? blk.m[r - 1] : 0;
   for (int j = 0; j < 8; ++j) put(BY + j, (by >> (8 * j)) & 255);
@@ -406,21 +410,6 @@ TG_HD void row(const Block& blk, const Expanded& e, const uint64_t* hn_prev, con
     for (int i = 0; i < 8; ++i) put(tabcol(k, 3 + i), (ta >> i) & 1), put(tabcol(k, 11 + i), (tb >> i) & 1);
     put(tabcol(k, 19), (uint64_t)0);
   }
-  // looked-up triples, tuples() order
-#define TG_BYTE(w, j) ((unsigned)(((w) >> (8 * (j))) & 255))
-  for (int g = 0; g < NSLOT; ++g)
-    for (int j = 0; j < 8; ++j) {
-      look(TG_BYTE(sf[g][DIN], j), TG_BYTE(sf[g][A1], j));
-      look(TG_BYTE(sf[g][BIN], j), TG_BYTE(sf[g][C1], j));
-      look(TG_BYTE(sf[g][E1], (j + 4) % 8), TG_BYTE(sf[g][A2], j));
-      look(TG_BYTE(sf[g][F1], (j + 3) % 8), TG_BYTE(sf[g][C2], j));
-      look(TG_BYTE(sf[g][B2], j), 0u);
-    }
-  for (int g = 0; g < NFING; ++g)
-    for (int j = 0; j < 8; ++j) {
-      look(TG_BYTE(ff[g][0], j), TG_BYTE(ff[g][1], j));
-      look(TG_BYTE(ff[g][2], j), TG_BYTE(ff[g][3], j));
-    }
   for (int j = 0; j < 8; ++j) look(TG_BYTE(by, j), 0u);
 #undef TG_BYTE
 }
