@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """One-off soak of the STARK path: random AIRs / sizes / configurations proven on the GPU (compiled and interpreted AIR
-programs alternating) and by the oracle; proofs must be byte-identical, vx_stark_verify must accept them and reject a bit flip.
+programs alternating) and by the oracle; proofs must be byte-identical, vx_stark_verify must accept them and reject a bit flip; a third
+of the cases are proven again sharded by coset over 2 .. 2^rate_bits ranks (threads, one device) and every rank's proof must be the same bytes.
 
     python tools/soak_stark.py [seconds] [seed] [max_degree_bits] > gpurun_out/soak_stark.jsonl
 """
@@ -19,13 +20,14 @@ sys.path.insert(0, str(ROOT / "tests"))
 import oracle_lib  # noqa: E402  (checker only)
 import vectorx_amd as vx  # noqa: E402
 from stark_airs import cubic, fibonacci, logup, mulchain  # noqa: E402
-from vectorx_amd import blake2b_air, ed25519_air, sha256_air  # noqa: E402
+from vectorx_amd import blake2b_air, ed25519_air, sha256_air, sharded  # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2024)
 db_max = int(sys.argv[3]) if len(sys.argv) > 3 else 13
 oracle = oracle_lib.load()
 ctx = vx.Context(0)
+rank_ctxs = []                                   # round 6: contexts of the ranks of a proof sharded by coset (made on first use, kept)
 t_end = time.time() + budget
 n_ok, n_bad, by_kind = 0, 0, {}
 while time.time() < t_end:
@@ -94,6 +96,20 @@ while time.time() < t_end:
         os.environ.pop("VX_NO_JIT", None)
     want = oracle_lib.stark_prove(oracle, stark, trace, pis)
     ok = got == want
+    world = 1
+    max_world_bits = min(rate_bits, cfg["cap_height"])          # vx_stark_begin_sharded: a rank owns whole cosets and whole cap subtrees
+    if max_world_bits >= 1 and rng.random() < 0.5:  # round 6: the same proof over 2 .. 2^max_world_bits ranks (threads, one device)
+        world = 1 << int(rng.integers(1, max_world_bits + 1))
+        while len(rank_ctxs) < world:
+            rank_ctxs.append(vx.Context(0))
+        faulthandler.cancel_dump_traceback_later()
+        faulthandler.dump_traceback_later(180, exit=True)
+        if not jit:
+            os.environ["VX_NO_JIT"] = "1"
+        try:
+            ok = ok and all(p == got for p in sharded.prove_stark_sharded_threads(rank_ctxs[:world], stark, trace, pis, timeout_ms=120_000))
+        finally:
+            os.environ.pop("VX_NO_JIT", None)
     try:
         stark.verify(pis, got)
     except vx.VxError:
@@ -106,12 +122,12 @@ while time.time() < t_end:
     except vx.VxError:
         pass
     faulthandler.cancel_dump_traceback_later()
-    key = f"{kind}/rate{rate_bits}" + ("" if jit else "/interpreted") + ("/A" if "fri_arities" in cfg else "") + ("/D" if cfg.get("openings_digest") else "")
+    key = f"{kind}/rate{rate_bits}" + ("" if jit else "/interpreted") + ("/A" if "fri_arities" in cfg else "") + ("/D" if cfg.get("openings_digest") else "") + (f"/G{world}" if world > 1 else "")
     by_kind[key] = by_kind.get(key, 0) + 1
     if ok:
         n_ok += 1
     else:
         n_bad += 1
-        print(json.dumps({"FAIL": {"kind": kind, "degree_bits": lg, "jit": jit, **cfg}}), flush=True)
+        print(json.dumps({"FAIL": {"kind": kind, "degree_bits": lg, "jit": jit, "world": world, **cfg}}), flush=True)
 print(json.dumps({"stark_cases": n_ok + n_bad, "identical_and_verified": n_ok, "failures": n_bad, "seconds": budget, "max_degree_bits": db_max,
-                  "by_kind": by_kind}), flush=True)
+                  "sharded_cases": sum(v for k, v in by_kind.items() if "/G" in k), "by_kind": by_kind}), flush=True)
