@@ -566,15 +566,7 @@ static std::string jit_fused_source(const std::vector<const uint64_t*>& progs, i
   s << "typedef unsigned long long uint64_t;\ntypedef unsigned int uint32_t;\n"
     << "#define VX_ALPHA_POWS " << VX_ALPHA_POWS << "\n#define VX_JIT_FUSED_MAX " << VX_JIT_FUSED_MAX << "\n#define FW " << W << "\n#define FCOLS " << P.max_col
     << "\n#define FLOADS " << (P.max_col + W - 1) / W << "\n#define FWPS " << waves_per_simd << "\n"
-    << jit_limits_defines() << JIT_PRELUDE << JIT_DOT3
-    // VX_JIT_FUSED_CALLS=1 (A/B only): the general multiply and multiply-add as CALLED functions — the kernel's straight-line code is
-    // ~260 KB per tile against a 64 KB instruction cache (profiles/r06_pmc_sq_prove_recursion.md); calls shrink it to what the cache holds
-    << (getenv("VX_JIT_FUSED_CALLS") && atoi(getenv("VX_JIT_FUSED_CALLS")) ? R"VXJIT(
-__device__ __attribute__((noinline)) u64 gl_mul_nc_call(u64 a, u64 b) { return gl_mul_nc(a, b); }
-__device__ __attribute__((noinline)) u64 gl_mad_nc_call(u64 a, u64 b, u64 c) { return gl_mad_nc(a, b, c); }
-#define gl_mul_nc gl_mul_nc_call
-#define gl_mad_nc gl_mad_nc_call
-)VXJIT" : "") << R"VXJIT(
+    << jit_limits_defines() << JIT_PRELUDE << JIT_DOT3 << R"VXJIT(
 struct JitGateRt {
   int gate_index, selector_index, group_start, group_end;
 };
