@@ -194,7 +194,7 @@ def dag_pool_legs(pool, with_starks=True, passes=2):
         rec = record(runs, sizes + ", EACH JOB WITH ITS STARK TABLES (own AIRs standing in for Curta's chips): map = BLAKE2b over the job's own 8 headers "
                                   "(2240 compressions, 2^16 rows) + SHA-256 over the 14 nodes of their state / data root trees; reduce = SHA-256 over its "
                                   "children's roots; outer = SHA-256 over the authority set commitment chain (300 keys) + the 300 signatures of the precommit "
-                                  "verified THROUGH TABLES ONLY as one bus (SHA-512 over R || A || M, 4 batched EdDSA tables running the full program, the link "
+                                  "verified THROUGH TABLES ONLY as one bus (SHA-512 over R || A || M, 4 batched EdDSA tables running the full program — three of 2^20 rows and the last sized to the 9 signatures left over, 2^17 —, the link "
                                   "table, the verifier's sink).  ONE SYNTHETIC REQUEST (vectorx_amd/header_range.py: 512 headers of 35 840 bytes chained by their "
                                   "hashes, real Ed25519 authorities, a signed precommit), resident in host memory when the clock starts; every job hashes ITS "
                                   "part of it and its children's statements, TRACES GENERATED ON THE GPU INSIDE THE CLOCK (vx_trace_*: lane-seconds "
@@ -437,7 +437,7 @@ def dag_with_starks_leg(ctx, local_rank, in_flight=None, table_mode="per_job"):
             "tables": setup, "setup_seconds_untimed": round(time.perf_counter() - t_setup - sum(r["seconds"] for r in runs), 2),
             "root": res["root"][:32].hex(), **statement_record({"table_mode": table_mode, "small_tables": False}, spec, b"", res["root"]),
             "what": "64 map jobs = plonky2 2^18 + BLAKE2b table (2240 compressions: 2^16 rows of the byte / XOR-lookup table) + SHA-256 table 2^11; 63 reduce jobs = plonky2 2^16 + SHA-256 "
-                    "table 2^9; outer = plonky2 2^19 + SHA-256 chain 2^16 + SHA-512 2^16 + 4 batched EdDSA tables 2^20 (388 signature slots for 300 "
+                    "table 2^9; outer = plonky2 2^19 + SHA-256 chain 2^16 + SHA-512 2^16 + 3 batched EdDSA tables 2^20 + one 2^17 (303 signature slots for 300 "
                     "signatures); own AIRs standing in for Curta's chips, synthetic stand-in circuits; " + what_tables + "; the STARK proofs are part of a "
                     "job's digest; NOT the contract's timed region"}
 
@@ -486,7 +486,7 @@ def rotate_leg(ctx, local_rank, log_n=19, small=False):
             "setup_seconds_untimed": round(setup_s, 2),
             "what": f"ONE rotate request: plonky2 2^{log_n} (synthetic stand-in circuit) + BLAKE2b table over the epoch end header (2^16 rows) + SHA-256 table over the "
                     "current and the new authority set commitment chains (1198 compressions, 2^17 rows) + the justification's 300 signatures as one bus "
-                    "(SHA-512 2^16 + 4 EdDSA full 2^20 + link + sink) proven AHEAD on a lane of its own next to the plonky2 proof and the hash tables (seconds_by_kind "
+                    "(SHA-512 2^16 + 3 EdDSA full 2^20 + 1 EdDSA full 2^17 for the 9 signatures left over + link + sink) proven AHEAD on a lane of its own next to the plonky2 proof and the hash tables (seconds_by_kind "
                     "adds up to more than `seconds`), traces generated on the GPU inside the clock; the statement = the new "
                     "authority set hash (bytes32: /root/reference/circuits/rotate.rs:108); NOT the contract's timed region"}
 

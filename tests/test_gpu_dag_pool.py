@@ -170,3 +170,35 @@ def test_signature_bus_balances_only_when_every_signature_verifies(ctx):
             vx.stark_verify_bus(descs, proofs)
     finally:
         bus.free()
+
+
+def test_signature_bus_sizes_its_last_eddsa_table_to_the_signatures_left_over(ctx):
+    """26 signatures over tables of 2^18 rows (24 instances each): one full table and a LAST table of 2^17 rows for the two left over — the
+    rotate request's 300 = 3 x 97 + 9 in small.  Same AIR at two sizes on one bus: every proof verifies under the joint challenges, the bus
+    closes, every instance arrives at its R, and a forged signature in the small table opens the bus again."""
+    import vectorx_amd as vx
+    from vectorx_amd import eddsa_air as ea
+    from vectorx_amd import stark_chips
+    raw, eq = stark_chips.real_signatures(26)
+    state = {"raw": raw, "eq": eq}
+    bus = stark_chips.GeneratedSignatureBus(ctx, lambda job: (state["raw"], state["eq"]), [ctx], 26, sha_log_n=13, ed_log_n=18)
+    try:
+        assert (bus.cap, bus.ntab, bus.tail_log_n, bus.table_log_n(0), bus.table_log_n(1)) == (24, 2, 17, 18, 17)
+        blob = bus.prove(ctx, None)
+        descs, proofs = bus.last_bus[id(ctx)]
+        assert blob == b"".join(proofs) and len(proofs) == 5
+        assert [st.desc.degree_bits for st, _ in descs[1:3]] == [18, 17]
+        sums = vx.stark_verify_bus(descs, proofs)
+        assert bus.closed(ctx) and sum(int(x) for x in sums[:, 0]) % ea.P == 0
+        assert bus.last[id(ctx)][1] == [ea.decompress(sig[:32]) for _, _, sig in raw]
+        pk, msg, sig = raw[25]                                                   # the second instance of the small table
+        forged = sig[:32] + ((int.from_bytes(sig[32:], "little") + 1) % ea.ELL).to_bytes(32, "little")
+        state["raw"] = raw[:25] + [(pk, msg, forged)]
+        state["eq"] = eq[:25] + [ea.equation_inputs_full(pk, msg, forged, check=False)]
+        bus.prove(ctx, None)
+        assert not bus.closed(ctx)
+        descs, proofs = bus.last_bus[id(ctx)]
+        with pytest.raises(RuntimeError):
+            vx.stark_verify_bus(descs, proofs)
+    finally:
+        bus.free()

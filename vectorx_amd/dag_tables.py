@@ -192,7 +192,7 @@ def build_per_job(ctx, lanes, kinds=("map", "reduce", "outer"), small=False, edd
       reduce : SHA-256 over left root || right root of both trees (2^9 rows) -> the merged Subchain (the right one continues the left);
       outer  : SHA-256 over the authority set commitment chain (300 keys: 599 compressions, 2^16 rows) + the justification's 300
                signatures over the precommit message, verified through tables only as ONE bus: SHA-512 over R || A || M (2^16
-               rows), 4 batched EdDSA tables running the full program (2^20 rows, 97 instances each), the link table, the
+               rows), 4 batched EdDSA tables running the full program (three of 2^20 rows with 97 instances each, the last of 2^17 rows for the 9 left over), the link table, the
                verifier's sink -> the 96 output bytes (target header hash, state / data root commitments).
     -> ({kind: [(label, table)]}, [tables to free], setup record)"""
     from . import header_range as hr
@@ -277,12 +277,12 @@ def build_per_job(ctx, lanes, kinds=("map", "reduce", "outer"), small=False, edd
             assert results == [eddsa_air.decompress(sig[:32]) for _, _, sig in raw], "a generated EdDSA instance does not arrive at R"
             assert bus.closed(lane), "the signature bus does not balance"
         tables.append(bus)
-        rec["signature_bus"] = {"tables": bus.describe() if hasattr(bus, "describe") else f"SHA-512 bus variant 2^{lg} x 2012 + {bus.ntab} x EdDSA full program 2^{lg_ed} x {bus.lay.N} + link 2^{bus.link_log_n} x 41 + verifier sink 2^{bus.link_log_n} x 26",
+        rec["signature_bus"] = {"tables": bus.describe() if hasattr(bus, "describe") else f"SHA-512 bus variant 2^{lg} x 2012 + {bus.ntab} x EdDSA full program 2^{lg_ed} x {bus.lay.N} (the last one 2^{getattr(bus, 'tail_log_n', lg_ed)}: sized to the signatures left over) + link 2^{bus.link_log_n} x 41 + verifier sink 2^{bus.link_log_n} x 26",
                                 "signatures": nkeys, "signatures_per_eddsa_table": bus.cap, "eddsa_tables": bus.ntab,
                                 "traces": "SHA-512 and EdDSA generated per job on the GPU; link rows written by the host",
                                 "proven_as": "one bus: joint challenges over the 7 trace caps; the closing sums add up to 0",
                                 "setup_incl_signing_and_one_bus_per_lane_s": round(time.perf_counter() - t0, 2)}
-        rec["eddsa_outer"] = {"tables": bus.ntab, "rows_log2": lg_ed, "signatures_per_table": bus.cap}
+        rec["eddsa_outer"] = {"tables": bus.ntab, "rows_log2": lg_ed, "last_table_rows_log2": getattr(bus, "tail_log_n", lg_ed), "signatures_per_table": bus.cap}
 
         def outer_statement(lane, job):
             if job is None or len(job) < 5 or len(job[4]) != 1:
@@ -383,7 +383,7 @@ def build_rotate(ctx, lanes=None, small=False, eddsa_log_n=20, factory=None, bus
         bus.take_spent(lane)
         assert bus.closed(lane), "the signature bus does not balance"
     tables.append(bus)
-    rec["signature_bus"] = {"eddsa_tables": bus.ntab, "signatures": shape["num_authorities"], "setup_incl_one_bus_per_lane_s": round(time.perf_counter() - t0, 2),
+    rec["signature_bus"] = {"eddsa_tables": bus.ntab, "last_eddsa_table_rows_log2": getattr(bus, "tail_log_n", lg_ed), "signatures": shape["num_authorities"], "setup_incl_one_bus_per_lane_s": round(time.perf_counter() - t0, 2),
                             "proven": "ahead, on a lane of its own, next to the plonky2 proof and the hash tables" if bus_lane is not None else "in the job's order"}
     ahead = AheadTable(bus, bus_lane) if bus_lane is not None else None
     rec["ahead"] = ahead

@@ -376,8 +376,8 @@ class GeneratedSignatureBus:
     """A job's Ed25519 signatures verified THROUGH TABLES ONLY, proven as one bus (round 5): from the raw (public key, message, signature)
     triples `sigs_fn(job)` returns —
       * the SHA-512 table (bus variant) over R || A || M, its trace generated on the GPU (vx_trace_sha512_bus): sends (R, A, digest);
-      * ceil(len / capacity) batched EdDSA tables running the FULL program, traces generated on the GPU (vx_trace_eddsa): each
-        signature sends (A, S, digest, R) after decompressing both points, reducing the digest mod L and checking S < L;
+      * ceil(len / capacity) batched EdDSA tables running the FULL program (the last one sized to the signatures left over), traces
+        generated on the GPU (vx_trace_eddsa): each signature sends (A, S, digest, R) after decompressing both points, reducing the digest mod L and checking S < L;
       * the link table (40 words per signature, written by the host): joins the two on the digest, sends (A, S, R);
     all committed first, then the joint challenges, every second round on the GPU, one proof per table (prove_bus_device).  What leaves the
     the verifier's sink (25 words per signature, written by the host from the bytes of the public keys and signatures alone): receives
@@ -396,15 +396,24 @@ class GeneratedSignatureBus:
         self.link_log_n = max(4, (nsigs + 1).bit_length())
         self.cap = ea.capacity(self.lay, ed_log_n)
         self.ntab = max(1, -(-nsigs // self.cap))
+        # The LAST table holds what the full ones leave over and is sized to it (round 6): 300 signatures = 3 x 97 + 9, and 9 instances
+        # fit 2^17 rows — an eighth of the commitment, LDE and hashing of a 2^20-row table whose rows would be 97 % filler.  Same AIR,
+        # same program; only degree_bits differs (2^17 is the smallest size the chip is exercised at: tests/test_gpu_stark.py).
+        self.tail_log_n = ed_log_n
+        rem = max(1, nsigs - (self.ntab - 1) * self.cap)
+        while self.tail_log_n > 17 and ea.capacity(self.lay, self.tail_log_n - 1) >= rem:
+            self.tail_log_n -= 1
         # starky's transcript order by default since round 6 (the opening set is absorbed element by element, as an in-circuit verifier
         # of the reference would follow it); VX_OPENINGS_DIGEST=1 = this library's own variant, a tree hash of the openings made on the device
         od = openings_digest_default()
         self.sha = s5.make_stark(sha_log_n, bus=True, openings_digest=od)
         self.ed = ea.make_stark(self.lay, ed_log_n, openings_digest=od)
+        self.ed_tail = self.ed if self.tail_log_n == ed_log_n else ea.make_stark(self.lay, self.tail_log_n, openings_digest=od)
         self.link = link.make_stark(self.link_log_n, openings_digest=od)
         self.sink = ea.make_sink(self.lay, [], degree_bits=self.link_log_n, ntuple=link.NVERIFIER, openings_digest=od)[0]
         self._link_mod = link
-        sizes = [(2012, self.sha.desc.num_aux_columns, sha_log_n)] + [(self.lay.N, self.ed.desc.num_aux_columns, ed_log_n)] * self.ntab \
+        sizes = [(2012, self.sha.desc.num_aux_columns, sha_log_n)] + [(self.lay.N, self.ed.desc.num_aux_columns, ed_log_n)] * (self.ntab - 1) \
+            + [(self.lay.N, self.ed_tail.desc.num_aux_columns, self.tail_log_n)] \
             + [(link.N, self.link.desc.num_aux_columns, self.link_log_n), (link.NVERIFIER + 1, self.sink.desc.num_aux_columns, self.link_log_n)]
         self.bufs = {id(c): [(ctx.alloc(nc * (8 << lg)), ctx.alloc(max(8, na * (8 << lg)))) for nc, na, lg in sizes] for c in lanes}
         self.spent, self.last, self.last_bus = {}, {}, {}
@@ -414,6 +423,10 @@ class GeneratedSignatureBus:
         # instead of 140.  Buffers are the lane's; a helper only lends its stream and its scratch.
         import vectorx_amd as vx
         self.helpers = {id(c): [vx.Context(c.device) for _ in range(self.ntab - 1)] for c in lanes}
+
+    def table_log_n(self, t: int) -> int:
+        """log2 rows of EdDSA table t: the full tables' size, the last one's own"""
+        return self.tail_log_n if t == self.ntab - 1 else self.ed_log_n
 
     def prove(self, ctx=None, job=None) -> bytes:
         from . import eddsa_air as ea
@@ -431,7 +444,7 @@ class GeneratedSignatureBus:
 
         def generate(t):
             try:
-                per_table[t] = gens[t].trace_eddsa_table(self.ed_log_n, 256, eq[t * self.cap:(t + 1) * self.cap], bufs[1 + t][0], full=True)
+                per_table[t] = gens[t].trace_eddsa_table(self.table_log_n(t), 256, eq[t * self.cap:(t + 1) * self.cap], bufs[1 + t][0], full=True)
             except BaseException as e:          # surfaces after the join, with the generator's own message
                 failed.append(e)
 
@@ -449,7 +462,7 @@ class GeneratedSignatureBus:
             raise failed[0]
         results = [r for part in per_table for r in part]     # (the call returns the instances' results: it has synchronised its stream)
         for t in range(self.ntab):
-            items.append((self.ed, bufs[1 + t][0], nopi, bufs[1 + t][1]))
+            items.append((self.ed_tail if t == self.ntab - 1 else self.ed, bufs[1 + t][0], nopi, bufs[1 + t][1]))
         rows = [self._link_mod.row_of(pk, sig, dg) for (pk, _, sig), dg in zip(raw, digests)]
         c.upload(bufs[-2][0], self._link_mod.trace_of(rows, self.link_log_n))
         items.append((self.link, bufs[-2][0], nopi, bufs[-2][1]))
