@@ -531,12 +531,12 @@ def test_quotient_degree_factor_below_the_blowup(ctx, oracle, degree_bits, flags
     gc.free()
 
 
-@pytest.mark.parametrize("degree_bits", [5, 9, 12, 16, 18])      # 16 / 18 = the DAG's reduce / map sizes (2^19, the outer size, passes too: 49 s of oracle time, left to tools/soak_differential.py's range)
+@pytest.mark.parametrize("degree_bits", [5, 9, 12, 16, 18, 19])      # 16 / 18 / 19 = the DAG's reduce / map / outer sizes (2^19: ~50 s of oracle time)
 def test_recursion_mix_proof_bytes_identical_to_oracle(ctx, oracle, degree_bits):
     """The DAG's reduce / outer / map stand-ins since round 6: the recursive verifier's gate set in its declared row mix
     (vectorx_amd/synth.py RECURSIVE_VERIFIER_MIX with RECURSION_FLAGS — what mapreduce.circuit_shape() hands every GpuProver;
     /root/reference/circuits/builder/subchain_verification.rs:78, 233-289: a reduce job verifies its two children in-circuit).
-    Byte-identical to the oracle at the reduce and map sizes of the DAG (2^16, 2^18 rows: 127 of its 128 proofs) with exactly that flag set, compiled gate
+    Byte-identical to the oracle at the reduce, map and outer sizes of the DAG (2^16, 2^18, 2^19 rows) with exactly that flag set, compiled gate
     programs (the fused kernel), the product-tree lookup kernel, lookup polynomials from the device."""
     from vectorx_amd.mapreduce import circuit_shape
     from vectorx_amd.synth import RECURSION_FLAGS, RECURSIVE_VERIFIER_MIX

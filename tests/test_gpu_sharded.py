@@ -35,6 +35,24 @@ def _free(ctxs, circuits):
         c.close()
 
 
+@pytest.mark.parametrize("degree_bits,world", [(12, 4), (14, 8)])
+def test_sharded_proof_with_the_recursion_mix_is_byte_identical(oracle, degree_bits, world):
+    """the DAG's circuit shape (the recursive verifier's gate set in its declared row mix: the fused gate kernel, the product-tree lookup
+    kernel, lookup polynomials from the device) proven over G ranks by coset: every rank's bytes are the oracle's"""
+    from vectorx_amd.mapreduce import circuit_shape
+    sc = SynthCircuit(degree_bits, seed=950 + degree_bits, witness_seed=5, **circuit_shape(True))
+    sc.desc.pow_bits = 8
+    w = sc.witness()
+    expect = oracle_lib.OracleCircuit(oracle, sc.desc_ptr).prove(w)
+    ctxs, circuits = _rank_circuits(sc, world)
+    try:
+        assert circuits[0].program_gates()[:2] == (9, 9)
+        for r, p in enumerate(sharded.prove_sharded_threads(circuits, w)):
+            assert p == expect, f"rank {r} of {world}"
+    finally:
+        _free(ctxs, circuits)
+
+
 @pytest.mark.parametrize("degree_bits,world,flags", [(3, 2, 0), (4, 8, 0), (5, 4, 0), (6, 2, 0), (6, 8, 7), (8, 4, 1), (10, 8, 0),
                                                      (11, 2, 7), (13, 4, 0), (13, 8, 0), (9, 4, 15)])
 def test_sharded_proof_is_byte_identical(oracle, degree_bits, world, flags):
